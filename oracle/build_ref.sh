@@ -1,0 +1,46 @@
+#!/usr/bin/env bash
+# Build the reference's two native extensions from the sources where they lie
+# under /root/reference into oracle/_ref/ (git-ignored; never committed).
+#
+# TEST INFRASTRUCTURE ONLY.  The outputs are used in THIS container to
+#   (1) pin oracle/pq_oracle.c + oracle/pq_oracle.py against the real reference
+#       (tests/test_oracle_vs_reference.py, skipped when /root/reference is absent), and
+#   (2) generate the committed golden fixtures (tests/golden/make_golden.py).
+# Nothing under oracle/_ref is imported by the product (annlite_amd/), and the GPU
+# tests / smoke() / bench.py never touch it.
+#
+# Recipe mirrors the reference's own build flags (setup.py:51-55 compiler
+# directives, setup.py:125-144 "-O3 -march=native -fopenmp") so the LUT loops
+# FMA-contract exactly like a wheel built by the reference's setup.py on an FMA host.
+set -euo pipefail
+REF=${REF:-/root/reference}
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/_ref"
+if [ ! -d "$REF/bindings" ]; then
+  echo "build_ref: $REF not present, skipping (GPU box uses committed golden fixtures)"; exit 0
+fi
+mkdir -p "$OUT"
+PYINC=$(python3 -c "import sysconfig; print(sysconfig.get_paths()['include'])")
+NPINC=$(python3 -c "import numpy; print(numpy.get_include())")
+EXT=$(python3 -c "import sysconfig; print(sysconfig.get_config_var('EXT_SUFFIX'))")
+
+# 1) annlite.pq_bind  <- bindings/pq_bindings.pyx (Cython -> C++), generated C++ stays in _ref/
+if [ ! -f "$OUT/pq_bind$EXT" ] || [ "$REF/bindings/pq_bindings.pyx" -nt "$OUT/pq_bind$EXT" ]; then
+  cython -+ -3 --module-name annlite.pq_bind \
+    -X language_level=3 -X embedsignature=True -X annotation_typing=False \
+    -o "$OUT/pq_bind.cpp" "$REF/bindings/pq_bindings.pyx"
+  g++ -O3 -march=native -fopenmp -std=c++14 -shared -fPIC -w \
+    -I"$PYINC" -I"$NPINC" "$OUT/pq_bind.cpp" -o "$OUT/pq_bind$EXT"
+fi
+
+# 2) annlite.hnsw_bind <- bindings/hnsw_bindings.cpp (pybind11).  pybind11 3.x asserts the GIL
+#    on every inc/dec-ref; the reference creates a py::array_t inside gil_scoped_release
+#    (hnsw_bindings.cpp:312-326), so the two -D flags below are required or knn_query aborts.
+if [ ! -f "$OUT/hnsw_bind$EXT" ] || [ "$REF/bindings/hnsw_bindings.cpp" -nt "$OUT/hnsw_bind$EXT" ]; then
+  g++ -O3 -march=native -fopenmp -std=c++14 -shared -fPIC -w \
+    -DPYBIND11_NO_ASSERT_GIL_HELD_INCREF_DECREF -DNDEBUG \
+    $(python3 -m pybind11 --includes) -I"$REF/include/hnswlib" \
+    "$REF/bindings/hnsw_bindings.cpp" -o "$OUT/hnsw_bind$EXT" -pthread || \
+    echo "build_ref: hnsw_bind failed to build (only needed for the HNSW-over-PQ fixtures)"
+fi
+ls -la "$OUT"

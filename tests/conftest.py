@@ -1,0 +1,56 @@
+"""pytest configuration.
+
+markers
+  gpu   needs a real MI355X (run with ``-m gpu`` on the GPU box); everything else runs on CPU.
+"""
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: test needs a real AMD GPU (MI355X); deselected on CPU with -m "not gpu"')
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    g = {k: z[k] for k in z.files}
+    M, dsub, Ks, N, B, seed, K = (int(v) for v in g['meta'])
+    g.update(M=M, dsub=dsub, Ks=Ks, N=N, B=B, seed=seed, K=K, D=M * dsub)
+    return g
+
+
+@pytest.fixture(scope='session')
+def oracle():
+    """The CPU oracle (test infrastructure): oracle/pq_oracle.py over oracle/libpq_oracle.so."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import pq_oracle
+
+    pq_oracle.build()
+    return pq_oracle
+
+
+@pytest.fixture(params=golden_names())
+def golden(request):
+    return load_golden(request.param)
+
+
+def has_gpu():
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return False
