@@ -1,0 +1,165 @@
+"""ctypes binding of ``libannlite_hip.so`` (C ABI declared in ``include/annlite_hip.h``).
+
+The product path has NO fallback: if the shared library is missing, or a kernel launch fails
+(e.g. no MI355X visible), a ``RuntimeError`` is raised -- nothing here ever routes to CPU code.
+
+Device pointers come from ``torch.Tensor.data_ptr()``; tensors stay owned by PyTorch.  The HIP
+stream handed to every call is ``torch.cuda.current_stream().cuda_stream`` so launches order with
+the caller's torch work (PyTorch is plumbing here: memory, streams, ``torch.distributed``).
+"""
+import ctypes
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = 'libannlite_hip.so'
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+
+ANNLITE_OK = 0
+ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE = 1, 2, 3, 4
+
+LUT_L2, LUT_IP, LUT_IPDIST = 1, 2, 3
+LAYOUT_BMK, LAYOUT_TILED = 0, 1
+CODES_PLAIN, CODES_SKEWED = 0, 1
+
+# every symbol include/annlite_hip.h declares (tests/test_capi_symbols.py checks header == this list)
+SYMBOLS = (
+    'annlite_hip_abi_version',
+    'annlite_hip_last_error',
+    'annlite_hip_device_count',
+    'annlite_hip_device_arch',
+    'annlite_scan_plan_query',
+    'annlite_lut_build',
+    'annlite_lut_retile',
+    'annlite_adc_dist',
+    'annlite_adc_gather',
+    'annlite_adc_scan_topk',
+    'annlite_adc_scan_candidates',
+    'annlite_topk_merge',
+    'annlite_topk_rows',
+    'annlite_pq_encode',
+    'annlite_pq_decode',
+    'annlite_l2_normalize',
+    'annlite_kmeans_assign_accumulate',
+    'annlite_kmeans_update',
+    'annlite_exact_gather_dist',
+    'annlite_codes_skew',
+    'annlite_profile_enable',
+    'annlite_profile_last_scan_ms',
+)
+
+
+class ScanPlan(ctypes.Structure):
+    _fields_ = [
+        ('fast', ctypes.c_int32),
+        ('qi', ctypes.c_int32),
+        ('qt', ctypes.c_int32),
+        ('waves', ctypes.c_int32),
+        ('n_slices', ctypes.c_int32),
+        ('max_k', ctypes.c_int32),
+        ('lut_floats', ctypes.c_int64),
+        ('workspace_bytes', ctypes.c_int64),
+    ]
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load the HIP library; raise loudly if it has not been built (``python __graft_entry__.py``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} is missing: the HIP extension has not been built '
+            f'(run `make -C annlite_amd/csrc` or `python -c "import __graft_entry__ as g; g.build()"`). '
+            f'annlite_amd has no CPU fallback.'
+        )
+    L = ctypes.CDLL(LIB_PATH)
+    i64, i32, vp, sz = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+    L.annlite_hip_abi_version.restype = i32
+    L.annlite_hip_last_error.restype = ctypes.c_char_p
+    L.annlite_hip_device_count.argtypes = [ctypes.POINTER(i32)]
+    L.annlite_hip_device_arch.argtypes = [i32, ctypes.c_char_p, sz]
+    L.annlite_scan_plan_query.argtypes = [i64, i64, i64, i32, i64, i64, ctypes.POINTER(ScanPlan)]
+    L.annlite_lut_build.argtypes = [i32, vp, i64, i64, vp, i64, i64, vp, i32, i32, vp]
+    L.annlite_lut_retile.argtypes = [vp, i64, i64, i64, vp, i32, vp]
+    L.annlite_adc_dist.argtypes = [vp, i64, i64, vp, i32, i64, vp, vp]
+    L.annlite_adc_gather.argtypes = [vp, i64, i64, i64, vp, i32, i64, vp, i64, vp, vp]
+    L.annlite_adc_scan_topk.argtypes = [vp, i32, i32, i64, i64, i64, vp, vp, i64, i64, i64, vp, vp, vp, sz, vp]
+    L.annlite_adc_scan_candidates.argtypes = L.annlite_adc_scan_topk.argtypes
+    L.annlite_topk_merge.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
+    L.annlite_topk_rows.argtypes = [vp, i64, i64, i64, i64, vp, vp, vp]
+    L.annlite_pq_encode.argtypes = [vp, i64, i64, vp, i64, i64, vp, i32, vp]
+    L.annlite_pq_decode.argtypes = [vp, i32, i64, i64, i64, vp, i64, vp, vp]
+    L.annlite_l2_normalize.argtypes = [vp, i64, i64, vp, vp]
+    L.annlite_kmeans_assign_accumulate.argtypes = [vp, i64, i64, vp, i64, i64, vp, vp, vp, vp]
+    L.annlite_kmeans_update.argtypes = [vp, vp, i64, i64, i64, vp, vp]
+    L.annlite_exact_gather_dist.argtypes = [i32, vp, i64, i64, vp, i64, vp, i64, vp, vp]
+    L.annlite_codes_skew.argtypes = [vp, i64, i64, vp, i64, vp, i32, vp]
+    L.annlite_profile_enable.argtypes = [i32]
+    L.annlite_profile_last_scan_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]
+    for name in SYMBOLS:
+        fn = getattr(L, name)  # AttributeError here == the .so does not export a declared symbol
+        if name not in ('annlite_hip_last_error',):
+            fn.restype = i32
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().annlite_hip_last_error().decode('utf-8', 'replace')
+
+
+def check(rc: int, what: str = '') -> None:
+    """Map the C status codes onto the exception types the reference raises for the same
+    conditions (SURVEY.md section 8b "Error conventions"): argument/shape problems are
+    ``AssertionError`` in the reference (python ``assert``), everything else ``RuntimeError``."""
+    if rc == ANNLITE_OK:
+        return
+    msg = f'{what}: {last_error()}' if what else last_error()
+    if rc == ERR_INVALID:
+        raise AssertionError(msg)
+    raise RuntimeError(f'annlite_hip error {rc}: {msg}')
+
+
+def device_count() -> int:
+    n = ctypes.c_int(0)
+    rc = lib().annlite_hip_device_count(ctypes.byref(n))
+    return int(n.value) if rc == ANNLITE_OK else 0
+
+
+def device_arch(dev: int = 0) -> str:
+    buf = ctypes.create_string_buffer(256)
+    check(lib().annlite_hip_device_arch(dev, buf, 256), 'device_arch')
+    return buf.value.decode()
+
+
+def require_gpu() -> None:
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError('annlite_amd needs an AMD GPU (MI355X / gfx950); no HIP device is visible and there is no CPU fallback')
+
+
+def stream_ptr() -> int:
+    import torch
+
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def scan_plan(N: int, M: int, Ks: int, code_bytes: int, B: int, k: int) -> ScanPlan:
+    p = ScanPlan()
+    check(lib().annlite_scan_plan_query(N, M, Ks, code_bytes, B, k, ctypes.byref(p)), 'scan_plan')
+    return p
+
+
+def profile_enable(on: bool) -> None:
+    check(lib().annlite_profile_enable(int(bool(on))), 'profile_enable')
+
+
+def profile_last_scan_ms() -> float:
+    ms = ctypes.c_float(0.0)
+    check(lib().annlite_profile_last_scan_ms(ctypes.byref(ms)), 'profile_last_scan_ms')
+    return float(ms.value)

@@ -1,0 +1,336 @@
+"""``PQFlatGpuIndex`` -- exhaustive PQ/ADC index on one MI355X, plugging in where the reference
+constructs ``HnswIndex(pq_codec=...)`` per cell (annlite/container.py:48-59).
+
+Semantics = the reference's flat ADC index ``PQIndex`` (annlite/core/index/pq_index.py:11-56) made
+metric-aware and batched, with ``HnswIndex``'s pre/post-processing so it is a drop-in for the seam
+``CellContainer`` uses (SURVEY.md section 8b "Index plugin seam"):
+
+  * ``search(x[D], limit, indices)`` -> ``(dists[k], ids[k])`` ascending        hnsw/index.py:139-167
+      reshape to (1, D), cast f32, ``l2_normalize`` if cosine (index.py:28-29), tables through
+      ``PQCodec.get_dist_mat`` (which normalises again, pq.py:309-310), ``sqrt`` of the distances
+      for EUCLIDEAN (index.py:164-165); cosine / inner product distances are ``M/Ks - <q, x^>``.
+  * ``add_with_ids(data[N,D], offsets)``   encode + store rows at ``offsets``      hnsw/index.py:124-137
+  * ``delete(ids)``  marks rows (never returned again)                            hnsw/index.py:169-171
+  * ``reset`` / ``dump`` / ``load`` / ``size`` / ``capacity``                      hnsw/index.py:116-122,185-191
+  * untrained codec -> ``RuntimeError('Please train the PQ ...')``                hnsw/index.py:32-35
+plus ``search_batch(X[B,D], limit)`` so that a whole ``AnnLite.search(docs)`` call is one launch
+instead of the reference's per-query python loop (annlite/container.py:214).
+
+Data layout in HBM: one ``uint8 [capacity, M]`` code table, stored pre-SKEWED (row n
+rotated left by n mod M bytes) when the fast scan plan applies; a ``uint32`` validity bitmap (delete
+marks / never-written rows); optionally the raw ``float32 [capacity, D]`` vectors for the exact
+re-rank stage (``rerank=True``; 10M x 128 fp32 = 5.1 GB of the 288 GB).
+"""
+import math
+from pathlib import Path
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from ... import ops
+from ..._capi import CODES_PLAIN, CODES_SKEWED, scan_plan
+from ...enums import ExpandMode, Metric
+from ..codec.pq import PQCodec
+from .base import BaseIndex
+
+
+class PQFlatGpuIndex(BaseIndex):
+    def __init__(
+        self,
+        dim: int,
+        pq_codec: Optional[PQCodec] = None,
+        dtype: np.dtype = np.float32,
+        metric: Metric = Metric.COSINE,
+        rerank: bool = False,
+        skewed: bool = True,
+        index_file: Optional[Union[str, Path]] = None,
+        **kwargs,
+    ):
+        # HNSW-only kwargs the reference forwards (ef_construction, ef_search, max_connection) are accepted and ignored
+        for k in ('ef_construction', 'ef_search', 'max_connection'):
+            kwargs.pop(k, None)
+        super().__init__(dim, dtype=dtype, metric=metric, **kwargs)
+        assert pq_codec is not None, 'PQFlatGpuIndex needs a PQCodec'
+        self.pq_codec = pq_codec
+        self.rerank = bool(rerank)
+        self._want_skew = bool(skewed)
+        self._ws = ops.ScanWorkspace()
+        # device storage is allocated on first use so that constructing an index (and the host-side
+        # error paths, e.g. "not trained") does not need a GPU
+        self._codes = None
+        self._valid_bool = None
+        self._valid_bits_cache = None
+        self._vectors = None
+        self._n_rows = 0
+        if index_file:
+            self.load(index_file)
+
+    # ------------------------------------------------------------------ storage
+    @property
+    def M(self) -> int:
+        return self.pq_codec.n_subvectors
+
+    @property
+    def Ks(self) -> int:
+        return self.pq_codec.n_clusters
+
+    @property
+    def code_bytes(self) -> int:
+        return np.dtype(self.pq_codec.code_dtype).itemsize
+
+    def _layout(self) -> int:
+        fast = self.code_bytes == 1 and self.M in (8, 16, 32, 64) and self.Ks <= 256
+        return CODES_SKEWED if (fast and self._want_skew) else CODES_PLAIN
+
+    def _alloc(self, capacity: int):
+        dev = ops.device()
+        tdt = {1: torch.uint8, 2: torch.int16, 4: torch.int32}[self.code_bytes]
+        self._codes = torch.zeros((capacity, self.M), dtype=tdt, device=dev)
+        # validity: bool per row is the source of truth, the uint32 bitmap the kernels read is packed lazily
+        self._valid_bool = torch.zeros((((capacity + 31) // 32 + 2) * 32,), dtype=torch.bool, device=dev)
+        self._valid_bits_cache: Optional[torch.Tensor] = None
+        self._vectors = torch.zeros((capacity, self.dim), dtype=torch.float32, device=dev) if self.rerank else None
+        self._capacity = capacity
+        self._n_rows = 0  # scan range = highest written row id + 1
+        self._size = 0
+
+    def _ensure_alloc(self):
+        if self._codes is None:
+            self._alloc(self._capacity)
+
+    def _expand_capacity(self, new_capacity: int):
+        self._ensure_alloc()
+        old_codes, old_valid, old_vec, n_rows, size = self._codes, self._valid_bool, self._vectors, self._n_rows, self._size
+        self._alloc(new_capacity)
+        self._codes[: old_codes.shape[0]] = old_codes
+        self._valid_bool[: old_codes.shape[0]] = old_valid[: old_codes.shape[0]]
+        if old_vec is not None:
+            self._vectors[: old_vec.shape[0]] = old_vec
+        self._n_rows, self._size = n_rows, size
+
+    # ------------------------------------------------------------------ pre-processing (hnsw/index.py:20-48)
+    def _pre(self, x) -> torch.Tensor:
+        if not self.pq_codec.is_trained:
+            raise RuntimeError('Please train the PQ before using HNSW quantization backend')
+        x = ops.to_dev(x, torch.float32)
+        if x.ndim == 1:
+            x = x.reshape(1, -1)
+        assert x.shape[-1] == self.dim, (
+            f'the query embedding dimension does not match with index dimension: {x.shape[-1]} vs {self.dim}')
+        if self.metric == Metric.COSINE:
+            x = ops.l2_normalize(x)
+        return x
+
+    @staticmethod
+    def _pack_bits(flags: torch.Tensor) -> torch.Tensor:
+        """bool [32*W] -> int32 [W] bitmap words (bit i of word w = flags[32*w + i]); plumbing only."""
+        shifts = torch.arange(32, device=flags.device, dtype=torch.int64)
+        packed = (flags.reshape(-1, 32).to(torch.int64) << shifts[None, :]).sum(dim=1)
+        return torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32)
+
+    @property
+    def _valid(self) -> torch.Tensor:
+        if self._valid_bits_cache is None:
+            self._valid_bits_cache = self._pack_bits(self._valid_bool)
+        return self._valid_bits_cache
+
+    def _set_bits(self, ids: torch.Tensor, value: bool):
+        self._valid_bool[ids] = value
+        self._valid_bits_cache = None
+
+    def _get_bits(self, ids: torch.Tensor) -> torch.Tensor:
+        return self._valid_bool[ids]
+
+    # ------------------------------------------------------------------ mutation
+    def add_with_ids(self, x, ids: List[int], **kwargs):
+        x = self._pre(x)
+        self._ensure_alloc()
+        ids_t = ops.to_dev(np.asarray(ids, dtype=np.int64) if not isinstance(ids, torch.Tensor) else ids, torch.int64)
+        assert ids_t.numel() == x.shape[0]
+        if ids_t.numel() == 0:
+            return
+        max_id = int(ids_t.max().item()) + 1
+        if max_id > self.capacity:
+            steps = math.ceil(max_id / self.expand_step_size)  # hnsw/index.py:132-135
+            self._expand_capacity(steps * self.expand_step_size)
+        codes = ops.pq_encode(x, self.pq_codec.codebooks_dev)
+        if self._layout() == CODES_SKEWED:
+            ops.codes_skew(codes, ids_t, out=self._codes)
+        else:
+            self._codes[ids_t] = codes
+        if self._vectors is not None:
+            self._vectors[ids_t] = x
+        was_valid = self._get_bits(ids_t)
+        self._set_bits(ids_t, True)
+        self._size += int((~was_valid).sum().item())
+        self._n_rows = max(self._n_rows, max_id)
+
+    def update_with_ids(self, x, ids: List[int], **kwargs):
+        """flat_index.py:70-71 semantics (overwrite rows); HnswIndex refuses updates, PQIndex allows."""
+        self.add_with_ids(x, ids)
+
+    def delete(self, ids: List[int]):
+        if self._codes is None or len(ids) == 0:
+            return
+        ids_t = ops.to_dev(np.asarray(list(ids), dtype=np.int64), torch.int64)
+        was_valid = self._get_bits(ids_t)
+        self._set_bits(ids_t, False)
+        self._size -= int(was_valid.sum().item())
+
+    def reset(self, capacity: Optional[int] = None):
+        super().reset(capacity=capacity)
+        self._codes = None
+        self._valid_bool = None
+        self._valid_bits_cache = None
+        self._vectors = None
+        self._n_rows = 0
+
+    @property
+    def size(self):
+        return self._size
+
+    # ------------------------------------------------------------------ search
+    def _filter_bits(self, indices) -> torch.Tensor:
+        """`indices` argument of search (pq_index.py:42-44, container.py:107-120): restrict to a subset."""
+        idx = ops.to_dev(np.asarray(indices, dtype=np.int64) if not isinstance(indices, torch.Tensor) else indices, torch.int64)
+        sel = torch.zeros_like(self._valid_bool)
+        sel[idx] = True
+        return self._pack_bits(sel & self._valid_bool)
+
+    def search_batch(self, x, limit: int = 10, indices=None, rerank_k: Optional[int] = None
+                     ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """All queries of ``x`` [B, D] in one launch.  Returns device tensors
+        ``(dists f32 [B, k], ids i64 [B, k])``, ascending by (distance, id); missing -> (+inf, -1).
+        With ``rerank=True`` indexes, the ADC scan produces ``n_slices * rerank_k`` candidates per query
+        that are re-scored exactly on the stored float vectors."""
+        is_np = not isinstance(x, torch.Tensor)
+        q = self._pre(x)
+        B = q.shape[0]
+        k = int(limit)
+        assert k >= 1
+        N = self._n_rows
+        valid = None
+        if N > 0:
+            valid = self._valid if indices is None else self._filter_bits(indices)
+        dev = q.device
+        if N == 0 or B == 0:
+            d = torch.full((B, k), float('inf'), dtype=torch.float32, device=dev)
+            i = torch.full((B, k), -1, dtype=torch.int64, device=dev)
+        elif self.rerank and self._vectors is not None:
+            d, i = self._search_rerank(q, k, valid, N, rerank_k)
+        elif k <= 64:
+            plan = scan_plan(N, self.M, self.Ks, self.code_bytes, B, k)
+            if plan.fast:
+                lut = self.pq_codec.get_dist_mat_tiled(q, plan.qi)
+            else:
+                lut = self.pq_codec.get_dist_mat(q)
+            d, i = ops.adc_scan_topk(self._codes, lut, B, k, self.M, self.Ks, valid_bits=valid, n_rows=N,
+                                     codes_layout=self._layout(), workspace=self._ws)
+            if self.metric == Metric.EUCLIDEAN:
+                d = torch.sqrt(d)  # hnsw/index.py:164-165
+        else:
+            d, i = self._search_large_k(q, k, valid, N)
+        if is_np:
+            return d.cpu().numpy(), i.cpu().numpy()
+        return d, i
+
+    def _plain_codes(self, N: int) -> torch.Tensor:
+        if self._layout() == CODES_SKEWED:
+            return ops.codes_skew(self._codes[:N], inverse=True)
+        return self._codes[:N]
+
+    def _search_large_k(self, q, k, valid, N):
+        """k > 64: all distances per query (adc_dist kernel) + a stable device sort (ties -> id asc)."""
+        lut = self.pq_codec.get_dist_mat(q)
+        codes = self._plain_codes(N)
+        shifts = torch.arange(32, device=q.device, dtype=torch.int64)
+        vb = (((valid.to(torch.int64) & 0xFFFFFFFF)[:, None] >> shifts[None, :]) & 1).bool().reshape(-1)[:N]  # unpack
+        kk = min(k, N)
+        ds, is_ = [], []
+        for b in range(q.shape[0]):
+            dist = ops.adc_dist(lut[b], codes)
+            dist = torch.where(vb, dist, torch.full_like(dist, float('inf')))
+            sd, si = torch.sort(dist, stable=True)
+            sd, si = sd[:kk], si[:kk]
+            si = torch.where(torch.isinf(sd) & ~vb[si], torch.full_like(si, -1), si)
+            ds.append(sd)
+            is_.append(si)
+        d, i = torch.stack(ds), torch.stack(is_)
+        if kk < k:
+            d = torch.cat([d, torch.full((d.shape[0], k - kk), float('inf'), device=d.device)], dim=1)
+            i = torch.cat([i, torch.full((i.shape[0], k - kk), -1, dtype=torch.int64, device=i.device)], dim=1)
+        if self.metric == Metric.EUCLIDEAN:
+            d = torch.sqrt(d)
+        return d, i
+
+    def _search_rerank(self, q, k, valid, N, rerank_k):
+        B = q.shape[0]
+        rk = int(rerank_k or 64)
+        rk = max(1, min(64, rk))
+        plan = scan_plan(N, self.M, self.Ks, self.code_bytes, B, rk)
+        lut = self.pq_codec.get_dist_mat_tiled(q, plan.qi) if plan.fast else self.pq_codec.get_dist_mat(q)
+        _, cand = ops.adc_scan_candidates(self._codes, lut, B, rk, self.M, self.Ks, valid_bits=valid, n_rows=N,
+                                          codes_layout=self._layout(), workspace=self._ws)
+        exact = ops.exact_gather_dist(int(self.metric), q, self._vectors, cand)  # [B, R]
+        kk = min(k, 64)
+        d, pos = ops.topk_rows(exact, kk)
+        i = torch.gather(cand, 1, pos.clamp(min=0))
+        i = torch.where(pos < 0, torch.full_like(i, -1), i)
+        i = torch.where(torch.isinf(d), torch.full_like(i, -1), i)
+        if self.metric == Metric.EUCLIDEAN:
+            d = torch.sqrt(d)
+        if kk < k:
+            d = torch.cat([d, torch.full((B, k - kk), float('inf'), device=d.device)], dim=1)
+            i = torch.cat([i, torch.full((B, k - kk), -1, dtype=torch.int64, device=i.device)], dim=1)
+        return d, i
+
+    def search(self, x, limit: int = 10, indices=None):
+        """ONE query, reference signature (hnsw/index.py:139-167): ``(dists[k'], ids[k'])`` numpy,
+        ``k' <= limit`` valid entries only."""
+        if indices is not None and len(indices) < limit:
+            limit = len(indices)  # hnsw/index.py:153-154
+        if limit <= 0:
+            return np.empty((0,), np.float32), np.empty((0,), np.int64)
+        d, i = self.search_batch(x, limit=limit, indices=indices)
+        if isinstance(d, torch.Tensor):
+            d, i = d.cpu().numpy(), i.cpu().numpy()
+        d, i = d[0], i[0]
+        keep = i >= 0
+        return d[keep], i[keep]
+
+    # ------------------------------------------------------------------ persistence (own format)
+    def dump(self, index_file: Union[str, Path]):
+        """hnsw/index.py:121-122 analogue.  Codes are saved in the PLAIN (reference) layout."""
+        self._ensure_alloc()
+        N = self._n_rows
+        state = {
+            'format': 'annlite_amd.PQFlatGpuIndex/1',
+            'dim': self.dim, 'M': self.M, 'Ks': self.Ks, 'metric': int(self.metric),
+            'n_rows': N, 'size': self._size, 'capacity': self._capacity,
+            'codes': ops.codes_to_numpy(self._plain_codes(N)) if N else np.zeros((0, self.M), self.pq_codec.code_dtype),
+            'valid': self._valid_bool[:N].cpu().numpy(),
+            'vectors': self._vectors[:N].cpu().numpy() if self._vectors is not None else None,
+        }
+        with open(str(index_file), 'wb') as f:
+            np.save(f, np.array([state], dtype=object), allow_pickle=True)
+
+    def load(self, index_file: Union[str, Path]):
+        with open(str(index_file), 'rb') as f:
+            state = np.load(f, allow_pickle=True)[0]
+        assert state['format'] == 'annlite_amd.PQFlatGpuIndex/1'
+        assert state['dim'] == self.dim and state['M'] == self.M and state['Ks'] == self.Ks
+        self._alloc(max(int(state['capacity']), self._capacity))
+        N = int(state['n_rows'])
+        if N:
+            codes = ops.to_dev(state['codes'])
+            if self._layout() == CODES_SKEWED:
+                ops.codes_skew(codes, ids=None, id_base=0, out=self._codes)
+            else:
+                self._codes[:N] = codes
+            if self._vectors is not None and state['vectors'] is not None:
+                self._vectors[:N] = ops.to_dev(state['vectors'])
+        v = ops.to_dev(state['valid'])
+        self._valid_bool[: v.numel()] = v
+        self._valid_bits_cache = None
+        self._n_rows, self._size = N, int(state['size'])

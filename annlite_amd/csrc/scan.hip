@@ -1,0 +1,874 @@
+// scan.hip -- batched asymmetric-distance (ADC) scan over a PQ code table + exact top-k.
+//
+// Reference semantics (jina-ai/annlite v0.5.11):
+//   for each query b:  d[n] = sum_{m=0..M-1, ascending, fp32} lut[b][m][codes[n][m]]
+//                      (bindings/pq_bindings.pyx:30-47,52-80 == include/hnswlib/space_pq.h:15-37)
+//   then the k smallest (annlite/math.py:94-120) -- with the build's fixed tie-break (d asc, n asc).
+//
+// MI355X design (DESIGN.md "ADC scan"):
+//   * The cost is B*N*M random 4-byte table look-ups, so the kernel is bound by LDS gather
+//     bandwidth, not HBM.  Each workgroup keeps the tables of QT queries in LDS (M*Ks*4 B per query,
+//     up to 128 KB of the CU's 160 KB) interleaved QI queries per entry ([k][h][m][QI]), so ONE
+//     ds_read_b128 (QI=4) / ds_read_b64 (QI=2) returns the entries of QI queries for one code byte.
+//   * Conflict-free gather by SKEWING the sub-space order across lanes: at step t lane l looks up
+//     sub-space m = (l + t) mod M.  With the [k][h][m][QI] layout the LDS bank slot of an entry is
+//     m mod 16 (b128) / m mod 32 (b64), so the lanes of every hardware conflict group hit distinct
+//     slots whatever the code bytes are.  A non-skewed gather (all lanes same m, random k) costs
+//     ~2.9x (max load of 16 balls in 16 bins).
+//   * Bit-exact sums despite the skew: a lane holds its M looked-up values in VGPRs and adds them
+//     in true ascending-m order with two exec-masked passes of v_pk_add_f32 (pass 1: steps t>=t0
+//     = sub-spaces 0..s-1, pass 2: steps t<t0 = sub-spaces s..M-1; t0 = (M-s) mod M).  The exec
+//     masks are compile-time constants because s = lane mod M.
+//   * Codes stream from HBM once per XCD: the table is cut into >= 8 row slices, slice -> XCD by
+//     blockIdx % 8, and the 32 workgroups of an XCD walk the SAME slice for different query tiles,
+//     so all but the first reader hit the XCD's 4 MB L2.
+//   * top-k without LDS: every wave keeps, per query, a sorted 64-entry list spread over its lanes
+//     (common.h WaveList); a row is offered only if it beats the wave's current k-th distance.
+//
+// No fallback to CPU exists; unsupported shapes use the generic kernel below (LUT through L2).
+#include <string.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+
+namespace annlite {
+
+struct ScanArgs {
+    const void *codes;       // [N][M] code bytes
+    const uint32_t *valid;   // optional bitmap
+    const float *lut;        // tiled or BMK
+    unsigned long long *partial;  // [B_pad][NS][k] keys
+    int64_t N;
+    int32_t Ks;
+    int32_t B;
+    int32_t k;
+    int32_t n_tiles;
+    int32_t n_slices;
+    int64_t slice_rows;      // multiple of 64
+};
+
+// ---- compile-time exec masks for the ordered accumulation ---------------------------------------
+template <int M>
+constexpr unsigned long long pass_mask(int t, int pass) {
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) {
+        const int s = l % M;
+        const bool p1 = (s == 0) || (s >= M - t);
+        if (pass == 0 ? p1 : !p1) m |= 1ull << l;
+    }
+    return m;
+}
+
+template <unsigned long long MASK>
+__device__ __forceinline__ void masked_pk_add2(f32x2 &a0, f32x2 &a1, const f32x2 x0, const f32x2 x1) {
+    if constexpr (MASK == 0ull) {
+        return;
+    } else if constexpr (MASK == ~0ull) {
+        a0 += x0;
+        a1 += x1;
+    } else {
+        unsigned long long sv;
+        asm("s_mov_b64 %[sv], exec\n\t"
+            "s_mov_b32 exec_lo, %[lo]\n\t"
+            "s_mov_b32 exec_hi, %[hi]\n\t"
+            "v_pk_add_f32 %[a0], %[a0], %[x0]\n\t"
+            "v_pk_add_f32 %[a1], %[a1], %[x1]\n\t"
+            "s_mov_b64 exec, %[sv]"
+            : [a0] "+v"(a0), [a1] "+v"(a1), [sv] "=&s"(sv)
+            : [x0] "v"(x0), [x1] "v"(x1), [lo] "i"((int)(uint32_t)(MASK & 0xffffffffull)),
+              [hi] "i"((int)(uint32_t)(MASK >> 32)));
+    }
+}
+
+template <unsigned long long MASK>
+__device__ __forceinline__ void masked_pk_add1(f32x2 &a0, const f32x2 x0) {
+    if constexpr (MASK == 0ull) {
+        return;
+    } else if constexpr (MASK == ~0ull) {
+        a0 += x0;
+    } else {
+        unsigned long long sv;
+        asm("s_mov_b64 %[sv], exec\n\t"
+            "s_mov_b32 exec_lo, %[lo]\n\t"
+            "s_mov_b32 exec_hi, %[hi]\n\t"
+            "v_pk_add_f32 %[a0], %[a0], %[x0]\n\t"
+            "s_mov_b64 exec, %[sv]"
+            : [a0] "+v"(a0), [sv] "=&s"(sv)
+            : [x0] "v"(x0), [lo] "i"((int)(uint32_t)(MASK & 0xffffffffull)),
+              [hi] "i"((int)(uint32_t)(MASK >> 32)));
+    }
+}
+
+// ---- compile-time loops -------------------------------------------------------------------------
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// rotate the CW dwords of a code row left by `s` BYTES (s = 4*a + b, lane-varying but constant over
+// the kernel): afterwards byte t of the row is the code of sub-space (s + t) mod M.
+template <int CW>
+__device__ __forceinline__ void rotate_row(uint32_t (&c)[CW], const bool (&abit)[8], uint32_t bsh) {
+    // dword rotation by a, one conditional stage per bit of a
+    int bit = 0;
+    static_for<0, (CW > 1 ? (CW > 2 ? (CW > 4 ? (CW > 8 ? 4 : 3) : 2) : 1) : 0)>([&](auto ST) {
+        constexpr int st = decltype(ST)::value;
+        constexpr int sh = 1 << st;
+        uint32_t n[CW];
+#pragma unroll
+        for (int i = 0; i < CW; ++i) n[i] = abit[st] ? c[(i + sh) % CW] : c[i];
+#pragma unroll
+        for (int i = 0; i < CW; ++i) c[i] = n[i];
+    });
+    (void)bit;
+    // byte rotation by b across the dword ring
+    uint32_t n[CW];
+#pragma unroll
+    for (int i = 0; i < CW; ++i) n[i] = __builtin_amdgcn_alignbyte(c[(i + 1) % CW], c[i], bsh);
+#pragma unroll
+    for (int i = 0; i < CW; ++i) c[i] = n[i];
+}
+
+template <int QI>
+struct LutVec;
+template <>
+struct LutVec<4> {
+    typedef f32x4 type;
+};
+template <>
+struct LutVec<2> {
+    typedef f32x2 type;
+};
+
+// =================================================================================================
+// Fast kernel: uint8 codes, Ks <= 256, M in {8,16,32,64}, k <= 64.
+//   M  sub-spaces            QI queries interleaved per LDS entry (4 -> ds_read_b128, 2 -> b64)
+//   NQ entry groups per WG   (QT = QI*NQ queries per workgroup)      NW waves per workgroup
+// LDS byte address of (code k, group h, sub-space m): ((k*NQ + h)*M + m) * QI*4
+// =================================================================================================
+template <int M, int QI, int NQ, int NW, bool SKEWED>
+__global__ __launch_bounds__(NW * 64) void adc_scan_fast_kernel(const ScanArgs a) {
+    constexpr int QT = QI * NQ;
+    constexpr int CW = M / 4;              // dwords per code row
+    constexpr int EB = QI * 4;             // bytes per LDS entry
+    constexpr int RB = M * EB;             // bytes per (k, h) row of entries
+    constexpr int KSTRIDE = NQ * RB;       // bytes between consecutive codes k
+    constexpr int NP = QI / 2;             // f32x2 pairs per entry
+    typedef typename LutVec<QI>::type lutv_t;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int km1 = a.k - 1;
+
+    // lane-constant skew
+    const int s = lane % M;
+    const uint32_t bsh = (uint32_t)(s & 3);
+    bool abit[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) abit[i] = (((s >> 2) >> i) & 1) != 0;
+    // byte offset inside a (k,h) row for step t: ((s+t) mod M) * EB
+    uint32_t moff[M];
+#pragma unroll
+    for (int t = 0; t < M; ++t) moff[t] = (uint32_t)(((s + t) % M) * EB);
+
+    const int n_items = a.n_tiles * a.n_slices;
+    const int64_t group_bytes = (int64_t)a.Ks * RB;  // one tiled-LUT group = [Ks][M][QI] floats
+
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        // item -> (slice, tile): slice % 8 == item % 8 == blockIdx % 8 (the XCD this block lands on,
+        // speed only), consecutive items of one XCD walk the tiles of the same slice.
+        const int xcd = item & 7;
+        const int j = item >> 3;
+        const int tile = j % a.n_tiles;
+        const int slice = (j / a.n_tiles) * 8 + xcd;
+
+        __syncthreads();  // previous item's LDS readers are done
+        {
+            // fill the LUT tile: NQ groups of [Ks][M][QI] -> LDS [k][h][m][QI]; 16 B pieces
+            const unsigned char *src0 = (const unsigned char *)a.lut + (int64_t)tile * NQ * group_bytes;
+            constexpr int PIECES_PER_ROW = RB / 16;
+            const int total = NQ * a.Ks * PIECES_PER_ROW;
+            for (int idx = tid; idx < total; idx += NW * 64) {
+                const int p = idx % PIECES_PER_ROW;
+                const int kh = idx / PIECES_PER_ROW;  // = h*Ks + k  (source order)
+                const int h = kh / a.Ks;
+                const int kk = kh - h * a.Ks;
+                const u32x4 v = *(const u32x4 *)(src0 + (int64_t)h * group_bytes + (int64_t)kk * RB + p * 16);
+                *(u32x4 *)(smem + (kk * NQ + h) * RB + p * 16) = v;
+            }
+        }
+        __syncthreads();
+
+        WaveList list[QT];
+        uint32_t thr_hi[QT], thr_lo[QT];
+        float thr_f[QT];
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            list[q].reset();
+            thr_hi[q] = kKeyInfHi;
+            thr_lo[q] = kIdNone;
+            thr_f[q] = __builtin_inff();
+        }
+
+        const int64_t slice_begin = (int64_t)slice * a.slice_rows;
+        int64_t slice_end = slice_begin + a.slice_rows;
+        if (slice_end > a.N) slice_end = a.N;
+
+        const uint32_t *codes32 = (const uint32_t *)a.codes;
+        auto load_row = [&](int64_t row, uint32_t (&c)[CW]) {
+            if (row >= a.N) row = a.N - 1;  // clamped, masked out below
+            const uint32_t *p = codes32 + row * CW;
+            if constexpr (CW == 2) {
+                const u32x2 v = *(const u32x2 *)p;
+                c[0] = v.x;
+                c[1] = v.y;
+            } else {
+#pragma unroll
+                for (int i = 0; i < CW / 4; ++i) {
+                    const u32x4 v = *(const u32x4 *)(p + 4 * i);
+                    c[4 * i + 0] = v.x;
+                    c[4 * i + 1] = v.y;
+                    c[4 * i + 2] = v.z;
+                    c[4 * i + 3] = v.w;
+                }
+            }
+        };
+
+        int64_t row0 = slice_begin + (int64_t)wave * 64;
+        uint32_t cnext[CW];
+        if (row0 < slice_end) load_row(row0 + lane, cnext);
+
+        for (; row0 < slice_end; row0 += (int64_t)NW * 64) {
+            uint32_t c[CW];
+#pragma unroll
+            for (int i = 0; i < CW; ++i) c[i] = cnext[i];
+            const int64_t rown = row0 + (int64_t)NW * 64;
+            if (rown < slice_end) load_row(rown + lane, cnext);  // software prefetch of the next group
+
+            // rows this wave-step may return
+            unsigned long long vmask = ~0ull;
+            if (slice_end - row0 < 64) vmask = (1ull << (int)(slice_end - row0)) - 1ull;
+            if (a.valid) {
+                const uint32_t *vw = a.valid + (row0 >> 5);
+                unsigned long long vb = (unsigned long long)vw[0];
+                if (row0 + 32 < a.N) vb |= (unsigned long long)vw[1] << 32;
+                vmask &= vb;
+            }
+
+            if constexpr (!SKEWED) rotate_row<CW>(c, abit, bsh);  // SKEWED tables are stored pre-rotated
+
+            f32x2 acc[NQ][NP];
+#pragma unroll
+            for (int h = 0; h < NQ; ++h)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) acc[h][p] = (f32x2){0.f, 0.f};
+
+#pragma unroll
+            for (int h = 0; h < NQ; ++h) {
+                lutv_t val[M];
+                static_for<0, M>([&](auto T) {
+                    constexpr int t = decltype(T)::value;
+                    const uint32_t code = (c[t / 4] >> (8 * (t % 4))) & 0xffu;
+                    const uint32_t addr = code * (uint32_t)KSTRIDE + moff[t];
+                    val[t] = *(const lutv_t *)(smem + addr + h * RB);
+                });
+                // ordered accumulation: pass 1 then pass 2, each ascending in t
+                static_for<0, M>([&](auto T) {
+                    constexpr int t = decltype(T)::value;
+                    constexpr unsigned long long mk = pass_mask<M>(t, 0);
+                    if constexpr (QI == 4) {
+                        masked_pk_add2<mk>(acc[h][0], acc[h][1], __builtin_shufflevector(val[t], val[t], 0, 1),
+                                           __builtin_shufflevector(val[t], val[t], 2, 3));
+                    } else {
+                        masked_pk_add1<mk>(acc[h][0], val[t]);
+                    }
+                });
+                static_for<0, M>([&](auto T) {
+                    constexpr int t = decltype(T)::value;
+                    constexpr unsigned long long mk = pass_mask<M>(t, 1);
+                    if constexpr (QI == 4) {
+                        masked_pk_add2<mk>(acc[h][0], acc[h][1], __builtin_shufflevector(val[t], val[t], 0, 1),
+                                           __builtin_shufflevector(val[t], val[t], 2, 3));
+                    } else {
+                        masked_pk_add1<mk>(acc[h][0], val[t]);
+                    }
+                });
+            }
+
+            // offer rows that can still enter a list (rare after warm-up)
+            const uint32_t rid = (uint32_t)(row0 + lane);
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                const float d = acc[q / QI][(q % QI) / 2][q % 2];
+                const unsigned long long pm = __ballot(d <= thr_f[q]) & vmask;
+                if (pm) {
+                    wavelist_offer(list[q], pm, f32_to_ordered(d), rid, km1, thr_hi[q], thr_lo[q], lane);
+                    thr_f[q] = (thr_hi[q] == kKeyInfHi) ? __builtin_inff() : ordered_to_f32(thr_hi[q]);
+                }
+            }
+        }
+
+        // ---- merge the NW per-wave lists of each query through LDS (re-using the LUT space) -----
+        __syncthreads();
+        unsigned long long *scratch = (unsigned long long *)smem;  // [QT][NW][64]
+#pragma unroll
+        for (int q = 0; q < QT; ++q)
+            scratch[(q * NW + wave) * 64 + lane] = ((unsigned long long)list[q].hi << 32) | list[q].lo;
+        __syncthreads();
+        for (int q = wave; q < QT; q += NW) {
+            WaveList L;
+            unsigned long long key = scratch[(q * NW + 0) * 64 + lane];
+            L.hi = (uint32_t)(key >> 32);
+            L.lo = (uint32_t)key;
+            uint32_t th = __builtin_amdgcn_readlane(L.hi, km1), tl = __builtin_amdgcn_readlane(L.lo, km1);
+            for (int w = 1; w < NW; ++w) {
+                key = scratch[(q * NW + w) * 64 + lane];
+                const uint32_t chi = (uint32_t)(key >> 32), clo = (uint32_t)key;
+                const unsigned long long pm = __ballot(lane <= km1 && key_less(chi, clo, th, tl));
+                wavelist_offer(L, pm, chi, clo, km1, th, tl, lane);
+            }
+            const int b = tile * QT + q;
+            if (b < a.B && lane <= km1)
+                a.partial[((int64_t)b * a.n_slices + slice) * a.k + lane] = ((unsigned long long)L.hi << 32) | L.lo;
+        }
+    }
+}
+
+// =================================================================================================
+// Generic kernel: any M / Ks / code width (1,2,4 bytes), k <= 64.  One query per workgroup, the
+// table is read through L2 in the reference's [B][M][Ks] layout.  Correct for every shape the
+// reference accepts; used when no fast instantiation exists (e.g. Ks > 256 => uint16 codes).
+// =================================================================================================
+template <typename CODE_T, int NW>
+__global__ __launch_bounds__(NW * 64) void adc_scan_generic_kernel(const ScanArgs a, int M) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int km1 = a.k - 1;
+    const int n_items = a.n_tiles * a.n_slices;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int b = item % a.n_tiles;  // QT == 1
+        const int slice = item / a.n_tiles;
+        const float *lut = a.lut + (int64_t)b * M * a.Ks;
+        WaveList L;
+        L.reset();
+        uint32_t th = kKeyInfHi, tl = kIdNone;
+        float tf = __builtin_inff();
+        const int64_t slice_begin = (int64_t)slice * a.slice_rows;
+        int64_t slice_end = slice_begin + a.slice_rows;
+        if (slice_end > a.N) slice_end = a.N;
+        const CODE_T *codes = (const CODE_T *)a.codes;
+        for (int64_t row0 = slice_begin + (int64_t)wave * 64; row0 < slice_end; row0 += (int64_t)NW * 64) {
+            int64_t row = row0 + lane;
+            const bool inb = row < slice_end;
+            if (!inb) row = a.N - 1;
+            const CODE_T *cr = codes + row * M;
+            float d = 0.f;
+            for (int m = 0; m < M; ++m) d += lut[(int64_t)m * a.Ks + (int64_t)cr[m]];
+            unsigned long long vmask = __ballot(inb);
+            if (a.valid) {
+                const uint32_t *vw = a.valid + (row0 >> 5);
+                unsigned long long vb = (unsigned long long)vw[0];
+                if (row0 + 32 < a.N) vb |= (unsigned long long)vw[1] << 32;
+                vmask &= vb;
+            }
+            const unsigned long long pm = __ballot(d <= tf) & vmask;
+            if (pm) {
+                wavelist_offer(L, pm, f32_to_ordered(d), (uint32_t)(row0 + lane), km1, th, tl, lane);
+                tf = (th == kKeyInfHi) ? __builtin_inff() : ordered_to_f32(th);
+            }
+        }
+        __syncthreads();
+        unsigned long long *scratch = (unsigned long long *)smem;  // [NW][64]
+        scratch[wave * 64 + lane] = ((unsigned long long)L.hi << 32) | L.lo;
+        __syncthreads();
+        if (wave == 0) {
+            for (int w = 1; w < NW; ++w) {
+                const unsigned long long key = scratch[w * 64 + lane];
+                const uint32_t chi = (uint32_t)(key >> 32), clo = (uint32_t)key;
+                const unsigned long long pm = __ballot(lane <= km1 && key_less(chi, clo, th, tl));
+                wavelist_offer(L, pm, chi, clo, km1, th, tl, lane);
+            }
+            if (lane <= km1)
+                a.partial[((int64_t)b * a.n_slices + slice) * a.k + lane] = ((unsigned long long)L.hi << 32) | L.lo;
+        }
+        __syncthreads();
+    }
+}
+
+// =================================================================================================
+// Final merge: partial keys [B][NS][k] -> (dist f32, id i64) [B][k]; one wave per query.
+// =================================================================================================
+__global__ __launch_bounds__(256) void merge_partial_kernel(const unsigned long long *partial, int B, int NS,
+                                                           int k, int64_t row_base, float *out_d,
+                                                           int64_t *out_i) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int km1 = k - 1;
+    const unsigned long long *src = partial + (int64_t)b * NS * k;
+    const int total = NS * k;
+    WaveList L;
+    L.reset();
+    uint32_t th = kKeyInfHi, tl = kIdNone;
+    for (int base = 0; base < total; base += 64) {
+        const int i = base + lane;
+        unsigned long long key = ~0ull;
+        if (i < total) key = src[i];
+        const uint32_t chi = (uint32_t)(key >> 32), clo = (uint32_t)key;
+        const unsigned long long pm = __ballot(key_less(chi, clo, th, tl));
+        wavelist_offer(L, pm, chi, clo, km1, th, tl, lane);
+    }
+    if (lane <= km1) {
+        const bool none = (L.hi == kKeyInfHi && L.lo == kIdNone);
+        out_d[(int64_t)b * k + lane] = none ? __builtin_inff() : ordered_to_f32(L.hi);
+        out_i[(int64_t)b * k + lane] = none ? (int64_t)-1 : row_base + (int64_t)L.lo;
+    }
+}
+
+// Unmerged candidates: partial keys [B][NS][k] -> (dist, id) [B][NS*k]  (rerank candidate generator)
+__global__ __launch_bounds__(256) void export_partial_kernel(const unsigned long long *partial, int64_t total,
+                                                            int64_t row_base, float *out_d, int64_t *out_i) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const unsigned long long key = partial[i];
+    const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+    const bool none = (hi == kKeyInfHi && lo == kIdNone);
+    out_d[i] = none ? __builtin_inff() : ordered_to_f32(hi);
+    out_i[i] = none ? (int64_t)-1 : row_base + (int64_t)lo;
+}
+
+// Merge G lists [G][B][k] of (dist, id) -> [B][k]  (after the RCCL all-gather).  One wave per query.
+__global__ __launch_bounds__(256) void merge_lists_kernel(const float *dist, const int64_t *id, int G, int B,
+                                                         int k, float *out_d, int64_t *out_i) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int km1 = k - 1;
+    // ids are 64-bit here (global row ids of different shards), so the list is kept directly as
+    // (float dist, int64 id) per lane; candidates are offered one by one (G*k is small).
+    const int total = G * k;
+    float ld = __builtin_inff();
+    int64_t li = INT64_MAX;
+    for (int c = 0; c < total; ++c) {
+        const int g = c / k, j = c - g * k;
+        const float cd = dist[((int64_t)g * B + b) * k + j];
+        const int64_t ci = id[((int64_t)g * B + b) * k + j];
+        if (ci < 0) continue;  // padding entry of a short shard
+        const bool less = (ld < cd) || (ld == cd && li < ci);
+        const int pos = __popcll(__ballot(less));
+        if (pos > km1) continue;
+        const float sd = __shfl_up(ld, 1);
+        const int64_t si = __shfl_up(li, 1);
+        if (lane == pos) {
+            ld = cd;
+            li = ci;
+        } else if (lane > pos) {
+            ld = sd;
+            li = si;
+        }
+    }
+    if (lane <= km1) {
+        const bool none = (li == INT64_MAX);
+        out_d[(int64_t)b * k + lane] = none ? __builtin_inff() : ld;
+        out_i[(int64_t)b * k + lane] = none ? (int64_t)-1 : li;
+    }
+}
+
+// Row-wise top-k of a dense matrix (annlite/math.py:94-120 with the fixed tie-break); wave per row.
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float *values, int B, int64_t N, int k,
+                                                       int64_t id_base, float *out_d, int64_t *out_i) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int km1 = k - 1;
+    const float *src = values + (int64_t)b * N;
+    WaveList L;
+    L.reset();
+    uint32_t th = kKeyInfHi, tl = kIdNone;
+    float tf = __builtin_inff();
+    for (int64_t base = 0; base < N; base += 64) {
+        const int64_t i = base + lane;
+        const float d = (i < N) ? src[i] : __builtin_inff();
+        const unsigned long long pm = __ballot(i < N && d <= tf);
+        if (pm) {
+            wavelist_offer(L, pm, f32_to_ordered(d), (uint32_t)i, km1, th, tl, lane);
+            tf = (th == kKeyInfHi) ? __builtin_inff() : ordered_to_f32(th);
+        }
+    }
+    if (lane <= km1) {
+        const bool none = (L.hi == kKeyInfHi && L.lo == kIdNone);
+        out_d[(int64_t)b * k + lane] = none ? __builtin_inff() : ordered_to_f32(L.hi);
+        out_i[(int64_t)b * k + lane] = none ? (int64_t)-1 : id_base + (int64_t)L.lo;
+    }
+}
+
+// =================================================================================================
+// all-distances scan (operator seam) and gathered ADC
+// =================================================================================================
+template <typename CODE_T>
+__global__ __launch_bounds__(256) void adc_dist_kernel(const float *adtable, int M, int Ks, const CODE_T *codes,
+                                                      int64_t N, float *out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *t = (float *)smem;
+    const bool in_lds = (int64_t)M * Ks * 4 <= 64 * 1024;
+    if (in_lds) {
+        for (int i = threadIdx.x; i < M * Ks; i += blockDim.x) t[i] = adtable[i];
+        __syncthreads();
+    }
+    const float *tab = in_lds ? t : adtable;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        const CODE_T *c = codes + n * M;
+        float d = 0.f;
+        for (int m = 0; m < M; ++m) d += tab[m * Ks + (int)c[m]];
+        out[n] = d;
+    }
+}
+
+template <typename CODE_T>
+__global__ __launch_bounds__(256) void adc_gather_kernel(const float *lut, int B, int M, int Ks, const CODE_T *codes,
+                                                        int64_t N, const int64_t *cand, int R, float *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * R) return;
+    const int b = (int)(i / R);
+    const int64_t row = cand[i];
+    if (row < 0 || row >= N) {
+        out[i] = __builtin_inff();
+        return;
+    }
+    const float *tab = lut + (int64_t)b * M * Ks;
+    const CODE_T *c = codes + row * M;
+    float d = 0.f;
+    for (int m = 0; m < M; ++m) d += tab[m * Ks + (int)c[m]];
+    out[i] = d;
+}
+
+// PLAIN <-> SKEWED code-table conversion (uint8): one thread per code byte
+__global__ __launch_bounds__(256) void codes_skew_kernel(const uint8_t *__restrict__ in, int64_t N, int M,
+                                                        const int64_t *__restrict__ ids, int64_t id_base,
+                                                        uint8_t *__restrict__ out, int inverse) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * M) return;
+    const int64_t i = t / M;
+    const int j = (int)(t - i * M);
+    const int64_t id = ids ? ids[i] : id_base + i;
+    const int r = (int)(id % M);
+    if (!inverse)
+        out[id * M + j] = in[i * M + (j + r) % M];
+    else
+        out[i * M + j] = in[id * M + ((j - r) % M + M) % M];
+}
+
+// =================================================================================================
+// host side
+// =================================================================================================
+struct FastCfg {
+    int M, QI, NQ, NW;
+};
+
+static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *c) {
+    if (code_bytes != 1 || Ks > 256 || Ks < 1 || k > 64 || k < 1) return false;
+    switch (M) {
+        case 8: *c = {8, 4, 2, 8}; return true;
+        case 16: *c = {16, 4, 2, 8}; return true;
+        case 32: *c = {32, 4, 1, 8}; return true;
+        case 64: *c = {64, 2, 1, 8}; return true;
+        default: return false;
+    }
+}
+
+static int round_up(int64_t x, int64_t m) { return (int)(((x + m - 1) / m) * m); }
+
+static void plan_slices(int64_t N, int n_tiles, int waves, int n_cu, bool xcd8, int *n_slices, int64_t *slice_rows) {
+    // at least one slice per XCD; more when few query tiles exist, as long as every wave keeps
+    // >= 8 steps of 64 rows
+    const int64_t min_rows = (int64_t)waves * 64 * 8;
+    int64_t want = (2 * (int64_t)n_cu + n_tiles - 1) / n_tiles;
+    int64_t cap = N / min_rows;
+    if (want > cap) want = cap;
+    int64_t ns = xcd8 ? ((want + 7) / 8) * 8 : want;
+    if (ns < (xcd8 ? 8 : 1)) ns = xcd8 ? 8 : 1;
+    int64_t rows = (N + ns - 1) / ns;
+    rows = ((rows + 63) / 64) * 64;
+    if (rows < 64) rows = 64;
+    *n_slices = (int)ns;
+    *slice_rows = rows;
+}
+
+}  // namespace annlite
+
+using namespace annlite;
+
+extern "C" int annlite_scan_plan_query(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t k,
+                                       annlite_scan_plan *plan) {
+    ANNLITE_REQUIRE(plan != nullptr, "plan is NULL");
+    ANNLITE_REQUIRE(N >= 0 && M >= 1 && Ks >= 1 && B >= 0, "bad shape N=%lld M=%lld Ks=%lld B=%lld", (long long)N,
+                    (long long)M, (long long)Ks, (long long)B);
+    ANNLITE_REQUIRE(code_bytes == 1 || code_bytes == 2 || code_bytes == 4, "code_bytes must be 1, 2 or 4");
+    ANNLITE_REQUIRE(k >= 1 && k <= 64, "k=%lld outside [1,64] (larger k: annlite_adc_dist + host-side selection)",
+                    (long long)k);
+    ANNLITE_REQUIRE(N < (1ll << 32) - 1, "N must be < 2^32-1 rows per call (shard the table)");
+    FastCfg c;
+    const int n_cu = device_cu_count();
+    memset(plan, 0, sizeof(*plan));
+    plan->max_k = 64;
+    if (fast_cfg(M, Ks, code_bytes, k, &c)) {
+        plan->fast = 1;
+        plan->qi = c.QI;
+        plan->qt = c.QI * c.NQ;
+        plan->waves = c.NW;
+        const int n_tiles = (int)((B + plan->qt - 1) / plan->qt);
+        int ns;
+        int64_t sr;
+        plan_slices(N > 0 ? N : 1, n_tiles > 0 ? n_tiles : 1, c.NW, n_cu, true, &ns, &sr);
+        plan->n_slices = ns;
+        plan->lut_floats = ((B + 15) / 16) * 16 * M * Ks;  // padded to 16 queries
+        plan->workspace_bytes = (int64_t)n_tiles * plan->qt * ns * k * 8;
+    } else {
+        plan->fast = 0;
+        plan->qi = 1;
+        plan->qt = 1;
+        plan->waves = 4;
+        int ns;
+        int64_t sr;
+        plan_slices(N > 0 ? N : 1, B > 0 ? (int)B : 1, 4, n_cu, false, &ns, &sr);
+        plan->n_slices = ns;
+        plan->lut_floats = B * M * Ks;
+        plan->workspace_bytes = B * ns * k * 8;
+    }
+    if (plan->workspace_bytes < 8) plan->workspace_bytes = 8;
+    return ANNLITE_OK;
+}
+
+template <int M, int QI, int NQ, int NW, bool SKEWED>
+static int launch_fast(const ScanArgs &a, int grid, hipStream_t st) {
+    const size_t lds = (size_t)a.Ks * NQ * M * QI * 4;
+    size_t need = lds;
+    const size_t scratch = (size_t)QI * NQ * NW * 64 * 8;
+    if (need < scratch) need = scratch;
+    auto fn = adc_scan_fast_kernel<M, QI, NQ, NW, SKEWED>;
+    ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
+    return launch_status("adc_scan_fast_kernel");
+}
+
+// ---- optional in-library timing of the dominant kernel (bench.py roofline leg) --------------------
+static thread_local int g_prof_on = 0;
+static thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+static thread_local int g_ev_valid = 0;
+
+static void prof_begin(hipStream_t st) {
+    if (!g_prof_on) return;
+    if (!g_ev0) {
+        (void)hipEventCreate(&g_ev0);
+        (void)hipEventCreate(&g_ev1);
+    }
+    (void)hipEventRecord(g_ev0, st);
+}
+static void prof_end(hipStream_t st) {
+    if (!g_prof_on) return;
+    (void)hipEventRecord(g_ev1, st);
+    g_ev_valid = 1;
+}
+
+// run the scan kernels: fills workspace with the per-(query, slice) sorted key lists [B][NS][k]
+static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M, int64_t Ks,
+                        const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B, int64_t k,
+                        void *workspace_dev, size_t workspace_bytes, hipStream_t st, annlite_scan_plan *plan_out) {
+    annlite_scan_plan plan;
+    int rc = annlite_scan_plan_query(N, M, Ks, code_bytes, B, k, &plan);
+    if (rc != ANNLITE_OK) return rc;
+    *plan_out = plan;
+    if (B == 0) return ANNLITE_OK;
+    ANNLITE_REQUIRE(codes_layout == ANNLITE_CODES_PLAIN || (codes_layout == ANNLITE_CODES_SKEWED && plan.fast),
+                    "codes_layout %d not supported by this plan (SKEWED needs the fast plan)", codes_layout);
+    ANNLITE_REQUIRE(lut_dev && workspace_dev, "null device pointer");
+    ANNLITE_REQUIRE(N == 0 || codes_dev, "codes_dev is NULL");
+    if (workspace_bytes < (size_t)plan.workspace_bytes) {
+        set_error("workspace %zu B < required %lld B", workspace_bytes, (long long)plan.workspace_bytes);
+        return ANNLITE_ERR_WORKSPACE;
+    }
+    const int n_cu = device_cu_count();
+    ScanArgs a;
+    a.codes = codes_dev;
+    a.valid = valid_bits_dev;
+    a.lut = lut_dev;
+    a.partial = (unsigned long long *)workspace_dev;
+    a.N = N;
+    a.Ks = (int)Ks;
+    a.B = (int)B;
+    a.k = (int)k;
+    a.n_tiles = (int)((B + plan.qt - 1) / plan.qt);
+    a.n_slices = plan.n_slices;
+    {
+        int ns;
+        int64_t sr;
+        plan_slices(N > 0 ? N : 1, a.n_tiles, plan.waves, n_cu, plan.fast != 0, &ns, &sr);
+        a.slice_rows = sr;
+    }
+    // slots of slices that hold no rows stay "none"
+    ANNLITE_HIP_TRY(hipMemsetAsync(workspace_dev, 0xff, (size_t)plan.workspace_bytes, st));
+    if (N == 0) return ANNLITE_OK;
+    const int n_items = a.n_tiles * a.n_slices;
+    if (plan.fast) {
+        int grid = n_items < n_cu ? n_items : n_cu;
+        const bool sk = codes_layout == ANNLITE_CODES_SKEWED;
+        prof_begin(st);
+        if (M == 8) rc = sk ? launch_fast<8, 4, 2, 8, true>(a, grid, st) : launch_fast<8, 4, 2, 8, false>(a, grid, st);
+        else if (M == 16) rc = sk ? launch_fast<16, 4, 2, 8, true>(a, grid, st) : launch_fast<16, 4, 2, 8, false>(a, grid, st);
+        else if (M == 32) rc = sk ? launch_fast<32, 4, 1, 8, true>(a, grid, st) : launch_fast<32, 4, 1, 8, false>(a, grid, st);
+        else rc = sk ? launch_fast<64, 2, 1, 8, true>(a, grid, st) : launch_fast<64, 2, 1, 8, false>(a, grid, st);
+        prof_end(st);
+        return rc;
+    }
+    const int grid = n_items < n_cu * 8 ? n_items : n_cu * 8;
+    const size_t lds = 4 * 64 * 8;
+    prof_begin(st);
+    if (code_bytes == 1)
+        hipLaunchKernelGGL((adc_scan_generic_kernel<uint8_t, 4>), dim3(grid), dim3(256), lds, st, a, (int)M);
+    else if (code_bytes == 2)
+        hipLaunchKernelGGL((adc_scan_generic_kernel<uint16_t, 4>), dim3(grid), dim3(256), lds, st, a, (int)M);
+    else
+        hipLaunchKernelGGL((adc_scan_generic_kernel<uint32_t, 4>), dim3(grid), dim3(256), lds, st, a, (int)M);
+    prof_end(st);
+    return launch_status("adc_scan_generic_kernel");
+}
+
+extern "C" int annlite_profile_enable(int on) {
+    g_prof_on = on ? 1 : 0;
+    g_ev_valid = 0;
+    return ANNLITE_OK;
+}
+
+extern "C" int annlite_profile_last_scan_ms(float *ms) {
+    ANNLITE_REQUIRE(ms != nullptr, "ms is NULL");
+    if (!g_ev_valid) {
+        set_error("no scan has been recorded (call annlite_profile_enable(1) first)");
+        return ANNLITE_ERR_INVALID;
+    }
+    ANNLITE_HIP_TRY(hipEventSynchronize(g_ev1));
+    ANNLITE_HIP_TRY(hipEventElapsedTime(ms, g_ev0, g_ev1));
+    return ANNLITE_OK;
+}
+
+extern "C" int annlite_adc_scan_topk(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M,
+                                     int64_t Ks, const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B,
+                                     int64_t k, int64_t row_base, float *out_dist_dev, int64_t *out_id_dev,
+                                     void *workspace_dev, size_t workspace_bytes, void *stream) {
+    annlite_scan_plan plan;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = scan_partial(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut_dev, B, k, workspace_dev,
+                          workspace_bytes, st, &plan);
+    if (rc != ANNLITE_OK || B == 0) return rc;
+    ANNLITE_REQUIRE(out_dist_dev && out_id_dev, "null output pointer");
+    hipLaunchKernelGGL(merge_partial_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st,
+                       (const unsigned long long *)workspace_dev, (int)B, plan.n_slices, (int)k, row_base,
+                       out_dist_dev, out_id_dev);
+    return launch_status("merge_partial_kernel");
+}
+
+extern "C" int annlite_adc_scan_candidates(const void *codes_dev, int code_bytes, int codes_layout, int64_t N,
+                                           int64_t M, int64_t Ks, const uint32_t *valid_bits_dev,
+                                           const float *lut_dev, int64_t B, int64_t k, int64_t row_base,
+                                           float *out_dist_dev, int64_t *out_id_dev, void *workspace_dev,
+                                           size_t workspace_bytes, void *stream) {
+    annlite_scan_plan plan;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = scan_partial(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut_dev, B, k, workspace_dev,
+                          workspace_bytes, st, &plan);
+    if (rc != ANNLITE_OK || B == 0) return rc;
+    ANNLITE_REQUIRE(out_dist_dev && out_id_dev, "null output pointer");
+    const int64_t total = B * plan.n_slices * k;
+    hipLaunchKernelGGL(export_partial_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const unsigned long long *)workspace_dev, total, row_base, out_dist_dev, out_id_dev);
+    return launch_status("export_partial_kernel");
+}
+
+extern "C" int annlite_codes_skew(const void *in_dev, int64_t N, int64_t M, const int64_t *ids_dev, int64_t id_base,
+                                  void *out_dev, int inverse, void *stream) {
+    ANNLITE_REQUIRE(N >= 0 && M >= 1 && id_base >= 0, "bad shape");
+    if (N == 0) return ANNLITE_OK;
+    ANNLITE_REQUIRE(in_dev && out_dev, "null device pointer");
+    const int64_t total = N * M;
+    hipLaunchKernelGGL(codes_skew_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t *)in_dev, N, (int)M, ids_dev, id_base, (uint8_t *)out_dev, inverse);
+    return launch_status("codes_skew_kernel");
+}
+
+extern "C" int annlite_topk_merge(const float *dist_dev, const int64_t *id_dev, int64_t G, int64_t B, int64_t k,
+                                  float *out_dist_dev, int64_t *out_id_dev, void *stream) {
+    ANNLITE_REQUIRE(G >= 1 && B >= 0 && k >= 1 && k <= 64, "bad G=%lld B=%lld k=%lld (k<=64)", (long long)G,
+                    (long long)B, (long long)k);
+    if (B == 0) return ANNLITE_OK;
+    ANNLITE_REQUIRE(dist_dev && id_dev && out_dist_dev && out_id_dev, "null device pointer");
+    hipLaunchKernelGGL(merge_lists_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dist_dev,
+                       id_dev, (int)G, (int)B, (int)k, out_dist_dev, out_id_dev);
+    return launch_status("merge_lists_kernel");
+}
+
+extern "C" int annlite_topk_rows(const float *values_dev, int64_t B, int64_t N, int64_t k, int64_t id_base,
+                                 float *out_dist_dev, int64_t *out_id_dev, void *stream) {
+    ANNLITE_REQUIRE(B >= 0 && N >= 0 && k >= 1 && k <= 64, "bad B=%lld N=%lld k=%lld (k<=64)", (long long)B,
+                    (long long)N, (long long)k);
+    ANNLITE_REQUIRE(N < (1ll << 32) - 1, "N must be < 2^32-1");
+    if (B == 0) return ANNLITE_OK;
+    ANNLITE_REQUIRE(out_dist_dev && out_id_dev && (N == 0 || values_dev), "null device pointer");
+    hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, values_dev,
+                       (int)B, N, (int)k, id_base, out_dist_dev, out_id_dev);
+    return launch_status("topk_rows_kernel");
+}
+
+extern "C" int annlite_adc_dist(const float *adtable_dev, int64_t M, int64_t Ks, const void *codes_dev, int code_bytes,
+                                int64_t N, float *out_dev, void *stream) {
+    ANNLITE_REQUIRE(M >= 1 && Ks >= 1 && N >= 0, "bad shape");
+    ANNLITE_REQUIRE(code_bytes == 1 || code_bytes == 2 || code_bytes == 4, "code_bytes must be 1, 2 or 4");
+    if (N == 0) return ANNLITE_OK;
+    ANNLITE_REQUIRE(adtable_dev && codes_dev && out_dev, "null device pointer");
+    const size_t tab = (size_t)M * Ks * 4;
+    const size_t lds = tab <= 64 * 1024 ? tab : 0;
+    int64_t blocks = (N + 255) / 256;
+    const int64_t cap = (int64_t)device_cu_count() * 8;
+    if (blocks > cap) blocks = cap;
+    hipStream_t st = (hipStream_t)stream;
+    if (code_bytes == 1)
+        hipLaunchKernelGGL(adc_dist_kernel<uint8_t>, dim3((unsigned)blocks), dim3(256), lds, st, adtable_dev, (int)M,
+                           (int)Ks, (const uint8_t *)codes_dev, N, out_dev);
+    else if (code_bytes == 2)
+        hipLaunchKernelGGL(adc_dist_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), lds, st, adtable_dev, (int)M,
+                           (int)Ks, (const uint16_t *)codes_dev, N, out_dev);
+    else
+        hipLaunchKernelGGL(adc_dist_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), lds, st, adtable_dev, (int)M,
+                           (int)Ks, (const uint32_t *)codes_dev, N, out_dev);
+    return launch_status("adc_dist_kernel");
+}
+
+extern "C" int annlite_adc_gather(const float *lut_bmk_dev, int64_t B, int64_t M, int64_t Ks, const void *codes_dev,
+                                  int code_bytes, int64_t N, const int64_t *cand_dev, int64_t R, float *out_dev,
+                                  void *stream) {
+    ANNLITE_REQUIRE(M >= 1 && Ks >= 1 && N >= 0 && B >= 0 && R >= 0, "bad shape");
+    ANNLITE_REQUIRE(code_bytes == 1 || code_bytes == 2 || code_bytes == 4, "code_bytes must be 1, 2 or 4");
+    if (B * R == 0) return ANNLITE_OK;
+    ANNLITE_REQUIRE(lut_bmk_dev && cand_dev && out_dev && (N == 0 || codes_dev), "null device pointer");
+    const int64_t total = B * R;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (code_bytes == 1)
+        hipLaunchKernelGGL(adc_gather_kernel<uint8_t>, dim3(blocks), dim3(256), 0, st, lut_bmk_dev, (int)B, (int)M,
+                           (int)Ks, (const uint8_t *)codes_dev, N, cand_dev, (int)R, out_dev);
+    else if (code_bytes == 2)
+        hipLaunchKernelGGL(adc_gather_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, lut_bmk_dev, (int)B, (int)M,
+                           (int)Ks, (const uint16_t *)codes_dev, N, cand_dev, (int)R, out_dev);
+    else
+        hipLaunchKernelGGL(adc_gather_kernel<uint32_t>, dim3(blocks), dim3(256), 0, st, lut_bmk_dev, (int)B, (int)M,
+                           (int)Ks, (const uint32_t *)codes_dev, N, cand_dev, (int)R, out_dev);
+    return launch_status("adc_gather_kernel");
+}

@@ -1,0 +1,334 @@
+"""``AnnLite`` facade -- the reference's public API (annlite/index.py:26-973) over the MI355X
+PQ/ADC hot path.
+
+Kept from the reference: the constructor signature (index.py:59-77, ``dim=`` alias 80-84),
+``train`` / ``partial_train`` / ``index`` / ``update`` / ``delete`` / ``search`` /
+``search_by_vectors`` / ``search_numpy`` / ``encode`` / ``decode`` / ``clear`` / ``close`` /
+``stat`` / ``is_trained`` / ``total_docs`` / ``index_size``, the error behaviour
+(``RuntimeError('The indexer is not trained ...')``, index.py:284-285, 349-350; read-only index logs
+and returns, 280-282), the result shape (``doc.matches = DocumentArray[Document(id=...)]`` with
+``scores[metric.name.lower()].value = dist``, container.py:226-233) and the on-disk location of the
+trained codec (``data_path/parameters-<md5>/pq_codec.params``, index.py:574-599, 679-687).
+
+Changed on purpose: the vector index per cell is the exhaustive
+GPU scan ``PQFlatGpuIndex`` instead of an HNSW graph walked one query at a time
+(container.py:48-59, 214); ALL queries of a ``search`` call go through one batched launch.
+
+Out of scope of this tier: IVF cells (``n_cells > 1``),
+PCA projection (``n_components``), RocksDB/SQLite persistence of documents, remote backup.  Documents
+and tags live in memory; the Mongo-style ``filter`` dict is evaluated on the host and handed to the
+GPU scan as a row bitmap (section 8f-3).
+"""
+import hashlib
+import logging
+import warnings
+from pathlib import Path
+from typing import Dict, List, Optional, Union
+
+import numpy as np
+import torch
+
+from . import ops
+from .core.codec.pq import PQCodec
+from .core.index.pq_flat_gpu import PQFlatGpuIndex
+from .enums import Metric
+from .filter import select as _filter_select
+
+try:  # real docarray when present (it is not in this image)
+    from docarray import Document, DocumentArray
+    from docarray.math.ndarray import to_numpy_array
+except Exception:  # pragma: no cover - depends on the environment
+    from .docarray_compat import Document, DocumentArray, to_numpy_array
+
+logger = logging.getLogger('annlite_amd')
+
+MAX_TRAINING_DATA_SIZE = 10240  # index.py:23
+
+
+class AnnLite:
+    """MI355X-native drop-in for :class:`annlite.AnnLite` on the PQ search path.
+
+    :param n_dim: dimensionality of input vectors (divisible by ``n_subvectors``)
+    :param metric: 'euclidean', 'inner_product' or 'cosine'
+    :param n_subvectors: number of PQ sub-quantisers = bytes per stored vector (required here: the
+        GPU index is PQ-encoded; the reference's un-quantised float-HNSW path is out of scope)
+    :param n_clusters: codewords per sub-quantiser (default 256)
+    :param rerank: keep the float vectors in HBM and re-score ADC candidates exactly (kwarg, rides
+        the reference's ``**kwargs`` channel to the index, container.py:56)
+    """
+
+    def __init__(
+        self,
+        n_dim: int,
+        metric: Union[str, Metric] = 'cosine',
+        n_cells: int = 1,
+        n_subvectors: Optional[int] = None,
+        n_clusters: Optional[int] = 256,
+        n_probe: int = 16,
+        n_components: Optional[int] = None,
+        initial_size: Optional[int] = None,
+        expand_step_size: int = 10240,
+        columns: Optional[Union[Dict, List]] = None,
+        filterable_attrs: Optional[Dict] = None,
+        data_path: Union[Path, str] = Path('./data'),
+        create_if_missing: bool = True,
+        read_only: bool = False,
+        verbose: bool = False,
+        **kwargs,
+    ):
+        logger.setLevel(logging.DEBUG if verbose else logging.INFO)
+        if 'dim' in kwargs:
+            warnings.warn('The argument `dim` will be deprecated, please use `n_dim` instead.')
+            n_dim = kwargs.pop('dim')
+        if n_subvectors:
+            assert n_dim % n_subvectors == 0, '"n_dim" needs to be divisible by "n_subvectors"'
+        if n_cells != 1:
+            raise NotImplementedError('n_cells > 1 (IVF coarse quantiser) is outside the accelerated hot path (SURVEY.md section 2 row 14)')
+        if n_components:
+            raise NotImplementedError('n_components (PCA projector) is outside the accelerated hot path (SURVEY.md section 2 row 15)')
+        if not n_subvectors:
+            raise NotImplementedError('annlite_amd accelerates the PQ path: pass n_subvectors (the un-quantised float-HNSW index is out of scope)')
+        self.n_dim = n_dim
+        self.n_components = n_components
+        self.n_subvectors = n_subvectors
+        self.n_clusters = n_clusters
+        self.n_probe = max(n_probe, n_cells)
+        self.n_cells = n_cells
+        if isinstance(metric, str):
+            metric = Metric.from_string(metric)
+        self.metric = metric
+        self.read_only = read_only
+
+        data_path = Path(data_path)
+        if create_if_missing:
+            data_path.mkdir(parents=True, exist_ok=True)
+        self.data_path = data_path
+
+        self._pq_codec = None
+        if self._pq_codec_path.exists():
+            logger.info(f'Load trained PQ codec (n_subvectors={self.n_subvectors}) from {self.model_path}')
+            self._pq_codec = PQCodec.load(self._pq_codec_path)
+        else:
+            self._pq_codec = PQCodec(dim=n_dim, n_subvectors=n_subvectors, n_clusters=n_clusters, metric=metric)
+
+        if columns is not None:
+            filterable_attrs = {n: t for n, t in (columns.items() if isinstance(columns, dict) else columns)}
+        self.filterable_attrs = filterable_attrs or {}
+
+        self._index_kwargs = dict(initial_size=initial_size, expand_step_size=expand_step_size, **kwargs)
+        self._vec_indexes = [self._new_index()]
+        # in-memory stand-ins for CellTable / DocStorage (offset <-> doc id, tags, documents)
+        self._offset2id: List[Optional[str]] = []
+        self._id2offset: Dict[str, int] = {}
+        self._tags: List[Optional[dict]] = []
+        self._docs: Dict[str, object] = {}
+
+    def _new_index(self) -> PQFlatGpuIndex:
+        return PQFlatGpuIndex(dim=self.n_dim, metric=self.metric, pq_codec=self._pq_codec, **self._index_kwargs)
+
+    # ------------------------------------------------------------------ bookkeeping (index.py:574-599, 952-963)
+    @property
+    def params_hash(self):
+        model_metas = (f'n_dim: {self.n_dim} metric: {self.metric} n_cells: {self.n_cells} '
+                       f'n_components: {self.n_components} n_subvectors: {self.n_subvectors}')
+        return hashlib.md5(f'{model_metas}'.encode()).hexdigest()
+
+    @property
+    def model_path(self):
+        return self.data_path / f'parameters-{self.params_hash}'
+
+    @property
+    def _pq_codec_path(self):
+        return self.model_path / 'pq_codec.params'
+
+    @property
+    def is_trained(self) -> bool:
+        return bool(self._pq_codec is not None and self._pq_codec.is_trained)
+
+    @property
+    def total_docs(self) -> int:
+        return len(self._id2offset)
+
+    @property
+    def index_size(self) -> int:
+        return sum(idx.size for idx in self._vec_indexes)
+
+    @property
+    def stat(self):
+        return {
+            'total_docs': self.total_docs, 'index_size': self.index_size, 'n_cells': self.n_cells,
+            'n_dim': self.n_dim, 'n_components': self.n_components, 'metric': self.metric.name,
+            'is_trained': self.is_trained,
+        }
+
+    def vec_index(self, cell_id: int = 0) -> PQFlatGpuIndex:
+        return self._vec_indexes[cell_id]
+
+    def _sanity_check(self, x):
+        assert x.ndim == 2, 'inputs must be a 2D array'
+        assert x.shape[1] == self.n_dim, (
+            f'inputs must have the same dimension as the index , got {x.shape[1]}, expected {self.n_dim}')
+        return x.shape
+
+    # ------------------------------------------------------------------ training (index.py:197-272, 679-687)
+    def train(self, x, auto_save: bool = True, force_train: bool = False):
+        self._sanity_check(x)
+        if self.is_trained and not force_train:
+            logger.warning('The indexer has been trained or is not trainable. Please use ``force_train=True`` to retrain.')
+            return
+        self._pq_codec.fit(x if isinstance(x, torch.Tensor) else np.ascontiguousarray(x, dtype=np.float32))
+        if auto_save:
+            self.dump_model()
+
+    def partial_train(self, x, auto_save: bool = True, force_train: bool = False):
+        self._sanity_check(x)
+        if self.is_trained and not force_train:
+            logger.warning('The annlite has been trained or is not trainable. Please use ``force_train=True`` to retrain.')
+            return
+        self._pq_codec.partial_fit(x)
+        self._pq_codec.build_codebook()
+        if auto_save:
+            self.dump_model()
+
+    def dump_model(self):
+        self.model_path.mkdir(parents=True, exist_ok=True)
+        self._pq_codec.dump(self._pq_codec_path)
+
+    # ------------------------------------------------------------------ index / update / delete
+    def index(self, docs, **kwargs):
+        """index.py:274-295 -> CellContainer.insert (container.py:262-308): offsets are dense row ids."""
+        if self.read_only:
+            logger.error('The indexer is readonly, cannot add new documents')
+            return
+        if not self.is_trained:
+            raise RuntimeError('The indexer is not trained, cannot add new documents')
+        x = to_numpy_array(docs.embeddings)
+        self._sanity_check(x)
+        offsets = []
+        for d in docs:
+            off = len(self._offset2id)
+            self._offset2id.append(d.id)
+            self._id2offset[d.id] = off
+            self._tags.append(dict(d.tags) if getattr(d, 'tags', None) else {})
+            self._docs[d.id] = d
+            offsets.append(off)
+        self.vec_index(0).add_with_ids(np.ascontiguousarray(x, dtype=np.float32), np.asarray(offsets, dtype=np.int64))
+
+    def update(self, docs, raise_errors_on_not_found: bool = False, insert_if_not_found: bool = True, **kwargs):
+        """index.py:297-332: delete + re-insert under a fresh offset (container.py:323-375)."""
+        if self.read_only:
+            logger.error('The indexer is readonly, cannot update documents')
+            return
+        if not self.is_trained:
+            raise RuntimeError('The indexer is not trained, cannot add new documents')
+        new_docs = DocumentArray()
+        for d in docs:
+            if d.id in self._id2offset:
+                self.delete([d.id])
+                new_docs.append(d)
+            elif raise_errors_on_not_found:
+                raise Exception(f'The document (id={d.id}) cannot be updated as it is not found in the index')
+            elif insert_if_not_found:
+                new_docs.append(d)
+        if len(new_docs):
+            self.index(new_docs)
+
+    def delete(self, docs, raise_errors_on_not_found: bool = False):
+        ids = docs if isinstance(docs, list) else docs[:, 'id']
+        offs = []
+        for doc_id in ids:
+            off = self._id2offset.pop(doc_id, None)
+            if off is None:
+                if raise_errors_on_not_found:
+                    raise Exception(f'The document (id={doc_id}) cannot be updated as it is not found in the index')
+                continue
+            self._offset2id[off] = None
+            self._tags[off] = None
+            self._docs.pop(doc_id, None)
+            offs.append(off)
+        if offs:
+            self.vec_index(0).delete(offs)
+
+    def clear(self):
+        self.vec_index(0).reset()
+        self._offset2id, self._id2offset, self._tags, self._docs = [], {}, [], {}
+
+    def close(self):
+        pass
+
+    # ------------------------------------------------------------------ search
+    def _filter_offsets(self, filter: Optional[dict]):
+        if not filter:
+            return None
+        return np.asarray(_filter_select(self._tags, filter), dtype=np.int64)
+
+    def _search_arrays(self, query_np, filter, limit):
+        self._sanity_check(query_np)
+        indices = self._filter_offsets(filter)
+        if indices is not None and len(indices) == 0:
+            B = query_np.shape[0]
+            return np.full((B, 0), np.inf, np.float32), np.full((B, 0), -1, np.int64)
+        n_avail = self.index_size if indices is None else len(indices)
+        k = min(int(limit), max(n_avail, 0))  # container.py:118-120  limit=min(limit, cell_size)
+        if k <= 0:
+            B = query_np.shape[0]
+            return np.full((B, 0), np.inf, np.float32), np.full((B, 0), -1, np.int64)
+        d, i = self.vec_index(0).search_batch(np.ascontiguousarray(query_np, dtype=np.float32), limit=k, indices=indices)
+        return d, i
+
+    def search(self, docs, filter: Optional[dict] = None, limit: int = 10, include_metadata: bool = True, **kwargs):
+        """index.py:334-359: attaches ``doc.matches`` in place; one batched GPU launch for all docs."""
+        if not self.is_trained:
+            raise RuntimeError('The indexer is not trained, cannot add new documents')
+        query_np = to_numpy_array(docs.embeddings)
+        match_dists, match_docs = self.search_by_vectors(query_np, filter=filter, limit=limit, include_metadata=include_metadata)
+        for doc, matches in zip(docs, match_docs):
+            doc.matches = matches
+
+    def search_by_vectors(self, query_np, filter: Optional[dict] = None, limit: int = 10, include_metadata: bool = True):
+        """index.py:361-387 -> CellContainer.search_cells (container.py:201-235)."""
+        d, i = self._search_arrays(query_np, filter, limit)
+        name = self.metric.name.lower()
+        topk_dists, topk_docs = [], []
+        for b in range(d.shape[0]):
+            keep = i[b] >= 0
+            dists = d[b][keep]
+            match_docs = DocumentArray()
+            for dist, off in zip(dists, i[b][keep]):
+                doc_id = self._offset2id[int(off)]
+                if include_metadata and doc_id in self._docs:
+                    src = self._docs[doc_id]
+                    doc = Document(id=doc_id, embedding=getattr(src, 'embedding', None), tags=dict(getattr(src, 'tags', {}) or {}))
+                else:
+                    doc = Document(id=doc_id)
+                doc.scores[name].value = dist
+                match_docs.append(doc)
+            topk_dists.append(dists)
+            topk_docs.append(match_docs)
+        return topk_dists, topk_docs
+
+    def search_numpy(self, query_np, filter: Dict = {}, limit: int = 10, **kwargs):
+        """index.py:485-522: (list of dists[k], list of doc-id arrays).  Ids are returned as the
+        stored document ids converted with ``int`` like container.py:260."""
+        if not self.is_trained:
+            raise RuntimeError('The indexer is not trained, cannot add new documents')
+        d, i = self._search_arrays(query_np, filter, limit)
+        dists, ids = [], []
+        for b in range(d.shape[0]):
+            keep = i[b] >= 0
+            dists.append(d[b][keep])
+            ids.append(np.array([int(self._offset2id[int(o)]) for o in i[b][keep]], dtype=int))
+        return dists, ids
+
+    def get_doc_by_id(self, doc_id: str):
+        return self._docs.get(doc_id)
+
+    # ------------------------------------------------------------------ codec passthrough (index.py:552-572)
+    def encode(self, x):
+        self._sanity_check(x)
+        return self._pq_codec.encode(x)
+
+    def decode(self, x):
+        assert len(x.shape) == 2
+        assert x.shape[1] == self.n_subvectors
+        return self._pq_codec.decode(x)

@@ -1,0 +1,241 @@
+"""Functional wrappers over the C ABI on torch device tensors.
+
+Every function takes/returns ``torch`` tensors living on the current HIP device and launches the
+hand-written gfx950 kernels of ``libannlite_hip.so`` on torch's current stream.  No function here
+computes anything on the CPU; without a GPU they raise ``RuntimeError`` (``_capi.require_gpu``).
+"""
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import (CODES_PLAIN, CODES_SKEWED, LAYOUT_BMK, LAYOUT_TILED, LUT_IP, LUT_IPDIST, LUT_L2,
+                    check, lib, scan_plan, stream_ptr)
+
+_CODE_TORCH = {1: torch.uint8, 2: torch.int16, 4: torch.int32}  # torch has no uint16/32 arithmetic; bits are what matter
+
+
+def device() -> torch.device:
+    _capi.require_gpu()
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def to_dev(a, dtype=None) -> torch.Tensor:
+    """numpy / torch (any device) -> contiguous tensor on the current HIP device."""
+    dev = device()
+    if isinstance(a, np.ndarray):
+        if a.dtype == np.uint16:
+            a = a.view(np.int16)
+        elif a.dtype == np.uint32:
+            a = a.view(np.int32)
+        elif a.dtype == np.uint64:
+            a = a.view(np.int64)
+        t = torch.from_numpy(np.ascontiguousarray(a))
+    else:
+        t = a
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.to(dev, non_blocking=True).contiguous()
+
+
+def code_bytes_of(t: torch.Tensor) -> int:
+    return t.element_size()
+
+
+def codes_to_numpy(t: torch.Tensor) -> np.ndarray:
+    a = t.cpu().numpy()
+    return {1: a, 2: a.view(np.uint16), 4: a.view(np.uint32)}[a.dtype.itemsize] if a.dtype.kind == 'i' else a
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------------------------------------- LUT
+def lut_build(queries: torch.Tensor, codebooks: torch.Tensor, kind: int, layout: int = LAYOUT_BMK,
+              qi: int = 4) -> torch.Tensor:
+    """f32 [B,D] x f32 [M,Ks,dsub] -> LUT.  BMK: [B,M,Ks]; TILED: flat padded buffer (see header)."""
+    assert queries.dtype == torch.float32 and codebooks.dtype == torch.float32
+    assert queries.ndim == 2 and codebooks.ndim == 3
+    B, D = queries.shape
+    M, Ks, dsub = codebooks.shape
+    assert D == M * dsub, 'input dimension must be Ds * M'
+    if layout == LAYOUT_BMK:
+        out = torch.empty((B, M, Ks), dtype=torch.float32, device=queries.device)
+    else:
+        out = torch.empty((((B + 15) // 16) * 16 * M * Ks,), dtype=torch.float32, device=queries.device)
+    check(lib().annlite_lut_build(kind, queries.data_ptr(), B, D, codebooks.data_ptr(), M, Ks, out.data_ptr(),
+                                  layout, qi, stream_ptr()), 'lut_build')
+    return out
+
+
+def lut_retile(lut_bmk: torch.Tensor, qi: int) -> torch.Tensor:
+    B, M, Ks = lut_bmk.shape
+    out = torch.empty((((B + 15) // 16) * 16 * M * Ks,), dtype=torch.float32, device=lut_bmk.device)
+    check(lib().annlite_lut_retile(lut_bmk.data_ptr(), B, M, Ks, out.data_ptr(), qi, stream_ptr()), 'lut_retile')
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- ADC
+def adc_dist(adtable: torch.Tensor, codes: torch.Tensor) -> torch.Tensor:
+    """pq_bind.dist_pqcodes_to_codebooks on device: f32 [M,Ks], codes [N,M] -> f32 [N]."""
+    assert adtable.ndim == 2 and codes.ndim == 2 and adtable.dtype == torch.float32
+    M, Ks = adtable.shape
+    N = codes.shape[0]
+    assert codes.shape[1] == M
+    out = torch.empty((N,), dtype=torch.float32, device=codes.device)
+    check(lib().annlite_adc_dist(adtable.data_ptr(), M, Ks, codes.data_ptr(), code_bytes_of(codes), N,
+                                 out.data_ptr(), stream_ptr()), 'adc_dist')
+    return out
+
+
+def adc_gather(lut_bmk: torch.Tensor, codes: torch.Tensor, cand: torch.Tensor) -> torch.Tensor:
+    B, M, Ks = lut_bmk.shape
+    assert cand.dtype == torch.int64 and cand.shape[0] == B
+    R = cand.shape[1]
+    out = torch.empty((B, R), dtype=torch.float32, device=codes.device)
+    check(lib().annlite_adc_gather(lut_bmk.data_ptr(), B, M, Ks, codes.data_ptr(), code_bytes_of(codes),
+                                   codes.shape[0], cand.data_ptr(), R, out.data_ptr(), stream_ptr()), 'adc_gather')
+    return out
+
+
+class ScanWorkspace:
+    """Re-usable device scratch for adc_scan_topk (avoids an allocation per search call)."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, nbytes: int, dev) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != dev:
+            self.buf = torch.empty((max(nbytes, 8),), dtype=torch.uint8, device=dev)
+        return self.buf
+
+
+def adc_scan_topk(codes: torch.Tensor, lut: torch.Tensor, B: int, k: int, M: int, Ks: int,
+                  valid_bits: Optional[torch.Tensor] = None, row_base: int = 0, n_rows: Optional[int] = None,
+                  codes_layout: int = CODES_PLAIN, workspace: Optional[ScanWorkspace] = None,
+                  out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Batched flat ADC scan + exact top-k.  ``lut`` must be in the plan's layout (TILED when
+    ``scan_plan(...).fast`` else BMK).  Returns (f32 [B,k], i64 [B,k]) ascending by (dist, id)."""
+    N = codes.shape[0] if n_rows is None else n_rows
+    cb = code_bytes_of(codes)
+    plan = scan_plan(N, M, Ks, cb, B, k)
+    dev = codes.device
+    ws = (workspace or ScanWorkspace()).get(int(plan.workspace_bytes), dev)
+    if out is None:
+        od = torch.empty((B, k), dtype=torch.float32, device=dev)
+        oi = torch.empty((B, k), dtype=torch.int64, device=dev)
+    else:
+        od, oi = out
+    check(lib().annlite_adc_scan_topk(codes.data_ptr(), cb, codes_layout, N, M, Ks, _ptr(valid_bits), lut.data_ptr(), B, k,
+                                      row_base, od.data_ptr(), oi.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      stream_ptr()), 'adc_scan_topk')
+    return od, oi
+
+
+def adc_scan_candidates(codes: torch.Tensor, lut: torch.Tensor, B: int, k: int, M: int, Ks: int,
+                        valid_bits: Optional[torch.Tensor] = None, row_base: int = 0, n_rows: Optional[int] = None,
+                        codes_layout: int = CODES_PLAIN, workspace: Optional[ScanWorkspace] = None
+                        ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Unmerged per-slice top-k lists: (f32 [B, n_slices*k], i64 [B, n_slices*k]); superset of the top-k."""
+    N = codes.shape[0] if n_rows is None else n_rows
+    cb = code_bytes_of(codes)
+    plan = scan_plan(N, M, Ks, cb, B, k)
+    dev = codes.device
+    ws = (workspace or ScanWorkspace()).get(int(plan.workspace_bytes), dev)
+    R = plan.n_slices * k
+    od = torch.empty((B, R), dtype=torch.float32, device=dev)
+    oi = torch.empty((B, R), dtype=torch.int64, device=dev)
+    check(lib().annlite_adc_scan_candidates(codes.data_ptr(), cb, codes_layout, N, M, Ks, _ptr(valid_bits),
+                                            lut.data_ptr(), B, k, row_base, od.data_ptr(), oi.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), stream_ptr()), 'adc_scan_candidates')
+    return od, oi
+
+
+def topk_merge(dist: torch.Tensor, ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[G,B,k] x2 -> [B,k] x2 (the merge after the RCCL all-gather of per-shard top-k)."""
+    G, B, k = dist.shape
+    od = torch.empty((B, k), dtype=torch.float32, device=dist.device)
+    oi = torch.empty((B, k), dtype=torch.int64, device=dist.device)
+    check(lib().annlite_topk_merge(dist.data_ptr(), ids.data_ptr(), G, B, k, od.data_ptr(), oi.data_ptr(),
+                                   stream_ptr()), 'topk_merge')
+    return od, oi
+
+
+def topk_rows(values: torch.Tensor, k: int, id_base: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    B, N = values.shape
+    od = torch.empty((B, k), dtype=torch.float32, device=values.device)
+    oi = torch.empty((B, k), dtype=torch.int64, device=values.device)
+    check(lib().annlite_topk_rows(values.data_ptr(), B, N, k, id_base, od.data_ptr(), oi.data_ptr(), stream_ptr()),
+          'topk_rows')
+    return od, oi
+
+
+def codes_skew(codes: torch.Tensor, ids: Optional[torch.Tensor] = None, id_base: int = 0,
+               out: Optional[torch.Tensor] = None, inverse: bool = False) -> torch.Tensor:
+    """PLAIN rows -> SKEWED table rows (scatter by ids) or back (inverse gather)."""
+    assert codes.dtype == torch.uint8
+    if inverse:
+        n = ids.shape[0] if ids is not None else codes.shape[0]
+        M = codes.shape[1]
+        out = torch.empty((n, M), dtype=torch.uint8, device=codes.device) if out is None else out
+    else:
+        n, M = codes.shape
+        out = torch.empty_like(codes) if out is None else out
+    check(lib().annlite_codes_skew(codes.data_ptr(), n, M, _ptr(ids), id_base, out.data_ptr(), int(inverse),
+                                   stream_ptr()), 'codes_skew')
+    return out
+
+
+# -------------------------------------------------------------------------------------------- codec
+def pq_encode(x: torch.Tensor, codebooks: torch.Tensor) -> torch.Tensor:
+    N, D = x.shape
+    M, Ks, dsub = codebooks.shape
+    assert D == M * dsub, 'input dimension must be Ds * M'
+    cb = 1 if Ks <= 256 else (2 if Ks <= 65536 else 4)
+    out = torch.empty((N, M), dtype=_CODE_TORCH[cb], device=x.device)
+    check(lib().annlite_pq_encode(x.data_ptr(), N, D, codebooks.data_ptr(), M, Ks, out.data_ptr(), cb, stream_ptr()),
+          'pq_encode')
+    return out
+
+
+def pq_decode(codes: torch.Tensor, codebooks: torch.Tensor) -> torch.Tensor:
+    N, M = codes.shape
+    Mc, Ks, dsub = codebooks.shape
+    assert M == Mc
+    out = torch.empty((N, M * dsub), dtype=torch.float32, device=codes.device)
+    check(lib().annlite_pq_decode(codes.data_ptr(), code_bytes_of(codes), N, M, Ks, codebooks.data_ptr(), dsub,
+                                  out.data_ptr(), stream_ptr()), 'pq_decode')
+    return out
+
+
+def l2_normalize(x: torch.Tensor) -> torch.Tensor:
+    N, D = x.shape
+    out = torch.empty_like(x)
+    check(lib().annlite_l2_normalize(x.data_ptr(), N, D, out.data_ptr(), stream_ptr()), 'l2_normalize')
+    return out
+
+
+def kmeans_assign_accumulate(x, codebooks, sums, counts, inertia=None):
+    N, D = x.shape
+    M, Ks, dsub = codebooks.shape
+    check(lib().annlite_kmeans_assign_accumulate(x.data_ptr(), N, D, codebooks.data_ptr(), M, Ks, sums.data_ptr(),
+                                                 counts.data_ptr(), _ptr(inertia), stream_ptr()),
+          'kmeans_assign_accumulate')
+
+
+def kmeans_update(sums, counts, codebooks):
+    M, Ks, dsub = codebooks.shape
+    check(lib().annlite_kmeans_update(sums.data_ptr(), counts.data_ptr(), M, Ks, dsub, codebooks.data_ptr(),
+                                      stream_ptr()), 'kmeans_update')
+
+
+def exact_gather_dist(metric: int, queries: torch.Tensor, vectors: torch.Tensor, cand: torch.Tensor) -> torch.Tensor:
+    B, D = queries.shape
+    N = vectors.shape[0]
+    R = cand.shape[1]
+    out = torch.empty((B, R), dtype=torch.float32, device=queries.device)
+    check(lib().annlite_exact_gather_dist(int(metric), queries.data_ptr(), B, D, vectors.data_ptr(), N,
+                                          cand.data_ptr(), R, out.data_ptr(), stream_ptr()), 'exact_gather_dist')
+    return out

@@ -1,0 +1,93 @@
+"""Row-sharded PQ/ADC search across the GPUs of one node: one process per GPU
+(``torch.distributed``, backend "nccl" == RCCL over xGMI), each rank scans its own contiguous slice
+of the code table and keeps a local top-k; ONE all-gather of ``[B, k]`` (f32 distance, i64 global
+row id) per batch, then every rank merges the ``G`` lists with the same (distance, id) order rule.
+
+The reference has no collective of any kind; its only multi-worker mode is Jina ``shards=N`` with
+``polling ALL`` and a gateway-side merge (tests/executor/test_executor.py:326-350), whose per-cell
+analogue inside one process is the hstack + argsort merge of annlite/container.py:130-138.  The
+exchange is 12 B * B * k per rank (120 KB at B=1024, k=10): latency-bound, so a single
+``all_gather_into_tensor`` per tensor is used and nothing is bucketed.
+
+The scan and the merge are injected callables so that the partition / gather logic can be covered
+by world_size-2 ``gloo`` tests on CPU (tests/test_sharded_gloo.py) with the oracle standing in for
+the kernels; the product wiring (``ShardedPQIndex``) always uses the HIP kernels.
+"""
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_total: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous row ranges: rank g holds rows [g*ceil(N/G), min(N, (g+1)*ceil(N/G)))
+    (global id = row_base + local row; row ids are insertion offsets, storage/table.py:251-257)."""
+    per = (n_total + world_size - 1) // world_size
+    lo = min(n_total, rank * per)
+    hi = min(n_total, lo + per)
+    return lo, hi
+
+
+def gather_and_merge(local_d: torch.Tensor, local_i: torch.Tensor, merge_fn: Callable,
+                     group: Optional[dist.ProcessGroup] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """all-gather the per-shard top-k lists and merge them; every rank returns the global result."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local_d, local_i
+    G = dist.get_world_size(group)
+    B, k = local_d.shape
+    # concatenation form ([G*B, k]): accepted by both RCCL and gloo; viewed as [G, B, k] for the merge
+    all_d = torch.empty((G * B, k), dtype=local_d.dtype, device=local_d.device)
+    all_i = torch.empty((G * B, k), dtype=local_i.dtype, device=local_i.device)
+    dist.all_gather_into_tensor(all_d, local_d.contiguous(), group=group)
+    dist.all_gather_into_tensor(all_i, local_i.contiguous(), group=group)
+    return merge_fn(all_d.view(G, B, k), all_i.view(G, B, k))
+
+
+class ShardedSearcher:
+    """``scan_fn(queries, k) -> (dist [B,k], global ids [B,k])`` over the local shard, then the
+    gather + ``merge_fn([G,B,k], [G,B,k]) -> ([B,k], [B,k])``."""
+
+    def __init__(self, scan_fn: Callable, merge_fn: Callable, group: Optional[dist.ProcessGroup] = None):
+        self.scan_fn = scan_fn
+        self.merge_fn = merge_fn
+        self.group = group
+
+    def search(self, queries, k: int):
+        d, i = self.scan_fn(queries, k)
+        return gather_and_merge(d, i, self.merge_fn, self.group)
+
+
+class ShardedPQIndex:
+    """Product wiring: a ``PQFlatGpuIndex`` per rank holding rows [row_base, row_base + n_local) of
+    the global table; ``search_batch`` returns global row ids on every rank."""
+
+    def __init__(self, index, row_base: int, group: Optional[dist.ProcessGroup] = None):
+        from . import ops
+
+        self.index = index
+        self.row_base = int(row_base)
+        self.group = group
+        self._merge = ops.topk_merge
+
+    def _scan(self, queries, k):
+        d, i = self.index.search_batch(queries, limit=k)
+        i = torch.where(i >= 0, i + self.row_base, i)
+        return d, i
+
+    def search_batch(self, queries: torch.Tensor, limit: int = 10):
+        return ShardedSearcher(self._scan, self._merge, self.group).search(queries, limit)
+
+
+def numpy_merge(all_d: torch.Tensor, all_i: torch.Tensor):
+    """Reference merge used by the CPU (gloo) tests only: lexsort by (distance, id), -1 ids last."""
+    G, B, k = all_d.shape
+    d = all_d.permute(1, 0, 2).reshape(B, G * k).cpu().numpy()
+    i = all_i.permute(1, 0, 2).reshape(B, G * k).cpu().numpy()
+    od = np.empty((B, k), dtype=d.dtype)
+    oi = np.empty((B, k), dtype=i.dtype)
+    for b in range(B):
+        key_i = np.where(i[b] < 0, np.iinfo(np.int64).max, i[b])
+        order = np.lexsort((key_i, d[b]))[:k]
+        od[b], oi[b] = d[b][order], i[b][order]
+    return torch.from_numpy(od), torch.from_numpy(oi)

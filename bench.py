@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec of the PQ/ADC search hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+             --master-port P bench.py --gpus N --steps K --warmup W)
+
+Workload (BASELINE.json `metric`: "queries/sec + recall@10, 10M x 128-dim PQ-m=16, batch-1k,
+1/2/4/8 GPU"): 10M synthetic float32 vectors of dimension 128 (low-rank mixture, SURVEY.md
+section 8d), PQ m=16 ks=256 trained on the first 20 480 rows, squared-L2 tables, batch of 1024
+queries, k=10.  The code table is row-sharded over the N ranks (STRONG scaling: the 10M rows are
+fixed), every rank scans its shard, one RCCL all-gather of [B,k] + a merge kernel gives every rank
+the global top-k.
+
+One "step" = the whole hot path for one batch: LUT build (tiled layout) -> ADC scan + per-shard
+top-k -> (N>1: all-gather + merge).  Inputs (queries, codebooks, codes) are resident in HBM before
+the timed region.  Prints ONE JSON line on rank 0 with the driver's contract fields plus
+`roofline` (dominant kernel = adc_scan_fast_kernel, algorithmic bytes B*N_local*M per launch over
+its HIP-event duration, vs the 8 TB/s HBM peak -- the kernel actually runs out of LDS)
+and `cpu_baseline` (the C oracle, single thread = the reference's execution model, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--rows', type=int, default=10_000_000)
+    p.add_argument('--dim', type=int, default=128)
+    p.add_argument('--m', type=int, default=16)
+    p.add_argument('--ks', type=int, default=256)
+    p.add_argument('--batch', type=int, default=1024)
+    p.add_argument('--k', type=int, default=10)
+    p.add_argument('--train-rows', type=int, default=20480)
+    p.add_argument('--train-iters', type=int, default=20)
+    p.add_argument('--recall-queries', type=int, default=128, help='queries used for recall@10 (0 = skip)')
+    p.add_argument('--cpu-queries', type=int, default=4, help='queries of the bounded CPU-baseline sample (0 = skip)')
+    p.add_argument('--layout', choices=['skewed', 'plain'], default='skewed')
+    p.add_argument('--no-rerank', action='store_true', help='skip the (untimed-in-value) exact re-rank leg')
+    return p.parse_args()
+
+
+def gen_chunk(chunk: int, rows: int, D: int, A: torch.Tensor, dev) -> torch.Tensor:
+    """x = z.A + 0.05 eps, z ~ N(0, I_r): identical for any number of ranks (seeded per chunk)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + chunk)
+    z = torch.randn((rows, A.shape[0]), generator=g, device=dev)
+    e = torch.randn((rows, D), generator=g, device=dev)
+    return (z @ A + 0.05 * e).contiguous()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from annlite_amd import Metric, PQCodec, _capi, ops
+    from annlite_amd.core.index.pq_flat_gpu import PQFlatGpuIndex
+    from annlite_amd.sharded import ShardedPQIndex, shard_range
+
+    N, D, M, Ks, B, k = args.rows, args.dim, args.m, args.ks, args.batch, args.k
+    r_lat = 16 if D <= 128 else 64
+    gA = torch.Generator(device=dev)
+    gA.manual_seed(99)
+    A = torch.randn((r_lat, D), generator=gA, device=dev)
+
+    # ---- train the codec on the first rows (rank 0), broadcast the codebooks ----------------------
+    codec = PQCodec(dim=D, n_subvectors=M, n_clusters=Ks, metric=Metric.EUCLIDEAN, n_init=1)
+    codec.seed = 7
+    CH = 250_000
+    t0 = time.time()
+    if rank == 0:
+        xt = gen_chunk(0, CH, D, A, dev)[: args.train_rows]
+        codec.fit(xt, iter=args.train_iters)
+        cb = codec.codebooks_dev.clone()
+    else:
+        cb = torch.empty((M, Ks, D // M), dtype=torch.float32, device=dev)
+    if world > 1:
+        dist.broadcast(cb, src=0)
+    codec.set_codebooks(cb)
+    train_s = time.time() - t0
+
+    # ---- build this rank's shard --------------------------------------------------------------------
+    lo, hi = shard_range(N, world, rank)
+    n_local = hi - lo
+    keep_vectors = not args.no_rerank
+    index = PQFlatGpuIndex(dim=D, metric=Metric.EUCLIDEAN, pq_codec=codec, initial_size=max(n_local, 64),
+                           rerank=keep_vectors, skewed=(args.layout == 'skewed'))
+    t0 = time.time()
+    c0, c1 = lo // CH, (hi + CH - 1) // CH
+    for c in range(c0, c1):
+        rows = min(CH, N - c * CH)
+        x = gen_chunk(c, rows, D, A, dev)
+        a, b = max(lo, c * CH), min(hi, c * CH + rows)
+        xs = x[a - c * CH: b - c * CH]
+        index.add_with_ids(xs, torch.arange(a - lo, b - lo, device=dev, dtype=torch.int64))
+    torch.cuda.synchronize()
+    index_s = time.time() - t0
+    sharded = ShardedPQIndex(index, row_base=lo)
+
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(4321)
+    zq = torch.randn((B, r_lat), generator=gq, device=dev)
+    eq = torch.randn((B, D), generator=gq, device=dev)
+    queries = (zq @ A + 0.05 * eq).contiguous()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # the product path is plain ADC (no re-rank): that is the reference's PQ search semantics
+    index.rerank = False
+
+    def step():
+        return sharded.search_batch(queries, limit=k)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    qps = B * args.steps / elapsed
+
+    # ---- roofline leg: HIP events around the dominant kernel, live, over the same steps ------------
+    _capi.profile_enable(True)
+    kms = []
+    for _ in range(max(3, min(args.steps, 10))):
+        step()
+        kms.append(_capi.profile_last_scan_ms())
+    _capi.profile_enable(False)
+    kernel_ms = float(np.mean(kms))
+    scan_bytes = float(B) * n_local * M  # algorithmic code bytes consumed per launch
+    achieved = scan_bytes / (kernel_ms * 1e-3) / 1e9
+    lookups_per_s = float(B) * n_local * M / (kernel_ms * 1e-3)
+
+    # ---- recall@10 vs exact brute force (subset of the queries), ADC-only and with re-rank ---------
+    recall_adc = recall_rr = None
+    rr_qps = None
+    nq = min(args.recall_queries, B)
+    if nq > 0:
+        qs = queries[:nq]
+        best_d = torch.full((nq, k), float('inf'), device=dev)
+        best_i = torch.full((nq, k), -1, dtype=torch.int64, device=dev)
+        qn = (qs * qs).sum(1)[:, None]
+        for c in range(c0, c1):
+            rows = min(CH, N - c * CH)
+            x = gen_chunk(c, rows, D, A, dev)
+            a, b = max(lo, c * CH), min(hi, c * CH + rows)
+            xs = x[a - c * CH: b - c * CH]
+            dd = qn + (xs * xs).sum(1)[None, :] - 2.0 * (qs @ xs.T)
+            cd, ci = torch.topk(dd, k, dim=1, largest=False)
+            md = torch.cat([best_d, cd], 1)
+            mi = torch.cat([best_i, ci + a], 1)
+            o = torch.argsort(md, dim=1)[:, :k]
+            best_d, best_i = torch.gather(md, 1, o), torch.gather(mi, 1, o)
+        if world > 1:
+            gd = [torch.empty_like(best_d) for _ in range(world)]
+            gi = [torch.empty_like(best_i) for _ in range(world)]
+            dist.all_gather(gd, best_d)
+            dist.all_gather(gi, best_i)
+            md, mi = torch.cat(gd, 1), torch.cat(gi, 1)
+            o = torch.argsort(md, dim=1)[:, :k]
+            best_i = torch.gather(mi, 1, o)
+        truth = best_i.cpu().numpy()
+        got = out[1][:nq].cpu().numpy()
+        recall_adc = float(np.mean([len(set(got[b]) & set(truth[b])) / k for b in range(nq)]))
+        if keep_vectors:
+            index.rerank = True
+            for _ in range(2):
+                rr = sharded.search_batch(queries, limit=k)
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            n_rr = max(3, args.steps // 4)
+            for _ in range(n_rr):
+                rr = sharded.search_batch(queries, limit=k)
+            torch.cuda.synchronize()
+            barrier()
+            rr_el = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([rr_el], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                rr_el = float(t.item())
+            rr_qps = B * n_rr / rr_el
+            got = rr[1][:nq].cpu().numpy()
+            recall_rr = float(np.mean([len(set(got[b]) & set(truth[b])) / k for b in range(nq)]))
+            index.rerank = False
+
+    # ---- CPU baseline: the oracle (C port of the reference loops) on a bounded sample, rank 0, N=1 --
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_queries > 0:
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        import pq_oracle
+
+        nqc = min(args.cpu_queries, B)
+        codes_np = ops.codes_to_numpy(index._plain_codes(n_local))
+        q_np = queries[:nqc].cpu().numpy()
+        cb_np = codec.codebooks
+        t0 = time.perf_counter()
+        lut = pq_oracle.batch_precompute_adc_table_c(q_np, D // M, Ks, cb_np, threads=1)
+        cd, ci = pq_oracle.adc_search_c(lut, codes_np, k, threads=1)
+        cpu_s = time.perf_counter() - t0
+        gd, gi = out[0][:nqc].cpu().numpy(), out[1][:nqc].cpu().numpy()
+        parity = bool(np.array_equal(np.sqrt(cd), gd) and np.array_equal(ci, gi))
+        threads = pq_oracle.max_threads()
+        t0 = time.perf_counter()
+        nq_all = min(B, max(nqc, threads * 2))
+        lut2 = pq_oracle.batch_precompute_adc_table_c(queries[:nq_all].cpu().numpy(), D // M, Ks, cb_np, threads=threads)
+        pq_oracle.adc_search_c(lut2, codes_np, k, threads=threads)
+        cpu_all_s = time.perf_counter() - t0
+        cpu = {
+            'value': nqc / cpu_s, 'unit': 'queries/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{nqc} queries x {n_local} rows (LUT + flat ADC scan + top-{k}), single thread = the reference execution model',
+            'all_cores': {'value': nq_all / cpu_all_s, 'cores': threads, 'sample': f'{nq_all} queries, OpenMP over queries'},
+            'gpu_matches_cpu_bit_exact': parity,
+        }
+
+    if rank == 0:
+        rec = {
+            'metric': 'queries/sec', 'value': qps, 'unit': 'queries/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {
+                'workload': f'{N} x {D}-dim float32, PQ m={M} ks={Ks}, L2, batch {B}, k={k}, exhaustive ADC scan + exact top-k',
+                'rows_total': N, 'rows_per_gpu': n_local, 'batch': B, 'k': k, 'parallelism': f'row-shard x{world}',
+                'codes_layout': args.layout,
+            },
+            'recall_at_10': recall_adc,
+            'rerank': None if recall_rr is None else {'recall_at_10': recall_rr, 'value': rr_qps, 'unit': 'queries/s',
+                                                       'candidates_per_query': 'n_slices*64 per shard'},
+            'roofline': {
+                'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                'traffic': None, 'kernel': 'adc_scan_fast_kernel', 'kernel_ms': kernel_ms,
+                'algorithmic_bytes_per_launch': scan_bytes, 'lds_lookups_per_s': lookups_per_s,
+            },
+            'cpu_baseline': cpu,
+            'setup': {'train_s': train_s, 'index_s': index_s},
+        }
+        print(json.dumps(rec))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

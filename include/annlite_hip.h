@@ -1,0 +1,227 @@
+/*
+ * annlite_hip.h -- C ABI of libannlite_hip.so: the MI355X (gfx950) implementation of annlite's
+ * PQ codec + asymmetric-distance (ADC) scan hot path.
+ *
+ * This is the drop-in boundary.  Every entry point is what a binding for
+ * the reference's `annlite.pq_bind` operator seam / `PQCodec` / index plugin would call; the
+ * reference interface each one replaces is cited as (file:line) relative to jina-ai/annlite
+ * v0.5.11.  The reference-side ctypes stub a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no exceptions across the boundary: every function returns an int status
+ *     (ANNLITE_OK == 0); annlite_hip_last_error() gives a thread-local message.
+ *   - all `*_dev` pointers are DEVICE pointers (HBM) owned by the caller (e.g. torch tensors'
+ *     data_ptr()); outputs are caller-allocated.  No torch / HIP types in the signatures:
+ *     `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - all launches are asynchronous on `stream`; the caller synchronises.
+ *   - no shared mutable state inside the library: calls on different streams / host threads are
+ *     independent (the reference's pq_bind is serial under the GIL, hnsw_bind attaches the LUT to a
+ *     shared space object and is not re-entrant: include/hnswlib/space_pq.h:55-64).
+ *   - there is NO CPU fallback in this library: if no gfx950 device is present the launches fail
+ *     with ANNLITE_ERR_HIP.
+ *
+ * Distances are float32, ADC sums are accumulated in float32 in ascending sub-space order, the LUT
+ * entries are sequential fused multiply-add chains -- bit-identical to the reference built with its
+ * own flags (setup.py:125-144) -- see DESIGN.md "Numerics".
+ */
+#ifndef ANNLITE_HIP_H_
+#define ANNLITE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANNLITE_HIP_ABI_VERSION 1
+
+/* exported symbols (the library is built with -fvisibility=hidden) */
+#define ANNLITE_API __attribute__((visibility("default")))
+
+/* status codes */
+#define ANNLITE_OK 0
+#define ANNLITE_ERR_INVALID 1     /* bad argument (shape, null pointer, k out of range ...)        */
+#define ANNLITE_ERR_UNSUPPORTED 2 /* valid request this build has no kernel for                    */
+#define ANNLITE_ERR_HIP 3         /* HIP runtime error (no device, launch failure ...)             */
+#define ANNLITE_ERR_WORKSPACE 4   /* workspace too small: call the matching *_workspace_bytes()    */
+
+/* metric ids == annlite/enums.py:25-28 (Metric.EUCLIDEAN / INNER_PRODUCT / COSINE) */
+#define ANNLITE_METRIC_EUCLIDEAN 1
+#define ANNLITE_METRIC_INNER_PRODUCT 2
+#define ANNLITE_METRIC_COSINE 3
+
+/* look-up-table kinds (what one table entry holds) */
+#define ANNLITE_LUT_L2 1     /* sum_j (C[m,k,j]-q[j])^2    bindings/pq_bindings.pyx:149-210 (and 85-145) */
+#define ANNLITE_LUT_IP 2     /* sum_j  C[m,k,j]*q[j]        bindings/pq_bindings.pyx:214-274              */
+#define ANNLITE_LUT_IPDIST 3 /* float32(1/Ks) - LUT_IP      annlite/core/codec/pq.py:316-322              */
+
+/* code-table layouts in HBM */
+#define ANNLITE_CODES_PLAIN 0  /* [N][M] row-major, byte m of row n = code of sub-space m (the reference's
+                                  PQIndex._data / HNSW level-0 record layout)                              */
+#define ANNLITE_CODES_SKEWED 1 /* [N][M], byte j of row n = code of sub-space (j + n) mod M: every row is
+                                  pre-rotated by its own row id so that the scan kernel's lane l (row n,
+                                  n mod M == l mod M) reads sub-space (l + t) mod M at byte t with no
+                                  in-register rotation (annlite_codes_skew converts; uint8 codes only)     */
+
+/* look-up-table layouts in HBM */
+#define ANNLITE_LAYOUT_BMK 0 /* [B][M][Ks]  -- the reference's layout (what get_dist_mat returns)       */
+#define ANNLITE_LAYOUT_TILED 1 /* [ceil16(B)/QI][Ks][M][QI] -- scan layout (B padded to 16), QI from the plan */
+
+ANNLITE_API int annlite_hip_abi_version(void);
+ANNLITE_API const char *annlite_hip_last_error(void);
+/* number of visible HIP devices and the gfx arch name of device `dev` (e.g. "gfx950:sramecc+:xnack-") */
+ANNLITE_API int annlite_hip_device_count(int *count);
+ANNLITE_API int annlite_hip_device_arch(int dev, char *buf, size_t buf_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Scan plan: how the ADC scan kernel wants its inputs for a (M, Ks, code width, k) problem.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct annlite_scan_plan {
+    int32_t fast;          /* 1: LDS-resident skewed-gather kernel, 0: generic (LUT read through L2)  */
+    int32_t qi;            /* queries interleaved per LUT entry in the tiled layout (4, 2 or 1)       */
+    int32_t qt;            /* queries per workgroup (multiple of qi)                                  */
+    int32_t waves;         /* waves per workgroup                                                     */
+    int32_t n_slices;      /* row slices the table is cut into (>= 8: one per XCD)                    */
+    int32_t max_k;         /* largest k this plan supports                                            */
+    int64_t lut_floats;    /* number of floats of a TILED LUT buffer for B queries                    */
+    int64_t workspace_bytes; /* scratch needed by annlite_adc_scan_topk()                             */
+} annlite_scan_plan;
+
+ANNLITE_API int annlite_scan_plan_query(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t k,
+                            annlite_scan_plan *plan);
+
+/* ------------------------------------------------------------------------------------------------
+ * LUT construction.
+ * replaces: pq_bind.batch_precompute_adc_table      (bindings/pq_bindings.pyx:149-210)  kind=L2
+ *           pq_bind.batch_precompute_adc_table_ip   (bindings/pq_bindings.pyx:214-274)  kind=IP
+ *           pq_bind.precompute_adc_table            (bindings/pq_bindings.pyx:85-145)   kind=L2, B=1
+ *           PQCodec.get_dist_mat                    (annlite/core/codec/pq.py:293-325)  kind=L2|IPDIST
+ * queries_dev   f32 [B][D]  (already normalised by the caller for COSINE, as pq.py:309-310 does)
+ * codebooks_dev f32 [M][Ks][dsub], dsub = D / M     (PQCodec.get_codebook(), pq.py:231-237)
+ * out_dev       f32, layout BMK: [B][M][Ks];  TILED: plan.lut_floats floats (pad queries zeroed)
+ * `qi` is only read for the TILED layout (take it from annlite_scan_plan_query()).
+ * Numerics: sequential fmaf chain over j, bit-exact vs the reference; the IP kinds run on the
+ * f32 MFMA (v_mfma_f32_16x16x4_f32), which is bitwise that same chain.
+ * ---------------------------------------------------------------------------------------------- */
+ANNLITE_API int annlite_lut_build(int kind, const float *queries_dev, int64_t B, int64_t D,
+                      const float *codebooks_dev, int64_t M, int64_t Ks, float *out_dev, int layout,
+                      int qi, void *stream);
+
+/* re-layout a [B][M][Ks] table (e.g. one the caller computed himself) into the scan layout */
+ANNLITE_API int annlite_lut_retile(const float *lut_bmk_dev, int64_t B, int64_t M, int64_t Ks, float *out_tiled_dev,
+                       int qi, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Flat ADC scan, all distances (the operator seam, one query).
+ * replaces: pq_bind.dist_pqcodes_to_codebooks (bindings/pq_bindings.pyx:52-80) == DistanceTable.adist
+ *           (annlite/core/codec/pq.py:350-368):  out[n] = sum_{m ascending} adtable[m][codes[n][m]]
+ * adtable_dev f32 [M][Ks] ; codes_dev [N][M] of code_bytes (1|2|4) ; out_dev f32 [N]
+ * ---------------------------------------------------------------------------------------------- */
+ANNLITE_API int annlite_adc_dist(const float *adtable_dev, int64_t M, int64_t Ks, const void *codes_dev,
+                     int code_bytes, int64_t N, float *out_dev, void *stream);
+
+/* Gathered ADC: out[b][r] = ADC distance of row cand[b][r] under query b's table (cand < 0 -> +inf).
+ * replaces: hnswlib::PQLookup (include/hnswlib/space_pq.h:15-37) evaluated over a candidate list --
+ * the "GPU ADC rerank of HNSW candidate lists" of BASELINE config 5.
+ * lut_bmk_dev f32 [B][M][Ks] ; cand_dev i64 [B][R] ; out_dev f32 [B][R] */
+ANNLITE_API int annlite_adc_gather(const float *lut_bmk_dev, int64_t B, int64_t M, int64_t Ks, const void *codes_dev,
+                       int code_bytes, int64_t N, const int64_t *cand_dev, int64_t R, float *out_dev,
+                       void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched flat ADC scan + top-k: the hot path.
+ * replaces, for B queries in ONE launch: PQIndex.search (annlite/core/index/pq_index.py:29-56:
+ * LUT -> adist over the code table -> math.top_k, annlite/math.py:94-120), i.e. the per-query loop
+ * of CellContainer.search_cells (annlite/container.py:214) over the index plugin's .search().
+ *
+ * codes_dev   [N][M] codes, row-major, code_bytes 1 (Ks<=256) or 2; codes_layout PLAIN or SKEWED
+ *             (SKEWED only with the fast plan)
+ * valid_bits  optional u32 bitmap, bit n set = row n may be returned (NULL = all N rows).  Carries
+ *             delete() marks (annlite/core/index/hnsw/index.py:169-171) and the `indices` filter
+ *             argument of search (pq_index.py:42-44).
+ * lut_dev     the tables in plan.layout order: TILED for plan.fast, else BMK
+ * out_dist_dev f32 [B][k], out_id_dev i64 [B][k]: ascending by (distance, row id) -- the fixed
+ *             tie-break -- ids are row_base + row; missing entries (k > #valid rows) are (+inf, -1).
+ * workspace   plan.workspace_bytes of device scratch.
+ * ---------------------------------------------------------------------------------------------- */
+ANNLITE_API int annlite_adc_scan_topk(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M,
+                          int64_t Ks, const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B, int64_t k,
+                          int64_t row_base, float *out_dist_dev, int64_t *out_id_dev,
+                          void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* Same scan, but return the UNMERGED per-slice lists: plan.n_slices * k candidates per query
+ * ([B][n_slices*k], unordered across slices, (+inf,-1) where a slice had fewer rows).  The set is a
+ * superset of the exact top-k; it is the candidate generator of the exact re-rank stage
+ *  -- the reference has no such stage. */
+ANNLITE_API int annlite_adc_scan_candidates(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M,
+                                int64_t Ks, const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B,
+                                int64_t k, int64_t row_base, float *out_dist_dev, int64_t *out_id_dev,
+                                void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* Measurement hooks (bench.py): when enabled on the calling thread, annlite_adc_scan_topk /
+ * _candidates bracket the scan kernel launch -- the dominant kernel -- with HIP events on the
+ * launch stream; annlite_profile_last_scan_ms() waits for the last one and returns its duration. */
+ANNLITE_API int annlite_profile_enable(int on);
+ANNLITE_API int annlite_profile_last_scan_ms(float *ms);
+
+/* Convert between the PLAIN and the SKEWED code-table layout (uint8 codes).
+ * forward (inverse=0): table_out[id][j] = codes_in[i][(j + id) mod M]   -- scatter rows i -> id
+ * inverse (inverse=1): codes_out[i][j]  = table_in[id][(j - id) mod M]  -- gather rows id -> i
+ * id = ids_dev[i] if ids_dev != NULL else id_base + i.  This is the storage step of the index
+ * plugin's add_with_ids (annlite/core/index/pq_index.py:25-27 -> flat_index.py:41-50 `_data[ids] = x`). */
+ANNLITE_API int annlite_codes_skew(const void *in_dev, int64_t N, int64_t M, const int64_t *ids_dev, int64_t id_base,
+                       void *out_dev, int inverse, void *stream);
+
+/* Merge G sorted candidate lists per query into one: in [G][B][k] -> out [B][k], same order rule.
+ * This is the step after the RCCL all-gather of per-shard top-k; the
+ * reference's analogue is the hstack+argsort merge of per-cell results (annlite/container.py:130-138). */
+ANNLITE_API int annlite_topk_merge(const float *dist_dev, const int64_t *id_dev, int64_t G, int64_t B, int64_t k,
+                       float *out_dist_dev, int64_t *out_id_dev, void *stream);
+
+/* Row-wise k smallest of a dense f32 matrix [B][N] -> ([B][k], [B][k]) with the fixed tie-break.
+ * replaces: annlite.math.top_k(values, k, descending=False) (annlite/math.py:94-120). k <= 64. */
+ANNLITE_API int annlite_topk_rows(const float *values_dev, int64_t B, int64_t N, int64_t k, int64_t id_base,
+                      float *out_dist_dev, int64_t *out_id_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Codec.
+ * ---------------------------------------------------------------------------------------------- */
+/* replaces: PQCodec.encode (annlite/core/codec/pq.py:158-177): codes[n][m] = argmin_k |x_sub - C[m,k]|^2,
+ * first minimum wins.  out codes [N][M] of code_bytes (1 if Ks<=256, 2 if Ks<=65536: pq.py:56-60). */
+ANNLITE_API int annlite_pq_encode(const float *x_dev, int64_t N, int64_t D, const float *codebooks_dev, int64_t M,
+                      int64_t Ks, void *out_codes_dev, int code_bytes, void *stream);
+
+/* replaces: PQCodec.decode (annlite/core/codec/pq.py:179-198): gather codewords. out f32 [N][D] */
+ANNLITE_API int annlite_pq_decode(const void *codes_dev, int code_bytes, int64_t N, int64_t M, int64_t Ks,
+                      const float *codebooks_dev, int64_t dsub, float *out_dev, void *stream);
+
+/* replaces: annlite.math.l2_normalize (annlite/math.py:6-18): rows with norm < 10*eps unscaled.
+ * In-place allowed (out_dev == x_dev). */
+ANNLITE_API int annlite_l2_normalize(const float *x_dev, int64_t N, int64_t D, float *out_dev, void *stream);
+
+/* One Lloyd iteration building block for PQCodec.fit (annlite/core/codec/pq.py:89-115, sklearn KMeans
+ * per sub-space): assign every training row to its nearest codeword in every sub-space and accumulate
+ * per-codeword sums/counts.  sums_dev f32 [M][Ks][dsub], counts_dev i32 [M][Ks] (both zeroed by the
+ * caller), inertia_dev f64 [M] (zeroed by caller, may be NULL). */
+ANNLITE_API int annlite_kmeans_assign_accumulate(const float *x_dev, int64_t N, int64_t D, const float *codebooks_dev,
+                                     int64_t M, int64_t Ks, float *sums_dev, int32_t *counts_dev,
+                                     double *inertia_dev, void *stream);
+/* codebooks[m][k] = sums/counts where counts > 0 (empty clusters keep their old centre). */
+ANNLITE_API int annlite_kmeans_update(const float *sums_dev, const int32_t *counts_dev, int64_t M, int64_t Ks,
+                          int64_t dsub, float *codebooks_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Exact re-rank (GPU analogue of FlatIndex.search,
+ * annlite/core/index/flat_index.py:15-39, and hnswlib's space_l2.h/space_ip.h distance functions):
+ * out[b][r] = exact distance between queries[b] and vectors[cand[b][r]] (cand < 0 -> +inf).
+ * metric EUCLIDEAN -> squared L2 ; INNER_PRODUCT / COSINE -> 1 - <q, x> (inputs already normalised
+ * for COSINE).  vectors_dev f32 [N][D]. */
+ANNLITE_API int annlite_exact_gather_dist(int metric, const float *queries_dev, int64_t B, int64_t D,
+                              const float *vectors_dev, int64_t N, const int64_t *cand_dev, int64_t R,
+                              float *out_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANNLITE_HIP_H_ */

@@ -1,0 +1,54 @@
+"""CPU: the C-ABI library loads and exports every symbol include/annlite_hip.h declares (no compute)."""
+import os
+import re
+import subprocess
+
+from conftest import ROOT
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'annlite_hip.h')).read()
+    return sorted(set(re.findall(r'ANNLITE_API\s+(?:const\s+char\s+\*|int\s+)(annlite_\w+)\s*\(', src)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from annlite_amd import _capi
+
+    declared = _declared()
+    assert len(declared) >= 20
+    assert sorted(_capi.SYMBOLS) == declared, set(declared) ^ set(_capi.SYMBOLS)
+    lib = _capi.lib()  # raises if the .so is missing or lacks a symbol
+    for name in declared:
+        assert hasattr(lib, name)
+    out = subprocess.check_output(['nm', '-D', '--defined-only', _capi.LIB_PATH]).decode()
+    exported = set(re.findall(r'\bT (annlite_\w+)', out))
+    assert exported == set(declared), exported ^ set(declared)
+    assert lib.annlite_hip_abi_version() == 1
+
+
+def test_scan_plan_arithmetic_no_gpu():
+    from annlite_amd import _capi
+
+    p = _capi.scan_plan(10_000_000, 16, 256, 1, 1024, 10)
+    assert (p.fast, p.qi, p.qt, p.waves) == (1, 4, 8, 8) and p.n_slices % 8 == 0
+    assert p.lut_floats == 1024 * 16 * 256
+    assert p.workspace_bytes == 1024 * p.n_slices * 10 * 8
+    p = _capi.scan_plan(1000, 64, 256, 1, 3, 10)
+    assert (p.fast, p.qi, p.qt) == (1, 2, 2) and p.lut_floats == 16 * 64 * 256
+    p = _capi.scan_plan(1000, 8, 512, 2, 5, 10)  # uint16 codes -> generic kernel
+    assert p.fast == 0 and p.qt == 1
+    import pytest
+
+    with pytest.raises(AssertionError):
+        _capi.scan_plan(1000, 16, 256, 1, 4, 65)  # k > 64
+    with pytest.raises(AssertionError):
+        _capi.scan_plan(1000, 16, 256, 3, 4, 10)  # bad code width
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: no file under annlite_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'annlite_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert 'pq_oracle' not in txt and 'oracle/' not in txt.replace('(oracle/', ''), os.path.join(dirpath, f)

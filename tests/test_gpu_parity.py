@@ -1,0 +1,434 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path, called through the C ABI
+(annlite_amd.ops -> libannlite_hip.so), against the CPU oracle and the golden fixtures produced by
+the compiled reference.
+
+bar: bit-exact (np.array_equal) for look-up tables, ADC distances, codes (except near-tie encode
+mismatches), and neighbour ids at the fixed tie-break (distance asc, row id asc).  Floating-point
+tolerance appears only where stated (l2_normalize: 1e-6 relative).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_names, has_gpu, load_golden
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason='needs an AMD GPU')]
+
+
+@pytest.fixture(scope='module')
+def ops():
+    import torch
+    from annlite_amd import ops as _ops
+
+    torch.cuda.set_device(0)
+    return _ops
+
+
+def untile(lut_tiled: np.ndarray, B, M, Ks, qi):
+    """[ceil16(B)/qi][Ks][M][qi] -> [B][M][Ks]"""
+    bp = ((B + 15) // 16) * 16
+    t = lut_tiled.reshape(bp // qi, Ks, M, qi)
+    return np.ascontiguousarray(t.transpose(0, 3, 2, 1).reshape(bp, M, Ks)[:B])
+
+
+def test_native_library_is_loaded(ops):
+    from annlite_amd import _capi
+
+    assert _capi.lib().annlite_hip_abi_version() == 1
+    assert _capi.device_count() >= 1
+    assert 'gfx950' in _capi.device_arch(0)
+    with open('/proc/self/maps') as f:
+        assert 'libannlite_hip.so' in f.read()
+
+
+# ------------------------------------------------------------------------------------------- LUT
+@pytest.mark.parametrize('name', golden_names())
+def test_lut_bit_exact_vs_reference_fixture(ops, name):
+    from annlite_amd._capi import LAYOUT_BMK, LAYOUT_TILED, LUT_IP, LUT_IPDIST, LUT_L2
+
+    g = load_golden(name)
+    q, cb = ops.to_dev(g['queries']), ops.to_dev(g['codebooks'])
+    assert np.array_equal(ops.lut_build(q, cb, LUT_L2, LAYOUT_BMK).cpu().numpy(), g['lut_l2_batch'])
+    assert np.array_equal(ops.lut_build(q, cb, LUT_IP, LAYOUT_BMK).cpu().numpy(), g['lut_ip_batch'])  # MFMA
+    assert np.array_equal(ops.lut_build(q, cb, LUT_IPDIST, LAYOUT_BMK).cpu().numpy(), g['dist_mat_inner_product'])
+    for qi in (4, 2):
+        for kind, want in ((LUT_L2, g['lut_l2_batch']), (LUT_IP, g['lut_ip_batch']), (LUT_IPDIST, g['dist_mat_inner_product'])):
+            t = ops.lut_build(q, cb, kind, LAYOUT_TILED, qi).cpu().numpy()
+            assert np.array_equal(untile(t, g['B'], g['M'], g['Ks'], qi), want)
+        t = ops.lut_retile(ops.to_dev(g['lut_l2_batch']), qi).cpu().numpy()
+        assert np.array_equal(untile(t, g['B'], g['M'], g['Ks'], qi), g['lut_l2_batch'])
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_pq_bind_module_mirror(ops, name):
+    """numpy in / numpy out like annlite.pq_bind; the reference's own checks
+    (tests/test_pq_bind.py:36-75, tests/test_pq_index.py:30-49) restated."""
+    from annlite_amd import pq_bind
+
+    g = load_golden(name)
+    t1 = pq_bind.precompute_adc_table(g['queries'][0], g['dsub'], g['Ks'], g['codebooks'])
+    assert isinstance(t1, np.ndarray) and np.array_equal(t1, g['lut_l2_single'])
+    tb = pq_bind.batch_precompute_adc_table(g['queries'], g['dsub'], g['Ks'], g['codebooks'])
+    assert np.array_equal(tb, g['lut_l2_batch'])
+    assert np.array_equal(pq_bind.batch_precompute_adc_table_ip(g['queries'], g['dsub'], g['Ks'], g['codebooks']), g['lut_ip_batch'])
+    ref = np.empty((g['M'], g['Ks']), np.float32)
+    for m in range(g['M']):
+        ref[m] = np.linalg.norm(g['codebooks'][m] - g['queries'][0][m * g['dsub']:(m + 1) * g['dsub']], axis=1) ** 2
+    np.testing.assert_array_almost_equal(ref, t1, decimal=4)
+    d = pq_bind.dist_pqcodes_to_codebooks(g['lut_l2_batch'][1], g['codes'])
+    assert np.array_equal(np.asarray(d, dtype=np.float32), g['adist'][1])
+
+
+# ------------------------------------------------------------------------------------ codec
+@pytest.mark.parametrize('name', golden_names())
+def test_codec_against_fixture(ops, oracle, name):
+    from annlite_amd import Metric, PQCodec
+
+    g = load_golden(name)
+    for mname, metric in (('euclidean', Metric.EUCLIDEAN), ('inner_product', Metric.INNER_PRODUCT), ('cosine', Metric.COSINE)):
+        c = PQCodec(dim=g['D'], n_subvectors=g['M'], n_clusters=g['Ks'], metric=metric)
+        c.set_codebooks(g['codebooks_cos'] if mname == 'cosine' else g['codebooks'])
+        dm = c.get_dist_mat(g['queries'])
+        assert dm.dtype == np.float32 and dm.flags['C_CONTIGUOUS'] and dm.shape == (g['B'], g['M'], g['Ks'])
+        if mname == 'cosine':
+            # GPU l2_normalize sums in another order than numpy's einsum: 1 ulp on the inputs
+            np.testing.assert_allclose(dm, g['dist_mat_cosine'], rtol=2e-5, atol=2e-6)
+        else:
+            assert np.array_equal(dm, g['dist_mat_' + mname])
+    c = PQCodec(dim=g['D'], n_subvectors=g['M'], n_clusters=g['Ks'], metric=Metric.EUCLIDEAN).set_codebooks(g['codebooks'])
+    assert c.get_subspace_splitting() == (g['M'], g['Ks'], g['dsub'])
+    assert c.get_codebook().shape == (g['M'], g['Ks'], g['dsub'])
+    assert np.array_equal(c.precompute_adc(g['queries'][0]).dtable, g['lut_l2_single'])
+    codes = c.encode(g['x'])
+    assert codes.dtype == g['codes'].dtype and codes.shape == g['codes'].shape
+    bad = np.argwhere(codes != g['codes'])
+    if len(bad):
+        best, second = oracle.encode_gap(g['x'], g['codebooks'])
+        for n, m in bad:
+            assert (second[n, m] - best[n, m]) / max(second[n, m], 1e-30) < 1e-5
+    assert np.array_equal(codes, oracle.encode_c(g['x'], g['codebooks']))  # same fmaf chain => identical
+    assert np.array_equal(c.decode(g['codes'][:64]), g['decoded'])
+    for b in range(g['B']):
+        adist = c.precompute_adc(g['queries'][b]).adist(g['codes'])
+        assert np.array_equal(np.asarray(adist, np.float32), g['adist'][b])
+
+
+def test_l2_normalize(ops, oracle):
+    from annlite_amd import math as amath
+
+    rs = np.random.RandomState(3)
+    x = rs.randn(257, 96).astype(np.float32)
+    x[5] = 0.0  # norm < 10*eps row stays unscaled (math.py:14-16)
+    x[6] = 1e-9
+    got = amath.l2_normalize(x)
+    np.testing.assert_allclose(got, oracle.l2_normalize(x), rtol=1e-6, atol=1e-12)
+    assert np.array_equal(got[5], x[5])
+
+
+# ------------------------------------------------------------------------------------ scan + top-k
+def _scan(ops, codes, lut_bmk, k, layout=0, valid=None, row_base=0):
+    import torch
+    from annlite_amd._capi import scan_plan
+
+    B, M, Ks = lut_bmk.shape
+    codes_d = ops.to_dev(codes)
+    plan = scan_plan(codes.shape[0], M, Ks, codes.dtype.itemsize, B, k)
+    lut_d = ops.to_dev(lut_bmk)
+    if plan.fast:
+        lut_d = ops.lut_retile(lut_d, plan.qi)
+    if layout == 1:
+        codes_d = ops.codes_skew(codes_d)
+    vb = None
+    if valid is not None:
+        bits = np.zeros(((len(valid) + 31) // 32 + 2) * 32, dtype=bool)
+        bits[:len(valid)] = valid
+        vb = ops.to_dev(np.packbits(bits.reshape(-1, 32), axis=1, bitorder='little').view(np.int32).reshape(-1))
+    d, i = ops.adc_scan_topk(codes_d, lut_d, B, k, M, Ks, valid_bits=vb, row_base=row_base, codes_layout=layout)
+    torch.cuda.synchronize()
+    return d.cpu().numpy(), i.cpu().numpy(), plan
+
+
+@pytest.mark.parametrize('name', [n for n in golden_names()])
+@pytest.mark.parametrize('layout', [0, 1])
+def test_scan_topk_vs_fixture(ops, oracle, name, layout):
+    g = load_golden(name)
+    if g['codes'].dtype != np.uint8 and layout == 1:
+        pytest.skip('SKEWED layout is uint8-only')
+    k = g['K']
+    d, i, plan = _scan(ops, g['codes'], g['lut_l2_batch'], k, layout)
+    if g['codes'].dtype == np.uint8:
+        rd, ri = oracle.adc_search_c(g['lut_l2_batch'], g['codes'], k)
+    else:
+        rd, ri = oracle.adc_search_numpy(g['lut_l2_batch'], g['codes'], k)
+    assert np.array_equal(d, rd)
+    assert np.array_equal(i, ri)
+    # and against the reference's own PQIndex.search output (zero rows up to capacity included)
+    if g['codes'].dtype == np.uint8:
+        cap = int(g['pqindex_capacity'][0])
+        table = np.zeros((cap, g['M']), np.uint8)
+        table[:g['N']] = g['codes']
+        d2, i2, _ = _scan(ops, table, g['lut_l2_batch'], k, layout)
+        assert np.array_equal(d2.astype(np.float64), g['pqindex_d'])
+
+
+SHAPES = [
+    # M, Ks, N, B, k
+    (16, 256, 5000, 37, 10), (16, 256, 64, 1, 1), (16, 256, 63, 9, 64), (16, 256, 1, 3, 5), (16, 256, 130, 8, 10),
+    (8, 256, 3000, 17, 10), (8, 200, 999, 5, 3), (32, 256, 2500, 6, 10), (64, 256, 1500, 5, 10), (64, 100, 700, 2, 7),
+    (16, 256, 40000, 24, 50), (4, 256, 1000, 5, 10), (3, 17, 500, 4, 10), (12, 256, 800, 3, 10),
+]
+
+
+@pytest.mark.parametrize('M,Ks,N,B,k', SHAPES)
+@pytest.mark.parametrize('layout', [0, 1])
+def test_scan_topk_random_shapes(ops, oracle, M, Ks, N, B, k, layout):
+    from annlite_amd._capi import scan_plan
+
+    if layout == 1 and not scan_plan(N, M, Ks, 1, B, k).fast:
+        pytest.skip('SKEWED needs the fast plan')
+    rs = np.random.RandomState(M * 7919 + N)
+    lut = rs.rand(B, M, Ks).astype(np.float32)
+    if M % 2 == 0:
+        lut[B // 2] -= 0.5  # negative entries (inner-product style tables)
+    codes = rs.randint(0, Ks, size=(N, M)).astype(np.uint8)
+    d, i, _ = _scan(ops, codes, lut, k, layout, row_base=1000)
+    rd, ri = oracle.adc_search_c(lut, codes, k, id_base=1000)
+    ri = np.where(ri == -1, -1, ri)
+    assert np.array_equal(d, rd)
+    assert np.array_equal(i, ri)
+
+
+def test_scan_ties_and_valid_bits(ops, oracle):
+    """duplicate rows => exact distance ties: ids must come out ascending (the fixed tie-break);
+    rows masked out by the validity bitmap (delete marks / `indices` filter) are never returned."""
+    rs = np.random.RandomState(11)
+    M, Ks, N, B, k = 16, 256, 4096, 12, 20
+    base = rs.randint(0, Ks, size=(64, M)).astype(np.uint8)
+    codes = base[rs.randint(0, 64, size=N)]  # every row has ~64 exact duplicates
+    lut = rs.rand(B, M, Ks).astype(np.float32)
+    for layout in (0, 1):
+        d, i, _ = _scan(ops, codes, lut, k, layout)
+        rd, ri = oracle.adc_search_c(lut, codes, k)
+        assert np.array_equal(d, rd) and np.array_equal(i, ri)
+    valid = rs.rand(N) < 0.3
+    d, i, _ = _scan(ops, codes, lut, k, 1, valid=valid)
+    idx = np.where(valid)[0]
+    rd, ri = oracle.adc_search_c(lut, codes[idx], k)
+    assert np.array_equal(d, rd) and np.array_equal(i, idx[ri])
+    # fewer valid rows than k: padded with (+inf, -1)
+    valid2 = np.zeros(N, bool)
+    valid2[[5, 77, 4000]] = True
+    d, i, _ = _scan(ops, codes, lut, k, 0, valid=valid2)
+    assert (i[:, 3:] == -1).all() and np.isinf(d[:, 3:]).all()
+    assert (np.sort(i[:, :3], axis=1) == np.array([5, 77, 4000])).all()
+
+
+def test_scan_uint16_generic(ops, oracle):
+    rs = np.random.RandomState(5)
+    M, Ks, N, B, k = 8, 768, 3000, 7, 10
+    lut = rs.rand(B, M, Ks).astype(np.float32)
+    codes = rs.randint(0, Ks, size=(N, M)).astype(np.uint16)
+    d, i, plan = _scan(ops, codes, lut, k)
+    assert not plan.fast
+    rd, ri = oracle.adc_search_numpy(lut, codes, k)
+    assert np.array_equal(d, rd) and np.array_equal(i, ri)
+
+
+def test_candidates_superset_and_gather(ops, oracle):
+    import torch
+    from annlite_amd._capi import scan_plan
+
+    rs = np.random.RandomState(21)
+    M, Ks, N, B, k = 16, 256, 30000, 9, 32
+    lut = rs.rand(B, M, Ks).astype(np.float32)
+    codes = rs.randint(0, Ks, size=(N, M)).astype(np.uint8)
+    plan = scan_plan(N, M, Ks, 1, B, k)
+    codes_d = ops.to_dev(codes)
+    lut_t = ops.lut_retile(ops.to_dev(lut), plan.qi)
+    cd, ci = ops.adc_scan_candidates(codes_d, lut_t, B, k, M, Ks)
+    torch.cuda.synchronize()
+    cd, ci = cd.cpu().numpy(), ci.cpu().numpy()
+    assert ci.shape == (B, plan.n_slices * k)
+    rd, ri = oracle.adc_search_c(lut, codes, k)
+    for b in range(B):
+        assert set(ri[b]).issubset(set(ci[b]))
+    # gathered ADC over the candidates reproduces their distances bit-for-bit (space_pq.h PQLookup)
+    gd = ops.adc_gather(ops.to_dev(lut), codes_d, ops.to_dev(ci)).cpu().numpy()
+    assert np.array_equal(gd, cd)
+    for b in range(2):
+        want = oracle.adc_gather_c(lut[b], codes, ci[b])
+        assert np.array_equal(gd[b], want)
+
+
+def test_topk_merge_and_rows(ops, oracle):
+    rs = np.random.RandomState(8)
+    G, B, k = 8, 33, 10
+    vals = rs.rand(B, G * 500).astype(np.float32)
+    vals[:, ::7] = vals[:, 1::7]  # ties
+    d, i = ops.topk_rows(ops.to_dev(vals), k)
+    for b in range(B):
+        rd, ri = oracle.top_k_c(vals[b], k)
+        assert np.array_equal(d[b].cpu().numpy(), rd) and np.array_equal(i[b].cpu().numpy(), ri)
+    # shard-wise top-k then merge == global top-k
+    sd, si = [], []
+    for g in range(G):
+        dd, ii = ops.topk_rows(ops.to_dev(vals[:, g * 500:(g + 1) * 500]), k, id_base=g * 500 + (1 << 33))
+        sd.append(dd)
+        si.append(ii)
+    import torch
+
+    md, mi = ops.topk_merge(torch.stack(sd), torch.stack(si))
+    assert np.array_equal(md.cpu().numpy(), d.cpu().numpy())
+    assert np.array_equal(mi.cpu().numpy() - (1 << 33), i.cpu().numpy())
+
+
+# ------------------------------------------------------------------------------------ index plugin
+@pytest.mark.parametrize('name', ['c1_m8_d128', 'c2_m16_d128', 'c4_m64_d768'])
+@pytest.mark.parametrize('mname,metric', [('euclidean', 1), ('inner_product', 2), ('cosine', 3)])
+def test_index_plugin_vs_oracle_and_hnsw_fixture(ops, oracle, name, mname, metric):
+    from annlite_amd import Metric, PQCodec, PQFlatGpuIndex
+
+    g = load_golden(name)
+    cb = g['codebooks_cos'] if metric == 3 else g['codebooks']
+    codec = PQCodec(dim=g['D'], n_subvectors=g['M'], n_clusters=g['Ks'], metric=Metric(metric)).set_codebooks(cb)
+    idx = PQFlatGpuIndex(dim=g['D'], metric=Metric(metric), pq_codec=codec, initial_size=512, expand_step_size=512)
+    idx.add_with_ids(g['x'], np.arange(g['N']))
+    assert idx.size == g['N'] and idx.capacity >= g['N']
+    ref_codes = g['codes_cos'] if metric == 3 else g['codes']
+    d, i = idx.search_batch(g['queries'], limit=g['K'])
+    if metric != 3:
+        # oracle on the reference's codes: exact parity (encode agrees on these fixtures)
+        rd, ri = oracle.index_search(g['queries'], cb, ref_codes, metric, g['K'])
+        assert np.array_equal(d, rd) and np.array_equal(i, ri)
+    else:
+        rd, ri = oracle.index_search(g['queries'], cb, ref_codes, metric, g['K'])
+        np.testing.assert_allclose(d, rd, rtol=1e-4, atol=1e-6)  # north-star tolerance for cosine
+        for b in range(g['B']):
+            if not np.array_equal(i[b], ri[b]):  # swaps only where the oracle's own gap is tiny
+                for j in np.where(i[b] != ri[b])[0]:
+                    assert abs(rd[b][j] - d[b][j]) <= 1e-4 * max(1.0, abs(rd[b][j]))
+    # HnswIndex(PQ) fixture: the exhaustive scan is never worse than the graph walk, and for EUCLIDEAN /
+    # IP its distance for every id the reference returned is bit-identical
+    key = 'hnsw_%s_d' % mname
+    if key in g:
+        assert (d <= g[key] + (1e-5 if metric == 3 else 0)).all()
+    # single-query reference signature
+    d1, i1 = idx.search(g['queries'][0], limit=g['K'])
+    assert np.array_equal(d1, d[0]) and np.array_equal(i1, i[0])
+    # delete marks
+    idx.delete([int(i[0][0])])
+    d2, i2 = idx.search(g['queries'][0], limit=g['K'])
+    assert int(i[0][0]) not in i2 and idx.size == g['N'] - 1
+    # subset search (`indices`), pq_index.py:42-44
+    sub = np.arange(0, g['N'], 3)
+    d3, i3 = idx.search(g['queries'][1], limit=5, indices=sub)
+    assert set(i3).issubset(set(sub))
+
+
+def test_index_untrained_raises(ops):
+    from annlite_amd import Metric, PQCodec, PQFlatGpuIndex
+
+    codec = PQCodec(dim=64, n_subvectors=8)
+    idx = PQFlatGpuIndex(dim=64, metric=Metric.EUCLIDEAN, pq_codec=codec)
+    with pytest.raises(RuntimeError):
+        idx.add_with_ids(np.zeros((3, 64), np.float32), [0, 1, 2])
+    with pytest.raises(RuntimeError):
+        idx.search(np.zeros(64, np.float32))
+
+
+def test_index_dump_load_large_k_and_rerank(ops, oracle, tmp_path):
+    from annlite_amd import Metric, PQCodec, PQFlatGpuIndex
+
+    g = load_golden('c2_m16_d128')
+    codec = PQCodec(dim=g['D'], n_subvectors=g['M'], n_clusters=g['Ks'], metric=Metric.EUCLIDEAN).set_codebooks(g['codebooks'])
+    idx = PQFlatGpuIndex(dim=g['D'], metric=Metric.EUCLIDEAN, pq_codec=codec, initial_size=256, expand_step_size=300)
+    idx.add_with_ids(g['x'][:500], np.arange(500))
+    idx.add_with_ids(g['x'][500:], np.arange(500, g['N']))  # forces capacity expansion
+    d, i = idx.search_batch(g['queries'], limit=10)
+    p = tmp_path / 'cell_0.pqgpu'
+    idx.dump(p)
+    idx2 = PQFlatGpuIndex(dim=g['D'], metric=Metric.EUCLIDEAN, pq_codec=codec, index_file=p)
+    d2, i2 = idx2.search_batch(g['queries'], limit=10)
+    assert np.array_equal(d, d2) and np.array_equal(i, i2) and idx2.size == idx.size
+    # k > 64 path
+    dk, ik = idx.search_batch(g['queries'], limit=100)
+    rd, ri = oracle.index_search(g['queries'], g['codebooks'], g['codes'], 1, 100)
+    assert np.array_equal(dk, rd) and np.array_equal(ik, ri)
+    # exact re-rank: result = exact distances of the best candidates
+    idr = PQFlatGpuIndex(dim=g['D'], metric=Metric.EUCLIDEAN, pq_codec=codec, rerank=True, initial_size=2048)
+    idr.add_with_ids(g['x'], np.arange(g['N']))
+    dr, ir = idr.search_batch(g['queries'], limit=10, rerank_k=64)
+    exact = np.sqrt(((g['queries'][:, None, :] - g['x'][None, :, :]) ** 2).sum(-1))
+    truth = np.argsort(exact, axis=1)[:, :10]
+    recall = np.mean([len(set(ir[b]) & set(truth[b])) / 10 for b in range(g['B'])])
+    assert recall >= 0.9, recall
+    np.testing.assert_allclose(dr, np.take_along_axis(exact, ir, axis=1), rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------ AnnLite facade
+def test_annlite_facade_end_to_end(ops, tmp_path):
+    """tests/test_pq_index.py:52-77 restated + result shape of AnnLite.search (container.py:226-233)."""
+    from annlite_amd import AnnLite
+    from annlite_amd.index import Document, DocumentArray
+
+    rs = np.random.RandomState(4)
+    N, D = 1000, 64
+    X = rs.rand(N, D).astype(np.float32)
+    docs = DocumentArray([Document(id=f'{i}', embedding=X[i], tags={'x': str(i), 'price': float(i)}) for i in range(N)])
+    ann = AnnLite(D, data_path=tmp_path / 'idx', n_subvectors=8, metric='euclidean')
+    with pytest.raises(RuntimeError):
+        ann.index(docs)
+    with pytest.raises(RuntimeError):
+        ann.search(docs)
+    ann._pq_codec.seed = 1
+    ann.train(X)
+    assert ann.is_trained and ann._pq_codec_path.exists()
+    ann.index(docs)
+    assert ann.stat['total_docs'] == N and ann.stat['index_size'] == N and ann.stat['metric'] == 'EUCLIDEAN'
+    query = DocumentArray([Document(embedding=X[i]) for i in range(10)])
+    ann.search(query, limit=7)
+    for qi, qd in enumerate(query):
+        assert len(qd.matches) == 7
+        vals = [m.scores['euclidean'].value for m in qd.matches]
+        assert vals == sorted(vals)
+        assert qd.matches[0].id == str(qi)  # a vector's own code is its nearest ADC neighbour here
+    dists, ids = ann.search_numpy(X[:4], limit=5)
+    assert len(dists) == 4 and ids[0].dtype.kind == 'i' and ids[0][0] == 0
+    # filter -> GPU bitmap
+    ann.search(query, filter={'price': {'$lt': 50.0}}, limit=5)
+    assert all(int(m.id) < 50 for qd in query for m in qd.matches)
+    # delete / update
+    ann.delete(['0'])
+    ann.search(query, limit=3)
+    assert query[0].matches[0].id != '0'
+    # a second AnnLite over the same data_path picks the trained codec up (index.py:136-140)
+    ann2 = AnnLite(D, data_path=tmp_path / 'idx', n_subvectors=8, metric='euclidean')
+    assert ann2.is_trained
+    assert np.array_equal(ann2._pq_codec.codebooks, ann._pq_codec.codebooks)
+
+
+def test_kmeans_fit_quality_vs_sklearn(ops):
+    """Training parity is statistical (pq.py:89-115 is unseeded sklearn): reconstruction MSE of the
+    GPU k-means must be within 5 % of sklearn KMeans on the same data."""
+    from sklearn.cluster import KMeans
+    from annlite_amd import Metric, PQCodec
+
+    rs = np.random.RandomState(0)
+    z = rs.randn(4000, 8).astype(np.float32)
+    x = (z @ rs.randn(8, 32).astype(np.float32) + 0.05 * rs.randn(4000, 32)).astype(np.float32)
+    c = PQCodec(dim=32, n_subvectors=4, n_clusters=64, metric=Metric.EUCLIDEAN, n_init=2)
+    c.seed = 7
+    c.fit(x, iter=50)
+    assert c.is_trained and c.codebooks.shape == (4, 64, 8)
+    rec = c.decode(c.encode(x))
+    mse = float(((rec - x) ** 2).mean())
+    ref_mse = 0.0
+    for m in range(4):
+        km = KMeans(n_clusters=64, n_init=2, max_iter=50, random_state=0).fit(x[:, m * 8:(m + 1) * 8])
+        ref_mse += km.inertia_ / x.shape[0] / 32
+    assert mse <= 1.05 * ref_mse, (mse, ref_mse)
+    # partial_fit + build_codebook give the same codebook shape (tests/test_codec.py:65-70)
+    c2 = PQCodec(dim=32, n_subvectors=4, n_clusters=64)
+    for s in range(0, 4000, 500):
+        c2.partial_fit(x[s:s + 500])
+    c2.build_codebook()
+    assert c2.codebooks.shape == c.codebooks.shape and c2.is_trained

@@ -1,0 +1,106 @@
+"""CPU: host-side logic that needs no GPU (enums, filters, docarray stand-in, shard ranges,
+constructor/assertion behaviour mirrored from the reference)."""
+import numpy as np
+import pytest
+
+
+def test_enums_match_reference_values():
+    from annlite_amd.enums import ExpandMode, Metric
+
+    assert (int(Metric.EUCLIDEAN), int(Metric.INNER_PRODUCT), int(Metric.COSINE)) == (1, 2, 3)  # enums.py:25-28
+    assert Metric.from_string('cosine') is Metric.COSINE and str(Metric.EUCLIDEAN) == 'EUCLIDEAN'
+    assert int(ExpandMode.STEP) == 1
+    with pytest.raises(ValueError):
+        Metric.from_string('manhattan')
+
+
+def test_codec_constructor_contract():
+    from annlite_amd import Metric, PQCodec
+
+    with pytest.raises(AssertionError):
+        PQCodec(dim=130, n_subvectors=8)  # pq.py:51-53
+    c = PQCodec(dim=128, n_subvectors=16, n_clusters=256, metric=Metric.COSINE)
+    assert c.d_subvector == 8 and c.code_dtype == np.uint8 and c.normalize_input and not c.is_trained
+    assert PQCodec(dim=64, n_subvectors=8, n_clusters=512).code_dtype == np.uint16  # pq.py:56-60
+    assert PQCodec(dim=64, n_subvectors=8, n_clusters=70000).code_dtype == np.uint32
+    assert c.get_subspace_splitting() == (16, 256, 8)
+    assert c.get_codebook().shape == (16, 256, 8) and c.get_codebook().dtype == np.float32
+    assert hash(c) == hash(PQCodec(dim=128, n_subvectors=16, n_clusters=256, metric=Metric.COSINE))
+    c.set_codebooks(np.ones((16, 256, 8), np.float32))
+    assert c.is_trained
+
+
+def test_codec_pickle_roundtrip(tmp_path):
+    from annlite_amd import Metric, PQCodec
+    from annlite_amd.core.codec.base import BaseCodec
+
+    c = PQCodec(dim=32, n_subvectors=4, n_clusters=16, metric=Metric.INNER_PRODUCT)
+    c.set_codebooks(np.random.RandomState(0).rand(4, 16, 8).astype(np.float32))
+    p = tmp_path / 'pq_codec.params'
+    c.dump(p)
+    c2 = BaseCodec.load(p)
+    assert c2.is_trained and c2.metric == Metric.INNER_PRODUCT and np.array_equal(c2.codebooks, c.codebooks)
+
+
+def test_annlite_constructor_and_untrained_errors(tmp_path):
+    from annlite_amd import AnnLite
+    from annlite_amd.index import Document, DocumentArray
+
+    with pytest.raises(AssertionError):
+        AnnLite(100, n_subvectors=8, data_path=tmp_path / 'a')  # index.py:86-89
+    with pytest.raises(NotImplementedError):
+        AnnLite(128, n_subvectors=8, n_cells=4, data_path=tmp_path / 'b')
+    ann = AnnLite(64, n_subvectors=8, data_path=tmp_path / 'c', dim=64)
+    assert not ann.is_trained and ann.stat['total_docs'] == 0 and ann.stat['metric'] == 'COSINE'
+    docs = DocumentArray([Document(id=str(i), embedding=np.zeros(64, np.float32)) for i in range(3)])
+    with pytest.raises(RuntimeError):
+        ann.index(docs)  # tests/test_pq_index.py:52-65
+    with pytest.raises(RuntimeError):
+        ann.search(docs)
+    with pytest.raises(RuntimeError):
+        ann.search_numpy(np.zeros((1, 64), np.float32))
+    ro = AnnLite(64, n_subvectors=8, data_path=tmp_path / 'd', read_only=True)
+    assert ro.index(docs) is None  # logs and returns, index.py:280-282
+
+
+def test_filter_and_docarray_standin():
+    from annlite_amd.docarray_compat import Document, DocumentArray
+    from annlite_amd.filter import match, select
+
+    tags = [{'price': 10, 'cat': 'a'}, {'price': 50, 'cat': 'b'}, None, {'price': 70, 'cat': 'a'}]
+    assert select(tags, {'price': {'$lt': 60}}) == [0, 1]
+    assert select(tags, {'$and': [{'cat': {'$eq': 'a'}}, {'price': {'$gte': 20}}]}) == [3]
+    assert select(tags, {'$or': [{'price': {'$gt': 60}}, {'cat': {'$in': ['b']}}]}) == [1, 3]
+    assert match({'x': 1}, {'x': 1}) and not match({'x': 1}, {'x': {'$ne': 1}})
+    with pytest.raises(ValueError):
+        select(tags, {'price': {'$regex': 'x'}})
+    da = DocumentArray([Document(id=str(i), embedding=np.full(4, i, np.float32)) for i in range(5)])
+    assert da.embeddings.shape == (5, 4) and da[:, 'id'] == ['0', '1', '2', '3', '4']
+    d = da[1]
+    d.scores['cosine'].value = 0.5
+    assert d.scores['cosine'].value == 0.5 and len(d.matches) == 0 and '3' in da
+
+
+def test_shard_ranges_cover_exactly():
+    from annlite_amd.sharded import shard_range
+
+    for n, g in ((10_000_000, 8), (1000, 3), (7, 8), (0, 2)):
+        rs = [shard_range(n, g, r) for r in range(g)]
+        assert rs[0][0] == 0 and rs[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(rs, rs[1:])) and all(lo <= hi for lo, hi in rs)
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from annlite_amd import ops
+
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.device()
+    from annlite_amd import Metric, PQCodec
+
+    c = PQCodec(dim=8, n_subvectors=2, n_clusters=4).set_codebooks(np.zeros((2, 4, 4), np.float32))
+    with pytest.raises(RuntimeError):
+        c.encode(np.zeros((3, 8), np.float32))
