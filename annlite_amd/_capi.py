@@ -76,6 +76,11 @@ def lib() -> ctypes.CDLL:
             f'(run `make -C annlite_amd/csrc` or `python -c "import __graft_entry__ as g; g.build()"`). '
             f'annlite_amd has no CPU fallback.'
         )
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so); it must be the one already mapped
+    # when our library's DT_NEEDED libamdhip64 is resolved, otherwise two runtimes coexist and device
+    # pointers allocated by torch are foreign to our launches ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
+
     L = ctypes.CDLL(LIB_PATH)
     i64, i32, vp, sz = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
     L.annlite_hip_abi_version.restype = i32

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Run only the hot path (LUT build + ADC scan + merge) a few times -- the command rocprofv3 wraps.
+
+    rocprofv3 --kernel-trace --stats -d gpurun_out/prof -- python scripts/prof_scan.py --rows 10000000
+    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU ... -d gpurun_out/pmc -- python scripts/prof_scan.py
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from annlite_amd import _capi, ops  # noqa: E402
+from annlite_amd._capi import LAYOUT_TILED, LUT_L2, scan_plan  # noqa: E402
+
+p = argparse.ArgumentParser()
+p.add_argument('--rows', type=int, default=1_000_000)
+p.add_argument('--m', type=int, default=16)
+p.add_argument('--batch', type=int, default=1024)
+p.add_argument('--k', type=int, default=10)
+p.add_argument('--iters', type=int, default=5)
+p.add_argument('--layout', type=int, default=1)
+a = p.parse_args()
+torch.cuda.set_device(0)
+dev = torch.device('cuda', 0)
+g = torch.Generator(device=dev)
+g.manual_seed(0)
+N, M, Ks, B, k = a.rows, a.m, 256, a.batch, a.k
+D = M * 8
+codes = torch.randint(0, 256, (N, M), generator=g, device=dev, dtype=torch.uint8)
+cb = torch.randn((M, Ks, D // M), generator=g, device=dev)
+q = torch.randn((B, D), generator=g, device=dev)
+plan = scan_plan(N, M, Ks, 1, B, k)
+ws = ops.ScanWorkspace()
+_capi.profile_enable(True)
+ms = []
+for it in range(a.iters):
+    lut = ops.lut_build(q, cb, LUT_L2, LAYOUT_TILED, plan.qi)
+    d, i = ops.adc_scan_topk(codes, lut, B, k, M, Ks, codes_layout=a.layout, workspace=ws)
+    ms.append(_capi.profile_last_scan_ms())
+torch.cuda.synchronize()
+look = B * N * M
+print('scan kernel ms:', ['%.3f' % x for x in ms], ' lookups/s %.3e' % (look / (min(ms) * 1e-3)), ' alg GB/s %.1f' % (look / (min(ms) * 1e-3) / 1e9))
