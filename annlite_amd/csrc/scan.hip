@@ -26,6 +26,7 @@
 //     (common.h WaveList); a row is offered only if it beats the wave's current k-th distance.
 //
 // No fallback to CPU exists; unsupported shapes use the generic kernel below (LUT through L2).
+#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
@@ -101,6 +102,90 @@ __device__ __forceinline__ void masked_pk_add1(f32x2 &a0, const f32x2 x0) {
     }
 }
 
+
+// ---- ordered accumulation, 8 steps per asm statement --------------------------------------------
+// One statement = 8 x { set exec to the compile-time lane mask of step t ; v_pk_add_f32 ... } and
+// ONE restore of exec to all-ones (the main loop runs with full waves and uniform control flow).
+// v1 of this kernel saved/restored exec around every step (4 SALU per 2 VALU): rocprof showed
+// 343 SALU + 255 VALU per wave-step and the LDS pipe only 21 % busy (profiles/r01_*).
+#define ANNLITE_MASK_LO(M, T, P) ((int)(uint32_t)(pass_mask<M>((T), (P)) & 0xffffffffull))
+#define ANNLITE_MASK_HI(M, T, P) ((int)(uint32_t)(pass_mask<M>((T), (P)) >> 32))
+#define ANNLITE_LOHALF(v) __builtin_shufflevector((v), (v), 0, 1)
+#define ANNLITE_HIHALF(v) __builtin_shufflevector((v), (v), 2, 3)
+
+#define ANNLITE_STEP_Q4(i)                                       \
+    "s_mov_b32 exec_lo, %[m" #i "]\n\t"                          \
+    "s_mov_b32 exec_hi, %[m" #i "]\n\t"                          \
+    "v_pk_add_f32 %[a0], %[a0], %[x" #i "]\n\t"                  \
+    "v_pk_add_f32 %[a1], %[a1], %[y" #i "]\n\t"
+
+template <int M, int T0, int PASS>
+__device__ __forceinline__ void pass8_q4(f32x2 &a0, f32x2 &a1, const f32x4 (&v)[M]) {
+    static_assert(M <= 32 && T0 + 8 <= M, "lo == hi masks need a lane period <= 32");
+    asm(ANNLITE_STEP_Q4(0) ANNLITE_STEP_Q4(1) ANNLITE_STEP_Q4(2) ANNLITE_STEP_Q4(3)
+        ANNLITE_STEP_Q4(4) ANNLITE_STEP_Q4(5) ANNLITE_STEP_Q4(6) ANNLITE_STEP_Q4(7)
+        "s_mov_b64 exec, -1"
+        : [a0] "+v"(a0), [a1] "+v"(a1)
+        : [x0] "v"(ANNLITE_LOHALF(v[T0 + 0])), [y0] "v"(ANNLITE_HIHALF(v[T0 + 0])),
+          [x1] "v"(ANNLITE_LOHALF(v[T0 + 1])), [y1] "v"(ANNLITE_HIHALF(v[T0 + 1])),
+          [x2] "v"(ANNLITE_LOHALF(v[T0 + 2])), [y2] "v"(ANNLITE_HIHALF(v[T0 + 2])),
+          [x3] "v"(ANNLITE_LOHALF(v[T0 + 3])), [y3] "v"(ANNLITE_HIHALF(v[T0 + 3])),
+          [x4] "v"(ANNLITE_LOHALF(v[T0 + 4])), [y4] "v"(ANNLITE_HIHALF(v[T0 + 4])),
+          [x5] "v"(ANNLITE_LOHALF(v[T0 + 5])), [y5] "v"(ANNLITE_HIHALF(v[T0 + 5])),
+          [x6] "v"(ANNLITE_LOHALF(v[T0 + 6])), [y6] "v"(ANNLITE_HIHALF(v[T0 + 6])),
+          [x7] "v"(ANNLITE_LOHALF(v[T0 + 7])), [y7] "v"(ANNLITE_HIHALF(v[T0 + 7])),
+          [m0] "i"(ANNLITE_MASK_LO(M, T0 + 0, PASS)), [m1] "i"(ANNLITE_MASK_LO(M, T0 + 1, PASS)),
+          [m2] "i"(ANNLITE_MASK_LO(M, T0 + 2, PASS)), [m3] "i"(ANNLITE_MASK_LO(M, T0 + 3, PASS)),
+          [m4] "i"(ANNLITE_MASK_LO(M, T0 + 4, PASS)), [m5] "i"(ANNLITE_MASK_LO(M, T0 + 5, PASS)),
+          [m6] "i"(ANNLITE_MASK_LO(M, T0 + 6, PASS)), [m7] "i"(ANNLITE_MASK_LO(M, T0 + 7, PASS)));
+}
+
+#define ANNLITE_STEP_Q2(i)                                       \
+    "s_mov_b32 exec_lo, %[l" #i "]\n\t"                          \
+    "s_mov_b32 exec_hi, %[h" #i "]\n\t"                          \
+    "v_pk_add_f32 %[a0], %[a0], %[x" #i "]\n\t"
+
+template <int M, int T0, int PASS>
+__device__ __forceinline__ void pass8_q2(f32x2 &a0, const f32x2 (&v)[M]) {
+    static_assert(T0 + 8 <= M, "block out of range");
+    asm(ANNLITE_STEP_Q2(0) ANNLITE_STEP_Q2(1) ANNLITE_STEP_Q2(2) ANNLITE_STEP_Q2(3)
+        ANNLITE_STEP_Q2(4) ANNLITE_STEP_Q2(5) ANNLITE_STEP_Q2(6) ANNLITE_STEP_Q2(7)
+        "s_mov_b64 exec, -1"
+        : [a0] "+v"(a0)
+        : [x0] "v"(v[T0 + 0]), [x1] "v"(v[T0 + 1]), [x2] "v"(v[T0 + 2]), [x3] "v"(v[T0 + 3]),
+          [x4] "v"(v[T0 + 4]), [x5] "v"(v[T0 + 5]), [x6] "v"(v[T0 + 6]), [x7] "v"(v[T0 + 7]),
+          [l0] "i"(ANNLITE_MASK_LO(M, T0 + 0, PASS)), [h0] "i"(ANNLITE_MASK_HI(M, T0 + 0, PASS)),
+          [l1] "i"(ANNLITE_MASK_LO(M, T0 + 1, PASS)), [h1] "i"(ANNLITE_MASK_HI(M, T0 + 1, PASS)),
+          [l2] "i"(ANNLITE_MASK_LO(M, T0 + 2, PASS)), [h2] "i"(ANNLITE_MASK_HI(M, T0 + 2, PASS)),
+          [l3] "i"(ANNLITE_MASK_LO(M, T0 + 3, PASS)), [h3] "i"(ANNLITE_MASK_HI(M, T0 + 3, PASS)),
+          [l4] "i"(ANNLITE_MASK_LO(M, T0 + 4, PASS)), [h4] "i"(ANNLITE_MASK_HI(M, T0 + 4, PASS)),
+          [l5] "i"(ANNLITE_MASK_LO(M, T0 + 5, PASS)), [h5] "i"(ANNLITE_MASK_HI(M, T0 + 5, PASS)),
+          [l6] "i"(ANNLITE_MASK_LO(M, T0 + 6, PASS)), [h6] "i"(ANNLITE_MASK_HI(M, T0 + 6, PASS)),
+          [l7] "i"(ANNLITE_MASK_LO(M, T0 + 7, PASS)), [h7] "i"(ANNLITE_MASK_HI(M, T0 + 7, PASS)));
+}
+
+
+// ---- ordered accumulation without touching EXEC: per-lane 0/1 weights -----------------------------
+// fma(v, 1.0f, acc) == acc + v (one rounding, identical to v_add_f32) and fma(v, 0.0f, acc) == acc for
+// finite v, so "lane masked out" becomes "weight 0".  w[t] = (w1, w2) per lane: w1 = 1 if step t
+// belongs to pass 1 for this lane (t >= t0) else 0, w2 = 1 - w1.  op_sel/op_sel_hi broadcast w1
+// (pass 1) or w2 (pass 2) to both halves of the packed op.  No SALU at all: the exec-mask version
+// was bound by the CU's single scalar unit (~180 SALU per 8192 look-ups, profiles/r01 notes).
+__device__ __forceinline__ void wfma_p1(f32x2 &acc, const f32x2 v, const f32x2 w) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(v), "v"(w));
+}
+__device__ __forceinline__ void wfma_p2(f32x2 &acc, const f32x2 v, const f32x2 w) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(v), "v"(w));
+}
+// MODE 2: the same with scalar (non-packed) v_fma_f32 -- A/B against the packed form
+__device__ __forceinline__ void sfma(f32x2 &acc, const f32x2 v, const float w) {
+    float ax = acc.x, ay = acc.y;
+    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(ax) : "v"(v.x), "v"(w));
+    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(ay) : "v"(v.y), "v"(w));
+    acc.x = ax;
+    acc.y = ay;
+}
+
 // ---- compile-time loops -------------------------------------------------------------------------
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
@@ -151,8 +236,8 @@ struct LutVec<2> {
 //   NQ entry groups per WG   (QT = QI*NQ queries per workgroup)      NW waves per workgroup
 // LDS byte address of (code k, group h, sub-space m): ((k*NQ + h)*M + m) * QI*4
 // =================================================================================================
-template <int M, int QI, int NQ, int NW, bool SKEWED>
-__global__ __launch_bounds__(NW * 64) void adc_scan_fast_kernel(const ScanArgs a) {
+template <int M, int QI, int NQ, int NW, int WPS, bool SKEWED, int MODE>
+__global__ __launch_bounds__(NW * 64, WPS) void adc_scan_fast_kernel(const ScanArgs a) {
     constexpr int QT = QI * NQ;
     constexpr int CW = M / 4;              // dwords per code row
     constexpr int EB = QI * 4;             // bytes per LDS entry
@@ -175,9 +260,18 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_fast_kernel(const ScanArgs a
 #pragma unroll
     for (int i = 0; i < 8; ++i) abit[i] = (((s >> 2) >> i) & 1) != 0;
     // byte offset inside a (k,h) row for step t: ((s+t) mod M) * EB
-    uint32_t moff[M];
+    const unsigned char *mbase[M];
 #pragma unroll
-    for (int t = 0; t < M; ++t) moff[t] = (uint32_t)(((s + t) % M) * EB);
+    for (int t = 0; t < M; ++t) mbase[t] = smem + ((s + t) % M) * EB;
+    // MODE 1: per-lane pass weights (w1, w2) for every step
+    f32x2 wt[MODE >= 1 ? M : 1];
+    if constexpr (MODE >= 1) {
+#pragma unroll
+        for (int t = 0; t < M; ++t) {
+            const bool p1 = (s == 0) || (s >= M - t);
+            wt[t] = (f32x2){p1 ? 1.f : 0.f, p1 ? 0.f : 1.f};
+        }
+    }
 
     const int n_items = a.n_tiles * a.n_slices;
     const int64_t group_bytes = (int64_t)a.Ks * RB;  // one tiled-LUT group = [Ks][M][QI] floats
@@ -242,17 +336,41 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_fast_kernel(const ScanArgs a
             }
         };
 
+        // ---- software-pipelined row loop ---------------------------------------------------------
+        // A wave's look-ups of quad h+1 (or of the NEXT row's quad 0) are issued chunk by chunk (8 steps)
+        // as soon as pass 2 has consumed that chunk of the current quad, so the LDS latency of one chunk
+        // hides behind the adds of the other(s) inside the same 16 (M) value registers.
+        constexpr int NCH = M / 8;
+        const int64_t stride = (int64_t)NW * 64;
         int64_t row0 = slice_begin + (int64_t)wave * 64;
         uint32_t cnext[CW];
-        if (row0 < slice_end) load_row(row0 + lane, cnext);
+        const unsigned char *addr[M];  // LDS pointers (32-bit): smem + code*KSTRIDE + moff[t]
+        lutv_t val[M];
+        auto make_addr = [&](uint32_t (&cc)[CW]) {
+            if constexpr (!SKEWED) rotate_row<CW>(cc, abit, bsh);  // SKEWED tables are stored pre-rotated
+            static_for<0, M>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                const uint32_t code = __builtin_amdgcn_ubfe(cc[t / 4], 8 * (t % 4), 8);
+                addr[t] = mbase[t] + code * (uint32_t)KSTRIDE;
+            });
+        };
+        auto issue_chunk = [&](auto C, auto H) {
+            constexpr int c8 = decltype(C)::value * 8;
+            constexpr int hoff = decltype(H)::value * RB;
+            static_for<0, 8>([&](auto I) {
+                constexpr int t = c8 + decltype(I)::value;
+                val[t] = *(const lutv_t *)(addr[t] + hoff);
+            });
+        };
+        if (row0 < slice_end) {
+            uint32_t c0[CW];
+            load_row(row0 + lane, c0);
+            load_row(row0 + stride + lane, cnext);
+            make_addr(c0);
+            static_for<0, NCH>([&](auto C) { issue_chunk(C, std::integral_constant<int, 0>{}); });
+        }
 
-        for (; row0 < slice_end; row0 += (int64_t)NW * 64) {
-            uint32_t c[CW];
-#pragma unroll
-            for (int i = 0; i < CW; ++i) c[i] = cnext[i];
-            const int64_t rown = row0 + (int64_t)NW * 64;
-            if (rown < slice_end) load_row(rown + lane, cnext);  // software prefetch of the next group
-
+        for (; row0 < slice_end; row0 += stride) {
             // rows this wave-step may return
             unsigned long long vmask = ~0ull;
             if (slice_end - row0 < 64) vmask = (1ull << (int)(slice_end - row0)) - 1ull;
@@ -263,55 +381,98 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_fast_kernel(const ScanArgs a
                 vmask &= vb;
             }
 
-            if constexpr (!SKEWED) rotate_row<CW>(c, abit, bsh);  // SKEWED tables are stored pre-rotated
-
             f32x2 acc[NQ][NP];
 #pragma unroll
             for (int h = 0; h < NQ; ++h)
 #pragma unroll
                 for (int p = 0; p < NP; ++p) acc[h][p] = (f32x2){0.f, 0.f};
 
+            static_for<0, NQ>([&](auto H) {
+                constexpr int h = decltype(H)::value;
+                // ordered accumulation: pass 1 (steps t >= t0) over all chunks ...
+                static_for<0, NCH>([&](auto C) {
+                    constexpr int t0 = decltype(C)::value * 8;
+                    if constexpr (MODE == 2) {
+                        static_for<0, 8>([&](auto I) {
+                            constexpr int t = t0 + decltype(I)::value;
+                            if constexpr (QI == 4) {
+                                sfma(acc[h][0], ANNLITE_LOHALF(val[t]), wt[t].x);
+                                sfma(acc[h][1], ANNLITE_HIHALF(val[t]), wt[t].x);
+                            } else {
+                                sfma(acc[h][0], val[t], wt[t].x);
+                            }
+                        });
+                    } else if constexpr (MODE == 1) {
+                        static_for<0, 8>([&](auto I) {
+                            constexpr int t = t0 + decltype(I)::value;
+                            if constexpr (QI == 4) {
+                                wfma_p1(acc[h][0], ANNLITE_LOHALF(val[t]), wt[t]);
+                                wfma_p1(acc[h][1], ANNLITE_HIHALF(val[t]), wt[t]);
+                            } else {
+                                wfma_p1(acc[h][0], val[t], wt[t]);
+                            }
+                        });
+                    } else if constexpr (QI == 4) pass8_q4<M, t0, 0>(acc[h][0], acc[h][1], val);
+                    else pass8_q2<M, t0, 0>(acc[h][0], val);
+                });
+                // ... then pass 2 (t < t0) chunk by chunk, re-filling each chunk as soon as it is consumed
+                static_for<0, NCH>([&](auto C) {
+                    constexpr int cidx = decltype(C)::value;
+                    constexpr int t0 = cidx * 8;
+                    if constexpr (MODE == 2) {
+                        static_for<0, 8>([&](auto I) {
+                            constexpr int t = t0 + decltype(I)::value;
+                            if constexpr (QI == 4) {
+                                sfma(acc[h][0], ANNLITE_LOHALF(val[t]), wt[t].y);
+                                sfma(acc[h][1], ANNLITE_HIHALF(val[t]), wt[t].y);
+                            } else {
+                                sfma(acc[h][0], val[t], wt[t].y);
+                            }
+                        });
+                    } else if constexpr (MODE == 1) {
+                        static_for<0, 8>([&](auto I) {
+                            constexpr int t = t0 + decltype(I)::value;
+                            if constexpr (QI == 4) {
+                                wfma_p2(acc[h][0], ANNLITE_LOHALF(val[t]), wt[t]);
+                                wfma_p2(acc[h][1], ANNLITE_HIHALF(val[t]), wt[t]);
+                            } else {
+                                wfma_p2(acc[h][0], val[t], wt[t]);
+                            }
+                        });
+                    } else if constexpr (QI == 4) pass8_q4<M, t0, 1>(acc[h][0], acc[h][1], val);
+                    else pass8_q2<M, t0, 1>(acc[h][0], val);
+                    if constexpr (h + 1 < NQ) {
+                        issue_chunk(C, std::integral_constant<int, h + 1>{});
+                    } else {
+                        if constexpr (cidx == 0) {
+                            uint32_t cc[CW];
 #pragma unroll
-            for (int h = 0; h < NQ; ++h) {
-                lutv_t val[M];
-                static_for<0, M>([&](auto T) {
-                    constexpr int t = decltype(T)::value;
-                    const uint32_t code = (c[t / 4] >> (8 * (t % 4))) & 0xffu;
-                    const uint32_t addr = code * (uint32_t)KSTRIDE + moff[t];
-                    val[t] = *(const lutv_t *)(smem + addr + h * RB);
-                });
-                // ordered accumulation: pass 1 then pass 2, each ascending in t
-                static_for<0, M>([&](auto T) {
-                    constexpr int t = decltype(T)::value;
-                    constexpr unsigned long long mk = pass_mask<M>(t, 0);
-                    if constexpr (QI == 4) {
-                        masked_pk_add2<mk>(acc[h][0], acc[h][1], __builtin_shufflevector(val[t], val[t], 0, 1),
-                                           __builtin_shufflevector(val[t], val[t], 2, 3));
-                    } else {
-                        masked_pk_add1<mk>(acc[h][0], val[t]);
+                            for (int i = 0; i < CW; ++i) cc[i] = cnext[i];
+                            make_addr(cc);                                 // addresses of the next row
+                            load_row(row0 + 2 * stride + lane, cnext);    // global prefetch, two rows ahead
+                        }
+                        issue_chunk(C, std::integral_constant<int, 0>{});
                     }
                 });
-                static_for<0, M>([&](auto T) {
-                    constexpr int t = decltype(T)::value;
-                    constexpr unsigned long long mk = pass_mask<M>(t, 1);
-                    if constexpr (QI == 4) {
-                        masked_pk_add2<mk>(acc[h][0], acc[h][1], __builtin_shufflevector(val[t], val[t], 0, 1),
-                                           __builtin_shufflevector(val[t], val[t], 2, 3));
-                    } else {
-                        masked_pk_add1<mk>(acc[h][0], val[t]);
-                    }
-                });
-            }
+            });
 
-            // offer rows that can still enter a list (rare after warm-up)
+            // offer rows that can still enter a list (rare after warm-up): one branch for all queries
             const uint32_t rid = (uint32_t)(row0 + lane);
+            float dq[QT];
+            unsigned long long pmq[QT], any = 0;
 #pragma unroll
             for (int q = 0; q < QT; ++q) {
-                const float d = acc[q / QI][(q % QI) / 2][q % 2];
-                const unsigned long long pm = __ballot(d <= thr_f[q]) & vmask;
-                if (pm) {
-                    wavelist_offer(list[q], pm, f32_to_ordered(d), rid, km1, thr_hi[q], thr_lo[q], lane);
-                    thr_f[q] = (thr_hi[q] == kKeyInfHi) ? __builtin_inff() : ordered_to_f32(thr_hi[q]);
+                dq[q] = acc[q / QI][(q % QI) / 2][q % 2];
+                pmq[q] = __ballot(dq[q] <= thr_f[q]) & vmask;
+                any |= pmq[q];
+            }
+            if (any) {
+#pragma unroll
+                for (int q = 0; q < QT; ++q) {
+                    if (pmq[q]) {
+                        wavelist_offer(list[q], pmq[q], f32_to_ordered(dq[q]), rid, km1, thr_hi[q], thr_lo[q], lane);
+                        thr_f[q] = (thr_hi[q] == kKeyInfHi) ? __builtin_inff() : ordered_to_f32(thr_hi[q]);
+                    }
                 }
             }
         }
@@ -572,16 +733,35 @@ __global__ __launch_bounds__(256) void codes_skew_kernel(const uint8_t *__restri
 // host side
 // =================================================================================================
 struct FastCfg {
-    int M, QI, NQ, NW;
+    int M, QI, NQ, NW, WPS, wg_per_cu, id;
+    int mode;  // 0: exec-masked passes, 1: weight-fma passes
 };
+
+// Kernel variants per M.  ANNLITE_SCAN_VARIANT (env, read per call) selects among the M=16
+// instantiations for A/B measurements; variant 0 is the default for every M.
+static int scan_variant() {
+    const char *e = getenv("ANNLITE_SCAN_VARIANT");
+    return e ? atoi(e) : 0;
+}
 
 static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *c) {
     if (code_bytes != 1 || Ks > 256 || Ks < 1 || k > 64 || k < 1) return false;
+    const int v = scan_variant();
     switch (M) {
-        case 8: *c = {8, 4, 2, 8}; return true;
-        case 16: *c = {16, 4, 2, 8}; return true;
-        case 32: *c = {32, 4, 1, 8}; return true;
-        case 64: *c = {64, 2, 1, 8}; return true;
+        case 8: *c = {8, 4, 2, 8, 2, 1, 80, 0}; return true;
+        case 16:
+            if (v == 1) *c = {16, 4, 1, 8, 4, 2, 161, 0};        // QT=4, 2 workgroups / CU
+            else if (v == 2) *c = {16, 4, 2, 16, 4, 1, 162, 0};  // QT=8, 16 waves
+            else if (v == 3) *c = {16, 4, 2, 12, 3, 1, 163, 0};  // QT=8, 12 waves (3 / SIMD)
+            else if (v == 4) *c = {16, 4, 2, 8, 2, 1, 164, 1};   // QT=8, 8 waves, weight-fma
+            else if (v == 5) *c = {16, 4, 2, 12, 3, 1, 165, 1};  // QT=8, 12 waves, weight-fma
+            else if (v == 6) *c = {16, 4, 1, 8, 4, 2, 166, 1};   // QT=4, 2 WG / CU, weight-fma
+            else if (v == 7) *c = {16, 4, 2, 8, 2, 1, 167, 2};   // QT=8, 8 waves, scalar weight-fma
+            else if (v == 8) *c = {16, 4, 2, 8, 2, 1, 160, 0};   // QT=8, 8 waves, 1 workgroup / CU
+            else *c = {16, 4, 2, 12, 3, 1, 163, 0};              // default: QT=8, 12 waves (3 / SIMD)
+            return true;
+        case 32: *c = {32, 4, 1, 8, 2, 1, 320, 0}; return true;
+        case 64: *c = {64, 2, 1, 8, 2, 1, 640, 0}; return true;
         default: return false;
     }
 }
@@ -649,13 +829,13 @@ extern "C" int annlite_scan_plan_query(int64_t N, int64_t M, int64_t Ks, int cod
     return ANNLITE_OK;
 }
 
-template <int M, int QI, int NQ, int NW, bool SKEWED>
+template <int M, int QI, int NQ, int NW, int WPS, bool SKEWED, int MODE>
 static int launch_fast(const ScanArgs &a, int grid, hipStream_t st) {
     const size_t lds = (size_t)a.Ks * NQ * M * QI * 4;
     size_t need = lds;
     const size_t scratch = (size_t)QI * NQ * NW * 64 * 8;
     if (need < scratch) need = scratch;
-    auto fn = adc_scan_fast_kernel<M, QI, NQ, NW, SKEWED>;
+    auto fn = adc_scan_fast_kernel<M, QI, NQ, NW, WPS, SKEWED, MODE>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
     return launch_status("adc_scan_fast_kernel");
@@ -720,13 +900,29 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
     if (N == 0) return ANNLITE_OK;
     const int n_items = a.n_tiles * a.n_slices;
     if (plan.fast) {
-        int grid = n_items < n_cu ? n_items : n_cu;
+        FastCfg c;
+        fast_cfg(M, Ks, code_bytes, k, &c);
+        int grid = n_items < n_cu * c.wg_per_cu ? n_items : n_cu * c.wg_per_cu;
         const bool sk = codes_layout == ANNLITE_CODES_SKEWED;
         prof_begin(st);
-        if (M == 8) rc = sk ? launch_fast<8, 4, 2, 8, true>(a, grid, st) : launch_fast<8, 4, 2, 8, false>(a, grid, st);
-        else if (M == 16) rc = sk ? launch_fast<16, 4, 2, 8, true>(a, grid, st) : launch_fast<16, 4, 2, 8, false>(a, grid, st);
-        else if (M == 32) rc = sk ? launch_fast<32, 4, 1, 8, true>(a, grid, st) : launch_fast<32, 4, 1, 8, false>(a, grid, st);
-        else rc = sk ? launch_fast<64, 2, 1, 8, true>(a, grid, st) : launch_fast<64, 2, 1, 8, false>(a, grid, st);
+#define ANNLITE_LAUNCH_M(MM, QI_, NQ_, NW_, WPS_, MODE_) \
+    (sk ? launch_fast<MM, QI_, NQ_, NW_, WPS_, true, MODE_>(a, grid, st) : launch_fast<MM, QI_, NQ_, NW_, WPS_, false, MODE_>(a, grid, st))
+#define ANNLITE_LAUNCH(MM, QI_, NQ_, NW_, WPS_) ANNLITE_LAUNCH_M(MM, QI_, NQ_, NW_, WPS_, 0)
+        switch (c.id) {
+            case 80: rc = ANNLITE_LAUNCH(8, 4, 2, 8, 2); break;
+            case 160: rc = ANNLITE_LAUNCH(16, 4, 2, 8, 2); break;
+            case 161: rc = ANNLITE_LAUNCH(16, 4, 1, 8, 4); break;
+            case 162: rc = ANNLITE_LAUNCH(16, 4, 2, 16, 4); break;
+            case 163: rc = ANNLITE_LAUNCH(16, 4, 2, 12, 3); break;
+            case 164: rc = ANNLITE_LAUNCH_M(16, 4, 2, 8, 2, 1); break;
+            case 165: rc = ANNLITE_LAUNCH_M(16, 4, 2, 12, 3, 1); break;
+            case 166: rc = ANNLITE_LAUNCH_M(16, 4, 1, 8, 4, 1); break;
+            case 167: rc = ANNLITE_LAUNCH_M(16, 4, 2, 8, 2, 2); break;
+            case 320: rc = ANNLITE_LAUNCH(32, 4, 1, 8, 2); break;
+            default: rc = ANNLITE_LAUNCH(64, 2, 1, 8, 2); break;
+        }
+#undef ANNLITE_LAUNCH
+#undef ANNLITE_LAUNCH_M
         prof_end(st);
         return rc;
     }
