@@ -90,6 +90,56 @@ __device__ __forceinline__ bool key_less(uint32_t ahi, uint32_t alo, uint32_t bh
     return (ahi < bhi) || (ahi == bhi && alo < blo);
 }
 
+// ---- bulk path: bitonic networks over the 64 lanes (used when many rows arrive at once) ----------
+// compare-exchange with the lane `stride` away; keep_min lanes keep the smaller key
+__device__ __forceinline__ void wave_cmpx(uint32_t &hi, uint32_t &lo, int stride, bool keep_min) {
+    const uint32_t phi = __shfl_xor(hi, stride), plo = __shfl_xor(lo, stride);
+    const bool p_less = key_less(phi, plo, hi, lo);
+    if (keep_min == p_less) {
+        hi = phi;
+        lo = plo;
+    }
+}
+// ascending sort of one key per lane (21 compare-exchange stages)
+__device__ __forceinline__ void wave_sort64(uint32_t &hi, uint32_t &lo, int lane) {
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const bool asc = (lane & size) == 0;
+            const bool lower = (lane & stride) == 0;
+            wave_cmpx(hi, lo, stride, lower == asc);
+        }
+    }
+}
+// L <- the 64 smallest of (L  U  C) where C is ascending over the lanes: min(L[i], C[63-i]) is a
+// bitonic sequence holding exactly those 64, then a 6-stage bitonic merge sorts it
+__device__ __forceinline__ void wavelist_merge_sorted(WaveList &L, uint32_t chi, uint32_t clo, int lane) {
+    const uint32_t rhi = __shfl(chi, 63 - lane), rlo = __shfl(clo, 63 - lane);
+    if (key_less(rhi, rlo, L.hi, L.lo)) {
+        L.hi = rhi;
+        L.lo = rlo;
+    }
+#pragma unroll
+    for (int stride = 32; stride > 0; stride >>= 1) wave_cmpx(L.hi, L.lo, stride, (lane & stride) == 0);
+}
+// insert the candidates of the lanes in `pm` (unconditionally; worse-than-64th entries fall off)
+__device__ __forceinline__ void wavelist_insert_many(WaveList &L, unsigned long long pm, uint32_t hi, uint32_t lo,
+                                                     int lane) {
+    if (__popcll(pm) > 8) {
+        const bool mine = (pm >> lane) & 1ull;
+        uint32_t chi = mine ? hi : kKeyInfHi, clo = mine ? lo : kIdNone;
+        wave_sort64(chi, clo, lane);
+        wavelist_merge_sorted(L, chi, clo, lane);
+    } else {
+        while (pm) {
+            const int src = __builtin_ctzll(pm);
+            pm &= pm - 1;
+            wavelist_insert(L, __builtin_amdgcn_readlane(hi, src), __builtin_amdgcn_readlane(lo, src), lane);
+        }
+    }
+}
+
 // Offer every lane's candidate (hi, lo) where `pm` has a bit set; keeps the list exact.
 // thr_hi/thr_lo = key of the current k-th entry (wave-uniform), updated on every insertion.
 __device__ __forceinline__ void wavelist_offer(WaveList &L, unsigned long long pm, uint32_t hi, uint32_t lo,

@@ -48,6 +48,7 @@ struct ScanArgs {
     int32_t n_tiles;
     int32_t n_slices;
     int64_t slice_rows;      // multiple of 64
+    const float *smax;       // [ceil16(B)] sum_m max_k |lut[b][m][k]|  (filter kernel: rounding slack)
 };
 
 // ---- compile-time exec masks for the ordered accumulation ---------------------------------------
@@ -185,6 +186,23 @@ __device__ __forceinline__ void sfma(f32x2 &acc, const f32x2 v, const float w) {
     acc.x = ax;
     acc.y = ay;
 }
+
+// (code byte B of a dword) << SH in ONE VOP2-SDWA op (v_bfe_u32 + v_lshl_add_u32 are two 4.5-cycle VOP3 ops,
+// scripts/valu_ubench.hip)
+template <int BYTE>
+__device__ __forceinline__ uint32_t byte_shl(uint32_t dword, uint32_t sh) {
+    uint32_t r;
+    if constexpr (BYTE == 0)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "s"(sh), "v"(dword));
+    else if constexpr (BYTE == 1)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "s"(sh), "v"(dword));
+    else if constexpr (BYTE == 2)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "s"(sh), "v"(dword));
+    else
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "s"(sh), "v"(dword));
+    return r;
+}
+constexpr int ilog2_c(int x) { return x <= 1 ? 0 : 1 + ilog2_c(x / 2); }
 
 // ---- compile-time loops -------------------------------------------------------------------------
 template <int I, int N, typename F>
@@ -503,6 +521,285 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_fast_kernel(const ScanA
     }
 }
 
+
+// =================================================================================================
+// Filter kernel (default): the VALU cost of the ordered two-pass sum (2 lane-masked adds per
+// look-up) bounds adc_scan_fast_kernel, so this version
+//   1. adds the M values of a row in the lane's ROTATED order -- ONE plain v_pk_add_f32 per two
+//      look-ups, values consumed as they arrive.  |d_fast - d_exact| <= 2*gamma_{M-1} * sum_m|v_m|
+//      <= slack[q] := 2*M*2^-24 * Smax[q] * (1+2^-10), Smax[q] = sum_m max_k |lut[q][m][k]|
+//      (lut_smax_kernel), because both are fp32 summations of the same M terms;
+//   2. FILTERS: a row can only be in the top-k if d_exact <= thr, hence d_fast <= thr + slack;
+//   3. for the few rows that pass, recomputes the EXACT ascending-m sum from the still-held
+//      values (the two-pass masked add of the fast kernel) and offers (ordered(d_exact), id);
+//   4. shares the k-th key between the waves of the workgroup through LDS (atomic min), so all
+//      waves filter with the tightest bound any of them has proven;
+//   5. inserts floods (first step of a work item) with a bitonic sort + merge instead of one
+//      by one.
+// Returned distances and ids are bit-identical to the fast kernel / the oracle.
+// LDS: [LUT tile Ks*KSTRIDE][shthr f32 x QT (thr+slack) @ +0][shkey u64 x QT @ +64]
+// =================================================================================================
+template <int M, int NQ, int NW, int WPS, bool SKEWED, bool DBUF>
+__global__ __launch_bounds__(NW * 64, WPS) void adc_scan_filter_kernel(const ScanArgs a) {
+    constexpr int QI = 4;
+    constexpr int QT = QI * NQ;
+    constexpr int CW = M / 4;
+    constexpr int EB = QI * 4;
+    constexpr int RB = M * EB;
+    constexpr int KSTRIDE = NQ * RB;
+    static_assert(M % 8 == 0 && M <= 32, "QI=4 instantiations only");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int km1 = a.k - 1;
+    const int s = lane % M;
+    const uint32_t bsh = (uint32_t)(s & 3);
+    bool abit[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) abit[i] = (((s >> 2) >> i) & 1) != 0;
+    const unsigned char *mbase[M];
+#pragma unroll
+    for (int t = 0; t < M; ++t) mbase[t] = smem + ((s + t) % M) * EB;
+
+    const int lut_bytes = a.Ks * KSTRIDE;
+    volatile float *shthr = (volatile float *)(smem + lut_bytes);
+    unsigned long long *shkey = (unsigned long long *)(smem + lut_bytes + 64);
+
+    const int n_items = a.n_tiles * a.n_slices;
+    const int64_t group_bytes = (int64_t)a.Ks * RB;
+
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int xcd = item & 7;
+        const int j = item >> 3;
+        const int tile = j % a.n_tiles;
+        const int slice = (j / a.n_tiles) * 8 + xcd;
+
+        __syncthreads();
+        {
+            const unsigned char *src0 = (const unsigned char *)a.lut + (int64_t)tile * NQ * group_bytes;
+            constexpr int PIECES_PER_ROW = RB / 16;
+            const int total = NQ * a.Ks * PIECES_PER_ROW;
+            for (int idx = tid; idx < total; idx += NW * 64) {
+                const int p = idx % PIECES_PER_ROW;
+                const int kh = idx / PIECES_PER_ROW;
+                const int h = kh / a.Ks;
+                const int kk = kh - h * a.Ks;
+                const u32x4 v = *(const u32x4 *)(src0 + (int64_t)h * group_bytes + (int64_t)kk * RB + p * 16);
+                *(u32x4 *)(smem + (kk * NQ + h) * RB + p * 16) = v;
+            }
+            if (tid < QT) {
+                shthr[tid] = __builtin_inff();
+                shkey[tid] = ~0ull;
+            }
+        }
+        float slack[QT];
+#pragma unroll
+        for (int q = 0; q < QT; ++q)
+            slack[q] = a.smax[tile * QT + q] * (float)(2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
+        __syncthreads();
+
+        WaveList list[QT];
+#pragma unroll
+        for (int q = 0; q < QT; ++q) list[q].reset();
+
+        const int64_t slice_begin = (int64_t)slice * a.slice_rows;
+        int64_t slice_end = slice_begin + a.slice_rows;
+        if (slice_end > a.N) slice_end = a.N;
+
+        const uint32_t *codes32 = (const uint32_t *)a.codes;
+        auto load_row = [&](int64_t row, uint32_t (&c)[CW]) {
+            if (row >= a.N) row = a.N - 1;
+            const uint32_t *p = codes32 + row * CW;
+            if constexpr (CW == 2) {
+                const u32x2 v = *(const u32x2 *)p;
+                c[0] = v.x;
+                c[1] = v.y;
+            } else {
+#pragma unroll
+                for (int i = 0; i < CW / 4; ++i) {
+                    const u32x4 v = *(const u32x4 *)(p + 4 * i);
+                    c[4 * i + 0] = v.x;
+                    c[4 * i + 1] = v.y;
+                    c[4 * i + 2] = v.z;
+                    c[4 * i + 3] = v.w;
+                }
+            }
+        };
+
+        const int64_t stride = (int64_t)NW * 64;
+        int64_t row0 = slice_begin + (int64_t)wave * 64;
+        uint32_t cnext[CW];
+        const unsigned char *addr[M];
+        // DBUF: one landing buffer per entry group -- the next row's look-ups of group h are issued as
+        // soon as group h of the current row has been filtered (more look-ups in flight per wave,
+        // ~64 more VGPRs).  !DBUF: one buffer, refilled with the NEXT group right after the filter
+        // (fewer registers -> more waves per SIMD).
+        constexpr int NB = DBUF ? NQ : 1;
+        f32x4 val[NB][M];
+        auto make_addr = [&](uint32_t (&cc)[CW]) {
+            if constexpr (!SKEWED) rotate_row<CW>(cc, abit, bsh);
+            static_for<0, M>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                static_assert((KSTRIDE & (KSTRIDE - 1)) == 0, "KSTRIDE must be a power of two");
+                addr[t] = mbase[t] + byte_shl<t % 4>(cc[t / 4], (uint32_t)ilog2_c(KSTRIDE));
+            });
+        };
+        auto issue_group = [&](auto H) {
+            constexpr int h = decltype(H)::value;
+            static_for<0, M>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                val[DBUF ? h : 0][t] = *(const f32x4 *)(addr[t] + h * RB);
+            });
+        };
+        // workgroup bound (thr + slack) of each group's 4 queries, re-read every step.  LDS returns
+        // in order, so the read is issued BEFORE the refill look-ups of the group and consumed one
+        // step later -- reading it at the point of use would drain the whole look-up queue.
+        f32x4 th[NQ];
+#pragma unroll
+        for (int h = 0; h < NQ; ++h) th[h] = *(const f32x4 *)(smem + lut_bytes + h * 16);
+        if (row0 < slice_end) {
+            uint32_t c0[CW];
+            load_row(row0 + lane, c0);
+            load_row(row0 + stride + lane, cnext);
+            make_addr(c0);
+            static_for<0, NB>([&](auto H) { issue_group(H); });
+        }
+
+        int step_no = 0;
+        for (; row0 < slice_end; row0 += stride, ++step_no) {
+            unsigned long long vmask = ~0ull;
+            if (slice_end - row0 < 64) vmask = (1ull << (int)(slice_end - row0)) - 1ull;
+            if (a.valid) {
+                const uint32_t *vw = a.valid + (row0 >> 5);
+                unsigned long long vb = (unsigned long long)vw[0];
+                if (row0 + 32 < a.N) vb |= (unsigned long long)vw[1] << 32;
+                vmask &= vb;
+            }
+            const uint32_t rid = (uint32_t)(row0 + lane);
+            const bool refresh = (step_no & 3) == 0;  // other waves' bounds are picked up every 4th step
+
+            static_for<0, NQ>([&](auto H) {
+                constexpr int h = decltype(H)::value;
+                constexpr int hb = DBUF ? h : 0;
+                // 1. fast sum, rotated order
+                f32x4 fs = val[hb][0];
+                static_for<1, M>([&](auto T) { fs += val[hb][decltype(T)::value]; });
+                // 2. filter
+                unsigned long long pm[4], any = 0;
+#pragma unroll
+                for (int jq = 0; jq < 4; ++jq) {
+                    pm[jq] = __ballot(fs[jq] <= th[h][jq]) & vmask;
+                    any |= pm[jq];
+                }
+                if (any) {
+                    // 3. exact ascending-m sums of the 4 queries from the held values
+                    f32x2 e0 = {0.f, 0.f}, e1 = {0.f, 0.f};
+                    static_for<0, 2>([&](auto P) {
+                        static_for<0, M / 8>([&](auto C) {
+                            pass8_q4<M, decltype(C)::value * 8, decltype(P)::value>(e0, e1, val[hb]);
+                        });
+                    });
+                    const float ex[4] = {e0.x, e0.y, e1.x, e1.y};
+#pragma unroll
+                    for (int jq = 0; jq < 4; ++jq) {
+                        if (pm[jq]) {
+                            const int q = h * 4 + jq;
+                            const uint32_t khi = f32_to_ordered(ex[jq]);
+                            const unsigned long long sk = *(volatile unsigned long long *)(shkey + q);
+                            const uint32_t skhi = (uint32_t)(sk >> 32), sklo = (uint32_t)sk;
+                            const unsigned long long px = __ballot(key_less(khi, rid, skhi, sklo)) & pm[jq];
+                            if (px) {
+                                wavelist_insert_many(list[q], px, khi, rid, lane);
+                                // 4. publish this wave's k-th key if it tightens the workgroup bound
+                                const uint32_t ohi = __builtin_amdgcn_readlane(list[q].hi, km1);
+                                const uint32_t olo = __builtin_amdgcn_readlane(list[q].lo, km1);
+                                if (lane == 0 && ohi != kKeyInfHi) {
+                                    const unsigned long long mine = ((unsigned long long)ohi << 32) | olo;
+                                    const unsigned long long old = atomicMin(shkey + q, mine);
+                                    if (mine < old) shthr[q] = ordered_to_f32(ohi) + slack[q];
+                                }
+                            }
+                        }
+                    }
+                }
+                // plain LDS read (ds_read_b128) behind a compiler barrier so it is re-issued every step; a
+                // volatile access would be lowered to a FLAT load + vmcnt(0)/lgkmcnt(0) drains
+                if (refresh) {
+                    asm volatile("" ::: "memory");
+                    th[h] = *(const f32x4 *)(smem + lut_bytes + h * 16);
+                }
+                if constexpr (DBUF) {
+                    // refill this group's buffer with the next row's look-ups
+                    if constexpr (h == 0) {
+                        uint32_t cc[CW];
+#pragma unroll
+                        for (int i = 0; i < CW; ++i) cc[i] = cnext[i];
+                        make_addr(cc);
+                        load_row(row0 + 2 * stride + lane, cnext);
+                    }
+                    issue_group(H);
+                } else if constexpr (h + 1 < NQ) {
+                    issue_group(std::integral_constant<int, h + 1>{});  // next group of the same row
+                } else {
+                    uint32_t cc[CW];
+#pragma unroll
+                    for (int i = 0; i < CW; ++i) cc[i] = cnext[i];
+                    make_addr(cc);
+                    load_row(row0 + 2 * stride + lane, cnext);
+                    issue_group(std::integral_constant<int, 0>{});  // first group of the next row
+                }
+            });
+        }
+
+        // ---- merge the NW per-wave lists of each query through LDS (re-using the LUT space) -----
+        __syncthreads();
+        unsigned long long *scratch = (unsigned long long *)smem;  // [QT][NW][64]
+#pragma unroll
+        for (int q = 0; q < QT; ++q)
+            scratch[(q * NW + wave) * 64 + lane] = ((unsigned long long)list[q].hi << 32) | list[q].lo;
+        __syncthreads();
+        for (int q = wave; q < QT; q += NW) {
+            WaveList L;
+            unsigned long long key = scratch[(q * NW + 0) * 64 + lane];
+            L.hi = (uint32_t)(key >> 32);
+            L.lo = (uint32_t)key;
+            for (int w = 1; w < NW; ++w) {
+                key = scratch[(q * NW + w) * 64 + lane];
+                // every wave list is ascending over the lanes: sorted merge, keep the 64 smallest
+                wavelist_merge_sorted(L, (uint32_t)(key >> 32), (uint32_t)key, lane);
+            }
+            const int b = tile * QT + q;
+            if (b < a.B && lane <= km1)
+                a.partial[((int64_t)b * a.n_slices + slice) * a.k + lane] = ((unsigned long long)L.hi << 32) | L.lo;
+        }
+    }
+}
+
+// Smax[b] = sum_m max_k |lut[b][m][k]| from the TILED table [Bpad/QI][Ks][M][QI]; one wave per group
+__global__ __launch_bounds__(256) void lut_smax_kernel(const float *__restrict__ lut, int n_groups, int M, int Ks,
+                                                      int QI, float *__restrict__ smax) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= n_groups) return;
+    const float *base = lut + (int64_t)g * Ks * M * QI;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < M; ++m) {
+        float mx[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = lane; k < Ks; k += 64)
+            for (int i = 0; i < QI; ++i) mx[i] = fmaxf(mx[i], fabsf(base[((int64_t)k * M + m) * QI + i]));
+        for (int i = 0; i < QI; ++i) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], o));
+            acc[i] += mx[i];
+        }
+    }
+    if (lane == 0)
+        for (int i = 0; i < QI; ++i) smax[g * QI + i] = acc[i];
+}
+
 // =================================================================================================
 // Generic kernel: any M / Ks / code width (1,2,4 bytes), k <= 64.  One query per workgroup, the
 // table is read through L2 in the reference's [B][M][Ks] layout.  Correct for every shape the
@@ -734,7 +1031,7 @@ __global__ __launch_bounds__(256) void codes_skew_kernel(const uint8_t *__restri
 // =================================================================================================
 struct FastCfg {
     int M, QI, NQ, NW, WPS, wg_per_cu, id;
-    int mode;  // 0: exec-masked passes, 1: weight-fma passes
+    int mode;  // 0: exec-masked passes, 1/2: weight-fma passes, 3: FILTER kernel (fast sum + exact recompute)
 };
 
 // Kernel variants per M.  ANNLITE_SCAN_VARIANT (env, read per call) selects among the M=16
@@ -748,8 +1045,16 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
     if (code_bytes != 1 || Ks > 256 || Ks < 1 || k > 64 || k < 1) return false;
     const int v = scan_variant();
     switch (M) {
-        case 8: *c = {8, 4, 2, 8, 2, 1, 80, 0}; return true;
+        case 8:
+            if (v >= 20) *c = {8, 4, 2, 8, 2, 1, 80, 0};
+            else *c = {8, 4, 2, 8, 2, 1, 81, 3};
+            return true;
         case 16:
+            if (v == 0) { *c = {16, 4, 2, 12, 3, 1, 1601, 3}; return true; }  // default: filter kernel, 12 waves, single buffer
+            if (v == 9) { *c = {16, 4, 2, 8, 2, 1, 1600, 3}; return true; }   // filter kernel, 8 waves, double buffer
+            if (v == 10) { *c = {16, 4, 2, 12, 3, 1, 1601, 3}; return true; }  // filter kernel, 12 waves, single buffer
+            if (v == 11) { *c = {16, 4, 1, 8, 4, 2, 1602, 3}; return true; }   // filter kernel, QT=4, 2 WG / CU
+            if (v == 12) { *c = {16, 4, 2, 16, 4, 1, 1603, 3}; return true; }  // filter kernel, 16 waves, single buffer
             if (v == 1) *c = {16, 4, 1, 8, 4, 2, 161, 0};        // QT=4, 2 workgroups / CU
             else if (v == 2) *c = {16, 4, 2, 16, 4, 1, 162, 0};  // QT=8, 16 waves
             else if (v == 3) *c = {16, 4, 2, 12, 3, 1, 163, 0};  // QT=8, 12 waves (3 / SIMD)
@@ -758,9 +1063,12 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
             else if (v == 6) *c = {16, 4, 1, 8, 4, 2, 166, 1};   // QT=4, 2 WG / CU, weight-fma
             else if (v == 7) *c = {16, 4, 2, 8, 2, 1, 167, 2};   // QT=8, 8 waves, scalar weight-fma
             else if (v == 8) *c = {16, 4, 2, 8, 2, 1, 160, 0};   // QT=8, 8 waves, 1 workgroup / CU
-            else *c = {16, 4, 2, 12, 3, 1, 163, 0};              // default: QT=8, 12 waves (3 / SIMD)
+            else *c = {16, 4, 2, 12, 3, 1, 163, 0};              // (v >= 20) two-pass kernel, QT=8, 12 waves
             return true;
-        case 32: *c = {32, 4, 1, 8, 2, 1, 320, 0}; return true;
+        case 32:
+            if (v >= 20) *c = {32, 4, 1, 8, 2, 1, 320, 0};
+            else *c = {32, 4, 1, 8, 2, 1, 321, 3};
+            return true;
         case 64: *c = {64, 2, 1, 8, 2, 1, 640, 0}; return true;
         default: return false;
     }
@@ -788,6 +1096,18 @@ static void plan_slices(int64_t N, int n_tiles, int waves, int n_cu, bool xcd8, 
 
 using namespace annlite;
 
+template <int M, int NQ, int NW, int WPS, bool SKEWED, bool DBUF>
+static int launch_filter(const ScanArgs &a, int grid, hipStream_t st) {
+    const size_t lds_lut = (size_t)a.Ks * NQ * M * 16;
+    size_t need = lds_lut + 128;
+    const size_t scratch = (size_t)4 * NQ * NW * 64 * 8;
+    if (need < scratch) need = scratch;
+    auto fn = adc_scan_filter_kernel<M, NQ, NW, WPS, SKEWED, DBUF>;
+    ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
+    return launch_status("adc_scan_filter_kernel");
+}
+
 extern "C" int annlite_scan_plan_query(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t k,
                                        annlite_scan_plan *plan) {
     ANNLITE_REQUIRE(plan != nullptr, "plan is NULL");
@@ -812,7 +1132,8 @@ extern "C" int annlite_scan_plan_query(int64_t N, int64_t M, int64_t Ks, int cod
         plan_slices(N > 0 ? N : 1, n_tiles > 0 ? n_tiles : 1, c.NW, n_cu, true, &ns, &sr);
         plan->n_slices = ns;
         plan->lut_floats = ((B + 15) / 16) * 16 * M * Ks;  // padded to 16 queries
-        plan->workspace_bytes = (int64_t)n_tiles * plan->qt * ns * k * 8;
+        // [partial keys][Smax f32 x ceil16(B)]
+        plan->workspace_bytes = (int64_t)n_tiles * plan->qt * ns * k * 8 + ((B + 15) / 16) * 16 * 4 + 256;
     } else {
         plan->fast = 0;
         plan->qi = 1;
@@ -889,6 +1210,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
     a.k = (int)k;
     a.n_tiles = (int)((B + plan.qt - 1) / plan.qt);
     a.n_slices = plan.n_slices;
+    a.smax = nullptr;
     {
         int ns;
         int64_t sr;
@@ -904,11 +1226,30 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         fast_cfg(M, Ks, code_bytes, k, &c);
         int grid = n_items < n_cu * c.wg_per_cu ? n_items : n_cu * c.wg_per_cu;
         const bool sk = codes_layout == ANNLITE_CODES_SKEWED;
+        if (c.mode == 3) {
+            // rounding slack of the fast filter sum needs Smax[b] = sum_m max_k |lut[b][m][k]|
+            const int64_t part_bytes = (int64_t)a.n_tiles * plan.qt * plan.n_slices * k * 8;
+            float *smax = (float *)((char *)workspace_dev + ((part_bytes + 255) / 256) * 256);
+            const int n_groups = (int)(((B + 15) / 16) * 16 / c.QI);
+            hipLaunchKernelGGL(lut_smax_kernel, dim3((n_groups + 3) / 4), dim3(256), 0, st, lut_dev, n_groups, (int)M,
+                               (int)Ks, c.QI, smax);
+            rc = launch_status("lut_smax_kernel");
+            if (rc != ANNLITE_OK) return rc;
+            a.smax = smax;
+        }
         prof_begin(st);
+#define ANNLITE_LAUNCH_F(MM, NQ_, NW_, WPS_, DB_) \
+    (sk ? launch_filter<MM, NQ_, NW_, WPS_, true, DB_>(a, grid, st) : launch_filter<MM, NQ_, NW_, WPS_, false, DB_>(a, grid, st))
 #define ANNLITE_LAUNCH_M(MM, QI_, NQ_, NW_, WPS_, MODE_) \
     (sk ? launch_fast<MM, QI_, NQ_, NW_, WPS_, true, MODE_>(a, grid, st) : launch_fast<MM, QI_, NQ_, NW_, WPS_, false, MODE_>(a, grid, st))
 #define ANNLITE_LAUNCH(MM, QI_, NQ_, NW_, WPS_) ANNLITE_LAUNCH_M(MM, QI_, NQ_, NW_, WPS_, 0)
         switch (c.id) {
+            case 81: rc = ANNLITE_LAUNCH_F(8, 2, 8, 2, true); break;
+            case 1600: rc = ANNLITE_LAUNCH_F(16, 2, 8, 2, true); break;
+            case 1601: rc = ANNLITE_LAUNCH_F(16, 2, 12, 3, false); break;
+            case 1602: rc = ANNLITE_LAUNCH_F(16, 1, 8, 4, true); break;
+            case 1603: rc = ANNLITE_LAUNCH_F(16, 2, 16, 4, false); break;
+            case 321: rc = ANNLITE_LAUNCH_F(32, 1, 8, 2, true); break;
             case 80: rc = ANNLITE_LAUNCH(8, 4, 2, 8, 2); break;
             case 160: rc = ANNLITE_LAUNCH(16, 4, 2, 8, 2); break;
             case 161: rc = ANNLITE_LAUNCH(16, 4, 1, 8, 4); break;
@@ -923,6 +1264,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         }
 #undef ANNLITE_LAUNCH
 #undef ANNLITE_LAUNCH_M
+#undef ANNLITE_LAUNCH_F
         prof_end(st);
         return rc;
     }

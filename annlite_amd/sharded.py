@@ -13,6 +13,7 @@ The scan and the merge are injected callables so that the partition / gather log
 by world_size-2 ``gloo`` tests on CPU (tests/test_sharded_gloo.py) with the oracle standing in for
 the kernels; the product wiring (``ShardedPQIndex``) always uses the HIP kernels.
 """
+import os
 from typing import Callable, Optional, Tuple
 
 import numpy as np
@@ -32,8 +33,10 @@ def shard_range(n_total: int, world_size: int, rank: int) -> Tuple[int, int]:
 def gather_and_merge(local_d: torch.Tensor, local_i: torch.Tensor, merge_fn: Callable,
                      group: Optional[dist.ProcessGroup] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """all-gather the per-shard top-k lists and merge them; every rank returns the global result."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local_d, local_i
+    if dist.get_world_size(group) == 1 and not os.environ.get('ANNLITE_FORCE_GATHER'):
+        return local_d, local_i  # (the env switch lets a 1-GPU box exercise the RCCL + merge path)
     G = dist.get_world_size(group)
     B, k = local_d.shape
     # concatenation form ([G*B, k]): accepted by both RCCL and gloo; viewed as [G, B, k] for the merge

@@ -15,7 +15,7 @@ the global top-k.
 One "step" = the whole hot path for one batch: LUT build (tiled layout) -> ADC scan + per-shard
 top-k -> (N>1: all-gather + merge).  Inputs (queries, codebooks, codes) are resident in HBM before
 the timed region.  Prints ONE JSON line on rank 0 with the driver's contract fields plus
-`roofline` (dominant kernel = adc_scan_fast_kernel, algorithmic bytes B*N_local*M per launch over
+`roofline` (dominant kernel = adc_scan_filter_kernel, algorithmic bytes B*N_local*M per launch over
 its HIP-event duration, vs the 8 TB/s HBM peak -- the kernel actually runs out of LDS)
 and `cpu_baseline` (the C oracle, single thread = the reference's execution model, bounded sample).
 """
@@ -72,7 +72,8 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or 'RANK' in os.environ  # torchrun with 1 rank also initialises RCCL
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)
 
@@ -164,6 +165,18 @@ def main():
     scan_bytes = float(B) * n_local * M  # algorithmic code bytes consumed per launch
     achieved = scan_bytes / (kernel_ms * 1e-3) / 1e9
     lookups_per_s = float(B) * n_local * M / (kernel_ms * 1e-3)
+
+    # measured HBM traffic of the same launch, from the committed rocprofv3 PMC pass (FETCH_SIZE x2
+    # gfx950 correction + WRITE_SIZE, profiles/*/traffic.json); bench.py cannot run rocprof on itself
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+            tj = json.load(f)
+        key = f'{n_local}x{M}x{B}'
+        if key in tj:
+            traffic = tj[key]['hbm_bytes_per_launch']
+    except Exception:
+        traffic = None
 
     # ---- recall@10 vs exact brute force (subset of the queries), ADC-only and with re-rank ---------
     recall_adc = recall_rr = None
@@ -262,14 +275,14 @@ def main():
                                                        'candidates_per_query': 'n_slices*64 per shard'},
             'roofline': {
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                'traffic': None, 'kernel': 'adc_scan_fast_kernel', 'kernel_ms': kernel_ms,
+                'traffic': traffic, 'kernel': 'adc_scan_filter_kernel', 'kernel_ms': kernel_ms,
                 'algorithmic_bytes_per_launch': scan_bytes, 'lds_lookups_per_s': lookups_per_s,
             },
             'cpu_baseline': cpu,
             'setup': {'train_s': train_s, 'index_s': index_s},
         }
         print(json.dumps(rec))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
