@@ -432,3 +432,78 @@ def test_kmeans_fit_quality_vs_sklearn(ops):
         c2.partial_fit(x[s:s + 500])
     c2.build_codebook()
     assert c2.codebooks.shape == c.codebooks.shape and c2.is_trained
+
+
+# ------------------------------------------------------------------------------------ filter-kernel specific
+def test_filter_slack_with_badly_conditioned_tables(ops, oracle):
+    """The default scan kernel filters with a sum taken in a per-lane ROTATED order and recomputes the
+    exact ascending-m sum only for rows inside `thr + slack`.  Tables whose entries span 12 orders of
+    magnitude make the two summation orders differ in the leading bits; ids and distances must still be
+    the oracle's, bit for bit, for every lane skew (rows 0..63 of a wave-step have different orders)."""
+    rs = np.random.RandomState(77)
+    M, Ks, N, B, k = 16, 256, 20000, 16, 25
+    mag = 10.0 ** rs.uniform(-6, 6, size=(B, M, 1))
+    lut = (rs.rand(B, M, Ks) * mag).astype(np.float32)
+    lut[1] = -lut[1]                      # all-negative table
+    lut[2, ::2] = -lut[2, ::2]            # mixed signs: catastrophic cancellation between sub-spaces
+    lut[3] = np.float32(1e-30) * rs.rand(M, Ks).astype(np.float32)  # denormal-range sums
+    codes = rs.randint(0, Ks, size=(N, M)).astype(np.uint8)
+    codes[5000:5064] = codes[5000]        # a full wave-step of duplicates: 64 exact ties, 64 different skews
+    for layout in (0, 1):
+        d, i, plan = _scan(ops, codes, lut, k, layout)
+        assert plan.fast
+        rd, ri = oracle.adc_search_c(lut, codes, k)
+        assert np.array_equal(d, rd)
+        assert np.array_equal(i, ri)
+
+
+@pytest.mark.parametrize('variant', ['0', '9', '11', '20'])
+def test_scan_kernel_variants_agree(ops, oracle, variant, monkeypatch):
+    """every selectable M=16 scan kernel (filter 12-wave / 8-wave double buffer / QT=4, two-pass) is bit-exact"""
+    monkeypatch.setenv('ANNLITE_SCAN_VARIANT', variant)
+    rs = np.random.RandomState(3)
+    M, Ks, N, B, k = 16, 256, 70000, 40, 10
+    lut = rs.rand(B, M, Ks).astype(np.float32)
+    codes = rs.randint(0, Ks, size=(N, M)).astype(np.uint8)
+    d, i, _ = _scan(ops, codes, lut, k, 1)
+    rd, ri = oracle.adc_search_c(lut, codes, k)
+    assert np.array_equal(d, rd) and np.array_equal(i, ri)
+
+
+def test_full_size_properties_config2(ops, oracle):
+    """BASELINE config 2 at full size (1M x 128-d, PQ m=16, batch 1024, k=10) through size-independent
+    properties: ascending order, every returned distance equals the gathered ADC distance of that row
+    (adc_gather kernel = space_pq.h PQLookup), a second run is identical (idempotence), PLAIN and SKEWED
+    tables agree, and a sample of queries equals the CPU oracle exactly."""
+    import torch
+    from annlite_amd._capi import LAYOUT_BMK, LAYOUT_TILED, LUT_L2, scan_plan
+
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    N, D, M, Ks, B, k = 1_000_000, 128, 16, 256, 1024, 10
+    cb = torch.randn((M, Ks, D // M), generator=g, device=dev)
+    x = torch.randn((N, D), generator=g, device=dev)
+    q = torch.randn((B, D), generator=g, device=dev)
+    codes = ops.pq_encode(x, cb)
+    plan = scan_plan(N, M, Ks, 1, B, k)
+    lut_t = ops.lut_build(q, cb, LUT_L2, LAYOUT_TILED, plan.qi)
+    lut_b = ops.lut_build(q, cb, LUT_L2, LAYOUT_BMK)
+    d, i = ops.adc_scan_topk(codes, lut_t, B, k, M, Ks)
+    d2, i2 = ops.adc_scan_topk(ops.codes_skew(codes), lut_t, B, k, M, Ks, codes_layout=1)
+    d3, i3 = ops.adc_scan_topk(codes, lut_t, B, k, M, Ks)
+    torch.cuda.synchronize()
+    assert torch.equal(d, d2) and torch.equal(i, i2) and torch.equal(d, d3) and torch.equal(i, i3)
+    assert bool((d[:, 1:] >= d[:, :-1]).all())
+    ties = d[:, 1:] == d[:, :-1]
+    assert bool((i[:, 1:][ties] > i[:, :-1][ties]).all())
+    assert bool(((i >= 0) & (i < N)).all())
+    assert torch.equal(ops.adc_gather(lut_b, codes, i), d)
+    # threshold property on a few queries: no row outside the result beats the k-th distance
+    for b in (0, 511, 1023):
+        full = ops.adc_dist(lut_b[b], codes)
+        assert int((full < d[b, -1]).sum().item()) <= k - 1
+    codes_np = codes.cpu().numpy()
+    sel = [0, 1, 500, 1023]
+    rd, ri = oracle.adc_search_c(lut_b[sel].cpu().numpy(), codes_np, k)
+    assert np.array_equal(d[sel].cpu().numpy(), rd) and np.array_equal(i[sel].cpu().numpy(), ri)
