@@ -46,6 +46,7 @@ SYMBOLS = (
     'annlite_codes_skew',
     'annlite_profile_enable',
     'annlite_profile_last_scan_ms',
+    'annlite_debug_counters',
 )
 
 
@@ -105,6 +106,7 @@ def lib() -> ctypes.CDLL:
     L.annlite_codes_skew.argtypes = [vp, i64, i64, vp, i64, vp, i32, vp]
     L.annlite_profile_enable.argtypes = [i32]
     L.annlite_profile_last_scan_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]
+    L.annlite_debug_counters.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     for name in SYMBOLS:
         fn = getattr(L, name)  # AttributeError here == the .so does not export a declared symbol
         if name not in ('annlite_hip_last_error',):
@@ -168,3 +170,9 @@ def profile_last_scan_ms() -> float:
     ms = ctypes.c_float(0.0)
     check(lib().annlite_profile_last_scan_ms(ctypes.byref(ms)), 'profile_last_scan_ms')
     return float(ms.value)
+
+
+def debug_counters():
+    out = (ctypes.c_uint64 * 8)()
+    check(lib().annlite_debug_counters(out), 'debug_counters')
+    return [int(v) for v in out]

@@ -102,9 +102,11 @@ __device__ __forceinline__ void wave_cmpx(uint32_t &hi, uint32_t &lo, int stride
 }
 // ascending sort of one key per lane (21 compare-exchange stages)
 __device__ __forceinline__ void wave_sort64(uint32_t &hi, uint32_t &lo, int lane) {
-#pragma unroll
+    // deliberately NOT unrolled: this is cold code that is inlined once per query of a workgroup tile;
+    // 21 unrolled stages x 16 queries blew the kernel up to >10k instructions (I-cache thrash)
+#pragma unroll 1
     for (int size = 2; size <= 64; size <<= 1) {
-#pragma unroll
+#pragma unroll 1
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             const bool asc = (lane & size) == 0;
             const bool lower = (lane & stride) == 0;
@@ -120,7 +122,7 @@ __device__ __forceinline__ void wavelist_merge_sorted(WaveList &L, uint32_t chi,
         L.hi = rhi;
         L.lo = rlo;
     }
-#pragma unroll
+#pragma unroll 1
     for (int stride = 32; stride > 0; stride >>= 1) wave_cmpx(L.hi, L.lo, stride, (lane & stride) == 0);
 }
 // insert the candidates of the lanes in `pm` (unconditionally; worse-than-64th entries fall off)

@@ -49,6 +49,13 @@ struct ScanArgs {
     int32_t n_slices;
     int64_t slice_rows;      // multiple of 64
     const float *smax;       // [ceil16(B)] sum_m max_k |lut[b][m][k]|  (filter kernel: rounding slack)
+    // quantised filter (qfilter kernel): 12-bit integer tables + the affine map back to distances
+    const uint16_t *q16;     // [ceil16(B)/8][Ks][M][8] u16
+    const float *qstep;      // [ceil16(B)]
+    const double *qlo;       // [ceil16(B)] sum_m min_k lut[b][m][k]
+    int32_t dbg_skip;        // debug bitmask (ANNLITE_DEBUG_SKIP): 1 no gathers, 2 no insert/publish, 4 no event at all
+    unsigned long long *dbg; // optional event counters (ANNLITE_DEBUG_COUNTERS=1): [0] slow-block entries,
+                             // [1] (wave,query) events, [2] events with an insertion, [3] bound publications
 };
 
 // ---- compile-time exec masks for the ordered accumulation ---------------------------------------
@@ -778,6 +785,375 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_filter_kernel(const Sca
     }
 }
 
+
+
+// One (wave, query) candidate event of the quantised-filter kernel.  Out of line on purpose (one shared
+// copy stays hot in the instruction cache; inlined 16x the kernel had >10k instructions).
+//
+// The top-k of a (workgroup, query) lives ONCE in LDS: 64 sorted (key, id) entries + a 4-byte lock.
+// A wave that has candidate rows (integer filter passed) gathers their exact fp32 sums, drops those
+// that do not beat the list's current k-th key, takes the lock, merges, publishes the new integer
+// bound.  The bound every wave filters with is therefore the k-th best of ALL rows the workgroup
+// has seen (with per-wave lists it was only the best single wave's k-th: 2.7x more events).
+extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
+
+template <int M>
+__device__ __attribute__((noinline)) void qfilter_event(unsigned long long pm, const uint32_t *cp /* M/4 dwords, true
+                                                        m order */, const float *lq, int km1, uint32_t rid,
+                                                        uint32_t list_off, uint32_t lock_off, uint32_t shq_off,
+                                                        float smax_b, float qstep_b, double qlo_b,
+                                                        unsigned long long *dbg, int skip) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long *list = (unsigned long long *)(g_smem + list_off);  // [64] ascending
+    // exact ascending-m fp32 sum, candidate lanes only (64 lanes x 16 uncoalesced 4-byte loads per event made
+    // the texture addresser the bottleneck although typically ONE lane needs them)
+    float ex = 0.f;
+    if (!(skip & 1) && ((pm >> lane) & 1ull)) {
+        float vals[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const uint32_t code = (cp[m / 4] >> (8 * (m % 4))) & 0xffu;
+            vals[m] = lq[((int64_t)code * M + m) * 4];
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) ex += vals[m];
+    }
+    const uint32_t khi = f32_to_ordered(ex);
+    // cheap pre-check against the current k-th key, without the lock (the key only ever decreases)
+    unsigned long long kth = __hip_atomic_load(list + km1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    unsigned long long px = __ballot(key_less(khi, rid, (uint32_t)(kth >> 32), (uint32_t)kth)) & pm;
+    if (!px || (skip & 2)) return;
+    if (dbg && lane == 0) atomicAdd(dbg + 2, 1ull);
+    // ---- critical section -------------------------------------------------------------------------
+    unsigned int *lock = (unsigned int *)(g_smem + lock_off);
+    for (;;) {
+        unsigned int got = 0;
+        if (lane == 0) got = (atomicCAS(lock, 0u, 1u) == 0u) ? 1u : 0u;
+        if (__builtin_amdgcn_readfirstlane(got)) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    unsigned long long e = __hip_atomic_load(list + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    WaveList L;
+    L.hi = (uint32_t)(e >> 32);
+    L.lo = (uint32_t)e;
+    const uint32_t thi = __builtin_amdgcn_readlane(L.hi, km1), tlo = __builtin_amdgcn_readlane(L.lo, km1);
+    px = __ballot(key_less(khi, rid, thi, tlo)) & px;  // the list may have tightened meanwhile
+    if (px) {
+        wavelist_insert_many(L, px, khi, rid, lane);
+        __hip_atomic_store(list + lane, ((unsigned long long)L.hi << 32) | L.lo, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t ohi = __builtin_amdgcn_readlane(L.hi, km1);
+        if (lane == 0 && ohi != kKeyInfHi && ohi != thi) {
+            if (dbg) atomicAdd(dbg + 3, 1ull);
+            const double thr = (double)ordered_to_f32(ohi);
+            const double slack = (double)smax_b * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
+            double qd = (thr + slack - qlo_b) / (double)qstep_b;
+            qd = __builtin_floor(qd) + 1.0;  // qthr
+            if (!(qd > 0.0)) qd = 0.0;
+            if (!(qd < 32767.0)) qd = 32767.0;
+            *(volatile unsigned short *)(g_smem + shq_off) = (unsigned short)(0x8000u | (uint32_t)qd);
+        }
+    }
+    // LDS executes one wave's instructions in order, so the list stores are visible before the release
+    if (lane == 0) __hip_atomic_store(lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// =================================================================================================
+// Quantised-filter kernel.  Same discipline as adc_scan_filter_kernel (cheap bound -> exact
+// recompute for the few rows that pass -> bit-exact output) but the cheap bound is an INTEGER sum
+// over a 12-bit quantised copy of the tables:
+//     Q[q][m][k] = min(QMAX, floor((lut[q][m][k] - lo[q][m]) / step[q])),  QMAX = floor(32767 / M)
+//   * 8 queries per 16-byte LDS entry (u16 each): one ds_read_b128 serves 8 look-ups per lane, half
+//     the LDS bytes of the fp32 filter, and a workgroup holds 16 queries in the same 128 KB;
+//   * two u16 partial sums share a dword and are added with ONE plain v_add_u32 (VOP2, 2.5 cycles per
+//     wave-instruction vs 4.5 for v_pk_add_f32 -- scripts/valu_ubench.hip); M*QMAX < 32768, so the
+//     low half never carries into the high half, and the filter test is ONE more VOP2 per dword:
+//     (0x8000|qthr) - S keeps bit 15 of a half set iff S <= qthr (no borrow can cross the halves);
+//   * bound: with L = sum_m lo[q][m], S = integer sum, every entry satisfies
+//     lo + step*(Q - 0.002) <= v <= lo + step*(Q + 1.002), hence d_real >= L + step*(S - 0.04); a row
+//     can be in the top-k only if d_exact <= thr, d_real <= thr + slack32, i.e.
+//     S <= qthr := floor((thr + slack32 - L) / step) + 1   (computed in double when thr changes);
+//   * rows with S <= qthr get their exact ascending-m fp32 sum from the fp32 table in global memory
+//     (L2-resident: 16 queries x 16 KB per workgroup), then the usual (ordered(d), id) offer.
+// LDS: [Q tile Ks*KSTRIDE][shq16 u16 x QT (0x8000|qthr) @ +0][locks u32 x QT @ +64][lists u64 x QT x 64 @ +128]
+// =================================================================================================
+template <int M, int NQ, int NW, int WPS, bool SKEWED>
+__global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const ScanArgs a) {
+    constexpr int QG = 8;                 // queries per LDS entry
+    constexpr int QT = QG * NQ;           // queries per workgroup
+    constexpr int CW = M / 4;
+    constexpr int EB = 16;
+    constexpr int RB = M * EB;
+    constexpr int KSTRIDE = NQ * RB;
+    static_assert(M % 8 == 0 && M <= 32 && (KSTRIDE & (KSTRIDE - 1)) == 0, "unsupported shape");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int km1 = a.k - 1;
+    const int s = lane % M;
+    // forward rotation (PLAIN tables) and its inverse (to read a row's bytes in true sub-space order)
+    const uint32_t bsh = (uint32_t)(s & 3);
+    bool abit[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) abit[i] = (((s >> 2) >> i) & 1) != 0;
+    const int sinv = (M - s) % M;
+    const uint32_t bsh_inv = (uint32_t)(sinv & 3);
+    bool abit_inv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) abit_inv[i] = (((sinv >> 2) >> i) & 1) != 0;
+    const unsigned char *mbase[M];
+#pragma unroll
+    for (int t = 0; t < M; ++t) mbase[t] = smem + ((s + t) % M) * EB;
+
+    const int lut_bytes = a.Ks * KSTRIDE;
+    const uint32_t shq_off = (uint32_t)lut_bytes, lock_off = shq_off + 64, list_off = shq_off + 128;
+    volatile uint16_t *shq = (volatile uint16_t *)(smem + shq_off);
+    volatile uint32_t *locks = (volatile uint32_t *)(smem + lock_off);
+    unsigned long long *lists = (unsigned long long *)(smem + list_off);  // [QT][64]
+
+    const int n_items = a.n_tiles * a.n_slices;
+    const int64_t group_bytes = (int64_t)a.Ks * RB;
+
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int xcd = item & 7;
+        const int j = item >> 3;
+        const int tile = j % a.n_tiles;
+        const int slice = (j / a.n_tiles) * 8 + xcd;
+
+        __syncthreads();
+        {
+            const unsigned char *src0 = (const unsigned char *)a.q16 + (int64_t)tile * NQ * group_bytes;
+            constexpr int PIECES_PER_ROW = RB / 16;
+            const int total = NQ * a.Ks * PIECES_PER_ROW;
+            for (int idx = tid; idx < total; idx += NW * 64) {
+                const int p = idx % PIECES_PER_ROW;
+                const int kh = idx / PIECES_PER_ROW;
+                const int h = kh / a.Ks;
+                const int kk = kh - h * a.Ks;
+                const u32x4 v = *(const u32x4 *)(src0 + (int64_t)h * group_bytes + (int64_t)kk * RB + p * 16);
+                *(u32x4 *)(smem + (kk * NQ + h) * RB + p * 16) = v;
+            }
+            if (tid < QT) {
+                shq[tid] = 0xffff;  // 0x8000 | 32767: everything passes until a bound exists
+                locks[tid] = 0;
+            }
+            for (int idx = tid; idx < QT * 64; idx += NW * 64) lists[idx] = ~0ull;
+        }
+        __syncthreads();
+
+        const int64_t slice_begin = (int64_t)slice * a.slice_rows;
+        int64_t slice_end = slice_begin + a.slice_rows;
+        if (slice_end > a.N) slice_end = a.N;
+
+        const uint32_t *codes32 = (const uint32_t *)a.codes;
+        auto load_row = [&](int64_t row, uint32_t (&c)[CW]) {
+            if (row >= a.N) row = a.N - 1;
+            const uint32_t *p = codes32 + row * CW;
+            if constexpr (CW == 2) {
+                const u32x2 v = *(const u32x2 *)p;
+                c[0] = v.x;
+                c[1] = v.y;
+            } else {
+#pragma unroll
+                for (int i = 0; i < CW / 4; ++i) {
+                    const u32x4 v = *(const u32x4 *)(p + 4 * i);
+                    c[4 * i + 0] = v.x;
+                    c[4 * i + 1] = v.y;
+                    c[4 * i + 2] = v.z;
+                    c[4 * i + 3] = v.w;
+                }
+            }
+        };
+
+        const int64_t stride = (int64_t)NW * 64;
+        int64_t row0 = slice_begin + (int64_t)wave * 64;
+        uint32_t ccur[CW], cnext[CW];   // rotated code bytes of the current / next row of this lane
+        const unsigned char *addr[M];
+        auto make_addr = [&](const uint32_t (&cc)[CW]) {
+            static_for<0, M>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                addr[t] = mbase[t] + byte_shl<t % 4>(cc[t / 4], (uint32_t)ilog2_c(KSTRIDE));
+            });
+        };
+        // integer sums of one entry group: 4 dwords x (2 x u16)
+        auto group_sum = [&](auto H, u32x4 &acc) {
+            constexpr int h = decltype(H)::value;
+            // issue all M look-ups of the group before the first add (the compiler otherwise re-used one
+            // register pair and waited lgkmcnt(0) after every second load)
+            u32x4 v[M];
+            static_for<0, M>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                v[t] = *(const u32x4 *)(addr[t] + h * RB);
+            });
+            asm volatile("" ::: "memory");
+            acc = v[0];
+            static_for<1, M>([&](auto T) { acc += v[decltype(T)::value]; });
+        };
+        u32x4 thp[NQ];  // packed (0x8000 | qthr) of the group's 8 queries
+#pragma unroll
+        for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
+        if (row0 < slice_end) {
+            load_row(row0 + lane, ccur);
+            if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
+            load_row(row0 + stride + lane, cnext);
+        }
+
+        int step_no = 0;
+        for (; row0 < slice_end; row0 += stride, ++step_no) {
+            unsigned long long vmask = ~0ull;
+            if (slice_end - row0 < 64) vmask = (1ull << (int)(slice_end - row0)) - 1ull;
+            if (a.valid) {
+                const uint32_t *vw = a.valid + (row0 >> 5);
+                unsigned long long vb = (unsigned long long)vw[0];
+                if (row0 + 32 < a.N) vb |= (unsigned long long)vw[1] << 32;
+                vmask &= vb;
+            }
+            const uint32_t rid = (uint32_t)(row0 + lane);
+            make_addr(ccur);
+            u32x4 acc[NQ];
+            static_for<0, NQ>([&](auto H) { group_sum(H, acc[decltype(H)::value]); });
+
+            // any (query, lane) with S <= qthr ?  (0x8000|qthr) - S has bit 15 of that half set
+            uint32_t anyv = 0;
+#pragma unroll
+            for (int h = 0; h < NQ; ++h)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) anyv |= thp[h][w] - acc[h][w];
+            const unsigned long long anym = __ballot((anyv & 0x80008000u) != 0) & vmask;
+            bool had_event = false;
+            if (anym) {
+                had_event = true;
+                if (a.dbg && lane == 0) atomicAdd(a.dbg + 0, 1ull);
+                // true sub-space order of this lane's row (undo the skew rotation once per event)
+                uint32_t cp[CW];
+#pragma unroll
+                for (int i = 0; i < CW; ++i) cp[i] = ccur[i];
+                rotate_row<CW>(cp, abit_inv, bsh_inv);
+#pragma unroll
+                for (int q = 0; q < QT; ++q) {
+                    const uint32_t w32 = acc[q / QG][(q % QG) / 2];
+                    const uint32_t tw32 = thp[q / QG][(q % QG) / 2];
+                    const uint32_t Sq = (q & 1) ? (w32 >> 16) : (w32 & 0xffffu);
+                    const uint32_t Tq = ((q & 1) ? (tw32 >> 16) : tw32) & 0x7fffu;
+                    const unsigned long long pm = __ballot(Sq <= Tq) & vmask;
+                    if (pm && !(a.dbg_skip & 4)) {
+                        if (a.dbg && lane == 0) {
+                            atomicAdd(a.dbg + 1, 1ull);
+                            atomicAdd(a.dbg + 4, (unsigned long long)__popcll(pm));
+                        }
+                        const int b = tile * QT + q;
+                        const float *lq = a.lut + ((int64_t)(b >> 2) * a.Ks) * (M * 4) + (b & 3);
+                        qfilter_event<M>(pm, cp, lq, km1, rid, list_off + q * 512, lock_off + q * 4, shq_off + q * 2,
+                                         a.smax[b], a.qstep[b], a.qlo[b], a.dbg, a.dbg_skip);
+                    }
+                }
+            }
+            // pick up the workgroup bound: every 4th step, and right after this wave's own events
+            if (had_event || (step_no & 3) == 3) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
+            }
+            // next row
+#pragma unroll
+            for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
+            if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
+            load_row(row0 + 2 * stride + lane, cnext);
+        }
+
+        // ---- the shared lists ARE the workgroup's result for this (tile, slice) ----------------------
+        __syncthreads();
+        for (int q = wave; q < QT; q += NW) {
+            const int b = tile * QT + q;
+            if (b < a.B && lane <= km1)
+                a.partial[((int64_t)b * a.n_slices + slice) * a.k + lane] = lists[q * 64 + lane];
+        }
+    }
+}
+
+// ---- quantisation of the fp32 TILED table [Bpad/4][Ks][M][4] -------------------------------------
+// pass 1: lo/hi per (query, sub-space): one wave per (group of 4 queries, m)
+__global__ __launch_bounds__(256) void lut_minmax_kernel(const float *__restrict__ lut, int n_g4, int M, int Ks,
+                                                        float *__restrict__ lo, float *__restrict__ hi) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_g4 * M) return;
+    const int g = w / M, m = w - g * M;
+    const f32x4 *base = (const f32x4 *)lut + (int64_t)g * Ks * M + m;
+    f32x4 mn = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+    f32x4 mx = -mn;
+    for (int k = lane; k < Ks; k += 64) {
+        const f32x4 v = base[(int64_t)k * M];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mn[i] = fminf(mn[i], v[i]);
+            mx[i] = fmaxf(mx[i], v[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[i] = fminf(mn[i], __shfl_xor(mn[i], o));
+            mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], o));
+        }
+    }
+    if (lane < 4) {
+        lo[(int64_t)(g * 4 + lane) * M + m] = mn[lane];
+        hi[(int64_t)(g * 4 + lane) * M + m] = mx[lane];
+    }
+}
+// pass 2: per query step / L / Smax
+__global__ __launch_bounds__(256) void lut_qparams_kernel(const float *__restrict__ lo, const float *__restrict__ hi,
+                                                         int Bpad, int M, int qmax, float *__restrict__ qstep,
+                                                         double *__restrict__ qlo, float *__restrict__ smax) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= Bpad) return;
+    float range = 0.f, sm = 0.f;
+    double L = 0.0;
+    for (int m = 0; m < M; ++m) {
+        const float l = lo[(int64_t)b * M + m], h = hi[(int64_t)b * M + m];
+        range = fmaxf(range, h - l);
+        sm += fmaxf(fabsf(l), fabsf(h));
+        L += (double)l;
+    }
+    float step = range / (float)qmax;
+    if (!(step > 0.f)) step = 1.f;
+    qstep[b] = step;
+    qlo[b] = L;
+    smax[b] = sm;
+}
+// pass 3: quantise; one thread per (group of 8 queries, k, m) -> one 16-byte store
+__global__ __launch_bounds__(256) void lut_quant_kernel(const float *__restrict__ lut, int n_g8, int M, int Ks,
+                                                       const float *__restrict__ lo, const float *__restrict__ qstep,
+                                                       int qmax, uint16_t *__restrict__ out) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (int64_t)n_g8 * Ks * M) return;
+    const int m = (int)(id % M);
+    const int k = (int)((id / M) % Ks);
+    const int g = (int)(id / ((int64_t)M * Ks));
+    uint32_t pk[4];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const f32x4 v = ((const f32x4 *)lut)[((int64_t)(g * 2 + half) * Ks + k) * M + m];
+        uint32_t q[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = g * 8 + half * 4 + i;
+            float t = floorf((v[i] - lo[(int64_t)b * M + m]) / qstep[b]);
+            if (!(t > 0.f)) t = 0.f;
+            if (t > (float)qmax) t = (float)qmax;
+            q[i] = (uint32_t)t;
+        }
+        pk[half * 2 + 0] = q[0] | (q[1] << 16);
+        pk[half * 2 + 1] = q[2] | (q[3] << 16);
+    }
+    ((u32x4 *)out)[id] = (u32x4){pk[0], pk[1], pk[2], pk[3]};
+}
+
 // Smax[b] = sum_m max_k |lut[b][m][k]| from the TILED table [Bpad/QI][Ks][M][QI]; one wave per group
 __global__ __launch_bounds__(256) void lut_smax_kernel(const float *__restrict__ lut, int n_groups, int M, int Ks,
                                                       int QI, float *__restrict__ smax) {
@@ -1031,7 +1407,9 @@ __global__ __launch_bounds__(256) void codes_skew_kernel(const uint8_t *__restri
 // =================================================================================================
 struct FastCfg {
     int M, QI, NQ, NW, WPS, wg_per_cu, id;
-    int mode;  // 0: exec-masked passes, 1/2: weight-fma passes, 3: FILTER kernel (fast sum + exact recompute)
+    int mode;  // 0: exec-masked passes, 1/2: weight-fma passes, 3: FILTER kernel (fast fp32 sum + exact
+               // recompute), 4: QFILTER kernel (12-bit integer tables, 8 queries per LDS entry)
+    int qt() const { return (mode == 4 ? 8 : QI) * NQ; }
 };
 
 // Kernel variants per M.  ANNLITE_SCAN_VARIANT (env, read per call) selects among the M=16
@@ -1046,11 +1424,16 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
     const int v = scan_variant();
     switch (M) {
         case 8:
-            if (v >= 20) *c = {8, 4, 2, 8, 2, 1, 80, 0};
-            else *c = {8, 4, 2, 8, 2, 1, 81, 3};
+            if (v >= 20 && v < 30) *c = {8, 4, 2, 8, 2, 1, 80, 0};
+            else if (v == 9) *c = {8, 4, 2, 8, 2, 1, 81, 3};
+            else *c = {8, 4, 2, 16, 4, 1, 830, 4};               // default: qfilter, 16 queries / WG
             return true;
         case 16:
-            if (v == 0) { *c = {16, 4, 2, 12, 3, 1, 1601, 3}; return true; }  // default: filter kernel, 12 waves, single buffer
+            if (v == 0) { *c = {16, 4, 2, 16, 4, 1, 1631, 4}; return true; }  // default: qfilter, 16 queries / WG, 16 waves
+            if (v == 8) { *c = {16, 4, 2, 12, 3, 1, 1601, 3}; return true; }  // fp32 filter kernel, 12 waves, single buffer
+            if (v == 30) { *c = {16, 4, 2, 12, 3, 1, 1630, 4}; return true; }  // qfilter, 16 queries / WG, 12 waves
+            if (v == 31) { *c = {16, 4, 2, 16, 4, 1, 1631, 4}; return true; }  // qfilter, 16 waves
+            if (v == 32) { *c = {16, 4, 2, 8, 2, 1, 1632, 4}; return true; }   // qfilter, 8 waves
             if (v == 9) { *c = {16, 4, 2, 8, 2, 1, 1600, 3}; return true; }   // filter kernel, 8 waves, double buffer
             if (v == 10) { *c = {16, 4, 2, 12, 3, 1, 1601, 3}; return true; }  // filter kernel, 12 waves, single buffer
             if (v == 11) { *c = {16, 4, 1, 8, 4, 2, 1602, 3}; return true; }   // filter kernel, QT=4, 2 WG / CU
@@ -1062,12 +1445,13 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
             else if (v == 5) *c = {16, 4, 2, 12, 3, 1, 165, 1};  // QT=8, 12 waves, weight-fma
             else if (v == 6) *c = {16, 4, 1, 8, 4, 2, 166, 1};   // QT=4, 2 WG / CU, weight-fma
             else if (v == 7) *c = {16, 4, 2, 8, 2, 1, 167, 2};   // QT=8, 8 waves, scalar weight-fma
-            else if (v == 8) *c = {16, 4, 2, 8, 2, 1, 160, 0};   // QT=8, 8 waves, 1 workgroup / CU
+            else if (v == 28) *c = {16, 4, 2, 8, 2, 1, 160, 0};  // QT=8, 8 waves, 1 workgroup / CU
             else *c = {16, 4, 2, 12, 3, 1, 163, 0};              // (v >= 20) two-pass kernel, QT=8, 12 waves
             return true;
         case 32:
-            if (v >= 20) *c = {32, 4, 1, 8, 2, 1, 320, 0};
-            else *c = {32, 4, 1, 8, 2, 1, 321, 3};
+            if (v >= 20 && v < 30) *c = {32, 4, 1, 8, 2, 1, 320, 0};
+            else if (v == 8 || v == 9) *c = {32, 4, 1, 8, 2, 1, 321, 3};
+            else *c = {32, 4, 1, 12, 3, 1, 3230, 4};             // default: qfilter, 8 queries / WG
             return true;
         case 64: *c = {64, 2, 1, 8, 2, 1, 640, 0}; return true;
         default: return false;
@@ -1095,6 +1479,16 @@ static void plan_slices(int64_t N, int n_tiles, int waves, int n_cu, bool xcd8, 
 }  // namespace annlite
 
 using namespace annlite;
+
+template <int M, int NQ, int NW, int WPS, bool SKEWED>
+static int launch_qfilter(const ScanArgs &a, int grid, hipStream_t st) {
+    const size_t lds_lut = (size_t)a.Ks * NQ * M * 16;
+    const size_t need = lds_lut + 128 + (size_t)8 * NQ * 64 * 8;
+    auto fn = adc_scan_qfilter_kernel<M, NQ, NW, WPS, SKEWED>;
+    ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
+    return launch_status("adc_scan_qfilter_kernel");
+}
 
 template <int M, int NQ, int NW, int WPS, bool SKEWED, bool DBUF>
 static int launch_filter(const ScanArgs &a, int grid, hipStream_t st) {
@@ -1124,7 +1518,7 @@ extern "C" int annlite_scan_plan_query(int64_t N, int64_t M, int64_t Ks, int cod
     if (fast_cfg(M, Ks, code_bytes, k, &c)) {
         plan->fast = 1;
         plan->qi = c.QI;
-        plan->qt = c.QI * c.NQ;
+        plan->qt = c.qt();
         plan->waves = c.NW;
         const int n_tiles = (int)((B + plan->qt - 1) / plan->qt);
         int ns;
@@ -1132,8 +1526,10 @@ extern "C" int annlite_scan_plan_query(int64_t N, int64_t M, int64_t Ks, int cod
         plan_slices(N > 0 ? N : 1, n_tiles > 0 ? n_tiles : 1, c.NW, n_cu, true, &ns, &sr);
         plan->n_slices = ns;
         plan->lut_floats = ((B + 15) / 16) * 16 * M * Ks;  // padded to 16 queries
-        // [partial keys][Smax f32 x ceil16(B)]
-        plan->workspace_bytes = (int64_t)n_tiles * plan->qt * ns * k * 8 + ((B + 15) / 16) * 16 * 4 + 256;
+        // [partial keys][Smax f32 x Bpad][qstep f32 x Bpad][qlo f64 x Bpad][lo,hi f32 x Bpad*M][q16 u16 x Bpad*M*Ks]
+        const int64_t bpad = ((B + 15) / 16) * 16;
+        plan->workspace_bytes = (int64_t)n_tiles * plan->qt * ns * k * 8 + 256 + bpad * 4 + 256;
+        if (c.mode == 4) plan->workspace_bytes += bpad * 4 + 256 + bpad * 8 + 256 + 2 * (bpad * M * 4 + 256) + bpad * M * Ks * 2 + 256;
     } else {
         plan->fast = 0;
         plan->qi = 1;
@@ -1163,6 +1559,7 @@ static int launch_fast(const ScanArgs &a, int grid, hipStream_t st) {
 }
 
 // ---- optional in-library timing of the dominant kernel (bench.py roofline leg) --------------------
+static unsigned long long *g_dbg = nullptr;  // debug only (ANNLITE_DEBUG_COUNTERS): leaked 64-byte device buffer
 static thread_local int g_prof_on = 0;
 static thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 static thread_local int g_ev_valid = 0;
@@ -1211,6 +1608,16 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
     a.n_tiles = (int)((B + plan.qt - 1) / plan.qt);
     a.n_slices = plan.n_slices;
     a.smax = nullptr;
+    a.q16 = nullptr;
+    a.qstep = nullptr;
+    a.qlo = nullptr;
+    a.dbg = nullptr;
+    a.dbg_skip = getenv("ANNLITE_DEBUG_SKIP") ? atoi(getenv("ANNLITE_DEBUG_SKIP")) : 0;
+    if (getenv("ANNLITE_DEBUG_COUNTERS")) {
+        if (!g_dbg) ANNLITE_HIP_TRY(hipMalloc((void **)&g_dbg, 64));
+        ANNLITE_HIP_TRY(hipMemsetAsync(g_dbg, 0, 64, st));
+        a.dbg = g_dbg;
+    }
     {
         int ns;
         int64_t sr;
@@ -1226,6 +1633,33 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         fast_cfg(M, Ks, code_bytes, k, &c);
         int grid = n_items < n_cu * c.wg_per_cu ? n_items : n_cu * c.wg_per_cu;
         const bool sk = codes_layout == ANNLITE_CODES_SKEWED;
+        if (c.mode == 4) {
+            // quantise the fp32 tables: min/max -> (step, L, Smax) -> 12-bit codes, all inside the workspace
+            const int64_t bpad = ((B + 15) / 16) * 16;
+            char *wp = (char *)workspace_dev + (((int64_t)a.n_tiles * plan.qt * plan.n_slices * k * 8 + 255) / 256) * 256;
+            auto carve = [&](int64_t bytes) { char *r = wp; wp += ((bytes + 255) / 256) * 256; return r; };
+            float *smax = (float *)carve(bpad * 4);
+            float *qstep = (float *)carve(bpad * 4);
+            double *qlo = (double *)carve(bpad * 8);
+            float *lo = (float *)carve(bpad * M * 4);
+            float *hi = (float *)carve(bpad * M * 4);
+            uint16_t *q16 = (uint16_t *)carve(bpad * M * Ks * 2);
+            const int qmax = (int)(32767 / M);
+            const int n_g4 = (int)(bpad / 4), n_g8 = (int)(bpad / 8);
+            hipLaunchKernelGGL(lut_minmax_kernel, dim3((n_g4 * (int)M + 3) / 4), dim3(256), 0, st, lut_dev, n_g4, (int)M,
+                               (int)Ks, lo, hi);
+            hipLaunchKernelGGL(lut_qparams_kernel, dim3((unsigned)((bpad + 255) / 256)), dim3(256), 0, st, lo, hi,
+                               (int)bpad, (int)M, qmax, qstep, qlo, smax);
+            const int64_t tot = (int64_t)n_g8 * Ks * M;
+            hipLaunchKernelGGL(lut_quant_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, lut_dev, n_g8,
+                               (int)M, (int)Ks, lo, qstep, qmax, q16);
+            rc = launch_status("lut_quant_kernel");
+            if (rc != ANNLITE_OK) return rc;
+            a.smax = smax;
+            a.qstep = qstep;
+            a.qlo = qlo;
+            a.q16 = q16;
+        }
         if (c.mode == 3) {
             // rounding slack of the fast filter sum needs Smax[b] = sum_m max_k |lut[b][m][k]|
             const int64_t part_bytes = (int64_t)a.n_tiles * plan.qt * plan.n_slices * k * 8;
@@ -1240,10 +1674,17 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         prof_begin(st);
 #define ANNLITE_LAUNCH_F(MM, NQ_, NW_, WPS_, DB_) \
     (sk ? launch_filter<MM, NQ_, NW_, WPS_, true, DB_>(a, grid, st) : launch_filter<MM, NQ_, NW_, WPS_, false, DB_>(a, grid, st))
+#define ANNLITE_LAUNCH_Q(MM, NQ_, NW_, WPS_) \
+    (sk ? launch_qfilter<MM, NQ_, NW_, WPS_, true>(a, grid, st) : launch_qfilter<MM, NQ_, NW_, WPS_, false>(a, grid, st))
 #define ANNLITE_LAUNCH_M(MM, QI_, NQ_, NW_, WPS_, MODE_) \
     (sk ? launch_fast<MM, QI_, NQ_, NW_, WPS_, true, MODE_>(a, grid, st) : launch_fast<MM, QI_, NQ_, NW_, WPS_, false, MODE_>(a, grid, st))
 #define ANNLITE_LAUNCH(MM, QI_, NQ_, NW_, WPS_) ANNLITE_LAUNCH_M(MM, QI_, NQ_, NW_, WPS_, 0)
         switch (c.id) {
+            case 830: rc = ANNLITE_LAUNCH_Q(8, 2, 16, 4); break;
+            case 3230: rc = ANNLITE_LAUNCH_Q(32, 1, 12, 3); break;
+            case 1630: rc = ANNLITE_LAUNCH_Q(16, 2, 12, 3); break;
+            case 1631: rc = ANNLITE_LAUNCH_Q(16, 2, 16, 4); break;
+            case 1632: rc = ANNLITE_LAUNCH_Q(16, 2, 8, 2); break;
             case 81: rc = ANNLITE_LAUNCH_F(8, 2, 8, 2, true); break;
             case 1600: rc = ANNLITE_LAUNCH_F(16, 2, 8, 2, true); break;
             case 1601: rc = ANNLITE_LAUNCH_F(16, 2, 12, 3, false); break;
@@ -1265,6 +1706,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
 #undef ANNLITE_LAUNCH
 #undef ANNLITE_LAUNCH_M
 #undef ANNLITE_LAUNCH_F
+#undef ANNLITE_LAUNCH_Q
         prof_end(st);
         return rc;
     }
@@ -1279,6 +1721,17 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         hipLaunchKernelGGL((adc_scan_generic_kernel<uint32_t, 4>), dim3(grid), dim3(256), lds, st, a, (int)M);
     prof_end(st);
     return launch_status("adc_scan_generic_kernel");
+}
+
+extern "C" int annlite_debug_counters(uint64_t *out8) {
+    ANNLITE_REQUIRE(out8 != nullptr, "out8 is NULL");
+    if (!g_dbg) {
+        set_error("no counters recorded (set ANNLITE_DEBUG_COUNTERS=1 before the scan)");
+        return ANNLITE_ERR_INVALID;
+    }
+    ANNLITE_HIP_TRY(hipDeviceSynchronize());
+    ANNLITE_HIP_TRY(hipMemcpy(out8, g_dbg, 64, hipMemcpyDeviceToHost));
+    return ANNLITE_OK;
 }
 
 extern "C" int annlite_profile_enable(int on) {

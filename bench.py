@@ -15,7 +15,7 @@ the global top-k.
 One "step" = the whole hot path for one batch: LUT build (tiled layout) -> ADC scan + per-shard
 top-k -> (N>1: all-gather + merge).  Inputs (queries, codebooks, codes) are resident in HBM before
 the timed region.  Prints ONE JSON line on rank 0 with the driver's contract fields plus
-`roofline` (dominant kernel = adc_scan_filter_kernel, algorithmic bytes B*N_local*M per launch over
+`roofline` (dominant kernel = adc_scan_qfilter_kernel, algorithmic bytes B*N_local*M per launch over
 its HIP-event duration, vs the 8 TB/s HBM peak -- the kernel actually runs out of LDS)
 and `cpu_baseline` (the C oracle, single thread = the reference's execution model, bounded sample).
 """
@@ -275,7 +275,7 @@ def main():
                                                        'candidates_per_query': 'n_slices*64 per shard'},
             'roofline': {
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                'traffic': traffic, 'kernel': 'adc_scan_filter_kernel', 'kernel_ms': kernel_ms,
+                'traffic': traffic, 'kernel': 'adc_scan_qfilter_kernel', 'kernel_ms': kernel_ms,
                 'algorithmic_bytes_per_launch': scan_bytes, 'lds_lookups_per_s': lookups_per_s,
             },
             'cpu_baseline': cpu,

@@ -164,6 +164,10 @@ ANNLITE_API int annlite_adc_scan_candidates(const void *codes_dev, int code_byte
  * launch stream; annlite_profile_last_scan_ms() waits for the last one and returns its duration. */
 ANNLITE_API int annlite_profile_enable(int on);
 ANNLITE_API int annlite_profile_last_scan_ms(float *ms);
+/* Debug aid: with ANNLITE_DEBUG_COUNTERS=1 in the environment the quantised-filter scan counts
+ * [0] slow-block entries [1] (wave,query) candidate events [2] events that inserted [3] bound
+ * publications [4] candidate rows; this copies the 8 uint64 counters of the last scan to the host. */
+ANNLITE_API int annlite_debug_counters(uint64_t *out8);
 
 /* Convert between the PLAIN and the SKEWED code-table layout (uint8 codes).
  * forward (inverse=0): table_out[id][j] = codes_in[i][(j + id) mod M]   -- scatter rows i -> id

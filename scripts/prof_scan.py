@@ -43,3 +43,8 @@ for it in range(a.iters):
 torch.cuda.synchronize()
 look = B * N * M
 print('scan kernel ms:', ['%.3f' % x for x in ms], ' lookups/s %.3e' % (look / (min(ms) * 1e-3)), ' alg GB/s %.1f' % (look / (min(ms) * 1e-3) / 1e9))
+
+if os.environ.get('ANNLITE_DEBUG_COUNTERS'):
+    c = _capi.debug_counters()
+    n_wave_steps = (N // 64) * ((B + plan.qt - 1) // plan.qt)
+    print('counters: slow-block entries %d, events %d, inserting events %d, publications %d, candidate rows %d ; wave-steps %d' % (c[0], c[1], c[2], c[3], c[4], n_wave_steps))

@@ -457,9 +457,10 @@ def test_filter_slack_with_badly_conditioned_tables(ops, oracle):
         assert np.array_equal(i, ri)
 
 
-@pytest.mark.parametrize('variant', ['0', '9', '11', '20'])
+@pytest.mark.parametrize('variant', ['0', '30', '8', '9', '11', '20'])
 def test_scan_kernel_variants_agree(ops, oracle, variant, monkeypatch):
-    """every selectable M=16 scan kernel (filter 12-wave / 8-wave double buffer / QT=4, two-pass) is bit-exact"""
+    """every selectable M=16 scan kernel (quantised filter 16/12 waves, fp32 filter 12-wave / 8-wave double
+    buffer / QT=4, two-pass) is bit-exact"""
     monkeypatch.setenv('ANNLITE_SCAN_VARIANT', variant)
     rs = np.random.RandomState(3)
     M, Ks, N, B, k = 16, 256, 70000, 40, 10
