@@ -53,6 +53,8 @@ struct ScanArgs {
     const uint16_t *q16;     // [ceil16(B)/8][Ks][M][8] u16
     const float *qstep;      // [ceil16(B)]
     const double *qlo;       // [ceil16(B)] sum_m min_k lut[b][m][k]
+    unsigned long long *gkey; // [ceil16(B)] best k-th key any workgroup has proven for the query (device-scope
+                             // atomic min; lets the 8+ row slices of a query tile share their progress)
     int32_t dbg_skip;        // debug bitmask (ANNLITE_DEBUG_SKIP): 1 no gathers, 2 no insert/publish, 4 no event at all
     unsigned long long *dbg; // optional event counters (ANNLITE_DEBUG_COUNTERS=1): [0] slow-block entries,
                              // [1] (wave,query) events, [2] events with an insertion, [3] bound publications
@@ -797,10 +799,27 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_filter_kernel(const Sca
 // has seen (with per-wave lists it was only the best single wave's k-th: 2.7x more events).
 extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 
+// integer filter bound (0x8000 | qthr) implied by a k-th key (see the kernel header for the derivation)
+template <int M>
+__device__ __forceinline__ unsigned short qbound_from_key(unsigned long long key, float smax_b, float qstep_b,
+                                                          double qlo_b) {
+    const uint32_t hi = (uint32_t)(key >> 32);
+    if (hi == kKeyInfHi) return 0xffff;
+    const double thr = (double)ordered_to_f32(hi);
+    const double slack = (double)smax_b * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
+    double qd = (thr + slack - qlo_b) / (double)qstep_b;
+    qd = __builtin_floor(qd) + 1.0;  // qthr
+    if (!(qd > 0.0)) qd = 0.0;
+    if (!(qd < 32767.0)) qd = 32767.0;
+    return (unsigned short)(0x8000u | (uint32_t)qd);
+}
+
+
 template <int M>
 __device__ __attribute__((noinline)) void qfilter_event(unsigned long long pm, const uint32_t *cp /* M/4 dwords, true
                                                         m order */, const float *lq, int km1, uint32_t rid,
                                                         uint32_t list_off, uint32_t lock_off, uint32_t shq_off,
+                                                        uint32_t gkl_off, unsigned long long *gkey_b,
                                                         float smax_b, float qstep_b, double qlo_b,
                                                         unsigned long long *dbg, int skip) {
     const int lane = threadIdx.x & 63;
@@ -819,8 +838,12 @@ __device__ __attribute__((noinline)) void qfilter_event(unsigned long long pm, c
         for (int m = 0; m < M; ++m) ex += vals[m];
     }
     const uint32_t khi = f32_to_ordered(ex);
-    // cheap pre-check against the current k-th key, without the lock (the key only ever decreases)
+    // cheap pre-check against the current bound, without the lock (it only ever decreases): the list's own
+    // k-th key or the best k-th key another workgroup has published for this query, whichever is smaller
+    unsigned long long *gkl = (unsigned long long *)(g_smem + gkl_off);
     unsigned long long kth = __hip_atomic_load(list + km1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned long long gk = __hip_atomic_load(gkl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (gk < kth) kth = gk;
     unsigned long long px = __ballot(key_less(khi, rid, (uint32_t)(kth >> 32), (uint32_t)kth)) & pm;
     if (!px || (skip & 2)) return;
     if (dbg && lane == 0) atomicAdd(dbg + 2, 1ull);
@@ -843,15 +866,14 @@ __device__ __attribute__((noinline)) void qfilter_event(unsigned long long pm, c
         __hip_atomic_store(list + lane, ((unsigned long long)L.hi << 32) | L.lo, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_WORKGROUP);
         const uint32_t ohi = __builtin_amdgcn_readlane(L.hi, km1);
-        if (lane == 0 && ohi != kKeyInfHi && ohi != thi) {
+        const uint32_t olo = __builtin_amdgcn_readlane(L.lo, km1);
+        const unsigned long long okey = ((unsigned long long)ohi << 32) | olo;
+        if (lane == 0 && ohi != kKeyInfHi && okey < gk) {
             if (dbg) atomicAdd(dbg + 3, 1ull);
-            const double thr = (double)ordered_to_f32(ohi);
-            const double slack = (double)smax_b * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
-            double qd = (thr + slack - qlo_b) / (double)qstep_b;
-            qd = __builtin_floor(qd) + 1.0;  // qthr
-            if (!(qd > 0.0)) qd = 0.0;
-            if (!(qd < 32767.0)) qd = 32767.0;
-            *(volatile unsigned short *)(g_smem + shq_off) = (unsigned short)(0x8000u | (uint32_t)qd);
+            // tell the other workgroups of this query (other row slices) and remember it locally
+            if (gkey_b) __hip_atomic_fetch_min(gkey_b, okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gkl, okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            *(volatile unsigned short *)(g_smem + shq_off) = qbound_from_key<M>(okey, smax_b, qstep_b, qlo_b);
         }
     }
     // LDS executes one wave's instructions in order, so the list stores are visible before the release
@@ -875,7 +897,8 @@ __device__ __attribute__((noinline)) void qfilter_event(unsigned long long pm, c
 //     S <= qthr := floor((thr + slack32 - L) / step) + 1   (computed in double when thr changes);
 //   * rows with S <= qthr get their exact ascending-m fp32 sum from the fp32 table in global memory
 //     (L2-resident: 16 queries x 16 KB per workgroup), then the usual (ordered(d), id) offer.
-// LDS: [Q tile Ks*KSTRIDE][shq16 u16 x QT (0x8000|qthr) @ +0][locks u32 x QT @ +64][lists u64 x QT x 64 @ +128]
+// LDS: [Q tile Ks*KSTRIDE][shq16 u16 x QT (0x8000|qthr) @ +0][locks u32 x QT @ +64][gkl u64 x QT @ +128]
+//      [lists u64 x QT x 64 @ +256]
 // =================================================================================================
 template <int M, int NQ, int NW, int WPS, bool SKEWED>
 __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const ScanArgs a) {
@@ -909,7 +932,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
     for (int t = 0; t < M; ++t) mbase[t] = smem + ((s + t) % M) * EB;
 
     const int lut_bytes = a.Ks * KSTRIDE;
-    const uint32_t shq_off = (uint32_t)lut_bytes, lock_off = shq_off + 64, list_off = shq_off + 128;
+    const uint32_t shq_off = (uint32_t)lut_bytes, lock_off = shq_off + 64, gkl_off = shq_off + 128,
+                   list_off = shq_off + 256;
+    unsigned long long *gkl = (unsigned long long *)(smem + gkl_off);  // [QT] best published k-th key
     volatile uint16_t *shq = (volatile uint16_t *)(smem + shq_off);
     volatile uint32_t *locks = (volatile uint32_t *)(smem + lock_off);
     unsigned long long *lists = (unsigned long long *)(smem + list_off);  // [QT][64]
@@ -937,8 +962,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                 *(u32x4 *)(smem + (kk * NQ + h) * RB + p * 16) = v;
             }
             if (tid < QT) {
-                shq[tid] = 0xffff;  // 0x8000 | 32767: everything passes until a bound exists
                 locks[tid] = 0;
+                // start from whatever other workgroups (other row slices, earlier items) already proved
+                const int b = tile * QT + tid;
+                const unsigned long long gk =
+                    a.gkey ? __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+                gkl[tid] = gk;
+                shq[tid] = qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]);
             }
             for (int idx = tid; idx < QT * 64; idx += NW * 64) lists[idx] = ~0ull;
         }
@@ -1047,8 +1077,19 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                         const int b = tile * QT + q;
                         const float *lq = a.lut + ((int64_t)(b >> 2) * a.Ks) * (M * 4) + (b & 3);
                         qfilter_event<M>(pm, cp, lq, km1, rid, list_off + q * 512, lock_off + q * 4, shq_off + q * 2,
-                                         a.smax[b], a.qstep[b], a.qlo[b], a.dbg, a.dbg_skip);
+                                         gkl_off + q * 8, a.gkey ? a.gkey + b : nullptr, a.smax[b], a.qstep[b], a.qlo[b], a.dbg,
+                                         a.dbg_skip);
                     }
+                }
+            }
+            // every 32 steps one wave imports the bounds other workgroups published for these queries
+            if (a.gkey && (step_no & 31) == 31 && wave == (step_no >> 5) % NW && lane < QT) {
+                const int b = tile * QT + lane;
+                const unsigned long long gk = __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (gk < __hip_atomic_load(gkl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    __hip_atomic_store(gkl + lane, gk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const unsigned short nb = qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]);
+                    if (nb < shq[lane]) shq[lane] = nb;
                 }
             }
             // pick up the workgroup bound: every 4th step, and right after this wave's own events
@@ -1072,6 +1113,44 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                 a.partial[((int64_t)b * a.n_slices + slice) * a.k + lane] = lists[q * 64 + lane];
         }
     }
+}
+
+
+// Seed bound: exact top-k of every query over the first S rows (one wave per query, exact ascending-m
+// sums from the fp32 TILED table).  Its k-th key is a valid upper bound of the final k-th key, so the
+// scan starts with a filter that passes ~k/S of the rows instead of all of them (the cold-start
+// "flood" cost 16 waves x 16 queries x 64 uncoalesced gathers per work item).
+template <int M, bool SKEWED>
+__global__ __launch_bounds__(256) void seed_bound_kernel(const uint8_t *__restrict__ codes, int64_t S,
+                                                        const uint32_t *__restrict__ valid,
+                                                        const float *__restrict__ lut, int B, int Ks, int k,
+                                                        unsigned long long *__restrict__ gkey) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float *lq = lut + ((int64_t)(b >> 2) * Ks) * (M * 4) + (b & 3);
+    WaveList L;
+    L.reset();
+    for (int64_t r0 = 0; r0 < S; r0 += 64) {
+        const int64_t r = r0 + lane;
+        bool ok = r < S;
+        if (ok && valid) ok = (valid[r >> 5] >> (r & 31)) & 1u;
+        float d = 0.f;
+        if (ok) {
+            const uint8_t *c = codes + r * M;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const int byte = SKEWED ? (int)(((m - r) % M + M) % M) : m;
+                d += lq[((int64_t)c[byte] * M + m) * 4];
+            }
+        }
+        const unsigned long long pm = __ballot(ok);
+        if (pm) wavelist_insert_many(L, pm, f32_to_ordered(d), (uint32_t)r, lane);
+    }
+    const uint32_t hi = __builtin_amdgcn_readlane(L.hi, k - 1), lo = __builtin_amdgcn_readlane(L.lo, k - 1);
+    // +1: the seed rows are in nobody's list, so the scan must still ACCEPT the row that sets the bound
+    // (bounds published by workgroups come from rows their own list already holds and stay strict)
+    if (lane == 0 && hi != kKeyInfHi) gkey[b] = (((unsigned long long)hi << 32) | lo) + 1ull;
 }
 
 // ---- quantisation of the fp32 TILED table [Bpad/4][Ks][M][4] -------------------------------------
@@ -1483,7 +1562,7 @@ using namespace annlite;
 template <int M, int NQ, int NW, int WPS, bool SKEWED>
 static int launch_qfilter(const ScanArgs &a, int grid, hipStream_t st) {
     const size_t lds_lut = (size_t)a.Ks * NQ * M * 16;
-    const size_t need = lds_lut + 128 + (size_t)8 * NQ * 64 * 8;
+    const size_t need = lds_lut + 256 + (size_t)8 * NQ * 64 * 8;
     auto fn = adc_scan_qfilter_kernel<M, NQ, NW, WPS, SKEWED>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
@@ -1529,7 +1608,8 @@ extern "C" int annlite_scan_plan_query(int64_t N, int64_t M, int64_t Ks, int cod
         // [partial keys][Smax f32 x Bpad][qstep f32 x Bpad][qlo f64 x Bpad][lo,hi f32 x Bpad*M][q16 u16 x Bpad*M*Ks]
         const int64_t bpad = ((B + 15) / 16) * 16;
         plan->workspace_bytes = (int64_t)n_tiles * plan->qt * ns * k * 8 + 256 + bpad * 4 + 256;
-        if (c.mode == 4) plan->workspace_bytes += bpad * 4 + 256 + bpad * 8 + 256 + 2 * (bpad * M * 4 + 256) + bpad * M * Ks * 2 + 256;
+        if (c.mode == 4)
+            plan->workspace_bytes += bpad * 4 + 256 + 2 * (bpad * 8 + 256) + 2 * (bpad * M * 4 + 256) + bpad * M * Ks * 2 + 256;
     } else {
         plan->fast = 0;
         plan->qi = 1;
@@ -1581,7 +1661,8 @@ static void prof_end(hipStream_t st) {
 // run the scan kernels: fills workspace with the per-(query, slice) sorted key lists [B][NS][k]
 static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M, int64_t Ks,
                         const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B, int64_t k,
-                        void *workspace_dev, size_t workspace_bytes, hipStream_t st, annlite_scan_plan *plan_out) {
+                        void *workspace_dev, size_t workspace_bytes, hipStream_t st, annlite_scan_plan *plan_out,
+                        bool share_across_slices) {
     annlite_scan_plan plan;
     int rc = annlite_scan_plan_query(N, M, Ks, code_bytes, B, k, &plan);
     if (rc != ANNLITE_OK) return rc;
@@ -1611,6 +1692,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
     a.q16 = nullptr;
     a.qstep = nullptr;
     a.qlo = nullptr;
+    a.gkey = nullptr;
     a.dbg = nullptr;
     a.dbg_skip = getenv("ANNLITE_DEBUG_SKIP") ? atoi(getenv("ANNLITE_DEBUG_SKIP")) : 0;
     if (getenv("ANNLITE_DEBUG_COUNTERS")) {
@@ -1641,6 +1723,23 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             float *smax = (float *)carve(bpad * 4);
             float *qstep = (float *)carve(bpad * 4);
             double *qlo = (double *)carve(bpad * 8);
+            unsigned long long *gk = (unsigned long long *)carve(bpad * 8);  // all-ones after the workspace memset
+            // per-slice lists stay complete (a superset generator for re-rank) unless sharing is requested
+            a.gkey = share_across_slices ? gk : nullptr;
+            if (share_across_slices && N >= 4096) {
+                const int64_t S = 1024;
+                const unsigned blocks = (unsigned)((B + 3) / 4);
+                const bool skw = codes_layout == ANNLITE_CODES_SKEWED;
+#define ANNLITE_SEED(MM)                                                                                               \
+    if (skw) hipLaunchKernelGGL((seed_bound_kernel<MM, true>), dim3(blocks), dim3(256), 0, st, (const uint8_t *)codes_dev, \
+                                S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, gk);                               \
+    else hipLaunchKernelGGL((seed_bound_kernel<MM, false>), dim3(blocks), dim3(256), 0, st, (const uint8_t *)codes_dev,  \
+                            S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, gk)
+                if (M == 8) { ANNLITE_SEED(8); } else if (M == 16) { ANNLITE_SEED(16); } else { ANNLITE_SEED(32); }
+#undef ANNLITE_SEED
+                rc = launch_status("seed_bound_kernel");
+                if (rc != ANNLITE_OK) return rc;
+            }
             float *lo = (float *)carve(bpad * M * 4);
             float *hi = (float *)carve(bpad * M * 4);
             uint16_t *q16 = (uint16_t *)carve(bpad * M * Ks * 2);
@@ -1758,7 +1857,7 @@ extern "C" int annlite_adc_scan_topk(const void *codes_dev, int code_bytes, int 
     annlite_scan_plan plan;
     hipStream_t st = (hipStream_t)stream;
     int rc = scan_partial(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut_dev, B, k, workspace_dev,
-                          workspace_bytes, st, &plan);
+                          workspace_bytes, st, &plan, true);
     if (rc != ANNLITE_OK || B == 0) return rc;
     ANNLITE_REQUIRE(out_dist_dev && out_id_dev, "null output pointer");
     hipLaunchKernelGGL(merge_partial_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st,
@@ -1775,7 +1874,7 @@ extern "C" int annlite_adc_scan_candidates(const void *codes_dev, int code_bytes
     annlite_scan_plan plan;
     hipStream_t st = (hipStream_t)stream;
     int rc = scan_partial(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut_dev, B, k, workspace_dev,
-                          workspace_bytes, st, &plan);
+                          workspace_bytes, st, &plan, false);
     if (rc != ANNLITE_OK || B == 0) return rc;
     ANNLITE_REQUIRE(out_dist_dev && out_id_dev, "null output pointer");
     const int64_t total = B * plan.n_slices * k;
