@@ -508,3 +508,30 @@ def test_full_size_properties_config2(ops, oracle):
     sel = [0, 1, 500, 1023]
     rd, ri = oracle.adc_search_c(lut_b[sel].cpu().numpy(), codes_np, k)
     assert np.array_equal(d[sel].cpu().numpy(), rd) and np.array_equal(i[sel].cpu().numpy(), ri)
+
+
+def test_bench_under_torchrun_rccl_gather_path(tmp_path):
+    """The driver launches bench.py with torch.distributed.run; exercise that launch mode with one rank and
+    the all-gather + merge path forced on (RCCL all_gather_into_tensor + merge_lists_kernel), small shape.
+    The JSON line must carry the contract fields and the GPU result must equal the CPU oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = dict(os.environ, ANNLITE_FORCE_GATHER='1', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--rows', '300000', '--steps', '3',
+           '--warmup', '1', '--recall-queries', '32', '--cpu-queries', '2']
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    rec = json.loads(line)
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in rec
+    assert rec['n_gpus'] == 1 and rec['value'] > 0 and rec['roofline']['frac'] > 0
+    assert rec['cpu_baseline']['gpu_matches_cpu_bit_exact'] is True
+    assert rec['rerank']['recall_at_10'] >= 0.9
