@@ -32,14 +32,32 @@ __global__ __launch_bounds__(256) void lut_l2_tiled_kernel(const float *__restri
     float acc[QI];
 #pragma unroll
     for (int i = 0; i < QI; ++i) acc[i] = 0.f;
-    for (int j = 0; j < dsub; ++j) {
-        const float cj = cw[j];
+    if ((dsub & 3) == 0) {
+        // 16-byte loads (the scalar loop below was bound by the number of load instructions: the codeword
+        // addresses of neighbouring lanes are Ks*dsub floats apart); same j-ascending fmaf chain
+        for (int j = 0; j < dsub; j += 4) {
+            const f32x4 cj = *(const f32x4 *)(cw + j);
 #pragma unroll
-        for (int i = 0; i < QI; ++i) {
-            const int b = bq * QI + i;
-            const float qj = (b < B) ? q[(int64_t)b * D + m * dsub + j] : cj;  // pad queries -> 0
-            const float c = cj - qj;
-            acc[i] = __builtin_fmaf(c, c, acc[i]);
+            for (int i = 0; i < QI; ++i) {
+                const int b = bq * QI + i;
+                const f32x4 qj = (b < B) ? *(const f32x4 *)(q + (int64_t)b * D + m * dsub + j) : cj;  // pad -> 0
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float c = cj[e] - qj[e];
+                    acc[i] = __builtin_fmaf(c, c, acc[i]);
+                }
+            }
+        }
+    } else {
+        for (int j = 0; j < dsub; ++j) {
+            const float cj = cw[j];
+#pragma unroll
+            for (int i = 0; i < QI; ++i) {
+                const int b = bq * QI + i;
+                const float qj = (b < B) ? q[(int64_t)b * D + m * dsub + j] : cj;  // pad queries -> 0
+                const float c = cj - qj;
+                acc[i] = __builtin_fmaf(c, c, acc[i]);
+            }
         }
     }
 #pragma unroll

@@ -55,6 +55,10 @@ struct ScanArgs {
     const double *qlo;       // [ceil16(B)] sum_m min_k lut[b][m][k]
     unsigned long long *gkey; // [ceil16(B)] best k-th key any workgroup has proven for the query (device-scope
                              // atomic min; lets the 8+ row slices of a query tile share their progress)
+    unsigned long long *gk2; // [ceil16(B)][n_slices] j-th key of every (query, slice) list, j = ceil(k/8): the 8
+                             // concurrently scanned slices of a query hold >= k rows at or below the MAX of
+                             // their j-th keys, a bound ~k/j times tighter than any single slice's own k-th
+    int32_t jm1;             // j - 1
     int32_t dbg_skip;        // debug bitmask (ANNLITE_DEBUG_SKIP): 1 no gathers, 2 no insert/publish, 4 no event at all
     unsigned long long *dbg; // optional event counters (ANNLITE_DEBUG_COUNTERS=1): [0] slow-block entries,
                              // [1] (wave,query) events, [2] events with an insertion, [3] bound publications
@@ -820,6 +824,7 @@ __device__ __attribute__((noinline)) void qfilter_event(unsigned long long pm, c
                                                         m order */, const float *lq, int km1, uint32_t rid,
                                                         uint32_t list_off, uint32_t lock_off, uint32_t shq_off,
                                                         uint32_t gkl_off, unsigned long long *gkey_b,
+                                                        uint32_t gjl_off, unsigned long long *gk2_slot, int jm1,
                                                         float smax_b, float qstep_b, double qlo_b,
                                                         unsigned long long *dbg, int skip) {
     const int lane = threadIdx.x & 63;
@@ -874,6 +879,17 @@ __device__ __attribute__((noinline)) void qfilter_event(unsigned long long pm, c
             if (gkey_b) __hip_atomic_fetch_min(gkey_b, okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(gkl, okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             *(volatile unsigned short *)(g_smem + shq_off) = qbound_from_key<M>(okey, smax_b, qstep_b, qlo_b);
+        }
+        if (gk2_slot) {
+            // this slice's j-th key, for the max-of-j-th bound the sibling slices compute
+            const uint32_t jhi = __builtin_amdgcn_readlane(L.hi, jm1);
+            const uint32_t jlo = __builtin_amdgcn_readlane(L.lo, jm1);
+            const unsigned long long jkey = ((unsigned long long)jhi << 32) | jlo;
+            volatile unsigned long long *gjl = (volatile unsigned long long *)(g_smem + gjl_off);
+            if (lane == 0 && jhi != kKeyInfHi && jkey < *gjl) {
+                *gjl = jkey;
+                __hip_atomic_store(gk2_slot, jkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     // LDS executes one wave's instructions in order, so the list stores are visible before the release
@@ -933,7 +949,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
 
     const int lut_bytes = a.Ks * KSTRIDE;
     const uint32_t shq_off = (uint32_t)lut_bytes, lock_off = shq_off + 64, gkl_off = shq_off + 128,
-                   list_off = shq_off + 256;
+                   list_off = shq_off + 256, gjl_off = list_off + QT * 512;
     unsigned long long *gkl = (unsigned long long *)(smem + gkl_off);  // [QT] best published k-th key
     volatile uint16_t *shq = (volatile uint16_t *)(smem + shq_off);
     volatile uint32_t *locks = (volatile uint32_t *)(smem + lock_off);
@@ -968,6 +984,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                 const unsigned long long gk =
                     a.gkey ? __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
                 gkl[tid] = gk;
+                ((unsigned long long *)(smem + gjl_off))[tid] = ~0ull;
                 shq[tid] = qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]);
             }
             for (int idx = tid; idx < QT * 64; idx += NW * 64) lists[idx] = ~0ull;
@@ -1077,19 +1094,49 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                         const int b = tile * QT + q;
                         const float *lq = a.lut + ((int64_t)(b >> 2) * a.Ks) * (M * 4) + (b & 3);
                         qfilter_event<M>(pm, cp, lq, km1, rid, list_off + q * 512, lock_off + q * 4, shq_off + q * 2,
-                                         gkl_off + q * 8, a.gkey ? a.gkey + b : nullptr, a.smax[b], a.qstep[b], a.qlo[b], a.dbg,
-                                         a.dbg_skip);
+                                         gkl_off + q * 8, a.gkey ? a.gkey + b : nullptr, gjl_off + q * 8,
+                                         a.gk2 ? a.gk2 + (int64_t)b * a.n_slices + slice : nullptr, a.jm1, a.smax[b],
+                                         a.qstep[b], a.qlo[b], a.dbg, a.dbg_skip);
                     }
                 }
             }
-            // every 32 steps one wave imports the bounds other workgroups published for these queries
-            if (a.gkey && (step_no & 31) == 31 && wave == (step_no >> 5) % NW && lane < QT) {
-                const int b = tile * QT + lane;
-                const unsigned long long gk = __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (gk < __hip_atomic_load(gkl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                    __hip_atomic_store(gkl + lane, gk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const unsigned short nb = qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]);
-                    if (nb < shq[lane]) shq[lane] = nb;
+            // Import what the other workgroups of these queries (the other row slices) have proven: the best
+            // k-th key any of them published and, per group of 8 concurrently scanned slices, the MAX of
+            // their j-th keys (8 disjoint slices x j rows >= k rows at or below it; +1: that row itself must
+            // still be accepted).  Bounds move on a log scale, so: steps 0, 1, 3, 7, ... then every 64th.
+            if (a.gkey) {
+                const bool pow2 = ((step_no + 1) & step_no) == 0;
+                if (pow2 || (step_no & 63) == 63) {
+                    const int rw = pow2 ? (__builtin_ctz((unsigned)step_no + 1u) % NW) : ((step_no >> 6) % NW);
+                    if (wave == rw) {
+#pragma unroll 1
+                        for (int q0 = 0; q0 < QT; q0 += 8) {
+                            const int q = q0 + (lane >> 3);
+                            const int b = tile * QT + q;
+                            unsigned long long bound =
+                                __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (a.gk2) {
+#pragma unroll 1
+                                for (int g0 = 0; g0 < a.n_slices; g0 += 8) {
+                                    unsigned long long v =
+                                        __hip_atomic_load(a.gk2 + (int64_t)b * a.n_slices + g0 + (lane & 7),
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                                    for (int o = 1; o < 8; o <<= 1) {
+                                        const unsigned long long p = __shfl_xor(v, o);
+                                        v = p > v ? p : v;
+                                    }
+                                    if (v != ~0ull && v + 1ull < bound) bound = v + 1ull;
+                                }
+                            }
+                            if ((lane & 7) == 0 &&
+                                bound < __hip_atomic_load(gkl + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                                __hip_atomic_store(gkl + q, bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                const unsigned short nb = qbound_from_key<M>(bound, a.smax[b], a.qstep[b], a.qlo[b]);
+                                if (nb < shq[q]) shq[q] = nb;
+                            }
+                        }
+                    }
                 }
             }
             // pick up the workgroup bound: every 4th step, and right after this wave's own events
@@ -1116,41 +1163,108 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
 }
 
 
-// Seed bound: exact top-k of every query over the first S rows (one wave per query, exact ascending-m
-// sums from the fp32 TILED table).  Its k-th key is a valid upper bound of the final k-th key, so the
-// scan starts with a filter that passes ~k/S of the rows instead of all of them (the cold-start
-// "flood" cost 16 waves x 16 queries x 64 uncoalesced gathers per work item).
+// Seed bound: exact top-k of every query over the first S rows.  Its k-th key is a valid upper bound
+// of the final k-th key, so the scan starts with a filter that passes ~k/S of the rows instead of all
+// of them (the cold-start "flood" cost 16 waves x 16 queries x 64 uncoalesced gathers per work item).
+// One 16-wave workgroup per group of 4 queries: their fp32 TILED rows [Ks][M][4] (64 KB at M=16) are
+// staged in LDS, so ONE ds_read_b128 per (row, m) feeds the four ascending-m sums (gathering the same
+// entries from L2 cost a 64-byte request per 4 useful bytes: 150 us for 4096 rows x 1024 queries).
+// The 16 wave lists of a query are merged through LDS.  The seed rows are scanned again by the main
+// kernel: only the bound leaves this kernel.
+constexpr int kSeedWaves = 16;
 template <int M, bool SKEWED>
-__global__ __launch_bounds__(256) void seed_bound_kernel(const uint8_t *__restrict__ codes, int64_t S,
-                                                        const uint32_t *__restrict__ valid,
-                                                        const float *__restrict__ lut, int B, int Ks, int k,
-                                                        unsigned long long *__restrict__ gkey) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
-    const float *lq = lut + ((int64_t)(b >> 2) * Ks) * (M * 4) + (b & 3);
-    WaveList L;
-    L.reset();
-    for (int64_t r0 = 0; r0 < S; r0 += 64) {
+__global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8_t *__restrict__ codes, int64_t S,
+                                                                    const uint32_t *__restrict__ valid,
+                                                                    const float *__restrict__ lut, int B, int Ks, int k,
+                                                                    unsigned long long *__restrict__ gkey) {
+    constexpr int CW = M / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [Ks][M + 1] x 4 queries: the pad entry spreads a fixed m over the banks (slot (code*(M+1) + m) % 16 =
+    // (code + m) % 16); unpadded, all 64 lanes of a look-up hit ONE 16-byte slot-bank (16-way conflict)
+    f32x4 *tab = (f32x4 *)smem;
+    unsigned long long *lists = (unsigned long long *)(smem + (size_t)Ks * (M + 1) * 16);  // [kSeedWaves][64]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g4 = blockIdx.x;
+    const int km1 = k - 1;
+    {
+        const f32x4 *src = (const f32x4 *)lut + (int64_t)g4 * Ks * M;
+        for (int i = tid; i < Ks * M; i += kSeedWaves * 64) tab[i + i / M] = src[i];
+    }
+    __syncthreads();
+    // inverse skew rotation of this lane's rows (row % M == lane % M: the rows of a wave start at a multiple of 64)
+    const int sinv = (M - lane % M) % M;
+    const uint32_t bsh_inv = (uint32_t)(sinv & 3);
+    bool abit_inv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) abit_inv[i] = (((sinv >> 2) >> i) & 1) != 0;
+
+    WaveList L[4];
+    uint32_t thi[4], tlo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        L[q].reset();
+        thi[q] = kKeyInfHi;
+        tlo[q] = kIdNone;
+    }
+    for (int64_t r0 = (int64_t)wave * 64; r0 < S; r0 += kSeedWaves * 64) {
         const int64_t r = r0 + lane;
         bool ok = r < S;
         if (ok && valid) ok = (valid[r >> 5] >> (r & 31)) & 1u;
-        float d = 0.f;
-        if (ok) {
-            const uint8_t *c = codes + r * M;
+        uint32_t c[CW];
+        {
+            const uint32_t *p = (const uint32_t *)(codes + (r < S ? r : S - 1) * M);
 #pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const int byte = SKEWED ? (int)(((m - r) % M + M) % M) : m;
-                d += lq[((int64_t)c[byte] * M + m) * 4];
+            for (int i = 0; i < CW; ++i) c[i] = p[i];
+        }
+        if constexpr (SKEWED) rotate_row<CW>(c, abit_inv, bsh_inv);
+        f32x4 v[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const uint32_t code = (c[m / 4] >> (8 * (m % 4))) & 0xffu;
+            v[m] = tab[code * (M + 1) + m];
+        }
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < M; ++m) d += v[m];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t khi = f32_to_ordered(d[q]);
+            const unsigned long long pm = __ballot(ok && key_less(khi, (uint32_t)r, thi[q], tlo[q]));
+            if (pm) {
+                wavelist_insert_many(L[q], pm, khi, (uint32_t)r, lane);
+                thi[q] = __builtin_amdgcn_readlane(L[q].hi, km1);
+                tlo[q] = __builtin_amdgcn_readlane(L[q].lo, km1);
             }
         }
-        const unsigned long long pm = __ballot(ok);
-        if (pm) wavelist_insert_many(L, pm, f32_to_ordered(d), (uint32_t)r, lane);
     }
-    const uint32_t hi = __builtin_amdgcn_readlane(L.hi, k - 1), lo = __builtin_amdgcn_readlane(L.lo, k - 1);
-    // +1: the seed rows are in nobody's list, so the scan must still ACCEPT the row that sets the bound
-    // (bounds published by workgroups come from rows their own list already holds and stay strict)
-    if (lane == 0 && hi != kKeyInfHi) gkey[b] = (((unsigned long long)hi << 32) | lo) + 1ull;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        WaveList X = L[0];
+        if (q == 1) X = L[1];
+        if (q == 2) X = L[2];
+        if (q == 3) X = L[3];
+        lists[wave * 64 + lane] = ((unsigned long long)X.hi << 32) | X.lo;
+        __syncthreads();
+#pragma unroll 1
+        for (int stride = kSeedWaves / 2; stride >= 1; stride >>= 1) {
+            if (wave < stride) {
+                const unsigned long long o = lists[(wave + stride) * 64 + lane];
+                wavelist_merge_sorted(X, (uint32_t)(o >> 32), (uint32_t)o, lane);
+                lists[wave * 64 + lane] = ((unsigned long long)X.hi << 32) | X.lo;
+            }
+            __syncthreads();
+        }
+        const int b = g4 * 4 + q;
+        if (wave == 0 && b < B) {
+            const uint32_t hi = __builtin_amdgcn_readlane(X.hi, km1), lo = __builtin_amdgcn_readlane(X.lo, km1);
+            // +1: the seed rows are in nobody's list, so the scan must still ACCEPT the row that sets the bound
+            // (bounds published by workgroups come from rows their own list already holds and stay strict)
+            if (lane == 0 && hi != kKeyInfHi) gkey[b] = (((unsigned long long)hi << 32) | lo) + 1ull;
+        }
+        __syncthreads();
+    }
 }
 
 // ---- quantisation of the fp32 TILED table [Bpad/4][Ks][M][4] -------------------------------------
@@ -1231,6 +1345,96 @@ __global__ __launch_bounds__(256) void lut_quant_kernel(const float *__restrict_
         pk[half * 2 + 1] = q[2] | (q[3] << 16);
     }
     ((u32x4 *)out)[id] = (u32x4){pk[0], pk[1], pk[2], pk[3]};
+}
+
+// The three passes above in one launch: one workgroup per group of 8 queries (two fp32 TILED groups of 4).
+// Thread t owns sub-space m = t % M of codes k = t / M, t / M + 256 / M, ...: per-(query, m) min/max by an
+// LDS tree, then (step, L, Smax) per query, then the 16-byte quantised entries.
+template <int M>
+__global__ __launch_bounds__(256) void lut_quantise_fused_kernel(const float *__restrict__ lut, int Ks, int qmax,
+                                                                uint16_t *__restrict__ out,
+                                                                float *__restrict__ qstep, double *__restrict__ qlo,
+                                                                float *__restrict__ smax) {
+    constexpr int KPT = 256 / M;  // codes covered per sweep of the block
+    __shared__ float s_lo[KPT][M][8], s_hi[KPT][M][8];
+    __shared__ float s_step[8];
+    const int tid = threadIdx.x;
+    const int m = tid % M, kr = tid / M;
+    const int g8 = blockIdx.x;
+    const f32x4 *base0 = (const f32x4 *)lut + (int64_t)(g8 * 2) * Ks * M;
+    const f32x4 *base1 = base0 + (int64_t)Ks * M;
+    float mn[8], mx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        mn[i] = __builtin_inff();
+        mx[i] = -__builtin_inff();
+    }
+    for (int k = kr; k < Ks; k += KPT) {
+        const f32x4 v0 = base0[(int64_t)k * M + m], v1 = base1[(int64_t)k * M + m];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mn[i] = fminf(mn[i], v0[i]);
+            mx[i] = fmaxf(mx[i], v0[i]);
+            mn[4 + i] = fminf(mn[4 + i], v1[i]);
+            mx[4 + i] = fmaxf(mx[4 + i], v1[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        s_lo[kr][m][i] = mn[i];
+        s_hi[kr][m][i] = mx[i];
+    }
+    __syncthreads();
+    // thread (m, i) for tid < M*8 folds the KPT partials
+    if (tid < M * 8) {
+        const int mm = tid / 8, i = tid % 8;
+        float l = s_lo[0][mm][i], h = s_hi[0][mm][i];
+        for (int r = 1; r < KPT; ++r) {
+            l = fminf(l, s_lo[r][mm][i]);
+            h = fmaxf(h, s_hi[r][mm][i]);
+        }
+        s_lo[0][mm][i] = l;
+        s_hi[0][mm][i] = h;
+    }
+    __syncthreads();
+    if (tid < 8) {
+        float range = 0.f, sm = 0.f;
+        double Lsum = 0.0;
+        for (int mm = 0; mm < M; ++mm) {
+            const float l = s_lo[0][mm][tid], h = s_hi[0][mm][tid];
+            range = fmaxf(range, h - l);
+            sm += fmaxf(fabsf(l), fabsf(h));
+            Lsum += (double)l;
+        }
+        float step = range / (float)qmax;
+        if (!(step > 0.f)) step = 1.f;
+        s_step[tid] = step;
+        const int b = g8 * 8 + tid;
+        qstep[b] = step;
+        qlo[b] = Lsum;
+        smax[b] = sm;
+    }
+    __syncthreads();
+    float lo_r[8], st_r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        lo_r[i] = s_lo[0][m][i];
+        st_r[i] = s_step[i];
+    }
+    u32x4 *o = (u32x4 *)out + (int64_t)g8 * Ks * M;
+    for (int k = kr; k < Ks; k += KPT) {
+        const f32x4 v0 = base0[(int64_t)k * M + m], v1 = base1[(int64_t)k * M + m];
+        uint32_t q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float v = i < 4 ? v0[i] : v1[i - 4];
+            float t = floorf((v - lo_r[i]) / st_r[i]);
+            if (!(t > 0.f)) t = 0.f;
+            if (t > (float)qmax) t = (float)qmax;
+            q[i] = (uint32_t)t;
+        }
+        o[(int64_t)k * M + m] = (u32x4){q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), q[6] | (q[7] << 16)};
+    }
 }
 
 // Smax[b] = sum_m max_k |lut[b][m][k]| from the TILED table [Bpad/QI][Ks][M][QI]; one wave per group
@@ -1562,7 +1766,7 @@ using namespace annlite;
 template <int M, int NQ, int NW, int WPS, bool SKEWED>
 static int launch_qfilter(const ScanArgs &a, int grid, hipStream_t st) {
     const size_t lds_lut = (size_t)a.Ks * NQ * M * 16;
-    const size_t need = lds_lut + 256 + (size_t)8 * NQ * 64 * 8;
+    const size_t need = lds_lut + 256 + (size_t)8 * NQ * 64 * 8 + 128;
     auto fn = adc_scan_qfilter_kernel<M, NQ, NW, WPS, SKEWED>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
@@ -1609,7 +1813,7 @@ extern "C" int annlite_scan_plan_query(int64_t N, int64_t M, int64_t Ks, int cod
         const int64_t bpad = ((B + 15) / 16) * 16;
         plan->workspace_bytes = (int64_t)n_tiles * plan->qt * ns * k * 8 + 256 + bpad * 4 + 256;
         if (c.mode == 4)
-            plan->workspace_bytes += bpad * 4 + 256 + 2 * (bpad * 8 + 256) + 2 * (bpad * M * 4 + 256) + bpad * M * Ks * 2 + 256;
+            plan->workspace_bytes += bpad * 4 + 256 + 2 * (bpad * 8 + 256) + (bpad * ns * 8 + 256) + bpad * M * Ks * 2 + 256;
     } else {
         plan->fast = 0;
         plan->qi = 1;
@@ -1707,7 +1911,18 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         a.slice_rows = sr;
     }
     // slots of slices that hold no rows stay "none"
-    ANNLITE_HIP_TRY(hipMemsetAsync(workspace_dev, 0xff, (size_t)plan.workspace_bytes, st));
+    {
+        // partial lists, and (quantised-filter plan) the shared bounds right behind them; the rest is scratch
+        size_t fill = (size_t)plan.workspace_bytes;
+        FastCfg c0;
+        if (plan.fast && fast_cfg(M, Ks, code_bytes, k, &c0) && c0.mode == 4) {
+            const size_t bpad = (size_t)((B + 15) / 16) * 16;
+            auto r256 = [](size_t x) { return (x + 255) / 256 * 256; };
+            fill = r256((size_t)a.n_tiles * plan.qt * plan.n_slices * k * 8) + r256(bpad * 8) +
+                   r256(bpad * plan.n_slices * 8);
+        }
+        ANNLITE_HIP_TRY(hipMemsetAsync(workspace_dev, 0xff, fill, st));
+    }
     if (N == 0) return ANNLITE_OK;
     const int n_items = a.n_tiles * a.n_slices;
     if (plan.fast) {
@@ -1720,39 +1935,47 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             const int64_t bpad = ((B + 15) / 16) * 16;
             char *wp = (char *)workspace_dev + (((int64_t)a.n_tiles * plan.qt * plan.n_slices * k * 8 + 255) / 256) * 256;
             auto carve = [&](int64_t bytes) { char *r = wp; wp += ((bytes + 255) / 256) * 256; return r; };
+            // [gkey][gk2] directly behind the partial lists: the one memset above covers exactly these three
+            unsigned long long *gk = (unsigned long long *)carve(bpad * 8);
+            unsigned long long *gk2 = (unsigned long long *)carve(bpad * plan.n_slices * 8);
             float *smax = (float *)carve(bpad * 4);
             float *qstep = (float *)carve(bpad * 4);
             double *qlo = (double *)carve(bpad * 8);
-            unsigned long long *gk = (unsigned long long *)carve(bpad * 8);  // all-ones after the workspace memset
             // per-slice lists stay complete (a superset generator for re-rank) unless sharing is requested
             a.gkey = share_across_slices ? gk : nullptr;
+            a.gk2 = share_across_slices ? gk2 : nullptr;
+            a.jm1 = (int)((k + 7) / 8) - 1;
             if (share_across_slices && N >= 4096) {
-                const int64_t S = 1024;
-                const unsigned blocks = (unsigned)((B + 3) / 4);
+                int64_t S = 4096;
+                if (const char *e = getenv("ANNLITE_SEED_ROWS")) S = atoll(e);
+                if (S > N) S = N;
                 const bool skw = codes_layout == ANNLITE_CODES_SKEWED;
-#define ANNLITE_SEED(MM)                                                                                               \
-    if (skw) hipLaunchKernelGGL((seed_bound_kernel<MM, true>), dim3(blocks), dim3(256), 0, st, (const uint8_t *)codes_dev, \
-                                S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, gk);                               \
-    else hipLaunchKernelGGL((seed_bound_kernel<MM, false>), dim3(blocks), dim3(256), 0, st, (const uint8_t *)codes_dev,  \
-                            S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, gk)
-                if (M == 8) { ANNLITE_SEED(8); } else if (M == 16) { ANNLITE_SEED(16); } else { ANNLITE_SEED(32); }
+#define ANNLITE_SEED(MM)                                                                                          \
+    {                                                                                                             \
+        auto fn = skw ? seed_bound_kernel<MM, true> : seed_bound_kernel<MM, false>;                               \
+        const size_t lds = (size_t)Ks * (MM + 1) * 16 + (size_t)kSeedWaves * 64 * 8;                                  \
+        ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(fn, dim3((unsigned)((B + 3) / 4)), dim3(kSeedWaves * 64), lds, st,                      \
+                           (const uint8_t *)codes_dev, S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, gk);   \
+    }
+                if (M == 8) ANNLITE_SEED(8) else if (M == 16) ANNLITE_SEED(16) else ANNLITE_SEED(32)
 #undef ANNLITE_SEED
                 rc = launch_status("seed_bound_kernel");
                 if (rc != ANNLITE_OK) return rc;
             }
-            float *lo = (float *)carve(bpad * M * 4);
-            float *hi = (float *)carve(bpad * M * 4);
             uint16_t *q16 = (uint16_t *)carve(bpad * M * Ks * 2);
             const int qmax = (int)(32767 / M);
-            const int n_g4 = (int)(bpad / 4), n_g8 = (int)(bpad / 8);
-            hipLaunchKernelGGL(lut_minmax_kernel, dim3((n_g4 * (int)M + 3) / 4), dim3(256), 0, st, lut_dev, n_g4, (int)M,
-                               (int)Ks, lo, hi);
-            hipLaunchKernelGGL(lut_qparams_kernel, dim3((unsigned)((bpad + 255) / 256)), dim3(256), 0, st, lo, hi,
-                               (int)bpad, (int)M, qmax, qstep, qlo, smax);
-            const int64_t tot = (int64_t)n_g8 * Ks * M;
-            hipLaunchKernelGGL(lut_quant_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, lut_dev, n_g8,
-                               (int)M, (int)Ks, lo, qstep, qmax, q16);
-            rc = launch_status("lut_quant_kernel");
+            const unsigned n_g8 = (unsigned)(bpad / 8);
+            if (M == 8)
+                hipLaunchKernelGGL(lut_quantise_fused_kernel<8>, dim3(n_g8), dim3(256), 0, st, lut_dev, (int)Ks, qmax, q16,
+                                   qstep, qlo, smax);
+            else if (M == 16)
+                hipLaunchKernelGGL(lut_quantise_fused_kernel<16>, dim3(n_g8), dim3(256), 0, st, lut_dev, (int)Ks, qmax, q16,
+                                   qstep, qlo, smax);
+            else
+                hipLaunchKernelGGL(lut_quantise_fused_kernel<32>, dim3(n_g8), dim3(256), 0, st, lut_dev, (int)Ks, qmax, q16,
+                                   qstep, qlo, smax);
+            rc = launch_status("lut_quantise_fused_kernel");
             if (rc != ANNLITE_OK) return rc;
             a.smax = smax;
             a.qstep = qstep;
