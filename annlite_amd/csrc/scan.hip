@@ -46,7 +46,8 @@ struct ScanArgs {
     int32_t B;
     int32_t k;
     int32_t n_tiles;
-    int32_t n_slices;
+    int32_t n_slices;        // 1, 2, 4 or a multiple of 8
+    int32_t n_items;         // work items (see item_map)
     int64_t slice_rows;      // multiple of 64
     const float *smax;       // [ceil16(B)] sum_m max_k |lut[b][m][k]|  (filter kernel: rounding slack)
     // quantised filter (qfilter kernel): 12-bit integer tables + the affine map back to distances
@@ -59,10 +60,26 @@ struct ScanArgs {
                              // concurrently scanned slices of a query hold >= k rows at or below the MAX of
                              // their j-th keys, a bound ~k/j times tighter than any single slice's own k-th
     int32_t jm1;             // j - 1
+    int32_t flush_mask;      // a wave flushes its candidate queue every (flush_mask + 1) steps, staggered by wave
     int32_t dbg_skip;        // debug bitmask (ANNLITE_DEBUG_SKIP): 1 no gathers, 2 no insert/publish, 4 no event at all
     unsigned long long *dbg; // optional event counters (ANNLITE_DEBUG_COUNTERS=1): [0] slow-block entries,
                              // [1] (wave,query) events, [2] events with an insertion, [3] bound publications
 };
+
+// work item -> (query tile, row slice).  item % 8 == blockIdx % 8 == the XCD the block lands on (speed
+// only): with >= 8 slices an XCD owns the slices congruent to it and consecutive items of one XCD walk the
+// tiles of the same slice (its L2 keeps the slice's rows); with fewer slices 8 / n_slices XCDs share one.
+__device__ __forceinline__ bool item_map(const ScanArgs &a, int item, int &tile, int &slice) {
+    const int xcd = item & 7, j = item >> 3;
+    if (a.n_slices >= 8) {
+        tile = j % a.n_tiles;
+        slice = (j / a.n_tiles) * 8 + xcd;
+        return true;
+    }
+    slice = xcd % a.n_slices;
+    tile = j * (8 / a.n_slices) + xcd / a.n_slices;
+    return tile < a.n_tiles;
+}
 
 // ---- compile-time exec masks for the ordered accumulation ---------------------------------------
 template <int M>
@@ -304,16 +321,14 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_fast_kernel(const ScanA
         }
     }
 
-    const int n_items = a.n_tiles * a.n_slices;
+    const int n_items = a.n_items;
     const int64_t group_bytes = (int64_t)a.Ks * RB;  // one tiled-LUT group = [Ks][M][QI] floats
 
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         // item -> (slice, tile): slice % 8 == item % 8 == blockIdx % 8 (the XCD this block lands on,
         // speed only), consecutive items of one XCD walk the tiles of the same slice.
-        const int xcd = item & 7;
-        const int j = item >> 3;
-        const int tile = j % a.n_tiles;
-        const int slice = (j / a.n_tiles) * 8 + xcd;
+        int tile, slice;
+        if (!item_map(a, item, tile, slice)) continue;
 
         __syncthreads();  // previous item's LDS readers are done
         {
@@ -581,14 +596,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_filter_kernel(const Sca
     volatile float *shthr = (volatile float *)(smem + lut_bytes);
     unsigned long long *shkey = (unsigned long long *)(smem + lut_bytes + 64);
 
-    const int n_items = a.n_tiles * a.n_slices;
+    const int n_items = a.n_items;
     const int64_t group_bytes = (int64_t)a.Ks * RB;
 
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int xcd = item & 7;
-        const int j = item >> 3;
-        const int tile = j % a.n_tiles;
-        const int slice = (j / a.n_tiles) * 8 + xcd;
+        int tile, slice;
+        if (!item_map(a, item, tile, slice)) continue;
 
         __syncthreads();
         {
@@ -819,20 +832,49 @@ __device__ __forceinline__ unsigned short qbound_from_key(unsigned long long key
 }
 
 
-template <int M>
-__device__ __attribute__((noinline)) void qfilter_event(unsigned long long pm, const uint32_t *cp /* M/4 dwords, true
-                                                        m order */, const float *lq, int km1, uint32_t rid,
-                                                        uint32_t list_off, uint32_t lock_off, uint32_t shq_off,
-                                                        uint32_t gkl_off, unsigned long long *gkey_b,
-                                                        uint32_t gjl_off, unsigned long long *gk2_slot, int jm1,
-                                                        float smax_b, float qstep_b, double qlo_b,
-                                                        unsigned long long *dbg, int skip) {
+// what a queue flush needs and a work item keeps constant
+struct FlushCtx {
+    const uint8_t *codes;
+    const float *lut;
+    const float *smax;
+    const float *qstep;
+    const double *qlo;
+    unsigned long long *gkey;
+    unsigned long long *gk2;
+    unsigned long long *dbg;
+    int32_t Ks, b0, n_slices, slice, km1, jm1, skip;
+    uint32_t list_off, lock_off, shq_off, gkl_off, gjl_off;
+};
+
+// Flush one wave's candidate queue: up to 64 (query, row) pairs whose integer sum passed the filter.
+// Lane i takes entry i: re-reads the row's code bytes, gathers its exact ascending-m fp32 sum from the
+// fp32 table in global memory, then the candidates are offered query by query to the shared lists.
+// Batching matters: one candidate at a time paid the gather latency, the call and the lock ~3.6 us each
+// (46 times per wave at 1.25M rows); a flush pays them once for everything queued since the last one.
+template <int M, bool SKEWED>
+__device__ __attribute__((noinline)) void qfilter_flush(const FlushCtx c, uint32_t queue_off, int qcnt) {
+    constexpr int CW = M / 4;
     const int lane = threadIdx.x & 63;
-    unsigned long long *list = (unsigned long long *)(g_smem + list_off);  // [64] ascending
-    // exact ascending-m fp32 sum, candidate lanes only (64 lanes x 16 uncoalesced 4-byte loads per event made
-    // the texture addresser the bottleneck although typically ONE lane needs them)
+    const bool act = lane < qcnt;
+    const unsigned long long e = act ? ((const unsigned long long *)(g_smem + queue_off))[lane] : 0ull;
+    const uint32_t rid = (uint32_t)e;
+    const int q = (int)(e >> 32);
     float ex = 0.f;
-    if (!(skip & 1) && ((pm >> lane) & 1ull)) {
+    if (act && !(c.skip & 1)) {
+        uint32_t cp[CW];
+        const uint32_t *p = (const uint32_t *)(c.codes + (int64_t)rid * M);
+#pragma unroll
+        for (int i = 0; i < CW; ++i) cp[i] = p[i];
+        if constexpr (SKEWED) {
+            // stored byte j of row n is the code of sub-space (j + n) mod M: rotate back by n mod M
+            const int sinv = (M - (int)(rid % M)) % M;
+            bool abit_inv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) abit_inv[i] = (((sinv >> 2) >> i) & 1) != 0;
+            rotate_row<CW>(cp, abit_inv, (uint32_t)(sinv & 3));
+        }
+        const int b = c.b0 + q;
+        const float *lq = c.lut + ((int64_t)(b >> 2) * c.Ks) * (M * 4) + (b & 3);
         float vals[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) {
@@ -843,57 +885,71 @@ __device__ __attribute__((noinline)) void qfilter_event(unsigned long long pm, c
         for (int m = 0; m < M; ++m) ex += vals[m];
     }
     const uint32_t khi = f32_to_ordered(ex);
-    // cheap pre-check against the current bound, without the lock (it only ever decreases): the list's own
-    // k-th key or the best k-th key another workgroup has published for this query, whichever is smaller
-    unsigned long long *gkl = (unsigned long long *)(g_smem + gkl_off);
-    unsigned long long kth = __hip_atomic_load(list + km1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const unsigned long long gk = __hip_atomic_load(gkl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (gk < kth) kth = gk;
-    unsigned long long px = __ballot(key_less(khi, rid, (uint32_t)(kth >> 32), (uint32_t)kth)) & pm;
-    if (!px || (skip & 2)) return;
-    if (dbg && lane == 0) atomicAdd(dbg + 2, 1ull);
-    // ---- critical section -------------------------------------------------------------------------
-    unsigned int *lock = (unsigned int *)(g_smem + lock_off);
-    for (;;) {
-        unsigned int got = 0;
-        if (lane == 0) got = (atomicCAS(lock, 0u, 1u) == 0u) ? 1u : 0u;
-        if (__builtin_amdgcn_readfirstlane(got)) break;
-        __builtin_amdgcn_s_sleep(2);
-    }
-    unsigned long long e = __hip_atomic_load(list + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    WaveList L;
-    L.hi = (uint32_t)(e >> 32);
-    L.lo = (uint32_t)e;
-    const uint32_t thi = __builtin_amdgcn_readlane(L.hi, km1), tlo = __builtin_amdgcn_readlane(L.lo, km1);
-    px = __ballot(key_less(khi, rid, thi, tlo)) & px;  // the list may have tightened meanwhile
-    if (px) {
-        wavelist_insert_many(L, px, khi, rid, lane);
-        __hip_atomic_store(list + lane, ((unsigned long long)L.hi << 32) | L.lo, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t ohi = __builtin_amdgcn_readlane(L.hi, km1);
-        const uint32_t olo = __builtin_amdgcn_readlane(L.lo, km1);
-        const unsigned long long okey = ((unsigned long long)ohi << 32) | olo;
-        if (lane == 0 && ohi != kKeyInfHi && okey < gk) {
-            if (dbg) atomicAdd(dbg + 3, 1ull);
-            // tell the other workgroups of this query (other row slices) and remember it locally
-            if (gkey_b) __hip_atomic_fetch_min(gkey_b, okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(gkl, okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            *(volatile unsigned short *)(g_smem + shq_off) = qbound_from_key<M>(okey, smax_b, qstep_b, qlo_b);
+    unsigned long long rem = __ballot(act);
+    while (rem) {
+        const int q0 = __builtin_amdgcn_readlane(q, __builtin_ctzll(rem));
+        const unsigned long long pm = __ballot(act && q == q0);
+        rem &= ~pm;
+        if (c.dbg && lane == 0) {
+            atomicAdd(c.dbg + 1, 1ull);
+            atomicAdd(c.dbg + 4, (unsigned long long)__popcll(pm));
         }
-        if (gk2_slot) {
-            // this slice's j-th key, for the max-of-j-th bound the sibling slices compute
-            const uint32_t jhi = __builtin_amdgcn_readlane(L.hi, jm1);
-            const uint32_t jlo = __builtin_amdgcn_readlane(L.lo, jm1);
-            const unsigned long long jkey = ((unsigned long long)jhi << 32) | jlo;
-            volatile unsigned long long *gjl = (volatile unsigned long long *)(g_smem + gjl_off);
-            if (lane == 0 && jhi != kKeyInfHi && jkey < *gjl) {
-                *gjl = jkey;
-                __hip_atomic_store(gk2_slot, jkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int b = c.b0 + q0;
+        unsigned long long *list = (unsigned long long *)(g_smem + c.list_off + q0 * 512);  // [64] ascending
+        unsigned long long *gkl = (unsigned long long *)(g_smem + c.gkl_off + q0 * 8);
+        // cheap pre-check against the current bound, without the lock (it only ever decreases): the list's
+        // own k-th key or the best bound imported from the other workgroups, whichever is smaller
+        unsigned long long kth = __hip_atomic_load(list + c.km1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned long long gk = __hip_atomic_load(gkl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (gk < kth) kth = gk;
+        unsigned long long px = __ballot(key_less(khi, rid, (uint32_t)(kth >> 32), (uint32_t)kth)) & pm;
+        if (!px || (c.skip & 2)) continue;
+        if (c.dbg && lane == 0) atomicAdd(c.dbg + 2, 1ull);
+        // ---- critical section ---------------------------------------------------------------------
+        unsigned int *lock = (unsigned int *)(g_smem + c.lock_off + q0 * 4);
+        for (;;) {
+            unsigned int got = 0;
+            if (lane == 0) got = (atomicCAS(lock, 0u, 1u) == 0u) ? 1u : 0u;
+            if (__builtin_amdgcn_readfirstlane(got)) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        const unsigned long long le = __hip_atomic_load(list + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        WaveList L;
+        L.hi = (uint32_t)(le >> 32);
+        L.lo = (uint32_t)le;
+        const uint32_t thi = __builtin_amdgcn_readlane(L.hi, c.km1), tlo = __builtin_amdgcn_readlane(L.lo, c.km1);
+        px = __ballot(key_less(khi, rid, thi, tlo)) & px;  // the list may have tightened meanwhile
+        if (px) {
+            wavelist_insert_many(L, px, khi, rid, lane);
+            __hip_atomic_store(list + lane, ((unsigned long long)L.hi << 32) | L.lo, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t ohi = __builtin_amdgcn_readlane(L.hi, c.km1);
+            const uint32_t olo = __builtin_amdgcn_readlane(L.lo, c.km1);
+            const unsigned long long okey = ((unsigned long long)ohi << 32) | olo;
+            if (lane == 0 && ohi != kKeyInfHi && okey < gk) {
+                if (c.dbg) atomicAdd(c.dbg + 3, 1ull);
+                // tell the other workgroups of this query (other row slices) and remember it locally
+                if (c.gkey) __hip_atomic_fetch_min(c.gkey + b, okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gkl, okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                *(volatile unsigned short *)(g_smem + c.shq_off + q0 * 2) =
+                    qbound_from_key<M>(okey, c.smax[b], c.qstep[b], c.qlo[b]);
+            }
+            if (c.gk2) {
+                // this slice's j-th key, for the max-of-j-th bound the sibling slices compute
+                const uint32_t jhi = __builtin_amdgcn_readlane(L.hi, c.jm1);
+                const uint32_t jlo = __builtin_amdgcn_readlane(L.lo, c.jm1);
+                const unsigned long long jkey = ((unsigned long long)jhi << 32) | jlo;
+                volatile unsigned long long *gjl = (volatile unsigned long long *)(g_smem + c.gjl_off + q0 * 8);
+                if (lane == 0 && jhi != kKeyInfHi && jkey < *gjl) {
+                    *gjl = jkey;
+                    __hip_atomic_store(c.gk2 + (int64_t)b * c.n_slices + c.slice, jkey, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
+        // LDS executes one wave's instructions in order, so the list stores are visible before the release
+        if (lane == 0) __hip_atomic_store(lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    // LDS executes one wave's instructions in order, so the list stores are visible before the release
-    if (lane == 0) __hip_atomic_store(lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // =================================================================================================
@@ -938,31 +994,24 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
     bool abit[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) abit[i] = (((s >> 2) >> i) & 1) != 0;
-    const int sinv = (M - s) % M;
-    const uint32_t bsh_inv = (uint32_t)(sinv & 3);
-    bool abit_inv[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) abit_inv[i] = (((sinv >> 2) >> i) & 1) != 0;
     const unsigned char *mbase[M];
 #pragma unroll
     for (int t = 0; t < M; ++t) mbase[t] = smem + ((s + t) % M) * EB;
 
     const int lut_bytes = a.Ks * KSTRIDE;
     const uint32_t shq_off = (uint32_t)lut_bytes, lock_off = shq_off + 64, gkl_off = shq_off + 128,
-                   list_off = shq_off + 256, gjl_off = list_off + QT * 512;
+                   list_off = shq_off + 256, gjl_off = list_off + QT * 512, queue_off = gjl_off + 128;
     unsigned long long *gkl = (unsigned long long *)(smem + gkl_off);  // [QT] best published k-th key
     volatile uint16_t *shq = (volatile uint16_t *)(smem + shq_off);
     volatile uint32_t *locks = (volatile uint32_t *)(smem + lock_off);
     unsigned long long *lists = (unsigned long long *)(smem + list_off);  // [QT][64]
 
-    const int n_items = a.n_tiles * a.n_slices;
+    const int n_items = a.n_items;
     const int64_t group_bytes = (int64_t)a.Ks * RB;
 
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int xcd = item & 7;
-        const int j = item >> 3;
-        const int tile = j % a.n_tiles;
-        const int slice = (j / a.n_tiles) * 8 + xcd;
+        int tile, slice;
+        if (!item_map(a, item, tile, slice)) continue;
 
         __syncthreads();
         {
@@ -1048,6 +1097,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
             load_row(row0 + stride + lane, cnext);
         }
 
+        const FlushCtx fc = {(const uint8_t *)a.codes, a.lut, a.smax, a.qstep, a.qlo, a.gkey, a.gk2, a.dbg,
+                             a.Ks, tile * QT, a.n_slices, slice, km1, a.jm1, a.dbg_skip,
+                             list_off, lock_off, shq_off, gkl_off, gjl_off};
+        int qcnt = 0;  // entries in this wave's candidate queue
         int step_no = 0;
         for (; row0 < slice_end; row0 += stride, ++step_no) {
             unsigned long long vmask = ~0ull;
@@ -1070,35 +1123,45 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
 #pragma unroll
                 for (int w = 0; w < 4; ++w) anyv |= thp[h][w] - acc[h][w];
             const unsigned long long anym = __ballot((anyv & 0x80008000u) != 0) & vmask;
-            bool had_event = false;
-            if (anym) {
-                had_event = true;
+            bool flushed = false;
+            if (anym && !(a.dbg_skip & 4)) {
                 if (a.dbg && lane == 0) atomicAdd(a.dbg + 0, 1ull);
-                // true sub-space order of this lane's row (undo the skew rotation once per event)
-                uint32_t cp[CW];
+                // queue (query, row) of every lane that passed; the exact work happens in batches
+                unsigned long long *queue = (unsigned long long *)(smem + queue_off + wave * 512);
 #pragma unroll
-                for (int i = 0; i < CW; ++i) cp[i] = ccur[i];
-                rotate_row<CW>(cp, abit_inv, bsh_inv);
+                for (int h = 0; h < NQ; ++h) {
 #pragma unroll
-                for (int q = 0; q < QT; ++q) {
-                    const uint32_t w32 = acc[q / QG][(q % QG) / 2];
-                    const uint32_t tw32 = thp[q / QG][(q % QG) / 2];
-                    const uint32_t Sq = (q & 1) ? (w32 >> 16) : (w32 & 0xffffu);
-                    const uint32_t Tq = ((q & 1) ? (tw32 >> 16) : tw32) & 0x7fffu;
-                    const unsigned long long pm = __ballot(Sq <= Tq) & vmask;
-                    if (pm && !(a.dbg_skip & 4)) {
-                        if (a.dbg && lane == 0) {
-                            atomicAdd(a.dbg + 1, 1ull);
-                            atomicAdd(a.dbg + 4, (unsigned long long)__popcll(pm));
+                    for (int w = 0; w < 4; ++w) {
+                        const uint32_t x = (thp[h][w] - acc[h][w]) & 0x80008000u;
+                        if (__ballot(x != 0) & vmask) {
+#pragma unroll
+                            for (int half = 0; half < 2; ++half) {
+                                const unsigned long long pm = __ballot((x & (half ? 0x80000000u : 0x8000u)) != 0) & vmask;
+                                if (pm) {
+                                    const int n = __popcll(pm);
+                                    if (qcnt + n > 64) {
+                                        qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
+                                        qcnt = 0;
+                                        flushed = true;
+                                    }
+                                    const int rank = __builtin_amdgcn_mbcnt_hi(
+                                        (uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                                    if ((pm >> lane) & 1ull)
+                                        queue[qcnt + rank] = ((unsigned long long)(h * QG + w * 2 + half) << 32) | rid;
+                                    qcnt += n;
+                                }
+                            }
                         }
-                        const int b = tile * QT + q;
-                        const float *lq = a.lut + ((int64_t)(b >> 2) * a.Ks) * (M * 4) + (b & 3);
-                        qfilter_event<M>(pm, cp, lq, km1, rid, list_off + q * 512, lock_off + q * 4, shq_off + q * 2,
-                                         gkl_off + q * 8, a.gkey ? a.gkey + b : nullptr, gjl_off + q * 8,
-                                         a.gk2 ? a.gk2 + (int64_t)b * a.n_slices + slice : nullptr, a.jm1, a.smax[b],
-                                         a.qstep[b], a.qlo[b], a.dbg, a.dbg_skip);
                     }
                 }
+            }
+            // flush when half full, and every (flush_mask + 1) steps: a flush costs ~7 us whatever it holds (two
+            // dependent global round trips + the list update), so waves flush rarely but staggered -- every few
+            // steps SOME wave of the workgroup tightens the shared bound
+            if (qcnt && (qcnt >= 32 || ((step_no + wave * 4) & a.flush_mask) == a.flush_mask)) {
+                qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
+                qcnt = 0;
+                flushed = true;
             }
             // Import what the other workgroups of these queries (the other row slices) have proven: the best
             // k-th key any of them published and, per group of 8 concurrently scanned slices, the MAX of
@@ -1118,9 +1181,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                             if (a.gk2) {
 #pragma unroll 1
                                 for (int g0 = 0; g0 < a.n_slices; g0 += 8) {
-                                    unsigned long long v =
-                                        __hip_atomic_load(a.gk2 + (int64_t)b * a.n_slices + g0 + (lane & 7),
-                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    unsigned long long v = 0ull;  // slots beyond n_slices never set the max
+                                    if (g0 + (lane & 7) < a.n_slices)
+                                        v = __hip_atomic_load(a.gk2 + (int64_t)b * a.n_slices + g0 + (lane & 7),
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                                     for (int o = 1; o < 8; o <<= 1) {
                                         const unsigned long long p = __shfl_xor(v, o);
@@ -1140,7 +1204,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                 }
             }
             // pick up the workgroup bound: every 4th step, and right after this wave's own events
-            if (had_event || (step_no & 3) == 3) {
+            if (flushed || (step_no & 3) == 3) {
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
@@ -1151,6 +1215,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
             if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
             load_row(row0 + 2 * stride + lane, cnext);
         }
+
+        if (qcnt) qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
 
         // ---- the shared lists ARE the workgroup's result for this (tile, slice) ----------------------
         __syncthreads();
@@ -1747,11 +1813,21 @@ static void plan_slices(int64_t N, int n_tiles, int waves, int n_cu, bool xcd8, 
     // at least one slice per XCD; more when few query tiles exist, as long as every wave keeps
     // >= 8 steps of 64 rows
     const int64_t min_rows = (int64_t)waves * 64 * 8;
-    int64_t want = (2 * (int64_t)n_cu + n_tiles - 1) / n_tiles;
+    // XCD-mapped plans: ONE work item per CU when the tiles allow it (every (query, slice) list pays its own
+    // logarithmic number of candidate events: 4 slices instead of 8 was 10% faster at 1.25M rows x 1024
+    // queries); 1, 2, 4 or a multiple of 8 slices (item_map)
+    int64_t want = ((xcd8 ? 1 : 2) * (int64_t)n_cu + n_tiles - 1) / n_tiles;
     int64_t cap = N / min_rows;
     if (want > cap) want = cap;
-    int64_t ns = xcd8 ? ((want + 7) / 8) * 8 : want;
-    if (ns < (xcd8 ? 8 : 1)) ns = xcd8 ? 8 : 1;
+    int64_t ns = want;
+    if (xcd8) ns = want <= 1 ? 1 : want <= 2 ? 2 : want <= 4 ? 4 : ((want + 7) / 8) * 8;
+    if (ns < 1) ns = 1;
+    if (xcd8) {
+        if (const char *e = getenv("ANNLITE_SCAN_SLICES")) {
+            const int64_t v = atoll(e);
+            if (v == 1 || v == 2 || v == 4 || (v >= 8 && v % 8 == 0 && v <= 4096)) ns = v;
+        }
+    }
     int64_t rows = (N + ns - 1) / ns;
     rows = ((rows + 63) / 64) * 64;
     if (rows < 64) rows = 64;
@@ -1766,7 +1842,7 @@ using namespace annlite;
 template <int M, int NQ, int NW, int WPS, bool SKEWED>
 static int launch_qfilter(const ScanArgs &a, int grid, hipStream_t st) {
     const size_t lds_lut = (size_t)a.Ks * NQ * M * 16;
-    const size_t need = lds_lut + 256 + (size_t)8 * NQ * 64 * 8 + 128;
+    const size_t need = lds_lut + 256 + (size_t)8 * NQ * 64 * 8 + 128 + (size_t)NW * 512;
     auto fn = adc_scan_qfilter_kernel<M, NQ, NW, WPS, SKEWED>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
@@ -1924,7 +2000,9 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         ANNLITE_HIP_TRY(hipMemsetAsync(workspace_dev, 0xff, fill, st));
     }
     if (N == 0) return ANNLITE_OK;
-    const int n_items = a.n_tiles * a.n_slices;
+    const int n_items = (plan.fast && a.n_slices < 8) ? ((a.n_tiles + 8 / a.n_slices - 1) / (8 / a.n_slices)) * 8
+                                                      : a.n_tiles * a.n_slices;
+    a.n_items = n_items;
     if (plan.fast) {
         FastCfg c;
         fast_cfg(M, Ks, code_bytes, k, &c);
@@ -1944,7 +2022,12 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             // per-slice lists stay complete (a superset generator for re-rank) unless sharing is requested
             a.gkey = share_across_slices ? gk : nullptr;
             a.gk2 = share_across_slices ? gk2 : nullptr;
-            a.jm1 = (int)((k + 7) / 8) - 1;
+            {
+                const int64_t grp = plan.n_slices < 8 ? plan.n_slices : 8;  // slices scanned concurrently
+                a.jm1 = (int)((k + grp - 1) / grp) - 1;
+                a.flush_mask = 63;
+                if (const char *e = getenv("ANNLITE_FLUSH_MASK")) a.flush_mask = atoi(e);
+            }
             if (share_across_slices && N >= 4096) {
                 int64_t S = 4096;
                 if (const char *e = getenv("ANNLITE_SEED_ROWS")) S = atoll(e);
