@@ -34,8 +34,10 @@ SYMBOLS = (
     'annlite_adc_dist',
     'annlite_adc_gather',
     'annlite_adc_scan_topk',
+    'annlite_adc_scan_topk_packed',
     'annlite_adc_scan_candidates',
     'annlite_topk_merge',
+    'annlite_topk_merge_packed',
     'annlite_topk_rows',
     'annlite_pq_encode',
     'annlite_pq_decode',
@@ -95,7 +97,9 @@ def lib() -> ctypes.CDLL:
     L.annlite_adc_gather.argtypes = [vp, i64, i64, i64, vp, i32, i64, vp, i64, vp, vp]
     L.annlite_adc_scan_topk.argtypes = [vp, i32, i32, i64, i64, i64, vp, vp, i64, i64, i64, vp, vp, vp, sz, vp]
     L.annlite_adc_scan_candidates.argtypes = L.annlite_adc_scan_topk.argtypes
+    L.annlite_adc_scan_topk_packed.argtypes = [vp, i32, i32, i64, i64, i64, vp, vp, i64, i64, i64, vp, vp, sz, vp]
     L.annlite_topk_merge.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
+    L.annlite_topk_merge_packed.argtypes = [vp, i64, i64, i64, vp, vp, vp]
     L.annlite_topk_rows.argtypes = [vp, i64, i64, i64, i64, vp, vp, vp]
     L.annlite_pq_encode.argtypes = [vp, i64, i64, vp, i64, i64, vp, i32, vp]
     L.annlite_pq_decode.argtypes = [vp, i32, i64, i64, i64, vp, i64, vp, vp]

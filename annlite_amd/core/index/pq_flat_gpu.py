@@ -235,6 +235,29 @@ class PQFlatGpuIndex(BaseIndex):
             return d.cpu().numpy(), i.cpu().numpy()
         return d, i
 
+    def search_batch_packed(self, x, limit: int, row_base: int = 0) -> Optional[torch.Tensor]:
+        """Plain ADC top-k of a device batch as ONE i64 tensor [B, k, 2] = (row_base + id or -1, bits of the RAW
+        ADC sum -- no sqrt): the per-rank contribution to the single all-gather of the row-sharded search.
+        ``None`` when this index state needs the general path (re-rank, k > 64)."""
+        k = int(limit)
+        if (self.rerank and self._vectors is not None) or k > 64:
+            return None
+        q = self._pre(x)
+        B, N = q.shape[0], self._n_rows
+        if N == 0 or B == 0:
+            out = torch.empty((B, k, 2), dtype=torch.int64, device=q.device)
+            out[..., 0] = -1
+            out[..., 1] = 0x7F800000  # +inf
+            return out
+        plan = scan_plan(N, self.M, self.Ks, self.code_bytes, B, k)
+        lut = self.pq_codec.get_dist_mat_tiled(q, plan.qi) if plan.fast else self.pq_codec.get_dist_mat(q)
+        return ops.adc_scan_topk_packed(self._codes, lut, B, k, self.M, self.Ks, valid_bits=self._valid, row_base=row_base,
+                                        n_rows=N, codes_layout=self._layout(), workspace=self._ws)
+
+    def finish_distances(self, d: torch.Tensor) -> torch.Tensor:
+        """Metric epilogue of ``search`` on raw ADC sums (hnsw/index.py:164-165)."""
+        return torch.sqrt(d) if self.metric == Metric.EUCLIDEAN else d
+
     def _plain_codes(self, N: int) -> torch.Tensor:
         if self._layout() == CODES_SKEWED:
             return ops.codes_skew(self._codes[:N], inverse=True)

@@ -1591,9 +1591,11 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_generic_kernel(const ScanArg
 // =================================================================================================
 // Final merge: partial keys [B][NS][k] -> (dist f32, id i64) [B][k]; one wave per query.
 // =================================================================================================
+// With `out_packed` the result is written as [B][k][2] int64 (global id, distance bits) instead: ONE buffer,
+// ONE all-gather per batch in the row-sharded search.
 __global__ __launch_bounds__(256) void merge_partial_kernel(const unsigned long long *partial, int B, int NS,
                                                            int k, int64_t row_base, float *out_d,
-                                                           int64_t *out_i) {
+                                                           int64_t *out_i, int64_t *out_packed) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -1613,8 +1615,15 @@ __global__ __launch_bounds__(256) void merge_partial_kernel(const unsigned long 
     }
     if (lane <= km1) {
         const bool none = (L.hi == kKeyInfHi && L.lo == kIdNone);
-        out_d[(int64_t)b * k + lane] = none ? __builtin_inff() : ordered_to_f32(L.hi);
-        out_i[(int64_t)b * k + lane] = none ? (int64_t)-1 : row_base + (int64_t)L.lo;
+        const float d = none ? __builtin_inff() : ordered_to_f32(L.hi);
+        const int64_t id = none ? (int64_t)-1 : row_base + (int64_t)L.lo;
+        if (out_packed) {
+            out_packed[((int64_t)b * k + lane) * 2 + 0] = id;
+            out_packed[((int64_t)b * k + lane) * 2 + 1] = (int64_t)__float_as_uint(d);
+        } else {
+            out_d[(int64_t)b * k + lane] = d;
+            out_i[(int64_t)b * k + lane] = id;
+        }
     }
 }
 
@@ -1631,8 +1640,9 @@ __global__ __launch_bounds__(256) void export_partial_kernel(const unsigned long
 }
 
 // Merge G lists [G][B][k] of (dist, id) -> [B][k]  (after the RCCL all-gather).  One wave per query.
-__global__ __launch_bounds__(256) void merge_lists_kernel(const float *dist, const int64_t *id, int G, int B,
-                                                         int k, float *out_d, int64_t *out_i) {
+// `packed` != NULL: the lists come as [G][B][k][2] int64 (id, distance bits) -- merge_partial_kernel's packed form.
+__global__ __launch_bounds__(256) void merge_lists_kernel(const float *dist, const int64_t *id, const int64_t *packed,
+                                                         int G, int B, int k, float *out_d, int64_t *out_i) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -1644,8 +1654,9 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float *dist, con
     int64_t li = INT64_MAX;
     for (int c = 0; c < total; ++c) {
         const int g = c / k, j = c - g * k;
-        const float cd = dist[((int64_t)g * B + b) * k + j];
-        const int64_t ci = id[((int64_t)g * B + b) * k + j];
+        const int64_t e = ((int64_t)g * B + b) * k + j;
+        const float cd = packed ? __uint_as_float((uint32_t)packed[e * 2 + 1]) : dist[e];
+        const int64_t ci = packed ? packed[e * 2] : id[e];
         if (ci < 0) continue;  // padding entry of a short shard
         const bool less = (ld < cd) || (ld == cd && li < ci);
         const int pos = __popcll(__ballot(less));
@@ -2156,20 +2167,37 @@ extern "C" int annlite_profile_last_scan_ms(float *ms) {
     return ANNLITE_OK;
 }
 
-extern "C" int annlite_adc_scan_topk(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M,
-                                     int64_t Ks, const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B,
-                                     int64_t k, int64_t row_base, float *out_dist_dev, int64_t *out_id_dev,
-                                     void *workspace_dev, size_t workspace_bytes, void *stream) {
+static int scan_topk_impl(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M, int64_t Ks,
+                          const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B, int64_t k, int64_t row_base,
+                          float *out_dist_dev, int64_t *out_id_dev, int64_t *out_packed_dev, void *workspace_dev,
+                          size_t workspace_bytes, void *stream) {
     annlite_scan_plan plan;
     hipStream_t st = (hipStream_t)stream;
     int rc = scan_partial(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut_dev, B, k, workspace_dev,
                           workspace_bytes, st, &plan, true);
     if (rc != ANNLITE_OK || B == 0) return rc;
-    ANNLITE_REQUIRE(out_dist_dev && out_id_dev, "null output pointer");
+    ANNLITE_REQUIRE(out_packed_dev || (out_dist_dev && out_id_dev), "null output pointer");
     hipLaunchKernelGGL(merge_partial_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st,
                        (const unsigned long long *)workspace_dev, (int)B, plan.n_slices, (int)k, row_base,
-                       out_dist_dev, out_id_dev);
+                       out_dist_dev, out_id_dev, out_packed_dev);
     return launch_status("merge_partial_kernel");
+}
+
+extern "C" int annlite_adc_scan_topk(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M,
+                                     int64_t Ks, const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B,
+                                     int64_t k, int64_t row_base, float *out_dist_dev, int64_t *out_id_dev,
+                                     void *workspace_dev, size_t workspace_bytes, void *stream) {
+    return scan_topk_impl(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut_dev, B, k, row_base,
+                          out_dist_dev, out_id_dev, nullptr, workspace_dev, workspace_bytes, stream);
+}
+
+extern "C" int annlite_adc_scan_topk_packed(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M,
+                                            int64_t Ks, const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B,
+                                            int64_t k, int64_t row_base, int64_t *out_packed_dev, void *workspace_dev,
+                                            size_t workspace_bytes, void *stream) {
+    ANNLITE_REQUIRE(B == 0 || out_packed_dev, "null output pointer");
+    return scan_topk_impl(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut_dev, B, k, row_base, nullptr,
+                          nullptr, out_packed_dev, workspace_dev, workspace_bytes, stream);
 }
 
 extern "C" int annlite_adc_scan_candidates(const void *codes_dev, int code_bytes, int codes_layout, int64_t N,
@@ -2207,7 +2235,19 @@ extern "C" int annlite_topk_merge(const float *dist_dev, const int64_t *id_dev, 
     if (B == 0) return ANNLITE_OK;
     ANNLITE_REQUIRE(dist_dev && id_dev && out_dist_dev && out_id_dev, "null device pointer");
     hipLaunchKernelGGL(merge_lists_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dist_dev,
-                       id_dev, (int)G, (int)B, (int)k, out_dist_dev, out_id_dev);
+                       id_dev, (const int64_t *)nullptr, (int)G, (int)B, (int)k, out_dist_dev, out_id_dev);
+    return launch_status("merge_lists_kernel");
+}
+
+extern "C" int annlite_topk_merge_packed(const int64_t *packed_dev, int64_t G, int64_t B, int64_t k, float *out_dist_dev,
+                                         int64_t *out_id_dev, void *stream) {
+    ANNLITE_REQUIRE(G >= 1 && B >= 0 && k >= 1 && k <= 64, "bad G=%lld B=%lld k=%lld (k<=64)", (long long)G,
+                    (long long)B, (long long)k);
+    if (B == 0) return ANNLITE_OK;
+    ANNLITE_REQUIRE(packed_dev && out_dist_dev && out_id_dev, "null device pointer");
+    hipLaunchKernelGGL(merge_lists_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)nullptr, (const int64_t *)nullptr, packed_dev, (int)G, (int)B, (int)k, out_dist_dev,
+                       out_id_dev);
     return launch_status("merge_lists_kernel");
 }
 

@@ -134,6 +134,33 @@ def adc_scan_topk(codes: torch.Tensor, lut: torch.Tensor, B: int, k: int, M: int
     return od, oi
 
 
+def adc_scan_topk_packed(codes: torch.Tensor, lut: torch.Tensor, B: int, k: int, M: int, Ks: int,
+                         valid_bits: Optional[torch.Tensor] = None, row_base: int = 0, n_rows: Optional[int] = None,
+                         codes_layout: int = CODES_PLAIN, workspace: Optional[ScanWorkspace] = None) -> torch.Tensor:
+    """``adc_scan_topk`` with the result in ONE i64 tensor [B, k, 2] = (global id, f32 distance bits): the
+    buffer a rank contributes to the single all-gather of the row-sharded search."""
+    N = codes.shape[0] if n_rows is None else n_rows
+    cb = code_bytes_of(codes)
+    plan = scan_plan(N, M, Ks, cb, B, k)
+    dev = codes.device
+    ws = (workspace or ScanWorkspace()).get(int(plan.workspace_bytes), dev)
+    out = torch.empty((B, k, 2), dtype=torch.int64, device=dev)
+    check(lib().annlite_adc_scan_topk_packed(codes.data_ptr(), cb, codes_layout, N, M, Ks, _ptr(valid_bits),
+                                             lut.data_ptr(), B, k, row_base, out.data_ptr(), ws.data_ptr(),
+                                             ws.numel(), stream_ptr()), 'adc_scan_topk_packed')
+    return out
+
+
+def topk_merge_packed(packed: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[G,B,k,2] i64 (id, distance bits) -> ([B,k] f32, [B,k] i64), same order rule as ``topk_merge``."""
+    G, B, k, _ = packed.shape
+    od = torch.empty((B, k), dtype=torch.float32, device=packed.device)
+    oi = torch.empty((B, k), dtype=torch.int64, device=packed.device)
+    check(lib().annlite_topk_merge_packed(packed.contiguous().data_ptr(), G, B, k, od.data_ptr(), oi.data_ptr(),
+                                          stream_ptr()), 'topk_merge_packed')
+    return od, oi
+
+
 def adc_scan_candidates(codes: torch.Tensor, lut: torch.Tensor, B: int, k: int, M: int, Ks: int,
                         valid_bits: Optional[torch.Tensor] = None, row_base: int = 0, n_rows: Optional[int] = None,
                         codes_layout: int = CODES_PLAIN, workspace: Optional[ScanWorkspace] = None

@@ -79,7 +79,22 @@ class ShardedPQIndex:
         return d, i
 
     def search_batch(self, queries: torch.Tensor, limit: int = 10):
-        return ShardedSearcher(self._scan, self._merge, self.group).search(queries, limit)
+        from . import ops
+
+        gather = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(self.group) > 1 or bool(os.environ.get('ANNLITE_FORCE_GATHER')))
+        packed = self.index.search_batch_packed(queries, limit, self.row_base) if gather and isinstance(
+            queries, torch.Tensor) else None
+        if packed is None:
+            return ShardedSearcher(self._scan, self._merge, self.group).search(queries, limit)
+        # ONE collective per batch: (global id, raw ADC sum) pairs, 16 B each; merged on the raw sums (the
+        # single-GPU order), the metric epilogue (sqrt for EUCLIDEAN) comes last
+        G = dist.get_world_size(self.group)
+        B, k, _ = packed.shape
+        gathered = torch.empty((G * B, k, 2), dtype=torch.int64, device=packed.device)
+        dist.all_gather_into_tensor(gathered, packed, group=self.group)
+        d, i = ops.topk_merge_packed(gathered.view(G, B, k, 2))
+        return self.index.finish_distances(d), i
 
 
 def numpy_merge(all_d: torch.Tensor, all_i: torch.Tensor):

@@ -150,6 +150,14 @@ ANNLITE_API int annlite_adc_scan_topk(const void *codes_dev, int code_bytes, int
                           int64_t row_base, float *out_dist_dev, int64_t *out_id_dev,
                           void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* Same scan and result, written as ONE buffer out_packed_dev i64 [B][k][2] = (row_base + row or -1, the f32
+ * distance's bits zero-extended): what a rank contributes to the single all-gather of the row-sharded
+ * search; annlite_topk_merge_packed consumes the gathered [G][B][k][2]. */
+ANNLITE_API int annlite_adc_scan_topk_packed(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M,
+                                 int64_t Ks, const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B,
+                                 int64_t k, int64_t row_base, int64_t *out_packed_dev, void *workspace_dev,
+                                 size_t workspace_bytes, void *stream);
+
 /* Same scan, but return the UNMERGED per-slice lists: plan.n_slices * k candidates per query
  * ([B][n_slices*k], unordered across slices, (+inf,-1) where a slice had fewer rows).  The set is a
  * superset of the exact top-k; it is the candidate generator of the exact re-rank stage
@@ -182,6 +190,10 @@ ANNLITE_API int annlite_codes_skew(const void *in_dev, int64_t N, int64_t M, con
  * reference's analogue is the hstack+argsort merge of per-cell results (annlite/container.py:130-138). */
 ANNLITE_API int annlite_topk_merge(const float *dist_dev, const int64_t *id_dev, int64_t G, int64_t B, int64_t k,
                        float *out_dist_dev, int64_t *out_id_dev, void *stream);
+
+/* The same merge over the packed form of annlite_adc_scan_topk_packed: in i64 [G][B][k][2]. */
+ANNLITE_API int annlite_topk_merge_packed(const int64_t *packed_dev, int64_t G, int64_t B, int64_t k,
+                              float *out_dist_dev, int64_t *out_id_dev, void *stream);
 
 /* Row-wise k smallest of a dense f32 matrix [B][N] -> ([B][k], [B][k]) with the fixed tie-break.
  * replaces: annlite.math.top_k(values, k, descending=False) (annlite/math.py:94-120). k <= 64. */

@@ -281,6 +281,36 @@ def test_topk_merge_and_rows(ops, oracle):
     assert np.array_equal(mi.cpu().numpy() - (1 << 33), i.cpu().numpy())
 
 
+def test_packed_scan_and_packed_merge_equal_the_two_tensor_path(ops):
+    """The one-buffer form used by the row-sharded search: same bits as (dist, id), and shard-wise packed
+    scans merged == one scan over the whole table (ties across shards resolved by global id)."""
+    import torch
+
+    from annlite_amd._capi import LAYOUT_TILED, LUT_L2, scan_plan
+
+    torch.manual_seed(5)
+    N, M, Ks, B, k, G = 6000, 16, 256, 37, 10, 3
+    codes = torch.randint(0, 256, (N, M), dtype=torch.uint8, device='cuda')
+    codes[N // 2:N // 2 + 40] = codes[:40]  # duplicates in different shards -> distance ties across shards
+    cb = torch.randn((M, Ks, 8), device='cuda')
+    q = torch.randn((B, M * 8), device='cuda')
+
+    def lut_for(n):
+        plan = scan_plan(n, M, Ks, 1, B, k)
+        return ops.lut_build(q, cb, LUT_L2, LAYOUT_TILED, plan.qi) if plan.fast else ops.lut_build(q, cb, LUT_L2)
+
+    d, i = ops.adc_scan_topk(codes, lut_for(N), B, k, M, Ks)
+    p = ops.adc_scan_topk_packed(codes, lut_for(N), B, k, M, Ks, row_base=7)
+    assert np.array_equal(p[..., 0].cpu().numpy(), i.cpu().numpy() + 7)
+    assert np.array_equal(p[..., 1].cpu().numpy().astype(np.uint32).view(np.float32), d.cpu().numpy())
+    per = N // G
+    parts = [ops.adc_scan_topk_packed(codes[g * per:(g + 1) * per].contiguous(), lut_for(per), B, k, M, Ks,
+                                      row_base=g * per) for g in range(G)]
+    md, mi = ops.topk_merge_packed(torch.stack(parts))
+    assert np.array_equal(md.cpu().numpy(), d.cpu().numpy())
+    assert np.array_equal(mi.cpu().numpy(), i.cpu().numpy())
+
+
 # ------------------------------------------------------------------------------------ index plugin
 @pytest.mark.parametrize('name', ['c1_m8_d128', 'c2_m16_d128', 'c4_m64_d768'])
 @pytest.mark.parametrize('mname,metric', [('euclidean', 1), ('inner_product', 2), ('cosine', 3)])
