@@ -1229,14 +1229,19 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
 }
 
 
-// Seed bound: exact top-k of every query over the first S rows.  Its k-th key is a valid upper bound
-// of the final k-th key, so the scan starts with a filter that passes ~k/S of the rows instead of all
-// of them (the cold-start "flood" cost 16 waves x 16 queries x 64 uncoalesced gathers per work item).
+// Seed bound: a valid upper bound of the final k-th key from the first S rows, so the scan starts with a
+// filter that passes ~k/S of the rows instead of all of them (the cold-start "flood" cost 16 waves x 16
+// queries x 64 uncoalesced gathers per work item).
 // One 16-wave workgroup per group of 4 queries: their fp32 TILED rows [Ks][M][4] (64 KB at M=16) are
-// staged in LDS, so ONE ds_read_b128 per (row, m) feeds the four ascending-m sums (gathering the same
-// entries from L2 cost a 64-byte request per 4 useful bytes: 150 us for 4096 rows x 1024 queries).
-// The 16 wave lists of a query are merged through LDS.  The seed rows are scanned again by the main
-// kernel: only the bound leaves this kernel.
+// staged in LDS, so ONE ds_read_b128 per (row, m) feeds the four exact ascending-m sums (gathering the
+// same entries from L2 cost a 64-byte request per 4 useful bytes: 150 us for 4096 rows x 1024 queries).
+// Selection without sorting networks: every lane keeps the MIN distance of the rows it saw; the 1024
+// (wave, lane) groups are disjoint, so the k-th smallest of their minima has >= k distinct rows at or
+// below it -- a valid bound, and equal to the exact k-th distance of the S rows unless two of the k best
+// rows fell into one lane (3 % at S=4096, k=10; then it is the (k+1)-th).  The k-th smallest is found by
+// rank counting over LDS broadcasts (each lane counts the keys below its own): 64 keys per wave, then
+// 16*k candidates per query.  (Sorted wave lists + a 4-level merge tree: 52 of 62 us in bitonic networks.)
+// The seed rows are scanned again by the main kernel: only the bound leaves this kernel.
 constexpr int kSeedWaves = 16;
 template <int M, bool SKEWED>
 __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8_t *__restrict__ codes, int64_t S,
@@ -1248,12 +1253,11 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
     // [Ks][M + 1] x 4 queries: the pad entry spreads a fixed m over the banks (slot (code*(M+1) + m) % 16 =
     // (code + m) % 16); unpadded, all 64 lanes of a look-up hit ONE 16-byte slot-bank (16-way conflict)
     f32x4 *tab = (f32x4 *)smem;
-    unsigned long long *lists = (unsigned long long *)(smem + (size_t)Ks * (M + 1) * 16);  // [kSeedWaves][64]
+    unsigned long long *cand = (unsigned long long *)(smem + (size_t)Ks * (M + 1) * 16);  // [kSeedWaves][k]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g4 = blockIdx.x;
-    const int km1 = k - 1;
     {
         const f32x4 *src = (const f32x4 *)lut + (int64_t)g4 * Ks * M;
         for (int i = tid; i < Ks * M; i += kSeedWaves * 64) tab[i + i / M] = src[i];
@@ -1266,14 +1270,7 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
 #pragma unroll
     for (int i = 0; i < 8; ++i) abit_inv[i] = (((sinv >> 2) >> i) & 1) != 0;
 
-    WaveList L[4];
-    uint32_t thi[4], tlo[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        L[q].reset();
-        thi[q] = kKeyInfHi;
-        tlo[q] = kIdNone;
-    }
+    uint32_t best[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // ordered distance keys
     for (int64_t r0 = (int64_t)wave * 64; r0 < S; r0 += kSeedWaves * 64) {
         const int64_t r = r0 + lane;
         bool ok = r < S;
@@ -1296,38 +1293,44 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
         for (int m = 0; m < M; ++m) d += v[m];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint32_t khi = f32_to_ordered(d[q]);
-            const unsigned long long pm = __ballot(ok && key_less(khi, (uint32_t)r, thi[q], tlo[q]));
-            if (pm) {
-                wavelist_insert_many(L[q], pm, khi, (uint32_t)r, lane);
-                thi[q] = __builtin_amdgcn_readlane(L[q].hi, km1);
-                tlo[q] = __builtin_amdgcn_readlane(L[q].lo, km1);
-            }
+            const uint32_t key = f32_to_ordered(d[q]);
+            if (ok && key < best[q]) best[q] = key;
         }
     }
+    // Selection keys: the low 10 bits of the ordered distance are replaced by (wave, lane), which makes the
+    // 1024 keys of a query unique (rank = number of smaller keys, no tie handling) and costs at most 1023
+    // ulps of tightness: the k smallest keys T_i bound k distinct rows by (T_i | 1023).
+    const int nc = kSeedWaves * k;  // candidates per query
+    uint32_t *cand32 = (uint32_t *)cand;                                  // [kSeedWaves][k]
+    uint32_t *wkeys = (uint32_t *)cand + kSeedWaves * 64 + wave * 64;     // this wave's 64 lane minima
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
-        WaveList X = L[0];
-        if (q == 1) X = L[1];
-        if (q == 2) X = L[2];
-        if (q == 3) X = L[3];
-        lists[wave * 64 + lane] = ((unsigned long long)X.hi << 32) | X.lo;
-        __syncthreads();
-#pragma unroll 1
-        for (int stride = kSeedWaves / 2; stride >= 1; stride >>= 1) {
-            if (wave < stride) {
-                const unsigned long long o = lists[(wave + stride) * 64 + lane];
-                wavelist_merge_sorted(X, (uint32_t)(o >> 32), (uint32_t)o, lane);
-                lists[wave * 64 + lane] = ((unsigned long long)X.hi << 32) | X.lo;
-            }
-            __syncthreads();
+        uint32_t mine = best[0];
+        if (q == 1) mine = best[1];
+        if (q == 2) mine = best[2];
+        if (q == 3) mine = best[3];
+        mine = (mine & ~1023u) | (uint32_t)(wave << 6) | (uint32_t)lane;
+        // rank among the wave's 64: all lanes read the 64 keys back with wave-uniform addresses (broadcast)
+        wkeys[lane] = mine;
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < 64; j += 4) {
+            const u32x4 o = *(const u32x4 *)(wkeys + j);
+            rank += (o.x < mine) + (o.y < mine) + (o.z < mine) + (o.w < mine);
         }
-        const int b = g4 * 4 + q;
-        if (wave == 0 && b < B) {
-            const uint32_t hi = __builtin_amdgcn_readlane(X.hi, km1), lo = __builtin_amdgcn_readlane(X.lo, km1);
-            // +1: the seed rows are in nobody's list, so the scan must still ACCEPT the row that sets the bound
-            // (bounds published by workgroups come from rows their own list already holds and stay strict)
-            if (lane == 0 && hi != kKeyInfHi) gkey[b] = (((unsigned long long)hi << 32) | lo) + 1ull;
+        if (rank < k) cand32[wave * k + rank] = mine;
+        __syncthreads();
+        // the k-th smallest of the 16*k candidates, same way: thread t ranks candidate t
+        for (int t = tid; t < nc; t += kSeedWaves * 64) {
+            const uint32_t me = cand32[t];
+            int rk = 0;
+#pragma unroll 8
+            for (int j = 0; j < nc; ++j) rk += cand32[j] < me;
+            const int b = g4 * 4 + q;
+            // the bound admits every row at or below (me | 1023), whatever its id; +1 in the distance field
+            // because the seed rows are in nobody's list: the scan must still ACCEPT the rows that set it
+            if (rk == k - 1 && b < B && (me | 1023u) != 0xffffffffu)
+                gkey[b] = ((unsigned long long)(me | 1023u) + 1ull) << 32;
         }
         __syncthreads();
     }
@@ -2040,14 +2043,14 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 if (const char *e = getenv("ANNLITE_FLUSH_MASK")) a.flush_mask = atoi(e);
             }
             if (share_across_slices && N >= 4096) {
-                int64_t S = 4096;
+                int64_t S = 8192;
                 if (const char *e = getenv("ANNLITE_SEED_ROWS")) S = atoll(e);
                 if (S > N) S = N;
                 const bool skw = codes_layout == ANNLITE_CODES_SKEWED;
 #define ANNLITE_SEED(MM)                                                                                          \
     {                                                                                                             \
         auto fn = skw ? seed_bound_kernel<MM, true> : seed_bound_kernel<MM, false>;                               \
-        const size_t lds = (size_t)Ks * (MM + 1) * 16 + (size_t)kSeedWaves * 64 * 8;                                  \
+        const size_t lds = (size_t)Ks * (MM + 1) * 16 + (size_t)2 * kSeedWaves * 64 * 8; /* cand + lane minima */                                  \
         ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(fn, dim3((unsigned)((B + 3) / 4)), dim3(kSeedWaves * 64), lds, st,                      \
                            (const uint8_t *)codes_dev, S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, gk);   \
