@@ -1423,8 +1423,12 @@ template <int M>
 __global__ __launch_bounds__(256) void lut_quantise_fused_kernel(const float *__restrict__ lut, int Ks, int qmax,
                                                                 uint16_t *__restrict__ out,
                                                                 float *__restrict__ qstep, double *__restrict__ qlo,
-                                                                float *__restrict__ smax) {
+                                                                float *__restrict__ smax, u32x4 *__restrict__ fill,
+                                                                int64_t fill_vec16) {
     constexpr int KPT = 256 / M;  // codes covered per sweep of the block
+    // this launch also resets the scan's result lists and shared bounds to "none" (all-ones): one launch less
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < fill_vec16; i += (int64_t)gridDim.x * 256)
+        fill[i] = (u32x4){~0u, ~0u, ~0u, ~0u};
     __shared__ float s_lo[KPT][M][8], s_hi[KPT][M][8];
     __shared__ float s_step[8];
     const int tid = threadIdx.x;
@@ -2001,6 +2005,8 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         a.slice_rows = sr;
     }
     // slots of slices that hold no rows stay "none"
+    size_t fill_bytes = 0;
+    bool fused_fill = false;
     {
         // partial lists, and (quantised-filter plan) the shared bounds right behind them; the rest is scratch
         size_t fill = (size_t)plan.workspace_bytes;
@@ -2011,7 +2017,10 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             fill = r256((size_t)a.n_tiles * plan.qt * plan.n_slices * k * 8) + r256(bpad * 8) +
                    r256(bpad * plan.n_slices * 8);
         }
-        ANNLITE_HIP_TRY(hipMemsetAsync(workspace_dev, 0xff, fill, st));
+        fill_bytes = fill;
+        FastCfg c1;
+        fused_fill = N > 0 && plan.fast && fast_cfg(M, Ks, code_bytes, k, &c1) && c1.mode == 4;  // lut_quantise_fused_kernel
+        if (!fused_fill) ANNLITE_HIP_TRY(hipMemsetAsync(workspace_dev, 0xff, fill, st));
     }
     if (N == 0) return ANNLITE_OK;
     const int n_items = (plan.fast && a.n_slices < 8) ? ((a.n_tiles + 8 / a.n_slices - 1) / (8 / a.n_slices)) * 8
@@ -2042,6 +2051,21 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 a.flush_mask = 63;
                 if (const char *e = getenv("ANNLITE_FLUSH_MASK")) a.flush_mask = atoi(e);
             }
+            // (the q16 table sits behind the small arrays; carve order is irrelevant to the kernels)
+            uint16_t *q16 = (uint16_t *)carve(bpad * M * Ks * 2);
+            const int qmax = (int)(32767 / M);
+            const unsigned n_g8 = (unsigned)(bpad / 8);
+            if (M == 8)
+                hipLaunchKernelGGL(lut_quantise_fused_kernel<8>, dim3(n_g8), dim3(256), 0, st, lut_dev, (int)Ks, qmax, q16,
+                                   qstep, qlo, smax, (u32x4 *)workspace_dev, (int64_t)(fill_bytes / 16));
+            else if (M == 16)
+                hipLaunchKernelGGL(lut_quantise_fused_kernel<16>, dim3(n_g8), dim3(256), 0, st, lut_dev, (int)Ks, qmax, q16,
+                                   qstep, qlo, smax, (u32x4 *)workspace_dev, (int64_t)(fill_bytes / 16));
+            else
+                hipLaunchKernelGGL(lut_quantise_fused_kernel<32>, dim3(n_g8), dim3(256), 0, st, lut_dev, (int)Ks, qmax, q16,
+                                   qstep, qlo, smax, (u32x4 *)workspace_dev, (int64_t)(fill_bytes / 16));
+            rc = launch_status("lut_quantise_fused_kernel");
+            if (rc != ANNLITE_OK) return rc;
             if (share_across_slices && N >= 4096) {
                 int64_t S = 8192;
                 if (const char *e = getenv("ANNLITE_SEED_ROWS")) S = atoll(e);
@@ -2060,20 +2084,6 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 rc = launch_status("seed_bound_kernel");
                 if (rc != ANNLITE_OK) return rc;
             }
-            uint16_t *q16 = (uint16_t *)carve(bpad * M * Ks * 2);
-            const int qmax = (int)(32767 / M);
-            const unsigned n_g8 = (unsigned)(bpad / 8);
-            if (M == 8)
-                hipLaunchKernelGGL(lut_quantise_fused_kernel<8>, dim3(n_g8), dim3(256), 0, st, lut_dev, (int)Ks, qmax, q16,
-                                   qstep, qlo, smax);
-            else if (M == 16)
-                hipLaunchKernelGGL(lut_quantise_fused_kernel<16>, dim3(n_g8), dim3(256), 0, st, lut_dev, (int)Ks, qmax, q16,
-                                   qstep, qlo, smax);
-            else
-                hipLaunchKernelGGL(lut_quantise_fused_kernel<32>, dim3(n_g8), dim3(256), 0, st, lut_dev, (int)Ks, qmax, q16,
-                                   qstep, qlo, smax);
-            rc = launch_status("lut_quantise_fused_kernel");
-            if (rc != ANNLITE_OK) return rc;
             a.smax = smax;
             a.qstep = qstep;
             a.qlo = qlo;

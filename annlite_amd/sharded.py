@@ -79,22 +79,42 @@ class ShardedPQIndex:
         return d, i
 
     def search_batch(self, queries: torch.Tensor, limit: int = 10):
-        from . import ops
+        return self.search_batch_async(queries, limit).result()
 
+    def search_batch_async(self, queries: torch.Tensor, limit: int = 10) -> 'PendingSearch':
+        """Enqueue the local scan and start the exchange; ``.result()`` waits for it and merges.  Calling
+        ``result()`` of batch i after ``search_batch_async`` of batch i+1 lets the all-gather of batch i run on
+        RCCL's stream while the compute stream already scans batch i+1 (batches are independent)."""
         gather = dist.is_available() and dist.is_initialized() and (
             dist.get_world_size(self.group) > 1 or bool(os.environ.get('ANNLITE_FORCE_GATHER')))
         packed = self.index.search_batch_packed(queries, limit, self.row_base) if gather and isinstance(
             queries, torch.Tensor) else None
         if packed is None:
-            return ShardedSearcher(self._scan, self._merge, self.group).search(queries, limit)
+            return PendingSearch(self, value=ShardedSearcher(self._scan, self._merge, self.group).search(queries, limit))
         # ONE collective per batch: (global id, raw ADC sum) pairs, 16 B each; merged on the raw sums (the
         # single-GPU order), the metric epilogue (sqrt for EUCLIDEAN) comes last
         G = dist.get_world_size(self.group)
         B, k, _ = packed.shape
         gathered = torch.empty((G * B, k, 2), dtype=torch.int64, device=packed.device)
-        dist.all_gather_into_tensor(gathered, packed, group=self.group)
-        d, i = ops.topk_merge_packed(gathered.view(G, B, k, 2))
-        return self.index.finish_distances(d), i
+        work = dist.all_gather_into_tensor(gathered, packed, group=self.group, async_op=True)
+        return PendingSearch(self, work=work, gathered=gathered.view(G, B, k, 2), packed=packed)
+
+
+class PendingSearch:
+    """Handle of one in-flight row-sharded batch (see ``ShardedPQIndex.search_batch_async``)."""
+
+    def __init__(self, owner, value=None, work=None, gathered=None, packed=None):
+        self._owner, self._value, self._work, self._gathered, self._packed = owner, value, work, gathered, packed
+
+    def result(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._value is None:
+            from . import ops
+
+            self._work.wait()  # the current stream waits for the collective; the host does not block
+            d, i = ops.topk_merge_packed(self._gathered)
+            self._value = (self._owner.index.finish_distances(d), i)
+            self._work = self._gathered = self._packed = None
+        return self._value
 
 
 def numpy_merge(all_d: torch.Tensor, all_i: torch.Tensor):
