@@ -265,7 +265,9 @@ class PQCodec(BaseCodec):
     def get_subspace_splitting(self):  # pq.py:239-244
         return (self.n_subvectors, self.n_clusters, self.d_subvector)
 
-    def _dist_mat_dev(self, x: torch.Tensor, layout: int, qi: int = 4) -> torch.Tensor:
+    def scan_inputs(self, x: torch.Tensor):
+        """(LUT kind, queries as the table build sees them) for ``get_dist_mat`` on device input: the metric
+        dispatch of pq.py:309-322 without building the tables (``ops.pq_search_topk`` builds them itself)."""
         if self.normalize_input:
             x = ops.l2_normalize(x)  # pq.py:309-310 (yes: again, even if the caller normalised)
         if self.metric == Metric.EUCLIDEAN:
@@ -274,6 +276,10 @@ class PQCodec(BaseCodec):
             kind = LUT_IPDIST  # float32(1/n_clusters) - <q_sub, codeword>, pq.py:316-322
         else:
             raise ValueError(f'Unable support metrics {self.metric}')
+        return kind, x
+
+    def _dist_mat_dev(self, x: torch.Tensor, layout: int, qi: int = 4) -> torch.Tensor:
+        kind, x = self.scan_inputs(x)
         return ops.lut_build(x, self.codebooks_dev, kind, layout, qi)
 
     def get_dist_mat(self, x):

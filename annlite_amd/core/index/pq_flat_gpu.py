@@ -220,13 +220,10 @@ class PQFlatGpuIndex(BaseIndex):
         elif self.rerank and self._vectors is not None:
             d, i = self._search_rerank(q, k, valid, N, rerank_k)
         elif k <= 64:
-            plan = scan_plan(N, self.M, self.Ks, self.code_bytes, B, k)
-            if plan.fast:
-                lut = self.pq_codec.get_dist_mat_tiled(q, plan.qi)
-            else:
-                lut = self.pq_codec.get_dist_mat(q)
-            d, i = ops.adc_scan_topk(self._codes, lut, B, k, self.M, self.Ks, valid_bits=valid, n_rows=N,
-                                     codes_layout=self._layout(), workspace=self._ws)
+            # table build + scan + top-k: one C call (annlite_pq_search_topk)
+            kind, xq = self.pq_codec.scan_inputs(q)
+            d, i = ops.pq_search_topk(kind, xq, self.pq_codec.codebooks_dev, self._codes, k, self.M, self.Ks,
+                                      valid_bits=valid, n_rows=N, codes_layout=self._layout(), workspace=self._ws)
             if self.metric == Metric.EUCLIDEAN:
                 d = torch.sqrt(d)  # hnsw/index.py:164-165
         else:
@@ -249,10 +246,10 @@ class PQFlatGpuIndex(BaseIndex):
             out[..., 0] = -1
             out[..., 1] = 0x7F800000  # +inf
             return out
-        plan = scan_plan(N, self.M, self.Ks, self.code_bytes, B, k)
-        lut = self.pq_codec.get_dist_mat_tiled(q, plan.qi) if plan.fast else self.pq_codec.get_dist_mat(q)
-        return ops.adc_scan_topk_packed(self._codes, lut, B, k, self.M, self.Ks, valid_bits=self._valid, row_base=row_base,
-                                        n_rows=N, codes_layout=self._layout(), workspace=self._ws)
+        kind, xq = self.pq_codec.scan_inputs(q)
+        return ops.pq_search_topk(kind, xq, self.pq_codec.codebooks_dev, self._codes, k, self.M, self.Ks,
+                                  valid_bits=self._valid, row_base=row_base, n_rows=N, codes_layout=self._layout(),
+                                  workspace=self._ws, packed=True)
 
     def finish_distances(self, d: torch.Tensor) -> torch.Tensor:
         """Metric epilogue of ``search`` on raw ADC sums (hnsw/index.py:164-165)."""

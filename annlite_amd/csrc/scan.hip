@@ -1510,6 +1510,149 @@ __global__ __launch_bounds__(256) void lut_quantise_fused_kernel(const float *__
     }
 }
 
+// annlite_pq_search_topk on the quantised-filter plan: the L2 tables are BUILT, reduced and quantised by one
+// launch (query batch in, neighbours out).  One 1024-thread workgroup per group of 8 queries; thread
+// (kr, m) = (tid / M, tid % M) owns sub-space m of codes kr, kr + 1024/M, ...: NSW = M/4 entries x 8
+// queries stay in registers between the min/max pass and the quantisation, nothing is read back.
+// entry = the reference's j-ascending fmaf chain over (codeword - query) (pq_bindings.pyx:204-206): the same
+// bits as lut_l2_tiled_kernel.  Also resets the scan's result lists / shared bounds (fill).
+template <int M>
+__global__ __launch_bounds__(1024) void lut_l2_build_quantise_kernel(const float *__restrict__ queries, int B, int D,
+                                                                    const float *__restrict__ cb, int Ks,
+                                                                    float *__restrict__ lut, int qmax,
+                                                                    uint16_t *__restrict__ out,
+                                                                    float *__restrict__ qstep, double *__restrict__ qlo,
+                                                                    float *__restrict__ smax, u32x4 *__restrict__ fill,
+                                                                    int64_t fill_vec16) {
+    constexpr int KPT = 1024 / M;   // codes per sweep
+    constexpr int NSW = 256 / KPT;  // sweeps (Ks <= 256)
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < fill_vec16; i += (int64_t)gridDim.x * 1024)
+        fill[i] = (u32x4){~0u, ~0u, ~0u, ~0u};
+    __shared__ float s_lo[16][M][8], s_hi[16][M][8];
+    __shared__ float s_step[8];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+    float *s_q = (float *)dyn_smem;  // the 8 queries, [8][D]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = tid % M, kr = tid / M;
+    const int g8 = blockIdx.x;
+    const int dsub = D / M;
+    for (int i = tid; i < 8 * D; i += 1024) {
+        const int b = g8 * 8 + i / D;
+        s_q[i] = b < B ? queries[(int64_t)b * D + i % D] : 0.f;
+    }
+    __syncthreads();
+    f32x4 *base0 = (f32x4 *)lut + (int64_t)(g8 * 2) * Ks * M;
+    f32x4 *base1 = base0 + (int64_t)Ks * M;
+    f32x4 v0[NSW], v1[NSW];
+    float mn[8], mx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        mn[i] = __builtin_inff();
+        mx[i] = -__builtin_inff();
+    }
+#pragma unroll
+    for (int sw = 0; sw < NSW; ++sw) {
+        const int k = kr + sw * KPT;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (k < Ks) {
+            const float *cw = cb + ((int64_t)m * Ks + k) * dsub;
+            for (int j = 0; j < dsub; j += 4) {
+                const f32x4 cj = *(const f32x4 *)(cw + j);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x4 qj = *(const f32x4 *)(s_q + i * D + m * dsub + j);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float c = cj[e] - qj[e];
+                        acc[i] = __builtin_fmaf(c, c, acc[i]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (g8 * 8 + i >= B) acc[i] = 0.f;  // pad queries -> 0, like lut_l2_tiled_kernel
+            v0[sw] = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+            v1[sw] = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+            base0[(int64_t)k * M + m] = v0[sw];
+            base1[(int64_t)k * M + m] = v1[sw];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                mn[i] = fminf(mn[i], acc[i]);
+                mx[i] = fmaxf(mx[i], acc[i]);
+            }
+        }
+    }
+    // lanes l, l + M, l + 2M, ... of a wave share m
+#pragma unroll
+    for (int o = M; o < 64; o <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            mn[i] = fminf(mn[i], __shfl_xor(mn[i], o));
+            mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], o));
+        }
+    }
+    if (lane < M) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s_lo[wave][m][i] = mn[i];
+            s_hi[wave][m][i] = mx[i];
+        }
+    }
+    __syncthreads();
+    if (tid < M * 8) {
+        const int mm = tid / 8, i = tid % 8;
+        float l = s_lo[0][mm][i], h = s_hi[0][mm][i];
+        for (int r = 1; r < 16; ++r) {
+            l = fminf(l, s_lo[r][mm][i]);
+            h = fmaxf(h, s_hi[r][mm][i]);
+        }
+        s_lo[0][mm][i] = l;
+        s_hi[0][mm][i] = h;
+    }
+    __syncthreads();
+    if (tid < 8) {
+        float range = 0.f, sm = 0.f;
+        double Lsum = 0.0;
+        for (int mm = 0; mm < M; ++mm) {
+            const float l = s_lo[0][mm][tid], h = s_hi[0][mm][tid];
+            range = fmaxf(range, h - l);
+            sm += fmaxf(fabsf(l), fabsf(h));
+            Lsum += (double)l;
+        }
+        float step = range / (float)qmax;
+        if (!(step > 0.f)) step = 1.f;
+        s_step[tid] = step;
+        const int b = g8 * 8 + tid;
+        qstep[b] = step;
+        qlo[b] = Lsum;
+        smax[b] = sm;
+    }
+    __syncthreads();
+    float lo_r[8], st_r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        lo_r[i] = s_lo[0][m][i];
+        st_r[i] = s_step[i];
+    }
+    u32x4 *o = (u32x4 *)out + (int64_t)g8 * Ks * M;
+#pragma unroll
+    for (int sw = 0; sw < NSW; ++sw) {
+        const int k = kr + sw * KPT;
+        if (k >= Ks) continue;
+        uint32_t q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float v = i < 4 ? v0[sw][i] : v1[sw][i - 4];
+            float t = floorf((v - lo_r[i]) / st_r[i]);
+            if (!(t > 0.f)) t = 0.f;
+            if (t > (float)qmax) t = (float)qmax;
+            q[i] = (uint32_t)t;
+        }
+        o[(int64_t)k * M + m] = (u32x4){q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), q[6] | (q[7] << 16)};
+    }
+}
+
 // Smax[b] = sum_m max_k |lut[b][m][k]| from the TILED table [Bpad/QI][Ks][M][QI]; one wave per group
 __global__ __launch_bounds__(256) void lut_smax_kernel(const float *__restrict__ lut, int n_groups, int M, int Ks,
                                                       int QI, float *__restrict__ smax) {
@@ -1957,10 +2100,17 @@ static void prof_end(hipStream_t st) {
 }
 
 // run the scan kernels: fills workspace with the per-(query, slice) sorted key lists [B][NS][k]
+// annlite_pq_search_topk: the L2 tables are built by the quantisation launch itself (lut_dev is then written)
+struct LutBuild {
+    const float *queries;
+    const float *codebooks;
+    int64_t D;
+};
+
 static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M, int64_t Ks,
                         const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B, int64_t k,
                         void *workspace_dev, size_t workspace_bytes, hipStream_t st, annlite_scan_plan *plan_out,
-                        bool share_across_slices) {
+                        bool share_across_slices, const LutBuild *build = nullptr) {
     annlite_scan_plan plan;
     int rc = annlite_scan_plan_query(N, M, Ks, code_bytes, B, k, &plan);
     if (rc != ANNLITE_OK) return rc;
@@ -2055,15 +2205,21 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             uint16_t *q16 = (uint16_t *)carve(bpad * M * Ks * 2);
             const int qmax = (int)(32767 / M);
             const unsigned n_g8 = (unsigned)(bpad / 8);
-            if (M == 8)
-                hipLaunchKernelGGL(lut_quantise_fused_kernel<8>, dim3(n_g8), dim3(256), 0, st, lut_dev, (int)Ks, qmax, q16,
-                                   qstep, qlo, smax, (u32x4 *)workspace_dev, (int64_t)(fill_bytes / 16));
-            else if (M == 16)
-                hipLaunchKernelGGL(lut_quantise_fused_kernel<16>, dim3(n_g8), dim3(256), 0, st, lut_dev, (int)Ks, qmax, q16,
-                                   qstep, qlo, smax, (u32x4 *)workspace_dev, (int64_t)(fill_bytes / 16));
-            else
-                hipLaunchKernelGGL(lut_quantise_fused_kernel<32>, dim3(n_g8), dim3(256), 0, st, lut_dev, (int)Ks, qmax, q16,
-                                   qstep, qlo, smax, (u32x4 *)workspace_dev, (int64_t)(fill_bytes / 16));
+            {
+                float *lut_rw = const_cast<float *>(lut_dev);
+                u32x4 *fillp = (u32x4 *)workspace_dev;
+                const int64_t fillv = (int64_t)(fill_bytes / 16);
+#define ANNLITE_QUANT(MM)                                                                                            \
+    if (build)                                                                                                       \
+        hipLaunchKernelGGL((lut_l2_build_quantise_kernel<MM>), dim3(n_g8), dim3(1024), (size_t)(8 * build->D * 4), st,  \
+                           build->queries, (int)B, (int)build->D, build->codebooks, (int)Ks, lut_rw, qmax, q16, qstep,   \
+                           qlo, smax, fillp, fillv);                                                                 \
+    else                                                                                                             \
+        hipLaunchKernelGGL((lut_quantise_fused_kernel<MM>), dim3(n_g8), dim3(256), 0, st, lut_rw, (int)Ks, qmax, q16,  \
+                           qstep, qlo, smax, fillp, fillv)
+                if (M == 8) { ANNLITE_QUANT(8); } else if (M == 16) { ANNLITE_QUANT(16); } else { ANNLITE_QUANT(32); }
+#undef ANNLITE_QUANT
+            }
             rc = launch_status("lut_quantise_fused_kernel");
             if (rc != ANNLITE_OK) return rc;
             if (share_across_slices && N >= 4096) {
@@ -2183,11 +2339,11 @@ extern "C" int annlite_profile_last_scan_ms(float *ms) {
 static int scan_topk_impl(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M, int64_t Ks,
                           const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B, int64_t k, int64_t row_base,
                           float *out_dist_dev, int64_t *out_id_dev, int64_t *out_packed_dev, void *workspace_dev,
-                          size_t workspace_bytes, void *stream) {
+                          size_t workspace_bytes, void *stream, const LutBuild *build = nullptr) {
     annlite_scan_plan plan;
     hipStream_t st = (hipStream_t)stream;
     int rc = scan_partial(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut_dev, B, k, workspace_dev,
-                          workspace_bytes, st, &plan, true);
+                          workspace_bytes, st, &plan, true, build);
     if (rc != ANNLITE_OK || B == 0) return rc;
     ANNLITE_REQUIRE(out_packed_dev || (out_dist_dev && out_id_dev), "null output pointer");
     hipLaunchKernelGGL(merge_partial_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st,
@@ -2211,6 +2367,52 @@ extern "C" int annlite_adc_scan_topk_packed(const void *codes_dev, int code_byte
     ANNLITE_REQUIRE(B == 0 || out_packed_dev, "null output pointer");
     return scan_topk_impl(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut_dev, B, k, row_base, nullptr,
                           nullptr, out_packed_dev, workspace_dev, workspace_bytes, stream);
+}
+
+static size_t r256z(size_t x) { return (x + 255) / 256 * 256; }
+
+extern "C" int annlite_pq_search_workspace_bytes(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t k,
+                                                 int64_t *bytes) {
+    ANNLITE_REQUIRE(bytes != nullptr, "bytes is NULL");
+    annlite_scan_plan plan;
+    int rc = annlite_scan_plan_query(N, M, Ks, code_bytes, B, k, &plan);
+    if (rc != ANNLITE_OK) return rc;
+    *bytes = (int64_t)(r256z((size_t)plan.workspace_bytes) + r256z((size_t)plan.lut_floats * 4));
+    return ANNLITE_OK;
+}
+
+extern "C" int annlite_pq_search_topk(int lut_kind, const float *queries_dev, int64_t B, int64_t D,
+                                      const float *codebooks_dev, const void *codes_dev, int code_bytes, int codes_layout,
+                                      int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev, int64_t k,
+                                      int64_t row_base, float *out_dist_dev, int64_t *out_id_dev, int64_t *out_packed_dev,
+                                      void *workspace_dev, size_t workspace_bytes, void *stream) {
+    ANNLITE_REQUIRE(M >= 1 && D >= M && D % M == 0,
+                    "input dimension must be dividable by number of sub-space (D=%lld, M=%lld)", (long long)D, (long long)M);
+    annlite_scan_plan plan;
+    int rc = annlite_scan_plan_query(N, M, Ks, code_bytes, B, k, &plan);
+    if (rc != ANNLITE_OK) return rc;
+    if (B == 0) return ANNLITE_OK;
+    const size_t scan_ws = r256z((size_t)plan.workspace_bytes);
+    const size_t need = scan_ws + r256z((size_t)plan.lut_floats * 4);
+    if (workspace_bytes < need) {
+        set_error("workspace %zu B < required %zu B (annlite_pq_search_workspace_bytes)", workspace_bytes, need);
+        return ANNLITE_ERR_WORKSPACE;
+    }
+    ANNLITE_REQUIRE(queries_dev && codebooks_dev && workspace_dev, "null device pointer");
+    float *lut = (float *)((char *)workspace_dev + scan_ws);
+    FastCfg c;
+    const bool fuse = N > 0 && plan.fast && fast_cfg(M, Ks, code_bytes, k, &c) && c.mode == 4 &&
+                      lut_kind == ANNLITE_LUT_L2 && ((D / M) % 4) == 0 && !getenv("ANNLITE_NO_FUSED_LUT");
+    if (!fuse) {
+        rc = annlite_lut_build(lut_kind, queries_dev, B, D, codebooks_dev, M, Ks, lut,
+                               plan.fast ? ANNLITE_LAYOUT_TILED : ANNLITE_LAYOUT_BMK, plan.qi, stream);
+        if (rc != ANNLITE_OK) return rc;
+        return scan_topk_impl(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut, B, k, row_base,
+                              out_dist_dev, out_id_dev, out_packed_dev, workspace_dev, scan_ws, stream);
+    }
+    const LutBuild lb = {queries_dev, codebooks_dev, D};
+    return scan_topk_impl(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut, B, k, row_base, out_dist_dev,
+                          out_id_dev, out_packed_dev, workspace_dev, scan_ws, stream, &lb);
 }
 
 extern "C" int annlite_adc_scan_candidates(const void *codes_dev, int code_bytes, int codes_layout, int64_t N,

@@ -7,6 +7,8 @@ computes anything on the CPU; without a GPU they raise ``RuntimeError`` (``_capi
 from typing import Optional, Tuple
 
 import numpy as np
+import ctypes
+
 import torch
 
 from . import _capi
@@ -149,6 +151,30 @@ def adc_scan_topk_packed(codes: torch.Tensor, lut: torch.Tensor, B: int, k: int,
                                              lut.data_ptr(), B, k, row_base, out.data_ptr(), ws.data_ptr(),
                                              ws.numel(), stream_ptr()), 'adc_scan_topk_packed')
     return out
+
+
+def pq_search_topk(lut_kind: int, queries: torch.Tensor, codebooks: torch.Tensor, codes: torch.Tensor, k: int, M: int,
+                   Ks: int, valid_bits: Optional[torch.Tensor] = None, row_base: int = 0, n_rows: Optional[int] = None,
+                   codes_layout: int = CODES_PLAIN, workspace: Optional[ScanWorkspace] = None, packed: bool = False):
+    """LUT build + scan + top-k in one C call (``annlite_pq_search_topk``).  ``queries`` f32 [B, D] already
+    pre-processed (normalised for cosine).  Returns (f32 [B,k], i64 [B,k]) or, with ``packed``, i64 [B,k,2]."""
+    N = codes.shape[0] if n_rows is None else n_rows
+    B, D = queries.shape
+    cb = code_bytes_of(codes)
+    need = ctypes.c_int64(0)
+    check(lib().annlite_pq_search_workspace_bytes(N, M, Ks, cb, B, k, ctypes.byref(need)), 'pq_search_workspace_bytes')
+    dev = codes.device
+    ws = (workspace or ScanWorkspace()).get(int(need.value), dev)
+    od = oi = op = None
+    if packed:
+        op = torch.empty((B, k, 2), dtype=torch.int64, device=dev)
+    else:
+        od = torch.empty((B, k), dtype=torch.float32, device=dev)
+        oi = torch.empty((B, k), dtype=torch.int64, device=dev)
+    check(lib().annlite_pq_search_topk(lut_kind, queries.data_ptr(), B, D, codebooks.data_ptr(), codes.data_ptr(), cb,
+                                       codes_layout, N, M, Ks, _ptr(valid_bits), k, row_base, _ptr(od), _ptr(oi), _ptr(op),
+                                       ws.data_ptr(), ws.numel(), stream_ptr()), 'pq_search_topk')
+    return op if packed else (od, oi)
 
 
 def topk_merge_packed(packed: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

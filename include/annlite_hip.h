@@ -158,6 +158,22 @@ ANNLITE_API int annlite_adc_scan_topk_packed(const void *codes_dev, int code_byt
                                  int64_t k, int64_t row_base, int64_t *out_packed_dev, void *workspace_dev,
                                  size_t workspace_bytes, void *stream);
 
+/* The index plugin's search() in ONE call: query batch in, neighbours out.
+ * replaces: PQIndex.search / HnswIndex.search's LUT step + scan + top_k for B queries
+ * (annlite/core/index/pq_index.py:29-56, hnsw/index.py:139-167: get_dist_mat -> adist/knn -> top_k).
+ * Equivalent to annlite_lut_build(lut_kind, ...) into the plan's layout followed by annlite_adc_scan_topk
+ * (or _packed when out_packed_dev != NULL; then out_dist_dev/out_id_dev may be NULL) -- same bits --
+ * but for L2 tables on the quantised-filter plan the tables are built, reduced and quantised by one
+ * launch.  queries_dev must already carry the caller's pre-processing (l2-normalised for COSINE).
+ * workspace: annlite_pq_search_workspace_bytes() bytes (scan scratch + the fp32 tables). */
+ANNLITE_API int annlite_pq_search_workspace_bytes(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t k,
+                                      int64_t *bytes);
+ANNLITE_API int annlite_pq_search_topk(int lut_kind, const float *queries_dev, int64_t B, int64_t D,
+                           const float *codebooks_dev, const void *codes_dev, int code_bytes, int codes_layout,
+                           int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev, int64_t k,
+                           int64_t row_base, float *out_dist_dev, int64_t *out_id_dev, int64_t *out_packed_dev,
+                           void *workspace_dev, size_t workspace_bytes, void *stream);
+
 /* Same scan, but return the UNMERGED per-slice lists: plan.n_slices * k candidates per query
  * ([B][n_slices*k], unordered across slices, (+inf,-1) where a slice had fewer rows).  The set is a
  * superset of the exact top-k; it is the candidate generator of the exact re-rank stage

@@ -22,6 +22,7 @@ p.add_argument('--batch', type=int, default=1024)
 p.add_argument('--k', type=int, default=10)
 p.add_argument('--iters', type=int, default=5)
 p.add_argument('--layout', type=int, default=1)
+p.add_argument('--fused', action='store_true', help='annlite_pq_search_topk (tables built inside)')
 a = p.parse_args()
 torch.cuda.set_device(0)
 dev = torch.device('cuda', 0)
@@ -37,8 +38,11 @@ ws = ops.ScanWorkspace()
 _capi.profile_enable(True)
 ms = []
 for it in range(a.iters):
-    lut = ops.lut_build(q, cb, LUT_L2, LAYOUT_TILED, plan.qi)
-    d, i = ops.adc_scan_topk(codes, lut, B, k, M, Ks, codes_layout=a.layout, workspace=ws)
+    if a.fused:
+        d, i = ops.pq_search_topk(LUT_L2, q, cb, codes, k, M, Ks, codes_layout=a.layout, workspace=ws)
+    else:
+        lut = ops.lut_build(q, cb, LUT_L2, LAYOUT_TILED, plan.qi)
+        d, i = ops.adc_scan_topk(codes, lut, B, k, M, Ks, codes_layout=a.layout, workspace=ws)
     ms.append(_capi.profile_last_scan_ms())
 torch.cuda.synchronize()
 look = B * N * M

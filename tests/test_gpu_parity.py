@@ -311,6 +311,30 @@ def test_packed_scan_and_packed_merge_equal_the_two_tensor_path(ops):
     assert np.array_equal(mi.cpu().numpy(), i.cpu().numpy())
 
 
+@pytest.mark.parametrize('M,dsub,kind', [(16, 8, 1), (8, 16, 1), (32, 4, 1), (16, 6, 1), (16, 8, 3), (64, 12, 1), (64, 12, 3)])
+def test_fused_search_entry_equals_lut_build_plus_scan(ops, M, dsub, kind):
+    """annlite_pq_search_topk (tables built + quantised inside one launch for L2 on the quantised-filter plan)
+    returns the same bits as annlite_lut_build + annlite_adc_scan_topk, and leaves the same fp32 tables."""
+    import torch
+
+    from annlite_amd._capi import LAYOUT_BMK, LAYOUT_TILED, scan_plan
+
+    torch.manual_seed(M * 100 + dsub + kind)
+    N, Ks, B, k = 30000, 256, 45, 10
+    D = M * dsub
+    codes = torch.randint(0, 256, (N, M), dtype=torch.uint8, device='cuda')
+    cb = torch.randn((M, Ks, dsub), device='cuda')
+    q = torch.randn((B, D), device='cuda')
+    plan = scan_plan(N, M, Ks, 1, B, k)
+    lut = ops.lut_build(q, cb, kind, LAYOUT_TILED if plan.fast else LAYOUT_BMK, plan.qi)
+    d0, i0 = ops.adc_scan_topk(codes, lut, B, k, M, Ks)
+    d1, i1 = ops.pq_search_topk(kind, q, cb, codes, k, M, Ks)
+    assert np.array_equal(d0.cpu().numpy(), d1.cpu().numpy()) and np.array_equal(i0.cpu().numpy(), i1.cpu().numpy())
+    p = ops.pq_search_topk(kind, q, cb, codes, k, M, Ks, row_base=3, packed=True)
+    assert np.array_equal(p[..., 0].cpu().numpy(), i0.cpu().numpy() + 3)
+    assert np.array_equal(p[..., 1].cpu().numpy().astype(np.uint32).view(np.float32), d0.cpu().numpy())
+
+
 # ------------------------------------------------------------------------------------ index plugin
 @pytest.mark.parametrize('name', ['c1_m8_d128', 'c2_m16_d128', 'c4_m64_d768'])
 @pytest.mark.parametrize('mname,metric', [('euclidean', 1), ('inner_product', 2), ('cosine', 3)])
