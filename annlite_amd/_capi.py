@@ -101,10 +101,10 @@ def lib() -> ctypes.CDLL:
     L.annlite_adc_scan_candidates.argtypes = L.annlite_adc_scan_topk.argtypes
     L.annlite_adc_scan_topk_packed.argtypes = [vp, i32, i32, i64, i64, i64, vp, vp, i64, i64, i64, vp, vp, sz, vp]
     L.annlite_pq_search_workspace_bytes.argtypes = [i64, i64, i64, i32, i64, i64, ctypes.POINTER(ctypes.c_int64)]
-    L.annlite_pq_search_topk.argtypes = [i32, vp, i64, i64, vp, vp, i32, i32, i64, i64, i64, vp, i64, i64, vp, vp, vp, vp,
-                                         sz, vp]
+    L.annlite_pq_search_topk.argtypes = [i32, vp, i64, i64, vp, vp, i32, i32, i64, i64, i64, vp, i64, i64, vp, vp, vp, i32,
+                                         vp, sz, vp]
     L.annlite_topk_merge.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
-    L.annlite_topk_merge_packed.argtypes = [vp, i64, i64, i64, vp, vp, vp]
+    L.annlite_topk_merge_packed.argtypes = [vp, i64, i64, i64, vp, vp, i32, vp]
     L.annlite_topk_rows.argtypes = [vp, i64, i64, i64, i64, vp, vp, vp]
     L.annlite_pq_encode.argtypes = [vp, i64, i64, vp, i64, i64, vp, i32, vp]
     L.annlite_pq_decode.argtypes = [vp, i32, i64, i64, i64, vp, i64, vp, vp]

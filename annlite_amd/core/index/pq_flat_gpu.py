@@ -198,7 +198,7 @@ class PQFlatGpuIndex(BaseIndex):
         sel[idx] = True
         return self._pack_bits(sel & self._valid_bool)
 
-    def search_batch(self, x, limit: int = 10, indices=None, rerank_k: Optional[int] = None
+    def search_batch(self, x, limit: int = 10, indices=None, rerank_k: Optional[int] = None, row_base: int = 0
                      ) -> Tuple[torch.Tensor, torch.Tensor]:
         """All queries of ``x`` [B, D] in one launch.  Returns device tensors
         ``(dists f32 [B, k], ids i64 [B, k])``, ascending by (distance, id); missing -> (+inf, -1).
@@ -223,11 +223,13 @@ class PQFlatGpuIndex(BaseIndex):
             # table build + scan + top-k: one C call (annlite_pq_search_topk)
             kind, xq = self.pq_codec.scan_inputs(q)
             d, i = ops.pq_search_topk(kind, xq, self.pq_codec.codebooks_dev, self._codes, k, self.M, self.Ks,
-                                      valid_bits=valid, n_rows=N, codes_layout=self._layout(), workspace=self._ws)
-            if self.metric == Metric.EUCLIDEAN:
-                d = torch.sqrt(d)  # hnsw/index.py:164-165
+                                      valid_bits=valid, n_rows=N, codes_layout=self._layout(), workspace=self._ws,
+                                      row_base=row_base, sqrt=self.metric == Metric.EUCLIDEAN)  # hnsw/index.py:164-165
+            row_base = 0
         else:
             d, i = self._search_large_k(q, k, valid, N)
+        if row_base:
+            i = torch.where(i >= 0, i + row_base, i)  # (paths that do not take row_base natively)
         if is_np:
             return d.cpu().numpy(), i.cpu().numpy()
         return d, i
@@ -251,9 +253,10 @@ class PQFlatGpuIndex(BaseIndex):
                                   valid_bits=self._valid, row_base=row_base, n_rows=N, codes_layout=self._layout(),
                                   workspace=self._ws, packed=True)
 
-    def finish_distances(self, d: torch.Tensor) -> torch.Tensor:
+    @property
+    def sqrt_epilogue(self) -> bool:
         """Metric epilogue of ``search`` on raw ADC sums (hnsw/index.py:164-165)."""
-        return torch.sqrt(d) if self.metric == Metric.EUCLIDEAN else d
+        return self.metric == Metric.EUCLIDEAN
 
     def _plain_codes(self, N: int) -> torch.Tensor:
         if self._layout() == CODES_SKEWED:

@@ -60,6 +60,13 @@ struct ScanArgs {
                              // concurrently scanned slices of a query hold >= k rows at or below the MAX of
                              // their j-th keys, a bound ~k/j times tighter than any single slice's own k-th
     int32_t jm1;             // j - 1
+    // final merge inside the scan (shared mode): the LAST workgroup of a query tile to finish merges its slices
+    unsigned int *tile_done; // [n_tiles] arrival counters, start at 0xffffffff (workspace fill); NULL = no in-kernel merge
+    float *out_d;            // [B][k]   (or NULL with out_packed)
+    int64_t *out_i;          // [B][k]
+    int64_t *out_packed;     // [B][k][2] (global id, distance bits)
+    int64_t row_base;
+    int32_t sqrt_out;        // metric epilogue of EUCLIDEAN search (hnsw/index.py:164-165): out_d = sqrt(sum); never for packed
     int32_t flush_mask;      // a wave flushes its candidate queue every (flush_mask + 1) steps, staggered by wave
     int32_t dbg_skip;        // debug bitmask (ANNLITE_DEBUG_SKIP): 1 no gathers, 2 no insert/publish, 4 no event at all
     unsigned long long *dbg; // optional event counters (ANNLITE_DEBUG_COUNTERS=1): [0] slow-block entries,
@@ -1222,8 +1229,52 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
         __syncthreads();
         for (int q = wave; q < QT; q += NW) {
             const int b = tile * QT + q;
+            // device-scope stores: the merging workgroup may sit on another XCD (own L2)
             if (b < a.B && lane <= km1)
-                a.partial[((int64_t)b * a.n_slices + slice) * a.k + lane] = lists[q * 64 + lane];
+                __hip_atomic_store(a.partial + ((int64_t)b * a.n_slices + slice) * a.k + lane, lists[q * 64 + lane],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (a.tile_done) {
+            // the last of the tile's n_slices workgroups to arrive merges them (saves the merge launch and the
+            // ~10 us kernel boundary in front of it)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have completed
+            __syncthreads();
+            volatile unsigned int *s_flag = (volatile unsigned int *)(smem + lock_off);  // locks are idle now
+            if (tid == 0) {
+                const unsigned int old =
+                    __hip_atomic_fetch_add(a.tile_done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *s_flag = (old + 1u == (unsigned int)(a.n_slices - 1)) ? 1u : 0u;
+            }
+            __syncthreads();
+            if (*s_flag) {
+                for (int q = wave; q < QT; q += NW) {
+                    const int b = tile * QT + q;
+                    if (b >= a.B) continue;
+                    WaveList L;
+                    L.reset();
+                    for (int sl = 0; sl < a.n_slices; ++sl) {
+                        unsigned long long key = ~0ull;
+                        if (lane <= km1)
+                            key = __hip_atomic_load(a.partial + ((int64_t)b * a.n_slices + sl) * a.k + lane,
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // every slice list is ascending over the lanes: sorted merge, keep the 64 smallest
+                        wavelist_merge_sorted(L, (uint32_t)(key >> 32), (uint32_t)key, lane);
+                    }
+                    if (lane <= km1) {
+                        const bool none = (L.hi == kKeyInfHi && L.lo == kIdNone);
+                        const float d = none ? __builtin_inff() : ordered_to_f32(L.hi);
+                        const int64_t id = none ? (int64_t)-1 : a.row_base + (int64_t)L.lo;
+                        if (a.out_packed) {
+                            a.out_packed[((int64_t)b * a.k + lane) * 2 + 0] = id;
+                            a.out_packed[((int64_t)b * a.k + lane) * 2 + 1] = (int64_t)__float_as_uint(d);
+                        } else {
+                            a.out_d[(int64_t)b * a.k + lane] = a.sqrt_out ? __builtin_sqrtf(d) : d;
+                            a.out_i[(int64_t)b * a.k + lane] = id;
+                        }
+                    }
+                }
+            }
+            __syncthreads();  // s_flag (the lock words) is re-initialised by the next item
         }
     }
 }
@@ -1745,7 +1796,7 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_generic_kernel(const ScanArg
 // ONE all-gather per batch in the row-sharded search.
 __global__ __launch_bounds__(256) void merge_partial_kernel(const unsigned long long *partial, int B, int NS,
                                                            int k, int64_t row_base, float *out_d,
-                                                           int64_t *out_i, int64_t *out_packed) {
+                                                           int64_t *out_i, int64_t *out_packed, int sqrt_out) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -1771,7 +1822,7 @@ __global__ __launch_bounds__(256) void merge_partial_kernel(const unsigned long 
             out_packed[((int64_t)b * k + lane) * 2 + 0] = id;
             out_packed[((int64_t)b * k + lane) * 2 + 1] = (int64_t)__float_as_uint(d);
         } else {
-            out_d[(int64_t)b * k + lane] = d;
+            out_d[(int64_t)b * k + lane] = sqrt_out ? __builtin_sqrtf(d) : d;
             out_i[(int64_t)b * k + lane] = id;
         }
     }
@@ -1792,7 +1843,8 @@ __global__ __launch_bounds__(256) void export_partial_kernel(const unsigned long
 // Merge G lists [G][B][k] of (dist, id) -> [B][k]  (after the RCCL all-gather).  One wave per query.
 // `packed` != NULL: the lists come as [G][B][k][2] int64 (id, distance bits) -- merge_partial_kernel's packed form.
 __global__ __launch_bounds__(256) void merge_lists_kernel(const float *dist, const int64_t *id, const int64_t *packed,
-                                                         int G, int B, int k, float *out_d, int64_t *out_i) {
+                                                         int G, int B, int k, float *out_d, int64_t *out_i,
+                                                         int sqrt_out) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -1823,7 +1875,7 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float *dist, con
     }
     if (lane <= km1) {
         const bool none = (li == INT64_MAX);
-        out_d[(int64_t)b * k + lane] = none ? __builtin_inff() : ld;
+        out_d[(int64_t)b * k + lane] = none ? __builtin_inff() : (sqrt_out ? __builtin_sqrtf(ld) : ld);
         out_i[(int64_t)b * k + lane] = none ? (int64_t)-1 : li;
     }
 }
@@ -2050,7 +2102,8 @@ extern "C" int annlite_scan_plan_query(int64_t N, int64_t M, int64_t Ks, int cod
         const int64_t bpad = ((B + 15) / 16) * 16;
         plan->workspace_bytes = (int64_t)n_tiles * plan->qt * ns * k * 8 + 256 + bpad * 4 + 256;
         if (c.mode == 4)
-            plan->workspace_bytes += bpad * 4 + 256 + 2 * (bpad * 8 + 256) + (bpad * ns * 8 + 256) + bpad * M * Ks * 2 + 256;
+            plan->workspace_bytes += bpad * 4 + 256 + 2 * (bpad * 8 + 256) + (bpad * ns * 8 + 256) + (n_tiles * 4 + 256) +
+                                     bpad * M * Ks * 2 + 256;
     } else {
         plan->fast = 0;
         plan->qi = 1;
@@ -2106,11 +2159,20 @@ struct LutBuild {
     const float *codebooks;
     int64_t D;
 };
+// where a scan that can merge its slices itself puts the final result (merged is set when it did)
+struct ScanOut {
+    float *d;
+    int64_t *i;
+    int64_t *packed;
+    int64_t row_base;
+    int sqrt_out;
+    bool merged;
+};
 
 static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M, int64_t Ks,
                         const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B, int64_t k,
                         void *workspace_dev, size_t workspace_bytes, hipStream_t st, annlite_scan_plan *plan_out,
-                        bool share_across_slices, const LutBuild *build = nullptr) {
+                        bool share_across_slices, const LutBuild *build = nullptr, ScanOut *outp = nullptr) {
     annlite_scan_plan plan;
     int rc = annlite_scan_plan_query(N, M, Ks, code_bytes, B, k, &plan);
     if (rc != ANNLITE_OK) return rc;
@@ -2125,7 +2187,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         return ANNLITE_ERR_WORKSPACE;
     }
     const int n_cu = device_cu_count();
-    ScanArgs a;
+    ScanArgs a = {};
     a.codes = codes_dev;
     a.valid = valid_bits_dev;
     a.lut = lut_dev;
@@ -2165,7 +2227,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             const size_t bpad = (size_t)((B + 15) / 16) * 16;
             auto r256 = [](size_t x) { return (x + 255) / 256 * 256; };
             fill = r256((size_t)a.n_tiles * plan.qt * plan.n_slices * k * 8) + r256(bpad * 8) +
-                   r256(bpad * plan.n_slices * 8);
+                   r256(bpad * plan.n_slices * 8) + r256((size_t)a.n_tiles * 4);
         }
         fill_bytes = fill;
         FastCfg c1;
@@ -2186,9 +2248,19 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             const int64_t bpad = ((B + 15) / 16) * 16;
             char *wp = (char *)workspace_dev + (((int64_t)a.n_tiles * plan.qt * plan.n_slices * k * 8 + 255) / 256) * 256;
             auto carve = [&](int64_t bytes) { char *r = wp; wp += ((bytes + 255) / 256) * 256; return r; };
-            // [gkey][gk2] directly behind the partial lists: the one memset above covers exactly these three
+            // [gkey][gk2][tile_done] directly behind the partial lists: the one fill covers exactly these four
             unsigned long long *gk = (unsigned long long *)carve(bpad * 8);
             unsigned long long *gk2 = (unsigned long long *)carve(bpad * plan.n_slices * 8);
+            unsigned int *tile_done = (unsigned int *)carve((int64_t)a.n_tiles * 4);
+            if (share_across_slices && outp && (outp->packed || (outp->d && outp->i))) {
+                a.tile_done = tile_done;
+                a.out_d = outp->d;
+                a.out_i = outp->i;
+                a.out_packed = outp->packed;
+                a.row_base = outp->row_base;
+                a.sqrt_out = outp->sqrt_out;
+                outp->merged = true;
+            }
             float *smax = (float *)carve(bpad * 4);
             float *qstep = (float *)carve(bpad * 4);
             double *qlo = (double *)carve(bpad * 8);
@@ -2339,16 +2411,19 @@ extern "C" int annlite_profile_last_scan_ms(float *ms) {
 static int scan_topk_impl(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M, int64_t Ks,
                           const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B, int64_t k, int64_t row_base,
                           float *out_dist_dev, int64_t *out_id_dev, int64_t *out_packed_dev, void *workspace_dev,
-                          size_t workspace_bytes, void *stream, const LutBuild *build = nullptr) {
+                          size_t workspace_bytes, void *stream, const LutBuild *build = nullptr, int flags = 0) {
     annlite_scan_plan plan;
     hipStream_t st = (hipStream_t)stream;
+    ANNLITE_REQUIRE(B == 0 || out_packed_dev || (out_dist_dev && out_id_dev), "null output pointer");
+    const int sqrt_out = (flags & ANNLITE_FLAG_SQRT) && !out_packed_dev ? 1 : 0;
+    ScanOut so = {out_dist_dev, out_id_dev, out_packed_dev, row_base, sqrt_out, false};
+    if (getenv("ANNLITE_NO_INKERNEL_MERGE")) so.d = nullptr, so.i = nullptr, so.packed = nullptr;
     int rc = scan_partial(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut_dev, B, k, workspace_dev,
-                          workspace_bytes, st, &plan, true, build);
-    if (rc != ANNLITE_OK || B == 0) return rc;
-    ANNLITE_REQUIRE(out_packed_dev || (out_dist_dev && out_id_dev), "null output pointer");
+                          workspace_bytes, st, &plan, true, build, &so);
+    if (rc != ANNLITE_OK || B == 0 || so.merged) return rc;
     hipLaunchKernelGGL(merge_partial_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st,
                        (const unsigned long long *)workspace_dev, (int)B, plan.n_slices, (int)k, row_base,
-                       out_dist_dev, out_id_dev, out_packed_dev);
+                       out_dist_dev, out_id_dev, out_packed_dev, sqrt_out);
     return launch_status("merge_partial_kernel");
 }
 
@@ -2385,7 +2460,7 @@ extern "C" int annlite_pq_search_topk(int lut_kind, const float *queries_dev, in
                                       const float *codebooks_dev, const void *codes_dev, int code_bytes, int codes_layout,
                                       int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev, int64_t k,
                                       int64_t row_base, float *out_dist_dev, int64_t *out_id_dev, int64_t *out_packed_dev,
-                                      void *workspace_dev, size_t workspace_bytes, void *stream) {
+                                      int flags, void *workspace_dev, size_t workspace_bytes, void *stream) {
     ANNLITE_REQUIRE(M >= 1 && D >= M && D % M == 0,
                     "input dimension must be dividable by number of sub-space (D=%lld, M=%lld)", (long long)D, (long long)M);
     annlite_scan_plan plan;
@@ -2408,11 +2483,11 @@ extern "C" int annlite_pq_search_topk(int lut_kind, const float *queries_dev, in
                                plan.fast ? ANNLITE_LAYOUT_TILED : ANNLITE_LAYOUT_BMK, plan.qi, stream);
         if (rc != ANNLITE_OK) return rc;
         return scan_topk_impl(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut, B, k, row_base,
-                              out_dist_dev, out_id_dev, out_packed_dev, workspace_dev, scan_ws, stream);
+                              out_dist_dev, out_id_dev, out_packed_dev, workspace_dev, scan_ws, stream, nullptr, flags);
     }
     const LutBuild lb = {queries_dev, codebooks_dev, D};
     return scan_topk_impl(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut, B, k, row_base, out_dist_dev,
-                          out_id_dev, out_packed_dev, workspace_dev, scan_ws, stream, &lb);
+                          out_id_dev, out_packed_dev, workspace_dev, scan_ws, stream, &lb, flags);
 }
 
 extern "C" int annlite_adc_scan_candidates(const void *codes_dev, int code_bytes, int codes_layout, int64_t N,
@@ -2450,19 +2525,19 @@ extern "C" int annlite_topk_merge(const float *dist_dev, const int64_t *id_dev, 
     if (B == 0) return ANNLITE_OK;
     ANNLITE_REQUIRE(dist_dev && id_dev && out_dist_dev && out_id_dev, "null device pointer");
     hipLaunchKernelGGL(merge_lists_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dist_dev,
-                       id_dev, (const int64_t *)nullptr, (int)G, (int)B, (int)k, out_dist_dev, out_id_dev);
+                       id_dev, (const int64_t *)nullptr, (int)G, (int)B, (int)k, out_dist_dev, out_id_dev, 0);
     return launch_status("merge_lists_kernel");
 }
 
 extern "C" int annlite_topk_merge_packed(const int64_t *packed_dev, int64_t G, int64_t B, int64_t k, float *out_dist_dev,
-                                         int64_t *out_id_dev, void *stream) {
+                                         int64_t *out_id_dev, int flags, void *stream) {
     ANNLITE_REQUIRE(G >= 1 && B >= 0 && k >= 1 && k <= 64, "bad G=%lld B=%lld k=%lld (k<=64)", (long long)G,
                     (long long)B, (long long)k);
     if (B == 0) return ANNLITE_OK;
     ANNLITE_REQUIRE(packed_dev && out_dist_dev && out_id_dev, "null device pointer");
     hipLaunchKernelGGL(merge_lists_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const float *)nullptr, (const int64_t *)nullptr, packed_dev, (int)G, (int)B, (int)k, out_dist_dev,
-                       out_id_dev);
+                       out_id_dev, (flags & ANNLITE_FLAG_SQRT) ? 1 : 0);
     return launch_status("merge_lists_kernel");
 }
 

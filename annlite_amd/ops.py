@@ -155,7 +155,8 @@ def adc_scan_topk_packed(codes: torch.Tensor, lut: torch.Tensor, B: int, k: int,
 
 def pq_search_topk(lut_kind: int, queries: torch.Tensor, codebooks: torch.Tensor, codes: torch.Tensor, k: int, M: int,
                    Ks: int, valid_bits: Optional[torch.Tensor] = None, row_base: int = 0, n_rows: Optional[int] = None,
-                   codes_layout: int = CODES_PLAIN, workspace: Optional[ScanWorkspace] = None, packed: bool = False):
+                   codes_layout: int = CODES_PLAIN, workspace: Optional[ScanWorkspace] = None, packed: bool = False,
+                   sqrt: bool = False):
     """LUT build + scan + top-k in one C call (``annlite_pq_search_topk``).  ``queries`` f32 [B, D] already
     pre-processed (normalised for cosine).  Returns (f32 [B,k], i64 [B,k]) or, with ``packed``, i64 [B,k,2]."""
     N = codes.shape[0] if n_rows is None else n_rows
@@ -173,17 +174,17 @@ def pq_search_topk(lut_kind: int, queries: torch.Tensor, codebooks: torch.Tensor
         oi = torch.empty((B, k), dtype=torch.int64, device=dev)
     check(lib().annlite_pq_search_topk(lut_kind, queries.data_ptr(), B, D, codebooks.data_ptr(), codes.data_ptr(), cb,
                                        codes_layout, N, M, Ks, _ptr(valid_bits), k, row_base, _ptr(od), _ptr(oi), _ptr(op),
-                                       ws.data_ptr(), ws.numel(), stream_ptr()), 'pq_search_topk')
+                                       1 if sqrt else 0, ws.data_ptr(), ws.numel(), stream_ptr()), 'pq_search_topk')
     return op if packed else (od, oi)
 
 
-def topk_merge_packed(packed: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+def topk_merge_packed(packed: torch.Tensor, sqrt: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """[G,B,k,2] i64 (id, distance bits) -> ([B,k] f32, [B,k] i64), same order rule as ``topk_merge``."""
     G, B, k, _ = packed.shape
     od = torch.empty((B, k), dtype=torch.float32, device=packed.device)
     oi = torch.empty((B, k), dtype=torch.int64, device=packed.device)
     check(lib().annlite_topk_merge_packed(packed.contiguous().data_ptr(), G, B, k, od.data_ptr(), oi.data_ptr(),
-                                          stream_ptr()), 'topk_merge_packed')
+                                          1 if sqrt else 0, stream_ptr()), 'topk_merge_packed')
     return od, oi
 
 

@@ -74,9 +74,7 @@ class ShardedPQIndex:
         self._merge = ops.topk_merge
 
     def _scan(self, queries, k):
-        d, i = self.index.search_batch(queries, limit=k)
-        i = torch.where(i >= 0, i + self.row_base, i)
-        return d, i
+        return self.index.search_batch(queries, limit=k, row_base=self.row_base)
 
     def search_batch(self, queries: torch.Tensor, limit: int = 10):
         return self.search_batch_async(queries, limit).result()
@@ -111,8 +109,7 @@ class PendingSearch:
             from . import ops
 
             self._work.wait()  # the current stream waits for the collective; the host does not block
-            d, i = ops.topk_merge_packed(self._gathered)
-            self._value = (self._owner.index.finish_distances(d), i)
+            self._value = ops.topk_merge_packed(self._gathered, sqrt=self._owner.index.sqrt_epilogue)
             self._work = self._gathered = self._packed = None
         return self._value
 

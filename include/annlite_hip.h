@@ -165,14 +165,17 @@ ANNLITE_API int annlite_adc_scan_topk_packed(const void *codes_dev, int code_byt
  * (or _packed when out_packed_dev != NULL; then out_dist_dev/out_id_dev may be NULL) -- same bits --
  * but for L2 tables on the quantised-filter plan the tables are built, reduced and quantised by one
  * launch.  queries_dev must already carry the caller's pre-processing (l2-normalised for COSINE).
+ * flags: ANNLITE_FLAG_SQRT.
  * workspace: annlite_pq_search_workspace_bytes() bytes (scan scratch + the fp32 tables). */
+#define ANNLITE_FLAG_SQRT 1 /* metric epilogue of EUCLIDEAN search: out_dist = sqrt(ADC sum) (hnsw/index.py:164-165);
+                               applied after all merging, ignored for packed output (raw sums travel) */
 ANNLITE_API int annlite_pq_search_workspace_bytes(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t k,
                                       int64_t *bytes);
 ANNLITE_API int annlite_pq_search_topk(int lut_kind, const float *queries_dev, int64_t B, int64_t D,
                            const float *codebooks_dev, const void *codes_dev, int code_bytes, int codes_layout,
                            int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev, int64_t k,
                            int64_t row_base, float *out_dist_dev, int64_t *out_id_dev, int64_t *out_packed_dev,
-                           void *workspace_dev, size_t workspace_bytes, void *stream);
+                           int flags, void *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* Same scan, but return the UNMERGED per-slice lists: plan.n_slices * k candidates per query
  * ([B][n_slices*k], unordered across slices, (+inf,-1) where a slice had fewer rows).  The set is a
@@ -209,7 +212,7 @@ ANNLITE_API int annlite_topk_merge(const float *dist_dev, const int64_t *id_dev,
 
 /* The same merge over the packed form of annlite_adc_scan_topk_packed: in i64 [G][B][k][2]. */
 ANNLITE_API int annlite_topk_merge_packed(const int64_t *packed_dev, int64_t G, int64_t B, int64_t k,
-                              float *out_dist_dev, int64_t *out_id_dev, void *stream);
+                              float *out_dist_dev, int64_t *out_id_dev, int flags, void *stream);
 
 /* Row-wise k smallest of a dense f32 matrix [B][N] -> ([B][k], [B][k]) with the fixed tie-break.
  * replaces: annlite.math.top_k(values, k, descending=False) (annlite/math.py:94-120). k <= 64. */
