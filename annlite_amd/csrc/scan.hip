@@ -1098,10 +1098,18 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
         u32x4 thp[NQ];  // packed (0x8000 | qthr) of the group's 8 queries
 #pragma unroll
         for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
+        uint32_t vcur = ~0u, vnext = ~0u;
+        auto load_valid = [&](int64_t row) -> uint32_t {
+            if (!a.valid) return ~0u;
+            if (row >= a.N) row = a.N - 1;
+            return a.valid[row >> 5];
+        };
         if (row0 < slice_end) {
             load_row(row0 + lane, ccur);
             if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
             load_row(row0 + stride + lane, cnext);
+            vcur = load_valid(row0 + lane);
+            vnext = load_valid(row0 + stride + lane);
         }
 
         const FlushCtx fc = {(const uint8_t *)a.codes, a.lut, a.smax, a.qstep, a.qlo, a.gkey, a.gk2, a.dbg,
@@ -1112,12 +1120,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
         for (; row0 < slice_end; row0 += stride, ++step_no) {
             unsigned long long vmask = ~0ull;
             if (slice_end - row0 < 64) vmask = (1ull << (int)(slice_end - row0)) - 1ull;
-            if (a.valid) {
-                const uint32_t *vw = a.valid + (row0 >> 5);
-                unsigned long long vb = (unsigned long long)vw[0];
-                if (row0 + 32 < a.N) vb |= (unsigned long long)vw[1] << 32;
-                vmask &= vb;
-            }
+            // validity word of this lane's row, fetched one step ahead with the code bytes (a scalar load here
+            // would make the wave drain lgkmcnt -- i.e. all its LDS look-ups -- before the first add)
+            if (a.valid) vmask &= __ballot((vcur >> (lane & 31)) & 1u);
             const uint32_t rid = (uint32_t)(row0 + lane);
             make_addr(ccur);
             u32x4 acc[NQ];
@@ -1221,6 +1226,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
             for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
             if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
             load_row(row0 + 2 * stride + lane, cnext);
+            vcur = vnext;
+            vnext = load_valid(row0 + 2 * stride + lane);
         }
 
         if (qcnt) qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);

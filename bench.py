@@ -161,6 +161,11 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     qps = B * args.steps / elapsed
 
+    if os.environ.get('ANNLITE_DEBUG_COUNTERS') and rank == 0:
+        c = _capi.debug_counters()  # of the last step (debug aid; the counters slow the kernel down)
+        print('counters: slow-block entries %d, flush query-groups %d, inserting %d, publications %d, candidate rows %d' %
+              (c[0], c[1], c[2], c[3], c[4]), file=sys.stderr)
+
     # ---- roofline leg: HIP events around the dominant kernel, live, over the same steps ------------
     _capi.profile_enable(True)
     kms = []
