@@ -22,6 +22,7 @@ p.add_argument('--batch', type=int, default=1024)
 p.add_argument('--k', type=int, default=10)
 p.add_argument('--iters', type=int, default=5)
 p.add_argument('--layout', type=int, default=1)
+p.add_argument('--valid', action='store_true', help='pass an all-ones validity bitmap (what the index plugin does)')
 p.add_argument('--fused', action='store_true', help='annlite_pq_search_topk (tables built inside)')
 a = p.parse_args()
 torch.cuda.set_device(0)
@@ -35,14 +36,15 @@ cb = torch.randn((M, Ks, D // M), generator=g, device=dev)
 q = torch.randn((B, D), generator=g, device=dev)
 plan = scan_plan(N, M, Ks, 1, B, k)
 ws = ops.ScanWorkspace()
+valid = torch.full(((N + 31) // 32 + 1,), -1, dtype=torch.int32, device=dev) if a.valid else None
 _capi.profile_enable(True)
 ms = []
 for it in range(a.iters):
     if a.fused:
-        d, i = ops.pq_search_topk(LUT_L2, q, cb, codes, k, M, Ks, codes_layout=a.layout, workspace=ws)
+        d, i = ops.pq_search_topk(LUT_L2, q, cb, codes, k, M, Ks, codes_layout=a.layout, workspace=ws, valid_bits=valid)
     else:
         lut = ops.lut_build(q, cb, LUT_L2, LAYOUT_TILED, plan.qi)
-        d, i = ops.adc_scan_topk(codes, lut, B, k, M, Ks, codes_layout=a.layout, workspace=ws)
+        d, i = ops.adc_scan_topk(codes, lut, B, k, M, Ks, codes_layout=a.layout, workspace=ws, valid_bits=valid)
     ms.append(_capi.profile_last_scan_ms())
 torch.cuda.synchronize()
 look = B * N * M
