@@ -839,6 +839,27 @@ __device__ __forceinline__ unsigned short qbound_from_key(unsigned long long key
 }
 
 
+// ---- M = 64: the "wrap-coded" SKEWED layout ------------------------------------------------------
+// With 64 sub-spaces a lane cannot afford one LDS base pointer per step (64 VGPRs).  Lane l (row n,
+// n % 64 == l) reads sub-space u = l + t at step t; the address is (code << 9) + l*8 + t*8 with t*8 as the
+// instruction's immediate -- correct while u < 64.  For u >= 64 the true entry is (code, u - 64): 512
+// bytes lower, i.e. the SAME offset inside the PREVIOUS table row.  So the stored byte of a wrapped
+// position is code - 1 (mod 256), and LDS carries one extra row 256 = copy of row 0 for code 0 - 1 = 255.
+// stored byte j of row n:  code[(j + n) % 64] - [(j + n % 64) >= 64]   (mod 256)
+// 0x01 in every byte of dword w (positions 4w..4w+3) whose position j satisfies j + r >= 64
+__device__ __forceinline__ uint32_t wrap64_mask(int w, int r) {
+    int nb = 4 * w + 4 - (64 - r);  // number of (upper) bytes of the dword that wrap
+    nb = nb < 0 ? 0 : (nb > 4 ? 4 : nb);
+    return nb == 0 ? 0u : (0x01010101u << (8 * (4 - nb)));
+}
+// per-byte x - y / x + y (mod 256) for y in {0, 1} per byte, no borrow/carry across bytes
+__device__ __forceinline__ uint32_t bytes_sub(uint32_t x, uint32_t y) {
+    return ((x | 0x80808080u) - y) ^ ((x ^ ~y) & 0x80808080u);
+}
+__device__ __forceinline__ uint32_t bytes_add(uint32_t x, uint32_t y) {
+    return ((x & 0x7f7f7f7fu) + y) ^ ((x ^ y) & 0x80808080u);
+}
+
 // what a queue flush needs and a work item keeps constant
 struct FlushCtx {
     const uint8_t *codes;
@@ -872,6 +893,11 @@ __device__ __attribute__((noinline)) void qfilter_flush(const FlushCtx c, uint32
         const uint32_t *p = (const uint32_t *)(c.codes + (int64_t)rid * M);
 #pragma unroll
         for (int i = 0; i < CW; ++i) cp[i] = p[i];
+        if constexpr (SKEWED && M == 64) {
+            const int r = (int)(rid % 64);
+#pragma unroll
+            for (int i = 0; i < CW; ++i) cp[i] = bytes_add(cp[i], wrap64_mask(i, r));  // undo the wrap coding
+        }
         if constexpr (SKEWED) {
             // stored byte j of row n is the code of sub-space (j + n) mod M: rotate back by n mod M
             const int sinv = (M - (int)(rid % M)) % M;
@@ -1286,6 +1312,339 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
     }
 }
 
+
+// =================================================================================================
+// Quantised-filter kernel for M = 64 (BASELINE config 4: 768-d, 12-float sub-spaces).  Same discipline as
+// adc_scan_qfilter_kernel; what differs is dictated by the table size (64 sub-spaces x 256 codes):
+//   * 4 queries per 8-byte LDS entry (u16 each), table [Ks + 1][64][8 B] = 128.5 KB, ds_read_b64; a
+//     half-wave reads sub-spaces (l + t) % 64 for 32 consecutive l: bank pair (l + t) % 32, conflict-free;
+//   * no per-step LDS base registers: the wrap-coded SKEWED layout (wrap64_mask) makes the address
+//     (stored byte << 9) + lane*8 with t*8 as the instruction's immediate -- one SDWA shift + one add;
+//   * QMAX = floor(32767 / 64) = 511 (9-bit entries), look-ups issued in 4 chunks of 16;
+//   * PLAIN tables are rotated and wrap-coded on the fly (slow path; the index plugin stores SKEWED).
+// LDS: [table (Ks+1)*512][shq u16 x 4 @ +0][locks u32 x 4 @ +64][gkl u64 x 4 @ +128][lists u64 x 4 x 64 @ +256]
+//      [gjl u64 x 4][queues u64 x NW x 64]
+// =================================================================================================
+template <int NW, bool SKEWED>
+__global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanArgs a) {
+    constexpr int M = 64, QT = 4, CW = 16, RB = 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int km1 = a.k - 1;
+    // forward rotation of PLAIN rows by lane bytes
+    const uint32_t bsh = (uint32_t)(lane & 3);
+    bool abit[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) abit[i] = (((lane >> 2) >> i) & 1) != 0;
+
+    const int lut_bytes = (a.Ks + 1) * RB;
+    const uint32_t shq_off = (uint32_t)lut_bytes, lock_off = shq_off + 64, gkl_off = shq_off + 128,
+                   list_off = shq_off + 256, gjl_off = list_off + QT * 512, queue_off = gjl_off + 128;
+    unsigned long long *gkl = (unsigned long long *)(smem + gkl_off);
+    volatile uint16_t *shq = (volatile uint16_t *)(smem + shq_off);
+    volatile uint32_t *locks = (volatile uint32_t *)(smem + lock_off);
+    unsigned long long *lists = (unsigned long long *)(smem + list_off);
+    const unsigned char *lbase = smem + lane * 8;
+
+    for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        int tile, slice;
+        if (!item_map(a, item, tile, slice)) continue;
+
+        __syncthreads();
+        {
+            const u32x4 *src = (const u32x4 *)((const unsigned char *)a.q16 + (int64_t)tile * a.Ks * RB);
+            const int total = a.Ks * (RB / 16);
+            for (int idx = tid; idx < total; idx += NW * 64) ((u32x4 *)smem)[idx] = src[idx];
+            for (int idx = tid; idx < RB / 16; idx += NW * 64) ((u32x4 *)(smem + a.Ks * RB))[idx] = src[idx];  // row Ks = row 0
+            if (tid < QT) {
+                locks[tid] = 0;
+                const int b = tile * QT + tid;
+                const unsigned long long gk =
+                    a.gkey ? __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+                gkl[tid] = gk;
+                ((unsigned long long *)(smem + gjl_off))[tid] = ~0ull;
+                shq[tid] = qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]);
+            }
+            for (int idx = tid; idx < QT * 64; idx += NW * 64) lists[idx] = ~0ull;
+        }
+        __syncthreads();
+
+        const int64_t slice_begin = (int64_t)slice * a.slice_rows;
+        int64_t slice_end = slice_begin + a.slice_rows;
+        if (slice_end > a.N) slice_end = a.N;
+
+        const uint32_t *codes32 = (const uint32_t *)a.codes;
+        auto load_row = [&](int64_t row, uint32_t (&c)[CW]) {
+            if (row >= a.N) row = a.N - 1;
+            const uint32_t *p = codes32 + row * CW;
+#pragma unroll
+            for (int i = 0; i < CW / 4; ++i) {
+                const u32x4 v = *(const u32x4 *)(p + 4 * i);
+                c[4 * i + 0] = v.x;
+                c[4 * i + 1] = v.y;
+                c[4 * i + 2] = v.z;
+                c[4 * i + 3] = v.w;
+            }
+        };
+        auto encode_plain = [&](uint32_t (&c)[CW]) {  // PLAIN row -> this lane's wrap-coded SKEWED row
+            rotate_row<CW>(c, abit, bsh);
+#pragma unroll
+            for (int i = 0; i < CW; ++i) c[i] = bytes_sub(c[i], wrap64_mask(i, lane));
+        };
+        auto load_valid = [&](int64_t row) -> uint32_t {
+            if (!a.valid) return ~0u;
+            if (row >= a.N) row = a.N - 1;
+            return a.valid[row >> 5];
+        };
+
+        const int64_t stride = (int64_t)NW * 64;
+        int64_t row0 = slice_begin + (int64_t)wave * 64;
+        uint32_t ccur[CW], cnext[CW];
+        uint32_t vcur = ~0u, vnext = ~0u;
+        u32x2 thp = *(const u32x2 *)(smem + shq_off);  // packed (0x8000 | qthr) of the 4 queries
+        if (row0 < slice_end) {
+            load_row(row0 + lane, ccur);
+            if constexpr (!SKEWED) encode_plain(ccur);
+            load_row(row0 + stride + lane, cnext);
+            vcur = load_valid(row0 + lane);
+            vnext = load_valid(row0 + stride + lane);
+        }
+        const FlushCtx fc = {(const uint8_t *)a.codes, a.lut, a.smax, a.qstep, a.qlo, a.gkey, a.gk2, a.dbg,
+                             a.Ks, tile * QT, a.n_slices, slice, km1, a.jm1, a.dbg_skip,
+                             list_off, lock_off, shq_off, gkl_off, gjl_off};
+        int qcnt = 0;
+        int step_no = 0;
+        for (; row0 < slice_end; row0 += stride, ++step_no) {
+            unsigned long long vmask = ~0ull;
+            if (slice_end - row0 < 64) vmask = (1ull << (int)(slice_end - row0)) - 1ull;
+            if (a.valid) vmask &= __ballot((vcur >> (lane & 31)) & 1u);
+            const uint32_t rid = (uint32_t)(row0 + lane);
+
+            u32x2 acc = {0u, 0u};
+            static_for<0, 4>([&](auto C) {
+                constexpr int c0 = decltype(C)::value * 16;
+                u32x2 v[16];
+                static_for<0, 16>([&](auto I) {
+                    constexpr int t = c0 + decltype(I)::value;
+                    const unsigned char *ad = lbase + byte_shl<t % 4>(ccur[t / 4], 9u);
+                    v[t - c0] = *(const u32x2 *)(ad + t * 8);
+                });
+                asm volatile("" ::: "memory");
+                static_for<0, 16>([&](auto I) { acc += v[decltype(I)::value]; });
+            });
+
+            const uint32_t x0 = (thp.x - acc.x) & 0x80008000u, x1 = (thp.y - acc.y) & 0x80008000u;
+            const unsigned long long anym = __ballot((x0 | x1) != 0) & vmask;
+            bool flushed = false;
+            if (anym && !(a.dbg_skip & 4)) {
+                if (a.dbg && lane == 0) atomicAdd(a.dbg + 0, 1ull);
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const uint32_t x = w ? x1 : x0;
+                    if (__ballot(x != 0) & vmask) {
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            const unsigned long long pm = __ballot((x & (half ? 0x80000000u : 0x8000u)) != 0) & vmask;
+                            if (pm) {
+                                const int n = __popcll(pm);
+                                if (qcnt + n > 64) {
+                                    qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
+                                    qcnt = 0;
+                                    flushed = true;
+                                }
+                                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32),
+                                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                                unsigned long long *queue = (unsigned long long *)(smem + queue_off + wave * 512);
+                                if ((pm >> lane) & 1ull) queue[qcnt + rank] = ((unsigned long long)(w * 2 + half) << 32) | rid;
+                                qcnt += n;
+                            }
+                        }
+                    }
+                }
+            }
+            if (qcnt && (qcnt >= 32 || ((step_no + wave * 4) & a.flush_mask) == a.flush_mask)) {
+                qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
+                qcnt = 0;
+                flushed = true;
+            }
+            // import the bounds of the other slices (see adc_scan_qfilter_kernel)
+            if (a.gkey) {
+                const bool pow2 = ((step_no + 1) & step_no) == 0;
+                if (pow2 || (step_no & 63) == 63) {
+                    const int rw = pow2 ? (__builtin_ctz((unsigned)step_no + 1u) % NW) : ((step_no >> 6) % NW);
+                    if (wave == rw) {
+                        const int q = lane >> 3;
+                        if (q < QT) {
+                            const int b = tile * QT + q;
+                            unsigned long long bound =
+                                __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (a.gk2) {
+#pragma unroll 1
+                                for (int g0 = 0; g0 < a.n_slices; g0 += 8) {
+                                    unsigned long long v = 0ull;
+                                    if (g0 + (lane & 7) < a.n_slices)
+                                        v = __hip_atomic_load(a.gk2 + (int64_t)b * a.n_slices + g0 + (lane & 7),
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                                    for (int o = 1; o < 8; o <<= 1) {
+                                        const unsigned long long p = __shfl_xor(v, o);
+                                        v = p > v ? p : v;
+                                    }
+                                    if (v != ~0ull && v + 1ull < bound) bound = v + 1ull;
+                                }
+                            }
+                            if ((lane & 7) == 0 &&
+                                bound < __hip_atomic_load(gkl + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                                __hip_atomic_store(gkl + q, bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                const unsigned short nb = qbound_from_key<M>(bound, a.smax[b], a.qstep[b], a.qlo[b]);
+                                if (nb < shq[q]) shq[q] = nb;
+                            }
+                        }
+                    }
+                }
+            }
+            if (flushed || (step_no & 3) == 3) {
+                asm volatile("" ::: "memory");
+                thp = *(const u32x2 *)(smem + shq_off);
+            }
+#pragma unroll
+            for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
+            if constexpr (!SKEWED) encode_plain(ccur);
+            load_row(row0 + 2 * stride + lane, cnext);
+            vcur = vnext;
+            vnext = load_valid(row0 + 2 * stride + lane);
+        }
+        if (qcnt) qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
+
+        __syncthreads();
+        for (int q = wave; q < QT; q += NW) {
+            const int b = tile * QT + q;
+            if (b < a.B && lane <= km1)
+                __hip_atomic_store(a.partial + ((int64_t)b * a.n_slices + slice) * a.k + lane, lists[q * 64 + lane],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (a.tile_done) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            volatile unsigned int *s_flag = (volatile unsigned int *)(smem + lock_off);
+            if (tid == 0) {
+                const unsigned int old =
+                    __hip_atomic_fetch_add(a.tile_done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *s_flag = (old + 1u == (unsigned int)(a.n_slices - 1)) ? 1u : 0u;
+            }
+            __syncthreads();
+            if (*s_flag) {
+                for (int q = wave; q < QT; q += NW) {
+                    const int b = tile * QT + q;
+                    if (b >= a.B) continue;
+                    WaveList L;
+                    L.reset();
+                    for (int sl = 0; sl < a.n_slices; ++sl) {
+                        unsigned long long key = ~0ull;
+                        if (lane <= km1)
+                            key = __hip_atomic_load(a.partial + ((int64_t)b * a.n_slices + sl) * a.k + lane,
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        wavelist_merge_sorted(L, (uint32_t)(key >> 32), (uint32_t)key, lane);
+                    }
+                    if (lane <= km1) {
+                        const bool none = (L.hi == kKeyInfHi && L.lo == kIdNone);
+                        const float d = none ? __builtin_inff() : ordered_to_f32(L.hi);
+                        const int64_t id = none ? (int64_t)-1 : a.row_base + (int64_t)L.lo;
+                        if (a.out_packed) {
+                            a.out_packed[((int64_t)b * a.k + lane) * 2 + 0] = id;
+                            a.out_packed[((int64_t)b * a.k + lane) * 2 + 1] = (int64_t)__float_as_uint(d);
+                        } else {
+                            a.out_d[(int64_t)b * a.k + lane] = a.sqrt_out ? __builtin_sqrtf(d) : d;
+                            a.out_i[(int64_t)b * a.k + lane] = id;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// quantisation of the fp32 TILED table [Bpad/4][Ks][64][4] for the M = 64 kernel: one workgroup per group of 4
+// queries; entries [g4][Ks][64][4 x u16] (8 bytes)
+__global__ __launch_bounds__(256) void lut_quantise64_kernel(const float *__restrict__ lut, int Ks, int qmax,
+                                                            uint16_t *__restrict__ out, float *__restrict__ qstep,
+                                                            double *__restrict__ qlo, float *__restrict__ smax) {
+    constexpr int M = 64, KPT = 4;
+    __shared__ float s_lo[KPT][M][4], s_hi[KPT][M][4];
+    __shared__ float s_step[4];
+    const int tid = threadIdx.x;
+    const int m = tid % M, kr = tid / M;
+    const int g4 = blockIdx.x;
+    const f32x4 *base = (const f32x4 *)lut + (int64_t)g4 * Ks * M;
+    f32x4 mn = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+    f32x4 mx = -mn;
+    for (int k = kr; k < Ks; k += KPT) {
+        const f32x4 v = base[(int64_t)k * M + m];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mn[i] = fminf(mn[i], v[i]);
+            mx[i] = fmaxf(mx[i], v[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s_lo[kr][m][i] = mn[i];
+        s_hi[kr][m][i] = mx[i];
+    }
+    __syncthreads();
+    {
+        const int mm = tid / 4, i = tid % 4;  // 256 threads = 64 x 4
+        float l = s_lo[0][mm][i], h = s_hi[0][mm][i];
+        for (int r = 1; r < KPT; ++r) {
+            l = fminf(l, s_lo[r][mm][i]);
+            h = fmaxf(h, s_hi[r][mm][i]);
+        }
+        __syncthreads();
+        s_lo[0][mm][i] = l;
+        s_hi[0][mm][i] = h;
+    }
+    __syncthreads();
+    if (tid < 4) {
+        float range = 0.f, sm = 0.f;
+        double Lsum = 0.0;
+        for (int mm = 0; mm < M; ++mm) {
+            const float l = s_lo[0][mm][tid], h = s_hi[0][mm][tid];
+            range = fmaxf(range, h - l);
+            sm += fmaxf(fabsf(l), fabsf(h));
+            Lsum += (double)l;
+        }
+        float step = range / (float)qmax;
+        if (!(step > 0.f)) step = 1.f;
+        s_step[tid] = step;
+        const int b = g4 * 4 + tid;
+        qstep[b] = step;
+        qlo[b] = Lsum;
+        smax[b] = sm;
+    }
+    __syncthreads();
+    float lo_r[4], st_r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lo_r[i] = s_lo[0][m][i];
+        st_r[i] = s_step[i];
+    }
+    u32x2 *o = (u32x2 *)out + (int64_t)g4 * Ks * M;
+    for (int k = kr; k < Ks; k += KPT) {
+        const f32x4 v = base[(int64_t)k * M + m];
+        uint32_t q[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t = floorf((v[i] - lo_r[i]) / st_r[i]);
+            if (!(t > 0.f)) t = 0.f;
+            if (t > (float)qmax) t = (float)qmax;
+            q[i] = (uint32_t)t;
+        }
+        o[(int64_t)k * M + m] = (u32x2){q[0] | (q[1] << 16), q[2] | (q[3] << 16)};
+    }
+}
 
 // Seed bound: a valid upper bound of the final k-th key from the first S rows, so the scan starts with a
 // filter that passes ~k/S of the rows instead of all of them (the cold-start "flood" cost 16 waves x 16
@@ -1965,10 +2324,16 @@ __global__ __launch_bounds__(256) void codes_skew_kernel(const uint8_t *__restri
     const int j = (int)(t - i * M);
     const int64_t id = ids ? ids[i] : id_base + i;
     const int r = (int)(id % M);
-    if (!inverse)
-        out[id * M + j] = in[i * M + (j + r) % M];
-    else
-        out[i * M + j] = in[id * M + ((j - r) % M + M) % M];
+    if (!inverse) {
+        uint8_t v = in[i * M + (j + r) % M];
+        if (M == 64 && j + r >= 64) v = (uint8_t)(v - 1);  // wrap-coded layout of the M = 64 kernel (see wrap64_mask)
+        out[id * M + j] = v;
+    } else {
+        const int jj = ((j - r) % M + M) % M;  // stored position of sub-space j
+        uint8_t v = in[id * M + jj];
+        if (M == 64 && jj + r >= 64) v = (uint8_t)(v + 1);
+        out[i * M + j] = v;
+    }
 }
 
 // =================================================================================================
@@ -1978,7 +2343,7 @@ struct FastCfg {
     int M, QI, NQ, NW, WPS, wg_per_cu, id;
     int mode;  // 0: exec-masked passes, 1/2: weight-fma passes, 3: FILTER kernel (fast fp32 sum + exact
                // recompute), 4: QFILTER kernel (12-bit integer tables, 8 queries per LDS entry)
-    int qt() const { return (mode == 4 ? 8 : QI) * NQ; }
+    int qt() const { return (mode == 4 ? (M == 64 ? 4 : 8) : QI) * NQ; }
 };
 
 // Kernel variants per M.  ANNLITE_SCAN_VARIANT (env, read per call) selects among the M=16
@@ -2022,7 +2387,12 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
             else if (v == 8 || v == 9) *c = {32, 4, 1, 8, 2, 1, 321, 3};
             else *c = {32, 4, 1, 12, 3, 1, 3230, 4};             // default: qfilter, 8 queries / WG
             return true;
-        case 64: *c = {64, 2, 1, 8, 2, 1, 640, 0}; return true;
+        case 64:
+            if (v >= 20 && v < 30) *c = {64, 2, 1, 8, 2, 1, 640, 0};  // two-pass kernel (PLAIN tables only: SKEWED is wrap-coded)
+            else if (v == 30) *c = {64, 4, 1, 16, 4, 1, 6430, 4};     // qfilter64, 16 waves (spills: 7.4 ms at C4 vs 5.9)
+            else if (v == 32) *c = {64, 4, 1, 8, 2, 1, 6432, 4};      // qfilter64, 8 waves (6.7 ms)
+            else *c = {64, 4, 1, 12, 3, 1, 6431, 4};                  // default: qfilter64, 4 queries / WG, 12 waves
+            return true;
         default: return false;
     }
 }
@@ -2067,6 +2437,15 @@ static int launch_qfilter(const ScanArgs &a, int grid, hipStream_t st) {
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
     return launch_status("adc_scan_qfilter_kernel");
+}
+
+template <int NW, bool SKEWED>
+static int launch_qfilter64(const ScanArgs &a, int grid, hipStream_t st) {
+    const size_t need = (size_t)(a.Ks + 1) * 512 + 256 + (size_t)4 * 512 + 128 + (size_t)NW * 512;
+    auto fn = adc_scan_qfilter64_kernel<NW, SKEWED>;
+    ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
+    return launch_status("adc_scan_qfilter64_kernel");
 }
 
 template <int M, int NQ, int NW, int WPS, bool SKEWED, bool DBUF>
@@ -2238,7 +2617,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         }
         fill_bytes = fill;
         FastCfg c1;
-        fused_fill = N > 0 && plan.fast && fast_cfg(M, Ks, code_bytes, k, &c1) && c1.mode == 4;  // lut_quantise_fused_kernel
+        fused_fill = N > 0 && plan.fast && fast_cfg(M, Ks, code_bytes, k, &c1) && c1.mode == 4 && M != 64;  // lut_quantise_fused_kernel
         if (!fused_fill) ANNLITE_HIP_TRY(hipMemsetAsync(workspace_dev, 0xff, fill, st));
     }
     if (N == 0) return ANNLITE_OK;
@@ -2296,12 +2675,15 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
     else                                                                                                             \
         hipLaunchKernelGGL((lut_quantise_fused_kernel<MM>), dim3(n_g8), dim3(256), 0, st, lut_rw, (int)Ks, qmax, q16,  \
                            qstep, qlo, smax, fillp, fillv)
-                if (M == 8) { ANNLITE_QUANT(8); } else if (M == 16) { ANNLITE_QUANT(16); } else { ANNLITE_QUANT(32); }
+                if (M == 64)
+                    hipLaunchKernelGGL(lut_quantise64_kernel, dim3((unsigned)(bpad / 4)), dim3(256), 0, st, lut_dev, (int)Ks,
+                                       qmax, q16, qstep, qlo, smax);
+                else if (M == 8) { ANNLITE_QUANT(8); } else if (M == 16) { ANNLITE_QUANT(16); } else { ANNLITE_QUANT(32); }
 #undef ANNLITE_QUANT
             }
             rc = launch_status("lut_quantise_fused_kernel");
             if (rc != ANNLITE_OK) return rc;
-            if (share_across_slices && N >= 4096) {
+            if (share_across_slices && N >= 4096 && M != 64) {  // (M = 64: the 4-query fp32 rows do not fit the LDS)
                 int64_t S = 8192;
                 if (const char *e = getenv("ANNLITE_SEED_ROWS")) S = atoll(e);
                 if (S > N) S = N;
@@ -2343,9 +2725,16 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
 #define ANNLITE_LAUNCH_M(MM, QI_, NQ_, NW_, WPS_, MODE_) \
     (sk ? launch_fast<MM, QI_, NQ_, NW_, WPS_, true, MODE_>(a, grid, st) : launch_fast<MM, QI_, NQ_, NW_, WPS_, false, MODE_>(a, grid, st))
 #define ANNLITE_LAUNCH(MM, QI_, NQ_, NW_, WPS_) ANNLITE_LAUNCH_M(MM, QI_, NQ_, NW_, WPS_, 0)
+        if (c.id == 640 && sk) {
+            set_error("the two-pass M=64 kernel reads PLAIN tables only (SKEWED M=64 tables are wrap-coded for the default kernel)");
+            return ANNLITE_ERR_UNSUPPORTED;
+        }
         switch (c.id) {
             case 830: rc = ANNLITE_LAUNCH_Q(8, 2, 16, 4); break;
             case 3230: rc = ANNLITE_LAUNCH_Q(32, 1, 12, 3); break;
+            case 6430: rc = sk ? launch_qfilter64<16, true>(a, grid, st) : launch_qfilter64<16, false>(a, grid, st); break;
+            case 6431: rc = sk ? launch_qfilter64<12, true>(a, grid, st) : launch_qfilter64<12, false>(a, grid, st); break;
+            case 6432: rc = sk ? launch_qfilter64<8, true>(a, grid, st) : launch_qfilter64<8, false>(a, grid, st); break;
             case 1630: rc = ANNLITE_LAUNCH_Q(16, 2, 12, 3); break;
             case 1631: rc = ANNLITE_LAUNCH_Q(16, 2, 16, 4); break;
             case 1632: rc = ANNLITE_LAUNCH_Q(16, 2, 8, 2); break;
@@ -2483,7 +2872,7 @@ extern "C" int annlite_pq_search_topk(int lut_kind, const float *queries_dev, in
     ANNLITE_REQUIRE(queries_dev && codebooks_dev && workspace_dev, "null device pointer");
     float *lut = (float *)((char *)workspace_dev + scan_ws);
     FastCfg c;
-    const bool fuse = N > 0 && plan.fast && fast_cfg(M, Ks, code_bytes, k, &c) && c.mode == 4 &&
+    const bool fuse = N > 0 && plan.fast && fast_cfg(M, Ks, code_bytes, k, &c) && c.mode == 4 && M != 64 &&
                       lut_kind == ANNLITE_LUT_L2 && ((D / M) % 4) == 0 && !getenv("ANNLITE_NO_FUSED_LUT");
     if (!fuse) {
         rc = annlite_lut_build(lut_kind, queries_dev, B, D, codebooks_dev, M, Ks, lut,

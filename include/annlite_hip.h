@@ -198,6 +198,9 @@ ANNLITE_API int annlite_debug_counters(uint64_t *out8);
 
 /* Convert between the PLAIN and the SKEWED code-table layout (uint8 codes).
  * forward (inverse=0): table_out[id][j] = codes_in[i][(j + id) mod M]   -- scatter rows i -> id
+ *                      (M = 64 only: minus 1 mod 256 where j + id mod 64 >= 64 -- the "wrap-coded" form the
+ *                      M = 64 scan kernel addresses without per-step base registers; SKEWED is an opaque,
+ *                      per-M storage format: always produce and undo it with this function)
  * inverse (inverse=1): codes_out[i][j]  = table_in[id][(j - id) mod M]  -- gather rows id -> i
  * id = ids_dev[i] if ids_dev != NULL else id_base + i.  This is the storage step of the index
  * plugin's add_with_ids (annlite/core/index/pq_index.py:25-27 -> flat_index.py:41-50 `_data[ids] = x`). */
