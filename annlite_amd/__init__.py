@@ -2,7 +2,7 @@
 
 Public surface (mirrors the reference's names, see DESIGN.md / INTEGRATION.md):
 
-    from annlite_amd import AnnLite, PQCodec, PQFlatGpuIndex, Metric, pq_bind
+    from annlite_amd import AnnLite, PQCodec, PQFlatGpuIndex, HnswPQGpuIndex, Metric, pq_bind
 
 The compute path is the hand-written HIP library ``annlite_amd/libannlite_hip.so`` (C ABI in
 ``include/annlite_hip.h``), loaded through ctypes; there is no CPU fallback.
@@ -24,6 +24,9 @@ def __getattr__(name):
     if name == 'PQFlatGpuIndex':
         from .core.index.pq_flat_gpu import PQFlatGpuIndex
         return PQFlatGpuIndex
+    if name == 'HnswPQGpuIndex':
+        from .core.index.hnsw_pq_gpu import HnswPQGpuIndex
+        return HnswPQGpuIndex
     if name in ('pq_bind', 'ops', 'math', 'sharded'):
         import importlib
         return importlib.import_module('.' + name, __name__)

@@ -1,0 +1,175 @@
+"""``HnswPQGpuIndex`` -- BASELINE config 5: HNSW-over-PQ candidate lists + GPU ADC / exact re-rank.
+
+Mirrors the reference's ``HnswIndex(pq_codec=...)`` (annlite/core/index/hnsw/index.py:52-191) where it
+differs from the exhaustive ``PQFlatGpuIndex``: a navigable graph proposes ``ef_search`` candidate rows per
+query instead of scanning every row.
+
+  * graph: ``libannlite_graph.so`` (``annlite_amd/csrc/hnsw_host.cpp``), host code like the reference's
+    hnswlib, same knobs -- ``max_connection`` (16), ``ef_construction`` (200), ``ef_search`` (50)
+    (hnsw/index.py:66-69) -- and the same form of edge distance, hnswlib::PQLookup over the stored code bytes
+    (include/hnswlib/space_pq.h:15-37), always with L2 tables (inner-product tables break the graph, see
+    hnsw_host.cpp);
+  * the candidates' distances and the final top-k come from the GPU: ``annlite_adc_gather`` (the a2 sum of
+    SURVEY.md section 8a, bit-equal to the flat scan's distances) + ``annlite_topk_rows``, or, with
+    ``rerank=True``, the exact distances on the stored float vectors (``annlite_exact_gather_dist``).
+
+Everything else (storage, encode, validity bitmap, dump/load of the code table, metric pre/post
+processing) is inherited from ``PQFlatGpuIndex``; ``search_exhaustive`` keeps the full scan available.
+"""
+import ctypes
+from pathlib import Path
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from ... import _graph_capi as gc
+from ... import ops
+from ...enums import Metric
+from .pq_flat_gpu import PQFlatGpuIndex
+
+
+class HnswPQGpuIndex(PQFlatGpuIndex):
+    def __init__(self, dim: int, pq_codec=None, metric: Metric = Metric.COSINE, ef_construction: int = 200,
+                 ef_search: int = 50, max_connection: int = 16, n_threads: int = 0, seed: int = 100, **kwargs):
+        super().__init__(dim, pq_codec=pq_codec, metric=metric, **kwargs)
+        self.ef_construction = int(ef_construction)  # hnsw/index.py:66-69
+        self.ef_search = int(ef_search)
+        self.max_connection = int(max_connection)
+        self.n_threads = int(n_threads)
+        self.seed = int(seed)
+        self._graph = None
+
+    # ------------------------------------------------------------------ graph handle
+    def _ensure_graph(self):
+        if self._graph is None:
+            if not self.pq_codec.is_trained:
+                raise RuntimeError('Please train the PQ before using HNSW quantization backend')  # hnsw/index.py:32-35
+            assert self.Ks <= 256, 'the graph stores uint8 codes'
+            cb = np.ascontiguousarray(self.pq_codec.codebooks, dtype=np.float32)
+            h = gc.lib().annlite_hnsw_create(cb.ctypes.data, self.M, self.Ks, self.dim // self.M,
+                                             max(int(self.capacity), 1), self.max_connection, self.ef_construction,
+                                             self.seed)
+            if not h:
+                raise RuntimeError('annlite_hnsw_create: ' + gc.lib().annlite_hnsw_last_error().decode())
+            self._graph = ctypes.c_void_p(h)
+        return self._graph
+
+    def __del__(self):
+        try:
+            if getattr(self, '_graph', None) is not None:
+                gc.lib().annlite_hnsw_free(self._graph)
+                self._graph = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ build
+    def add_with_ids(self, x, ids: List[int], **kwargs):
+        ids_np = np.ascontiguousarray(np.asarray(ids.cpu() if isinstance(ids, torch.Tensor) else ids, dtype=np.int64))
+        xq = self._pre(x)  # device, f32, normalised for cosine (hnsw/index.py:28-29)
+        if xq.shape[0] == 0:
+            return
+        super().add_with_ids(x, ids)  # code table / validity / float vectors (the parent pre-processes itself)
+        # the graph sees what the reference's add_items sees: the pre-processed vectors (+ their code bytes);
+        # PQCodec.get_dist_mat would normalise them once more for cosine (pq.py:309-310) -- do the same
+        _, xg = self.pq_codec.scan_inputs(xq)
+        codes = ops.pq_encode(xq, self.pq_codec.codebooks_dev)
+        x_np = np.ascontiguousarray(xg.cpu().numpy(), dtype=np.float32)
+        c_np = np.ascontiguousarray(codes.cpu().numpy(), dtype=np.uint8)
+        g = self._ensure_graph()
+        gc.check(gc.lib().annlite_hnsw_add(g, x_np.ctypes.data, c_np.ctypes.data, ids_np.ctypes.data, len(ids_np),
+                                           self.n_threads), 'annlite_hnsw_add')
+
+    def update_with_ids(self, x, ids: List[int], **kwargs):
+        raise RuntimeError('the HNSW graph does not support in-place updates (delete + add a new offset): '
+                           'hnsw/index.py:173-177')
+
+    def delete(self, ids: List[int]):
+        super().delete(ids)
+        if self._graph is not None:
+            for i in ids:
+                gc.lib().annlite_hnsw_mark_deleted(self._graph, int(i))  # hnsw/index.py:169-171 mark_deleted
+
+    def reset(self, capacity: Optional[int] = None):
+        super().reset(capacity=capacity)
+        if self._graph is not None:
+            gc.lib().annlite_hnsw_free(self._graph)
+            self._graph = None
+
+    # ------------------------------------------------------------------ search
+    def candidates(self, q_dev: torch.Tensor, ef: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Graph walk on the host: ``(ids i64 [B, ef], pq distance f32 [B, ef])`` on the device, -1 / +inf padded."""
+        ef = int(ef or self.ef_search)
+        _, xg = self.pq_codec.scan_inputs(q_dev)
+        x_np = np.ascontiguousarray(xg.cpu().numpy(), dtype=np.float32)
+        B = x_np.shape[0]
+        ids = np.empty((B, ef), dtype=np.int64)
+        dist = np.empty((B, ef), dtype=np.float32)
+        gc.check(gc.lib().annlite_hnsw_search(self._ensure_graph(), x_np.ctypes.data, B, ef, ids.ctypes.data,
+                                              dist.ctypes.data, self.n_threads), 'annlite_hnsw_search')
+        return ops.to_dev(ids, torch.int64), ops.to_dev(dist, torch.float32)
+
+    def search_exhaustive(self, x, limit: int = 10, **kw):
+        return super().search_batch(x, limit=limit, **kw)
+
+    def search_batch(self, x, limit: int = 10, indices=None, ef_search: Optional[int] = None, **kwargs):
+        """``(dists [B,k], ids [B,k])``; candidates from the graph (``max(ef_search, k)`` per query), distances
+        and top-k from the GPU.  ``indices`` (a filter) falls back to the exhaustive masked scan, which is what
+        the reference's pre-filter does to small candidate sets as well (container.py:107-120)."""
+        if indices is not None:
+            return super().search_batch(x, limit=limit, indices=indices)
+        is_np = not isinstance(x, torch.Tensor)
+        q = self._pre(x)
+        B, k = q.shape[0], int(limit)
+        N = self._n_rows
+        if N == 0 or B == 0 or self._graph is None:
+            d = torch.full((B, k), float('inf'), dtype=torch.float32, device=q.device)
+            i = torch.full((B, k), -1, dtype=torch.int64, device=q.device)
+        else:
+            ef = max(int(ef_search or self.ef_search), k)
+            cand, _ = self.candidates(q, ef)
+            # rows deleted after the walk started / never written are masked here as well
+            ok = (cand >= 0) & self._valid_bool[cand.clamp(min=0)]
+            cand = torch.where(ok, cand, torch.full_like(cand, -1))
+            if self.rerank and self._vectors is not None:
+                dist = ops.exact_gather_dist(int(self.metric), q, self._vectors, cand)
+            else:
+                lut = self.pq_codec.get_dist_mat(q)  # [B, M, Ks] on the device
+                dist = ops.adc_gather(lut, self._plain_table(N), cand)
+            kk = min(k, 64, ef)
+            d, pos = ops.topk_rows(dist, kk)
+            i = torch.gather(cand, 1, pos.clamp(min=0))
+            i = torch.where((pos < 0) | torch.isinf(d), torch.full_like(i, -1), i)
+            if self.metric == Metric.EUCLIDEAN:
+                d = torch.sqrt(d)  # hnsw/index.py:164-165
+            if kk < k:
+                d = torch.cat([d, torch.full((B, k - kk), float('inf'), device=d.device)], dim=1)
+                i = torch.cat([i, torch.full((B, k - kk), -1, dtype=torch.int64, device=i.device)], dim=1)
+        if is_np:
+            return d.cpu().numpy(), i.cpu().numpy()
+        return d, i
+
+    def _plain_table(self, N: int) -> torch.Tensor:
+        """Code rows in sub-space order for the gather kernel (cached; rebuilt after inserts)."""
+        key = (N, self._size)
+        if getattr(self, '_plain_cache_key', None) != key:
+            self._plain_cache = self._plain_codes(N).contiguous()
+            self._plain_cache_key = key
+        return self._plain_cache
+
+    # ------------------------------------------------------------------ persistence
+    def dump(self, index_file: Union[str, Path]):
+        super().dump(index_file)
+        if self._graph is not None:
+            gc.check(gc.lib().annlite_hnsw_save(self._graph, (str(index_file) + '.graph').encode()), 'annlite_hnsw_save')
+
+    def load(self, index_file: Union[str, Path]):
+        super().load(index_file)
+        gpath = str(index_file) + '.graph'
+        if Path(gpath).exists():
+            if self._graph is not None:
+                gc.lib().annlite_hnsw_free(self._graph)
+            h = gc.lib().annlite_hnsw_load(gpath.encode())
+            if not h:
+                raise RuntimeError('annlite_hnsw_load: ' + gc.lib().annlite_hnsw_last_error().decode())
+            self._graph = ctypes.c_void_p(h)
