@@ -164,6 +164,19 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     qps = B * args.steps / elapsed
 
+    # ---- second figure: the same steps with the host buffers the AnnLite API hands over --
+    # numpy queries in (H2D), numpy results out (D2H); never `value`
+    host_qps = None
+    if world == 1:
+        q_host = queries.cpu().numpy()
+        n_h = max(3, min(args.steps, 10))
+        index.search_batch(q_host, limit=k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_h):
+            hd, hi = index.search_batch(q_host, limit=k)  # numpy in -> numpy out (synchronous)
+        host_qps = B * n_h / (time.perf_counter() - t0)
+
     if os.environ.get('ANNLITE_DEBUG_COUNTERS') and rank == 0:
         c = _capi.debug_counters()  # of the last step (debug aid; the counters slow the kernel down)
         print('counters: slow-block entries %d, flush query-groups %d, inserting %d, publications %d, candidate rows %d' %
@@ -305,6 +318,8 @@ def main():
                 'algorithmic_bytes_per_launch': scan_bytes, 'lds_lookups_per_s': lookups_per_s,
             },
             'cpu_baseline': cpu,
+            'with_host_transfer': {'value': host_qps, 'unit': 'queries/s',
+                                   'note': 'numpy queries in, numpy results out per batch (PCIe both ways, synchronous)'},
             'setup': {'train_s': train_s, 'index_s': index_s},
         }
         print(json.dumps(rec))
