@@ -20,12 +20,14 @@
 #include "../../include/annlite_graph.h"
 
 #include <omp.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -44,6 +46,24 @@ void set_error(const char *fmt, ...) {
 }
 
 typedef std::pair<float, uint32_t> Cand;  // (distance, node)
+
+// threads worth starting: the CPUs this process may run on, capped by a cgroup CPU quota (a container that
+// reports 256 CPUs but is throttled to a few makes 256 spinning builders crawl)
+int usable_threads() {
+    int n = omp_get_max_threads();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long long period = 0;
+        if (fscanf(f, "%31s %lld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0) {
+            const long long q = atoll(quota);
+            if (q > 0) n = std::min<long long>(n, std::max<long long>(1, (q + period - 1) / period));
+        }
+        fclose(f);
+    }
+    return std::max(1, n);
+}
 
 struct SpinLock {
     std::atomic_flag f = ATOMIC_FLAG_INIT;
@@ -382,7 +402,7 @@ int annlite_hnsw_add(annlite_hnsw *g, const float *x, const uint8_t *codes, cons
         g->linkU[s].assign((size_t)lv[(size_t)i] * (g->Mc + 1), 0);
         g->link0[s * (g->M0 + 1)] = 0;
     }
-    const int nt = n_threads > 0 ? n_threads : omp_get_max_threads();
+    const int nt = n_threads > 0 ? n_threads : usable_threads();
     int64_t start = 0;
     if (g->enter < 0 && n > 0) {  // the very first point, single-threaded
         std::vector<float> lut((size_t)g->M * g->Ks);
@@ -394,7 +414,7 @@ int annlite_hnsw_add(annlite_hnsw *g, const float *x, const uint8_t *codes, cons
 #pragma omp parallel num_threads(nt)
     {
         std::vector<float> lut((size_t)g->M * g->Ks);
-        annlite_hnsw::Visited vis;
+        static thread_local annlite_hnsw::Visited vis;
 #pragma omp for schedule(dynamic, 16)
         for (int64_t i = start; i < n; ++i) {
             g->build_lut(x + (size_t)i * g->D, lut.data());
@@ -411,11 +431,13 @@ int annlite_hnsw_search(const annlite_hnsw *g, const float *queries, int64_t B, 
         set_error("bad arguments");
         return 1;
     }
-    const int nt = n_threads > 0 ? n_threads : omp_get_max_threads();
+    const int nt = n_threads > 0 ? n_threads : usable_threads();
 #pragma omp parallel num_threads(nt)
     {
         std::vector<float> lut((size_t)g->M * g->Ks);
-        annlite_hnsw::Visited vis;
+        // one visited array per THREAD for the life of the process (epoch-stamped, never cleared): allocating and
+        // zeroing cap x 4 bytes per thread per call cost 87 ms per 1024-query batch at 5M rows x 256 threads
+        static thread_local annlite_hnsw::Visited vis;
         std::vector<Cand> cands;
         std::vector<uint32_t> nb;
 #pragma omp for schedule(dynamic, 4)

@@ -79,7 +79,20 @@ def _f32c(a):
 
 
 def max_threads() -> int:
-    return int(lib().oracle_max_threads())
+    """Threads worth starting for the all-cores CPU baseline: OpenMP's default, capped by the CPU affinity
+    mask and by a cgroup CPU quota (a container may report 256 CPUs and be throttled to 16)."""
+    n = int(lib().oracle_max_threads())
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max' and int(period) > 0:
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 # ------------------------------------------------------------------------------------------------

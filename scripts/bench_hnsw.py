@@ -106,5 +106,5 @@ for _ in range(a.steps):
 walk_qps = B * a.steps / (time.perf_counter() - t)
 print(json.dumps({'config': f'HNSW-over-PQ: {N} x {D}-dim, PQ m={M} ks=256, L2, max_connection={a.max_connection}, '
                             f'ef_construction={a.ef_construction}, ef_search={a.ef_search}, batch {B}, k={k}',
-                  'build_s': build_s, 'build_rows_per_s': N / build_s, 'host_threads': os.cpu_count(),
+                  'build_s': build_s, 'build_rows_per_s': N / build_s, 'host_cpus_reported': os.cpu_count(), 'note': 'the graph library starts min(CPUs, affinity, cgroup quota) threads',
                   'graph_walk_queries_per_s': walk_qps, **res}))
