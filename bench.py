@@ -174,7 +174,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n_h):
-            hd, hi = index.search_batch(q_host, limit=k)  # numpy in -> numpy out (synchronous)
+            _host_d, _host_i = index.search_batch(q_host, limit=k)  # numpy in -> numpy out (synchronous)
         host_qps = B * n_h / (time.perf_counter() - t0)
 
     if os.environ.get('ANNLITE_DEBUG_COUNTERS') and rank == 0:

@@ -175,6 +175,7 @@ SHAPES = [
     (16, 256, 5000, 37, 10), (16, 256, 64, 1, 1), (16, 256, 63, 9, 64), (16, 256, 1, 3, 5), (16, 256, 130, 8, 10),
     (8, 256, 3000, 17, 10), (8, 200, 999, 5, 3), (32, 256, 2500, 6, 10), (64, 256, 1500, 5, 10), (64, 100, 700, 2, 7),
     (16, 256, 40000, 24, 50), (4, 256, 1000, 5, 10), (3, 17, 500, 4, 10), (12, 256, 800, 3, 10),
+    (64, 256, 70000, 9, 10), (64, 256, 8200, 4, 64), (8, 256, 50000, 33, 10), (32, 256, 30000, 17, 16),
 ]
 
 
@@ -197,11 +198,12 @@ def test_scan_topk_random_shapes(ops, oracle, M, Ks, N, B, k, layout):
     assert np.array_equal(i, ri)
 
 
-def test_scan_ties_and_valid_bits(ops, oracle):
+@pytest.mark.parametrize('M', [16, 8, 32, 64])
+def test_scan_ties_and_valid_bits(ops, oracle, M):
     """duplicate rows => exact distance ties: ids must come out ascending (the fixed tie-break);
     rows masked out by the validity bitmap (delete marks / `indices` filter) are never returned."""
     rs = np.random.RandomState(11)
-    M, Ks, N, B, k = 16, 256, 4096, 12, 20
+    Ks, N, B, k = 256, 4096, 12, 20
     base = rs.randint(0, Ks, size=(64, M)).astype(np.uint8)
     codes = base[rs.randint(0, 64, size=N)]  # every row has ~64 exact duplicates
     lut = rs.rand(B, M, Ks).astype(np.float32)
