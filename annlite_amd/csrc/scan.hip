@@ -1569,10 +1569,10 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
 
 // quantisation of the fp32 TILED table [Bpad/4][Ks][64][4] for the M = 64 kernel: one workgroup per group of 4
 // queries; entries [g4][Ks][64][4 x u16] (8 bytes)
-__global__ __launch_bounds__(256) void lut_quantise64_kernel(const float *__restrict__ lut, int Ks, int qmax,
+__global__ __launch_bounds__(1024) void lut_quantise64_kernel(const float *__restrict__ lut, int Ks, int qmax,
                                                             uint16_t *__restrict__ out, float *__restrict__ qstep,
                                                             double *__restrict__ qlo, float *__restrict__ smax) {
-    constexpr int M = 64, KPT = 4;
+    constexpr int M = 64, KPT = 16;  // 1024 threads: 16 codes per sweep
     __shared__ float s_lo[KPT][M][4], s_hi[KPT][M][4];
     __shared__ float s_step[4];
     const int tid = threadIdx.x;
@@ -1595,14 +1595,13 @@ __global__ __launch_bounds__(256) void lut_quantise64_kernel(const float *__rest
         s_hi[kr][m][i] = mx[i];
     }
     __syncthreads();
-    {
-        const int mm = tid / 4, i = tid % 4;  // 256 threads = 64 x 4
+    if (tid < M * 4) {
+        const int mm = tid / 4, i = tid % 4;
         float l = s_lo[0][mm][i], h = s_hi[0][mm][i];
         for (int r = 1; r < KPT; ++r) {
             l = fminf(l, s_lo[r][mm][i]);
             h = fmaxf(h, s_hi[r][mm][i]);
         }
-        __syncthreads();
         s_lo[0][mm][i] = l;
         s_hi[0][mm][i] = h;
     }
@@ -1660,24 +1659,33 @@ __global__ __launch_bounds__(256) void lut_quantise64_kernel(const float *__rest
 // 16*k candidates per query.  (Sorted wave lists + a 4-level merge tree: 52 of 62 us in bitonic networks.)
 // The seed rows are scanned again by the main kernel: only the bound leaves this kernel.
 constexpr int kSeedWaves = 16;
-template <int M, bool SKEWED>
+// QPB queries per workgroup: 4 (one fp32 TILED group) where their rows fit the LDS, 2 for M = 64
+template <int M, bool SKEWED, int QPB>
 __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8_t *__restrict__ codes, int64_t S,
                                                                     const uint32_t *__restrict__ valid,
                                                                     const float *__restrict__ lut, int B, int Ks, int k,
                                                                     unsigned long long *__restrict__ gkey) {
     constexpr int CW = M / 4;
+    constexpr int CH = M < 16 ? M : 16;  // look-ups in flight
+    typedef float fq __attribute__((ext_vector_type(QPB)));
+    static_assert(QPB == 4 || QPB == 2, "queries per block");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [Ks][M + 1] x 4 queries: the pad entry spreads a fixed m over the banks (slot (code*(M+1) + m) % 16 =
-    // (code + m) % 16); unpadded, all 64 lanes of a look-up hit ONE 16-byte slot-bank (16-way conflict)
-    f32x4 *tab = (f32x4 *)smem;
-    unsigned long long *cand = (unsigned long long *)(smem + (size_t)Ks * (M + 1) * 16);  // [kSeedWaves][k]
+    // [Ks][M + 1] x QPB queries: the pad entry spreads a fixed m over the banks (slot (code*(M+1) + m) % 16 =
+    // (code + m) % 16); unpadded, all 64 lanes of a look-up hit ONE slot-bank (16-way conflict)
+    fq *tab = (fq *)smem;
+    unsigned long long *cand = (unsigned long long *)(smem + (size_t)Ks * (M + 1) * sizeof(fq));  // [kSeedWaves][k]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g4 = blockIdx.x;
+    constexpr int BPG = 4 / QPB;                 // blocks per fp32 TILED group of 4 queries
+    const int g4 = blockIdx.x / BPG, h = blockIdx.x % BPG;
     {
         const f32x4 *src = (const f32x4 *)lut + (int64_t)g4 * Ks * M;
-        for (int i = tid; i < Ks * M; i += kSeedWaves * 64) tab[i + i / M] = src[i];
+        for (int i = tid; i < Ks * M; i += kSeedWaves * 64) {
+            const f32x4 e = src[i];
+            if constexpr (QPB == 4) tab[i + i / M] = e;
+            else tab[i + i / M] = h ? (fq){e.z, e.w} : (fq){e.x, e.y};
+        }
     }
     __syncthreads();
     // inverse skew rotation of this lane's rows (row % M == lane % M: the rows of a wave start at a multiple of 64)
@@ -1687,7 +1695,9 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
 #pragma unroll
     for (int i = 0; i < 8; ++i) abit_inv[i] = (((sinv >> 2) >> i) & 1) != 0;
 
-    uint32_t best[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // ordered distance keys
+    uint32_t best[QPB];  // ordered distance keys
+#pragma unroll
+    for (int q = 0; q < QPB; ++q) best[q] = 0xffffffffu;
     for (int64_t r0 = (int64_t)wave * 64; r0 < S; r0 += kSeedWaves * 64) {
         const int64_t r = r0 + lane;
         bool ok = r < S;
@@ -1698,18 +1708,27 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
 #pragma unroll
             for (int i = 0; i < CW; ++i) c[i] = p[i];
         }
-        if constexpr (SKEWED) rotate_row<CW>(c, abit_inv, bsh_inv);
-        f32x4 v[M];
+        if constexpr (SKEWED && M == 64) {
 #pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const uint32_t code = (c[m / 4] >> (8 * (m % 4))) & 0xffu;
-            v[m] = tab[code * (M + 1) + m];
+            for (int i = 0; i < CW; ++i) c[i] = bytes_add(c[i], wrap64_mask(i, lane));  // undo the wrap coding
         }
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (SKEWED) rotate_row<CW>(c, abit_inv, bsh_inv);
+        fq d;
 #pragma unroll
-        for (int m = 0; m < M; ++m) d += v[m];
+        for (int q = 0; q < QPB; ++q) d[q] = 0.f;
+        static_for<0, M / CH>([&](auto C) {
+            constexpr int m0 = decltype(C)::value * CH;
+            fq v[CH];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+            for (int i = 0; i < CH; ++i) {
+                const uint32_t code = (c[(m0 + i) / 4] >> (8 * ((m0 + i) % 4))) & 0xffu;
+                v[i] = tab[code * (M + 1) + m0 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) d += v[i];  // ascending m: the reference's order
+        });
+#pragma unroll
+        for (int q = 0; q < QPB; ++q) {
             const uint32_t key = f32_to_ordered(d[q]);
             if (ok && key < best[q]) best[q] = key;
         }
@@ -1721,11 +1740,11 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
     uint32_t *cand32 = (uint32_t *)cand;                                  // [kSeedWaves][k]
     uint32_t *wkeys = (uint32_t *)cand + kSeedWaves * 64 + wave * 64;     // this wave's 64 lane minima
 #pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < QPB; ++q) {
         uint32_t mine = best[0];
-        if (q == 1) mine = best[1];
-        if (q == 2) mine = best[2];
-        if (q == 3) mine = best[3];
+#pragma unroll
+        for (int qq = 1; qq < QPB; ++qq)
+            if (q == qq) mine = best[qq];
         mine = (mine & ~1023u) | (uint32_t)(wave << 6) | (uint32_t)lane;
         // rank among the wave's 64: all lanes read the 64 keys back with wave-uniform addresses (broadcast)
         wkeys[lane] = mine;
@@ -1743,7 +1762,7 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
             int rk = 0;
 #pragma unroll 8
             for (int j = 0; j < nc; ++j) rk += cand32[j] < me;
-            const int b = g4 * 4 + q;
+            const int b = g4 * 4 + h * QPB + q;
             // the bound admits every row at or below (me | 1023), whatever its id; +1 in the distance field
             // because the seed rows are in nobody's list: the scan must still ACCEPT the rows that set it
             if (rk == k - 1 && b < B && (me | 1023u) != 0xffffffffu)
@@ -2676,27 +2695,28 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         hipLaunchKernelGGL((lut_quantise_fused_kernel<MM>), dim3(n_g8), dim3(256), 0, st, lut_rw, (int)Ks, qmax, q16,  \
                            qstep, qlo, smax, fillp, fillv)
                 if (M == 64)
-                    hipLaunchKernelGGL(lut_quantise64_kernel, dim3((unsigned)(bpad / 4)), dim3(256), 0, st, lut_dev, (int)Ks,
+                    hipLaunchKernelGGL(lut_quantise64_kernel, dim3((unsigned)(bpad / 4)), dim3(1024), 0, st, lut_dev, (int)Ks,
                                        qmax, q16, qstep, qlo, smax);
                 else if (M == 8) { ANNLITE_QUANT(8); } else if (M == 16) { ANNLITE_QUANT(16); } else { ANNLITE_QUANT(32); }
 #undef ANNLITE_QUANT
             }
             rc = launch_status("lut_quantise_fused_kernel");
             if (rc != ANNLITE_OK) return rc;
-            if (share_across_slices && N >= 4096 && M != 64) {  // (M = 64: the 4-query fp32 rows do not fit the LDS)
+            if (share_across_slices && N >= 4096) {
                 int64_t S = 8192;
                 if (const char *e = getenv("ANNLITE_SEED_ROWS")) S = atoll(e);
                 if (S > N) S = N;
                 const bool skw = codes_layout == ANNLITE_CODES_SKEWED;
-#define ANNLITE_SEED(MM)                                                                                          \
+#define ANNLITE_SEED(MM, QPB_)                                                                                    \
     {                                                                                                             \
-        auto fn = skw ? seed_bound_kernel<MM, true> : seed_bound_kernel<MM, false>;                               \
-        const size_t lds = (size_t)Ks * (MM + 1) * 16 + (size_t)2 * kSeedWaves * 64 * 8; /* cand + lane minima */                                  \
+        auto fn = skw ? seed_bound_kernel<MM, true, QPB_> : seed_bound_kernel<MM, false, QPB_>;                   \
+        const size_t lds = (size_t)Ks * (MM + 1) * 4 * QPB_ + (size_t)2 * kSeedWaves * 64 * 8; /* cand + minima */ \
         ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(fn, dim3((unsigned)((B + 3) / 4)), dim3(kSeedWaves * 64), lds, st,                      \
+        hipLaunchKernelGGL(fn, dim3((unsigned)(((B + 3) / 4) * (4 / QPB_))), dim3(kSeedWaves * 64), lds, st,      \
                            (const uint8_t *)codes_dev, S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, gk);   \
     }
-                if (M == 8) ANNLITE_SEED(8) else if (M == 16) ANNLITE_SEED(16) else ANNLITE_SEED(32)
+                if (M == 8) ANNLITE_SEED(8, 4) else if (M == 16) ANNLITE_SEED(16, 4) else if (M == 32) ANNLITE_SEED(32, 4)
+                else ANNLITE_SEED(64, 2)
 #undef ANNLITE_SEED
                 rc = launch_status("seed_bound_kernel");
                 if (rc != ANNLITE_OK) return rc;
