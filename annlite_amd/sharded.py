@@ -72,6 +72,7 @@ class ShardedPQIndex:
         self.row_base = int(row_base)
         self.group = group
         self._merge = ops.topk_merge
+        self._xstream = None  # side stream of the exchange (all-gather + merge)
 
     def _scan(self, queries, k):
         return self.index.search_batch(queries, limit=k, row_base=self.row_base)
@@ -80,9 +81,10 @@ class ShardedPQIndex:
         return self.search_batch_async(queries, limit).result()
 
     def search_batch_async(self, queries: torch.Tensor, limit: int = 10) -> 'PendingSearch':
-        """Enqueue the local scan and start the exchange; ``.result()`` waits for it and merges.  Calling
-        ``result()`` of batch i after ``search_batch_async`` of batch i+1 lets the all-gather of batch i run on
-        RCCL's stream while the compute stream already scans batch i+1 (batches are independent)."""
+        """Enqueue the local scan and start the exchange; ``.result()`` merges.  The exchange (all-gather + merge)
+        runs on a side stream that waits for the scan through an event; the compute stream itself never waits,
+        so batch i+1's kernels follow batch i's scan back to back (a cross-stream wait on the compute stream
+        measured ~15 us of idle time per batch on one MI355X, twice per batch)."""
         gather = dist.is_available() and dist.is_initialized() and (
             dist.get_world_size(self.group) > 1 or bool(os.environ.get('ANNLITE_FORCE_GATHER')))
         packed = self.index.search_batch_packed(queries, limit, self.row_base) if gather and isinstance(
@@ -91,26 +93,40 @@ class ShardedPQIndex:
             return PendingSearch(self, value=ShardedSearcher(self._scan, self._merge, self.group).search(queries, limit))
         # ONE collective per batch: (global id, raw ADC sum) pairs, 16 B each; merged on the raw sums (the
         # single-GPU order), the metric epilogue (sqrt for EUCLIDEAN) comes last
+        from . import ops
+
+        if self._xstream is None:
+            self._xstream = torch.cuda.Stream(device=packed.device)
         G = dist.get_world_size(self.group)
         B, k, _ = packed.shape
-        gathered = torch.empty((G * B, k, 2), dtype=torch.int64, device=packed.device)
-        work = dist.all_gather_into_tensor(gathered, packed, group=self.group, async_op=True)
-        return PendingSearch(self, work=work, gathered=gathered.view(G, B, k, 2), packed=packed)
+        scanned = torch.cuda.Event()
+        scanned.record(torch.cuda.current_stream(packed.device))
+        with torch.cuda.stream(self._xstream):
+            self._xstream.wait_event(scanned)
+            packed.record_stream(self._xstream)
+            gathered = torch.empty((G * B, k, 2), dtype=torch.int64, device=packed.device)
+            work = dist.all_gather_into_tensor(gathered, packed, group=self.group, async_op=True)
+            work.wait()  # the SIDE stream waits for the collective
+            value = ops.topk_merge_packed(gathered.view(G, B, k, 2), sqrt=self.index.sqrt_epilogue)
+            done = torch.cuda.Event()
+            done.record(self._xstream)
+        return PendingSearch(self, value=value, done=done, keep=(packed, gathered))
 
 
 class PendingSearch:
     """Handle of one in-flight row-sharded batch (see ``ShardedPQIndex.search_batch_async``)."""
 
-    def __init__(self, owner, value=None, work=None, gathered=None, packed=None):
-        self._owner, self._value, self._work, self._gathered, self._packed = owner, value, work, gathered, packed
+    def __init__(self, owner, value=None, done=None, keep=None):
+        self._owner, self._value, self._done, self._keep = owner, value, done, keep
 
-    def result(self) -> Tuple[torch.Tensor, torch.Tensor]:
-        if self._value is None:
-            from . import ops
-
-            self._work.wait()  # the current stream waits for the collective; the host does not block
-            self._value = ops.topk_merge_packed(self._gathered, sqrt=self._owner.index.sqrt_epilogue)
-            self._work = self._gathered = self._packed = None
+    def result(self, wait: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+        """``(dists [B,k], ids [B,k])``.  With ``wait`` (default) the current stream is made to wait for the
+        exchange, so the tensors can be used right away; ``wait=False`` skips that (a throughput loop that only
+        reads results after a device synchronisation keeps its compute stream free of waits)."""
+        if self._done is not None and wait:
+            torch.cuda.current_stream().wait_event(self._done)
+            for t in self._value:
+                t.record_stream(torch.cuda.current_stream())
         return self._value
 
 

@@ -145,15 +145,15 @@ def main():
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    # K independent batches, software-pipelined one deep: batch i's all-gather (RCCL stream) overlaps the
-    # scan of batch i+1 (compute stream); every batch's merged result exists before the closing sync
+    # K independent batches: the exchange of batch i (all-gather + merge, side stream) overlaps the scan of
+    # batch i+1 (compute stream, never waits); every batch's merged result exists before the closing sync
     pending = None
     for _ in range(args.steps):
         nxt = sharded.search_batch_async(queries, limit=k)
         if pending is not None:
-            out = pending.result()
+            out = pending.result(wait=False)  # read only after the closing synchronisation
         pending = nxt
-    out = pending.result()
+    out = pending.result(wait=False)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
