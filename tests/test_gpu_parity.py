@@ -566,6 +566,55 @@ def test_full_size_properties_config2(ops, oracle):
     assert np.array_equal(d[sel].cpu().numpy(), rd) and np.array_equal(i[sel].cpu().numpy(), ri)
 
 
+@pytest.mark.parametrize('name,N,M,dsub,B,kind', [
+    ('config3', 10_000_000, 16, 8, 1024, 1),    # 10M x 128-d, PQ m=16, L2, batch 1024
+    ('config4', 10_000_000, 64, 12, 256, 3),    # 10M x 768-d, PQ m=64, cosine tables, batch 256
+])
+def test_full_size_properties_config3_config4(ops, oracle, name, N, M, dsub, B, kind):
+    """BASELINE configs 3 (one GPU's view: the whole 10M-row table; its 8-way sharding is the merge property
+    below) and 4 at FULL size through size-independent properties: ascending (distance, id) order, every
+    returned distance equals the gathered ADC distance of that row (adc_gather = space_pq.h PQLookup), the
+    one-call entry equals table build + scan, two row shards scanned separately and merged equal the full
+    scan (sharding linearity), no unreturned row beats the k-th distance, a few queries equal the CPU oracle."""
+    import torch
+    from annlite_amd._capi import LAYOUT_BMK, LAYOUT_TILED, scan_plan
+
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(17)
+    Ks, k, D = 256, 10, M * dsub
+    cb = torch.randn((M, Ks, dsub), generator=g, device=dev)
+    q = torch.randn((B, D), generator=g, device=dev)
+    if kind == 3:
+        q = q / q.norm(dim=1, keepdim=True)
+    # codes drawn directly (an encode of 10M x 768 floats would need 30 GB of inputs); every code equally likely
+    codes = torch.randint(0, Ks, (N, M), generator=g, device=dev, dtype=torch.uint8)
+    skewed = ops.codes_skew(codes)
+    assert torch.equal(ops.codes_skew(skewed, inverse=True), codes)  # layout round trip (wrap-coded for M = 64)
+    plan = scan_plan(N, M, Ks, 1, B, k)
+    lut_t = ops.lut_build(q, cb, kind, LAYOUT_TILED, plan.qi)
+    lut_b = ops.lut_build(q, cb, kind, LAYOUT_BMK)
+    d, i = ops.adc_scan_topk(skewed, lut_t, B, k, M, Ks, codes_layout=1)
+    d1, i1 = ops.pq_search_topk(kind, q, cb, skewed, k, M, Ks, codes_layout=1)
+    assert torch.equal(d, d1) and torch.equal(i, i1)
+    assert bool((d[:, 1:] >= d[:, :-1]).all())
+    ties = d[:, 1:] == d[:, :-1]
+    assert bool((i[:, 1:][ties] > i[:, :-1][ties]).all())
+    assert bool(((i >= 0) & (i < N)).all())
+    assert torch.equal(ops.adc_gather(lut_b, codes, i), d)
+    half = N // 2
+    parts = [ops.pq_search_topk(kind, q, cb, ops.codes_skew(codes[a:b].contiguous()), k, M, Ks, codes_layout=1,
+                                row_base=a, packed=True) for a, b in ((0, half), (half, N))]
+    md, mi = ops.topk_merge_packed(torch.stack(parts))
+    assert torch.equal(md, d) and torch.equal(mi, i)
+    for b in (0, B - 1):
+        full = ops.adc_dist(lut_b[b], codes)
+        assert int((full < d[b, -1]).sum().item()) <= k - 1
+    sel = [0, B // 2]
+    rd, ri = oracle.adc_search_c(lut_b[sel].cpu().numpy(), codes.cpu().numpy(), k, threads=oracle.max_threads())
+    assert np.array_equal(d[sel].cpu().numpy(), rd) and np.array_equal(i[sel].cpu().numpy(), ri)
+
+
 def test_bench_under_torchrun_rccl_gather_path(tmp_path):
     """The driver launches bench.py with torch.distributed.run; exercise that launch mode with one rank and
     the all-gather + merge path forced on (RCCL all_gather_into_tensor + merge_lists_kernel), small shape.
