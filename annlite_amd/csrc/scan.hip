@@ -239,6 +239,17 @@ __device__ __forceinline__ uint32_t byte_shl(uint32_t dword, uint32_t sh) {
         asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "s"(sh), "v"(dword));
     return r;
 }
+// the four bytes of a dword, each << SH, in ONE asm statement: the compiler puts a hazard s_nop behind every
+// asm statement it cannot look into -- 32 of them per step with one statement per byte
+__device__ __forceinline__ void byte_shl4(uint32_t dword, uint32_t sh, uint32_t &r0, uint32_t &r1, uint32_t &r2,
+                                          uint32_t &r3) {
+    asm("v_lshlrev_b32_sdwa %0, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_lshlrev_b32_sdwa %1, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_lshlrev_b32_sdwa %2, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_lshlrev_b32_sdwa %3, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+        : "s"(sh), "v"(dword));
+}
 constexpr int ilog2_c(int x) { return x <= 1 ? 0 : 1 + ilog2_c(x / 2); }
 
 // ---- compile-time loops -------------------------------------------------------------------------
@@ -1102,9 +1113,14 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
         uint32_t ccur[CW], cnext[CW];   // rotated code bytes of the current / next row of this lane
         const unsigned char *addr[M];
         auto make_addr = [&](const uint32_t (&cc)[CW]) {
-            static_for<0, M>([&](auto T) {
-                constexpr int t = decltype(T)::value;
-                addr[t] = mbase[t] + byte_shl<t % 4>(cc[t / 4], (uint32_t)ilog2_c(KSTRIDE));
+            static_for<0, CW>([&](auto W) {
+                constexpr int w = decltype(W)::value;
+                uint32_t o0, o1, o2, o3;
+                byte_shl4(cc[w], (uint32_t)ilog2_c(KSTRIDE), o0, o1, o2, o3);
+                addr[4 * w + 0] = mbase[4 * w + 0] + o0;
+                addr[4 * w + 1] = mbase[4 * w + 1] + o1;
+                addr[4 * w + 2] = mbase[4 * w + 2] + o2;
+                addr[4 * w + 3] = mbase[4 * w + 3] + o3;
             });
         };
         // integer sums of one entry group: 4 dwords x (2 x u16)
@@ -1426,10 +1442,14 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
             static_for<0, 4>([&](auto C) {
                 constexpr int c0 = decltype(C)::value * 16;
                 u32x2 v[16];
-                static_for<0, 16>([&](auto I) {
-                    constexpr int t = c0 + decltype(I)::value;
-                    const unsigned char *ad = lbase + byte_shl<t % 4>(ccur[t / 4], 9u);
-                    v[t - c0] = *(const u32x2 *)(ad + t * 8);
+                static_for<0, 4>([&](auto W) {
+                    constexpr int t = c0 + decltype(W)::value * 4;
+                    uint32_t o0, o1, o2, o3;
+                    byte_shl4(ccur[t / 4], 9u, o0, o1, o2, o3);
+                    v[t - c0 + 0] = *(const u32x2 *)(lbase + o0 + (t + 0) * 8);
+                    v[t - c0 + 1] = *(const u32x2 *)(lbase + o1 + (t + 1) * 8);
+                    v[t - c0 + 2] = *(const u32x2 *)(lbase + o2 + (t + 2) * 8);
+                    v[t - c0 + 3] = *(const u32x2 *)(lbase + o3 + (t + 3) * 8);
                 });
                 asm volatile("" ::: "memory");
                 static_for<0, 16>([&](auto I) { acc += v[decltype(I)::value]; });
