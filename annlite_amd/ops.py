@@ -103,15 +103,20 @@ def adc_gather(lut_bmk: torch.Tensor, codes: torch.Tensor, cand: torch.Tensor) -
 
 
 class ScanWorkspace:
-    """Re-usable device scratch for adc_scan_topk (avoids an allocation per search call)."""
+    """Re-usable device scratch for the scan (avoids an allocation per search call).  One buffer PER STREAM:
+    batches issued on different streams run concurrently (the next batch's kernels fill the CUs the previous
+    scan's tail leaves idle) and must not share scratch."""
 
     def __init__(self):
-        self.buf: Optional[torch.Tensor] = None
+        self.bufs = {}
 
     def get(self, nbytes: int, dev) -> torch.Tensor:
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != dev:
-            self.buf = torch.empty((max(nbytes, 8),), dtype=torch.uint8, device=dev)
-        return self.buf
+        key = stream_ptr()
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes or buf.device != dev:
+            buf = torch.empty((max(nbytes, 8),), dtype=torch.uint8, device=dev)
+            self.bufs[key] = buf
+        return buf
 
 
 def adc_scan_topk(codes: torch.Tensor, lut: torch.Tensor, B: int, k: int, M: int, Ks: int,

@@ -52,6 +52,7 @@ def parse():
     p.add_argument('--cpu-queries', type=int, default=4, help='queries of the bounded CPU-baseline sample (0 = skip)')
     p.add_argument('--metric', choices=['euclidean', 'cosine', 'inner_product'], default='euclidean',
                    help="BASELINE config 2/3: euclidean; config 4 (10M x 768, m=64, batch 256): cosine")
+    p.add_argument('--streams', type=int, choices=[1, 2], default=2, help='streams the timed batches alternate on')
     p.add_argument('--layout', choices=['skewed', 'plain'], default='skewed')
     p.add_argument('--no-rerank', action='store_true', help='skip the (untimed-in-value) exact re-rank leg')
     return p.parse_args()
@@ -140,16 +141,23 @@ def main():
     def step():
         return sharded.search_batch(queries, limit=k)
 
-    for _ in range(args.warmup):
-        step()
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)] if args.streams == 2 else [torch.cuda.current_stream(dev)]
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream(dev))
+    for w_i in range(max(args.warmup, len(streams))):  # (every stream warms its own scratch buffer up)
+        with torch.cuda.stream(streams[w_i % len(streams)]):
+            step()
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
     # K independent batches: the exchange of batch i (all-gather + merge, side stream) overlaps the scan of
     # batch i+1 (compute stream, never waits); every batch's merged result exists before the closing sync
+    # Consecutive batches alternate between two streams: each batch's kernels are in order on their own stream,
+    # and the next batch's table build / seed / first workgroups fill the CUs the previous scan's tail leaves idle
     pending = None
-    for _ in range(args.steps):
-        nxt = sharded.search_batch_async(queries, limit=k)
+    for s_i in range(args.steps):
+        with torch.cuda.stream(streams[s_i % len(streams)]):
+            nxt = sharded.search_batch_async(queries, limit=k)
         if pending is not None:
             out = pending.result(wait=False)  # read only after the closing synchronisation
         pending = nxt
