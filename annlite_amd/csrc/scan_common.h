@@ -1,0 +1,329 @@
+// scan_common.h -- what the scan translation units share: kernel arguments, the work-item mapping, the
+// skew / byte helpers and the launcher prototypes (gfx950 only).
+#pragma once
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+
+namespace annlite {
+
+struct ScanArgs {
+    const void *codes;       // [N][M] code bytes
+    const uint32_t *valid;   // optional bitmap
+    const float *lut;        // tiled or BMK
+    unsigned long long *partial;  // [B_pad][NS][k] keys
+    int64_t N;
+    int32_t Ks;
+    int32_t B;
+    int32_t k;
+    int32_t n_tiles;
+    int32_t n_slices;        // 1, 2, 4 or a multiple of 8
+    int32_t n_items;         // work items (see item_map)
+    int64_t slice_rows;      // multiple of 64
+    const float *smax;       // [ceil16(B)] sum_m max_k |lut[b][m][k]|  (filter kernel: rounding slack)
+    // quantised filter (qfilter kernel): 12-bit integer tables + the affine map back to distances
+    const uint16_t *q16;     // [ceil16(B)/8][Ks][M][8] u16
+    const float *qstep;      // [ceil16(B)]
+    const double *qlo;       // [ceil16(B)] sum_m min_k lut[b][m][k]
+    unsigned long long *gkey; // [ceil16(B)] best k-th key any workgroup has proven for the query (device-scope
+                             // atomic min; lets the 8+ row slices of a query tile share their progress)
+    unsigned long long *gk2; // [ceil16(B)][n_slices] j-th key of every (query, slice) list, j = ceil(k/8): the 8
+                             // concurrently scanned slices of a query hold >= k rows at or below the MAX of
+                             // their j-th keys, a bound ~k/j times tighter than any single slice's own k-th
+    int32_t jm1;             // j - 1
+    // final merge inside the scan (shared mode): the LAST workgroup of a query tile to finish merges its slices
+    unsigned int *tile_done; // [n_tiles] arrival counters, start at 0xffffffff (workspace fill); NULL = no in-kernel merge
+    float *out_d;            // [B][k]   (or NULL with out_packed)
+    int64_t *out_i;          // [B][k]
+    int64_t *out_packed;     // [B][k][2] (global id, distance bits)
+    int64_t row_base;
+    int32_t sqrt_out;        // metric epilogue of EUCLIDEAN search (hnsw/index.py:164-165): out_d = sqrt(sum); never for packed
+    int32_t flush_mask;      // a wave flushes its candidate queue every (flush_mask + 1) steps, staggered by wave
+    int32_t dbg_skip;        // debug bitmask (ANNLITE_DEBUG_SKIP): 1 no gathers, 2 no insert/publish, 4 no event at all
+    unsigned long long *dbg; // optional event counters (ANNLITE_DEBUG_COUNTERS=1): [0] slow-block entries,
+                             // [1] (wave,query) events, [2] events with an insertion, [3] bound publications
+};
+
+// work item -> (query tile, row slice).  item % 8 == blockIdx % 8 == the XCD the block lands on (speed
+// only): with >= 8 slices an XCD owns the slices congruent to it and consecutive items of one XCD walk the
+// tiles of the same slice (its L2 keeps the slice's rows); with fewer slices 8 / n_slices XCDs share one.
+__device__ __forceinline__ bool item_map(const ScanArgs &a, int item, int &tile, int &slice) {
+    const int xcd = item & 7, j = item >> 3;
+    if (a.n_slices >= 8) {
+        tile = j % a.n_tiles;
+        slice = (j / a.n_tiles) * 8 + xcd;
+        return true;
+    }
+    slice = xcd % a.n_slices;
+    tile = j * (8 / a.n_slices) + xcd / a.n_slices;
+    return tile < a.n_tiles;
+}
+
+// ---- compile-time exec masks for the ordered accumulation ---------------------------------------
+template <int M>
+constexpr unsigned long long pass_mask(int t, int pass) {
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) {
+        const int s = l % M;
+        const bool p1 = (s == 0) || (s >= M - t);
+        if (pass == 0 ? p1 : !p1) m |= 1ull << l;
+    }
+    return m;
+}
+
+template <unsigned long long MASK>
+__device__ __forceinline__ void masked_pk_add2(f32x2 &a0, f32x2 &a1, const f32x2 x0, const f32x2 x1) {
+    if constexpr (MASK == 0ull) {
+        return;
+    } else if constexpr (MASK == ~0ull) {
+        a0 += x0;
+        a1 += x1;
+    } else {
+        unsigned long long sv;
+        asm("s_mov_b64 %[sv], exec\n\t"
+            "s_mov_b32 exec_lo, %[lo]\n\t"
+            "s_mov_b32 exec_hi, %[hi]\n\t"
+            "v_pk_add_f32 %[a0], %[a0], %[x0]\n\t"
+            "v_pk_add_f32 %[a1], %[a1], %[x1]\n\t"
+            "s_mov_b64 exec, %[sv]"
+            : [a0] "+v"(a0), [a1] "+v"(a1), [sv] "=&s"(sv)
+            : [x0] "v"(x0), [x1] "v"(x1), [lo] "i"((int)(uint32_t)(MASK & 0xffffffffull)),
+              [hi] "i"((int)(uint32_t)(MASK >> 32)));
+    }
+}
+
+template <unsigned long long MASK>
+__device__ __forceinline__ void masked_pk_add1(f32x2 &a0, const f32x2 x0) {
+    if constexpr (MASK == 0ull) {
+        return;
+    } else if constexpr (MASK == ~0ull) {
+        a0 += x0;
+    } else {
+        unsigned long long sv;
+        asm("s_mov_b64 %[sv], exec\n\t"
+            "s_mov_b32 exec_lo, %[lo]\n\t"
+            "s_mov_b32 exec_hi, %[hi]\n\t"
+            "v_pk_add_f32 %[a0], %[a0], %[x0]\n\t"
+            "s_mov_b64 exec, %[sv]"
+            : [a0] "+v"(a0), [sv] "=&s"(sv)
+            : [x0] "v"(x0), [lo] "i"((int)(uint32_t)(MASK & 0xffffffffull)),
+              [hi] "i"((int)(uint32_t)(MASK >> 32)));
+    }
+}
+
+
+// ---- ordered accumulation, 8 steps per asm statement --------------------------------------------
+// One statement = 8 x { set exec to the compile-time lane mask of step t ; v_pk_add_f32 ... } and
+// ONE restore of exec to all-ones (the main loop runs with full waves and uniform control flow).
+// v1 of this kernel saved/restored exec around every step (4 SALU per 2 VALU): rocprof showed
+// 343 SALU + 255 VALU per wave-step and the LDS pipe only 21 % busy (profiles/r01_*).
+#define ANNLITE_MASK_LO(M, T, P) ((int)(uint32_t)(pass_mask<M>((T), (P)) & 0xffffffffull))
+#define ANNLITE_MASK_HI(M, T, P) ((int)(uint32_t)(pass_mask<M>((T), (P)) >> 32))
+#define ANNLITE_LOHALF(v) __builtin_shufflevector((v), (v), 0, 1)
+#define ANNLITE_HIHALF(v) __builtin_shufflevector((v), (v), 2, 3)
+
+#define ANNLITE_STEP_Q4(i)                                       \
+    "s_mov_b32 exec_lo, %[m" #i "]\n\t"                          \
+    "s_mov_b32 exec_hi, %[m" #i "]\n\t"                          \
+    "v_pk_add_f32 %[a0], %[a0], %[x" #i "]\n\t"                  \
+    "v_pk_add_f32 %[a1], %[a1], %[y" #i "]\n\t"
+
+template <int M, int T0, int PASS>
+__device__ __forceinline__ void pass8_q4(f32x2 &a0, f32x2 &a1, const f32x4 (&v)[M]) {
+    static_assert(M <= 32 && T0 + 8 <= M, "lo == hi masks need a lane period <= 32");
+    asm(ANNLITE_STEP_Q4(0) ANNLITE_STEP_Q4(1) ANNLITE_STEP_Q4(2) ANNLITE_STEP_Q4(3)
+        ANNLITE_STEP_Q4(4) ANNLITE_STEP_Q4(5) ANNLITE_STEP_Q4(6) ANNLITE_STEP_Q4(7)
+        "s_mov_b64 exec, -1"
+        : [a0] "+v"(a0), [a1] "+v"(a1)
+        : [x0] "v"(ANNLITE_LOHALF(v[T0 + 0])), [y0] "v"(ANNLITE_HIHALF(v[T0 + 0])),
+          [x1] "v"(ANNLITE_LOHALF(v[T0 + 1])), [y1] "v"(ANNLITE_HIHALF(v[T0 + 1])),
+          [x2] "v"(ANNLITE_LOHALF(v[T0 + 2])), [y2] "v"(ANNLITE_HIHALF(v[T0 + 2])),
+          [x3] "v"(ANNLITE_LOHALF(v[T0 + 3])), [y3] "v"(ANNLITE_HIHALF(v[T0 + 3])),
+          [x4] "v"(ANNLITE_LOHALF(v[T0 + 4])), [y4] "v"(ANNLITE_HIHALF(v[T0 + 4])),
+          [x5] "v"(ANNLITE_LOHALF(v[T0 + 5])), [y5] "v"(ANNLITE_HIHALF(v[T0 + 5])),
+          [x6] "v"(ANNLITE_LOHALF(v[T0 + 6])), [y6] "v"(ANNLITE_HIHALF(v[T0 + 6])),
+          [x7] "v"(ANNLITE_LOHALF(v[T0 + 7])), [y7] "v"(ANNLITE_HIHALF(v[T0 + 7])),
+          [m0] "i"(ANNLITE_MASK_LO(M, T0 + 0, PASS)), [m1] "i"(ANNLITE_MASK_LO(M, T0 + 1, PASS)),
+          [m2] "i"(ANNLITE_MASK_LO(M, T0 + 2, PASS)), [m3] "i"(ANNLITE_MASK_LO(M, T0 + 3, PASS)),
+          [m4] "i"(ANNLITE_MASK_LO(M, T0 + 4, PASS)), [m5] "i"(ANNLITE_MASK_LO(M, T0 + 5, PASS)),
+          [m6] "i"(ANNLITE_MASK_LO(M, T0 + 6, PASS)), [m7] "i"(ANNLITE_MASK_LO(M, T0 + 7, PASS)));
+}
+
+#define ANNLITE_STEP_Q2(i)                                       \
+    "s_mov_b32 exec_lo, %[l" #i "]\n\t"                          \
+    "s_mov_b32 exec_hi, %[h" #i "]\n\t"                          \
+    "v_pk_add_f32 %[a0], %[a0], %[x" #i "]\n\t"
+
+template <int M, int T0, int PASS>
+__device__ __forceinline__ void pass8_q2(f32x2 &a0, const f32x2 (&v)[M]) {
+    static_assert(T0 + 8 <= M, "block out of range");
+    asm(ANNLITE_STEP_Q2(0) ANNLITE_STEP_Q2(1) ANNLITE_STEP_Q2(2) ANNLITE_STEP_Q2(3)
+        ANNLITE_STEP_Q2(4) ANNLITE_STEP_Q2(5) ANNLITE_STEP_Q2(6) ANNLITE_STEP_Q2(7)
+        "s_mov_b64 exec, -1"
+        : [a0] "+v"(a0)
+        : [x0] "v"(v[T0 + 0]), [x1] "v"(v[T0 + 1]), [x2] "v"(v[T0 + 2]), [x3] "v"(v[T0 + 3]),
+          [x4] "v"(v[T0 + 4]), [x5] "v"(v[T0 + 5]), [x6] "v"(v[T0 + 6]), [x7] "v"(v[T0 + 7]),
+          [l0] "i"(ANNLITE_MASK_LO(M, T0 + 0, PASS)), [h0] "i"(ANNLITE_MASK_HI(M, T0 + 0, PASS)),
+          [l1] "i"(ANNLITE_MASK_LO(M, T0 + 1, PASS)), [h1] "i"(ANNLITE_MASK_HI(M, T0 + 1, PASS)),
+          [l2] "i"(ANNLITE_MASK_LO(M, T0 + 2, PASS)), [h2] "i"(ANNLITE_MASK_HI(M, T0 + 2, PASS)),
+          [l3] "i"(ANNLITE_MASK_LO(M, T0 + 3, PASS)), [h3] "i"(ANNLITE_MASK_HI(M, T0 + 3, PASS)),
+          [l4] "i"(ANNLITE_MASK_LO(M, T0 + 4, PASS)), [h4] "i"(ANNLITE_MASK_HI(M, T0 + 4, PASS)),
+          [l5] "i"(ANNLITE_MASK_LO(M, T0 + 5, PASS)), [h5] "i"(ANNLITE_MASK_HI(M, T0 + 5, PASS)),
+          [l6] "i"(ANNLITE_MASK_LO(M, T0 + 6, PASS)), [h6] "i"(ANNLITE_MASK_HI(M, T0 + 6, PASS)),
+          [l7] "i"(ANNLITE_MASK_LO(M, T0 + 7, PASS)), [h7] "i"(ANNLITE_MASK_HI(M, T0 + 7, PASS)));
+}
+
+
+// ---- ordered accumulation without touching EXEC: per-lane 0/1 weights -----------------------------
+// fma(v, 1.0f, acc) == acc + v (one rounding, identical to v_add_f32) and fma(v, 0.0f, acc) == acc for
+// finite v, so "lane masked out" becomes "weight 0".  w[t] = (w1, w2) per lane: w1 = 1 if step t
+// belongs to pass 1 for this lane (t >= t0) else 0, w2 = 1 - w1.  op_sel/op_sel_hi broadcast w1
+// (pass 1) or w2 (pass 2) to both halves of the packed op.  No SALU at all: the exec-mask version
+// was bound by the CU's single scalar unit (~180 SALU per 8192 look-ups, profiles/r01 notes).
+__device__ __forceinline__ void wfma_p1(f32x2 &acc, const f32x2 v, const f32x2 w) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(v), "v"(w));
+}
+__device__ __forceinline__ void wfma_p2(f32x2 &acc, const f32x2 v, const f32x2 w) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(v), "v"(w));
+}
+// MODE 2: the same with scalar (non-packed) v_fma_f32 -- A/B against the packed form
+__device__ __forceinline__ void sfma(f32x2 &acc, const f32x2 v, const float w) {
+    float ax = acc.x, ay = acc.y;
+    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(ax) : "v"(v.x), "v"(w));
+    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(ay) : "v"(v.y), "v"(w));
+    acc.x = ax;
+    acc.y = ay;
+}
+
+// (code byte B of a dword) << SH in ONE VOP2-SDWA op (v_bfe_u32 + v_lshl_add_u32 are two 4.5-cycle VOP3 ops,
+// scripts/valu_ubench.hip)
+template <int BYTE>
+__device__ __forceinline__ uint32_t byte_shl(uint32_t dword, uint32_t sh) {
+    uint32_t r;
+    if constexpr (BYTE == 0)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "s"(sh), "v"(dword));
+    else if constexpr (BYTE == 1)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "s"(sh), "v"(dword));
+    else if constexpr (BYTE == 2)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "s"(sh), "v"(dword));
+    else
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "s"(sh), "v"(dword));
+    return r;
+}
+// the four bytes of a dword, each << SH, in ONE asm statement: the compiler puts a hazard s_nop behind every
+// asm statement it cannot look into -- 32 of them per step with one statement per byte
+__device__ __forceinline__ void byte_shl4(uint32_t dword, uint32_t sh, uint32_t &r0, uint32_t &r1, uint32_t &r2,
+                                          uint32_t &r3) {
+    asm("v_lshlrev_b32_sdwa %0, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_lshlrev_b32_sdwa %1, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_lshlrev_b32_sdwa %2, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_lshlrev_b32_sdwa %3, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+        : "s"(sh), "v"(dword));
+}
+constexpr int ilog2_c(int x) { return x <= 1 ? 0 : 1 + ilog2_c(x / 2); }
+
+// ---- compile-time loops -------------------------------------------------------------------------
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// rotate the CW dwords of a code row left by `s` BYTES (s = 4*a + b, lane-varying but constant over
+// the kernel): afterwards byte t of the row is the code of sub-space (s + t) mod M.
+template <int CW>
+__device__ __forceinline__ void rotate_row(uint32_t (&c)[CW], const bool (&abit)[8], uint32_t bsh) {
+    // dword rotation by a, one conditional stage per bit of a
+    int bit = 0;
+    static_for<0, (CW > 1 ? (CW > 2 ? (CW > 4 ? (CW > 8 ? 4 : 3) : 2) : 1) : 0)>([&](auto ST) {
+        constexpr int st = decltype(ST)::value;
+        constexpr int sh = 1 << st;
+        uint32_t n[CW];
+#pragma unroll
+        for (int i = 0; i < CW; ++i) n[i] = abit[st] ? c[(i + sh) % CW] : c[i];
+#pragma unroll
+        for (int i = 0; i < CW; ++i) c[i] = n[i];
+    });
+    (void)bit;
+    // byte rotation by b across the dword ring
+    uint32_t n[CW];
+#pragma unroll
+    for (int i = 0; i < CW; ++i) n[i] = __builtin_amdgcn_alignbyte(c[(i + 1) % CW], c[i], bsh);
+#pragma unroll
+    for (int i = 0; i < CW; ++i) c[i] = n[i];
+}
+
+template <int QI>
+struct LutVec;
+template <>
+struct LutVec<4> {
+    typedef f32x4 type;
+};
+template <>
+struct LutVec<2> {
+    typedef f32x2 type;
+};
+
+// integer filter bound (0x8000 | qthr) implied by a k-th key (see the kernel header for the derivation)
+template <int M>
+__device__ __forceinline__ unsigned short qbound_from_key(unsigned long long key, float smax_b, float qstep_b,
+                                                          double qlo_b) {
+    const uint32_t hi = (uint32_t)(key >> 32);
+    if (hi == kKeyInfHi) return 0xffff;
+    const double thr = (double)ordered_to_f32(hi);
+    const double slack = (double)smax_b * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
+    double qd = (thr + slack - qlo_b) / (double)qstep_b;
+    qd = __builtin_floor(qd) + 1.0;  // qthr
+    if (!(qd > 0.0)) qd = 0.0;
+    if (!(qd < 32767.0)) qd = 32767.0;
+    return (unsigned short)(0x8000u | (uint32_t)qd);
+}
+
+
+// ---- M = 64: the "wrap-coded" SKEWED layout ------------------------------------------------------
+// With 64 sub-spaces a lane cannot afford one LDS base pointer per step (64 VGPRs).  Lane l (row n,
+// n % 64 == l) reads sub-space u = l + t at step t; the address is (code << 9) + l*8 + t*8 with t*8 as the
+// instruction's immediate -- correct while u < 64.  For u >= 64 the true entry is (code, u - 64): 512
+// bytes lower, i.e. the SAME offset inside the PREVIOUS table row.  So the stored byte of a wrapped
+// position is code - 1 (mod 256), and LDS carries one extra row 256 = copy of row 0 for code 0 - 1 = 255.
+// stored byte j of row n:  code[(j + n) % 64] - [(j + n % 64) >= 64]   (mod 256)
+// 0x01 in every byte of dword w (positions 4w..4w+3) whose position j satisfies j + r >= 64
+__device__ __forceinline__ uint32_t wrap64_mask(int w, int r) {
+    int nb = 4 * w + 4 - (64 - r);  // number of (upper) bytes of the dword that wrap
+    nb = nb < 0 ? 0 : (nb > 4 ? 4 : nb);
+    return nb == 0 ? 0u : (0x01010101u << (8 * (4 - nb)));
+}
+// per-byte x - y / x + y (mod 256) for y in {0, 1} per byte, no borrow/carry across bytes
+__device__ __forceinline__ uint32_t bytes_sub(uint32_t x, uint32_t y) {
+    return ((x | 0x80808080u) - y) ^ ((x ^ ~y) & 0x80808080u);
+}
+__device__ __forceinline__ uint32_t bytes_add(uint32_t x, uint32_t y) {
+    return ((x & 0x7f7f7f7fu) + y) ^ ((x ^ y) & 0x80808080u);
+}
+
+
+// ---- launchers of the scan kernels, one translation unit per kernel family -----------------------
+// (scan_qfilter.hip: the default quantised-filter kernels; scan_legacy.hip: the exact two-pass and the fp32
+// filter kernels kept as selectable variants; scan_prep.hip: table quantisation / seed bound / Smax)
+struct LutBuild {  // annlite_pq_search_topk: the L2 tables are built by the quantisation launch itself
+    const float *queries;
+    const float *codebooks;
+    int64_t D;
+};
+int launch_qfilter_scan(int id, bool skewed, const ScanArgs &a, int grid, hipStream_t st);
+int launch_legacy_scan(int id, bool skewed, const ScanArgs &a, int grid, hipStream_t st);
+int launch_lut_quantise(int64_t M, int64_t Ks, int64_t B, int64_t bpad, const float *lut_dev, const LutBuild *build,
+                        uint16_t *q16, float *qstep, double *qlo, float *smax, void *fill, size_t fill_bytes,
+                        hipStream_t st);
+int launch_seed_bound(int64_t M, bool skewed, const void *codes_dev, int64_t S, const uint32_t *valid_bits_dev,
+                      const float *lut_dev, int64_t B, int64_t Ks, int64_t k, unsigned long long *gkey, hipStream_t st);
+int launch_lut_smax(const float *lut_dev, int n_groups, int64_t M, int64_t Ks, int QI, float *smax, hipStream_t st);
+
+}  // namespace annlite

@@ -1,0 +1,600 @@
+// scan_prep.hip -- what runs before the quantised-filter scan of a batch: quantisation of the fp32 tables
+// (optionally building them in the same launch), the seed bound, and Smax for the fp32 filter variant.
+#include "scan_common.h"
+
+namespace annlite {
+
+// quantisation of the fp32 TILED table [Bpad/4][Ks][64][4] for the M = 64 kernel: one workgroup per group of 4
+// queries; entries [g4][Ks][64][4 x u16] (8 bytes)
+__global__ __launch_bounds__(1024) void lut_quantise64_kernel(const float *__restrict__ lut, int Ks, int qmax,
+                                                            uint16_t *__restrict__ out, float *__restrict__ qstep,
+                                                            double *__restrict__ qlo, float *__restrict__ smax) {
+    constexpr int M = 64, KPT = 16;  // 1024 threads: 16 codes per sweep
+    __shared__ float s_lo[KPT][M][4], s_hi[KPT][M][4];
+    __shared__ float s_step[4];
+    const int tid = threadIdx.x;
+    const int m = tid % M, kr = tid / M;
+    const int g4 = blockIdx.x;
+    const f32x4 *base = (const f32x4 *)lut + (int64_t)g4 * Ks * M;
+    f32x4 mn = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+    f32x4 mx = -mn;
+    for (int k = kr; k < Ks; k += KPT) {
+        const f32x4 v = base[(int64_t)k * M + m];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mn[i] = fminf(mn[i], v[i]);
+            mx[i] = fmaxf(mx[i], v[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s_lo[kr][m][i] = mn[i];
+        s_hi[kr][m][i] = mx[i];
+    }
+    __syncthreads();
+    if (tid < M * 4) {
+        const int mm = tid / 4, i = tid % 4;
+        float l = s_lo[0][mm][i], h = s_hi[0][mm][i];
+        for (int r = 1; r < KPT; ++r) {
+            l = fminf(l, s_lo[r][mm][i]);
+            h = fmaxf(h, s_hi[r][mm][i]);
+        }
+        s_lo[0][mm][i] = l;
+        s_hi[0][mm][i] = h;
+    }
+    __syncthreads();
+    if (tid < 4) {
+        float range = 0.f, sm = 0.f;
+        double Lsum = 0.0;
+        for (int mm = 0; mm < M; ++mm) {
+            const float l = s_lo[0][mm][tid], h = s_hi[0][mm][tid];
+            range = fmaxf(range, h - l);
+            sm += fmaxf(fabsf(l), fabsf(h));
+            Lsum += (double)l;
+        }
+        float step = range / (float)qmax;
+        if (!(step > 0.f)) step = 1.f;
+        s_step[tid] = step;
+        const int b = g4 * 4 + tid;
+        qstep[b] = step;
+        qlo[b] = Lsum;
+        smax[b] = sm;
+    }
+    __syncthreads();
+    float lo_r[4], st_r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lo_r[i] = s_lo[0][m][i];
+        st_r[i] = s_step[i];
+    }
+    u32x2 *o = (u32x2 *)out + (int64_t)g4 * Ks * M;
+    for (int k = kr; k < Ks; k += KPT) {
+        const f32x4 v = base[(int64_t)k * M + m];
+        uint32_t q[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t = floorf((v[i] - lo_r[i]) / st_r[i]);
+            if (!(t > 0.f)) t = 0.f;
+            if (t > (float)qmax) t = (float)qmax;
+            q[i] = (uint32_t)t;
+        }
+        o[(int64_t)k * M + m] = (u32x2){q[0] | (q[1] << 16), q[2] | (q[3] << 16)};
+    }
+}
+
+// Seed bound: a valid upper bound of the final k-th key from the first S rows, so the scan starts with a
+// filter that passes ~k/S of the rows instead of all of them (the cold-start "flood" cost 16 waves x 16
+// queries x 64 uncoalesced gathers per work item).
+// One 16-wave workgroup per group of 4 queries: their fp32 TILED rows [Ks][M][4] (64 KB at M=16) are
+// staged in LDS, so ONE ds_read_b128 per (row, m) feeds the four exact ascending-m sums (gathering the
+// same entries from L2 cost a 64-byte request per 4 useful bytes: 150 us for 4096 rows x 1024 queries).
+// Selection without sorting networks: every lane keeps the MIN distance of the rows it saw; the 1024
+// (wave, lane) groups are disjoint, so the k-th smallest of their minima has >= k distinct rows at or
+// below it -- a valid bound, and equal to the exact k-th distance of the S rows unless two of the k best
+// rows fell into one lane (3 % at S=4096, k=10; then it is the (k+1)-th).  The k-th smallest is found by
+// rank counting over LDS broadcasts (each lane counts the keys below its own): 64 keys per wave, then
+// 16*k candidates per query.  (Sorted wave lists + a 4-level merge tree: 52 of 62 us in bitonic networks.)
+// The seed rows are scanned again by the main kernel: only the bound leaves this kernel.
+constexpr int kSeedWaves = 16;
+// QPB queries per workgroup: 4 (one fp32 TILED group) where their rows fit the LDS, 2 for M = 64
+template <int M, bool SKEWED, int QPB>
+__global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8_t *__restrict__ codes, int64_t S,
+                                                                    const uint32_t *__restrict__ valid,
+                                                                    const float *__restrict__ lut, int B, int Ks, int k,
+                                                                    unsigned long long *__restrict__ gkey) {
+    constexpr int CW = M / 4;
+    constexpr int CH = M < 16 ? M : 16;  // look-ups in flight
+    typedef float fq __attribute__((ext_vector_type(QPB)));
+    static_assert(QPB == 4 || QPB == 2, "queries per block");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [Ks][M + 1] x QPB queries: the pad entry spreads a fixed m over the banks (slot (code*(M+1) + m) % 16 =
+    // (code + m) % 16); unpadded, all 64 lanes of a look-up hit ONE slot-bank (16-way conflict)
+    fq *tab = (fq *)smem;
+    unsigned long long *cand = (unsigned long long *)(smem + (size_t)Ks * (M + 1) * sizeof(fq));  // [kSeedWaves][k]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int BPG = 4 / QPB;                 // blocks per fp32 TILED group of 4 queries
+    const int g4 = blockIdx.x / BPG, h = blockIdx.x % BPG;
+    {
+        const f32x4 *src = (const f32x4 *)lut + (int64_t)g4 * Ks * M;
+        for (int i = tid; i < Ks * M; i += kSeedWaves * 64) {
+            const f32x4 e = src[i];
+            if constexpr (QPB == 4) tab[i + i / M] = e;
+            else tab[i + i / M] = h ? (fq){e.z, e.w} : (fq){e.x, e.y};
+        }
+    }
+    __syncthreads();
+    // inverse skew rotation of this lane's rows (row % M == lane % M: the rows of a wave start at a multiple of 64)
+    const int sinv = (M - lane % M) % M;
+    const uint32_t bsh_inv = (uint32_t)(sinv & 3);
+    bool abit_inv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) abit_inv[i] = (((sinv >> 2) >> i) & 1) != 0;
+
+    uint32_t best[QPB];  // ordered distance keys
+#pragma unroll
+    for (int q = 0; q < QPB; ++q) best[q] = 0xffffffffu;
+    for (int64_t r0 = (int64_t)wave * 64; r0 < S; r0 += kSeedWaves * 64) {
+        const int64_t r = r0 + lane;
+        bool ok = r < S;
+        if (ok && valid) ok = (valid[r >> 5] >> (r & 31)) & 1u;
+        uint32_t c[CW];
+        {
+            const uint32_t *p = (const uint32_t *)(codes + (r < S ? r : S - 1) * M);
+#pragma unroll
+            for (int i = 0; i < CW; ++i) c[i] = p[i];
+        }
+        if constexpr (SKEWED && M == 64) {
+#pragma unroll
+            for (int i = 0; i < CW; ++i) c[i] = bytes_add(c[i], wrap64_mask(i, lane));  // undo the wrap coding
+        }
+        if constexpr (SKEWED) rotate_row<CW>(c, abit_inv, bsh_inv);
+        fq d;
+#pragma unroll
+        for (int q = 0; q < QPB; ++q) d[q] = 0.f;
+        static_for<0, M / CH>([&](auto C) {
+            constexpr int m0 = decltype(C)::value * CH;
+            fq v[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const uint32_t code = (c[(m0 + i) / 4] >> (8 * ((m0 + i) % 4))) & 0xffu;
+                v[i] = tab[code * (M + 1) + m0 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) d += v[i];  // ascending m: the reference's order
+        });
+#pragma unroll
+        for (int q = 0; q < QPB; ++q) {
+            const uint32_t key = f32_to_ordered(d[q]);
+            if (ok && key < best[q]) best[q] = key;
+        }
+    }
+    // Selection keys: the low 10 bits of the ordered distance are replaced by (wave, lane), which makes the
+    // 1024 keys of a query unique (rank = number of smaller keys, no tie handling) and costs at most 1023
+    // ulps of tightness: the k smallest keys T_i bound k distinct rows by (T_i | 1023).
+    const int nc = kSeedWaves * k;  // candidates per query
+    uint32_t *cand32 = (uint32_t *)cand;                                  // [kSeedWaves][k]
+    uint32_t *wkeys = (uint32_t *)cand + kSeedWaves * 64 + wave * 64;     // this wave's 64 lane minima
+#pragma unroll 1
+    for (int q = 0; q < QPB; ++q) {
+        uint32_t mine = best[0];
+#pragma unroll
+        for (int qq = 1; qq < QPB; ++qq)
+            if (q == qq) mine = best[qq];
+        mine = (mine & ~1023u) | (uint32_t)(wave << 6) | (uint32_t)lane;
+        // rank among the wave's 64: all lanes read the 64 keys back with wave-uniform addresses (broadcast)
+        wkeys[lane] = mine;
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < 64; j += 4) {
+            const u32x4 o = *(const u32x4 *)(wkeys + j);
+            rank += (o.x < mine) + (o.y < mine) + (o.z < mine) + (o.w < mine);
+        }
+        if (rank < k) cand32[wave * k + rank] = mine;
+        __syncthreads();
+        // the k-th smallest of the 16*k candidates, same way: thread t ranks candidate t
+        for (int t = tid; t < nc; t += kSeedWaves * 64) {
+            const uint32_t me = cand32[t];
+            int rk = 0;
+#pragma unroll 8
+            for (int j = 0; j < nc; ++j) rk += cand32[j] < me;
+            const int b = g4 * 4 + h * QPB + q;
+            // the bound admits every row at or below (me | 1023), whatever its id; +1 in the distance field
+            // because the seed rows are in nobody's list: the scan must still ACCEPT the rows that set it
+            if (rk == k - 1 && b < B && (me | 1023u) != 0xffffffffu)
+                gkey[b] = ((unsigned long long)(me | 1023u) + 1ull) << 32;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- quantisation of the fp32 TILED table [Bpad/4][Ks][M][4] -------------------------------------
+// pass 1: lo/hi per (query, sub-space): one wave per (group of 4 queries, m)
+__global__ __launch_bounds__(256) void lut_minmax_kernel(const float *__restrict__ lut, int n_g4, int M, int Ks,
+                                                        float *__restrict__ lo, float *__restrict__ hi) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_g4 * M) return;
+    const int g = w / M, m = w - g * M;
+    const f32x4 *base = (const f32x4 *)lut + (int64_t)g * Ks * M + m;
+    f32x4 mn = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+    f32x4 mx = -mn;
+    for (int k = lane; k < Ks; k += 64) {
+        const f32x4 v = base[(int64_t)k * M];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mn[i] = fminf(mn[i], v[i]);
+            mx[i] = fmaxf(mx[i], v[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[i] = fminf(mn[i], __shfl_xor(mn[i], o));
+            mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], o));
+        }
+    }
+    if (lane < 4) {
+        lo[(int64_t)(g * 4 + lane) * M + m] = mn[lane];
+        hi[(int64_t)(g * 4 + lane) * M + m] = mx[lane];
+    }
+}
+// pass 2: per query step / L / Smax
+__global__ __launch_bounds__(256) void lut_qparams_kernel(const float *__restrict__ lo, const float *__restrict__ hi,
+                                                         int Bpad, int M, int qmax, float *__restrict__ qstep,
+                                                         double *__restrict__ qlo, float *__restrict__ smax) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= Bpad) return;
+    float range = 0.f, sm = 0.f;
+    double L = 0.0;
+    for (int m = 0; m < M; ++m) {
+        const float l = lo[(int64_t)b * M + m], h = hi[(int64_t)b * M + m];
+        range = fmaxf(range, h - l);
+        sm += fmaxf(fabsf(l), fabsf(h));
+        L += (double)l;
+    }
+    float step = range / (float)qmax;
+    if (!(step > 0.f)) step = 1.f;
+    qstep[b] = step;
+    qlo[b] = L;
+    smax[b] = sm;
+}
+// pass 3: quantise; one thread per (group of 8 queries, k, m) -> one 16-byte store
+__global__ __launch_bounds__(256) void lut_quant_kernel(const float *__restrict__ lut, int n_g8, int M, int Ks,
+                                                       const float *__restrict__ lo, const float *__restrict__ qstep,
+                                                       int qmax, uint16_t *__restrict__ out) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (int64_t)n_g8 * Ks * M) return;
+    const int m = (int)(id % M);
+    const int k = (int)((id / M) % Ks);
+    const int g = (int)(id / ((int64_t)M * Ks));
+    uint32_t pk[4];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const f32x4 v = ((const f32x4 *)lut)[((int64_t)(g * 2 + half) * Ks + k) * M + m];
+        uint32_t q[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = g * 8 + half * 4 + i;
+            float t = floorf((v[i] - lo[(int64_t)b * M + m]) / qstep[b]);
+            if (!(t > 0.f)) t = 0.f;
+            if (t > (float)qmax) t = (float)qmax;
+            q[i] = (uint32_t)t;
+        }
+        pk[half * 2 + 0] = q[0] | (q[1] << 16);
+        pk[half * 2 + 1] = q[2] | (q[3] << 16);
+    }
+    ((u32x4 *)out)[id] = (u32x4){pk[0], pk[1], pk[2], pk[3]};
+}
+
+// The three passes above in one launch: one workgroup per group of 8 queries (two fp32 TILED groups of 4).
+// Thread t owns sub-space m = t % M of codes k = t / M, t / M + 256 / M, ...: per-(query, m) min/max by an
+// LDS tree, then (step, L, Smax) per query, then the 16-byte quantised entries.
+template <int M>
+__global__ __launch_bounds__(256) void lut_quantise_fused_kernel(const float *__restrict__ lut, int Ks, int qmax,
+                                                                uint16_t *__restrict__ out,
+                                                                float *__restrict__ qstep, double *__restrict__ qlo,
+                                                                float *__restrict__ smax, u32x4 *__restrict__ fill,
+                                                                int64_t fill_vec16) {
+    constexpr int KPT = 256 / M;  // codes covered per sweep of the block
+    // this launch also resets the scan's result lists and shared bounds to "none" (all-ones): one launch less
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < fill_vec16; i += (int64_t)gridDim.x * 256)
+        fill[i] = (u32x4){~0u, ~0u, ~0u, ~0u};
+    __shared__ float s_lo[KPT][M][8], s_hi[KPT][M][8];
+    __shared__ float s_step[8];
+    const int tid = threadIdx.x;
+    const int m = tid % M, kr = tid / M;
+    const int g8 = blockIdx.x;
+    const f32x4 *base0 = (const f32x4 *)lut + (int64_t)(g8 * 2) * Ks * M;
+    const f32x4 *base1 = base0 + (int64_t)Ks * M;
+    float mn[8], mx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        mn[i] = __builtin_inff();
+        mx[i] = -__builtin_inff();
+    }
+    for (int k = kr; k < Ks; k += KPT) {
+        const f32x4 v0 = base0[(int64_t)k * M + m], v1 = base1[(int64_t)k * M + m];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mn[i] = fminf(mn[i], v0[i]);
+            mx[i] = fmaxf(mx[i], v0[i]);
+            mn[4 + i] = fminf(mn[4 + i], v1[i]);
+            mx[4 + i] = fmaxf(mx[4 + i], v1[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        s_lo[kr][m][i] = mn[i];
+        s_hi[kr][m][i] = mx[i];
+    }
+    __syncthreads();
+    // thread (m, i) for tid < M*8 folds the KPT partials
+    if (tid < M * 8) {
+        const int mm = tid / 8, i = tid % 8;
+        float l = s_lo[0][mm][i], h = s_hi[0][mm][i];
+        for (int r = 1; r < KPT; ++r) {
+            l = fminf(l, s_lo[r][mm][i]);
+            h = fmaxf(h, s_hi[r][mm][i]);
+        }
+        s_lo[0][mm][i] = l;
+        s_hi[0][mm][i] = h;
+    }
+    __syncthreads();
+    if (tid < 8) {
+        float range = 0.f, sm = 0.f;
+        double Lsum = 0.0;
+        for (int mm = 0; mm < M; ++mm) {
+            const float l = s_lo[0][mm][tid], h = s_hi[0][mm][tid];
+            range = fmaxf(range, h - l);
+            sm += fmaxf(fabsf(l), fabsf(h));
+            Lsum += (double)l;
+        }
+        float step = range / (float)qmax;
+        if (!(step > 0.f)) step = 1.f;
+        s_step[tid] = step;
+        const int b = g8 * 8 + tid;
+        qstep[b] = step;
+        qlo[b] = Lsum;
+        smax[b] = sm;
+    }
+    __syncthreads();
+    float lo_r[8], st_r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        lo_r[i] = s_lo[0][m][i];
+        st_r[i] = s_step[i];
+    }
+    u32x4 *o = (u32x4 *)out + (int64_t)g8 * Ks * M;
+    for (int k = kr; k < Ks; k += KPT) {
+        const f32x4 v0 = base0[(int64_t)k * M + m], v1 = base1[(int64_t)k * M + m];
+        uint32_t q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float v = i < 4 ? v0[i] : v1[i - 4];
+            float t = floorf((v - lo_r[i]) / st_r[i]);
+            if (!(t > 0.f)) t = 0.f;
+            if (t > (float)qmax) t = (float)qmax;
+            q[i] = (uint32_t)t;
+        }
+        o[(int64_t)k * M + m] = (u32x4){q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), q[6] | (q[7] << 16)};
+    }
+}
+
+// annlite_pq_search_topk on the quantised-filter plan: the L2 tables are BUILT, reduced and quantised by one
+// launch (query batch in, neighbours out).  One 1024-thread workgroup per group of 8 queries; thread
+// (kr, m) = (tid / M, tid % M) owns sub-space m of codes kr, kr + 1024/M, ...: NSW = M/4 entries x 8
+// queries stay in registers between the min/max pass and the quantisation, nothing is read back.
+// entry = the reference's j-ascending fmaf chain over (codeword - query) (pq_bindings.pyx:204-206): the same
+// bits as lut_l2_tiled_kernel.  Also resets the scan's result lists / shared bounds (fill).
+template <int M>
+__global__ __launch_bounds__(1024) void lut_l2_build_quantise_kernel(const float *__restrict__ queries, int B, int D,
+                                                                    const float *__restrict__ cb, int Ks,
+                                                                    float *__restrict__ lut, int qmax,
+                                                                    uint16_t *__restrict__ out,
+                                                                    float *__restrict__ qstep, double *__restrict__ qlo,
+                                                                    float *__restrict__ smax, u32x4 *__restrict__ fill,
+                                                                    int64_t fill_vec16) {
+    constexpr int KPT = 1024 / M;   // codes per sweep
+    constexpr int NSW = 256 / KPT;  // sweeps (Ks <= 256)
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < fill_vec16; i += (int64_t)gridDim.x * 1024)
+        fill[i] = (u32x4){~0u, ~0u, ~0u, ~0u};
+    __shared__ float s_lo[16][M][8], s_hi[16][M][8];
+    __shared__ float s_step[8];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+    float *s_q = (float *)dyn_smem;  // the 8 queries, [8][D]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = tid % M, kr = tid / M;
+    const int g8 = blockIdx.x;
+    const int dsub = D / M;
+    for (int i = tid; i < 8 * D; i += 1024) {
+        const int b = g8 * 8 + i / D;
+        s_q[i] = b < B ? queries[(int64_t)b * D + i % D] : 0.f;
+    }
+    __syncthreads();
+    f32x4 *base0 = (f32x4 *)lut + (int64_t)(g8 * 2) * Ks * M;
+    f32x4 *base1 = base0 + (int64_t)Ks * M;
+    f32x4 v0[NSW], v1[NSW];
+    float mn[8], mx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        mn[i] = __builtin_inff();
+        mx[i] = -__builtin_inff();
+    }
+#pragma unroll
+    for (int sw = 0; sw < NSW; ++sw) {
+        const int k = kr + sw * KPT;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (k < Ks) {
+            const float *cw = cb + ((int64_t)m * Ks + k) * dsub;
+            for (int j = 0; j < dsub; j += 4) {
+                const f32x4 cj = *(const f32x4 *)(cw + j);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x4 qj = *(const f32x4 *)(s_q + i * D + m * dsub + j);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float c = cj[e] - qj[e];
+                        acc[i] = __builtin_fmaf(c, c, acc[i]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (g8 * 8 + i >= B) acc[i] = 0.f;  // pad queries -> 0, like lut_l2_tiled_kernel
+            v0[sw] = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+            v1[sw] = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+            base0[(int64_t)k * M + m] = v0[sw];
+            base1[(int64_t)k * M + m] = v1[sw];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                mn[i] = fminf(mn[i], acc[i]);
+                mx[i] = fmaxf(mx[i], acc[i]);
+            }
+        }
+    }
+    // lanes l, l + M, l + 2M, ... of a wave share m
+#pragma unroll
+    for (int o = M; o < 64; o <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            mn[i] = fminf(mn[i], __shfl_xor(mn[i], o));
+            mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], o));
+        }
+    }
+    if (lane < M) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s_lo[wave][m][i] = mn[i];
+            s_hi[wave][m][i] = mx[i];
+        }
+    }
+    __syncthreads();
+    if (tid < M * 8) {
+        const int mm = tid / 8, i = tid % 8;
+        float l = s_lo[0][mm][i], h = s_hi[0][mm][i];
+        for (int r = 1; r < 16; ++r) {
+            l = fminf(l, s_lo[r][mm][i]);
+            h = fmaxf(h, s_hi[r][mm][i]);
+        }
+        s_lo[0][mm][i] = l;
+        s_hi[0][mm][i] = h;
+    }
+    __syncthreads();
+    if (tid < 8) {
+        float range = 0.f, sm = 0.f;
+        double Lsum = 0.0;
+        for (int mm = 0; mm < M; ++mm) {
+            const float l = s_lo[0][mm][tid], h = s_hi[0][mm][tid];
+            range = fmaxf(range, h - l);
+            sm += fmaxf(fabsf(l), fabsf(h));
+            Lsum += (double)l;
+        }
+        float step = range / (float)qmax;
+        if (!(step > 0.f)) step = 1.f;
+        s_step[tid] = step;
+        const int b = g8 * 8 + tid;
+        qstep[b] = step;
+        qlo[b] = Lsum;
+        smax[b] = sm;
+    }
+    __syncthreads();
+    float lo_r[8], st_r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        lo_r[i] = s_lo[0][m][i];
+        st_r[i] = s_step[i];
+    }
+    u32x4 *o = (u32x4 *)out + (int64_t)g8 * Ks * M;
+#pragma unroll
+    for (int sw = 0; sw < NSW; ++sw) {
+        const int k = kr + sw * KPT;
+        if (k >= Ks) continue;
+        uint32_t q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float v = i < 4 ? v0[sw][i] : v1[sw][i - 4];
+            float t = floorf((v - lo_r[i]) / st_r[i]);
+            if (!(t > 0.f)) t = 0.f;
+            if (t > (float)qmax) t = (float)qmax;
+            q[i] = (uint32_t)t;
+        }
+        o[(int64_t)k * M + m] = (u32x4){q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), q[6] | (q[7] << 16)};
+    }
+}
+
+// Smax[b] = sum_m max_k |lut[b][m][k]| from the TILED table [Bpad/QI][Ks][M][QI]; one wave per group
+__global__ __launch_bounds__(256) void lut_smax_kernel(const float *__restrict__ lut, int n_groups, int M, int Ks,
+                                                      int QI, float *__restrict__ smax) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= n_groups) return;
+    const float *base = lut + (int64_t)g * Ks * M * QI;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < M; ++m) {
+        float mx[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = lane; k < Ks; k += 64)
+            for (int i = 0; i < QI; ++i) mx[i] = fmaxf(mx[i], fabsf(base[((int64_t)k * M + m) * QI + i]));
+        for (int i = 0; i < QI; ++i) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], o));
+            acc[i] += mx[i];
+        }
+    }
+    if (lane == 0)
+        for (int i = 0; i < QI; ++i) smax[g * QI + i] = acc[i];
+}
+
+}  // namespace annlite
+
+using namespace annlite;
+
+int annlite::launch_lut_quantise(int64_t M, int64_t Ks, int64_t B, int64_t bpad, const float *lut_dev, const LutBuild *build,
+                                 uint16_t *q16, float *qstep, double *qlo, float *smax, void *fill, size_t fill_bytes,
+                                 hipStream_t st) {
+    const int qmax = (int)(32767 / M);
+    const unsigned n_g8 = (unsigned)(bpad / 8);
+    float *lut_rw = const_cast<float *>(lut_dev);
+    u32x4 *fillp = (u32x4 *)fill;
+    const int64_t fillv = (int64_t)(fill_bytes / 16);
+#define ANNLITE_QUANT(MM)                                                                                            \
+    if (build)                                                                                                       \
+        hipLaunchKernelGGL((lut_l2_build_quantise_kernel<MM>), dim3(n_g8), dim3(1024), (size_t)(8 * build->D * 4), st,  \
+                           build->queries, (int)B, (int)build->D, build->codebooks, (int)Ks, lut_rw, qmax, q16, qstep,   \
+                           qlo, smax, fillp, fillv);                                                                 \
+    else                                                                                                             \
+        hipLaunchKernelGGL((lut_quantise_fused_kernel<MM>), dim3(n_g8), dim3(256), 0, st, lut_rw, (int)Ks, qmax, q16,  \
+                           qstep, qlo, smax, fillp, fillv)
+    if (M == 64)  // (no fill, no build: the caller memsets and builds the tables itself)
+        hipLaunchKernelGGL(lut_quantise64_kernel, dim3((unsigned)(bpad / 4)), dim3(1024), 0, st, lut_dev, (int)Ks, qmax, q16,
+                           qstep, qlo, smax);
+    else if (M == 8) { ANNLITE_QUANT(8); } else if (M == 16) { ANNLITE_QUANT(16); } else { ANNLITE_QUANT(32); }
+#undef ANNLITE_QUANT
+    return launch_status("lut_quantise_fused_kernel");
+}
+
+int annlite::launch_seed_bound(int64_t M, bool skw, const void *codes_dev, int64_t S, const uint32_t *valid_bits_dev,
+                               const float *lut_dev, int64_t B, int64_t Ks, int64_t k, unsigned long long *gk,
+                               hipStream_t st) {
+#define ANNLITE_SEED(MM, QPB_)                                                                                    \
+    {                                                                                                             \
+        auto fn = skw ? seed_bound_kernel<MM, true, QPB_> : seed_bound_kernel<MM, false, QPB_>;                   \
+        const size_t lds = (size_t)Ks * (MM + 1) * 4 * QPB_ + (size_t)2 * kSeedWaves * 64 * 8; /* cand + minima */ \
+        ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(fn, dim3((unsigned)(((B + 3) / 4) * (4 / QPB_))), dim3(kSeedWaves * 64), lds, st,      \
+                           (const uint8_t *)codes_dev, S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, gk);   \
+    }
+    if (M == 8) ANNLITE_SEED(8, 4) else if (M == 16) ANNLITE_SEED(16, 4) else if (M == 32) ANNLITE_SEED(32, 4)
+    else ANNLITE_SEED(64, 2)
+#undef ANNLITE_SEED
+    return launch_status("seed_bound_kernel");
+}
+
+int annlite::launch_lut_smax(const float *lut_dev, int n_groups, int64_t M, int64_t Ks, int QI, float *smax, hipStream_t st) {
+    hipLaunchKernelGGL(lut_smax_kernel, dim3((n_groups + 3) / 4), dim3(256), 0, st, lut_dev, n_groups, (int)M, (int)Ks, QI,
+                       smax);
+    return launch_status("lut_smax_kernel");
+}

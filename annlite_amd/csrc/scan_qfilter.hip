@@ -1,0 +1,766 @@
+// scan_qfilter.hip -- the default ADC scan kernels: integer filter over quantised tables in LDS, exact fp32
+// recompute for the rows that pass (bit-exact results), shared top-k lists, bounds shared across row slices.
+// See DESIGN.md section 3.1 for the design and its measured history.
+#include "scan_common.h"
+
+namespace annlite {
+
+// The top-k of a (workgroup, query) lives ONCE in LDS: 64 sorted (key, id) entries + a 4-byte lock.  The
+// bound every wave filters with is the k-th best of ALL rows the workgroup has seen.
+extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
+
+// what a queue flush needs and a work item keeps constant
+struct FlushCtx {
+    const uint8_t *codes;
+    const float *lut;
+    const float *smax;
+    const float *qstep;
+    const double *qlo;
+    unsigned long long *gkey;
+    unsigned long long *gk2;
+    unsigned long long *dbg;
+    int32_t Ks, b0, n_slices, slice, km1, jm1, skip;
+    uint32_t list_off, lock_off, shq_off, gkl_off, gjl_off;
+};
+
+// Flush one wave's candidate queue: up to 64 (query, row) pairs whose integer sum passed the filter.
+// Lane i takes entry i: re-reads the row's code bytes, gathers its exact ascending-m fp32 sum from the
+// fp32 table in global memory, then the candidates are offered query by query to the shared lists.
+// Batching matters: one candidate at a time paid the gather latency, the call and the lock ~3.6 us each
+// (46 times per wave at 1.25M rows); a flush pays them once for everything queued since the last one.
+template <int M, bool SKEWED>
+__device__ __attribute__((noinline)) void qfilter_flush(const FlushCtx c, uint32_t queue_off, int qcnt) {
+    constexpr int CW = M / 4;
+    const int lane = threadIdx.x & 63;
+    const bool act = lane < qcnt;
+    const unsigned long long e = act ? ((const unsigned long long *)(g_smem + queue_off))[lane] : 0ull;
+    const uint32_t rid = (uint32_t)e;
+    const int q = (int)(e >> 32);
+    float ex = 0.f;
+    if (act && !(c.skip & 1)) {
+        uint32_t cp[CW];
+        const uint32_t *p = (const uint32_t *)(c.codes + (int64_t)rid * M);
+#pragma unroll
+        for (int i = 0; i < CW; ++i) cp[i] = p[i];
+        if constexpr (SKEWED && M == 64) {
+            const int r = (int)(rid % 64);
+#pragma unroll
+            for (int i = 0; i < CW; ++i) cp[i] = bytes_add(cp[i], wrap64_mask(i, r));  // undo the wrap coding
+        }
+        if constexpr (SKEWED) {
+            // stored byte j of row n is the code of sub-space (j + n) mod M: rotate back by n mod M
+            const int sinv = (M - (int)(rid % M)) % M;
+            bool abit_inv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) abit_inv[i] = (((sinv >> 2) >> i) & 1) != 0;
+            rotate_row<CW>(cp, abit_inv, (uint32_t)(sinv & 3));
+        }
+        const int b = c.b0 + q;
+        const float *lq = c.lut + ((int64_t)(b >> 2) * c.Ks) * (M * 4) + (b & 3);
+        float vals[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const uint32_t code = (cp[m / 4] >> (8 * (m % 4))) & 0xffu;
+            vals[m] = lq[((int64_t)code * M + m) * 4];
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) ex += vals[m];
+    }
+    const uint32_t khi = f32_to_ordered(ex);
+    unsigned long long rem = __ballot(act);
+    while (rem) {
+        const int q0 = __builtin_amdgcn_readlane(q, __builtin_ctzll(rem));
+        const unsigned long long pm = __ballot(act && q == q0);
+        rem &= ~pm;
+        if (c.dbg && lane == 0) {
+            atomicAdd(c.dbg + 1, 1ull);
+            atomicAdd(c.dbg + 4, (unsigned long long)__popcll(pm));
+        }
+        const int b = c.b0 + q0;
+        unsigned long long *list = (unsigned long long *)(g_smem + c.list_off + q0 * 512);  // [64] ascending
+        unsigned long long *gkl = (unsigned long long *)(g_smem + c.gkl_off + q0 * 8);
+        // cheap pre-check against the current bound, without the lock (it only ever decreases): the list's
+        // own k-th key or the best bound imported from the other workgroups, whichever is smaller
+        unsigned long long kth = __hip_atomic_load(list + c.km1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned long long gk = __hip_atomic_load(gkl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (gk < kth) kth = gk;
+        unsigned long long px = __ballot(key_less(khi, rid, (uint32_t)(kth >> 32), (uint32_t)kth)) & pm;
+        if (!px || (c.skip & 2)) continue;
+        if (c.dbg && lane == 0) atomicAdd(c.dbg + 2, 1ull);
+        // ---- critical section ---------------------------------------------------------------------
+        unsigned int *lock = (unsigned int *)(g_smem + c.lock_off + q0 * 4);
+        for (;;) {
+            unsigned int got = 0;
+            if (lane == 0) got = (atomicCAS(lock, 0u, 1u) == 0u) ? 1u : 0u;
+            if (__builtin_amdgcn_readfirstlane(got)) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        const unsigned long long le = __hip_atomic_load(list + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        WaveList L;
+        L.hi = (uint32_t)(le >> 32);
+        L.lo = (uint32_t)le;
+        const uint32_t thi = __builtin_amdgcn_readlane(L.hi, c.km1), tlo = __builtin_amdgcn_readlane(L.lo, c.km1);
+        px = __ballot(key_less(khi, rid, thi, tlo)) & px;  // the list may have tightened meanwhile
+        if (px) {
+            wavelist_insert_many(L, px, khi, rid, lane);
+            __hip_atomic_store(list + lane, ((unsigned long long)L.hi << 32) | L.lo, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t ohi = __builtin_amdgcn_readlane(L.hi, c.km1);
+            const uint32_t olo = __builtin_amdgcn_readlane(L.lo, c.km1);
+            const unsigned long long okey = ((unsigned long long)ohi << 32) | olo;
+            if (lane == 0 && ohi != kKeyInfHi && okey < gk) {
+                if (c.dbg) atomicAdd(c.dbg + 3, 1ull);
+                // tell the other workgroups of this query (other row slices) and remember it locally
+                if (c.gkey) __hip_atomic_fetch_min(c.gkey + b, okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gkl, okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                *(volatile unsigned short *)(g_smem + c.shq_off + q0 * 2) =
+                    qbound_from_key<M>(okey, c.smax[b], c.qstep[b], c.qlo[b]);
+            }
+            if (c.gk2) {
+                // this slice's j-th key, for the max-of-j-th bound the sibling slices compute
+                const uint32_t jhi = __builtin_amdgcn_readlane(L.hi, c.jm1);
+                const uint32_t jlo = __builtin_amdgcn_readlane(L.lo, c.jm1);
+                const unsigned long long jkey = ((unsigned long long)jhi << 32) | jlo;
+                volatile unsigned long long *gjl = (volatile unsigned long long *)(g_smem + c.gjl_off + q0 * 8);
+                if (lane == 0 && jhi != kKeyInfHi && jkey < *gjl) {
+                    *gjl = jkey;
+                    __hip_atomic_store(c.gk2 + (int64_t)b * c.n_slices + c.slice, jkey, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        // LDS executes one wave's instructions in order, so the list stores are visible before the release
+        if (lane == 0) __hip_atomic_store(lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+// =================================================================================================
+// Quantised-filter kernel.  Same discipline as adc_scan_filter_kernel (cheap bound -> exact
+// recompute for the few rows that pass -> bit-exact output) but the cheap bound is an INTEGER sum
+// over a 12-bit quantised copy of the tables:
+//     Q[q][m][k] = min(QMAX, floor((lut[q][m][k] - lo[q][m]) / step[q])),  QMAX = floor(32767 / M)
+//   * 8 queries per 16-byte LDS entry (u16 each): one ds_read_b128 serves 8 look-ups per lane, half
+//     the LDS bytes of the fp32 filter, and a workgroup holds 16 queries in the same 128 KB;
+//   * two u16 partial sums share a dword and are added with ONE plain v_add_u32 (VOP2, 2.5 cycles per
+//     wave-instruction vs 4.5 for v_pk_add_f32 -- scripts/valu_ubench.hip); M*QMAX < 32768, so the
+//     low half never carries into the high half, and the filter test is ONE more VOP2 per dword:
+//     (0x8000|qthr) - S keeps bit 15 of a half set iff S <= qthr (no borrow can cross the halves);
+//   * bound: with L = sum_m lo[q][m], S = integer sum, every entry satisfies
+//     lo + step*(Q - 0.002) <= v <= lo + step*(Q + 1.002), hence d_real >= L + step*(S - 0.04); a row
+//     can be in the top-k only if d_exact <= thr, d_real <= thr + slack32, i.e.
+//     S <= qthr := floor((thr + slack32 - L) / step) + 1   (computed in double when thr changes);
+//   * rows with S <= qthr get their exact ascending-m fp32 sum from the fp32 table in global memory
+//     (L2-resident: 16 queries x 16 KB per workgroup), then the usual (ordered(d), id) offer.
+// LDS: [Q tile Ks*KSTRIDE][shq16 u16 x QT (0x8000|qthr) @ +0][locks u32 x QT @ +64][gkl u64 x QT @ +128]
+//      [lists u64 x QT x 64 @ +256]
+// =================================================================================================
+template <int M, int NQ, int NW, int WPS, bool SKEWED>
+__global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const ScanArgs a) {
+    constexpr int QG = 8;                 // queries per LDS entry
+    constexpr int QT = QG * NQ;           // queries per workgroup
+    constexpr int CW = M / 4;
+    constexpr int EB = 16;
+    constexpr int RB = M * EB;
+    constexpr int KSTRIDE = NQ * RB;
+    static_assert(M % 8 == 0 && M <= 32 && (KSTRIDE & (KSTRIDE - 1)) == 0, "unsupported shape");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int km1 = a.k - 1;
+    const int s = lane % M;
+    // forward rotation (PLAIN tables) and its inverse (to read a row's bytes in true sub-space order)
+    const uint32_t bsh = (uint32_t)(s & 3);
+    bool abit[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) abit[i] = (((s >> 2) >> i) & 1) != 0;
+    const unsigned char *mbase[M];
+#pragma unroll
+    for (int t = 0; t < M; ++t) mbase[t] = smem + ((s + t) % M) * EB;
+
+    const int lut_bytes = a.Ks * KSTRIDE;
+    const uint32_t shq_off = (uint32_t)lut_bytes, lock_off = shq_off + 64, gkl_off = shq_off + 128,
+                   list_off = shq_off + 256, gjl_off = list_off + QT * 512, queue_off = gjl_off + 128;
+    unsigned long long *gkl = (unsigned long long *)(smem + gkl_off);  // [QT] best published k-th key
+    volatile uint16_t *shq = (volatile uint16_t *)(smem + shq_off);
+    volatile uint32_t *locks = (volatile uint32_t *)(smem + lock_off);
+    unsigned long long *lists = (unsigned long long *)(smem + list_off);  // [QT][64]
+
+    const int n_items = a.n_items;
+    const int64_t group_bytes = (int64_t)a.Ks * RB;
+
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        int tile, slice;
+        if (!item_map(a, item, tile, slice)) continue;
+
+        __syncthreads();
+        {
+            const unsigned char *src0 = (const unsigned char *)a.q16 + (int64_t)tile * NQ * group_bytes;
+            constexpr int PIECES_PER_ROW = RB / 16;
+            const int total = NQ * a.Ks * PIECES_PER_ROW;
+            for (int idx = tid; idx < total; idx += NW * 64) {
+                const int p = idx % PIECES_PER_ROW;
+                const int kh = idx / PIECES_PER_ROW;
+                const int h = kh / a.Ks;
+                const int kk = kh - h * a.Ks;
+                const u32x4 v = *(const u32x4 *)(src0 + (int64_t)h * group_bytes + (int64_t)kk * RB + p * 16);
+                *(u32x4 *)(smem + (kk * NQ + h) * RB + p * 16) = v;
+            }
+            if (tid < QT) {
+                locks[tid] = 0;
+                // start from whatever other workgroups (other row slices, earlier items) already proved
+                const int b = tile * QT + tid;
+                const unsigned long long gk =
+                    a.gkey ? __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+                gkl[tid] = gk;
+                ((unsigned long long *)(smem + gjl_off))[tid] = ~0ull;
+                shq[tid] = qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]);
+            }
+            for (int idx = tid; idx < QT * 64; idx += NW * 64) lists[idx] = ~0ull;
+        }
+        __syncthreads();
+
+        const int64_t slice_begin = (int64_t)slice * a.slice_rows;
+        int64_t slice_end = slice_begin + a.slice_rows;
+        if (slice_end > a.N) slice_end = a.N;
+
+        const uint32_t *codes32 = (const uint32_t *)a.codes;
+        auto load_row = [&](int64_t row, uint32_t (&c)[CW]) {
+            if (row >= a.N) row = a.N - 1;
+            const uint32_t *p = codes32 + row * CW;
+            if constexpr (CW == 2) {
+                const u32x2 v = *(const u32x2 *)p;
+                c[0] = v.x;
+                c[1] = v.y;
+            } else {
+#pragma unroll
+                for (int i = 0; i < CW / 4; ++i) {
+                    const u32x4 v = *(const u32x4 *)(p + 4 * i);
+                    c[4 * i + 0] = v.x;
+                    c[4 * i + 1] = v.y;
+                    c[4 * i + 2] = v.z;
+                    c[4 * i + 3] = v.w;
+                }
+            }
+        };
+
+        const int64_t stride = (int64_t)NW * 64;
+        int64_t row0 = slice_begin + (int64_t)wave * 64;
+        uint32_t ccur[CW], cnext[CW];   // rotated code bytes of the current / next row of this lane
+        const unsigned char *addr[M];
+        auto make_addr = [&](const uint32_t (&cc)[CW]) {
+            static_for<0, CW>([&](auto W) {
+                constexpr int w = decltype(W)::value;
+                uint32_t o0, o1, o2, o3;
+                byte_shl4(cc[w], (uint32_t)ilog2_c(KSTRIDE), o0, o1, o2, o3);
+                addr[4 * w + 0] = mbase[4 * w + 0] + o0;
+                addr[4 * w + 1] = mbase[4 * w + 1] + o1;
+                addr[4 * w + 2] = mbase[4 * w + 2] + o2;
+                addr[4 * w + 3] = mbase[4 * w + 3] + o3;
+            });
+        };
+        // integer sums of one entry group: 4 dwords x (2 x u16)
+        auto group_sum = [&](auto H, u32x4 &acc) {
+            constexpr int h = decltype(H)::value;
+            // issue all M look-ups of the group before the first add (the compiler otherwise re-used one
+            // register pair and waited lgkmcnt(0) after every second load)
+            u32x4 v[M];
+            static_for<0, M>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                v[t] = *(const u32x4 *)(addr[t] + h * RB);
+            });
+            asm volatile("" ::: "memory");
+            acc = v[0];
+            static_for<1, M>([&](auto T) { acc += v[decltype(T)::value]; });
+        };
+        u32x4 thp[NQ];  // packed (0x8000 | qthr) of the group's 8 queries
+#pragma unroll
+        for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
+        uint32_t vcur = ~0u, vnext = ~0u;
+        auto load_valid = [&](int64_t row) -> uint32_t {
+            if (!a.valid) return ~0u;
+            if (row >= a.N) row = a.N - 1;
+            return a.valid[row >> 5];
+        };
+        if (row0 < slice_end) {
+            load_row(row0 + lane, ccur);
+            if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
+            load_row(row0 + stride + lane, cnext);
+            vcur = load_valid(row0 + lane);
+            vnext = load_valid(row0 + stride + lane);
+        }
+
+        const FlushCtx fc = {(const uint8_t *)a.codes, a.lut, a.smax, a.qstep, a.qlo, a.gkey, a.gk2, a.dbg,
+                             a.Ks, tile * QT, a.n_slices, slice, km1, a.jm1, a.dbg_skip,
+                             list_off, lock_off, shq_off, gkl_off, gjl_off};
+        int qcnt = 0;  // entries in this wave's candidate queue
+        int step_no = 0;
+        for (; row0 < slice_end; row0 += stride, ++step_no) {
+            unsigned long long vmask = ~0ull;
+            if (slice_end - row0 < 64) vmask = (1ull << (int)(slice_end - row0)) - 1ull;
+            // validity word of this lane's row, fetched one step ahead with the code bytes (a scalar load here
+            // would make the wave drain lgkmcnt -- i.e. all its LDS look-ups -- before the first add)
+            if (a.valid) vmask &= __ballot((vcur >> (lane & 31)) & 1u);
+            const uint32_t rid = (uint32_t)(row0 + lane);
+            make_addr(ccur);
+            u32x4 acc[NQ];
+            static_for<0, NQ>([&](auto H) { group_sum(H, acc[decltype(H)::value]); });
+
+            // any (query, lane) with S <= qthr ?  (0x8000|qthr) - S has bit 15 of that half set
+            uint32_t anyv = 0;
+#pragma unroll
+            for (int h = 0; h < NQ; ++h)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) anyv |= thp[h][w] - acc[h][w];
+            const unsigned long long anym = __ballot((anyv & 0x80008000u) != 0) & vmask;
+            bool flushed = false;
+            if (anym && !(a.dbg_skip & 4)) {
+                if (a.dbg && lane == 0) atomicAdd(a.dbg + 0, 1ull);
+                // queue (query, row) of every lane that passed; the exact work happens in batches
+                unsigned long long *queue = (unsigned long long *)(smem + queue_off + wave * 512);
+#pragma unroll
+                for (int h = 0; h < NQ; ++h) {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const uint32_t x = (thp[h][w] - acc[h][w]) & 0x80008000u;
+                        if (__ballot(x != 0) & vmask) {
+#pragma unroll
+                            for (int half = 0; half < 2; ++half) {
+                                const unsigned long long pm = __ballot((x & (half ? 0x80000000u : 0x8000u)) != 0) & vmask;
+                                if (pm) {
+                                    const int n = __popcll(pm);
+                                    if (qcnt + n > 64) {
+                                        qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
+                                        qcnt = 0;
+                                        flushed = true;
+                                    }
+                                    const int rank = __builtin_amdgcn_mbcnt_hi(
+                                        (uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                                    if ((pm >> lane) & 1ull)
+                                        queue[qcnt + rank] = ((unsigned long long)(h * QG + w * 2 + half) << 32) | rid;
+                                    qcnt += n;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            // flush when half full, and every (flush_mask + 1) steps: a flush costs ~7 us whatever it holds (two
+            // dependent global round trips + the list update), so waves flush rarely but staggered -- every few
+            // steps SOME wave of the workgroup tightens the shared bound
+            if (qcnt && (qcnt >= 32 || ((step_no + wave * 4) & a.flush_mask) == a.flush_mask)) {
+                qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
+                qcnt = 0;
+                flushed = true;
+            }
+            // Import what the other workgroups of these queries (the other row slices) have proven: the best
+            // k-th key any of them published and, per group of 8 concurrently scanned slices, the MAX of
+            // their j-th keys (8 disjoint slices x j rows >= k rows at or below it; +1: that row itself must
+            // still be accepted).  Bounds move on a log scale, so: steps 0, 1, 3, 7, ... then every 64th.
+            if (a.gkey) {
+                const bool pow2 = ((step_no + 1) & step_no) == 0;
+                if (pow2 || (step_no & 63) == 63) {
+                    const int rw = pow2 ? (__builtin_ctz((unsigned)step_no + 1u) % NW) : ((step_no >> 6) % NW);
+                    if (wave == rw) {
+#pragma unroll 1
+                        for (int q0 = 0; q0 < QT; q0 += 8) {
+                            const int q = q0 + (lane >> 3);
+                            const int b = tile * QT + q;
+                            unsigned long long bound =
+                                __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (a.gk2) {
+#pragma unroll 1
+                                for (int g0 = 0; g0 < a.n_slices; g0 += 8) {
+                                    unsigned long long v = 0ull;  // slots beyond n_slices never set the max
+                                    if (g0 + (lane & 7) < a.n_slices)
+                                        v = __hip_atomic_load(a.gk2 + (int64_t)b * a.n_slices + g0 + (lane & 7),
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                                    for (int o = 1; o < 8; o <<= 1) {
+                                        const unsigned long long p = __shfl_xor(v, o);
+                                        v = p > v ? p : v;
+                                    }
+                                    if (v != ~0ull && v + 1ull < bound) bound = v + 1ull;
+                                }
+                            }
+                            if ((lane & 7) == 0 &&
+                                bound < __hip_atomic_load(gkl + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                                __hip_atomic_store(gkl + q, bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                const unsigned short nb = qbound_from_key<M>(bound, a.smax[b], a.qstep[b], a.qlo[b]);
+                                if (nb < shq[q]) shq[q] = nb;
+                            }
+                        }
+                    }
+                }
+            }
+            // pick up the workgroup bound: every 4th step, and right after this wave's own events
+            if (flushed || (step_no & 3) == 3) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
+            }
+            // next row
+#pragma unroll
+            for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
+            if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
+            load_row(row0 + 2 * stride + lane, cnext);
+            vcur = vnext;
+            vnext = load_valid(row0 + 2 * stride + lane);
+        }
+
+        if (qcnt) qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
+
+        // ---- the shared lists ARE the workgroup's result for this (tile, slice) ----------------------
+        __syncthreads();
+        for (int q = wave; q < QT; q += NW) {
+            const int b = tile * QT + q;
+            // device-scope stores: the merging workgroup may sit on another XCD (own L2)
+            if (b < a.B && lane <= km1)
+                __hip_atomic_store(a.partial + ((int64_t)b * a.n_slices + slice) * a.k + lane, lists[q * 64 + lane],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (a.tile_done) {
+            // the last of the tile's n_slices workgroups to arrive merges them (saves the merge launch and the
+            // ~10 us kernel boundary in front of it)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have completed
+            __syncthreads();
+            volatile unsigned int *s_flag = (volatile unsigned int *)(smem + lock_off);  // locks are idle now
+            if (tid == 0) {
+                const unsigned int old =
+                    __hip_atomic_fetch_add(a.tile_done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *s_flag = (old + 1u == (unsigned int)(a.n_slices - 1)) ? 1u : 0u;
+            }
+            __syncthreads();
+            if (*s_flag) {
+                for (int q = wave; q < QT; q += NW) {
+                    const int b = tile * QT + q;
+                    if (b >= a.B) continue;
+                    WaveList L;
+                    L.reset();
+                    for (int sl = 0; sl < a.n_slices; ++sl) {
+                        unsigned long long key = ~0ull;
+                        if (lane <= km1)
+                            key = __hip_atomic_load(a.partial + ((int64_t)b * a.n_slices + sl) * a.k + lane,
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // every slice list is ascending over the lanes: sorted merge, keep the 64 smallest
+                        wavelist_merge_sorted(L, (uint32_t)(key >> 32), (uint32_t)key, lane);
+                    }
+                    if (lane <= km1) {
+                        const bool none = (L.hi == kKeyInfHi && L.lo == kIdNone);
+                        const float d = none ? __builtin_inff() : ordered_to_f32(L.hi);
+                        const int64_t id = none ? (int64_t)-1 : a.row_base + (int64_t)L.lo;
+                        if (a.out_packed) {
+                            a.out_packed[((int64_t)b * a.k + lane) * 2 + 0] = id;
+                            a.out_packed[((int64_t)b * a.k + lane) * 2 + 1] = (int64_t)__float_as_uint(d);
+                        } else {
+                            a.out_d[(int64_t)b * a.k + lane] = a.sqrt_out ? __builtin_sqrtf(d) : d;
+                            a.out_i[(int64_t)b * a.k + lane] = id;
+                        }
+                    }
+                }
+            }
+            __syncthreads();  // s_flag (the lock words) is re-initialised by the next item
+        }
+    }
+}
+
+
+// =================================================================================================
+// Quantised-filter kernel for M = 64 (BASELINE config 4: 768-d, 12-float sub-spaces).  Same discipline as
+// adc_scan_qfilter_kernel; what differs is dictated by the table size (64 sub-spaces x 256 codes):
+//   * 4 queries per 8-byte LDS entry (u16 each), table [Ks + 1][64][8 B] = 128.5 KB, ds_read_b64; a
+//     half-wave reads sub-spaces (l + t) % 64 for 32 consecutive l: bank pair (l + t) % 32, conflict-free;
+//   * no per-step LDS base registers: the wrap-coded SKEWED layout (wrap64_mask) makes the address
+//     (stored byte << 9) + lane*8 with t*8 as the instruction's immediate -- one SDWA shift + one add;
+//   * QMAX = floor(32767 / 64) = 511 (9-bit entries), look-ups issued in 4 chunks of 16;
+//   * PLAIN tables are rotated and wrap-coded on the fly (slow path; the index plugin stores SKEWED).
+// LDS: [table (Ks+1)*512][shq u16 x 4 @ +0][locks u32 x 4 @ +64][gkl u64 x 4 @ +128][lists u64 x 4 x 64 @ +256]
+//      [gjl u64 x 4][queues u64 x NW x 64]
+// =================================================================================================
+template <int NW, bool SKEWED>
+__global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanArgs a) {
+    constexpr int M = 64, QT = 4, CW = 16, RB = 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int km1 = a.k - 1;
+    // forward rotation of PLAIN rows by lane bytes
+    const uint32_t bsh = (uint32_t)(lane & 3);
+    bool abit[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) abit[i] = (((lane >> 2) >> i) & 1) != 0;
+
+    const int lut_bytes = (a.Ks + 1) * RB;
+    const uint32_t shq_off = (uint32_t)lut_bytes, lock_off = shq_off + 64, gkl_off = shq_off + 128,
+                   list_off = shq_off + 256, gjl_off = list_off + QT * 512, queue_off = gjl_off + 128;
+    unsigned long long *gkl = (unsigned long long *)(smem + gkl_off);
+    volatile uint16_t *shq = (volatile uint16_t *)(smem + shq_off);
+    volatile uint32_t *locks = (volatile uint32_t *)(smem + lock_off);
+    unsigned long long *lists = (unsigned long long *)(smem + list_off);
+    const unsigned char *lbase = smem + lane * 8;
+
+    for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        int tile, slice;
+        if (!item_map(a, item, tile, slice)) continue;
+
+        __syncthreads();
+        {
+            const u32x4 *src = (const u32x4 *)((const unsigned char *)a.q16 + (int64_t)tile * a.Ks * RB);
+            const int total = a.Ks * (RB / 16);
+            for (int idx = tid; idx < total; idx += NW * 64) ((u32x4 *)smem)[idx] = src[idx];
+            for (int idx = tid; idx < RB / 16; idx += NW * 64) ((u32x4 *)(smem + a.Ks * RB))[idx] = src[idx];  // row Ks = row 0
+            if (tid < QT) {
+                locks[tid] = 0;
+                const int b = tile * QT + tid;
+                const unsigned long long gk =
+                    a.gkey ? __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+                gkl[tid] = gk;
+                ((unsigned long long *)(smem + gjl_off))[tid] = ~0ull;
+                shq[tid] = qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]);
+            }
+            for (int idx = tid; idx < QT * 64; idx += NW * 64) lists[idx] = ~0ull;
+        }
+        __syncthreads();
+
+        const int64_t slice_begin = (int64_t)slice * a.slice_rows;
+        int64_t slice_end = slice_begin + a.slice_rows;
+        if (slice_end > a.N) slice_end = a.N;
+
+        const uint32_t *codes32 = (const uint32_t *)a.codes;
+        auto load_row = [&](int64_t row, uint32_t (&c)[CW]) {
+            if (row >= a.N) row = a.N - 1;
+            const uint32_t *p = codes32 + row * CW;
+#pragma unroll
+            for (int i = 0; i < CW / 4; ++i) {
+                const u32x4 v = *(const u32x4 *)(p + 4 * i);
+                c[4 * i + 0] = v.x;
+                c[4 * i + 1] = v.y;
+                c[4 * i + 2] = v.z;
+                c[4 * i + 3] = v.w;
+            }
+        };
+        auto encode_plain = [&](uint32_t (&c)[CW]) {  // PLAIN row -> this lane's wrap-coded SKEWED row
+            rotate_row<CW>(c, abit, bsh);
+#pragma unroll
+            for (int i = 0; i < CW; ++i) c[i] = bytes_sub(c[i], wrap64_mask(i, lane));
+        };
+        auto load_valid = [&](int64_t row) -> uint32_t {
+            if (!a.valid) return ~0u;
+            if (row >= a.N) row = a.N - 1;
+            return a.valid[row >> 5];
+        };
+
+        const int64_t stride = (int64_t)NW * 64;
+        int64_t row0 = slice_begin + (int64_t)wave * 64;
+        uint32_t ccur[CW], cnext[CW];
+        uint32_t vcur = ~0u, vnext = ~0u;
+        u32x2 thp = *(const u32x2 *)(smem + shq_off);  // packed (0x8000 | qthr) of the 4 queries
+        if (row0 < slice_end) {
+            load_row(row0 + lane, ccur);
+            if constexpr (!SKEWED) encode_plain(ccur);
+            load_row(row0 + stride + lane, cnext);
+            vcur = load_valid(row0 + lane);
+            vnext = load_valid(row0 + stride + lane);
+        }
+        const FlushCtx fc = {(const uint8_t *)a.codes, a.lut, a.smax, a.qstep, a.qlo, a.gkey, a.gk2, a.dbg,
+                             a.Ks, tile * QT, a.n_slices, slice, km1, a.jm1, a.dbg_skip,
+                             list_off, lock_off, shq_off, gkl_off, gjl_off};
+        int qcnt = 0;
+        int step_no = 0;
+        for (; row0 < slice_end; row0 += stride, ++step_no) {
+            unsigned long long vmask = ~0ull;
+            if (slice_end - row0 < 64) vmask = (1ull << (int)(slice_end - row0)) - 1ull;
+            if (a.valid) vmask &= __ballot((vcur >> (lane & 31)) & 1u);
+            const uint32_t rid = (uint32_t)(row0 + lane);
+
+            u32x2 acc = {0u, 0u};
+            static_for<0, 4>([&](auto C) {
+                constexpr int c0 = decltype(C)::value * 16;
+                u32x2 v[16];
+                static_for<0, 4>([&](auto W) {
+                    constexpr int t = c0 + decltype(W)::value * 4;
+                    uint32_t o0, o1, o2, o3;
+                    byte_shl4(ccur[t / 4], 9u, o0, o1, o2, o3);
+                    v[t - c0 + 0] = *(const u32x2 *)(lbase + o0 + (t + 0) * 8);
+                    v[t - c0 + 1] = *(const u32x2 *)(lbase + o1 + (t + 1) * 8);
+                    v[t - c0 + 2] = *(const u32x2 *)(lbase + o2 + (t + 2) * 8);
+                    v[t - c0 + 3] = *(const u32x2 *)(lbase + o3 + (t + 3) * 8);
+                });
+                asm volatile("" ::: "memory");
+                static_for<0, 16>([&](auto I) { acc += v[decltype(I)::value]; });
+            });
+
+            const uint32_t x0 = (thp.x - acc.x) & 0x80008000u, x1 = (thp.y - acc.y) & 0x80008000u;
+            const unsigned long long anym = __ballot((x0 | x1) != 0) & vmask;
+            bool flushed = false;
+            if (anym && !(a.dbg_skip & 4)) {
+                if (a.dbg && lane == 0) atomicAdd(a.dbg + 0, 1ull);
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const uint32_t x = w ? x1 : x0;
+                    if (__ballot(x != 0) & vmask) {
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            const unsigned long long pm = __ballot((x & (half ? 0x80000000u : 0x8000u)) != 0) & vmask;
+                            if (pm) {
+                                const int n = __popcll(pm);
+                                if (qcnt + n > 64) {
+                                    qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
+                                    qcnt = 0;
+                                    flushed = true;
+                                }
+                                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32),
+                                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                                unsigned long long *queue = (unsigned long long *)(smem + queue_off + wave * 512);
+                                if ((pm >> lane) & 1ull) queue[qcnt + rank] = ((unsigned long long)(w * 2 + half) << 32) | rid;
+                                qcnt += n;
+                            }
+                        }
+                    }
+                }
+            }
+            if (qcnt && (qcnt >= 32 || ((step_no + wave * 4) & a.flush_mask) == a.flush_mask)) {
+                qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
+                qcnt = 0;
+                flushed = true;
+            }
+            // import the bounds of the other slices (see adc_scan_qfilter_kernel)
+            if (a.gkey) {
+                const bool pow2 = ((step_no + 1) & step_no) == 0;
+                if (pow2 || (step_no & 63) == 63) {
+                    const int rw = pow2 ? (__builtin_ctz((unsigned)step_no + 1u) % NW) : ((step_no >> 6) % NW);
+                    if (wave == rw) {
+                        const int q = lane >> 3;
+                        if (q < QT) {
+                            const int b = tile * QT + q;
+                            unsigned long long bound =
+                                __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (a.gk2) {
+#pragma unroll 1
+                                for (int g0 = 0; g0 < a.n_slices; g0 += 8) {
+                                    unsigned long long v = 0ull;
+                                    if (g0 + (lane & 7) < a.n_slices)
+                                        v = __hip_atomic_load(a.gk2 + (int64_t)b * a.n_slices + g0 + (lane & 7),
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                                    for (int o = 1; o < 8; o <<= 1) {
+                                        const unsigned long long p = __shfl_xor(v, o);
+                                        v = p > v ? p : v;
+                                    }
+                                    if (v != ~0ull && v + 1ull < bound) bound = v + 1ull;
+                                }
+                            }
+                            if ((lane & 7) == 0 &&
+                                bound < __hip_atomic_load(gkl + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                                __hip_atomic_store(gkl + q, bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                const unsigned short nb = qbound_from_key<M>(bound, a.smax[b], a.qstep[b], a.qlo[b]);
+                                if (nb < shq[q]) shq[q] = nb;
+                            }
+                        }
+                    }
+                }
+            }
+            if (flushed || (step_no & 3) == 3) {
+                asm volatile("" ::: "memory");
+                thp = *(const u32x2 *)(smem + shq_off);
+            }
+#pragma unroll
+            for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
+            if constexpr (!SKEWED) encode_plain(ccur);
+            load_row(row0 + 2 * stride + lane, cnext);
+            vcur = vnext;
+            vnext = load_valid(row0 + 2 * stride + lane);
+        }
+        if (qcnt) qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
+
+        __syncthreads();
+        for (int q = wave; q < QT; q += NW) {
+            const int b = tile * QT + q;
+            if (b < a.B && lane <= km1)
+                __hip_atomic_store(a.partial + ((int64_t)b * a.n_slices + slice) * a.k + lane, lists[q * 64 + lane],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (a.tile_done) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            volatile unsigned int *s_flag = (volatile unsigned int *)(smem + lock_off);
+            if (tid == 0) {
+                const unsigned int old =
+                    __hip_atomic_fetch_add(a.tile_done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *s_flag = (old + 1u == (unsigned int)(a.n_slices - 1)) ? 1u : 0u;
+            }
+            __syncthreads();
+            if (*s_flag) {
+                for (int q = wave; q < QT; q += NW) {
+                    const int b = tile * QT + q;
+                    if (b >= a.B) continue;
+                    WaveList L;
+                    L.reset();
+                    for (int sl = 0; sl < a.n_slices; ++sl) {
+                        unsigned long long key = ~0ull;
+                        if (lane <= km1)
+                            key = __hip_atomic_load(a.partial + ((int64_t)b * a.n_slices + sl) * a.k + lane,
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        wavelist_merge_sorted(L, (uint32_t)(key >> 32), (uint32_t)key, lane);
+                    }
+                    if (lane <= km1) {
+                        const bool none = (L.hi == kKeyInfHi && L.lo == kIdNone);
+                        const float d = none ? __builtin_inff() : ordered_to_f32(L.hi);
+                        const int64_t id = none ? (int64_t)-1 : a.row_base + (int64_t)L.lo;
+                        if (a.out_packed) {
+                            a.out_packed[((int64_t)b * a.k + lane) * 2 + 0] = id;
+                            a.out_packed[((int64_t)b * a.k + lane) * 2 + 1] = (int64_t)__float_as_uint(d);
+                        } else {
+                            a.out_d[(int64_t)b * a.k + lane] = a.sqrt_out ? __builtin_sqrtf(d) : d;
+                            a.out_i[(int64_t)b * a.k + lane] = id;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace annlite
+
+using namespace annlite;
+
+template <int M, int NQ, int NW, int WPS, bool SKEWED>
+static int launch_qfilter(const ScanArgs &a, int grid, hipStream_t st) {
+    const size_t lds_lut = (size_t)a.Ks * NQ * M * 16;
+    const size_t need = lds_lut + 256 + (size_t)8 * NQ * 64 * 8 + 128 + (size_t)NW * 512;
+    auto fn = adc_scan_qfilter_kernel<M, NQ, NW, WPS, SKEWED>;
+    ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
+    return launch_status("adc_scan_qfilter_kernel");
+}
+
+template <int NW, bool SKEWED>
+static int launch_qfilter64(const ScanArgs &a, int grid, hipStream_t st) {
+    const size_t need = (size_t)(a.Ks + 1) * 512 + 256 + (size_t)4 * 512 + 128 + (size_t)NW * 512;
+    auto fn = adc_scan_qfilter64_kernel<NW, SKEWED>;
+    ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
+    return launch_status("adc_scan_qfilter64_kernel");
+}
+
+int annlite::launch_qfilter_scan(int id, bool sk, const ScanArgs &a, int grid, hipStream_t st) {
+#define ANNLITE_LAUNCH_Q(MM, NQ_, NW_, WPS_) \
+    (sk ? launch_qfilter<MM, NQ_, NW_, WPS_, true>(a, grid, st) : launch_qfilter<MM, NQ_, NW_, WPS_, false>(a, grid, st))
+    switch (id) {
+        case 830: return ANNLITE_LAUNCH_Q(8, 2, 16, 4);
+        case 3230: return ANNLITE_LAUNCH_Q(32, 1, 12, 3);
+        case 1630: return ANNLITE_LAUNCH_Q(16, 2, 12, 3);
+        case 1631: return ANNLITE_LAUNCH_Q(16, 2, 16, 4);
+        case 1632: return ANNLITE_LAUNCH_Q(16, 2, 8, 2);
+        case 6430: return sk ? launch_qfilter64<16, true>(a, grid, st) : launch_qfilter64<16, false>(a, grid, st);
+        case 6431: return sk ? launch_qfilter64<12, true>(a, grid, st) : launch_qfilter64<12, false>(a, grid, st);
+        case 6432: return sk ? launch_qfilter64<8, true>(a, grid, st) : launch_qfilter64<8, false>(a, grid, st);
+        default: set_error("no quantised-filter kernel with id %d", id); return ANNLITE_ERR_UNSUPPORTED;
+    }
+#undef ANNLITE_LAUNCH_Q
+}
