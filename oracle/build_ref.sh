@@ -20,17 +20,21 @@ if [ ! -d "$REF/bindings" ]; then
   echo "build_ref: $REF not present, skipping (GPU box uses committed golden fixtures)"; exit 0
 fi
 mkdir -p "$OUT"
+rm -f "$OUT"/*.cpp "$OUT"/*.c  # never keep generated sources (they quote the reference)
 PYINC=$(python3 -c "import sysconfig; print(sysconfig.get_paths()['include'])")
 NPINC=$(python3 -c "import numpy; print(numpy.get_include())")
 EXT=$(python3 -c "import sysconfig; print(sysconfig.get_config_var('EXT_SUFFIX'))")
 
-# 1) annlite.pq_bind  <- bindings/pq_bindings.pyx (Cython -> C++), generated C++ stays in _ref/
+# 1) annlite.pq_bind  <- bindings/pq_bindings.pyx (Cython -> C++); the generated C++ (it quotes the .pyx
+#    lines) is a temporary outside the repo and is deleted: only the .so stays in _ref/
 if [ ! -f "$OUT/pq_bind$EXT" ] || [ "$REF/bindings/pq_bindings.pyx" -nt "$OUT/pq_bind$EXT" ]; then
+  TMPCPP=$(mktemp -d)/pq_bind.cpp
   cython -+ -3 --module-name annlite.pq_bind \
     -X language_level=3 -X embedsignature=True -X annotation_typing=False \
-    -o "$OUT/pq_bind.cpp" "$REF/bindings/pq_bindings.pyx"
+    -o "$TMPCPP" "$REF/bindings/pq_bindings.pyx"
   g++ -O3 -march=native -fopenmp -std=c++14 -shared -fPIC -w \
-    -I"$PYINC" -I"$NPINC" "$OUT/pq_bind.cpp" -o "$OUT/pq_bind$EXT"
+    -I"$PYINC" -I"$NPINC" "$TMPCPP" -o "$OUT/pq_bind$EXT"
+  rm -rf "$(dirname "$TMPCPP")"
 fi
 
 # 2) annlite.hnsw_bind <- bindings/hnsw_bindings.cpp (pybind11).  pybind11 3.x asserts the GIL
