@@ -324,6 +324,10 @@ def main():
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                 'traffic': traffic, 'kernel': 'adc_scan_qfilter64_kernel' if M == 64 else 'adc_scan_qfilter_kernel', 'kernel_ms': kernel_ms,
                 'algorithmic_bytes_per_launch': scan_bytes, 'lds_lookups_per_s': lookups_per_s,
+                # the limiter the kernel is designed against: one ds_read_b128 (4 LDS cycles) serves 64 lanes x 8
+                # queries (M=64: ds_read_b64, 2 cycles, 64 x 4); 256 CUs at 2.4 GHz
+                'lds': {'achieved': lookups_per_s, 'peak': 256 * 128 * 2.4e9, 'unit': 'look-ups/s',
+                        'frac': lookups_per_s / (256 * 128 * 2.4e9)},
             },
             'cpu_baseline': cpu,
             'with_host_transfer': {'value': host_qps, 'unit': 'queries/s',
