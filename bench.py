@@ -49,7 +49,8 @@ def parse():
     p.add_argument('--train-rows', type=int, default=20480)
     p.add_argument('--train-iters', type=int, default=20)
     p.add_argument('--recall-queries', type=int, default=128, help='queries used for recall@10 (0 = skip)')
-    p.add_argument('--cpu-queries', type=int, default=4, help='queries of the bounded CPU-baseline sample (0 = skip)')
+    p.add_argument('--cpu-queries', type=int, default=256,
+                   help='queries of the bounded single-thread CPU-baseline sample (0 = skip); 256 x 10M rows = ~10 s')
     p.add_argument('--metric', choices=['euclidean', 'cosine', 'inner_product'], default='euclidean',
                    help="BASELINE config 2/3: euclidean; config 4 (10M x 768, m=64, batch 256): cosine")
     p.add_argument('--streams', type=int, choices=[1, 2], default=2, help='streams the timed batches alternate on')
@@ -297,7 +298,7 @@ def main():
             parity = bool(np.array_equal(cd, gd) and np.array_equal(ci, gi))
         threads = pq_oracle.max_threads()
         t0 = time.perf_counter()
-        nq_all = min(B, max(nqc, threads * 2))
+        nq_all = min(B, max(nqc, threads * 64))  # ~5 s on all cores at 10M rows
         pq_oracle.index_search(queries[:nq_all].cpu().numpy(), cb_np, codes_np, omet, k, threads=threads)
         cpu_all_s = time.perf_counter() - t0
         cpu = {
