@@ -216,7 +216,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                     a.gkey ? __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
                 gkl[tid] = gk;
                 ((unsigned long long *)(smem + gjl_off))[tid] = ~0ull;
-                shq[tid] = qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]);
+                // pad queries of the last tile (b >= B) must never pass the filter (their all-zero tables give S = 0
+                // for every row: 15 pad queries made a 1-query batch 15x slower than a 16-query one): 0x7fff - S
+                // never has bit 15 set and never borrows from the neighbouring field
+                shq[tid] = b < a.B ? qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]) : (unsigned short)0x7fff;
             }
             for (int idx = tid; idx < QT * 64; idx += NW * 64) lists[idx] = ~0ull;
         }
@@ -519,7 +522,10 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
                     a.gkey ? __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
                 gkl[tid] = gk;
                 ((unsigned long long *)(smem + gjl_off))[tid] = ~0ull;
-                shq[tid] = qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]);
+                // pad queries of the last tile (b >= B) must never pass the filter (their all-zero tables give S = 0
+                // for every row: 15 pad queries made a 1-query batch 15x slower than a 16-query one): 0x7fff - S
+                // never has bit 15 set and never borrows from the neighbouring field
+                shq[tid] = b < a.B ? qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]) : (unsigned short)0x7fff;
             }
             for (int idx = tid; idx < QT * 64; idx += NW * 64) lists[idx] = ~0ull;
         }

@@ -513,6 +513,29 @@ def test_filter_slack_with_badly_conditioned_tables(ops, oracle):
         assert np.array_equal(i, ri)
 
 
+def test_pad_queries_of_a_ragged_batch_generate_no_candidates(ops, oracle, monkeypatch):
+    """B not a multiple of the 16-query tile: the pad queries (all-zero tables) must not pass the integer filter.
+    They once made a 1-query search 15x slower than a 16-query one; counted through the debug counters."""
+    import torch
+
+    from annlite_amd import _capi
+    from annlite_amd._capi import LUT_L2
+
+    monkeypatch.setenv('ANNLITE_DEBUG_COUNTERS', '1')
+    torch.manual_seed(2)
+    N, M, Ks, k = 200_000, 16, 256, 10
+    codes = torch.randint(0, 256, (N, M), dtype=torch.uint8, device='cuda')
+    cb = torch.randn((M, Ks, 8), device='cuda')
+    for B in (1, 3):
+        q = torch.randn((B, M * 8), device='cuda')
+        d, i = ops.pq_search_topk(LUT_L2, q, cb, ops.codes_skew(codes), k, M, Ks, codes_layout=1)
+        c = _capi.debug_counters()
+        assert c[4] < N // 20, c  # candidate rows of the whole launch (the pads alone used to contribute 15 * N)
+        lut = ops.lut_build(q, cb, LUT_L2).cpu().numpy()
+        rd, ri = oracle.adc_search_c(lut, codes.cpu().numpy(), k)
+        assert np.array_equal(d.cpu().numpy(), rd) and np.array_equal(i.cpu().numpy(), ri)
+
+
 @pytest.mark.parametrize('variant', ['0', '30', '8', '9', '11', '20'])
 def test_scan_kernel_variants_agree(ops, oracle, variant, monkeypatch):
     """every selectable M=16 scan kernel (quantised filter 16/12 waves, fp32 filter 12-wave / 8-wave double
