@@ -134,6 +134,64 @@ __device__ __attribute__((noinline)) void qfilter_flush(const FlushCtx c, uint32
     }
 }
 
+// Final merge of a tile by the last workgroup to arrive.  The NW waves are dealt out over the tile's REAL
+// queries: wave w folds the slices (w % wpq), (w % wpq) + wpq, ... of query w / wpq (a slice is merged only if
+// it holds something better than the running k-th), the wpq lists of a query meet in LDS and its first wave
+// writes the result.  Full tiles of big batches get one wave per query (few slices each); a single query with
+// 256 slices gets all 16 waves (one wave folding 256 slices in sequence cost ~100 us of a 0.3 ms search).
+template <int NW>
+__device__ __forceinline__ void merge_tile_slices(const ScanArgs &a, int b0, int QT, int km1, int wave, int lane,
+                                                  unsigned long long *scratch /* [NW][64], LDS */) {
+    int nq = a.B - b0;
+    if (nq > QT) nq = QT;
+    for (int q0 = 0; q0 < nq; q0 += NW) {
+        const int nqc = nq - q0 < NW ? nq - q0 : NW;
+        const int wpq = NW / nqc;  // waves per query
+        const int my_q = wave / wpq, my_part = wave - my_q * wpq;
+        const bool active = my_q < nqc;
+        const int b = b0 + q0 + my_q;
+        WaveList L;
+        L.reset();
+        if (active) {
+            uint32_t thi = kKeyInfHi, tlo = kIdNone;
+            for (int sl = my_part; sl < a.n_slices; sl += wpq) {
+                unsigned long long key = ~0ull;
+                if (lane <= km1)
+                    key = __hip_atomic_load(a.partial + ((int64_t)b * a.n_slices + sl) * a.k + lane, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t chi = (uint32_t)(key >> 32), clo = (uint32_t)key;
+                if (__ballot(key_less(chi, clo, thi, tlo))) {
+                    wavelist_merge_sorted(L, chi, clo, lane);  // slice lists are ascending over the lanes
+                    thi = __builtin_amdgcn_readlane(L.hi, km1);
+                    tlo = __builtin_amdgcn_readlane(L.lo, km1);
+                }
+            }
+        }
+        if (wpq > 1) {
+            scratch[wave * 64 + lane] = ((unsigned long long)L.hi << 32) | L.lo;
+            __syncthreads();
+            if (active && my_part == 0)
+                for (int w = 1; w < wpq; ++w) {
+                    const unsigned long long o = scratch[(wave + w) * 64 + lane];
+                    wavelist_merge_sorted(L, (uint32_t)(o >> 32), (uint32_t)o, lane);
+                }
+        }
+        if (active && my_part == 0 && lane <= km1) {
+            const bool none = (L.hi == kKeyInfHi && L.lo == kIdNone);
+            const float d = none ? __builtin_inff() : ordered_to_f32(L.hi);
+            const int64_t id = none ? (int64_t)-1 : a.row_base + (int64_t)L.lo;
+            if (a.out_packed) {
+                a.out_packed[((int64_t)b * a.k + lane) * 2 + 0] = id;
+                a.out_packed[((int64_t)b * a.k + lane) * 2 + 1] = (int64_t)__float_as_uint(d);
+            } else {
+                a.out_d[(int64_t)b * a.k + lane] = a.sqrt_out ? __builtin_sqrtf(d) : d;
+                a.out_i[(int64_t)b * a.k + lane] = id;
+            }
+        }
+        if (wpq > 1) __syncthreads();  // scratch is reused by the next chunk
+    }
+}
+
 // =================================================================================================
 // Quantised-filter kernel.  Same discipline as adc_scan_filter_kernel (cheap bound -> exact
 // recompute for the few rows that pass -> bit-exact output) but the cheap bound is an INTEGER sum
@@ -436,34 +494,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                 *s_flag = (old + 1u == (unsigned int)(a.n_slices - 1)) ? 1u : 0u;
             }
             __syncthreads();
-            if (*s_flag) {
-                for (int q = wave; q < QT; q += NW) {
-                    const int b = tile * QT + q;
-                    if (b >= a.B) continue;
-                    WaveList L;
-                    L.reset();
-                    for (int sl = 0; sl < a.n_slices; ++sl) {
-                        unsigned long long key = ~0ull;
-                        if (lane <= km1)
-                            key = __hip_atomic_load(a.partial + ((int64_t)b * a.n_slices + sl) * a.k + lane,
-                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        // every slice list is ascending over the lanes: sorted merge, keep the 64 smallest
-                        wavelist_merge_sorted(L, (uint32_t)(key >> 32), (uint32_t)key, lane);
-                    }
-                    if (lane <= km1) {
-                        const bool none = (L.hi == kKeyInfHi && L.lo == kIdNone);
-                        const float d = none ? __builtin_inff() : ordered_to_f32(L.hi);
-                        const int64_t id = none ? (int64_t)-1 : a.row_base + (int64_t)L.lo;
-                        if (a.out_packed) {
-                            a.out_packed[((int64_t)b * a.k + lane) * 2 + 0] = id;
-                            a.out_packed[((int64_t)b * a.k + lane) * 2 + 1] = (int64_t)__float_as_uint(d);
-                        } else {
-                            a.out_d[(int64_t)b * a.k + lane] = a.sqrt_out ? __builtin_sqrtf(d) : d;
-                            a.out_i[(int64_t)b * a.k + lane] = id;
-                        }
-                    }
-                }
-            }
+            if (*s_flag) merge_tile_slices<NW>(a, tile * QT, QT, km1, wave, lane, (unsigned long long *)(smem + queue_off));
             __syncthreads();  // s_flag (the lock words) is re-initialised by the next item
         }
     }
@@ -699,33 +730,7 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
                 *s_flag = (old + 1u == (unsigned int)(a.n_slices - 1)) ? 1u : 0u;
             }
             __syncthreads();
-            if (*s_flag) {
-                for (int q = wave; q < QT; q += NW) {
-                    const int b = tile * QT + q;
-                    if (b >= a.B) continue;
-                    WaveList L;
-                    L.reset();
-                    for (int sl = 0; sl < a.n_slices; ++sl) {
-                        unsigned long long key = ~0ull;
-                        if (lane <= km1)
-                            key = __hip_atomic_load(a.partial + ((int64_t)b * a.n_slices + sl) * a.k + lane,
-                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        wavelist_merge_sorted(L, (uint32_t)(key >> 32), (uint32_t)key, lane);
-                    }
-                    if (lane <= km1) {
-                        const bool none = (L.hi == kKeyInfHi && L.lo == kIdNone);
-                        const float d = none ? __builtin_inff() : ordered_to_f32(L.hi);
-                        const int64_t id = none ? (int64_t)-1 : a.row_base + (int64_t)L.lo;
-                        if (a.out_packed) {
-                            a.out_packed[((int64_t)b * a.k + lane) * 2 + 0] = id;
-                            a.out_packed[((int64_t)b * a.k + lane) * 2 + 1] = (int64_t)__float_as_uint(d);
-                        } else {
-                            a.out_d[(int64_t)b * a.k + lane] = a.sqrt_out ? __builtin_sqrtf(d) : d;
-                            a.out_i[(int64_t)b * a.k + lane] = id;
-                        }
-                    }
-                }
-            }
+            if (*s_flag) merge_tile_slices<NW>(a, tile * QT, QT, km1, wave, lane, (unsigned long long *)(smem + queue_off));
             __syncthreads();
         }
     }
