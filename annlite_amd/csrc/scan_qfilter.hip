@@ -154,16 +154,25 @@ __device__ __forceinline__ void merge_tile_slices(const ScanArgs &a, int b0, int
         L.reset();
         if (active) {
             uint32_t thi = kKeyInfHi, tlo = kIdNone;
-            for (int sl = my_part; sl < a.n_slices; sl += wpq) {
-                unsigned long long key = ~0ull;
-                if (lane <= km1)
-                    key = __hip_atomic_load(a.partial + ((int64_t)b * a.n_slices + sl) * a.k + lane, __ATOMIC_RELAXED,
-                                            __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t chi = (uint32_t)(key >> 32), clo = (uint32_t)key;
-                if (__ballot(key_less(chi, clo, thi, tlo))) {
-                    wavelist_merge_sorted(L, chi, clo, lane);  // slice lists are ascending over the lanes
-                    thi = __builtin_amdgcn_readlane(L.hi, km1);
-                    tlo = __builtin_amdgcn_readlane(L.lo, km1);
+            // four slice lists in flight per round trip (the loads are device-scope, ~1 us each when chained)
+            for (int sl0 = my_part; sl0 < a.n_slices; sl0 += 4 * wpq) {
+                unsigned long long key[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int sl = sl0 + u * wpq;
+                    key[u] = ~0ull;
+                    if (lane <= km1 && sl < a.n_slices)
+                        key[u] = __hip_atomic_load(a.partial + ((int64_t)b * a.n_slices + sl) * a.k + lane,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t chi = (uint32_t)(key[u] >> 32), clo = (uint32_t)key[u];
+                    if (__ballot(key_less(chi, clo, thi, tlo))) {
+                        wavelist_merge_sorted(L, chi, clo, lane);  // slice lists are ascending over the lanes
+                        thi = __builtin_amdgcn_readlane(L.hi, km1);
+                        tlo = __builtin_amdgcn_readlane(L.lo, km1);
+                    }
                 }
             }
         }
