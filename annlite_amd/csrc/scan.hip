@@ -319,16 +319,20 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
 
 static int round_up(int64_t x, int64_t m) { return (int)(((x + m - 1) / m) * m); }
 
-static void plan_slices(int64_t N, int n_tiles, int waves, int n_cu, bool xcd8, int *n_slices, int64_t *slice_rows) {
+static void plan_slices(int64_t N, int n_tiles, int waves, int n_cu, bool xcd8, int *n_slices, int64_t *slice_rows,
+                        int64_t B = 0) {
     // at least one slice per XCD; more when few query tiles exist, as long as every wave keeps
     // >= 8 steps of 64 rows
-    const int64_t min_rows = (int64_t)waves * 64 * 8;
+    const int64_t min_rows = (int64_t)waves * 64 * (xcd8 ? 16 : 8);
     // XCD-mapped plans: ONE work item per CU when the tiles allow it (every (query, slice) list pays its own
     // logarithmic number of candidate events: 4 slices instead of 8 was 10% faster at 1.25M rows x 1024
     // queries); 1, 2, 4 or a multiple of 8 slices (item_map)
     int64_t want = ((xcd8 ? 1 : 2) * (int64_t)n_cu + n_tiles - 1) / n_tiles;
     int64_t cap = N / min_rows;
     if (want > cap) want = cap;
+    // a single tile with several real queries: every (query, slice) list pays its own candidate events, 128
+    // slices beat 256 from 3 queries on (10M rows: 8 queries 0.23 vs 0.27 ms, 16 queries 0.31 vs 0.40 ms)
+    if (xcd8 && n_tiles == 1 && B > 2 && want > 128) want = 128;
     int64_t ns = want;
     if (xcd8) ns = want <= 1 ? 1 : want <= 2 ? 2 : want <= 4 ? 4 : ((want + 7) / 8) * 8;
     if (ns < 1) ns = 1;
@@ -370,7 +374,7 @@ extern "C" int annlite_scan_plan_query(int64_t N, int64_t M, int64_t Ks, int cod
         const int n_tiles = (int)((B + plan->qt - 1) / plan->qt);
         int ns;
         int64_t sr;
-        plan_slices(N > 0 ? N : 1, n_tiles > 0 ? n_tiles : 1, c.NW, n_cu, true, &ns, &sr);
+        plan_slices(N > 0 ? N : 1, n_tiles > 0 ? n_tiles : 1, c.NW, n_cu, true, &ns, &sr, B);
         plan->n_slices = ns;
         plan->lut_floats = ((B + 15) / 16) * 16 * M * Ks;  // padded to 16 queries
         // [partial keys][Smax f32 x Bpad][qstep f32 x Bpad][qlo f64 x Bpad][lo,hi f32 x Bpad*M][q16 u16 x Bpad*M*Ks]
@@ -469,7 +473,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
     {
         int ns;
         int64_t sr;
-        plan_slices(N > 0 ? N : 1, a.n_tiles, plan.waves, n_cu, plan.fast != 0, &ns, &sr);
+        plan_slices(N > 0 ? N : 1, a.n_tiles, plan.waves, n_cu, plan.fast != 0, &ns, &sr, B);
         a.slice_rows = sr;
     }
     // slots of slices that hold no rows stay "none"
