@@ -53,7 +53,8 @@ def parse():
                    help='queries of the bounded single-thread CPU-baseline sample (0 = skip); 256 x 10M rows = ~10 s')
     p.add_argument('--metric', choices=['euclidean', 'cosine', 'inner_product'], default='euclidean',
                    help="BASELINE config 2/3: euclidean; config 4 (10M x 768, m=64, batch 256): cosine")
-    p.add_argument('--streams', type=int, choices=[1, 2], default=2, help='streams the timed batches alternate on')
+    p.add_argument('--streams', type=int, choices=[0, 1, 2], default=0,
+                   help='streams the timed batches alternate on (0 = auto: 2 when the exchange runs, else 1)')
     p.add_argument('--layout', choices=['skewed', 'plain'], default='skewed')
     p.add_argument('--no-rerank', action='store_true', help='skip the (untimed-in-value) exact re-rank leg')
     return p.parse_args()
@@ -142,7 +143,8 @@ def main():
     def step():
         return sharded.search_batch(queries, limit=k)
 
-    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)] if args.streams == 2 else [torch.cuda.current_stream(dev)]
+    n_streams = args.streams or (2 if (world > 1 or os.environ.get('ANNLITE_FORCE_GATHER')) else 1)
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)] if n_streams == 2 else [torch.cuda.current_stream(dev)]
     for st in streams:
         st.wait_stream(torch.cuda.current_stream(dev))
     for w_i in range(max(args.warmup, len(streams))):  # (every stream warms its own scratch buffer up)
