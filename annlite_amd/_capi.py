@@ -33,6 +33,7 @@ SYMBOLS = (
     'annlite_lut_retile',
     'annlite_adc_dist',
     'annlite_adc_gather',
+    'annlite_graph_search',
     'annlite_adc_scan_topk',
     'annlite_adc_scan_topk_packed',
     'annlite_pq_search_workspace_bytes',
@@ -97,6 +98,7 @@ def lib() -> ctypes.CDLL:
     L.annlite_lut_retile.argtypes = [vp, i64, i64, i64, vp, i32, vp]
     L.annlite_adc_dist.argtypes = [vp, i64, i64, vp, i32, i64, vp, vp]
     L.annlite_adc_gather.argtypes = [vp, i64, i64, i64, vp, i32, i64, vp, i64, vp, vp]
+    L.annlite_graph_search.argtypes = [vp, i32, vp, i64, vp, i64, i64, i64, vp, vp, i64, i32, vp, vp, vp]
     L.annlite_adc_scan_topk.argtypes = [vp, i32, i32, i64, i64, i64, vp, vp, i64, i64, i64, vp, vp, vp, sz, vp]
     L.annlite_adc_scan_candidates.argtypes = L.annlite_adc_scan_topk.argtypes
     L.annlite_adc_scan_topk_packed.argtypes = [vp, i32, i32, i64, i64, i64, vp, vp, i64, i64, i64, vp, vp, sz, vp]

@@ -15,6 +15,8 @@ SYMBOLS = (
     'annlite_hnsw_add',
     'annlite_hnsw_search',
     'annlite_hnsw_mark_deleted',
+    'annlite_hnsw_links_per_node',
+    'annlite_hnsw_export',
     'annlite_hnsw_save',
     'annlite_hnsw_load',
 )
@@ -40,6 +42,8 @@ def lib():
         L.annlite_hnsw_add.argtypes = [vp, vp, vp, vp, i64, i32]
         L.annlite_hnsw_search.argtypes = [vp, vp, i64, i32, vp, vp, i32]
         L.annlite_hnsw_mark_deleted.argtypes = [vp, i64]
+        L.annlite_hnsw_links_per_node.argtypes = [vp]
+        L.annlite_hnsw_export.argtypes = [vp, i64, vp, vp, i64, vp]
         L.annlite_hnsw_save.argtypes = [vp, ctypes.c_char_p]
         L.annlite_hnsw_load.argtypes = [ctypes.c_char_p]
         L.annlite_hnsw_load.restype = vp

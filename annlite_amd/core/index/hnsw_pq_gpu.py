@@ -31,14 +31,18 @@ from .pq_flat_gpu import PQFlatGpuIndex
 
 class HnswPQGpuIndex(PQFlatGpuIndex):
     def __init__(self, dim: int, pq_codec=None, metric: Metric = Metric.COSINE, ef_construction: int = 200,
-                 ef_search: int = 50, max_connection: int = 16, n_threads: int = 0, seed: int = 100, **kwargs):
+                 ef_search: int = 50, max_connection: int = 16, n_threads: int = 0, seed: int = 100,
+                 walk: str = 'gpu', **kwargs):
         super().__init__(dim, pq_codec=pq_codec, metric=metric, **kwargs)
         self.ef_construction = int(ef_construction)  # hnsw/index.py:66-69
         self.ef_search = int(ef_search)
         self.max_connection = int(max_connection)
         self.n_threads = int(n_threads)
         self.seed = int(seed)
+        assert walk in ('gpu', 'host')
+        self.walk = walk  # where the graph is walked at query time: GPU kernel (default) or the host library
         self._graph = None
+        self._gpu_graph = None  # (key, links i32 [N, L+1], seeds i32 [S]) exported for the GPU walk
 
     # ------------------------------------------------------------------ graph handle
     def _ensure_graph(self):
@@ -97,10 +101,38 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
             self._graph = None
 
     # ------------------------------------------------------------------ search
+    def _export_graph(self):
+        """Level-0 lists + seed set of the host graph on the device (re-exported after inserts / deletes)."""
+        key = (int(gc.lib().annlite_hnsw_size(self._graph)), self._size)
+        if self._gpu_graph is None or self._gpu_graph[0] != key:
+            n = self._n_rows
+            lpn = int(gc.lib().annlite_hnsw_links_per_node(self._graph))
+            links = np.empty((n, lpn + 1), dtype=np.uint32)
+            seeds = np.empty((1024,), dtype=np.int64)
+            ns = ctypes.c_int64(0)
+            gc.check(gc.lib().annlite_hnsw_export(self._graph, n, links.ctypes.data, seeds.ctypes.data, seeds.size,
+                                                  ctypes.byref(ns)), 'annlite_hnsw_export')
+            dev = self._codes.device
+            self._gpu_graph = (key, torch.from_numpy(links.view(np.int32)).to(dev),
+                               torch.from_numpy(seeds[:ns.value].astype(np.int32)).to(dev))
+        return self._gpu_graph[1], self._gpu_graph[2]
+
+    def _gpu_walk_ok(self) -> bool:
+        return self.walk == 'gpu' and self.M in (8, 16, 32) and self.Ks <= 256
+
     def candidates(self, q_dev: torch.Tensor, ef: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Graph walk on the host: ``(ids i64 [B, ef], pq distance f32 [B, ef])`` on the device, -1 / +inf padded."""
+        """Graph walk: ``(ids i64 [B, ef], L2 pq distance f32 [B, ef])`` on the device, -1 / +inf padded, ascending.
+        ``walk='gpu'``: ``annlite_graph_search`` (one wave per query); ``walk='host'``: libannlite_graph.so."""
         ef = int(ef or self.ef_search)
         _, xg = self.pq_codec.scan_inputs(q_dev)
+        if self._gpu_walk_ok() and ef <= 256:
+            from ..._capi import LAYOUT_BMK, LUT_L2
+
+            self._ensure_graph()
+            links, seeds = self._export_graph()
+            lut = ops.lut_build(xg, self.pq_codec.codebooks_dev, LUT_L2, LAYOUT_BMK)
+            return ops.graph_search(links, seeds, self._plain_table(self._n_rows), lut, ef, valid_bits=self._valid,
+                                    n_rows=self._n_rows)
         x_np = np.ascontiguousarray(xg.cpu().numpy(), dtype=np.float32)
         B = x_np.shape[0]
         ids = np.empty((B, ef), dtype=np.int64)

@@ -1,0 +1,252 @@
+// graph.hip -- beam search over the level-0 lists of the HNSW-over-PQ graph ON THE GPU (BASELINE config 5).
+//
+// The reference walks its graph on the host, one query per call (hnsw_bindings.cpp:302-375 -> hnswalg.h
+// searchBaseLayerST); libannlite_graph.so does the same, batch-parallel over CPU threads.  This kernel
+// moves the walk next to the code table: ONE WAVE PER QUERY, its L2 look-up table (M*Ks fp32 = 16 KB at
+// M=16) and a visited hash set in LDS, the ef_search best nodes seen so far as a sorted list spread over
+// the lanes' registers (two entries per lane for ef = 128).  The upper layers of the hierarchy are not
+// descended: the nodes of its top levels (annlite_hnsw_export: up to 4096 "seeds") are scanned flat --
+// a coalesced gather of a few thousand code rows -- and the walk starts from the best of them.
+//
+// Per expansion (best unexpanded node of the list): its link list is one coalesced 132-byte read, the
+// lanes that hold unseen neighbours fetch those rows' code bytes (the only random HBM traffic: 16 x 64-byte
+// sectors) and evaluate hnswlib::PQLookup from LDS -- fp32 adds in ascending sub-space order, the same
+// bits as the flat scan (space_pq.h:15-37) -- and the survivors are inserted into the sorted list.
+// The walk ends when the list holds no unexpanded node (hnswalg.h searchBaseLayerST's stop rule).
+#include "scan_common.h"
+
+namespace annlite {
+
+constexpr uint32_t kEmpty = 0xffffffffu;
+
+// sorted list of 64 * E entries across the lanes: entry i lives in lane i % 64, slot i / 64
+template <int E>
+struct BeamList {
+    uint32_t hi[E], lo[E];  // ordered distance key, node id
+    bool exp[E];            // expanded already
+};
+
+template <int E>
+__device__ __forceinline__ void beam_insert(BeamList<E> &L, uint32_t chi, uint32_t clo, int lane) {
+    // entries smaller than the candidate form a prefix of the list
+    int pos = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) pos += __popcll(__ballot(key_less(L.hi[e], L.lo[e], chi, clo)));
+    // shift entries [pos, end) up by one, dropping the last; entry i - 1 of slot e lane l is (e, l-1), or (e-1, 63) for l = 0
+    uint32_t phi[E], plo[E];
+    bool pex[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        phi[e] = __shfl_up(L.hi[e], 1);
+        plo[e] = __shfl_up(L.lo[e], 1);
+        pex[e] = __shfl_up((int)L.exp[e], 1) != 0;
+    }
+#pragma unroll
+    for (int e = E - 1; e >= 1; --e) {
+        const uint32_t bh = __builtin_amdgcn_readlane(L.hi[e - 1], 63), bl = __builtin_amdgcn_readlane(L.lo[e - 1], 63);
+        const bool bx = __builtin_amdgcn_readlane((int)L.exp[e - 1], 63) != 0;
+        if (lane == 0) {
+            phi[e] = bh;
+            plo[e] = bl;
+            pex[e] = bx;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int idx = e * 64 + lane;
+        if (idx == pos) {
+            L.hi[e] = chi;
+            L.lo[e] = clo;
+            L.exp[e] = false;
+        } else if (idx > pos) {
+            L.hi[e] = phi[e];
+            L.lo[e] = plo[e];
+            L.exp[e] = pex[e];
+        }
+    }
+}
+
+template <int M, int E>
+__global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *__restrict__ links, int links_per_node,
+                                                               const uint32_t *__restrict__ seeds, int n_seeds,
+                                                               const uint8_t *__restrict__ codes, int64_t N,
+                                                               const uint32_t *__restrict__ valid,
+                                                               const float *__restrict__ lut_bmk, int B, int Ks, int ef,
+                                                               int hash_bits, int64_t *__restrict__ out_ids,
+                                                               float *__restrict__ out_dist) {
+    constexpr int CW = M / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * (blockDim.x >> 6) + wave;  // 1..4 waves per workgroup, as many as the LDS holds
+    if (b >= B) return;  // (whole waves leave; no block-wide barrier below)
+    const uint32_t hash_n = 1u << hash_bits;
+    const size_t per_wave = (size_t)M * Ks * 4 + (size_t)hash_n * 4;  // (same formula as launch_beam)
+    float *s_lut = (float *)(smem + wave * per_wave);
+    uint32_t *s_hash = (uint32_t *)(smem + wave * per_wave + (size_t)M * Ks * 4);
+    {
+        const f32x4 *src = (const f32x4 *)(lut_bmk + (int64_t)b * M * Ks);
+        for (int i = lane; i < M * Ks / 4; i += 64) ((f32x4 *)s_lut)[i] = src[i];
+        for (uint32_t i = lane; i < hash_n / 4; i += 64) ((u32x4 *)s_hash)[i] = (u32x4){kEmpty, kEmpty, kEmpty, kEmpty};
+    }
+    // (one wave: its LDS writes are visible to its own later reads in program order)
+
+    auto visit = [&](uint32_t node) -> bool {  // true if the node was NOT seen before (and is recorded now)
+        uint32_t h = (node * 2654435761u) >> (32 - hash_bits);
+        for (uint32_t probe = 0; probe < hash_n; ++probe) {
+            const uint32_t old = atomicCAS(s_hash + h, kEmpty, node);
+            if (old == kEmpty) return true;
+            if (old == node) return false;
+            h = (h + 1) & (hash_n - 1);
+        }
+        return false;  // table full: treat as seen (the walk ends a little early; ef <= 256 never gets here)
+    };
+    auto pq_lookup = [&](uint32_t node) -> float {  // hnswlib::PQLookup: ascending-m fp32 adds
+        const uint32_t *p = (const uint32_t *)(codes + (int64_t)node * M);
+        uint32_t c[CW];
+#pragma unroll
+        for (int i = 0; i < CW; ++i) c[i] = p[i];
+        float d = 0.f;
+#pragma unroll
+        for (int m = 0; m < M; ++m) d += s_lut[m * Ks + ((c[m / 4] >> (8 * (m % 4))) & 0xffu)];
+        return d;
+    };
+    auto is_valid = [&](uint32_t node) -> bool { return !valid || ((valid[node >> 5] >> (node & 31)) & 1u); };
+
+    BeamList<E> L;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        L.hi[e] = kKeyInfHi;
+        L.lo[e] = kIdNone;
+        L.exp[e] = true;  // empty slots are never picked
+    }
+    const int cap = ef < 64 * E ? ef : 64 * E;  // entries beyond `cap` are ignored at the end
+    auto worst = [&](uint32_t &whi, uint32_t &wlo) {
+        const int i = cap - 1;
+        whi = kKeyInfHi;
+        wlo = kIdNone;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (i / 64 == e) {
+                whi = __builtin_amdgcn_readlane(L.hi[e], i % 64);
+                wlo = __builtin_amdgcn_readlane(L.lo[e], i % 64);
+            }
+    };
+    auto offer = [&](bool mine, uint32_t node, float d) {
+        uint32_t whi, wlo;
+        worst(whi, wlo);
+        const uint32_t khi = f32_to_ordered(d);
+        unsigned long long pm = __ballot(mine && key_less(khi, node, whi, wlo));
+        while (pm) {
+            const int src = __builtin_ctzll(pm);
+            pm &= pm - 1;
+            const uint32_t chi = __builtin_amdgcn_readlane(khi, src), clo = __builtin_amdgcn_readlane(node, src);
+            worst(whi, wlo);
+            if (key_less(chi, clo, whi, wlo)) beam_insert<E>(L, chi, clo, lane);
+        }
+    };
+
+    // ---- seeds: the top of the hierarchy, scanned flat -------------------------------------------------
+    // (seeds are distinct: no visited check while scanning them; only the ones that made the list are recorded --
+    // recording all of them would fill the hash table before the walk starts)
+    for (int s0 = 0; s0 < n_seeds; s0 += 64) {
+        const bool have = s0 + lane < n_seeds;
+        const uint32_t node = have ? seeds[s0 + lane] : 0u;
+        const bool mine = have && (int64_t)node < N;
+        const float d = mine ? pq_lookup(node) : 0.f;
+        offer(mine, node, d);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (L.lo[e] != kIdNone) visit(L.lo[e]);
+
+    // ---- walk ------------------------------------------------------------------------------------------
+    for (;;) {
+        int pick = -1;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (pick < 0) {
+                const unsigned long long m = __ballot(!L.exp[e] && (e * 64 + lane) < cap);
+                if (m) pick = e * 64 + __builtin_ctzll(m);
+            }
+        }
+        if (pick < 0) break;
+        uint32_t node = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (pick / 64 == e) {
+                node = __builtin_amdgcn_readlane(L.lo[e], pick % 64);
+                if (lane == pick % 64) L.exp[e] = true;
+            }
+        const uint32_t *ll = links + (int64_t)node * (links_per_node + 1);
+        const uint32_t cnt = ll[0];
+        bool mine = false;
+        uint32_t nb = 0;
+        float d = 0.f;
+        for (uint32_t base = 0; base < cnt; base += 64) {  // (links_per_node <= 64 in practice: one round)
+            mine = base + lane < cnt;
+            nb = mine ? ll[1 + base + lane] : 0u;
+            mine = mine && (int64_t)nb < N && visit(nb);
+            d = mine ? pq_lookup(nb) : 0.f;
+            offer(mine, nb, d);
+        }
+    }
+
+    // ---- result: the list, ascending; deleted rows dropped here (they still route the walk, like hnswlib) ---
+    // compacting is left to the host-side top-k (ids of dropped rows become -1 / +inf)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = e * 64 + lane;
+        if (i < ef) {
+            const bool none = (L.hi[e] == kKeyInfHi && L.lo[e] == kIdNone) || i >= cap || !is_valid(L.lo[e]);
+            out_ids[(int64_t)b * ef + i] = none ? (int64_t)-1 : (int64_t)L.lo[e];
+            out_dist[(int64_t)b * ef + i] = none ? __builtin_inff() : ordered_to_f32(L.hi[e]);
+        }
+    }
+}
+
+}  // namespace annlite
+
+using namespace annlite;
+
+template <int M, int E>
+static int launch_beam(const uint32_t *links, int lpn, const uint32_t *seeds, int n_seeds, const uint8_t *codes, int64_t N,
+                       const uint32_t *valid, const float *lut, int64_t B, int64_t Ks, int ef, int hash_bits,
+                       int64_t *out_ids, float *out_dist, hipStream_t st) {
+    const size_t per_wave = (size_t)M * Ks * 4 + ((size_t)4 << hash_bits);
+    int wpb = (int)((size_t)160 * 1024 / per_wave);
+    if (wpb > 4) wpb = 4;
+    ANNLITE_REQUIRE(wpb >= 1, "M * Ks tables do not fit the LDS");
+    const size_t lds = wpb * per_wave;
+    auto fn = graph_beam_search_kernel<M, E>;
+    ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fn, dim3((unsigned)((B + wpb - 1) / wpb)), dim3(wpb * 64), lds, st, links, lpn, seeds, n_seeds, codes, N,
+                       valid, lut, (int)B, (int)Ks, ef, hash_bits, out_ids, out_dist);
+    return launch_status("graph_beam_search_kernel");
+}
+
+extern "C" int annlite_graph_search(const uint32_t *links_dev, int links_per_node, const uint32_t *seeds_dev, int64_t n_seeds,
+                                    const void *codes_dev, int64_t N, int64_t M, int64_t Ks,
+                                    const uint32_t *valid_bits_dev, const float *lut_bmk_dev, int64_t B, int ef,
+                                    int64_t *out_ids_dev, float *out_dist_dev, void *stream) {
+    ANNLITE_REQUIRE(B >= 0 && N >= 0 && ef >= 1 && ef <= 256, "bad B=%lld N=%lld ef=%d (ef <= 256)", (long long)B,
+                    (long long)N, ef);
+    ANNLITE_REQUIRE(Ks >= 1 && Ks <= 256 && (M == 8 || M == 16 || M == 32), "graph search supports M in {8,16,32}, Ks <= 256");
+    ANNLITE_REQUIRE(links_per_node >= 1 && n_seeds >= 1 && N < (1ll << 32) - 1, "bad graph");
+    if (B == 0) return ANNLITE_OK;
+    ANNLITE_REQUIRE(links_dev && seeds_dev && codes_dev && lut_bmk_dev && out_ids_dev && out_dist_dev, "null device pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int hash_bits = ef <= 64 ? 12 : ef <= 128 ? 13 : 14;  // 4096 / 8192 / 16384 entries: a walk records ~25 nodes per list entry
+    const uint8_t *codes = (const uint8_t *)codes_dev;
+#define ANNLITE_BEAM(MM)                                                                                                \
+    (ef <= 64 ? launch_beam<MM, 1>(links_dev, links_per_node, seeds_dev, (int)n_seeds, codes, N, valid_bits_dev, lut_bmk_dev, \
+                                   B, Ks, ef, hash_bits, out_ids_dev, out_dist_dev, st)                               \
+     : ef <= 128 ? launch_beam<MM, 2>(links_dev, links_per_node, seeds_dev, (int)n_seeds, codes, N, valid_bits_dev,     \
+                                      lut_bmk_dev, B, Ks, ef, hash_bits, out_ids_dev, out_dist_dev, st)               \
+                 : launch_beam<MM, 4>(links_dev, links_per_node, seeds_dev, (int)n_seeds, codes, N, valid_bits_dev,     \
+                                      lut_bmk_dev, B, Ks, ef, hash_bits, out_ids_dev, out_dist_dev, st))
+    if (M == 8) return ANNLITE_BEAM(8);
+    if (M == 16) return ANNLITE_BEAM(16);
+    return ANNLITE_BEAM(32);
+#undef ANNLITE_BEAM
+}

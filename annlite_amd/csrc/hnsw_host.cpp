@@ -481,6 +481,37 @@ int annlite_hnsw_search(const annlite_hnsw *g, const float *queries, int64_t B, 
     return 0;
 }
 
+int annlite_hnsw_export(const annlite_hnsw *g, int64_t n_rows, uint32_t *links_out, int64_t *seeds_out, int64_t max_seeds,
+                        int64_t *n_seeds_out) {
+    if (!g || n_rows < 0 || n_rows > g->cap || !links_out || !seeds_out || !n_seeds_out || max_seeds < 1) {
+        set_error("bad arguments");
+        return 1;
+    }
+    const size_t stride = (size_t)g->M0 + 1;
+    std::memcpy(links_out, g->link0.data(), (size_t)n_rows * stride * 4);
+    // seed set: every node of the highest levels, as many levels as fit max_seeds (the top of the hierarchy,
+    // which the GPU walk scans flat instead of descending)
+    int lv = g->maxlevel;
+    std::vector<int64_t> count((size_t)std::max(lv, 0) + 2, 0);
+    for (int64_t i = 0; i < n_rows; ++i)
+        if (g->level[(size_t)i] >= 0 && !g->deleted[(size_t)i]) count[(size_t)std::min(g->level[(size_t)i], lv)]++;
+    int64_t acc = 0;
+    int min_level = lv;
+    for (int l = lv; l >= 0; --l) {
+        if (acc + count[(size_t)l] > max_seeds && acc > 0) break;
+        acc += count[(size_t)l];
+        min_level = l;
+        if (acc >= max_seeds) break;
+    }
+    int64_t ns = 0;
+    for (int64_t i = 0; i < n_rows && ns < max_seeds; ++i)
+        if (g->level[(size_t)i] >= min_level && !g->deleted[(size_t)i]) seeds_out[ns++] = i;
+    *n_seeds_out = ns;
+    return 0;
+}
+
+int annlite_hnsw_links_per_node(const annlite_hnsw *g) { return g ? g->M0 : 0; }
+
 int annlite_hnsw_mark_deleted(annlite_hnsw *g, int64_t label) {
     if (!g || label < 0 || label >= g->cap || g->level[(size_t)label] < 0) {
         set_error("label %lld not in the graph", (long long)label);

@@ -102,6 +102,21 @@ def adc_gather(lut_bmk: torch.Tensor, codes: torch.Tensor, cand: torch.Tensor) -
     return out
 
 
+def graph_search(links: torch.Tensor, seeds: torch.Tensor, codes: torch.Tensor, lut_bmk: torch.Tensor, ef: int,
+                 valid_bits: Optional[torch.Tensor] = None, n_rows: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """GPU beam search over exported HNSW level-0 lists (``annlite_graph_search``): ``links`` i32 [N, L+1]
+    (count, ids), ``seeds`` i32 [S], PLAIN ``codes`` u8 [N, M], L2 tables f32 [B, M, Ks].  Returns
+    (ids i64 [B, ef] ascending by PQ distance, -1 padded; dist f32 [B, ef])."""
+    B, M, Ks = lut_bmk.shape
+    N = codes.shape[0] if n_rows is None else n_rows
+    out_i = torch.empty((B, ef), dtype=torch.int64, device=codes.device)
+    out_d = torch.empty((B, ef), dtype=torch.float32, device=codes.device)
+    check(lib().annlite_graph_search(links.data_ptr(), links.shape[1] - 1, seeds.data_ptr(), seeds.numel(), codes.data_ptr(),
+                                     N, M, Ks, _ptr(valid_bits), lut_bmk.data_ptr(), B, int(ef), out_i.data_ptr(),
+                                     out_d.data_ptr(), stream_ptr()), 'graph_search')
+    return out_i, out_d
+
+
 class ScanWorkspace:
     """Re-usable device scratch for the scan (avoids an allocation per search call).  One buffer PER STREAM:
     batches issued on different streams run concurrently (the next batch's kernels fill the CUs the previous

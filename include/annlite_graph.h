@@ -40,6 +40,12 @@ ANNLITE_GRAPH_API int annlite_hnsw_add(annlite_hnsw *g, const float *x, const ui
  * Replaces the graph part of Index.knn_query(query, k, dtables) (hnsw/index.py:139-167). */
 ANNLITE_GRAPH_API int annlite_hnsw_search(const annlite_hnsw *g, const float *queries, int64_t B, int ef,
                                           int64_t *out_ids, float *out_dist, int n_threads);
+/* For the GPU walk (annlite_graph_search in annlite_hip.h): the level-0 link lists of rows [0, n_rows) as
+ * u32 [n_rows][links_per_node + 1] (count, ids) and a seed set -- all nodes of the top levels of the hierarchy,
+ * as many levels as fit max_seeds -- which the GPU scans flat instead of descending the upper layers. */
+ANNLITE_GRAPH_API int annlite_hnsw_links_per_node(const annlite_hnsw *g);
+ANNLITE_GRAPH_API int annlite_hnsw_export(const annlite_hnsw *g, int64_t n_rows, uint32_t *links_out, int64_t *seeds_out,
+                                          int64_t max_seeds, int64_t *n_seeds_out);
 ANNLITE_GRAPH_API int annlite_hnsw_mark_deleted(annlite_hnsw *g, int64_t label);
 ANNLITE_GRAPH_API int annlite_hnsw_save(const annlite_hnsw *g, const char *path);
 ANNLITE_GRAPH_API annlite_hnsw *annlite_hnsw_load(const char *path);

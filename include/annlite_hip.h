@@ -129,6 +129,20 @@ ANNLITE_API int annlite_adc_gather(const float *lut_bmk_dev, int64_t B, int64_t 
                        int code_bytes, int64_t N, const int64_t *cand_dev, int64_t R, float *out_dev,
                        void *stream);
 
+/* Beam search over the level-0 lists of an HNSW-over-PQ graph, on the GPU (BASELINE config 5): one wave per
+ * query, its L2 table and a visited set in LDS, the ef best nodes as a sorted list in registers.
+ * replaces: the graph walk of hnsw_bind.Index.knn_query (bindings/hnsw_bindings.cpp:302-375 ->
+ * include/hnswlib/hnswalg.h searchBaseLayerST) for a whole batch; edge distances are hnswlib::PQLookup
+ * (space_pq.h:15-37) bit for bit.  The graph comes from libannlite_graph.so (annlite_hnsw_export).
+ * links_dev u32 [N][links_per_node + 1] (count, ids) ; seeds_dev u32 [n_seeds] DISTINCT nodes (top of the
+ * hierarchy, scanned flat) ; codes_dev u8 [N][M] PLAIN ; lut_bmk_dev f32 [B][M][Ks] L2 tables ; ef <= 256 ; M in {8, 16, 32}
+ * out_ids_dev i64 [B][ef] ascending by distance (-1 padded, deleted rows per valid_bits dropped),
+ * out_dist_dev f32 [B][ef] (+inf padded). */
+ANNLITE_API int annlite_graph_search(const uint32_t *links_dev, int links_per_node, const uint32_t *seeds_dev,
+                         int64_t n_seeds, const void *codes_dev, int64_t N, int64_t M, int64_t Ks,
+                         const uint32_t *valid_bits_dev, const float *lut_bmk_dev, int64_t B, int ef,
+                         int64_t *out_ids_dev, float *out_dist_dev, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Batched flat ADC scan + top-k: the hot path.
  * replaces, for B queries in ONE launch: PQIndex.search (annlite/core/index/pq_index.py:29-56:

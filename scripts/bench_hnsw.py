@@ -93,17 +93,27 @@ def timed(fn):
 
 
 res = {}
-for name, rerank, graph in (('hnsw_adc', False, True), ('hnsw_exact_rerank', True, True),
-                            ('exhaustive_adc', False, False), ('exhaustive_exact_rerank', True, False)):
+for name, rerank, graph, walk in (('hnsw_gpu_walk_adc', False, True, 'gpu'), ('hnsw_gpu_walk_exact_rerank', True, True, 'gpu'),
+                                  ('hnsw_host_walk_adc', False, True, 'host'), ('hnsw_host_walk_exact_rerank', True, True, 'host'),
+                                  ('exhaustive_adc', False, False, None), ('exhaustive_exact_rerank', True, False, None)):
     index.rerank = rerank
+    if walk:
+        index.walk = walk
     fn = (lambda: index.search_batch(q, limit=k)) if graph else (lambda: index.search_exhaustive(q, limit=k))
     (d, i), qps = timed(fn)
     res[name] = {'queries_per_s': qps, 'recall_at_10': recall(i)}
-# the host part alone (graph walk, all cores)
-t = time.perf_counter()
-for _ in range(a.steps):
+# the walks alone
+walks = {}
+for walk in ('gpu', 'host'):
+    index.walk = walk
     index.candidates(q, a.ef_search)
-walk_qps = B * a.steps / (time.perf_counter() - t)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(a.steps):
+        index.candidates(q, a.ef_search)
+    torch.cuda.synchronize()
+    walks[walk] = B * a.steps / (time.perf_counter() - t)
+walk_qps = walks
 print(json.dumps({'config': f'HNSW-over-PQ: {N} x {D}-dim, PQ m={M} ks=256, L2, max_connection={a.max_connection}, '
                             f'ef_construction={a.ef_construction}, ef_search={a.ef_search}, batch {B}, k={k}',
                   'build_s': build_s, 'build_rows_per_s': N / build_s, 'host_cpus_reported': os.cpu_count(), 'note': 'the graph library starts min(CPUs, affinity, cgroup quota) threads',

@@ -666,8 +666,9 @@ def test_bench_under_torchrun_rccl_gather_path(tmp_path):
 
 
 # ------------------------------------------------------------------------------------ config 5: HNSW-over-PQ
+@pytest.mark.parametrize('walk', ['gpu', 'host'])
 @pytest.mark.parametrize('mname,metric', [('euclidean', 1), ('cosine', 3)])
-def test_hnsw_pq_candidates_with_gpu_rerank(ops, mname, metric):
+def test_hnsw_pq_candidates_with_gpu_rerank(ops, mname, metric, walk):
     """HnswPQGpuIndex: graph candidates (host) + distances / top-k on the GPU.  Against the exhaustive scan with
     the same codec: the ids agree for >= 90 % of the top-10, and where an id is returned its distance is the
     exhaustive scan's distance bit for bit (same a2 / PQLookup sum); with rerank, recall vs exact search."""
@@ -684,7 +685,7 @@ def test_hnsw_pq_candidates_with_gpu_rerank(ops, mname, metric):
     codec.seed = 1
     codec.fit(x[:8192], iter=10)
     flat = PQFlatGpuIndex(dim=D, metric=Metric(metric), pq_codec=codec, initial_size=N)
-    hn = HnswPQGpuIndex(dim=D, metric=Metric(metric), pq_codec=codec, initial_size=N, ef_search=128, rerank=True)
+    hn = HnswPQGpuIndex(dim=D, metric=Metric(metric), pq_codec=codec, initial_size=N, ef_search=128, rerank=True, walk=walk)
     ids = list(range(N))
     flat.add_with_ids(x, ids)
     hn.add_with_ids(x[:N // 2], ids[:N // 2])  # two batches: the second inserts into a populated graph
