@@ -701,6 +701,17 @@ def test_hnsw_pq_candidates_with_gpu_rerank(ops, mname, metric, walk):
         for j, i in enumerate(hi[b]):
             if int(i) in pos:
                 assert hd[b][j] == fd[b][pos[int(i)]]
+    # the walk's own output: ascending, and every distance is the PQLookup sum of that row under the L2 tables
+    # (bit-equal to the gather kernel), whichever side walked the graph
+    from annlite_amd._capi import LAYOUT_BMK, LUT_L2
+    qd = hn._pre(torch.from_numpy(q).cuda())
+    cid, cd = hn.candidates(qd, 128)
+    _, xg = codec.scan_inputs(qd)
+    lut_l2 = ops.lut_build(xg, codec.codebooks_dev, LUT_L2, LAYOUT_BMK)
+    want = ops.adc_gather(lut_l2, hn._plain_table(N), cid)
+    ok = cid >= 0
+    assert torch.equal(cd[ok], want[ok]) and bool((cd[:, 1:] >= cd[:, :-1]).all())
+    assert bool(((cid[:, 1:] != cid[:, :-1]) | ~ok[:, 1:]).all())  # no node twice
     # reference single-query signature + deletions
     d1, i1 = hn.search(q[0], limit=k)
     assert np.array_equal(i1, hi[0][hi[0] >= 0])
