@@ -3,7 +3,7 @@
 // The reference walks its graph on the host, one query per call (hnsw_bindings.cpp:302-375 -> hnswalg.h
 // searchBaseLayerST); libannlite_graph.so does the same, batch-parallel over CPU threads.  This kernel
 // moves the walk next to the code table: ONE WAVE PER QUERY, its L2 look-up table (M*Ks fp32 = 16 KB at
-// M=16) and a visited hash set in LDS, the ef_search best nodes seen so far as a sorted list spread over
+// M=16) and a 4096-entry visited hash set (16 KB) in LDS, the ef_search best nodes seen so far as a sorted list spread over
 // the lanes' registers (two entries per lane for ef = 128).  The upper layers of the hierarchy are not
 // descended: the nodes of its top levels (annlite_hnsw_export: up to 4096 "seeds") are scanned flat --
 // a coalesced gather of a few thousand code rows -- and the walk starts from the best of them.
@@ -93,13 +93,13 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
 
     auto visit = [&](uint32_t node) -> bool {  // true if the node was NOT seen before (and is recorded now)
         uint32_t h = (node * 2654435761u) >> (32 - hash_bits);
-        for (uint32_t probe = 0; probe < hash_n; ++probe) {
+        for (uint32_t probe = 0; probe < 256; ++probe) {  // (a nearly full table ends the walk a little early)
             const uint32_t old = atomicCAS(s_hash + h, kEmpty, node);
             if (old == kEmpty) return true;
             if (old == node) return false;
             h = (h + 1) & (hash_n - 1);
         }
-        return false;  // table full: treat as seen (the walk ends a little early; ef <= 256 never gets here)
+        return false;  // table (nearly) full: treat as seen
     };
     auto pq_lookup = [&](uint32_t node) -> float {  // hnswlib::PQLookup: ascending-m fp32 adds
         const uint32_t *p = (const uint32_t *)(codes + (int64_t)node * M);
@@ -236,7 +236,10 @@ extern "C" int annlite_graph_search(const uint32_t *links_dev, int links_per_nod
     if (B == 0) return ANNLITE_OK;
     ANNLITE_REQUIRE(links_dev && seeds_dev && codes_dev && lut_bmk_dev && out_ids_dev && out_dist_dev, "null device pointer");
     hipStream_t st = (hipStream_t)stream;
-    const int hash_bits = ef <= 64 ? 12 : ef <= 128 ? 13 : 14;  // 4096 / 8192 / 16384 entries: a walk records ~25 nodes per list entry
+    // 4096 entries up to ef = 128 (a walk records 2-3k nodes: 5M rows, ef 128 gave the same recall as 8192 entries at
+    // 1.5x the speed -- 5 instead of 3 waves per CU), 8192 beyond; a nearly full table ends the walk a little early
+    int hash_bits = ef <= 128 ? 12 : 13;
+    if (const char *e = getenv("ANNLITE_GRAPH_HASH_BITS")) hash_bits = atoi(e);
     const uint8_t *codes = (const uint8_t *)codes_dev;
 #define ANNLITE_BEAM(MM)                                                                                                \
     (ef <= 64 ? launch_beam<MM, 1>(links_dev, links_per_node, seeds_dev, (int)n_seeds, codes, N, valid_bits_dev, lut_bmk_dev, \
