@@ -91,15 +91,18 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
     }
     // (one wave: its LDS writes are visible to its own later reads in program order)
 
-    auto visit = [&](uint32_t node) -> bool {  // true if the node was NOT seen before (and is recorded now)
+    // true if the node was not seen before (it is recorded now).  A (nearly) full table cannot record any more: the
+    // node is then reported as new every time -- evaluated again, never lost -- and `offer` keeps it out of the list
+    // if it is already there, so a walk that outgrows the table only gets slower, not worse.
+    auto visit = [&](uint32_t node) -> bool {
         uint32_t h = (node * 2654435761u) >> (32 - hash_bits);
-        for (uint32_t probe = 0; probe < 256; ++probe) {  // (a nearly full table ends the walk a little early)
+        for (uint32_t probe = 0; probe < 64; ++probe) {
             const uint32_t old = atomicCAS(s_hash + h, kEmpty, node);
             if (old == kEmpty) return true;
             if (old == node) return false;
             h = (h + 1) & (hash_n - 1);
         }
-        return false;  // table (nearly) full: treat as seen
+        return true;
     };
     auto pq_lookup = [&](uint32_t node) -> float {  // hnswlib::PQLookup: ascending-m fp32 adds
         const uint32_t *p = (const uint32_t *)(codes + (int64_t)node * M);
@@ -142,7 +145,10 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
             pm &= pm - 1;
             const uint32_t chi = __builtin_amdgcn_readlane(khi, src), clo = __builtin_amdgcn_readlane(node, src);
             worst(whi, wlo);
-            if (key_less(chi, clo, whi, wlo)) beam_insert<E>(L, chi, clo, lane);
+            bool dup = false;
+#pragma unroll
+            for (int e = 0; e < E; ++e) dup = dup || __ballot(L.lo[e] == clo && L.hi[e] == chi) != 0ull;
+            if (!dup && key_less(chi, clo, whi, wlo)) beam_insert<E>(L, chi, clo, lane);
         }
     };
 
@@ -237,7 +243,7 @@ extern "C" int annlite_graph_search(const uint32_t *links_dev, int links_per_nod
     ANNLITE_REQUIRE(links_dev && seeds_dev && codes_dev && lut_bmk_dev && out_ids_dev && out_dist_dev, "null device pointer");
     hipStream_t st = (hipStream_t)stream;
     // 4096 entries up to ef = 128 (a walk records 2-3k nodes: 5M rows, ef 128 gave the same recall as 8192 entries at
-    // 1.5x the speed -- 5 instead of 3 waves per CU), 8192 beyond; a nearly full table ends the walk a little early
+    // 1.5x the speed -- 5 instead of 3 waves per CU), 8192 beyond; a full table only costs re-evaluations (see visit)
     int hash_bits = ef <= 128 ? 12 : 13;
     if (const char *e = getenv("ANNLITE_GRAPH_HASH_BITS")) hash_bits = atoi(e);
     const uint8_t *codes = (const uint8_t *)codes_dev;
