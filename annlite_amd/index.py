@@ -124,7 +124,15 @@ class AnnLite:
         self._docs: Dict[str, object] = {}
 
     def _new_index(self) -> PQFlatGpuIndex:
-        return PQFlatGpuIndex(dim=self.n_dim, metric=self.metric, pq_codec=self._pq_codec, **self._index_kwargs)
+        """The per-cell vector index (container.py:48-59 builds ``HnswIndex(...)`` there).  Default: the exhaustive
+        GPU scan; ``AnnLite(..., graph=True, ef_search=..., max_connection=..., ef_construction=...)`` selects the
+        HNSW-over-PQ index with the reference's knobs (graph walked on the GPU, BASELINE config 5)."""
+        kw = dict(self._index_kwargs)
+        if kw.pop('graph', False):
+            from .core.index.hnsw_pq_gpu import HnswPQGpuIndex
+
+            return HnswPQGpuIndex(dim=self.n_dim, metric=self.metric, pq_codec=self._pq_codec, **kw)
+        return PQFlatGpuIndex(dim=self.n_dim, metric=self.metric, pq_codec=self._pq_codec, **kw)
 
     # ------------------------------------------------------------------ bookkeeping (index.py:574-599, 952-963)
     @property

@@ -727,3 +727,27 @@ def test_hnsw_pq_candidates_with_gpu_rerank(ops, mname, metric, walk):
     truth = torch.cdist(qt, xt).topk(k + 1, largest=False).indices.cpu().numpy()
     rr = np.mean([len(set(ri[b]) & (set(truth[b]) - {int(i1[0])} if b == 0 else set(truth[b][:k]))) / k for b in range(B)])
     assert rr >= 0.9, rr
+
+
+def test_annlite_facade_with_graph_index(ops, tmp_path):
+    """AnnLite(..., graph=True): same API, HnswPQGpuIndex underneath; its matches agree with the exhaustive facade."""
+    from annlite_amd import AnnLite
+    from annlite_amd.docarray_compat import Document, DocumentArray
+
+    rs = np.random.RandomState(5)
+    N, D = 6000, 64
+    A = rs.randn(10, D).astype(np.float32)
+    x = (rs.randn(N, 10).astype(np.float32) @ A + 0.05 * rs.randn(N, D).astype(np.float32)).astype(np.float32)
+    q = (rs.randn(20, 10).astype(np.float32) @ A + 0.05 * rs.randn(20, D).astype(np.float32)).astype(np.float32)
+    res = []
+    for graph in (False, True):
+        ann = AnnLite(D, metric='euclidean', n_subvectors=8, data_path=str(tmp_path / ('g%d' % graph)), graph=graph,
+                      ef_search=128)
+        ann._pq_codec.seed = 1  # same codebooks for both facades
+        ann.train(x[:4096])
+        ann.index(DocumentArray([Document(id=str(i), embedding=x[i]) for i in range(N)]))
+        docs = DocumentArray([Document(id='q%d' % i, embedding=q[i]) for i in range(len(q))])
+        ann.search(docs, limit=10)
+        res.append([[m.id for m in d.matches] for d in docs])
+    agree = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(*res)])
+    assert agree >= 0.9, agree
