@@ -48,6 +48,12 @@ SYMBOLS = (
     'annlite_kmeans_assign_accumulate',
     'annlite_kmeans_update',
     'annlite_exact_gather_dist',
+    'annlite_ivf_select_cells',
+    'annlite_ivf_max_tiles',
+    'annlite_ivf_plan',
+    'annlite_pq_search_tiles_workspace_bytes',
+    'annlite_pq_search_tiles',
+    'annlite_ivf_merge',
     'annlite_codes_skew',
     'annlite_profile_enable',
     'annlite_profile_last_scan_ms',
@@ -115,12 +121,21 @@ def lib() -> ctypes.CDLL:
     L.annlite_kmeans_update.argtypes = [vp, vp, i64, i64, i64, vp, vp]
     L.annlite_exact_gather_dist.argtypes = [i32, vp, i64, i64, vp, i64, vp, i64, vp, vp]
     L.annlite_codes_skew.argtypes = [vp, i64, i64, vp, i64, vp, i32, vp]
+    L.annlite_ivf_select_cells.argtypes = [i32, vp, i64, i64, vp, i64, i64, vp, vp]
+    L.annlite_ivf_max_tiles.argtypes = [i64, i64, i64, i64]
+    L.annlite_ivf_plan.argtypes = [vp, i64, i64, i64, i64, vp, vp, i64, vp, vp, vp, vp, vp]
+    L.annlite_pq_search_tiles_workspace_bytes.argtypes = [i64, i64, i64, i32, i64, i64, ctypes.POINTER(ctypes.c_int64)]
+    L.annlite_pq_search_tiles.argtypes = [i32, vp, i64, i64, vp, vp, i32, i32, i64, i64, i64, vp, i64, vp, vp, vp, vp,
+                                          vp, sz, vp]
+    L.annlite_ivf_merge.argtypes = [vp, vp, vp, i64, i64, i64, vp, i64, vp, vp, i32, vp]
     L.annlite_profile_enable.argtypes = [i32]
     L.annlite_profile_last_scan_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]
     L.annlite_debug_counters.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     for name in SYMBOLS:
         fn = getattr(L, name)  # AttributeError here == the .so does not export a declared symbol
-        if name not in ('annlite_hip_last_error',):
+        if name == 'annlite_ivf_max_tiles':
+            fn.restype = i64
+        elif name not in ('annlite_hip_last_error',):
             fn.restype = i32
     _lib = L
     return L

@@ -1,0 +1,202 @@
+"""``IvfPQGpuIndex`` -- PQ/ADC index over coarse cells on one MI355X: the structure of the reference's
+``AnnLite(n_cells > 1)`` (``VQCodec`` coarse quantiser annlite/core/codec/vq.py, ``_cell_selection``
+annlite/index.py:458-466, one vector index per cell + ``CellContainer.ivf_search`` merge, container.py:88-144)
+as ONE code table and one scan launch for all queries and cells.
+
+Semantics:
+  * ``n_probe >= n_cells`` (what the reference always does: ``n_probe = max(n_probe, n_cells)``, index.py:94):
+    every cell is visited -- the result is the exhaustive scan's (``PQFlatGpuIndex.search_batch``), which is
+    what runs.
+  * ``n_probe < n_cells`` (this build's extension, opt-in): a query scans only the rows of its ``n_probe``
+    nearest cells; the result is the exact top-k of those rows under the fixed order (distance asc, id asc).
+
+Layout in HBM on top of the flat index's storage (codes by offset, validity, optional float vectors):
+  * ``_cell_of``  i32 [capacity]        cell of every offset (nearest centroid in squared L2, vq.py:81-90)
+  * sealed view, rebuilt lazily after a mutation (one sort + one gather over the live rows):
+      ``_table``     u8 [Nt, M] SKEWED by table row: the live rows grouped by cell, every cell starts at a
+                     multiple of 64 rows, ascending offset inside a cell
+      ``_row_ids``   i64 [Nt] offset of every table row (-1: padding)
+      ``_cell_rows`` i64 [C, 2] (begin, end) of every cell, ``_cell_order`` i32 [C] cells by descending size
+Search = ``annlite_ivf_select_cells`` -> ``annlite_ivf_plan`` (query tiles of one cell each) -> gather of the slot
+queries -> ``annlite_pq_search_tiles`` (tables + scan + per-slot top-k) -> ``annlite_ivf_merge``.
+"""
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from ... import ops
+from ..._capi import CODES_SKEWED, scan_plan
+from ...enums import Metric
+from ..codec.pq import PQCodec
+from ..codec.vq import VQCodec
+from .pq_flat_gpu import PQFlatGpuIndex
+
+
+class IvfPQGpuIndex(PQFlatGpuIndex):
+    def __init__(self, dim: int, pq_codec: Optional[PQCodec] = None, vq_codec: Optional[VQCodec] = None,
+                 n_probe: Optional[int] = None, **kwargs):
+        super().__init__(dim, pq_codec=pq_codec, **kwargs)
+        assert vq_codec is not None, 'IvfPQGpuIndex needs a VQCodec'
+        self.vq_codec = vq_codec
+        self.n_probe = n_probe  # None: every cell (the reference's behaviour)
+        self._cell_of = None
+        self._sealed = False
+        self._table = self._row_ids = self._cell_rows = self._cell_order = self._pos_of = None
+        self._tws = ops.ScanWorkspace()
+
+    @property
+    def n_cells(self) -> int:
+        return self.vq_codec.n_clusters
+
+    # ------------------------------------------------------------------ storage
+    def _alloc(self, capacity: int):
+        old = self._cell_of
+        super()._alloc(capacity)
+        self._cell_of = torch.zeros((capacity,), dtype=torch.int32, device=self._codes.device)
+        if old is not None:
+            n = min(old.numel(), capacity)
+            self._cell_of[:n] = old[:n]
+        self._sealed = False
+
+    def add_with_ids(self, x, ids, **kwargs):
+        xq = self._pre(x)  # (normalised for cosine: the PQ codes and the float vectors see this)
+        ids_t = ops.to_dev(np.asarray(ids, dtype=np.int64) if not isinstance(ids, torch.Tensor) else ids, torch.int64)
+        if ids_t.numel() == 0:
+            return
+        # the reference assigns cells on the vectors as given (index.py:291-292, vq.py:81-90)
+        raw = ops.to_dev(x, torch.float32)
+        raw = raw.reshape(1, -1) if raw.ndim == 1 else raw
+        cells = self.vq_codec.encode(raw)
+        self._add_preprocessed(xq, ids_t)
+        self._cell_of[ids_t] = cells.to(torch.int32)
+        self._sealed = False
+
+    def _add_preprocessed(self, xq: torch.Tensor, ids_t: torch.Tensor):
+        # PQFlatGpuIndex.add_with_ids normalises again for cosine; normalising a unit vector is idempotent up to
+        # rounding, so hand it the caller's input path instead of re-implementing the storage update
+        super().add_with_ids(xq, ids_t)
+
+    def delete(self, ids):
+        super().delete(ids)
+        self._sealed = False
+
+    def reset(self, capacity: Optional[int] = None):
+        super().reset(capacity=capacity)
+        self._cell_of = None
+        self._sealed = False
+
+    # ------------------------------------------------------------------ sealed (cell-sorted) view
+    def _seal(self):
+        if self._sealed:
+            return
+        dev = self._codes.device
+        N, C = self._n_rows, self.n_cells
+        live = torch.nonzero(self._valid_bool[:N]).flatten()  # ascending offsets
+        cell = self._cell_of[:N][live].to(torch.int64)
+        order = torch.sort(cell, stable=True).indices          # by cell, offsets ascending inside a cell
+        offs = live[order]
+        cell_sorted = cell[order]
+        counts = torch.bincount(cell_sorted, minlength=C)
+        padded = (counts + 63) // 64 * 64
+        begin = torch.cumsum(padded, 0) - padded
+        rank = torch.arange(offs.numel(), device=dev) - (torch.cumsum(counts, 0) - counts)[cell_sorted]
+        pos = begin[cell_sorted] + rank
+        Nt = max(64, int(padded.sum().item()))
+        self._table = torch.zeros((Nt, self.M), dtype=torch.uint8, device=dev)
+        if offs.numel():
+            plain = self._plain_codes(N)[offs].contiguous()
+            ops.codes_skew(plain, pos.contiguous(), out=self._table)
+        self._row_ids = torch.full((Nt,), -1, dtype=torch.int64, device=dev)
+        self._row_ids[pos] = offs
+        self._pos_of = torch.full((max(N, 1),), -1, dtype=torch.int64, device=dev)
+        self._pos_of[offs] = pos
+        self._cell_rows = torch.stack([begin, begin + counts], dim=1).contiguous()
+        self._cell_order = torch.sort(counts, descending=True, stable=True).indices.to(torch.int32).contiguous()
+        self._n_table = Nt
+        self._sealed = True
+
+    def _select_kind_and_centroids(self) -> Tuple[int, torch.Tensor]:
+        """cdist(query, vq codebook, metric) of ``_cell_selection`` (index.py:462-464) as a ranking."""
+        cb = self.vq_codec.codebook_dev
+        if self.metric == Metric.EUCLIDEAN:
+            return 0, cb
+        if self.metric == Metric.COSINE:
+            return 1, ops.l2_normalize(cb)  # queries are normalised by _pre: 1 - cos ranks like -<q, c/|c|>
+        return 1, cb
+
+    # ------------------------------------------------------------------ search
+    def search_batch(self, x, limit: int = 10, indices=None, rerank_k: Optional[int] = None, row_base: int = 0,
+                     n_probe: Optional[int] = None):
+        P = self.n_probe if n_probe is None else n_probe
+        C = self.n_cells
+        if P is None or P >= C:
+            return super().search_batch(x, limit=limit, indices=indices, rerank_k=rerank_k, row_base=row_base)
+        is_np = not isinstance(x, torch.Tensor)
+        q = self._pre(x)
+        B, k = q.shape[0], int(limit)
+        assert 1 <= k <= 64, 'pruned search supports limit <= 64'
+        assert self.M in (8, 16, 32, 64) and self.Ks <= 256 and self.code_bytes == 1, \
+            'pruned search needs the quantised-filter scan plan (M in {8,16,32,64}, Ks <= 256)'
+        dev = q.device
+        if self._n_rows == 0 or B == 0:
+            d = torch.full((B, k), float('inf'), dtype=torch.float32, device=dev)
+            i = torch.full((B, k), -1, dtype=torch.int64, device=dev)
+        else:
+            self._seal()
+            d, i = self._search_pruned(q, k, max(1, int(P)), indices, rerank_k)
+            if row_base:
+                i = torch.where(i >= 0, i + row_base, i)
+        if is_np:
+            return d.cpu().numpy(), i.cpu().numpy()
+        return d, i
+
+    def probe_cells(self, q: torch.Tensor, n_probe: int) -> torch.Tensor:
+        kind, cent = self._select_kind_and_centroids()
+        return ops.ivf_select_cells(kind, q, cent, n_probe)
+
+    def _table_bits(self, indices) -> Optional[torch.Tensor]:
+        """``indices`` filter (offsets) as a bitmap over TABLE rows; None = every stored row."""
+        if indices is None:
+            return None  # the cell ranges hold live rows only; padding lies outside every range
+        idx = ops.to_dev(np.asarray(indices, dtype=np.int64) if not isinstance(indices, torch.Tensor) else indices, torch.int64)
+        idx = idx[(idx >= 0) & (idx < self._pos_of.numel())]
+        pos = self._pos_of[idx]
+        pos = pos[pos >= 0]
+        sel = torch.zeros((((self._n_table + 31) // 32 + 2) * 32,), dtype=torch.bool, device=pos.device)
+        sel[pos] = True
+        return self._pack_bits(sel)
+
+    def _search_pruned(self, q, k, P, indices, rerank_k):
+        B = q.shape[0]
+        rerank = self.rerank and self._vectors is not None
+        ks = max(k, min(64, int(rerank_k or 64))) if rerank else k
+        cells = self.probe_cells(q, P)
+        qt = scan_plan(self._n_table, self.M, self.Ks, 1, 16, ks).qt
+        vmap, slot_of, tile_rows, _ = ops.ivf_plan(cells, self.n_cells, qt, self._cell_rows, self._cell_order)
+        slot_q = q.index_select(0, vmap.clamp(min=0).to(torch.int64))
+        kind, xq = self.pq_codec.scan_inputs(slot_q)
+        sd, si = ops.pq_search_tiles(kind, xq, self.pq_codec.codebooks_dev, self._table, ks, self.M, self.Ks, tile_rows,
+                                     vmap, valid_bits=self._table_bits(indices), n_rows=self._n_table,
+                                     codes_layout=CODES_SKEWED, workspace=self._tws)
+        if not rerank:
+            return ops.ivf_merge(sd, si, slot_of, k, self._row_ids, 0, sqrt=self.metric == Metric.EUCLIDEAN)
+        _, cand = ops.ivf_merge(sd, si, slot_of, ks, self._row_ids, 0)
+        exact = ops.exact_gather_dist(int(self.metric), q, self._vectors, cand)
+        d, pos = ops.topk_rows(exact, k)
+        i = torch.gather(cand, 1, pos.clamp(min=0))
+        i = torch.where((pos < 0) | torch.isinf(d), torch.full_like(i, -1), i)
+        if self.metric == Metric.EUCLIDEAN:
+            d = torch.sqrt(d)
+        return d, i
+
+    # ------------------------------------------------------------------ persistence
+    def dump(self, index_file):
+        super().dump(index_file)
+        np.save(str(index_file) + '.cells.npy', self._cell_of[: self._n_rows].cpu().numpy())
+
+    def load(self, index_file):
+        super().load(index_file)
+        cells = np.load(str(index_file) + '.cells.npy')
+        self._cell_of[: cells.shape[0]] = ops.to_dev(cells)
+        self._sealed = False

@@ -1,0 +1,262 @@
+// ivf.hip -- the coarse-quantiser side of a pruned (IVF) PQ search (gfx950 only): which cells a query probes, the
+// grouping of (query, cell) pairs into the scan's query tiles, and the merge of a query's per-cell lists.
+//
+// Reference seam: AnnLite._cell_selection (annlite/index.py:458-466: cdist(query, vq codebook) -> top_k(n_probe)),
+// CellContainer.ivf_search (container.py:88-144: per-cell search, lists concatenated and re-sorted).  The reference
+// sets n_probe = max(n_probe, n_cells) (index.py:94), i.e. it always visits every cell; the pruned search is the
+// build's extension of the same structure.
+//
+// The scan itself is annlite_pq_search_tiles (scan.hip): the rows of a cell are contiguous in the code table, a
+// query tile = up to QT queries that probe the same cell, one work item per tile.
+#include "common.h"
+
+namespace annlite {
+
+// ---- cell selection ------------------------------------------------------------------------------
+// One 256-thread workgroup per QB queries: the query vectors sit in LDS (read by broadcast), thread t owns the
+// centroids t, t + 256, ... and keeps QB running sums while it streams a centroid row ONCE; the QB x C distances
+// go to LDS and the P nearest are picked by rank counting under the fixed order (distance asc, cell asc).
+constexpr int kSelQB = 8;
+template <int KIND>  // 0: squared L2, 1: negative inner product
+__global__ __launch_bounds__(256) void ivf_select_cells_kernel(const float *__restrict__ q, int B, int D,
+                                                              const float *__restrict__ cent, int C, int P,
+                                                              int32_t *__restrict__ cells) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *qs = (float *)smem;               // [QB][D]
+    float *ds = qs + (size_t)kSelQB * D;     // [QB][C]
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x * kSelQB;
+    for (int i = tid; i < kSelQB * D; i += 256) {
+        const int qi = i / D, j = i - qi * D;
+        qs[i] = b0 + qi < B ? q[(int64_t)(b0 + qi) * D + j] : 0.f;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float acc[kSelQB];
+#pragma unroll
+        for (int u = 0; u < kSelQB; ++u) acc[u] = 0.f;
+        const float *cr = cent + (int64_t)c * D;
+        for (int j = 0; j < D; ++j) {  // sequential in j: one defined summation order per (query, cell)
+            const float cv = cr[j];
+#pragma unroll
+            for (int u = 0; u < kSelQB; ++u) {
+                const float qv = qs[u * D + j];
+                if constexpr (KIND == 0) {
+                    const float d = cv - qv;
+                    acc[u] = __builtin_fmaf(d, d, acc[u]);
+                } else {
+                    acc[u] = __builtin_fmaf(cv, qv, acc[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kSelQB; ++u) ds[u * C + c] = KIND == 0 ? acc[u] : -acc[u];
+    }
+    __syncthreads();
+    if (P == 1) {
+        // nearest centroid only (cell assignment of the indexed rows, VQCodec.encode): argmin by reduction --
+        // wave u / 2 takes queries 2*(u/2), 2*(u/2)+1 ... : one wave per pair of queries
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int u = wave; u < kSelQB; u += 4) {
+            if (b0 + u >= B) continue;
+            const float *row = ds + u * C;
+            float best = __builtin_inff();
+            int bi = 0x7fffffff;
+            for (int c = lane; c < C; c += 64) {
+                const float v = row[c];
+                if (v < best || (v == best && c < bi)) best = v, bi = c;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(best, o);
+                const int oi = __shfl_xor(bi, o);
+                if (ov < best || (ov == best && oi < bi)) best = ov, bi = oi;
+            }
+            if (lane == 0) cells[b0 + u] = bi;
+        }
+        return;
+    }
+    for (int i = tid; i < kSelQB * C; i += 256) {
+        const int u = i / C, c = i - u * C;
+        if (b0 + u >= B) continue;
+        const float *row = ds + u * C;
+        const float me = row[c];
+        int rank = 0;
+        for (int o = 0; o < C; ++o) {
+            const float v = row[o];
+            rank += (v < me) || (v == me && o < c);
+        }
+        if (rank < P) cells[(int64_t)(b0 + u) * P + rank] = c;
+    }
+}
+
+// ---- grouping (query, cell) pairs into query tiles -----------------------------------------------
+// ONE workgroup.  Pairs that probe the same cell are packed into tiles of `qt` slots; the tiles of a cell are
+// consecutive and the cells come in `order` (descending size: the scan hands tiles out longest first).
+//   vmap[v]      query of slot v, or -1 (padding)            [n_tiles_max * qt]
+//   slot_of[i]   slot of pair i = (query i / P, probe i % P) [n_pairs]
+//   tile_rows[t] (begin, end) of the tile's cell, begin = -1 for tiles past the last used one
+// The slot order inside a cell depends on atomic arrival order; results do not (every slot has its own list).
+__global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *__restrict__ cells, int n_pairs, int P, int C,
+                                                       int qt, const int64_t *__restrict__ cell_rows,
+                                                       const int32_t *__restrict__ order, int n_tiles_max,
+                                                       int32_t *__restrict__ vmap, int32_t *__restrict__ slot_of,
+                                                       int64_t *__restrict__ tile_rows, int32_t *__restrict__ n_tiles_used) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *cnt = (int *)smem;        // [C] pairs per cell
+    int *tstart = cnt + C;         // [C] first tile of the cell
+    int *wsum = tstart + C;        // [16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < C; i += 1024) cnt[i] = 0;
+    for (int i = tid; i < n_tiles_max * qt; i += 1024) vmap[i] = -1;
+    for (int i = tid; i < n_tiles_max; i += 1024) {
+        tile_rows[2 * i] = -1;
+        tile_rows[2 * i + 1] = -1;
+    }
+    __syncthreads();
+    for (int i = tid; i < n_pairs; i += 1024) slot_of[i] = atomicAdd(&cnt[cells[i]], 1);  // rank inside the cell
+    __syncthreads();
+    // exclusive scan of the tile counts in `order`; thread t owns positions [t*per, (t+1)*per)
+    const int per = (C + 1023) / 1024;
+    int local = 0;
+    for (int u = 0; u < per; ++u) {
+        const int j = tid * per + u;
+        if (j < C) local += (cnt[order[j]] + qt - 1) / qt;
+    }
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    int run = base + incl - local;
+    for (int u = 0; u < per; ++u) {
+        const int j = tid * per + u;
+        if (j < C) {
+            const int c = order[j];
+            const int nt = (cnt[c] + qt - 1) / qt;
+            tstart[c] = run;
+            const int64_t rb = cell_rows[2 * c], re = cell_rows[2 * c + 1];
+            for (int t = 0; t < nt; ++t) {
+                tile_rows[2 * (int64_t)(run + t)] = rb;
+                tile_rows[2 * (int64_t)(run + t) + 1] = re;
+            }
+            run += nt;
+        }
+    }
+    if (tid == 1023 && n_tiles_used) *n_tiles_used = run;
+    __syncthreads();
+    for (int i = tid; i < n_pairs; i += 1024) {
+        const int r = slot_of[i];
+        const int v = (tstart[cells[i]] + r / qt) * qt + r % qt;
+        slot_of[i] = v;
+        vmap[v] = i / P;
+    }
+}
+
+// ---- merge of a query's per-cell lists --------------------------------------------------------------
+// One wave per query.  List v (slot of a (query, cell) pair) holds k entries ascending in (distance, table row);
+// rows of a cell are stored in ascending external id, so after the row -> id translation every list is ascending
+// in (distance, id) and the lists are merged under the fixed tie-break.
+__global__ __launch_bounds__(256) void ivf_merge_kernel(const float *__restrict__ vd, const int64_t *__restrict__ vi,
+                                                       const int32_t *__restrict__ slot_of, int B, int P, int k,
+                                                       const int64_t *__restrict__ row_ids, int64_t id_base,
+                                                       float *__restrict__ out_d, int64_t *__restrict__ out_i,
+                                                       int sqrt_out) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    WaveList L;
+    L.reset();
+    for (int p = 0; p < P; ++p) {
+        const int v = slot_of[(int64_t)b * P + p];
+        uint32_t chi = kKeyInfHi, clo = kIdNone;
+        if (lane < k) {
+            const int64_t row = vi[(int64_t)v * k + lane];
+            if (row >= 0) {
+                chi = f32_to_ordered(vd[(int64_t)v * k + lane]);
+                clo = (uint32_t)(row_ids ? row_ids[row] : row);
+            }
+        }
+        wavelist_merge_sorted(L, chi, clo, lane);
+    }
+    if (lane < k) {
+        const bool none = (L.hi == kKeyInfHi && L.lo == kIdNone);
+        const float d = none ? __builtin_inff() : ordered_to_f32(L.hi);
+        out_d[(int64_t)b * k + lane] = sqrt_out && !none ? __builtin_sqrtf(d) : d;
+        out_i[(int64_t)b * k + lane] = none ? (int64_t)-1 : id_base + (int64_t)L.lo;
+    }
+}
+
+}  // namespace annlite
+
+using namespace annlite;
+
+extern "C" int annlite_ivf_select_cells(int kind, const float *queries_dev, int64_t B, int64_t D,
+                                        const float *centroids_dev, int64_t C, int64_t P, int32_t *cells_dev,
+                                        void *stream) {
+    ANNLITE_REQUIRE(kind == 0 || kind == 1, "kind must be 0 (squared L2) or 1 (negative inner product), got %d", kind);
+    ANNLITE_REQUIRE(B >= 0 && D >= 1 && C >= 1 && P >= 1 && P <= C, "bad shape B=%lld D=%lld C=%lld P=%lld", (long long)B,
+                    (long long)D, (long long)C, (long long)P);
+    const size_t lds = (size_t)kSelQB * (size_t)(D + C) * 4;
+    ANNLITE_REQUIRE(lds <= 160 * 1024, "n_cells + dim too large for the selection kernel (%zu B of LDS)", lds);
+    if (B == 0) return ANNLITE_OK;
+    ANNLITE_REQUIRE(queries_dev && centroids_dev && cells_dev, "null device pointer");
+    const unsigned grid = (unsigned)((B + kSelQB - 1) / kSelQB);
+    if (kind == 0) {
+        ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)ivf_select_cells_kernel<0>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ivf_select_cells_kernel<0>, dim3(grid), dim3(256), lds, (hipStream_t)stream, queries_dev, (int)B,
+                           (int)D, centroids_dev, (int)C, (int)P, cells_dev);
+    } else {
+        ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)ivf_select_cells_kernel<1>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ivf_select_cells_kernel<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, queries_dev, (int)B,
+                           (int)D, centroids_dev, (int)C, (int)P, cells_dev);
+    }
+    return launch_status("ivf_select_cells_kernel");
+}
+
+extern "C" int64_t annlite_ivf_max_tiles(int64_t B, int64_t P, int64_t C, int64_t qt) {
+    if (B <= 0 || P <= 0 || C <= 0 || qt <= 0) return 0;
+    const int64_t pairs = B * P;
+    // every probed cell has at most one partly filled tile
+    return pairs / qt + (C < pairs ? C : pairs);
+}
+
+extern "C" int annlite_ivf_plan(const int32_t *cells_dev, int64_t B, int64_t P, int64_t C, int64_t qt,
+                                const int64_t *cell_rows_dev, const int32_t *cell_order_dev, int64_t n_tiles_max,
+                                int32_t *vmap_dev, int32_t *slot_of_dev, int64_t *tile_rows_dev, int32_t *n_tiles_used_dev,
+                                void *stream) {
+    ANNLITE_REQUIRE(B >= 0 && P >= 1 && C >= 1 && C <= 16384 && qt >= 1, "bad shape B=%lld P=%lld C=%lld qt=%lld",
+                    (long long)B, (long long)P, (long long)C, (long long)qt);
+    ANNLITE_REQUIRE(n_tiles_max >= annlite_ivf_max_tiles(B, P, C, qt), "n_tiles_max=%lld too small (annlite_ivf_max_tiles)",
+                    (long long)n_tiles_max);
+    ANNLITE_REQUIRE(B * P < (1ll << 31) && n_tiles_max * qt < (1ll << 31), "too many (query, cell) pairs");
+    if (B == 0) return ANNLITE_OK;
+    ANNLITE_REQUIRE(cells_dev && cell_rows_dev && cell_order_dev && vmap_dev && slot_of_dev && tile_rows_dev,
+                    "null device pointer");
+    const size_t lds = (size_t)(2 * C + 16) * 4;
+    ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)ivf_plan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, cells_dev, (int)(B * P), (int)P, (int)C,
+                       (int)qt, cell_rows_dev, cell_order_dev, (int)n_tiles_max, vmap_dev, slot_of_dev, tile_rows_dev,
+                       n_tiles_used_dev);
+    return launch_status("ivf_plan_kernel");
+}
+
+extern "C" int annlite_ivf_merge(const float *slot_dist_dev, const int64_t *slot_row_dev, const int32_t *slot_of_dev,
+                                 int64_t B, int64_t P, int64_t k, const int64_t *row_ids_dev, int64_t id_base,
+                                 float *out_dist_dev, int64_t *out_id_dev, int flags, void *stream) {
+    ANNLITE_REQUIRE(B >= 0 && P >= 1 && k >= 1 && k <= 64, "bad B=%lld P=%lld k=%lld (k<=64)", (long long)B, (long long)P,
+                    (long long)k);
+    if (B == 0) return ANNLITE_OK;
+    ANNLITE_REQUIRE(slot_dist_dev && slot_row_dev && slot_of_dev && out_dist_dev && out_id_dev, "null device pointer");
+    hipLaunchKernelGGL(ivf_merge_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, slot_dist_dev,
+                       slot_row_dev, slot_of_dev, (int)B, (int)P, (int)k, row_ids_dev, id_base, out_dist_dev, out_id_dev,
+                       (flags & ANNLITE_FLAG_SQRT) ? 1 : 0);
+    return launch_status("ivf_merge_kernel");
+}

@@ -353,8 +353,9 @@ static void plan_slices(int64_t N, int n_tiles, int waves, int n_cu, bool xcd8, 
 
 using namespace annlite;
 
-extern "C" int annlite_scan_plan_query(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t k,
-                                       annlite_scan_plan *plan) {
+// force_ns > 0: tile mode (every query tile scans its own row range as ONE work item)
+static int plan_query_impl(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t k, int force_ns,
+                           annlite_scan_plan *plan) {
     ANNLITE_REQUIRE(plan != nullptr, "plan is NULL");
     ANNLITE_REQUIRE(N >= 0 && M >= 1 && Ks >= 1 && B >= 0, "bad shape N=%lld M=%lld Ks=%lld B=%lld", (long long)N,
                     (long long)M, (long long)Ks, (long long)B);
@@ -375,6 +376,7 @@ extern "C" int annlite_scan_plan_query(int64_t N, int64_t M, int64_t Ks, int cod
         int ns;
         int64_t sr;
         plan_slices(N > 0 ? N : 1, n_tiles > 0 ? n_tiles : 1, c.NW, n_cu, true, &ns, &sr, B);
+        if (force_ns > 0) ns = force_ns;
         plan->n_slices = ns;
         plan->lut_floats = ((B + 15) / 16) * 16 * M * Ks;  // padded to 16 queries
         // [partial keys][Smax f32 x Bpad][qstep f32 x Bpad][qlo f64 x Bpad][lo,hi f32 x Bpad*M][q16 u16 x Bpad*M*Ks]
@@ -382,7 +384,7 @@ extern "C" int annlite_scan_plan_query(int64_t N, int64_t M, int64_t Ks, int cod
         plan->workspace_bytes = (int64_t)n_tiles * plan->qt * ns * k * 8 + 256 + bpad * 4 + 256;
         if (c.mode == 4)
             plan->workspace_bytes += bpad * 4 + 256 + 2 * (bpad * 8 + 256) + (bpad * ns * 8 + 256) + (n_tiles * 4 + 256) +
-                                     bpad * M * Ks * 2 + 256;
+                                     256 /* item counter */ + bpad * M * Ks * 2 + 256;
     } else {
         plan->fast = 0;
         plan->qi = 1;
@@ -397,6 +399,11 @@ extern "C" int annlite_scan_plan_query(int64_t N, int64_t M, int64_t Ks, int cod
     }
     if (plan->workspace_bytes < 8) plan->workspace_bytes = 8;
     return ANNLITE_OK;
+}
+
+extern "C" int annlite_scan_plan_query(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t k,
+                                       annlite_scan_plan *plan) {
+    return plan_query_impl(N, M, Ks, code_bytes, B, k, 0, plan);
 }
 
 static unsigned long long *g_dbg = nullptr;  // debug only (ANNLITE_DEBUG_COUNTERS): leaked 64-byte device buffer
@@ -428,16 +435,29 @@ struct ScanOut {
     int sqrt_out;
     bool merged;
 };
+// tile mode (annlite_pq_search_tiles): query tile t = queries [t*qt, (t+1)*qt) scans rows tile_rows[t]
+struct TileMode {
+    const int64_t *tile_rows;  // [B / qt][2]
+    const int32_t *vmap;       // [B]
+};
 
 static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M, int64_t Ks,
                         const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B, int64_t k,
                         void *workspace_dev, size_t workspace_bytes, hipStream_t st, annlite_scan_plan *plan_out,
-                        bool share_across_slices, const LutBuild *build = nullptr, ScanOut *outp = nullptr) {
+                        bool share_across_slices, const LutBuild *build = nullptr, ScanOut *outp = nullptr,
+                        const TileMode *tm = nullptr) {
     annlite_scan_plan plan;
-    int rc = annlite_scan_plan_query(N, M, Ks, code_bytes, B, k, &plan);
+    int rc = plan_query_impl(N, M, Ks, code_bytes, B, k, tm ? 1 : 0, &plan);
     if (rc != ANNLITE_OK) return rc;
     *plan_out = plan;
     if (B == 0) return ANNLITE_OK;
+    if (tm) {
+        FastCfg ct;
+        ANNLITE_REQUIRE(plan.fast && fast_cfg(M, Ks, code_bytes, k, &ct) && ct.mode == 4,
+                        "tile mode needs the quantised-filter plan (M in {8,16,32,64}, Ks <= 256, uint8 codes)");
+        ANNLITE_REQUIRE(B % plan.qt == 0 && tm->tile_rows && tm->vmap && outp && share_across_slices,
+                        "tile mode: B=%lld must be a multiple of the tile size %d", (long long)B, plan.qt);
+    }
     ANNLITE_REQUIRE(codes_layout == ANNLITE_CODES_PLAIN || (codes_layout == ANNLITE_CODES_SKEWED && plan.fast),
                     "codes_layout %d not supported by this plan (SKEWED needs the fast plan)", codes_layout);
     ANNLITE_REQUIRE(lut_dev && workspace_dev, "null device pointer");
@@ -474,7 +494,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         int ns;
         int64_t sr;
         plan_slices(N > 0 ? N : 1, a.n_tiles, plan.waves, n_cu, plan.fast != 0, &ns, &sr, B);
-        a.slice_rows = sr;
+        a.slice_rows = tm ? ((N + 63) / 64) * 64 : sr;
     }
     // slots of slices that hold no rows stay "none"
     size_t fill_bytes = 0;
@@ -487,7 +507,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             const size_t bpad = (size_t)((B + 15) / 16) * 16;
             auto r256 = [](size_t x) { return (x + 255) / 256 * 256; };
             fill = r256((size_t)a.n_tiles * plan.qt * plan.n_slices * k * 8) + r256(bpad * 8) +
-                   r256(bpad * plan.n_slices * 8) + r256((size_t)a.n_tiles * 4);
+                   r256(bpad * plan.n_slices * 8) + r256((size_t)a.n_tiles * 4) + 256 /* item counter */;
         }
         fill_bytes = fill;
         FastCfg c1;
@@ -495,8 +515,9 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         if (!fused_fill) ANNLITE_HIP_TRY(hipMemsetAsync(workspace_dev, 0xff, fill, st));
     }
     if (N == 0) return ANNLITE_OK;
-    const int n_items = (plan.fast && a.n_slices < 8) ? ((a.n_tiles + 8 / a.n_slices - 1) / (8 / a.n_slices)) * 8
-                                                      : a.n_tiles * a.n_slices;
+    const int n_items = tm ? a.n_tiles
+                           : (plan.fast && a.n_slices < 8) ? ((a.n_tiles + 8 / a.n_slices - 1) / (8 / a.n_slices)) * 8
+                                                           : a.n_tiles * a.n_slices;
     a.n_items = n_items;
     if (plan.fast) {
         FastCfg c;
@@ -512,6 +533,12 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             unsigned long long *gk = (unsigned long long *)carve(bpad * 8);
             unsigned long long *gk2 = (unsigned long long *)carve(bpad * plan.n_slices * 8);
             unsigned int *tile_done = (unsigned int *)carve((int64_t)a.n_tiles * 4);
+            unsigned int *item_counter = (unsigned int *)carve(4);
+            if (tm) {
+                a.tile_rows = tm->tile_rows;
+                a.vmap = tm->vmap;
+                a.item_counter = item_counter;
+            }
             if (share_across_slices && outp && (outp->packed || (outp->d && outp->i))) {
                 a.tile_done = tile_done;
                 a.out_d = outp->d;
@@ -537,7 +564,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             uint16_t *q16 = (uint16_t *)carve(bpad * M * Ks * 2);
             rc = launch_lut_quantise(M, Ks, B, bpad, lut_dev, build, q16, qstep, qlo, smax, workspace_dev, fill_bytes, st);
             if (rc != ANNLITE_OK) return rc;
-            if (share_across_slices && N >= 4096) {
+            if (share_across_slices && N >= 4096 && !tm) {  // (tile mode seeds inside the scan kernel)
                 int64_t S = 8192;
                 if (const char *e = getenv("ANNLITE_SEED_ROWS")) S = atoll(e);
                 if (S > N) S = N;
@@ -608,7 +635,8 @@ extern "C" int annlite_profile_last_scan_ms(float *ms) {
 static int scan_topk_impl(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M, int64_t Ks,
                           const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B, int64_t k, int64_t row_base,
                           float *out_dist_dev, int64_t *out_id_dev, int64_t *out_packed_dev, void *workspace_dev,
-                          size_t workspace_bytes, void *stream, const LutBuild *build = nullptr, int flags = 0) {
+                          size_t workspace_bytes, void *stream, const LutBuild *build = nullptr, int flags = 0,
+                          const TileMode *tm = nullptr) {
     annlite_scan_plan plan;
     hipStream_t st = (hipStream_t)stream;
     ANNLITE_REQUIRE(B == 0 || out_packed_dev || (out_dist_dev && out_id_dev), "null output pointer");
@@ -616,8 +644,9 @@ static int scan_topk_impl(const void *codes_dev, int code_bytes, int codes_layou
     ScanOut so = {out_dist_dev, out_id_dev, out_packed_dev, row_base, sqrt_out, false};
     if (getenv("ANNLITE_NO_INKERNEL_MERGE")) so.d = nullptr, so.i = nullptr, so.packed = nullptr;
     int rc = scan_partial(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut_dev, B, k, workspace_dev,
-                          workspace_bytes, st, &plan, true, build, &so);
+                          workspace_bytes, st, &plan, true, build, &so, tm);
     if (rc != ANNLITE_OK || B == 0 || so.merged) return rc;
+    ANNLITE_REQUIRE(!tm, "tile mode: the scan did not merge in-kernel");
     hipLaunchKernelGGL(merge_partial_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st,
                        (const unsigned long long *)workspace_dev, (int)B, plan.n_slices, (int)k, row_base,
                        out_dist_dev, out_id_dev, out_packed_dev, sqrt_out);
@@ -653,15 +682,15 @@ extern "C" int annlite_pq_search_workspace_bytes(int64_t N, int64_t M, int64_t K
     return ANNLITE_OK;
 }
 
-extern "C" int annlite_pq_search_topk(int lut_kind, const float *queries_dev, int64_t B, int64_t D,
-                                      const float *codebooks_dev, const void *codes_dev, int code_bytes, int codes_layout,
-                                      int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev, int64_t k,
-                                      int64_t row_base, float *out_dist_dev, int64_t *out_id_dev, int64_t *out_packed_dev,
-                                      int flags, void *workspace_dev, size_t workspace_bytes, void *stream) {
+static int pq_search_impl(int lut_kind, const float *queries_dev, int64_t B, int64_t D, const float *codebooks_dev,
+                          const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M, int64_t Ks,
+                          const uint32_t *valid_bits_dev, int64_t k, int64_t row_base, float *out_dist_dev,
+                          int64_t *out_id_dev, int64_t *out_packed_dev, int flags, void *workspace_dev,
+                          size_t workspace_bytes, void *stream, const TileMode *tm) {
     ANNLITE_REQUIRE(M >= 1 && D >= M && D % M == 0,
                     "input dimension must be dividable by number of sub-space (D=%lld, M=%lld)", (long long)D, (long long)M);
     annlite_scan_plan plan;
-    int rc = annlite_scan_plan_query(N, M, Ks, code_bytes, B, k, &plan);
+    int rc = plan_query_impl(N, M, Ks, code_bytes, B, k, tm ? 1 : 0, &plan);
     if (rc != ANNLITE_OK) return rc;
     if (B == 0) return ANNLITE_OK;
     const size_t scan_ws = r256z((size_t)plan.workspace_bytes);
@@ -680,11 +709,44 @@ extern "C" int annlite_pq_search_topk(int lut_kind, const float *queries_dev, in
                                plan.fast ? ANNLITE_LAYOUT_TILED : ANNLITE_LAYOUT_BMK, plan.qi, stream);
         if (rc != ANNLITE_OK) return rc;
         return scan_topk_impl(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut, B, k, row_base,
-                              out_dist_dev, out_id_dev, out_packed_dev, workspace_dev, scan_ws, stream, nullptr, flags);
+                              out_dist_dev, out_id_dev, out_packed_dev, workspace_dev, scan_ws, stream, nullptr, flags, tm);
     }
     const LutBuild lb = {queries_dev, codebooks_dev, D};
     return scan_topk_impl(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut, B, k, row_base, out_dist_dev,
-                          out_id_dev, out_packed_dev, workspace_dev, scan_ws, stream, &lb, flags);
+                          out_id_dev, out_packed_dev, workspace_dev, scan_ws, stream, &lb, flags, tm);
+}
+
+extern "C" int annlite_pq_search_topk(int lut_kind, const float *queries_dev, int64_t B, int64_t D,
+                                      const float *codebooks_dev, const void *codes_dev, int code_bytes, int codes_layout,
+                                      int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev, int64_t k,
+                                      int64_t row_base, float *out_dist_dev, int64_t *out_id_dev, int64_t *out_packed_dev,
+                                      int flags, void *workspace_dev, size_t workspace_bytes, void *stream) {
+    return pq_search_impl(lut_kind, queries_dev, B, D, codebooks_dev, codes_dev, code_bytes, codes_layout, N, M, Ks,
+                          valid_bits_dev, k, row_base, out_dist_dev, out_id_dev, out_packed_dev, flags, workspace_dev,
+                          workspace_bytes, stream, nullptr);
+}
+
+extern "C" int annlite_pq_search_tiles_workspace_bytes(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t V,
+                                                       int64_t k, int64_t *bytes) {
+    ANNLITE_REQUIRE(bytes != nullptr, "bytes is NULL");
+    annlite_scan_plan plan;
+    int rc = plan_query_impl(N, M, Ks, code_bytes, V, k, 1, &plan);
+    if (rc != ANNLITE_OK) return rc;
+    *bytes = (int64_t)(r256z((size_t)plan.workspace_bytes) + r256z((size_t)plan.lut_floats * 4));
+    return ANNLITE_OK;
+}
+
+extern "C" int annlite_pq_search_tiles(int lut_kind, const float *queries_dev, int64_t V, int64_t D,
+                                       const float *codebooks_dev, const void *codes_dev, int code_bytes, int codes_layout,
+                                       int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev, int64_t k,
+                                       const int64_t *tile_rows_dev, const int32_t *vmap_dev, float *out_dist_dev,
+                                       int64_t *out_id_dev, void *workspace_dev, size_t workspace_bytes, void *stream) {
+    ANNLITE_REQUIRE(V == 0 || (tile_rows_dev && vmap_dev), "null tile table");
+    ANNLITE_REQUIRE(N > 0 || V == 0, "tile mode needs a non-empty code table");
+    const TileMode tm = {tile_rows_dev, vmap_dev};
+    return pq_search_impl(lut_kind, queries_dev, V, D, codebooks_dev, codes_dev, code_bytes, codes_layout, N, M, Ks,
+                          valid_bits_dev, k, 0, out_dist_dev, out_id_dev, nullptr, 0, workspace_dev, workspace_bytes, stream,
+                          &tm);
 }
 
 extern "C" int annlite_adc_scan_candidates(const void *codes_dev, int code_bytes, int codes_layout, int64_t N,

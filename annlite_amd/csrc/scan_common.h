@@ -46,6 +46,11 @@ struct ScanArgs {
     int32_t dbg_skip;        // debug bitmask (ANNLITE_DEBUG_SKIP): 1 no gathers, 2 no insert/publish, 4 no event at all
     unsigned long long *dbg; // optional event counters (ANNLITE_DEBUG_COUNTERS=1): [0] slow-block entries,
                              // [1] (wave,query) events, [2] events with an insertion, [3] bound publications
+    // tile mode (IVF cells, annlite_pq_search_tiles): every query tile scans its OWN row range, one work item per
+    // tile (n_slices = 1); the tiles are handed out dynamically, longest first
+    const int64_t *tile_rows;    // [n_tiles][2] (begin: multiple of 64, end); begin < 0: unused tile; NULL = slices
+    const int32_t *vmap;         // [n_tiles * QT] >= 0: the slot holds a query; < 0: padding (never passes the filter)
+    unsigned int *item_counter;  // starts at 0xffffffff (workspace fill): next item = atomicAdd + 1
 };
 
 // work item -> (query tile, row slice).  item % 8 == blockIdx % 8 == the XCD the block lands on (speed

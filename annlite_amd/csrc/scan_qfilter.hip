@@ -113,8 +113,10 @@ __device__ __attribute__((noinline)) void qfilter_flush(const FlushCtx c, uint32
                 // tell the other workgroups of this query (other row slices) and remember it locally
                 if (c.gkey) __hip_atomic_fetch_min(c.gkey + b, okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(gkl, okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                *(volatile unsigned short *)(g_smem + c.shq_off + q0 * 2) =
-                    qbound_from_key<M>(okey, c.smax[b], c.qstep[b], c.qlo[b]);
+                // (min: in tile mode the integer seed bound can be tighter than the first k-th key)
+                volatile unsigned short *sp = (volatile unsigned short *)(g_smem + c.shq_off + q0 * 2);
+                const unsigned short nb = qbound_from_key<M>(okey, c.smax[b], c.qstep[b], c.qlo[b]);
+                if (nb < *sp) *sp = nb;
             }
             if (c.gk2) {
                 // this slice's j-th key, for the max-of-j-th bound the sibling slices compute
@@ -221,7 +223,7 @@ __device__ __forceinline__ void merge_tile_slices(const ScanArgs &a, int b0, int
 // LDS: [Q tile Ks*KSTRIDE][shq16 u16 x QT (0x8000|qthr) @ +0][locks u32 x QT @ +64][gkl u64 x QT @ +128]
 //      [lists u64 x QT x 64 @ +256]
 // =================================================================================================
-template <int M, int NQ, int NW, int WPS, bool SKEWED>
+template <int M, int NQ, int NW, int WPS, bool SKEWED, bool TILES>
 __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const ScanArgs a) {
     constexpr int QG = 8;                 // queries per LDS entry
     constexpr int QT = QG * NQ;           // queries per workgroup
@@ -258,9 +260,31 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
     const int n_items = a.n_items;
     const int64_t group_bytes = (int64_t)a.Ks * RB;
 
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    for (int it = 0;; ++it) {
+        int item = blockIdx.x + it * gridDim.x;
         int tile, slice;
-        if (!item_map(a, item, tile, slice)) continue;
+        int64_t slice_begin, slice_end;
+        if constexpr (TILES) {
+            // tile mode: one item per query tile with its own row range, taken from a device-wide counter
+            volatile unsigned int *s_item = (volatile unsigned int *)(smem + shq_off + 48);
+            __syncthreads();  // every wave is done with the previous item (and has read s_item)
+            if (tid == 0)
+                *s_item = __hip_atomic_fetch_add(a.item_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            __syncthreads();
+            item = (int)*s_item;
+            if (item >= n_items) break;
+            tile = item;
+            slice = 0;
+            slice_begin = a.tile_rows[2 * tile];
+            slice_end = a.tile_rows[2 * tile + 1];
+            if (slice_begin < 0) continue;  // unused tile: nobody reads its outputs
+        } else {
+            if (item >= n_items) break;
+            if (!item_map(a, item, tile, slice)) continue;
+            slice_begin = (int64_t)slice * a.slice_rows;
+            slice_end = slice_begin + a.slice_rows;
+        }
+        if (slice_end > a.N) slice_end = a.N;
 
         __syncthreads();
         {
@@ -286,15 +310,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                 // pad queries of the last tile (b >= B) must never pass the filter (their all-zero tables give S = 0
                 // for every row: 15 pad queries made a 1-query batch 15x slower than a 16-query one): 0x7fff - S
                 // never has bit 15 set and never borrows from the neighbouring field
-                shq[tid] = b < a.B ? qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]) : (unsigned short)0x7fff;
+                bool real = b < a.B;
+                if constexpr (TILES) real = real && a.vmap[b] >= 0;  // padding slots sit in every tile
+                shq[tid] = real ? qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]) : (unsigned short)0x7fff;
             }
             for (int idx = tid; idx < QT * 64; idx += NW * 64) lists[idx] = ~0ull;
         }
         __syncthreads();
-
-        const int64_t slice_begin = (int64_t)slice * a.slice_rows;
-        int64_t slice_end = slice_begin + a.slice_rows;
-        if (slice_end > a.N) slice_end = a.N;
 
         const uint32_t *codes32 = (const uint32_t *)a.codes;
         auto load_row = [&](int64_t row, uint32_t (&c)[CW]) {
@@ -360,6 +382,66 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
             load_row(row0 + stride + lane, cnext);
             vcur = load_valid(row0 + lane);
             vnext = load_valid(row0 + stride + lane);
+        }
+        if constexpr (TILES) {
+            // Integer seed bound (no separate seed launch, no exact sums): every wave takes the per-query MINIMUM
+            // integer sum S of its first 64 rows; the NW minima belong to distinct rows, so >= k rows have
+            // S <= Sk := the k-th smallest of them.  d_exact <= L + step*(S + 1.002 M) + slack32 for every row, so the
+            // final k-th distance is <= U = L + step*(Sk + 1.002 M) + slack32, and a row can only be in the top-k if
+            // L + step*(S - 0.04) <= d_real <= U + slack32, i.e. S <= Sk + 1.002 M + 0.04 + 2 slack32 / step.
+            // Without it every row of the first steps is a candidate (16 waves x 16 queries x 64 exact gathers).
+            if (a.k <= NW) {
+                uint32_t *smin = (uint32_t *)(smem + queue_off);  // [NW][NQ * 4] packed minima (queues are idle)
+                u32x4 sacc[NQ];
+                const bool have = row0 < slice_end;
+                bool ok = have && row0 + lane < slice_end;
+                if (ok && a.valid) ok = (vcur >> (lane & 31)) & 1u;
+                if (have) {
+                    make_addr(ccur);
+                    static_for<0, NQ>([&](auto H) { group_sum(H, sacc[decltype(H)::value]); });
+                }
+#pragma unroll
+                for (int h = 0; h < NQ; ++h)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        uint32_t x = ok ? sacc[h][w] : 0x7fff7fffu;
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) {
+                            const uint32_t y = (uint32_t)__shfl_xor((int)x, o);
+                            asm("v_pk_min_u16 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y));
+                        }
+                        if (lane == 0) smin[wave * (NQ * 4) + h * 4 + w] = x;
+                    }
+                __syncthreads();
+                if (tid < QT) {
+                    const int b = tile * QT + tid;
+                    if (b < a.B && a.vmap[b] >= 0) {
+                        const volatile uint16_t *sm16 = (const volatile uint16_t *)smin;
+                        uint32_t sk = 0x7fffu;  // k-th smallest of the NW minima (rank counting, ties by wave)
+#pragma unroll 1
+                        for (int i = 0; i < NW; ++i) {
+                            const uint32_t vi = sm16[i * (NQ * 8) + tid];
+                            int rank = 0;
+#pragma unroll 1
+                            for (int j = 0; j < NW; ++j) {
+                                const uint32_t vj = sm16[j * (NQ * 8) + tid];
+                                rank += (vj < vi) || (vj == vi && j < i);
+                            }
+                            if (rank == km1) sk = vi;
+                        }
+                        if (sk < 0x7fffu) {
+                            const double slack = (double)a.smax[b] * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
+                            double qd = __builtin_floor((double)sk + 1.002 * M + 0.04 + 2.0 * slack / (double)a.qstep[b]) + 1.0;
+                            if (!(qd < 32767.0)) qd = 32767.0;
+                            const unsigned short nb = (unsigned short)(0x8000u | (uint32_t)qd);
+                            if (nb < shq[tid]) shq[tid] = nb;
+                        }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
+            }
         }
 
         const FlushCtx fc = {(const uint8_t *)a.codes, a.lut, a.smax, a.qstep, a.qlo, a.gkey, a.gk2, a.dbg,
@@ -522,7 +604,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
 // LDS: [table (Ks+1)*512][shq u16 x 4 @ +0][locks u32 x 4 @ +64][gkl u64 x 4 @ +128][lists u64 x 4 x 64 @ +256]
 //      [gjl u64 x 4][queues u64 x NW x 64]
 // =================================================================================================
-template <int NW, bool SKEWED>
+template <int NW, bool SKEWED, bool TILES>
 __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanArgs a) {
     constexpr int M = 64, QT = 4, CW = 16, RB = 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -545,9 +627,30 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
     unsigned long long *lists = (unsigned long long *)(smem + list_off);
     const unsigned char *lbase = smem + lane * 8;
 
-    for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+    for (int it = 0;; ++it) {
+        int item = blockIdx.x + it * gridDim.x;
         int tile, slice;
-        if (!item_map(a, item, tile, slice)) continue;
+        int64_t slice_begin, slice_end;
+        if constexpr (TILES) {  // (see adc_scan_qfilter_kernel)
+            volatile unsigned int *s_item = (volatile unsigned int *)(smem + shq_off + 48);
+            __syncthreads();
+            if (tid == 0)
+                *s_item = __hip_atomic_fetch_add(a.item_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            __syncthreads();
+            item = (int)*s_item;
+            if (item >= a.n_items) break;
+            tile = item;
+            slice = 0;
+            slice_begin = a.tile_rows[2 * tile];
+            slice_end = a.tile_rows[2 * tile + 1];
+            if (slice_begin < 0) continue;
+        } else {
+            if (item >= a.n_items) break;
+            if (!item_map(a, item, tile, slice)) continue;
+            slice_begin = (int64_t)slice * a.slice_rows;
+            slice_end = slice_begin + a.slice_rows;
+        }
+        if (slice_end > a.N) slice_end = a.N;
 
         __syncthreads();
         {
@@ -565,15 +668,13 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
                 // pad queries of the last tile (b >= B) must never pass the filter (their all-zero tables give S = 0
                 // for every row: 15 pad queries made a 1-query batch 15x slower than a 16-query one): 0x7fff - S
                 // never has bit 15 set and never borrows from the neighbouring field
-                shq[tid] = b < a.B ? qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]) : (unsigned short)0x7fff;
+                bool real = b < a.B;
+                if constexpr (TILES) real = real && a.vmap[b] >= 0;
+                shq[tid] = real ? qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]) : (unsigned short)0x7fff;
             }
             for (int idx = tid; idx < QT * 64; idx += NW * 64) lists[idx] = ~0ull;
         }
         __syncthreads();
-
-        const int64_t slice_begin = (int64_t)slice * a.slice_rows;
-        int64_t slice_end = slice_begin + a.slice_rows;
-        if (slice_end > a.N) slice_end = a.N;
 
         const uint32_t *codes32 = (const uint32_t *)a.codes;
         auto load_row = [&](int64_t row, uint32_t (&c)[CW]) {
@@ -611,6 +712,73 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
             vcur = load_valid(row0 + lane);
             vnext = load_valid(row0 + stride + lane);
         }
+        // integer sums of this lane's row for the 4 queries (2 dwords x 2 u16), look-ups in 4 chunks of 16
+        auto row_sums = [&](const uint32_t (&cc)[CW], u32x2 &acc) {
+            static_for<0, 4>([&](auto C) {
+                constexpr int c0 = decltype(C)::value * 16;
+                u32x2 v[16];
+                static_for<0, 4>([&](auto W) {
+                    constexpr int t = c0 + decltype(W)::value * 4;
+                    uint32_t o0, o1, o2, o3;
+                    byte_shl4(cc[t / 4], 9u, o0, o1, o2, o3);
+                    v[t - c0 + 0] = *(const u32x2 *)(lbase + o0 + (t + 0) * 8);
+                    v[t - c0 + 1] = *(const u32x2 *)(lbase + o1 + (t + 1) * 8);
+                    v[t - c0 + 2] = *(const u32x2 *)(lbase + o2 + (t + 2) * 8);
+                    v[t - c0 + 3] = *(const u32x2 *)(lbase + o3 + (t + 3) * 8);
+                });
+                asm volatile("" ::: "memory");
+                static_for<0, 16>([&](auto I) { acc += v[decltype(I)::value]; });
+            });
+        };
+        if constexpr (TILES) {
+            // integer seed bound from the per-wave minima of the first rows (see adc_scan_qfilter_kernel)
+            if (a.k <= NW) {
+                uint32_t *smin = (uint32_t *)(smem + queue_off);  // [NW][2]
+                u32x2 sacc = {0u, 0u};
+                const bool have = row0 < slice_end;
+                bool ok = have && row0 + lane < slice_end;
+                if (ok && a.valid) ok = (vcur >> (lane & 31)) & 1u;
+                if (have) row_sums(ccur, sacc);
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    uint32_t x = ok ? (w ? sacc.y : sacc.x) : 0x7fff7fffu;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const uint32_t y = (uint32_t)__shfl_xor((int)x, o);
+                        asm("v_pk_min_u16 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y));
+                    }
+                    if (lane == 0) smin[wave * 2 + w] = x;
+                }
+                __syncthreads();
+                if (tid < QT) {
+                    const int b = tile * QT + tid;
+                    if (b < a.B && a.vmap[b] >= 0) {
+                        const volatile uint16_t *sm16 = (const volatile uint16_t *)smin;
+                        uint32_t sk = 0x7fffu;  // k-th smallest of the NW minima (rank counting, ties by wave)
+#pragma unroll 1
+                        for (int i = 0; i < NW; ++i) {
+                            const uint32_t vi = sm16[i * 4 + tid];
+                            int rank = 0;
+#pragma unroll 1
+                            for (int j = 0; j < NW; ++j) {
+                                const uint32_t vj = sm16[j * 4 + tid];
+                                rank += (vj < vi) || (vj == vi && j < i);
+                            }
+                            if (rank == km1) sk = vi;
+                        }
+                        if (sk < 0x7fffu) {
+                            const double slack = (double)a.smax[b] * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
+                            double qd = __builtin_floor((double)sk + 1.002 * M + 0.04 + 2.0 * slack / (double)a.qstep[b]) + 1.0;
+                            if (!(qd < 32767.0)) qd = 32767.0;
+                            const unsigned short nb = (unsigned short)(0x8000u | (uint32_t)qd);
+                            if (nb < shq[tid]) shq[tid] = nb;
+                        }
+                    }
+                }
+                __syncthreads();
+                thp = *(const u32x2 *)(smem + shq_off);
+            }
+        }
         const FlushCtx fc = {(const uint8_t *)a.codes, a.lut, a.smax, a.qstep, a.qlo, a.gkey, a.gk2, a.dbg,
                              a.Ks, tile * QT, a.n_slices, slice, km1, a.jm1, a.dbg_skip,
                              list_off, lock_off, shq_off, gkl_off, gjl_off};
@@ -623,21 +791,7 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
             const uint32_t rid = (uint32_t)(row0 + lane);
 
             u32x2 acc = {0u, 0u};
-            static_for<0, 4>([&](auto C) {
-                constexpr int c0 = decltype(C)::value * 16;
-                u32x2 v[16];
-                static_for<0, 4>([&](auto W) {
-                    constexpr int t = c0 + decltype(W)::value * 4;
-                    uint32_t o0, o1, o2, o3;
-                    byte_shl4(ccur[t / 4], 9u, o0, o1, o2, o3);
-                    v[t - c0 + 0] = *(const u32x2 *)(lbase + o0 + (t + 0) * 8);
-                    v[t - c0 + 1] = *(const u32x2 *)(lbase + o1 + (t + 1) * 8);
-                    v[t - c0 + 2] = *(const u32x2 *)(lbase + o2 + (t + 2) * 8);
-                    v[t - c0 + 3] = *(const u32x2 *)(lbase + o3 + (t + 3) * 8);
-                });
-                asm volatile("" ::: "memory");
-                static_for<0, 16>([&](auto I) { acc += v[decltype(I)::value]; });
-            });
+            row_sums(ccur, acc);
 
             const uint32_t x0 = (thp.x - acc.x) & 0x80008000u, x1 = (thp.y - acc.y) & 0x80008000u;
             const unsigned long long anym = __ballot((x0 | x1) != 0) & vmask;
@@ -753,7 +907,8 @@ template <int M, int NQ, int NW, int WPS, bool SKEWED>
 static int launch_qfilter(const ScanArgs &a, int grid, hipStream_t st) {
     const size_t lds_lut = (size_t)a.Ks * NQ * M * 16;
     const size_t need = lds_lut + 256 + (size_t)8 * NQ * 64 * 8 + 128 + (size_t)NW * 512;
-    auto fn = adc_scan_qfilter_kernel<M, NQ, NW, WPS, SKEWED>;
+    auto fn = a.tile_rows ? adc_scan_qfilter_kernel<M, NQ, NW, WPS, SKEWED, true>
+                          : adc_scan_qfilter_kernel<M, NQ, NW, WPS, SKEWED, false>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
     return launch_status("adc_scan_qfilter_kernel");
@@ -762,7 +917,7 @@ static int launch_qfilter(const ScanArgs &a, int grid, hipStream_t st) {
 template <int NW, bool SKEWED>
 static int launch_qfilter64(const ScanArgs &a, int grid, hipStream_t st) {
     const size_t need = (size_t)(a.Ks + 1) * 512 + 256 + (size_t)4 * 512 + 128 + (size_t)NW * 512;
-    auto fn = adc_scan_qfilter64_kernel<NW, SKEWED>;
+    auto fn = a.tile_rows ? adc_scan_qfilter64_kernel<NW, SKEWED, true> : adc_scan_qfilter64_kernel<NW, SKEWED, false>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
     return launch_status("adc_scan_qfilter64_kernel");

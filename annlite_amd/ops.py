@@ -198,6 +198,74 @@ def pq_search_topk(lut_kind: int, queries: torch.Tensor, codebooks: torch.Tensor
     return op if packed else (od, oi)
 
 
+def ivf_select_cells(kind: int, queries: torch.Tensor, centroids: torch.Tensor, n_probe: int) -> torch.Tensor:
+    """The ``n_probe`` nearest cells of every query, i32 [B, P] ascending in (distance, cell)
+    (``AnnLite._cell_selection``, annlite/index.py:458-466).  kind 0: squared L2, 1: negative inner product."""
+    B, D = queries.shape
+    C = centroids.shape[0]
+    cells = torch.empty((B, n_probe), dtype=torch.int32, device=queries.device)
+    check(lib().annlite_ivf_select_cells(kind, queries.data_ptr(), B, D, centroids.data_ptr(), C, n_probe,
+                                         cells.data_ptr(), stream_ptr()), 'ivf_select_cells')
+    return cells
+
+
+def ivf_max_tiles(B: int, P: int, C: int, qt: int) -> int:
+    return int(lib().annlite_ivf_max_tiles(B, P, C, qt))
+
+
+def ivf_plan(cells: torch.Tensor, n_cells: int, qt: int, cell_rows: torch.Tensor, cell_order: torch.Tensor):
+    """(query, cell) pairs -> query tiles of ``qt`` slots probing one cell each.  Returns
+    ``(vmap i32 [T*qt], slot_of i32 [B, P], tile_rows i64 [T, 2], n_tiles_used i32 [1])``."""
+    B, P = cells.shape
+    T = ivf_max_tiles(B, P, n_cells, qt)
+    dev = cells.device
+    vmap = torch.empty((T * qt,), dtype=torch.int32, device=dev)
+    slot_of = torch.empty((B, P), dtype=torch.int32, device=dev)
+    tile_rows = torch.empty((T, 2), dtype=torch.int64, device=dev)
+    used = torch.empty((1,), dtype=torch.int32, device=dev)
+    check(lib().annlite_ivf_plan(cells.data_ptr(), B, P, n_cells, qt, cell_rows.data_ptr(), cell_order.data_ptr(), T,
+                                 vmap.data_ptr(), slot_of.data_ptr(), tile_rows.data_ptr(), used.data_ptr(),
+                                 stream_ptr()), 'ivf_plan')
+    return vmap, slot_of, tile_rows, used
+
+
+def pq_search_tiles(lut_kind: int, slot_queries: torch.Tensor, codebooks: torch.Tensor, codes: torch.Tensor, k: int,
+                    M: int, Ks: int, tile_rows: torch.Tensor, vmap: torch.Tensor,
+                    valid_bits: Optional[torch.Tensor] = None, n_rows: Optional[int] = None,
+                    codes_layout: int = CODES_PLAIN, workspace: Optional[ScanWorkspace] = None
+                    ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``annlite_pq_search_tiles``: slot queries f32 [V, D]; tile t = slots [t*qt, (t+1)*qt) scans rows
+    ``tile_rows[t]`` only.  Returns per-slot (f32 [V,k], i64 [V,k] table rows)."""
+    N = codes.shape[0] if n_rows is None else n_rows
+    V, D = slot_queries.shape
+    cb = code_bytes_of(codes)
+    need = ctypes.c_int64(0)
+    check(lib().annlite_pq_search_tiles_workspace_bytes(N, M, Ks, cb, V, k, ctypes.byref(need)),
+          'pq_search_tiles_workspace_bytes')
+    dev = codes.device
+    ws = (workspace or ScanWorkspace()).get(int(need.value), dev)
+    od = torch.empty((V, k), dtype=torch.float32, device=dev)
+    oi = torch.empty((V, k), dtype=torch.int64, device=dev)
+    check(lib().annlite_pq_search_tiles(lut_kind, slot_queries.data_ptr(), V, D, codebooks.data_ptr(), codes.data_ptr(),
+                                        cb, codes_layout, N, M, Ks, _ptr(valid_bits), k, tile_rows.data_ptr(),
+                                        vmap.data_ptr(), od.data_ptr(), oi.data_ptr(), ws.data_ptr(), ws.numel(),
+                                        stream_ptr()), 'pq_search_tiles')
+    return od, oi
+
+
+def ivf_merge(slot_dist: torch.Tensor, slot_rows: torch.Tensor, slot_of: torch.Tensor, k: int,
+              row_ids: Optional[torch.Tensor] = None, id_base: int = 0, sqrt: bool = False
+              ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Merge every query's per-cell lists: ([V,k], [V,k]) + slot_of [B,P] -> ([B,k] f32, [B,k] i64 ids)."""
+    B, P = slot_of.shape
+    od = torch.empty((B, k), dtype=torch.float32, device=slot_dist.device)
+    oi = torch.empty((B, k), dtype=torch.int64, device=slot_dist.device)
+    check(lib().annlite_ivf_merge(slot_dist.data_ptr(), slot_rows.data_ptr(), slot_of.data_ptr(), B, P, k,
+                                  _ptr(row_ids), id_base, od.data_ptr(), oi.data_ptr(), 1 if sqrt else 0, stream_ptr()),
+          'ivf_merge')
+    return od, oi
+
+
 def topk_merge_packed(packed: torch.Tensor, sqrt: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """[G,B,k,2] i64 (id, distance bits) -> ([B,k] f32, [B,k] i64), same order rule as ``topk_merge``."""
     G, B, k, _ = packed.shape

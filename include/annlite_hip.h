@@ -273,6 +273,58 @@ ANNLITE_API int annlite_exact_gather_dist(int metric, const float *queries_dev, 
                               const float *vectors_dev, int64_t N, const int64_t *cand_dev, int64_t R,
                               float *out_dev, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Pruned (IVF) search over cells (follow-on of rank 4).
+ * Reference structure: AnnLite(n_cells > 1): VQCodec coarse quantiser (annlite/core/codec/vq.py),
+ * AnnLite._cell_selection (annlite/index.py:458-466: cdist(query, vq codebook) -> top_k(n_probe)),
+ * CellContainer.ivf_search (annlite/container.py:88-144: one index per cell, lists merged).  The
+ * reference always probes every cell (n_probe = max(n_probe, n_cells), index.py:94); probing fewer
+ * is this build's extension of the same structure.
+ * Table layout: the rows of a cell are CONTIGUOUS in the code table, every cell starts at a multiple
+ * of 64 rows (padding rows are invalid in the bitmap), rows of a cell ascend in external id.
+ * ---------------------------------------------------------------------------------------------- */
+/* cells[b][0..P) = the P nearest centroids of query b, ascending in (distance, cell).
+ * kind 0: squared L2; kind 1: negative inner product (cosine: pass normalised centroids).
+ * centroids_dev f32 [C][D] (VQCodec.codebook). */
+ANNLITE_API int annlite_ivf_select_cells(int kind, const float *queries_dev, int64_t B, int64_t D,
+                             const float *centroids_dev, int64_t C, int64_t P, int32_t *cells_dev, void *stream);
+
+/* Upper bound of the query tiles annlite_ivf_plan can produce (qt = tile size of the scan plan). */
+ANNLITE_API int64_t annlite_ivf_max_tiles(int64_t B, int64_t P, int64_t C, int64_t qt);
+
+/* Group the B*P (query, cell) pairs into query tiles of qt slots that probe ONE cell each.
+ *   cell_rows_dev  i64 [C][2]  (begin, end) rows of every cell in the code table
+ *   cell_order_dev i32 [C]     cells in descending size (tiles are scanned longest first)
+ *   vmap_dev       i32 [n_tiles_max*qt]  out: query of every slot, -1 = padding slot
+ *   slot_of_dev    i32 [B*P]   out: slot of pair (b, p)
+ *   tile_rows_dev  i64 [n_tiles_max][2]  out: row range of every tile (begin -1: unused tile)
+ *   n_tiles_used_dev i32 [1]   out (may be NULL) */
+ANNLITE_API int annlite_ivf_plan(const int32_t *cells_dev, int64_t B, int64_t P, int64_t C, int64_t qt,
+                     const int64_t *cell_rows_dev, const int32_t *cell_order_dev, int64_t n_tiles_max,
+                     int32_t *vmap_dev, int32_t *slot_of_dev, int64_t *tile_rows_dev, int32_t *n_tiles_used_dev,
+                     void *stream);
+
+/* annlite_pq_search_topk where query tile t = queries [t*qt, (t+1)*qt) scans ONLY rows
+ * tile_rows[t] (one work item per tile, handed out dynamically; the bound of a tile is seeded inside
+ * the scan kernel from integer sums).  V = n_tiles * qt slot queries (queries_dev f32 [V][D]: the
+ * probing query of every slot, anything for padding slots); out [V][k]: per-slot top-k, ids are TABLE
+ * ROWS.  Quantised-filter plans only (M in {8,16,32,64}, Ks <= 256, uint8 codes). */
+ANNLITE_API int annlite_pq_search_tiles_workspace_bytes(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t V,
+                                            int64_t k, int64_t *bytes);
+ANNLITE_API int annlite_pq_search_tiles(int lut_kind, const float *queries_dev, int64_t V, int64_t D,
+                            const float *codebooks_dev, const void *codes_dev, int code_bytes, int codes_layout,
+                            int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev, int64_t k,
+                            const int64_t *tile_rows_dev, const int32_t *vmap_dev, float *out_dist_dev,
+                            int64_t *out_id_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* Merge the P per-cell lists of every query: slot lists [V][k] (distance, table row) -> [B][k]
+ * (distance, id_base + row_ids[row]) under the fixed tie-break; row_ids_dev i64 [N] or NULL (ids =
+ * rows).  flags: ANNLITE_FLAG_SQRT.
+ * replaces: the hstack + argsort merge of CellContainer.ivf_search (annlite/container.py:130-138). */
+ANNLITE_API int annlite_ivf_merge(const float *slot_dist_dev, const int64_t *slot_row_dev, const int32_t *slot_of_dev,
+                      int64_t B, int64_t P, int64_t k, const int64_t *row_ids_dev, int64_t id_base,
+                      float *out_dist_dev, int64_t *out_id_dev, int flags, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

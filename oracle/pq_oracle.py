@@ -350,3 +350,65 @@ def index_search(x, codebooks, codes, metric, k, sqrt_euclidean=True, threads=1)
     if metric == EUCLIDEAN and sqrt_euclidean:
         d = np.sqrt(d)
     return d, i
+
+
+# ------------------------------------------------------------------------------------------------
+# pruned (IVF) search: AnnLite(n_cells > 1) structure -- VQCodec.encode (annlite/core/codec/vq.py:78-90),
+# AnnLite._cell_selection (annlite/index.py:458-466), CellContainer.ivf_search (annlite/container.py:88-144)
+# ------------------------------------------------------------------------------------------------
+def cell_distances(queries, centroids, kind):
+    """What the build's selection kernel ranks cells by: kind 0 = squared L2 as the fp32 chain
+    acc = fma(c - q, c - q, acc) over j; kind 1 = -(fp32 chain acc = fma(c, q, acc)).  As rankings these are
+    the reference's cdist(query, vq codebook, metric) (annlite/math.py:21-61): 'euclidean' = sqrt of the squared
+    distance, 'cosine' = 1 - <q, c>/(|q||c|) with unit q and centroids normalised by the caller."""
+    q = _f32c(queries)
+    c = _f32c(centroids)
+    acc = np.zeros((q.shape[0], c.shape[0]), dtype=np.float32)
+    for j in range(q.shape[1]):
+        if kind == 0:
+            d = (c[None, :, j] - q[:, None, j]).astype(np.float32)
+            acc = _fma32(d, d, acc)
+        else:
+            acc = _fma32(np.broadcast_to(c[None, :, j], acc.shape), np.broadcast_to(q[:, None, j], acc.shape), acc)
+    return acc if kind == 0 else -acc
+
+
+def select_cells(queries, centroids, kind, n_probe):
+    """top_k(dists, k=n_probe) of _cell_selection with the fixed tie-break (distance asc, cell asc)."""
+    d = cell_distances(queries, centroids, kind)
+    order = np.lexsort((np.broadcast_to(np.arange(d.shape[1]), d.shape), d), axis=1)
+    return order[:, :n_probe].astype(np.int32)
+
+
+def assign_cells(x, centroids):
+    """VQCodec.encode: nearest centroid in squared L2, first minimum wins."""
+    return select_cells(x, centroids, 0, 1)[:, 0]
+
+
+def ivf_search(x, codebooks, codes, cell_of_row, probe_cells, metric, k, valid=None, sqrt_euclidean=True):
+    """index_search restricted, per query, to the rows whose cell is in probe_cells[b]: the exact top-k
+    (distance asc, id asc) of the union of the probed cells = ivf_search's concatenate + argsort
+    (container.py:130-138) without its early-skip heuristic (container.py:120-121)."""
+    x = _f32c(np.atleast_2d(x))
+    if metric == COSINE:
+        x = _f32c(l2_normalize(x))
+    lut = get_dist_mat_c(x, codebooks, metric)
+    cell_of_row = np.asarray(cell_of_row)
+    ds, is_ = [], []
+    for b in range(x.shape[0]):
+        sel = np.isin(cell_of_row, probe_cells[b])
+        if valid is not None:
+            sel &= np.asarray(valid, dtype=bool)
+        rows = np.nonzero(sel)[0]
+        if rows.size:
+            dist = dist_pqcodes_to_codebooks_c(lut[b], np.ascontiguousarray(codes[rows]))
+            d, i = top_k_numpy(dist, k)
+            i = np.where(i >= 0, rows[np.clip(i, 0, rows.size - 1)], -1)
+        else:
+            d, i = np.full(k, np.inf, np.float32), np.full(k, -1, np.int64)
+        ds.append(d)
+        is_.append(i)
+    d, i = np.stack(ds), np.stack(is_)
+    if metric == EUCLIDEAN and sqrt_euclidean:
+        d = np.sqrt(d)
+    return d, i

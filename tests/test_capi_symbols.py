@@ -8,7 +8,7 @@ from conftest import ROOT
 
 def _declared():
     src = open(os.path.join(ROOT, 'include', 'annlite_hip.h')).read()
-    return sorted(set(re.findall(r'ANNLITE_API\s+(?:const\s+char\s+\*|int\s+)(annlite_\w+)\s*\(', src)))
+    return sorted(set(re.findall(r'ANNLITE_API\s+(?:const\s+char\s+\*|int64_t\s+|int\s+)(annlite_\w+)\s*\(', src)))
 
 
 def test_header_symbols_are_exported_and_bound():
