@@ -642,7 +642,7 @@ static int scan_topk_impl(const void *codes_dev, int code_bytes, int codes_layou
     ANNLITE_REQUIRE(B == 0 || out_packed_dev || (out_dist_dev && out_id_dev), "null output pointer");
     const int sqrt_out = (flags & ANNLITE_FLAG_SQRT) && !out_packed_dev ? 1 : 0;
     ScanOut so = {out_dist_dev, out_id_dev, out_packed_dev, row_base, sqrt_out, false};
-    if (getenv("ANNLITE_NO_INKERNEL_MERGE")) so.d = nullptr, so.i = nullptr, so.packed = nullptr;
+    if (getenv("ANNLITE_NO_INKERNEL_MERGE") && !tm) so.d = nullptr, so.i = nullptr, so.packed = nullptr;
     int rc = scan_partial(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut_dev, B, k, workspace_dev,
                           workspace_bytes, st, &plan, true, build, &so, tm);
     if (rc != ANNLITE_OK || B == 0 || so.merged) return rc;

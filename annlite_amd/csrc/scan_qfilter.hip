@@ -8,6 +8,7 @@ namespace annlite {
 // The top-k of a (workgroup, query) lives ONCE in LDS: 64 sorted (key, id) entries + a 4-byte lock.  The
 // bound every wave filters with is the k-th best of ALL rows the workgroup has seen.
 extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
+constexpr int kTileCandBytes = 12288;  // tile mode: LDS bytes of the per-slot candidate buffers (all slots together)
 
 // what a queue flush needs and a work item keeps constant
 struct FlushCtx {
@@ -23,6 +24,110 @@ struct FlushCtx {
     uint32_t list_off, lock_off, shq_off, gkl_off, gjl_off;
 };
 
+// exact ascending-m fp32 sum of table row `rid` for query slot q (the reference's order, space_pq.h:32-35): re-reads
+// the row's code bytes and gathers its M entries from the fp32 TILED table in global memory
+template <int M, bool SKEWED>
+__device__ __forceinline__ float exact_row_sum(const FlushCtx &c, int q, uint32_t rid) {
+    constexpr int CW = M / 4;
+    uint32_t cp[CW];
+    const uint32_t *p = (const uint32_t *)(c.codes + (int64_t)rid * M);
+#pragma unroll
+    for (int i = 0; i < CW; ++i) cp[i] = p[i];
+    if constexpr (SKEWED && M == 64) {
+        const int r = (int)(rid % 64);
+#pragma unroll
+        for (int i = 0; i < CW; ++i) cp[i] = bytes_add(cp[i], wrap64_mask(i, r));  // undo the wrap coding
+    }
+    if constexpr (SKEWED) {
+        // stored byte j of row n is the code of sub-space (j + n) mod M: rotate back by n mod M
+        const int sinv = (M - (int)(rid % M)) % M;
+        bool abit_inv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) abit_inv[i] = (((sinv >> 2) >> i) & 1) != 0;
+        rotate_row<CW>(cp, abit_inv, (uint32_t)(sinv & 3));
+    }
+    const int b = c.b0 + q;
+    const float *lq = c.lut + ((int64_t)(b >> 2) * c.Ks) * (M * 4) + (b & 3);
+    float vals[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const uint32_t code = (cp[m / 4] >> (8 * (m % 4))) & 0xffu;
+        vals[m] = lq[((int64_t)code * M + m) * 4];
+    }
+    float ex = 0.f;
+#pragma unroll
+    for (int m = 0; m < M; ++m) ex += vals[m];
+    return ex;
+}
+
+// Offer the candidates (khi, rid) of the lanes in pm to the shared list of query slot q0: pre-check against the
+// current bound without the lock, then insert under the lock and publish the new k-th key / filter bound.
+template <int M>
+__device__ __forceinline__ void offer_to_list(const FlushCtx &c, int q0, unsigned long long pm, uint32_t khi, uint32_t rid,
+                                              int lane) {
+    if (c.dbg && lane == 0) {
+        atomicAdd(c.dbg + 1, 1ull);
+        atomicAdd(c.dbg + 4, (unsigned long long)__popcll(pm));
+    }
+    const int b = c.b0 + q0;
+    unsigned long long *list = (unsigned long long *)(g_smem + c.list_off + q0 * 512);  // [64] ascending
+    unsigned long long *gkl = (unsigned long long *)(g_smem + c.gkl_off + q0 * 8);
+    // cheap pre-check against the current bound, without the lock (it only ever decreases): the list's
+    // own k-th key or the best bound imported from the other workgroups, whichever is smaller
+    unsigned long long kth = __hip_atomic_load(list + c.km1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned long long gk = __hip_atomic_load(gkl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (gk < kth) kth = gk;
+    unsigned long long px = __ballot(key_less(khi, rid, (uint32_t)(kth >> 32), (uint32_t)kth)) & pm;
+    if (!px || (c.skip & 2)) return;
+    if (c.dbg && lane == 0) atomicAdd(c.dbg + 2, 1ull);
+    // ---- critical section ---------------------------------------------------------------------
+    unsigned int *lock = (unsigned int *)(g_smem + c.lock_off + q0 * 4);
+    for (;;) {
+        unsigned int got = 0;
+        if (lane == 0) got = (atomicCAS(lock, 0u, 1u) == 0u) ? 1u : 0u;
+        if (__builtin_amdgcn_readfirstlane(got)) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    const unsigned long long le = __hip_atomic_load(list + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    WaveList L;
+    L.hi = (uint32_t)(le >> 32);
+    L.lo = (uint32_t)le;
+    const uint32_t thi = __builtin_amdgcn_readlane(L.hi, c.km1), tlo = __builtin_amdgcn_readlane(L.lo, c.km1);
+    px = __ballot(key_less(khi, rid, thi, tlo)) & px;  // the list may have tightened meanwhile
+    if (px) {
+        wavelist_insert_many(L, px, khi, rid, lane);
+        __hip_atomic_store(list + lane, ((unsigned long long)L.hi << 32) | L.lo, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t ohi = __builtin_amdgcn_readlane(L.hi, c.km1);
+        const uint32_t olo = __builtin_amdgcn_readlane(L.lo, c.km1);
+        const unsigned long long okey = ((unsigned long long)ohi << 32) | olo;
+        if (lane == 0 && ohi != kKeyInfHi && okey < gk) {
+            if (c.dbg) atomicAdd(c.dbg + 3, 1ull);
+            // tell the other workgroups of this query (other row slices) and remember it locally
+            if (c.gkey) __hip_atomic_fetch_min(c.gkey + b, okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gkl, okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // (min: in tile mode the integer seed bound can be tighter than the first k-th key)
+            volatile unsigned short *sp = (volatile unsigned short *)(g_smem + c.shq_off + q0 * 2);
+            const unsigned short nb = qbound_from_key<M>(okey, c.smax[b], c.qstep[b], c.qlo[b]);
+            if (nb < *sp) *sp = nb;
+        }
+        if (c.gk2) {
+            // this slice's j-th key, for the max-of-j-th bound the sibling slices compute
+            const uint32_t jhi = __builtin_amdgcn_readlane(L.hi, c.jm1);
+            const uint32_t jlo = __builtin_amdgcn_readlane(L.lo, c.jm1);
+            const unsigned long long jkey = ((unsigned long long)jhi << 32) | jlo;
+            volatile unsigned long long *gjl = (volatile unsigned long long *)(g_smem + c.gjl_off + q0 * 8);
+            if (lane == 0 && jhi != kKeyInfHi && jkey < *gjl) {
+                *gjl = jkey;
+                __hip_atomic_store(c.gk2 + (int64_t)b * c.n_slices + c.slice, jkey, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    // LDS executes one wave's instructions in order, so the list stores are visible before the release
+    if (lane == 0) __hip_atomic_store(lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // Flush one wave's candidate queue: up to 64 (query, row) pairs whose integer sum passed the filter.
 // Lane i takes entry i: re-reads the row's code bytes, gathers its exact ascending-m fp32 sum from the
 // fp32 table in global memory, then the candidates are offered query by query to the shared lists.
@@ -30,109 +135,36 @@ struct FlushCtx {
 // (46 times per wave at 1.25M rows); a flush pays them once for everything queued since the last one.
 template <int M, bool SKEWED>
 __device__ __attribute__((noinline)) void qfilter_flush(const FlushCtx c, uint32_t queue_off, int qcnt) {
-    constexpr int CW = M / 4;
     const int lane = threadIdx.x & 63;
     const bool act = lane < qcnt;
     const unsigned long long e = act ? ((const unsigned long long *)(g_smem + queue_off))[lane] : 0ull;
     const uint32_t rid = (uint32_t)e;
     const int q = (int)(e >> 32);
     float ex = 0.f;
-    if (act && !(c.skip & 1)) {
-        uint32_t cp[CW];
-        const uint32_t *p = (const uint32_t *)(c.codes + (int64_t)rid * M);
-#pragma unroll
-        for (int i = 0; i < CW; ++i) cp[i] = p[i];
-        if constexpr (SKEWED && M == 64) {
-            const int r = (int)(rid % 64);
-#pragma unroll
-            for (int i = 0; i < CW; ++i) cp[i] = bytes_add(cp[i], wrap64_mask(i, r));  // undo the wrap coding
-        }
-        if constexpr (SKEWED) {
-            // stored byte j of row n is the code of sub-space (j + n) mod M: rotate back by n mod M
-            const int sinv = (M - (int)(rid % M)) % M;
-            bool abit_inv[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) abit_inv[i] = (((sinv >> 2) >> i) & 1) != 0;
-            rotate_row<CW>(cp, abit_inv, (uint32_t)(sinv & 3));
-        }
-        const int b = c.b0 + q;
-        const float *lq = c.lut + ((int64_t)(b >> 2) * c.Ks) * (M * 4) + (b & 3);
-        float vals[M];
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const uint32_t code = (cp[m / 4] >> (8 * (m % 4))) & 0xffu;
-            vals[m] = lq[((int64_t)code * M + m) * 4];
-        }
-#pragma unroll
-        for (int m = 0; m < M; ++m) ex += vals[m];
-    }
+    if (act && !(c.skip & 1)) ex = exact_row_sum<M, SKEWED>(c, q, rid);
     const uint32_t khi = f32_to_ordered(ex);
     unsigned long long rem = __ballot(act);
     while (rem) {
         const int q0 = __builtin_amdgcn_readlane(q, __builtin_ctzll(rem));
         const unsigned long long pm = __ballot(act && q == q0);
         rem &= ~pm;
-        if (c.dbg && lane == 0) {
-            atomicAdd(c.dbg + 1, 1ull);
-            atomicAdd(c.dbg + 4, (unsigned long long)__popcll(pm));
-        }
-        const int b = c.b0 + q0;
-        unsigned long long *list = (unsigned long long *)(g_smem + c.list_off + q0 * 512);  // [64] ascending
-        unsigned long long *gkl = (unsigned long long *)(g_smem + c.gkl_off + q0 * 8);
-        // cheap pre-check against the current bound, without the lock (it only ever decreases): the list's
-        // own k-th key or the best bound imported from the other workgroups, whichever is smaller
-        unsigned long long kth = __hip_atomic_load(list + c.km1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const unsigned long long gk = __hip_atomic_load(gkl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (gk < kth) kth = gk;
-        unsigned long long px = __ballot(key_less(khi, rid, (uint32_t)(kth >> 32), (uint32_t)kth)) & pm;
-        if (!px || (c.skip & 2)) continue;
-        if (c.dbg && lane == 0) atomicAdd(c.dbg + 2, 1ull);
-        // ---- critical section ---------------------------------------------------------------------
-        unsigned int *lock = (unsigned int *)(g_smem + c.lock_off + q0 * 4);
-        for (;;) {
-            unsigned int got = 0;
-            if (lane == 0) got = (atomicCAS(lock, 0u, 1u) == 0u) ? 1u : 0u;
-            if (__builtin_amdgcn_readfirstlane(got)) break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-        const unsigned long long le = __hip_atomic_load(list + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        WaveList L;
-        L.hi = (uint32_t)(le >> 32);
-        L.lo = (uint32_t)le;
-        const uint32_t thi = __builtin_amdgcn_readlane(L.hi, c.km1), tlo = __builtin_amdgcn_readlane(L.lo, c.km1);
-        px = __ballot(key_less(khi, rid, thi, tlo)) & px;  // the list may have tightened meanwhile
-        if (px) {
-            wavelist_insert_many(L, px, khi, rid, lane);
-            __hip_atomic_store(list + lane, ((unsigned long long)L.hi << 32) | L.lo, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
-            const uint32_t ohi = __builtin_amdgcn_readlane(L.hi, c.km1);
-            const uint32_t olo = __builtin_amdgcn_readlane(L.lo, c.km1);
-            const unsigned long long okey = ((unsigned long long)ohi << 32) | olo;
-            if (lane == 0 && ohi != kKeyInfHi && okey < gk) {
-                if (c.dbg) atomicAdd(c.dbg + 3, 1ull);
-                // tell the other workgroups of this query (other row slices) and remember it locally
-                if (c.gkey) __hip_atomic_fetch_min(c.gkey + b, okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(gkl, okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                // (min: in tile mode the integer seed bound can be tighter than the first k-th key)
-                volatile unsigned short *sp = (volatile unsigned short *)(g_smem + c.shq_off + q0 * 2);
-                const unsigned short nb = qbound_from_key<M>(okey, c.smax[b], c.qstep[b], c.qlo[b]);
-                if (nb < *sp) *sp = nb;
-            }
-            if (c.gk2) {
-                // this slice's j-th key, for the max-of-j-th bound the sibling slices compute
-                const uint32_t jhi = __builtin_amdgcn_readlane(L.hi, c.jm1);
-                const uint32_t jlo = __builtin_amdgcn_readlane(L.lo, c.jm1);
-                const unsigned long long jkey = ((unsigned long long)jhi << 32) | jlo;
-                volatile unsigned long long *gjl = (volatile unsigned long long *)(g_smem + c.gjl_off + q0 * 8);
-                if (lane == 0 && jhi != kKeyInfHi && jkey < *gjl) {
-                    *gjl = jkey;
-                    __hip_atomic_store(c.gk2 + (int64_t)b * c.n_slices + c.slice, jkey, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        // LDS executes one wave's instructions in order, so the list stores are visible before the release
-        if (lane == 0) __hip_atomic_store(lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        offer_to_list<M>(c, q0, pm, khi, rid, lane);
+    }
+}
+
+// Tile mode: the candidates of ONE query slot, collected by all waves of the workgroup since the last round
+// (row ids in LDS), are scored and inserted by the wave that owns the slot -- one list update per round instead
+// of one per (wave, query) event (2.4 candidates per event at 39k-row cells: the events cost 1.4x the scan).
+template <int M, bool SKEWED>
+__device__ __attribute__((noinline)) void qfilter_round(const FlushCtx c, int q0, uint32_t buf_off, int n) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t *buf = (const uint32_t *)(g_smem + buf_off);
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const bool act = c0 + lane < n;
+        const uint32_t rid = act ? buf[c0 + lane] : 0u;
+        float ex = 0.f;
+        if (act && !(c.skip & 1)) ex = exact_row_sum<M, SKEWED>(c, q0, rid);
+        offer_to_list<M>(c, q0, __ballot(act), f32_to_ordered(ex), rid, lane);
     }
 }
 
@@ -311,7 +343,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                 // for every row: 15 pad queries made a 1-query batch 15x slower than a 16-query one): 0x7fff - S
                 // never has bit 15 set and never borrows from the neighbouring field
                 bool real = b < a.B;
-                if constexpr (TILES) real = real && a.vmap[b] >= 0;  // padding slots sit in every tile
+                if constexpr (TILES) {
+                    real = real && a.vmap[b] >= 0;  // padding slots sit in every tile
+                    ((volatile uint32_t *)(smem + queue_off + NW * 512))[tid] = 0;  // candidates collected for the slot
+                }
                 shq[tid] = real ? qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]) : (unsigned short)0x7fff;
             }
             for (int idx = tid; idx < QT * 64; idx += NW * 64) lists[idx] = ~0ull;
@@ -358,14 +393,21 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
             constexpr int h = decltype(H)::value;
             // issue all M look-ups of the group before the first add (the compiler otherwise re-used one
             // register pair and waited lgkmcnt(0) after every second load)
-            u32x4 v[M];
-            static_for<0, M>([&](auto T) {
-                constexpr int t = decltype(T)::value;
-                v[t] = *(const u32x4 *)(addr[t] + h * RB);
+            // (tile mode keeps 8 look-ups in flight instead of M: its extra scalar state pushed 9 of the 16 loop-
+            // invariant LDS base registers into scratch, reloaded every step -- 2.2 us per step instead of 1.3)
+            constexpr int CH = (TILES && M > 8) ? 8 : M;
+            static_for<0, M / CH>([&](auto C) {
+                constexpr int c0 = decltype(C)::value * CH;
+                u32x4 v[CH];
+                static_for<0, CH>([&](auto T) {
+                    constexpr int t = decltype(T)::value;
+                    v[t] = *(const u32x4 *)(addr[c0 + t] + h * RB);
+                });
+                asm volatile("" ::: "memory");
+                if constexpr (c0 == 0) acc = v[0];
+                else acc += v[0];
+                static_for<1, CH>([&](auto T) { acc += v[decltype(T)::value]; });
             });
-            asm volatile("" ::: "memory");
-            acc = v[0];
-            static_for<1, M>([&](auto T) { acc += v[decltype(T)::value]; });
         };
         u32x4 thp[NQ];  // packed (0x8000 | qthr) of the group's 8 queries
 #pragma unroll
@@ -413,28 +455,25 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                         if (lane == 0) smin[wave * (NQ * 4) + h * 4 + w] = x;
                     }
                 __syncthreads();
-                if (tid < QT) {
-                    const int b = tile * QT + tid;
+                if (tid < QT * NW) {
+                    // thread (q, i) ranks minimum i of slot q among the NW (ties by wave); the one of rank k-1 sets the bound
+                    const int q = tid / NW, i = tid - q * NW;
+                    const int b = tile * QT + q;
                     if (b < a.B && a.vmap[b] >= 0) {
                         const volatile uint16_t *sm16 = (const volatile uint16_t *)smin;
-                        uint32_t sk = 0x7fffu;  // k-th smallest of the NW minima (rank counting, ties by wave)
-#pragma unroll 1
-                        for (int i = 0; i < NW; ++i) {
-                            const uint32_t vi = sm16[i * (NQ * 8) + tid];
-                            int rank = 0;
-#pragma unroll 1
-                            for (int j = 0; j < NW; ++j) {
-                                const uint32_t vj = sm16[j * (NQ * 8) + tid];
-                                rank += (vj < vi) || (vj == vi && j < i);
-                            }
-                            if (rank == km1) sk = vi;
+                        const uint32_t vi = sm16[i * (NQ * 8) + q];
+                        int rank = 0;
+#pragma unroll 4
+                        for (int j = 0; j < NW; ++j) {
+                            const uint32_t vj = sm16[j * (NQ * 8) + q];
+                            rank += (vj < vi) || (vj == vi && j < i);
                         }
-                        if (sk < 0x7fffu) {
+                        if (rank == km1 && vi < 0x7fffu) {
                             const double slack = (double)a.smax[b] * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
-                            double qd = __builtin_floor((double)sk + 1.002 * M + 0.04 + 2.0 * slack / (double)a.qstep[b]) + 1.0;
+                            double qd = __builtin_floor((double)vi + 1.002 * M + 0.04 + 2.0 * slack / (double)a.qstep[b]) + 1.0;
                             if (!(qd < 32767.0)) qd = 32767.0;
                             const unsigned short nb = (unsigned short)(0x8000u | (uint32_t)qd);
-                            if (nb < shq[tid]) shq[tid] = nb;
+                            if (nb < shq[q]) shq[q] = nb;
                         }
                     }
                 }
@@ -449,6 +488,105 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                              list_off, lock_off, shq_off, gkl_off, gjl_off};
         int qcnt = 0;  // entries in this wave's candidate queue
         int step_no = 0;
+        if constexpr (TILES) {
+            if (a.flush_mask & 0x100) {
+                // pull the tile's fp32 tables (QT x Ks x M floats, contiguous) towards the caches: the rounds gather
+                // from them at random and found them cold in HBM (87 of 190 us per 39k-row tile)
+                const char *tb = (const char *)(a.lut + (int64_t)tile * QT * a.Ks * M);
+                const int total16 = QT * a.Ks * M / 4;
+                u32x4 sink = {0u, 0u, 0u, 0u};
+#pragma unroll 8
+                for (int i = tid; i < total16; i += NW * 64) sink |= *(const u32x4 *)(tb + (int64_t)i * 16);
+                if (sink.x == 0x12345678u && sink.y == 0x9abcdef0u && a.dbg) a.dbg[7] = 1;  // (keeps the loads alive)
+            }
+            // Tile mode: a tile is short (a 39k-row cell = 38 steps), so the candidate events of the streaming
+            // scheme below (2.4 candidates per (wave, query) event, each paying lock + list + bound update) cost
+            // more than the scan.  Instead every wave APPENDS the rows that pass the filter to a per-slot buffer in
+            // LDS and, in ROUNDS after steps 0, 3, 15, 63, 255, ... and the last one, the wave that owns slot q
+            // scores and inserts all of slot q's candidates at once (one list update per slot and round; the bound
+            // moves on a log scale anyway).  All waves run the same number of steps so the rounds' barriers meet.
+            constexpr int CAP = kTileCandBytes / (QT * 4);
+            volatile uint32_t *ccnt = (volatile uint32_t *)(smem + queue_off + NW * 512);  // [QT]
+            const uint32_t cbuf_off = queue_off + NW * 512 + 64;
+            uint32_t *cbuf = (uint32_t *)(smem + cbuf_off);                                // [QT][CAP] row ids
+            const int n_steps = (int)((slice_end - slice_begin + stride - 1) / stride);
+            for (; step_no < n_steps; ++step_no, row0 += stride) {
+                if (row0 < slice_end) {
+                    unsigned long long vmask = ~0ull;
+                    if (slice_end - row0 < 64) vmask = (1ull << (int)(slice_end - row0)) - 1ull;
+                    if (a.valid) vmask &= __ballot((vcur >> (lane & 31)) & 1u);
+                    const uint32_t rid = (uint32_t)(row0 + lane);
+                    make_addr(ccur);
+                    u32x4 acc[NQ];
+                    static_for<0, NQ>([&](auto H) { group_sum(H, acc[decltype(H)::value]); });
+                    uint32_t anyv = 0;
+#pragma unroll
+                    for (int h = 0; h < NQ; ++h)
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) anyv |= thp[h][w] - acc[h][w];
+                    const unsigned long long anym = __ballot((anyv & 0x80008000u) != 0) & vmask;
+                    if (anym && !(a.dbg_skip & 4)) {
+                        if (a.dbg && lane == 0) atomicAdd(a.dbg + 0, 1ull);
+#pragma unroll
+                        for (int h = 0; h < NQ; ++h) {
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) {
+                                const uint32_t x = (thp[h][w] - acc[h][w]) & 0x80008000u;
+                                if (__ballot(x != 0) & vmask) {
+#pragma unroll
+                                    for (int half = 0; half < 2; ++half) {
+                                        const unsigned long long pm =
+                                            __ballot((x & (half ? 0x80000000u : 0x8000u)) != 0) & vmask;
+                                        if (pm) {
+                                            const int q = h * QG + w * 2 + half;
+                                            const int n = __popcll(pm);
+                                            uint32_t base = 0;
+                                            if (lane == 0) base = atomicAdd((uint32_t *)&ccnt[q], (uint32_t)n);
+                                            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                                            const int rank = __builtin_amdgcn_mbcnt_hi(
+                                                (uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                                            const bool mine = (pm >> lane) & 1ull;
+                                            const bool fits = base + (uint32_t)rank < (uint32_t)CAP;
+                                            if (mine && fits) cbuf[q * CAP + base + rank] = rid;
+                                            if (base + (uint32_t)n > (uint32_t)CAP) {
+                                                // buffer full: this wave scores and inserts the overflow itself
+                                                const unsigned long long om = __ballot(mine && !fits);
+                                                const int orank = __builtin_amdgcn_mbcnt_hi(
+                                                    (uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u));
+                                                unsigned long long *queue = (unsigned long long *)(smem + queue_off + wave * 512);
+                                                if (mine && !fits) queue[orank] = ((unsigned long long)q << 32) | rid;
+                                                qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, __popcll(om));
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
+                    if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
+                    load_row(row0 + 2 * stride + lane, cnext);
+                    vcur = vnext;
+                    vnext = load_valid(row0 + 2 * stride + lane);
+                }
+                const int r = step_no + 1;
+                if (((r & (r - 1)) == 0 && (__builtin_ctz((unsigned)r) & 1) == 0) || (r & 255) == 0 || r == n_steps) {
+                    __syncthreads();  // every wave's appends are in LDS
+                    for (int q = wave; q < QT; q += NW) {
+                        uint32_t n = ccnt[q];
+                        if (n > (uint32_t)CAP) n = CAP;  // (what did not fit was handled by the wave that found it)
+                        if (n) {
+                            qfilter_round<M, SKEWED>(fc, q, cbuf_off + q * CAP * 4, (int)n);
+                            if (lane == 0) ccnt[q] = 0;
+                        }
+                    }
+                    __syncthreads();  // bounds published, buffers empty
+#pragma unroll
+                    for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
+                }
+            }
+        } else
         for (; row0 < slice_end; row0 += stride, ++step_no) {
             unsigned long long vmask = ~0ull;
             if (slice_end - row0 < 64) vmask = (1ull << (int)(slice_end - row0)) - 1ull;
@@ -511,7 +649,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
             // k-th key any of them published and, per group of 8 concurrently scanned slices, the MAX of
             // their j-th keys (8 disjoint slices x j rows >= k rows at or below it; +1: that row itself must
             // still be accepted).  Bounds move on a log scale, so: steps 0, 1, 3, 7, ... then every 64th.
-            if (a.gkey) {
+            if (!TILES && a.gkey) {  // (tile mode: one slice per tile, nothing to import)
                 const bool pow2 = ((step_no + 1) & step_no) == 0;
                 if (pow2 || (step_no & 63) == 63) {
                     const int rw = pow2 ? (__builtin_ctz((unsigned)step_no + 1u) % NW) : ((step_no >> 6) % NW);
@@ -566,6 +704,21 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
 
         // ---- the shared lists ARE the workgroup's result for this (tile, slice) ----------------------
         __syncthreads();
+        if constexpr (TILES) {
+            // one slice per tile: the lists are final -- no partial lists, no arrival counter, no merge
+            for (int q = wave; q < QT; q += NW) {
+                const int b = tile * QT + q;
+                if (b < a.B && lane <= km1) {
+                    const unsigned long long key = lists[q * 64 + lane];
+                    const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+                    const bool none = (hi == kKeyInfHi && lo == kIdNone);
+                    const float d = none ? __builtin_inff() : ordered_to_f32(hi);
+                    a.out_d[(int64_t)b * a.k + lane] = a.sqrt_out ? __builtin_sqrtf(d) : d;
+                    a.out_i[(int64_t)b * a.k + lane] = none ? (int64_t)-1 : a.row_base + (int64_t)lo;
+                }
+            }
+            continue;
+        }
         for (int q = wave; q < QT; q += NW) {
             const int b = tile * QT + q;
             // device-scope stores: the merging workgroup may sit on another XCD (own L2)
@@ -828,7 +981,7 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
                 flushed = true;
             }
             // import the bounds of the other slices (see adc_scan_qfilter_kernel)
-            if (a.gkey) {
+            if (!TILES && a.gkey) {  // (tile mode: one slice per tile, nothing to import)
                 const bool pow2 = ((step_no + 1) & step_no) == 0;
                 if (pow2 || (step_no & 63) == 63) {
                     const int rw = pow2 ? (__builtin_ctz((unsigned)step_no + 1u) % NW) : ((step_no >> 6) % NW);
@@ -877,6 +1030,20 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
         if (qcnt) qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
 
         __syncthreads();
+        if constexpr (TILES) {  // (see adc_scan_qfilter_kernel)
+            for (int q = wave; q < QT; q += NW) {
+                const int b = tile * QT + q;
+                if (b < a.B && lane <= km1) {
+                    const unsigned long long key = lists[q * 64 + lane];
+                    const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+                    const bool none = (hi == kKeyInfHi && lo == kIdNone);
+                    const float d = none ? __builtin_inff() : ordered_to_f32(hi);
+                    a.out_d[(int64_t)b * a.k + lane] = a.sqrt_out ? __builtin_sqrtf(d) : d;
+                    a.out_i[(int64_t)b * a.k + lane] = none ? (int64_t)-1 : a.row_base + (int64_t)lo;
+                }
+            }
+            continue;
+        }
         for (int q = wave; q < QT; q += NW) {
             const int b = tile * QT + q;
             if (b < a.B && lane <= km1)
@@ -906,7 +1073,8 @@ using namespace annlite;
 template <int M, int NQ, int NW, int WPS, bool SKEWED>
 static int launch_qfilter(const ScanArgs &a, int grid, hipStream_t st) {
     const size_t lds_lut = (size_t)a.Ks * NQ * M * 16;
-    const size_t need = lds_lut + 256 + (size_t)8 * NQ * 64 * 8 + 128 + (size_t)NW * 512;
+    const size_t need = lds_lut + 256 + (size_t)8 * NQ * 64 * 8 + 128 + (size_t)NW * 512 +
+                        (a.tile_rows ? (size_t)kTileCandBytes + 64 : 0);
     auto fn = a.tile_rows ? adc_scan_qfilter_kernel<M, NQ, NW, WPS, SKEWED, true>
                           : adc_scan_qfilter_kernel<M, NQ, NW, WPS, SKEWED, false>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
