@@ -53,7 +53,7 @@ SYMBOLS = (
     'annlite_ivf_plan',
     'annlite_pq_search_tiles_workspace_bytes',
     'annlite_pq_search_tiles',
-    'annlite_ivf_merge',
+    'annlite_ivf_rescore',
     'annlite_codes_skew',
     'annlite_profile_enable',
     'annlite_profile_last_scan_ms',
@@ -125,9 +125,10 @@ def lib() -> ctypes.CDLL:
     L.annlite_ivf_max_tiles.argtypes = [i64, i64, i64, i64]
     L.annlite_ivf_plan.argtypes = [vp, i64, i64, i64, i64, vp, vp, i64, vp, vp, vp, vp, vp]
     L.annlite_pq_search_tiles_workspace_bytes.argtypes = [i64, i64, i64, i32, i64, i64, ctypes.POINTER(ctypes.c_int64)]
-    L.annlite_pq_search_tiles.argtypes = [i32, vp, i64, i64, vp, vp, i32, i32, i64, i64, i64, vp, i64, vp, vp, vp, vp,
-                                          vp, sz, vp]
-    L.annlite_ivf_merge.argtypes = [vp, vp, vp, i64, i64, i64, vp, i64, vp, vp, i32, vp]
+    L.annlite_pq_search_tiles.argtypes = [i32, vp, i64, i64, vp, vp, i32, i32, i64, i64, i64, vp, i64, vp, vp, vp, i64,
+                                          vp, vp, sz, vp]
+    L.annlite_ivf_rescore.argtypes = [vp, i64, i64, i64, vp, i64, vp, vp, i64, vp, vp, i64, vp, i64, vp, i64, i64, vp,
+                                      vp, i32, vp]
     L.annlite_profile_enable.argtypes = [i32]
     L.annlite_profile_last_scan_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]
     L.annlite_debug_counters.argtypes = [ctypes.POINTER(ctypes.c_uint64)]

@@ -17,8 +17,10 @@ Layout in HBM on top of the flat index's storage (codes by offset, validity, opt
                      multiple of 64 rows, ascending offset inside a cell
       ``_row_ids``   i64 [Nt] offset of every table row (-1: padding)
       ``_cell_rows`` i64 [C, 2] (begin, end) of every cell, ``_cell_order`` i32 [C] cells by descending size
+      ``_table_plain`` the same rows in the PLAIN layout (read by the exact re-score)
 Search = ``annlite_ivf_select_cells`` -> ``annlite_ivf_plan`` (query tiles of one cell each) -> gather of the slot
-queries -> ``annlite_pq_search_tiles`` (tables + scan + per-slot top-k) -> ``annlite_ivf_merge``.
+queries -> ``annlite_pq_search_tiles`` (quantised tables + integer scan: per-slot candidate lists) ->
+``annlite_lut_build`` for the real queries -> ``annlite_ivf_rescore`` (exact sums of the candidates, top-k).
 """
 from typing import Optional, Tuple
 
@@ -42,7 +44,8 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
         self.n_probe = n_probe  # None: every cell (the reference's behaviour)
         self._cell_of = None
         self._sealed = False
-        self._table = self._row_ids = self._cell_rows = self._cell_order = self._pos_of = None
+        self._table = self._table_plain = self._row_ids = self._cell_rows = self._cell_order = self._pos_of = None
+        self.cand_cap = 256  # emitted candidates per (query, cell) list; an overflowing list falls back to the whole cell
         self._tws = ops.ScanWorkspace()
 
     @property
@@ -60,22 +63,15 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
         self._sealed = False
 
     def add_with_ids(self, x, ids, **kwargs):
-        xq = self._pre(x)  # (normalised for cosine: the PQ codes and the float vectors see this)
         ids_t = ops.to_dev(np.asarray(ids, dtype=np.int64) if not isinstance(ids, torch.Tensor) else ids, torch.int64)
         if ids_t.numel() == 0:
             return
+        super().add_with_ids(x, ids_t)  # codes / validity / float vectors exactly as the flat index stores them
         # the reference assigns cells on the vectors as given (index.py:291-292, vq.py:81-90)
         raw = ops.to_dev(x, torch.float32)
         raw = raw.reshape(1, -1) if raw.ndim == 1 else raw
-        cells = self.vq_codec.encode(raw)
-        self._add_preprocessed(xq, ids_t)
-        self._cell_of[ids_t] = cells.to(torch.int32)
+        self._cell_of[ids_t] = self.vq_codec.encode(raw).to(torch.int32)
         self._sealed = False
-
-    def _add_preprocessed(self, xq: torch.Tensor, ids_t: torch.Tensor):
-        # PQFlatGpuIndex.add_with_ids normalises again for cosine; normalising a unit vector is idempotent up to
-        # rounding, so hand it the caller's input path instead of re-implementing the storage update
-        super().add_with_ids(xq, ids_t)
 
     def delete(self, ids):
         super().delete(ids)
@@ -104,9 +100,11 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
         pos = begin[cell_sorted] + rank
         Nt = max(64, int(padded.sum().item()))
         self._table = torch.zeros((Nt, self.M), dtype=torch.uint8, device=dev)
+        self._table_plain = torch.zeros((Nt, self.M), dtype=torch.uint8, device=dev)
         if offs.numel():
             plain = self._plain_codes(N)[offs].contiguous()
             ops.codes_skew(plain, pos.contiguous(), out=self._table)
+            self._table_plain[pos] = plain
         self._row_ids = torch.full((Nt,), -1, dtype=torch.int64, device=dev)
         self._row_ids[pos] = offs
         self._pos_of = torch.full((max(N, 1),), -1, dtype=torch.int64, device=dev)
@@ -168,7 +166,6 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
         return self._pack_bits(sel)
 
     def _search_pruned(self, q, k, P, indices, rerank_k):
-        B = q.shape[0]
         rerank = self.rerank and self._vectors is not None
         ks = max(k, min(64, int(rerank_k or 64))) if rerank else k
         cells = self.probe_cells(q, P)
@@ -176,15 +173,18 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
         vmap, slot_of, tile_rows, _ = ops.ivf_plan(cells, self.n_cells, qt, self._cell_rows, self._cell_order)
         slot_q = q.index_select(0, vmap.clamp(min=0).to(torch.int64))
         kind, xq = self.pq_codec.scan_inputs(slot_q)
-        sd, si = ops.pq_search_tiles(kind, xq, self.pq_codec.codebooks_dev, self._table, ks, self.M, self.Ks, tile_rows,
-                                     vmap, valid_bits=self._table_bits(indices), n_rows=self._n_table,
-                                     codes_layout=CODES_SKEWED, workspace=self._tws)
+        bits = self._table_bits(indices)
+        cand, count = ops.pq_search_tiles(kind, xq, self.pq_codec.codebooks_dev, self._table, ks, self.M, self.Ks,
+                                          tile_rows, vmap, valid_bits=bits, n_rows=self._n_table,
+                                          codes_layout=CODES_SKEWED, workspace=self._tws, cand_cap=self.cand_cap)
+        lut = self.pq_codec.get_dist_mat(q)  # [B, M, Ks], the reference's tables for the real queries
         if not rerank:
-            return ops.ivf_merge(sd, si, slot_of, k, self._row_ids, 0, sqrt=self.metric == Metric.EUCLIDEAN)
-        _, cand = ops.ivf_merge(sd, si, slot_of, ks, self._row_ids, 0)
-        exact = ops.exact_gather_dist(int(self.metric), q, self._vectors, cand)
+            return ops.ivf_rescore(lut, self._table_plain, cand, count, slot_of, tile_rows, qt, k, self._row_ids, bits,
+                                   sqrt=self.metric == Metric.EUCLIDEAN)
+        _, ids = ops.ivf_rescore(lut, self._table_plain, cand, count, slot_of, tile_rows, qt, ks, self._row_ids, bits)
+        exact = ops.exact_gather_dist(int(self.metric), q, self._vectors, ids)
         d, pos = ops.topk_rows(exact, k)
-        i = torch.gather(cand, 1, pos.clamp(min=0))
+        i = torch.gather(ids, 1, pos.clamp(min=0))
         i = torch.where((pos < 0) | torch.isinf(d), torch.full_like(i, -1), i)
         if self.metric == Metric.EUCLIDEAN:
             d = torch.sqrt(d)

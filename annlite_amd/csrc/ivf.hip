@@ -15,7 +15,7 @@ namespace annlite {
 // ---- cell selection ------------------------------------------------------------------------------
 // One 256-thread workgroup per QB queries: the query vectors sit in LDS (read by broadcast), thread t owns the
 // centroids t, t + 256, ... and keeps QB running sums while it streams a centroid row ONCE; the QB x C distances
-// go to LDS and the P nearest are picked by rank counting under the fixed order (distance asc, cell asc).
+// go to LDS, where one wave per query picks the P nearest under the fixed order (distance asc, cell asc).
 constexpr int kSelQB = 8;
 template <int KIND>  // 0: squared L2, 1: negative inner product
 __global__ __launch_bounds__(256) void ivf_select_cells_kernel(const float *__restrict__ q, int B, int D,
@@ -53,13 +53,14 @@ __global__ __launch_bounds__(256) void ivf_select_cells_kernel(const float *__re
         for (int u = 0; u < kSelQB; ++u) ds[u * C + c] = KIND == 0 ? acc[u] : -acc[u];
     }
     __syncthreads();
-    if (P == 1) {
-        // nearest centroid only (cell assignment of the indexed rows, VQCodec.encode): argmin by reduction --
-        // wave u / 2 takes queries 2*(u/2), 2*(u/2)+1 ... : one wave per pair of queries
-        const int lane = tid & 63, wave = tid >> 6;
-        for (int u = wave; u < kSelQB; u += 4) {
-            if (b0 + u >= B) continue;
-            const float *row = ds + u * C;
+    // the P nearest, one wave per query: P rounds of "lane-local minimum over its cells -> wave argmin -> mark taken"
+    // under the fixed order (distance asc, cell asc).  (Rank counting every cell against every other was C^2 per
+    // query: 0.88 ms for 1024 queries x 1024 cells.)
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int u = wave; u < kSelQB; u += 4) {
+        if (b0 + u >= B) continue;
+        float *row = ds + u * C;
+        for (int p = 0; p < P; ++p) {
             float best = __builtin_inff();
             int bi = 0x7fffffff;
             for (int c = lane; c < C; c += 64) {
@@ -72,21 +73,9 @@ __global__ __launch_bounds__(256) void ivf_select_cells_kernel(const float *__re
                 const int oi = __shfl_xor(bi, o);
                 if (ov < best || (ov == best && oi < bi)) best = ov, bi = oi;
             }
-            if (lane == 0) cells[b0 + u] = bi;
+            if (lane == 0) cells[(int64_t)(b0 + u) * P + p] = bi;
+            if (bi < C && lane == (bi & 63)) row[bi] = __builtin_inff();  // taken (LDS ops of a wave execute in order)
         }
-        return;
-    }
-    for (int i = tid; i < kSelQB * C; i += 256) {
-        const int u = i / C, c = i - u * C;
-        if (b0 + u >= B) continue;
-        const float *row = ds + u * C;
-        const float me = row[c];
-        int rank = 0;
-        for (int o = 0; o < C; ++o) {
-            const float v = row[o];
-            rank += (v < me) || (v == me && o < c);
-        }
-        if (rank < P) cells[(int64_t)(b0 + u) * P + rank] = c;
     }
 }
 
@@ -158,37 +147,83 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *__restric
     }
 }
 
-// ---- merge of a query's per-cell lists --------------------------------------------------------------
-// One wave per query.  List v (slot of a (query, cell) pair) holds k entries ascending in (distance, table row);
-// rows of a cell are stored in ascending external id, so after the row -> id translation every list is ascending
-// in (distance, id) and the lists are merged under the fixed tie-break.
-__global__ __launch_bounds__(256) void ivf_merge_kernel(const float *__restrict__ vd, const int64_t *__restrict__ vi,
-                                                       const int32_t *__restrict__ slot_of, int B, int P, int k,
-                                                       const int64_t *__restrict__ row_ids, int64_t id_base,
-                                                       float *__restrict__ out_d, int64_t *__restrict__ out_i,
-                                                       int sqrt_out) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
+// ---- exact re-score of a query's candidate lists ---------------------------------------------------
+// One 256-thread workgroup per query.  The query's fp32 table [M][Ks] (what get_dist_mat returns for it) sits in
+// LDS; the candidate rows its P probed (cell, slot) lists hold get their exact ascending-m fp32 ADC sum -- the
+// reference's sum (space_pq.h:32-35 / pq_bindings.pyx:44-45), bit for bit -- and the k best under the fixed order
+// (distance asc, id asc) survive: per wave in a sorted wave list, the four lists are merged at the end.
+// A slot whose list overflowed (count 0xffffffff) is re-scored over ALL rows of its cell.
+// codes: the cell-sorted table in the PLAIN layout.  ids: row_ids[row] (external offsets), < 2^32.
+__global__ __launch_bounds__(256) void ivf_rescore_kernel(const float *__restrict__ lut, int B, int M, int Ks,
+                                                         const uint8_t *__restrict__ codes,
+                                                         const uint32_t *__restrict__ valid,
+                                                         const uint32_t *__restrict__ cand, int cand_cap,
+                                                         const uint32_t *__restrict__ cand_count,
+                                                         const int32_t *__restrict__ slot_of, int P,
+                                                         const int64_t *__restrict__ tile_rows, int qt,
+                                                         const int64_t *__restrict__ row_ids, int64_t id_base, int k,
+                                                         float *__restrict__ out_d, int64_t *__restrict__ out_i,
+                                                         int sqrt_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *tab = (float *)smem;                                               // [M][Ks]
+    unsigned long long *wl = (unsigned long long *)(smem + (size_t)M * Ks * 4);  // [4][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    {
+        const f32x4 *src = (const f32x4 *)(lut + (int64_t)b * M * Ks);
+        for (int i = tid; i < M * Ks / 4; i += 256) ((f32x4 *)tab)[i] = src[i];
+    }
+    __syncthreads();
+    const int km1 = k - 1;
+    const int MW = M / 4;
     WaveList L;
     L.reset();
+    uint32_t thr_hi = kKeyInfHi, thr_lo = kIdNone;
     for (int p = 0; p < P; ++p) {
         const int v = slot_of[(int64_t)b * P + p];
-        uint32_t chi = kKeyInfHi, clo = kIdNone;
-        if (lane < k) {
-            const int64_t row = vi[(int64_t)v * k + lane];
-            if (row >= 0) {
-                chi = f32_to_ordered(vd[(int64_t)v * k + lane]);
-                clo = (uint32_t)(row_ids ? row_ids[row] : row);
-            }
+        const uint32_t n = cand_count[v];
+        const bool range = n == 0xffffffffu;
+        int64_t rb = 0, total = n;
+        if (range) {
+            rb = tile_rows[2 * (int64_t)(v / qt)];
+            total = tile_rows[2 * (int64_t)(v / qt) + 1] - rb;
         }
-        wavelist_merge_sorted(L, chi, clo, lane);
+        const uint32_t *cl = cand + (int64_t)v * cand_cap;
+        for (int64_t i0 = (int64_t)wave * 64; i0 < total; i0 += 256) {
+            const int64_t i = i0 + lane;
+            bool act = i < total;
+            int64_t row = 0;
+            if (act) row = range ? rb + i : (int64_t)cl[i];
+            if (act && range && valid) act = (valid[row >> 5] >> (row & 31)) & 1u;
+            float d = 0.f;
+            const uint32_t *p32 = (const uint32_t *)(codes + row * M);
+            for (int w = 0; w < MW; ++w) {
+                const uint32_t word = p32[w];
+                const float *t = tab + (w * 4) * Ks;
+                d += t[word & 0xffu];
+                d += t[Ks + ((word >> 8) & 0xffu)];
+                d += t[2 * Ks + ((word >> 16) & 0xffu)];
+                d += t[3 * Ks + (word >> 24)];
+            }
+            const uint32_t hi = f32_to_ordered(d);
+            const uint32_t lo = act ? (uint32_t)(row_ids ? row_ids[row] : row) : kIdNone;
+            const unsigned long long pm = __ballot(act && key_less(hi, lo, thr_hi, thr_lo));
+            if (pm) wavelist_offer(L, pm, hi, lo, km1, thr_hi, thr_lo, lane);
+        }
     }
-    if (lane < k) {
-        const bool none = (L.hi == kKeyInfHi && L.lo == kIdNone);
-        const float d = none ? __builtin_inff() : ordered_to_f32(L.hi);
-        out_d[(int64_t)b * k + lane] = sqrt_out && !none ? __builtin_sqrtf(d) : d;
-        out_i[(int64_t)b * k + lane] = none ? (int64_t)-1 : id_base + (int64_t)L.lo;
+    wl[wave * 64 + lane] = ((unsigned long long)L.hi << 32) | L.lo;
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < 4; ++w) {
+            const unsigned long long o = wl[w * 64 + lane];
+            wavelist_merge_sorted(L, (uint32_t)(o >> 32), (uint32_t)o, lane);
+        }
+        if (lane < k) {
+            const bool none = (L.hi == kKeyInfHi && L.lo == kIdNone);
+            const float d = none ? __builtin_inff() : ordered_to_f32(L.hi);
+            out_d[(int64_t)b * k + lane] = sqrt_out && !none ? __builtin_sqrtf(d) : d;
+            out_i[(int64_t)b * k + lane] = none ? (int64_t)-1 : id_base + (int64_t)L.lo;
+        }
     }
 }
 
@@ -248,15 +283,27 @@ extern "C" int annlite_ivf_plan(const int32_t *cells_dev, int64_t B, int64_t P, 
     return launch_status("ivf_plan_kernel");
 }
 
-extern "C" int annlite_ivf_merge(const float *slot_dist_dev, const int64_t *slot_row_dev, const int32_t *slot_of_dev,
-                                 int64_t B, int64_t P, int64_t k, const int64_t *row_ids_dev, int64_t id_base,
-                                 float *out_dist_dev, int64_t *out_id_dev, int flags, void *stream) {
+extern "C" int annlite_ivf_rescore(const float *lut_bmk_dev, int64_t B, int64_t M, int64_t Ks,
+                                   const void *codes_plain_dev, int64_t N, const uint32_t *valid_bits_dev,
+                                   const uint32_t *cand_dev, int64_t cand_cap, const uint32_t *cand_count_dev,
+                                   const int32_t *slot_of_dev, int64_t P, const int64_t *tile_rows_dev, int64_t qt,
+                                   const int64_t *row_ids_dev, int64_t id_base, int64_t k, float *out_dist_dev,
+                                   int64_t *out_id_dev, int flags, void *stream) {
     ANNLITE_REQUIRE(B >= 0 && P >= 1 && k >= 1 && k <= 64, "bad B=%lld P=%lld k=%lld (k<=64)", (long long)B, (long long)P,
                     (long long)k);
+    ANNLITE_REQUIRE(M >= 4 && M % 4 == 0 && Ks >= 1 && Ks <= 256 && (M * Ks) % 4 == 0, "bad M=%lld Ks=%lld (uint8 codes, M %% 4 == 0)",
+                    (long long)M, (long long)Ks);
+    ANNLITE_REQUIRE(N >= 0 && N < (1ll << 32) - 1 && qt >= 1 && cand_cap >= 1, "bad N / qt / cand_cap");
     if (B == 0) return ANNLITE_OK;
-    ANNLITE_REQUIRE(slot_dist_dev && slot_row_dev && slot_of_dev && out_dist_dev && out_id_dev, "null device pointer");
-    hipLaunchKernelGGL(ivf_merge_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, slot_dist_dev,
-                       slot_row_dev, slot_of_dev, (int)B, (int)P, (int)k, row_ids_dev, id_base, out_dist_dev, out_id_dev,
+    ANNLITE_REQUIRE(lut_bmk_dev && codes_plain_dev && cand_dev && cand_count_dev && slot_of_dev && tile_rows_dev &&
+                        out_dist_dev && out_id_dev,
+                    "null device pointer");
+    const size_t lds = (size_t)M * Ks * 4 + 4 * 64 * 8;
+    ANNLITE_REQUIRE(lds <= 160 * 1024, "table of %zu B does not fit the LDS", lds);
+    ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)ivf_rescore_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ivf_rescore_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, lut_bmk_dev, (int)B, (int)M,
+                       (int)Ks, (const uint8_t *)codes_plain_dev, valid_bits_dev, cand_dev, (int)cand_cap, cand_count_dev,
+                       slot_of_dev, (int)P, tile_rows_dev, (int)qt, row_ids_dev, id_base, (int)k, out_dist_dev, out_id_dev,
                        (flags & ANNLITE_FLAG_SQRT) ? 1 : 0);
-    return launch_status("ivf_merge_kernel");
+    return launch_status("ivf_rescore_kernel");
 }

@@ -76,15 +76,30 @@ __global__ __launch_bounds__(256) void lut_bmk_kernel(int kind, const float *__r
     const float *cw = cb + ((int64_t)m * Ks + k) * dsub;
     const float *qs = q + (int64_t)b * D + m * dsub;
     float acc = 0.f;
-    if (kind == ANNLITE_LUT_L2) {
+    if ((dsub & 3) == 0) {
+        // 16-byte loads, same j-ascending chains (the scalar loops are bound by the number of load instructions)
+        for (int j = 0; j < dsub; j += 4) {
+            const f32x4 cj = *(const f32x4 *)(cw + j);
+            const f32x4 qj = *(const f32x4 *)(qs + j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (kind == ANNLITE_LUT_L2) {
+                    const float c = cj[e] - qj[e];
+                    acc = __builtin_fmaf(c, c, acc);
+                } else {
+                    acc = __builtin_fmaf(cj[e], qj[e], acc);
+                }
+            }
+        }
+    } else if (kind == ANNLITE_LUT_L2) {
         for (int j = 0; j < dsub; ++j) {
             const float c = cw[j] - qs[j];
             acc = __builtin_fmaf(c, c, acc);
         }
     } else {
         for (int j = 0; j < dsub; ++j) acc = __builtin_fmaf(cw[j], qs[j], acc);
-        if (kind == ANNLITE_LUT_IPDIST) acc = inv_ks - acc;
     }
+    if (kind == ANNLITE_LUT_IPDIST) acc = inv_ks - acc;
     out[id] = acc;
 }
 

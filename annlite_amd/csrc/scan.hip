@@ -439,6 +439,9 @@ struct ScanOut {
 struct TileMode {
     const int64_t *tile_rows;  // [B / qt][2]
     const int32_t *vmap;       // [B]
+    uint32_t *cand;            // [B][cand_cap] out
+    uint32_t *cand_count;      // [B] out
+    int64_t cand_cap;
 };
 
 static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M, int64_t Ks,
@@ -455,7 +458,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         FastCfg ct;
         ANNLITE_REQUIRE(plan.fast && fast_cfg(M, Ks, code_bytes, k, &ct) && ct.mode == 4,
                         "tile mode needs the quantised-filter plan (M in {8,16,32,64}, Ks <= 256, uint8 codes)");
-        ANNLITE_REQUIRE(B % plan.qt == 0 && tm->tile_rows && tm->vmap && outp && share_across_slices,
+        ANNLITE_REQUIRE(B % plan.qt == 0 && tm->tile_rows && tm->vmap && tm->cand && tm->cand_count && tm->cand_cap >= 64,
                         "tile mode: B=%lld must be a multiple of the tile size %d", (long long)B, plan.qt);
     }
     ANNLITE_REQUIRE(codes_layout == ANNLITE_CODES_PLAIN || (codes_layout == ANNLITE_CODES_SKEWED && plan.fast),
@@ -538,6 +541,10 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 a.tile_rows = tm->tile_rows;
                 a.vmap = tm->vmap;
                 a.item_counter = item_counter;
+                a.cand = tm->cand;
+                a.cand_count = tm->cand_count;
+                a.cand_cap = (int32_t)tm->cand_cap;
+                if (outp) outp->merged = true;  // (the tile scan's result is the candidate lists)
             }
             if (share_across_slices && outp && (outp->packed || (outp->d && outp->i))) {
                 a.tile_done = tile_done;
@@ -562,7 +569,9 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             }
             // (the q16 table sits behind the small arrays; carve order is irrelevant to the kernels)
             uint16_t *q16 = (uint16_t *)carve(bpad * M * Ks * 2);
-            rc = launch_lut_quantise(M, Ks, B, bpad, lut_dev, build, q16, qstep, qlo, smax, workspace_dev, fill_bytes, st);
+            // (tile mode with the fused L2 build: the slots' fp32 tables are never read -- do not store them)
+            rc = launch_lut_quantise(M, Ks, B, bpad, (tm && build) ? nullptr : lut_dev, build, q16, qstep, qlo, smax,
+                                     workspace_dev, fill_bytes, st);
             if (rc != ANNLITE_OK) return rc;
             if (share_across_slices && N >= 4096 && !tm) {  // (tile mode seeds inside the scan kernel)
                 int64_t S = 8192;
@@ -639,7 +648,7 @@ static int scan_topk_impl(const void *codes_dev, int code_bytes, int codes_layou
                           const TileMode *tm = nullptr) {
     annlite_scan_plan plan;
     hipStream_t st = (hipStream_t)stream;
-    ANNLITE_REQUIRE(B == 0 || out_packed_dev || (out_dist_dev && out_id_dev), "null output pointer");
+    ANNLITE_REQUIRE(B == 0 || tm || out_packed_dev || (out_dist_dev && out_id_dev), "null output pointer");
     const int sqrt_out = (flags & ANNLITE_FLAG_SQRT) && !out_packed_dev ? 1 : 0;
     ScanOut so = {out_dist_dev, out_id_dev, out_packed_dev, row_base, sqrt_out, false};
     if (getenv("ANNLITE_NO_INKERNEL_MERGE") && !tm) so.d = nullptr, so.i = nullptr, so.packed = nullptr;
@@ -739,14 +748,15 @@ extern "C" int annlite_pq_search_tiles_workspace_bytes(int64_t N, int64_t M, int
 extern "C" int annlite_pq_search_tiles(int lut_kind, const float *queries_dev, int64_t V, int64_t D,
                                        const float *codebooks_dev, const void *codes_dev, int code_bytes, int codes_layout,
                                        int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev, int64_t k,
-                                       const int64_t *tile_rows_dev, const int32_t *vmap_dev, float *out_dist_dev,
-                                       int64_t *out_id_dev, void *workspace_dev, size_t workspace_bytes, void *stream) {
-    ANNLITE_REQUIRE(V == 0 || (tile_rows_dev && vmap_dev), "null tile table");
+                                       const int64_t *tile_rows_dev, const int32_t *vmap_dev, uint32_t *cand_dev,
+                                       int64_t cand_cap, uint32_t *cand_count_dev, void *workspace_dev,
+                                       size_t workspace_bytes, void *stream) {
+    ANNLITE_REQUIRE(V == 0 || (tile_rows_dev && vmap_dev && cand_dev && cand_count_dev), "null tile table / output");
     ANNLITE_REQUIRE(N > 0 || V == 0, "tile mode needs a non-empty code table");
-    const TileMode tm = {tile_rows_dev, vmap_dev};
+    ANNLITE_REQUIRE(cand_cap >= 64 && cand_cap < (1ll << 30), "cand_cap=%lld outside [64, 2^30)", (long long)cand_cap);
+    const TileMode tm = {tile_rows_dev, vmap_dev, cand_dev, cand_count_dev, cand_cap};
     return pq_search_impl(lut_kind, queries_dev, V, D, codebooks_dev, codes_dev, code_bytes, codes_layout, N, M, Ks,
-                          valid_bits_dev, k, 0, out_dist_dev, out_id_dev, nullptr, 0, workspace_dev, workspace_bytes, stream,
-                          &tm);
+                          valid_bits_dev, k, 0, nullptr, nullptr, nullptr, 0, workspace_dev, workspace_bytes, stream, &tm);
 }
 
 extern "C" int annlite_adc_scan_candidates(const void *codes_dev, int code_bytes, int codes_layout, int64_t N,

@@ -51,6 +51,9 @@ struct ScanArgs {
     const int64_t *tile_rows;    // [n_tiles][2] (begin: multiple of 64, end); begin < 0: unused tile; NULL = slices
     const int32_t *vmap;         // [n_tiles * QT] >= 0: the slot holds a query; < 0: padding (never passes the filter)
     unsigned int *item_counter;  // starts at 0xffffffff (workspace fill): next item = atomicAdd + 1
+    uint32_t *cand;              // [n_tiles * QT][cand_cap] out: table rows of every slot that can be in its top-k
+    uint32_t *cand_count;        // [n_tiles * QT] out: entries of the slot's list; 0xffffffff: it overflowed
+    int32_t cand_cap;
 };
 
 // work item -> (query tile, row slice).  item % 8 == blockIdx % 8 == the XCD the block lands on (speed

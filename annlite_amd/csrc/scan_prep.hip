@@ -447,8 +447,10 @@ __global__ __launch_bounds__(1024) void lut_l2_build_quantise_kernel(const float
                 if (g8 * 8 + i >= B) acc[i] = 0.f;  // pad queries -> 0, like lut_l2_tiled_kernel
             v0[sw] = (f32x4){acc[0], acc[1], acc[2], acc[3]};
             v1[sw] = (f32x4){acc[4], acc[5], acc[6], acc[7]};
-            base0[(int64_t)k * M + m] = v0[sw];
-            base1[(int64_t)k * M + m] = v1[sw];
+            if (lut) {  // (tile mode never reads the fp32 tables of its slots: NULL)
+                base0[(int64_t)k * M + m] = v0[sw];
+                base1[(int64_t)k * M + m] = v1[sw];
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 mn[i] = fminf(mn[i], acc[i]);

@@ -152,22 +152,6 @@ __device__ __attribute__((noinline)) void qfilter_flush(const FlushCtx c, uint32
     }
 }
 
-// Tile mode: the candidates of ONE query slot, collected by all waves of the workgroup since the last round
-// (row ids in LDS), are scored and inserted by the wave that owns the slot -- one list update per round instead
-// of one per (wave, query) event (2.4 candidates per event at 39k-row cells: the events cost 1.4x the scan).
-template <int M, bool SKEWED>
-__device__ __attribute__((noinline)) void qfilter_round(const FlushCtx c, int q0, uint32_t buf_off, int n) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t *buf = (const uint32_t *)(g_smem + buf_off);
-    for (int c0 = 0; c0 < n; c0 += 64) {
-        const bool act = c0 + lane < n;
-        const uint32_t rid = act ? buf[c0 + lane] : 0u;
-        float ex = 0.f;
-        if (act && !(c.skip & 1)) ex = exact_row_sum<M, SKEWED>(c, q0, rid);
-        offer_to_list<M>(c, q0, __ballot(act), f32_to_ordered(ex), rid, lane);
-    }
-}
-
 // Final merge of a tile by the last workgroup to arrive.  The NW waves are dealt out over the tile's REAL
 // queries: wave w folds the slices (w % wpq), (w % wpq) + wpq, ... of query w / wpq (a slice is merged only if
 // it holds something better than the running k-th), the wpq lists of a query meet in LDS and its first wave
@@ -234,6 +218,137 @@ __device__ __forceinline__ void merge_tile_slices(const ScanArgs &a, int b0, int
         if (wpq > 1) __syncthreads();  // scratch is reused by the next chunk
     }
 }
+
+// =================================================================================================
+// Tile mode (IVF cells, annlite_pq_search_tiles): what the two kernels below share.
+// A tile is short (a 39k-row cell = 38 steps of a 16-wave workgroup) and the exact fp32 recompute of its ~1300
+// candidates (16 cold table gathers each) cost more than the scan itself, so tiles are scanned with INTEGERS only:
+//   * every wave APPENDS the rows that pass the filter, with their integer sums S, to a per-slot buffer in LDS;
+//   * in ROUNDS (after steps 0, 3, 15, 63, 255, ... and the last one) the wave that owns slot q folds the slot's
+//     buffer into the slot's k smallest (S, row), which tightens the filter -- S <= Sk + margin, see below -- and
+//     EMITS the rows that still pass to the slot's candidate list in global memory;
+//   * the exact distances of the emitted rows are computed afterwards, per QUERY, by ivf_rescore_kernel (ivf.hip)
+//     with the query's fp32 table in LDS.  A list that overflows is flagged: the re-score pass walks that cell.
+// Filter bound from integers: for ANY k distinct rows of the cell with S <= Sk, d_exact <= L + step*(S + 1.002 M)
+// + slack32 holds for each, so the cell's k-th exact distance is <= U = L + step*(Sk + 1.002 M) + slack32, and a
+// row can be in the top-k only if L + step*(S - 0.04) <= d_real <= U + slack32, i.e.
+//     S <= Sk + margin,  margin = floor(1.002 M + 0.04 + 2 slack32 / step) + 1.
+// The first Sk of a tile (the "seed") is the k-th smallest of the NW per-wave minima of the first 64-row blocks.
+// LDS (on top of the streaming layout): [ccnt u32 x QT][cbuf u64 x QT x CAP] behind the wave queues; the gkl slots
+// hold the margins, the gjl slots the emitted counts and overflow flags (one slice per tile: both are idle).
+// =================================================================================================
+template <int QT>
+struct TileState {
+    static constexpr int CAP = kTileCandBytes / (QT * 8);
+    volatile uint32_t *ccnt;        // [QT] rows buffered since the last round
+    uint32_t *gcnt;                 // [QT] rows emitted
+    volatile uint32_t *gflag;       // [QT] the emitted list overflowed
+    volatile uint32_t *marg;        // [QT]
+    unsigned long long *cbuf;       // [QT][CAP] (S << 32 | row)
+    unsigned long long *lists;      // [QT][64] k smallest (S, row) of every slot, ascending over the lanes
+    volatile uint16_t *shq;         // [QT] 0x8000 | filter bound
+    uint32_t *cand;                 // the tile's QT lists in global memory
+    int cand_cap;
+
+    __device__ __forceinline__ void bind(unsigned char *smem, uint32_t queue_end, uint32_t gjl_off, uint32_t gkl_off,
+                                         unsigned long long *lists_, volatile uint16_t *shq_, const ScanArgs &a, int tile) {
+        ccnt = (volatile uint32_t *)(smem + queue_end);
+        cbuf = (unsigned long long *)(smem + queue_end + 64);
+        gcnt = (uint32_t *)(smem + gjl_off);
+        gflag = (volatile uint32_t *)(smem + gjl_off + 64);
+        marg = (volatile uint32_t *)(smem + gkl_off);
+        lists = lists_;
+        shq = shq_;
+        cand = a.cand + (int64_t)tile * QT * a.cand_cap;
+        cand_cap = a.cand_cap;
+    }
+    template <int M>
+    __device__ __forceinline__ void init_slot(int q, bool real, float smax_b, float qstep_b) {
+        ccnt[q] = 0;
+        gcnt[q] = 0;
+        gflag[q] = 0;
+        uint32_t mg = 0;
+        if (real) {
+            const double slack = (double)smax_b * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
+            double x = __builtin_floor(1.002 * M + 0.04 + 2.0 * slack / (double)qstep_b) + 1.0;
+            if (!(x < 32767.0)) x = 32767.0;
+            mg = (uint32_t)x;
+        }
+        marg[q] = mg;
+        shq[q] = real ? (unsigned short)0xffff : (unsigned short)0x7fff;  // everything / nothing passes
+    }
+    __device__ __forceinline__ void tighten(int q, uint32_t sk) {
+        uint32_t thr = sk + marg[q];
+        if (thr > 32767u) thr = 32767u;
+        const unsigned short nb = (unsigned short)(0x8000u | thr);
+        if (nb < shq[q]) shq[q] = nb;
+    }
+    // rows of slot q go to its global list (or raise the flag: the re-score pass then walks the whole cell)
+    __device__ __forceinline__ void emit(int q, unsigned long long pm, uint32_t rid, int lane) {
+        const int n = __popcll(pm);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&gcnt[q], (uint32_t)n);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+        if (base + (uint32_t)n > (uint32_t)cand_cap) {
+            if (lane == 0) gflag[q] = 1u;
+        } else if ((pm >> lane) & 1ull) {
+            cand[(int64_t)q * cand_cap + base + rank] = rid;
+        }
+    }
+    // the lanes in pm passed slot q's filter with integer sum sv
+    __device__ __forceinline__ void append(int q, unsigned long long pm, uint32_t sv, uint32_t rid, int lane) {
+        const int n = __popcll(pm);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd((uint32_t *)&ccnt[q], (uint32_t)n);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+        const bool mine = (pm >> lane) & 1ull;
+        const bool fits = base + (uint32_t)rank < (uint32_t)CAP;
+        if (mine && fits) cbuf[q * CAP + base + rank] = ((unsigned long long)sv << 32) | rid;
+        if (base + (uint32_t)n > (uint32_t)CAP) emit(q, __ballot(mine && !fits), rid, lane);  // buffer full
+    }
+    static __device__ __forceinline__ bool is_round(int step_no, int n_steps) {
+        const int r = step_no + 1;
+        return ((r & (r - 1)) == 0 && (__builtin_ctz((unsigned)r) & 1) == 0) || (r & 255) == 0 || r == n_steps;
+    }
+    // the calling wave owns slot q (between the two barriers of a round)
+    __device__ __forceinline__ void round(int q, int km1, int lane) {
+        uint32_t n = ccnt[q];
+        if (n > (uint32_t)CAP) n = CAP;  // (what did not fit went straight to the global list)
+        if (n == 0) return;
+        const unsigned long long le = lists[q * 64 + lane];
+        WaveList L;
+        L.hi = (uint32_t)(le >> 32);
+        L.lo = (uint32_t)le;
+        for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+            const bool act = c0 + lane < n;
+            const unsigned long long e = act ? cbuf[q * CAP + c0 + lane] : ~0ull;
+            const uint32_t thi = __builtin_amdgcn_readlane(L.hi, km1), tlo = __builtin_amdgcn_readlane(L.lo, km1);
+            const unsigned long long px = __ballot(act && key_less((uint32_t)(e >> 32), (uint32_t)e, thi, tlo));
+            if (px) wavelist_insert_many(L, px, (uint32_t)(e >> 32), (uint32_t)e, lane);
+        }
+        lists[q * 64 + lane] = ((unsigned long long)L.hi << 32) | L.lo;
+        const uint32_t sk = __builtin_amdgcn_readlane(L.hi, km1);
+        uint32_t thr = 32767u;
+        if (sk != kKeyInfHi) {
+            thr = sk + marg[q];
+            if (thr > 32767u) thr = 32767u;
+            if (lane == 0 && (unsigned short)(0x8000u | thr) < shq[q]) shq[q] = (unsigned short)(0x8000u | thr);
+        }
+        for (uint32_t c0 = 0; c0 < n; c0 += 64) {  // emit what still passes the (tightened) filter
+            const bool act = c0 + lane < n;
+            const unsigned long long e = act ? cbuf[q * CAP + c0 + lane] : ~0ull;
+            const unsigned long long pm = __ballot(act && (uint32_t)(e >> 32) <= thr);
+            if (pm) emit(q, pm, (uint32_t)e, lane);
+        }
+        if (lane == 0) ccnt[q] = 0;
+    }
+    __device__ __forceinline__ void finish(int q, uint32_t *cand_count_slot) {
+        const uint32_t g = gcnt[q];
+        *cand_count_slot = (gflag[q] || g > (uint32_t)cand_cap) ? 0xffffffffu : g;
+    }
+};
 
 // =================================================================================================
 // Quantised-filter kernel.  Same discipline as adc_scan_filter_kernel (cheap bound -> exact
@@ -317,6 +432,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
             slice_end = slice_begin + a.slice_rows;
         }
         if (slice_end > a.N) slice_end = a.N;
+        TileState<QT> ts;
+        if constexpr (TILES) ts.bind(smem, queue_off + NW * 512, gjl_off, gkl_off, lists, shq, a, tile);
 
         __syncthreads();
         {
@@ -337,16 +454,18 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                 const int b = tile * QT + tid;
                 const unsigned long long gk =
                     a.gkey ? __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
-                gkl[tid] = gk;
-                ((unsigned long long *)(smem + gjl_off))[tid] = ~0ull;
+                if constexpr (!TILES) {  // (tile mode keeps its margins / counters in these slots)
+                    gkl[tid] = gk;
+                    ((unsigned long long *)(smem + gjl_off))[tid] = ~0ull;
+                }
                 // pad queries of the last tile (b >= B) must never pass the filter (their all-zero tables give S = 0
                 // for every row: 15 pad queries made a 1-query batch 15x slower than a 16-query one): 0x7fff - S
                 // never has bit 15 set and never borrows from the neighbouring field
                 bool real = b < a.B;
                 if constexpr (TILES) {
                     real = real && a.vmap[b] >= 0;  // padding slots sit in every tile
-                    ((volatile uint32_t *)(smem + queue_off + NW * 512))[tid] = 0;  // candidates collected for the slot
-                }
+                    ts.template init_slot<M>(tid, real, real ? a.smax[b] : 0.f, real ? a.qstep[b] : 1.f);
+                } else
                 shq[tid] = real ? qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]) : (unsigned short)0x7fff;
             }
             for (int idx = tid; idx < QT * 64; idx += NW * 64) lists[idx] = ~0ull;
@@ -468,13 +587,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                             const uint32_t vj = sm16[j * (NQ * 8) + q];
                             rank += (vj < vi) || (vj == vi && j < i);
                         }
-                        if (rank == km1 && vi < 0x7fffu) {
-                            const double slack = (double)a.smax[b] * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
-                            double qd = __builtin_floor((double)vi + 1.002 * M + 0.04 + 2.0 * slack / (double)a.qstep[b]) + 1.0;
-                            if (!(qd < 32767.0)) qd = 32767.0;
-                            const unsigned short nb = (unsigned short)(0x8000u | (uint32_t)qd);
-                            if (nb < shq[q]) shq[q] = nb;
-                        }
+                        if (rank == km1 && vi < 0x7fffu) ts.tighten(q, vi);
                     }
                 }
                 __syncthreads();
@@ -489,26 +602,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
         int qcnt = 0;  // entries in this wave's candidate queue
         int step_no = 0;
         if constexpr (TILES) {
-            if (a.flush_mask & 0x100) {
-                // pull the tile's fp32 tables (QT x Ks x M floats, contiguous) towards the caches: the rounds gather
-                // from them at random and found them cold in HBM (87 of 190 us per 39k-row tile)
-                const char *tb = (const char *)(a.lut + (int64_t)tile * QT * a.Ks * M);
-                const int total16 = QT * a.Ks * M / 4;
-                u32x4 sink = {0u, 0u, 0u, 0u};
-#pragma unroll 8
-                for (int i = tid; i < total16; i += NW * 64) sink |= *(const u32x4 *)(tb + (int64_t)i * 16);
-                if (sink.x == 0x12345678u && sink.y == 0x9abcdef0u && a.dbg) a.dbg[7] = 1;  // (keeps the loads alive)
-            }
-            // Tile mode: a tile is short (a 39k-row cell = 38 steps), so the candidate events of the streaming
-            // scheme below (2.4 candidates per (wave, query) event, each paying lock + list + bound update) cost
-            // more than the scan.  Instead every wave APPENDS the rows that pass the filter to a per-slot buffer in
-            // LDS and, in ROUNDS after steps 0, 3, 15, 63, 255, ... and the last one, the wave that owns slot q
-            // scores and inserts all of slot q's candidates at once (one list update per slot and round; the bound
-            // moves on a log scale anyway).  All waves run the same number of steps so the rounds' barriers meet.
-            constexpr int CAP = kTileCandBytes / (QT * 4);
-            volatile uint32_t *ccnt = (volatile uint32_t *)(smem + queue_off + NW * 512);  // [QT]
-            const uint32_t cbuf_off = queue_off + NW * 512 + 64;
-            uint32_t *cbuf = (uint32_t *)(smem + cbuf_off);                                // [QT][CAP] row ids
+            // integers only: append -> rounds -> emission (TileState); all waves run the same number of steps so
+            // that the rounds' barriers meet
             const int n_steps = (int)((slice_end - slice_begin + stride - 1) / stride);
             for (; step_no < n_steps; ++step_no, row0 += stride) {
                 if (row0 < slice_end) {
@@ -537,27 +632,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                                     for (int half = 0; half < 2; ++half) {
                                         const unsigned long long pm =
                                             __ballot((x & (half ? 0x80000000u : 0x8000u)) != 0) & vmask;
-                                        if (pm) {
-                                            const int q = h * QG + w * 2 + half;
-                                            const int n = __popcll(pm);
-                                            uint32_t base = 0;
-                                            if (lane == 0) base = atomicAdd((uint32_t *)&ccnt[q], (uint32_t)n);
-                                            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                                            const int rank = __builtin_amdgcn_mbcnt_hi(
-                                                (uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-                                            const bool mine = (pm >> lane) & 1ull;
-                                            const bool fits = base + (uint32_t)rank < (uint32_t)CAP;
-                                            if (mine && fits) cbuf[q * CAP + base + rank] = rid;
-                                            if (base + (uint32_t)n > (uint32_t)CAP) {
-                                                // buffer full: this wave scores and inserts the overflow itself
-                                                const unsigned long long om = __ballot(mine && !fits);
-                                                const int orank = __builtin_amdgcn_mbcnt_hi(
-                                                    (uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u));
-                                                unsigned long long *queue = (unsigned long long *)(smem + queue_off + wave * 512);
-                                                if (mine && !fits) queue[orank] = ((unsigned long long)q << 32) | rid;
-                                                qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, __popcll(om));
-                                            }
-                                        }
+                                        if (pm)
+                                            ts.append(h * QG + w * 2 + half, pm,
+                                                      half ? (acc[h][w] >> 16) : (acc[h][w] & 0xffffu), rid, lane);
                                     }
                                 }
                             }
@@ -570,17 +647,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                     vcur = vnext;
                     vnext = load_valid(row0 + 2 * stride + lane);
                 }
-                const int r = step_no + 1;
-                if (((r & (r - 1)) == 0 && (__builtin_ctz((unsigned)r) & 1) == 0) || (r & 255) == 0 || r == n_steps) {
+                if (TileState<QT>::is_round(step_no, n_steps)) {
                     __syncthreads();  // every wave's appends are in LDS
-                    for (int q = wave; q < QT; q += NW) {
-                        uint32_t n = ccnt[q];
-                        if (n > (uint32_t)CAP) n = CAP;  // (what did not fit was handled by the wave that found it)
-                        if (n) {
-                            qfilter_round<M, SKEWED>(fc, q, cbuf_off + q * CAP * 4, (int)n);
-                            if (lane == 0) ccnt[q] = 0;
-                        }
-                    }
+                    for (int q = wave; q < QT; q += NW) ts.round(q, km1, lane);
                     __syncthreads();  // bounds published, buffers empty
 #pragma unroll
                     for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
@@ -705,18 +774,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
         // ---- the shared lists ARE the workgroup's result for this (tile, slice) ----------------------
         __syncthreads();
         if constexpr (TILES) {
-            // one slice per tile: the lists are final -- no partial lists, no arrival counter, no merge
-            for (int q = wave; q < QT; q += NW) {
-                const int b = tile * QT + q;
-                if (b < a.B && lane <= km1) {
-                    const unsigned long long key = lists[q * 64 + lane];
-                    const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
-                    const bool none = (hi == kKeyInfHi && lo == kIdNone);
-                    const float d = none ? __builtin_inff() : ordered_to_f32(hi);
-                    a.out_d[(int64_t)b * a.k + lane] = a.sqrt_out ? __builtin_sqrtf(d) : d;
-                    a.out_i[(int64_t)b * a.k + lane] = none ? (int64_t)-1 : a.row_base + (int64_t)lo;
-                }
-            }
+            // the tile's result = the candidate lists it emitted; their lengths (or "walk the whole cell")
+            if (tid < QT) ts.finish(tid, a.cand_count + tile * QT + tid);
             continue;
         }
         for (int q = wave; q < QT; q += NW) {
@@ -804,6 +863,8 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
             slice_end = slice_begin + a.slice_rows;
         }
         if (slice_end > a.N) slice_end = a.N;
+        TileState<QT> ts;
+        if constexpr (TILES) ts.bind(smem, queue_off + NW * 512, gjl_off, gkl_off, lists, shq, a, tile);
 
         __syncthreads();
         {
@@ -816,13 +877,18 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
                 const int b = tile * QT + tid;
                 const unsigned long long gk =
                     a.gkey ? __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
-                gkl[tid] = gk;
-                ((unsigned long long *)(smem + gjl_off))[tid] = ~0ull;
+                if constexpr (!TILES) {
+                    gkl[tid] = gk;
+                    ((unsigned long long *)(smem + gjl_off))[tid] = ~0ull;
+                }
                 // pad queries of the last tile (b >= B) must never pass the filter (their all-zero tables give S = 0
                 // for every row: 15 pad queries made a 1-query batch 15x slower than a 16-query one): 0x7fff - S
                 // never has bit 15 set and never borrows from the neighbouring field
                 bool real = b < a.B;
-                if constexpr (TILES) real = real && a.vmap[b] >= 0;
+                if constexpr (TILES) {
+                    real = real && a.vmap[b] >= 0;
+                    ts.template init_slot<M>(tid, real, real ? a.smax[b] : 0.f, real ? a.qstep[b] : 1.f);
+                } else
                 shq[tid] = real ? qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]) : (unsigned short)0x7fff;
             }
             for (int idx = tid; idx < QT * 64; idx += NW * 64) lists[idx] = ~0ull;
@@ -903,29 +969,19 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
                     if (lane == 0) smin[wave * 2 + w] = x;
                 }
                 __syncthreads();
-                if (tid < QT) {
-                    const int b = tile * QT + tid;
+                if (tid < QT * NW) {
+                    const int q = tid / NW, i = tid - q * NW;
+                    const int b = tile * QT + q;
                     if (b < a.B && a.vmap[b] >= 0) {
                         const volatile uint16_t *sm16 = (const volatile uint16_t *)smin;
-                        uint32_t sk = 0x7fffu;  // k-th smallest of the NW minima (rank counting, ties by wave)
-#pragma unroll 1
-                        for (int i = 0; i < NW; ++i) {
-                            const uint32_t vi = sm16[i * 4 + tid];
-                            int rank = 0;
-#pragma unroll 1
-                            for (int j = 0; j < NW; ++j) {
-                                const uint32_t vj = sm16[j * 4 + tid];
-                                rank += (vj < vi) || (vj == vi && j < i);
-                            }
-                            if (rank == km1) sk = vi;
+                        const uint32_t vi = sm16[i * 4 + q];
+                        int rank = 0;
+#pragma unroll 4
+                        for (int j = 0; j < NW; ++j) {
+                            const uint32_t vj = sm16[j * 4 + q];
+                            rank += (vj < vi) || (vj == vi && j < i);
                         }
-                        if (sk < 0x7fffu) {
-                            const double slack = (double)a.smax[b] * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
-                            double qd = __builtin_floor((double)sk + 1.002 * M + 0.04 + 2.0 * slack / (double)a.qstep[b]) + 1.0;
-                            if (!(qd < 32767.0)) qd = 32767.0;
-                            const unsigned short nb = (unsigned short)(0x8000u | (uint32_t)qd);
-                            if (nb < shq[tid]) shq[tid] = nb;
-                        }
+                        if (rank == km1 && vi < 0x7fffu) ts.tighten(q, vi);
                     }
                 }
                 __syncthreads();
@@ -937,6 +993,48 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
                              list_off, lock_off, shq_off, gkl_off, gjl_off};
         int qcnt = 0;
         int step_no = 0;
+        if constexpr (TILES) {  // integers only: append -> rounds -> emission (TileState)
+            const int n_steps = (int)((slice_end - slice_begin + stride - 1) / stride);
+            for (; step_no < n_steps; ++step_no, row0 += stride) {
+                if (row0 < slice_end) {
+                    unsigned long long vmask = ~0ull;
+                    if (slice_end - row0 < 64) vmask = (1ull << (int)(slice_end - row0)) - 1ull;
+                    if (a.valid) vmask &= __ballot((vcur >> (lane & 31)) & 1u);
+                    const uint32_t rid = (uint32_t)(row0 + lane);
+                    u32x2 acc = {0u, 0u};
+                    row_sums(ccur, acc);
+                    const uint32_t x0 = (thp.x - acc.x) & 0x80008000u, x1 = (thp.y - acc.y) & 0x80008000u;
+                    const unsigned long long anym = __ballot((x0 | x1) != 0) & vmask;
+                    if (anym && !(a.dbg_skip & 4)) {
+                        if (a.dbg && lane == 0) atomicAdd(a.dbg + 0, 1ull);
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) {
+                            const uint32_t x = w ? x1 : x0;
+                            const uint32_t sw = w ? acc.y : acc.x;
+                            if (__ballot(x != 0) & vmask) {
+#pragma unroll
+                                for (int half = 0; half < 2; ++half) {
+                                    const unsigned long long pm = __ballot((x & (half ? 0x80000000u : 0x8000u)) != 0) & vmask;
+                                    if (pm) ts.append(w * 2 + half, pm, half ? (sw >> 16) : (sw & 0xffffu), rid, lane);
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
+                    if constexpr (!SKEWED) encode_plain(ccur);
+                    load_row(row0 + 2 * stride + lane, cnext);
+                    vcur = vnext;
+                    vnext = load_valid(row0 + 2 * stride + lane);
+                }
+                if (TileState<QT>::is_round(step_no, n_steps)) {
+                    __syncthreads();
+                    for (int q = wave; q < QT; q += NW) ts.round(q, km1, lane);
+                    __syncthreads();
+                    thp = *(const u32x2 *)(smem + shq_off);
+                }
+            }
+        } else
         for (; row0 < slice_end; row0 += stride, ++step_no) {
             unsigned long long vmask = ~0ull;
             if (slice_end - row0 < 64) vmask = (1ull << (int)(slice_end - row0)) - 1ull;
@@ -1030,18 +1128,8 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
         if (qcnt) qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
 
         __syncthreads();
-        if constexpr (TILES) {  // (see adc_scan_qfilter_kernel)
-            for (int q = wave; q < QT; q += NW) {
-                const int b = tile * QT + q;
-                if (b < a.B && lane <= km1) {
-                    const unsigned long long key = lists[q * 64 + lane];
-                    const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
-                    const bool none = (hi == kKeyInfHi && lo == kIdNone);
-                    const float d = none ? __builtin_inff() : ordered_to_f32(hi);
-                    a.out_d[(int64_t)b * a.k + lane] = a.sqrt_out ? __builtin_sqrtf(d) : d;
-                    a.out_i[(int64_t)b * a.k + lane] = none ? (int64_t)-1 : a.row_base + (int64_t)lo;
-                }
-            }
+        if constexpr (TILES) {
+            if (tid < QT) ts.finish(tid, a.cand_count + tile * QT + tid);
             continue;
         }
         for (int q = wave; q < QT; q += NW) {
@@ -1084,7 +1172,8 @@ static int launch_qfilter(const ScanArgs &a, int grid, hipStream_t st) {
 
 template <int NW, bool SKEWED>
 static int launch_qfilter64(const ScanArgs &a, int grid, hipStream_t st) {
-    const size_t need = (size_t)(a.Ks + 1) * 512 + 256 + (size_t)4 * 512 + 128 + (size_t)NW * 512;
+    const size_t need = (size_t)(a.Ks + 1) * 512 + 256 + (size_t)4 * 512 + 128 + (size_t)NW * 512 +
+                        (a.tile_rows ? (size_t)kTileCandBytes + 64 : 0);
     auto fn = a.tile_rows ? adc_scan_qfilter64_kernel<NW, SKEWED, true> : adc_scan_qfilter64_kernel<NW, SKEWED, false>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);

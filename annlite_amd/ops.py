@@ -232,10 +232,11 @@ def ivf_plan(cells: torch.Tensor, n_cells: int, qt: int, cell_rows: torch.Tensor
 def pq_search_tiles(lut_kind: int, slot_queries: torch.Tensor, codebooks: torch.Tensor, codes: torch.Tensor, k: int,
                     M: int, Ks: int, tile_rows: torch.Tensor, vmap: torch.Tensor,
                     valid_bits: Optional[torch.Tensor] = None, n_rows: Optional[int] = None,
-                    codes_layout: int = CODES_PLAIN, workspace: Optional[ScanWorkspace] = None
+                    codes_layout: int = CODES_PLAIN, workspace: Optional[ScanWorkspace] = None, cand_cap: int = 256
                     ) -> Tuple[torch.Tensor, torch.Tensor]:
     """``annlite_pq_search_tiles``: slot queries f32 [V, D]; tile t = slots [t*qt, (t+1)*qt) scans rows
-    ``tile_rows[t]`` only.  Returns per-slot (f32 [V,k], i64 [V,k] table rows)."""
+    ``tile_rows[t]`` only, with integer sums.  Returns the per-slot candidate lists
+    ``(cand u32-as-i32 [V, cand_cap] table rows, count i32 [V])`` (count -1: overflow, re-score the whole cell)."""
     N = codes.shape[0] if n_rows is None else n_rows
     V, D = slot_queries.shape
     cb = code_bytes_of(codes)
@@ -244,25 +245,29 @@ def pq_search_tiles(lut_kind: int, slot_queries: torch.Tensor, codebooks: torch.
           'pq_search_tiles_workspace_bytes')
     dev = codes.device
     ws = (workspace or ScanWorkspace()).get(int(need.value), dev)
-    od = torch.empty((V, k), dtype=torch.float32, device=dev)
-    oi = torch.empty((V, k), dtype=torch.int64, device=dev)
+    cand = torch.empty((V, cand_cap), dtype=torch.int32, device=dev)
+    count = torch.empty((V,), dtype=torch.int32, device=dev)
     check(lib().annlite_pq_search_tiles(lut_kind, slot_queries.data_ptr(), V, D, codebooks.data_ptr(), codes.data_ptr(),
                                         cb, codes_layout, N, M, Ks, _ptr(valid_bits), k, tile_rows.data_ptr(),
-                                        vmap.data_ptr(), od.data_ptr(), oi.data_ptr(), ws.data_ptr(), ws.numel(),
-                                        stream_ptr()), 'pq_search_tiles')
-    return od, oi
+                                        vmap.data_ptr(), cand.data_ptr(), cand_cap, count.data_ptr(), ws.data_ptr(),
+                                        ws.numel(), stream_ptr()), 'pq_search_tiles')
+    return cand, count
 
 
-def ivf_merge(slot_dist: torch.Tensor, slot_rows: torch.Tensor, slot_of: torch.Tensor, k: int,
-              row_ids: Optional[torch.Tensor] = None, id_base: int = 0, sqrt: bool = False
-              ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Merge every query's per-cell lists: ([V,k], [V,k]) + slot_of [B,P] -> ([B,k] f32, [B,k] i64 ids)."""
-    B, P = slot_of.shape
-    od = torch.empty((B, k), dtype=torch.float32, device=slot_dist.device)
-    oi = torch.empty((B, k), dtype=torch.int64, device=slot_dist.device)
-    check(lib().annlite_ivf_merge(slot_dist.data_ptr(), slot_rows.data_ptr(), slot_of.data_ptr(), B, P, k,
-                                  _ptr(row_ids), id_base, od.data_ptr(), oi.data_ptr(), 1 if sqrt else 0, stream_ptr()),
-          'ivf_merge')
+def ivf_rescore(lut_bmk: torch.Tensor, codes_plain: torch.Tensor, cand: torch.Tensor, count: torch.Tensor,
+                slot_of: torch.Tensor, tile_rows: torch.Tensor, qt: int, k: int, row_ids: Optional[torch.Tensor] = None,
+                valid_bits: Optional[torch.Tensor] = None, id_base: int = 0, sqrt: bool = False
+                ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Exact distances of every query's candidate rows + top-k: ``lut_bmk`` f32 [B, M, Ks] (``get_dist_mat``),
+    ``codes_plain`` u8 [N, M] (cell-sorted, PLAIN).  Returns ([B,k] f32, [B,k] i64 ids)."""
+    B, M, Ks = lut_bmk.shape
+    P = slot_of.shape[1]
+    od = torch.empty((B, k), dtype=torch.float32, device=lut_bmk.device)
+    oi = torch.empty((B, k), dtype=torch.int64, device=lut_bmk.device)
+    check(lib().annlite_ivf_rescore(lut_bmk.data_ptr(), B, M, Ks, codes_plain.data_ptr(), codes_plain.shape[0],
+                                    _ptr(valid_bits), cand.data_ptr(), cand.shape[1], count.data_ptr(), slot_of.data_ptr(),
+                                    P, tile_rows.data_ptr(), qt, _ptr(row_ids), id_base, k, od.data_ptr(), oi.data_ptr(),
+                                    1 if sqrt else 0, stream_ptr()), 'ivf_rescore')
     return od, oi
 
 

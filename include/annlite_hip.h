@@ -304,26 +304,38 @@ ANNLITE_API int annlite_ivf_plan(const int32_t *cells_dev, int64_t B, int64_t P,
                      int32_t *vmap_dev, int32_t *slot_of_dev, int64_t *tile_rows_dev, int32_t *n_tiles_used_dev,
                      void *stream);
 
-/* annlite_pq_search_topk where query tile t = queries [t*qt, (t+1)*qt) scans ONLY rows
- * tile_rows[t] (one work item per tile, handed out dynamically; the bound of a tile is seeded inside
- * the scan kernel from integer sums).  V = n_tiles * qt slot queries (queries_dev f32 [V][D]: the
- * probing query of every slot, anything for padding slots); out [V][k]: per-slot top-k, ids are TABLE
- * ROWS.  Quantised-filter plans only (M in {8,16,32,64}, Ks <= 256, uint8 codes). */
+/* The scan of annlite_pq_search_topk where query tile t = slots [t*qt, (t+1)*qt) scans ONLY rows
+ * tile_rows[t] (one work item per tile, handed out dynamically) -- with INTEGER sums only: a tile is
+ * too short to amortise exact fp32 recomputes.  The kernel keeps, per slot, the k smallest integer
+ * sums (which bound the slot's k-th exact distance from above: any k rows with S <= Sk give
+ * d_kth <= L + step*(Sk + 1.002 M) + slack) and EMITS every row that can still be in the slot's exact
+ * top-k:  cand[v][0..cand_count[v])  (table rows; cand_count 0xffffffff = the list overflowed
+ * cand_cap, re-score the whole cell).  annlite_ivf_rescore turns the lists into exact results.
+ * V = n_tiles * qt slot queries (queries_dev f32 [V][D]: the probing query of every slot, anything
+ * for padding slots).  Quantised-filter plans only (M in {8,16,32,64}, Ks <= 256, uint8 codes). */
 ANNLITE_API int annlite_pq_search_tiles_workspace_bytes(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t V,
                                             int64_t k, int64_t *bytes);
 ANNLITE_API int annlite_pq_search_tiles(int lut_kind, const float *queries_dev, int64_t V, int64_t D,
                             const float *codebooks_dev, const void *codes_dev, int code_bytes, int codes_layout,
                             int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev, int64_t k,
-                            const int64_t *tile_rows_dev, const int32_t *vmap_dev, float *out_dist_dev,
-                            int64_t *out_id_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+                            const int64_t *tile_rows_dev, const int32_t *vmap_dev, uint32_t *cand_dev,
+                            int64_t cand_cap, uint32_t *cand_count_dev, void *workspace_dev, size_t workspace_bytes,
+                            void *stream);
 
-/* Merge the P per-cell lists of every query: slot lists [V][k] (distance, table row) -> [B][k]
- * (distance, id_base + row_ids[row]) under the fixed tie-break; row_ids_dev i64 [N] or NULL (ids =
- * rows).  flags: ANNLITE_FLAG_SQRT.
- * replaces: the hstack + argsort merge of CellContainer.ivf_search (annlite/container.py:130-138). */
-ANNLITE_API int annlite_ivf_merge(const float *slot_dist_dev, const int64_t *slot_row_dev, const int32_t *slot_of_dev,
-                      int64_t B, int64_t P, int64_t k, const int64_t *row_ids_dev, int64_t id_base,
-                      float *out_dist_dev, int64_t *out_id_dev, int flags, void *stream);
+/* Exact re-score + merge, one workgroup per query: the query's fp32 table lut_bmk[b] ([M][Ks], what
+ * get_dist_mat returns) in LDS, exact ascending-m ADC sums (space_pq.h:32-35) of the candidate rows of
+ * its P probed slots (slot_of_dev i32 [B][P]), top-k under the fixed tie-break -> [B][k] (distance,
+ * id_base + row_ids[row]).  codes_plain_dev: the cell-sorted table in the PLAIN layout [N][M];
+ * valid_bits_dev (may be NULL) is consulted for overflowed slots, which are re-scored over
+ * tile_rows[slot / qt].  flags: ANNLITE_FLAG_SQRT.
+ * replaces: the per-cell search + hstack/argsort merge of CellContainer.ivf_search
+ * (annlite/container.py:88-144). */
+ANNLITE_API int annlite_ivf_rescore(const float *lut_bmk_dev, int64_t B, int64_t M, int64_t Ks,
+                        const void *codes_plain_dev, int64_t N, const uint32_t *valid_bits_dev,
+                        const uint32_t *cand_dev, int64_t cand_cap, const uint32_t *cand_count_dev,
+                        const int32_t *slot_of_dev, int64_t P, const int64_t *tile_rows_dev, int64_t qt,
+                        const int64_t *row_ids_dev, int64_t id_base, int64_t k, float *out_dist_dev,
+                        int64_t *out_id_dev, int flags, void *stream);
 
 #ifdef __cplusplus
 }

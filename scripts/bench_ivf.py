@@ -112,17 +112,22 @@ def main():
         st['plan'], (vmap, slot_of, tile_rows, used) = timed(lambda: ops.ivf_plan(cells, C, qt, idx._cell_rows, idx._cell_order))
         st['gather'], slot_q = timed(lambda: q.index_select(0, vmap.clamp(min=0).to(torch.int64)))
         kind, xq = codec.scan_inputs(slot_q)
-        st['tables_scan'], (sd, si) = timed(lambda: ops.pq_search_tiles(
+        st['tables_scan'], (cand, count) = timed(lambda: ops.pq_search_tiles(
             kind, xq, codec.codebooks_dev, idx._table, k, M, Ks, tile_rows, vmap, n_rows=idx._n_table,
-            codes_layout=CODES_SKEWED, workspace=idx._tws))
+            codes_layout=CODES_SKEWED, workspace=idx._tws, cand_cap=idx.cand_cap))
         _capi.profile_enable(True)
         ops.pq_search_tiles(kind, xq, codec.codebooks_dev, idx._table, k, M, Ks, tile_rows, vmap, n_rows=idx._n_table,
-                            codes_layout=CODES_SKEWED, workspace=idx._tws)
+                            codes_layout=CODES_SKEWED, workspace=idx._tws, cand_cap=idx.cand_cap)
         st['scan_kernel'] = _capi.profile_last_scan_ms()
         _capi.profile_enable(False)
         if os.environ.get('ANNLITE_DEBUG_COUNTERS'):
             st['counters'] = _capi.debug_counters()[:5]
-        st['merge'], _ = timed(lambda: ops.ivf_merge(sd, si, slot_of, k, idx._row_ids, 0, sqrt=True))
+        st['lut_real'], lut = timed(lambda: codec.get_dist_mat(q))
+        st['rescore'], _ = timed(lambda: ops.ivf_rescore(lut, idx._table_plain, cand, count, slot_of, tile_rows, qt, k,
+                                                         idx._row_ids, sqrt=True))
+        cnt = count[vmap >= 0].to(torch.int64)
+        st['cand_per_slot_mean_max_overflow'] = [float(cnt[cnt >= 0].float().mean().item()), int(cnt.max().item()),
+                                                 int((cnt < 0).sum().item())]
         rec = {'n_probe': P, 'ms': ms, 'qps': B / ms * 1e3, 'tiles_used': int(used.item()), 'slots': int(vmap.numel()),
                'recall_vs_exhaustive_adc': recall(r[1], adc_truth),
                'recall_vs_exact': recall(r[1], truth) if idx._vectors is not None else None, 'stages_ms': st}
