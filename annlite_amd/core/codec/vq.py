@@ -88,8 +88,33 @@ class VQCodec(BaseCodec):
         inertia = ((x - cb[a]) ** 2).sum()
         return new, counts, inertia
 
+    @staticmethod
+    def _kmeanspp(x: torch.Tensor, C: int, gen: torch.Generator) -> torch.Tensor:
+        """k-means++ seeding (sklearn's default ``init``): every next centre is drawn with probability
+        proportional to the squared distance to the nearest centre chosen so far."""
+        N = x.shape[0]
+        cb = torch.empty((C, x.shape[1]), dtype=torch.float32, device=x.device)
+        first = torch.randint(0, N, (1,), generator=gen, device=x.device)
+        cb[0] = x[first[0]]
+        d2 = ((x - cb[0]) ** 2).sum(1)
+        x2 = (x * x).sum(1)
+        trials = 2 + int(np.log(C))  # sklearn's greedy variant: the best of a few draws per step
+        for c in range(1, C):
+            total = d2.sum()
+            if float(total.item()) <= 0.0:  # fewer distinct rows than centres
+                cb[c] = x[torch.randint(0, N, (1,), generator=gen, device=x.device)[0]]
+                continue
+            cand = torch.multinomial(d2 / total, trials, replacement=True, generator=gen)
+            xc = x[cand]
+            dist = (x2[None, :] + (xc * xc).sum(1)[:, None] - 2.0 * (xc @ x.T)).clamp_(min=0.0)  # [trials, N]
+            dc = torch.minimum(d2[None, :], dist)
+            best = int(torch.argmin(dc.sum(1)).item())
+            cb[c] = x[cand[best]]
+            d2 = dc[best]
+        return cb
+
     def fit(self, x):
-        """vq.py:34-50."""
+        """vq.py:34-50 (k-means++ seeding, Lloyd iterations, best of ``n_init`` runs by inertia)."""
         if _is_np(x):
             assert x.dtype == np.float32
         else:
@@ -107,7 +132,7 @@ class VQCodec(BaseCodec):
         tol = 1e-4 * float(x.var(dim=0, unbiased=False).mean().item())
         best, best_inertia = None, float('inf')
         for _ in range(max(1, self.n_init)):
-            cb = x[torch.randperm(N, generator=gen, device=x.device)[:C]].clone()
+            cb = self._kmeanspp(x, C, gen)
             for _it in range(max(1, self.iter)):
                 new, counts, _ = self._lloyd_step(x, cb)
                 empty = torch.nonzero(counts == 0).flatten()
