@@ -14,10 +14,14 @@ Changed on purpose: the vector index per cell 
 GPU scan ``PQFlatGpuIndex`` instead of an HNSW graph walked one query at a time
 (container.py:48-59, 214); ALL queries of a ``search`` call go through one batched launch.
 
-Out of scope of this tier: IVF cells (``n_cells > 1``),
-PCA projection (``n_components``), RocksDB/SQLite persistence of documents, remote backup.  Documents
-and tags live in memory; the Mongo-style ``filter`` dict is evaluated on the host and handed to the
-GPU scan as a row bitmap (section 8f-3).
+``n_cells > 1`` (index.py:125-133, 458-483): a ``VQCodec`` coarse quantiser assigns every vector to a cell and ONE
+``IvfPQGpuIndex`` holds all cells.  Like the reference (``n_probe = max(n_probe, n_cells)``, index.py:94) a search
+visits every cell, so results equal the single-cell index; ``ivf_prune=True`` (kwarg) makes the search honour
+``n_probe`` -- the pruned scan of SURVEY.md section 8f's follow-on.
+
+Out of scope of this tier: PCA projection (``n_components``), RocksDB/SQLite
+persistence of documents, remote backup.  Documents and tags live in memory; the Mongo-style ``filter`` dict is
+evaluated on the host and handed to the GPU scan as a row bitmap (section 8f-3).
 """
 import hashlib
 import logging
@@ -82,8 +86,7 @@ class AnnLite:
             n_dim = kwargs.pop('dim')
         if n_subvectors:
             assert n_dim % n_subvectors == 0, '"n_dim" needs to be divisible by "n_subvectors"'
-        if n_cells != 1:
-            raise NotImplementedError('n_cells > 1 (IVF coarse quantiser) is outside the accelerated hot path (SURVEY.md section 2 row 14)')
+        assert n_cells >= 1
         if n_components:
             raise NotImplementedError('n_components (PCA projector) is outside the accelerated hot path (SURVEY.md section 2 row 15)')
         if not n_subvectors:
@@ -92,7 +95,9 @@ class AnnLite:
         self.n_components = n_components
         self.n_subvectors = n_subvectors
         self.n_clusters = n_clusters
-        self.n_probe = max(n_probe, n_cells)
+        self.n_probe = max(n_probe, n_cells)  # index.py:94: the reference visits every cell
+        self._n_probe_arg = n_probe
+        self._ivf_prune = bool(kwargs.pop('ivf_prune', False))
         self.n_cells = n_cells
         if isinstance(metric, str):
             metric = Metric.from_string(metric)
@@ -111,6 +116,16 @@ class AnnLite:
         else:
             self._pq_codec = PQCodec(dim=n_dim, n_subvectors=n_subvectors, n_clusters=n_clusters, metric=metric)
 
+        self._vq_codec = None
+        if n_cells > 1:  # index.py:125-133
+            from .core.codec.vq import VQCodec
+
+            if self._vq_codec_path.exists():
+                logger.info(f'Load trained VQ codec (K={self.n_cells}) from {self.model_path}')
+                self._vq_codec = VQCodec.load(self._vq_codec_path)
+            else:
+                self._vq_codec = VQCodec(self.n_cells, metric=self.metric)
+
         if columns is not None:
             filterable_attrs = {n: t for n, t in (columns.items() if isinstance(columns, dict) else columns)}
         self.filterable_attrs = filterable_attrs or {}
@@ -128,6 +143,12 @@ class AnnLite:
         GPU scan; ``AnnLite(..., graph=True, ef_search=..., max_connection=..., ef_construction=...)`` selects the
         HNSW-over-PQ index with the reference's knobs (graph walked on the GPU, BASELINE config 5)."""
         kw = dict(self._index_kwargs)
+        if self._vq_codec is not None:
+            from .core.index.ivf_pq_gpu import IvfPQGpuIndex
+
+            assert not kw.pop('graph', False), 'graph=True and n_cells > 1 cannot be combined'
+            return IvfPQGpuIndex(dim=self.n_dim, metric=self.metric, pq_codec=self._pq_codec, vq_codec=self._vq_codec,
+                                 n_probe=self._n_probe_arg if self._ivf_prune else None, **kw)
         if kw.pop('graph', False):
             from .core.index.hnsw_pq_gpu import HnswPQGpuIndex
 
@@ -150,7 +171,13 @@ class AnnLite:
         return self.model_path / 'pq_codec.params'
 
     @property
+    def _vq_codec_path(self):
+        return self.model_path / 'vq_codec.params'  # index.py:589-591
+
+    @property
     def is_trained(self) -> bool:
+        if self._vq_codec is not None and not self._vq_codec.is_trained:  # index.py:929-930
+            return False
         return bool(self._pq_codec is not None and self._pq_codec.is_trained)
 
     @property
@@ -184,7 +211,11 @@ class AnnLite:
         if self.is_trained and not force_train:
             logger.warning('The indexer has been trained or is not trainable. Please use ``force_train=True`` to retrain.')
             return
-        self._pq_codec.fit(x if isinstance(x, torch.Tensor) else np.ascontiguousarray(x, dtype=np.float32))
+        x = x if isinstance(x, torch.Tensor) else np.ascontiguousarray(x, dtype=np.float32)
+        if self._vq_codec is not None:  # index.py:218-222
+            logger.info(f'Start training VQ codec (K={self.n_cells}) with {x.shape[0]} data...')
+            self._vq_codec.fit(x)
+        self._pq_codec.fit(x)
         if auto_save:
             self.dump_model()
 
@@ -193,6 +224,9 @@ class AnnLite:
         if self.is_trained and not force_train:
             logger.warning('The annlite has been trained or is not trainable. Please use ``force_train=True`` to retrain.')
             return
+        if self._vq_codec is not None:  # index.py:259-263
+            self._vq_codec.partial_fit(x)
+            self._vq_codec.build_codebook()
         self._pq_codec.partial_fit(x)
         self._pq_codec.build_codebook()
         if auto_save:
@@ -201,6 +235,8 @@ class AnnLite:
     def dump_model(self):
         self.model_path.mkdir(parents=True, exist_ok=True)
         self._pq_codec.dump(self._pq_codec_path)
+        if self._vq_codec is not None:
+            self._vq_codec.dump(self._vq_codec_path)  # index.py:684-685
 
     # ------------------------------------------------------------------ index / update / delete
     def index(self, docs, **kwargs):

@@ -48,8 +48,10 @@ def test_annlite_constructor_and_untrained_errors(tmp_path):
 
     with pytest.raises(AssertionError):
         AnnLite(100, n_subvectors=8, data_path=tmp_path / 'a')  # index.py:86-89
+    ivf = AnnLite(128, n_subvectors=8, n_cells=4, n_probe=2, data_path=tmp_path / 'b')  # index.py:125-133
+    assert ivf.n_probe == 4 and not ivf.is_trained and ivf.stat['n_cells'] == 4  # index.py:94: max(n_probe, n_cells)
     with pytest.raises(NotImplementedError):
-        AnnLite(128, n_subvectors=8, n_cells=4, data_path=tmp_path / 'b')
+        AnnLite(128, n_subvectors=8, n_components=16, data_path=tmp_path / 'b2')
     ann = AnnLite(64, n_subvectors=8, data_path=tmp_path / 'c', dim=64)
     assert not ann.is_trained and ann.stat['total_docs'] == 0 and ann.stat['metric'] == 'COSINE'
     docs = DocumentArray([Document(id=str(i), embedding=np.zeros(64, np.float32)) for i in range(3)])

@@ -329,3 +329,38 @@ def test_vq_codec_training_quality():
         vq2.partial_fit(x[s:s + 1000])
     vq2.build_codebook()
     assert vq2.is_trained and vq2.codebook.shape == (16, 32)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason='needs an AMD GPU')
+def test_annlite_facade_with_cells(tmp_path):
+    """AnnLite(n_cells > 1): like the reference every cell is visited, so the matches equal the single-cell
+    facade's; ivf_prune=True honours n_probe (matches come from the probed cells, most of them the same)."""
+    from annlite_amd import AnnLite
+    from annlite_amd.docarray_compat import Document, DocumentArray
+
+    rs = np.random.RandomState(5)
+    N, D = 6000, 64
+    x, q = _data(rs, N, D, 20)
+    res = {}
+    for name, kw in (('flat', {}), ('cells', dict(n_cells=8, n_probe=2)), ('pruned', dict(n_cells=8, n_probe=3, ivf_prune=True))):
+        ann = AnnLite(D, metric='euclidean', n_subvectors=8, data_path=str(tmp_path / name), **kw)
+        ann._pq_codec.seed = 1  # same PQ codebooks for the three facades
+        if ann._vq_codec is not None:
+            ann._vq_codec.seed = 2
+        ann.train(x[:4096])
+        assert ann.is_trained
+        ann.index(DocumentArray([Document(id=str(i), embedding=x[i]) for i in range(N)]))
+        docs = DocumentArray([Document(id='q%d' % i, embedding=q[i]) for i in range(len(q))])
+        ann.search(docs, limit=10)
+        res[name] = [[(m.id, m.scores['euclidean'].value) for m in d.matches] for d in docs]
+        if name == 'cells':  # a second facade over the same data_path picks both trained codecs up (index.py:125-140)
+            again = AnnLite(D, metric='euclidean', n_subvectors=8, data_path=str(tmp_path / name), **kw)
+            assert again.is_trained and np.array_equal(again._vq_codec.codebook, ann._vq_codec.codebook)
+    # (every facade trains its own PQ codebooks: same seed, but the k-means sums are fp32 atomics, so the codewords
+    # agree only to the last bits -- ids must agree, distances to 1e-5)
+    same = np.mean([[a[0] == b[0] for a, b in zip(ra, rb)] for ra, rb in zip(res['cells'], res['flat'])])
+    assert same >= 0.99, same
+    assert np.allclose([[m[1] for m in r] for r in res['cells']], [[m[1] for m in r] for r in res['flat']], rtol=1e-5)
+    agree = np.mean([len({m for m, _ in a} & {m for m, _ in b}) / 10 for a, b in zip(res['pruned'], res['flat'])])
+    assert 0.5 <= agree <= 1.0
