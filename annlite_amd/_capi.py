@@ -54,6 +54,7 @@ SYMBOLS = (
     'annlite_pq_search_tiles_workspace_bytes',
     'annlite_pq_search_tiles',
     'annlite_ivf_rescore',
+    'annlite_ivf_candidate_ids',
     'annlite_codes_skew',
     'annlite_profile_enable',
     'annlite_profile_last_scan_ms',
@@ -127,6 +128,7 @@ def lib() -> ctypes.CDLL:
     L.annlite_pq_search_tiles_workspace_bytes.argtypes = [i64, i64, i64, i32, i64, i64, ctypes.POINTER(ctypes.c_int64)]
     L.annlite_pq_search_tiles.argtypes = [i32, vp, i64, i64, vp, vp, i32, i32, i64, i64, i64, vp, i64, vp, vp, vp, i64,
                                           vp, vp, sz, vp]
+    L.annlite_ivf_candidate_ids.argtypes = [vp, i64, vp, vp, i64, i64, vp, i64, vp, i64, vp]
     L.annlite_ivf_rescore.argtypes = [vp, i64, i64, i64, vp, i64, vp, vp, i64, vp, vp, i64, vp, i64, vp, i64, i64, vp,
                                       vp, i32, vp]
     L.annlite_profile_enable.argtypes = [i32]

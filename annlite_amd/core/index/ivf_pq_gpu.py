@@ -149,6 +149,13 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
             return d.cpu().numpy(), i.cpu().numpy()
         return d, i
 
+    def search_batch_packed(self, x, limit: int, row_base: int = 0):
+        """(row-sharded search, sharded.py) the packed fast path is the exhaustive scan's: with pruning active the
+        caller takes the general path through ``search_batch``."""
+        if self.n_probe is not None and self.n_probe < self.n_cells:
+            return None
+        return super().search_batch_packed(x, limit, row_base=row_base)
+
     def probe_cells(self, q: torch.Tensor, n_probe: int) -> torch.Tensor:
         kind, cent = self._select_kind_and_centroids()
         return ops.ivf_select_cells(kind, q, cent, n_probe)
@@ -167,23 +174,30 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
 
     def _search_pruned(self, q, k, P, indices, rerank_k):
         rerank = self.rerank and self._vectors is not None
-        ks = max(k, min(64, int(rerank_k or 64))) if rerank else k
+        k_out = k
+        if rerank:  # the scan keeps the rows that can be in a cell's ADC top-`rerank_k`; all of them are re-ranked
+            k = max(k, min(32, int(rerank_k or 16)))
         cells = self.probe_cells(q, P)
-        qt = scan_plan(self._n_table, self.M, self.Ks, 1, 16, ks).qt
+        qt = scan_plan(self._n_table, self.M, self.Ks, 1, 16, k).qt
         vmap, slot_of, tile_rows, _ = ops.ivf_plan(cells, self.n_cells, qt, self._cell_rows, self._cell_order)
         slot_q = q.index_select(0, vmap.clamp(min=0).to(torch.int64))
         kind, xq = self.pq_codec.scan_inputs(slot_q)
         bits = self._table_bits(indices)
-        cand, count = ops.pq_search_tiles(kind, xq, self.pq_codec.codebooks_dev, self._table, ks, self.M, self.Ks,
+        cand, count = ops.pq_search_tiles(kind, xq, self.pq_codec.codebooks_dev, self._table, k, self.M, self.Ks,
                                           tile_rows, vmap, valid_bits=bits, n_rows=self._n_table,
-                                          codes_layout=CODES_SKEWED, workspace=self._tws, cand_cap=self.cand_cap)
-        lut = self.pq_codec.get_dist_mat(q)  # [B, M, Ks], the reference's tables for the real queries
+                                          codes_layout=CODES_SKEWED, workspace=self._tws,
+                                          cand_cap=max(self.cand_cap, 32 * k))  # ~k ln(rows / k) rows pass per list
         if not rerank:
+            lut = self.pq_codec.get_dist_mat(q)  # [B, M, Ks], the reference's tables for the real queries
             return ops.ivf_rescore(lut, self._table_plain, cand, count, slot_of, tile_rows, qt, k, self._row_ids, bits,
                                    sqrt=self.metric == Metric.EUCLIDEAN)
-        _, ids = ops.ivf_rescore(lut, self._table_plain, cand, count, slot_of, tile_rows, qt, ks, self._row_ids, bits)
+        # float re-rank: every row the integer scan let through (a superset of each probed cell's ADC top-k, 3-4 k
+        # rows per list) is scored exactly on the stored vectors
+        R = P * 5 * k  # a list holds ~3-4 k rows
+        ids = ops.ivf_candidate_ids(cand, count, slot_of, R, self._row_ids)
         exact = ops.exact_gather_dist(int(self.metric), q, self._vectors, ids)
-        d, pos = ops.topk_rows(exact, k)
+        kk = min(k_out, 64)
+        d, pos = ops.topk_rows(exact, kk)
         i = torch.gather(ids, 1, pos.clamp(min=0))
         i = torch.where((pos < 0) | torch.isinf(d), torch.full_like(i, -1), i)
         if self.metric == Metric.EUCLIDEAN:

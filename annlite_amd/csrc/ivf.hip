@@ -227,6 +227,34 @@ __global__ __launch_bounds__(256) void ivf_rescore_kernel(const float *__restric
     }
 }
 
+// ---- candidate lists of a query as one dense id row (exact re-rank on the float vectors) -------------
+// One wave per query: its P lists are copied back to back into ids[b][0..R), translated to external ids, the
+// rest of the row is -1.  Lists that overflowed (count 0xffffffff) contribute nothing and entries beyond R are
+// dropped: the float re-rank's candidate set is a heuristic either way.
+__global__ __launch_bounds__(256) void ivf_candidate_ids_kernel(const uint32_t *__restrict__ cand, int cand_cap,
+                                                               const uint32_t *__restrict__ cand_count,
+                                                               const int32_t *__restrict__ slot_of, int B, int P,
+                                                               const int64_t *__restrict__ row_ids, int64_t id_base,
+                                                               int64_t *__restrict__ ids, int R) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    int64_t *row = ids + (int64_t)b * R;
+    int off = 0;
+    for (int p = 0; p < P && off < R; ++p) {
+        const int v = slot_of[(int64_t)b * P + p];
+        uint32_t n = cand_count[v];
+        if (n == 0xffffffffu) n = 0;
+        if ((int)n > R - off) n = (uint32_t)(R - off);
+        for (uint32_t j = lane; j < n; j += 64) {
+            const int64_t r = (int64_t)cand[(int64_t)v * cand_cap + j];
+            row[off + j] = id_base + (row_ids ? row_ids[r] : r);
+        }
+        off += (int)n;
+    }
+    for (int j = off + lane; j < R; j += 64) row[j] = -1;
+}
+
 }  // namespace annlite
 
 using namespace annlite;
@@ -306,4 +334,16 @@ extern "C" int annlite_ivf_rescore(const float *lut_bmk_dev, int64_t B, int64_t 
                        slot_of_dev, (int)P, tile_rows_dev, (int)qt, row_ids_dev, id_base, (int)k, out_dist_dev, out_id_dev,
                        (flags & ANNLITE_FLAG_SQRT) ? 1 : 0);
     return launch_status("ivf_rescore_kernel");
+}
+
+extern "C" int annlite_ivf_candidate_ids(const uint32_t *cand_dev, int64_t cand_cap, const uint32_t *cand_count_dev,
+                                         const int32_t *slot_of_dev, int64_t B, int64_t P, const int64_t *row_ids_dev,
+                                         int64_t id_base, int64_t *out_ids_dev, int64_t R, void *stream) {
+    ANNLITE_REQUIRE(B >= 0 && P >= 1 && R >= 1 && R < (1ll << 31) && cand_cap >= 1, "bad B=%lld P=%lld R=%lld", (long long)B,
+                    (long long)P, (long long)R);
+    if (B == 0) return ANNLITE_OK;
+    ANNLITE_REQUIRE(cand_dev && cand_count_dev && slot_of_dev && out_ids_dev, "null device pointer");
+    hipLaunchKernelGGL(ivf_candidate_ids_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, cand_dev,
+                       (int)cand_cap, cand_count_dev, slot_of_dev, (int)B, (int)P, row_ids_dev, id_base, out_ids_dev, (int)R);
+    return launch_status("ivf_candidate_ids_kernel");
 }

@@ -233,7 +233,8 @@ __device__ __forceinline__ void merge_tile_slices(const ScanArgs &a, int b0, int
 // + slack32 holds for each, so the cell's k-th exact distance is <= U = L + step*(Sk + 1.002 M) + slack32, and a
 // row can be in the top-k only if L + step*(S - 0.04) <= d_real <= U + slack32, i.e.
 //     S <= Sk + margin,  margin = floor(1.002 M + 0.04 + 2 slack32 / step) + 1.
-// The first Sk of a tile (the "seed") is the k-th smallest of the NW per-wave minima of the first 64-row blocks.
+// The first Sk of a tile (the "seed") is the k-th smallest of the 4 NW minima over the 16-lane rows of every wave's
+// first 64-row block (4 NW disjoint groups of 16 rows).
 // LDS (on top of the streaming layout): [ccnt u32 x QT][cbuf u64 x QT x CAP] behind the wave queues; the gkl slots
 // hold the margins, the gjl slots the emitted counts and overflow flags (one slice per tile: both are idle).
 // =================================================================================================
@@ -411,20 +412,26 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
         int item = blockIdx.x + it * gridDim.x;
         int tile, slice;
         int64_t slice_begin, slice_end;
+        unsigned int next_item = 0;  // (tile mode, thread 0)
         if constexpr (TILES) {
-            // tile mode: one item per query tile with its own row range, taken from a device-wide counter
+            // tile mode: one item per query tile with its own row range, taken from a device-wide counter.  The
+            // index of the NEXT item is fetched while this one's table is loaded (two LDS slots, alternating), so
+            // the atomic's round trip is off the critical path.
             volatile unsigned int *s_item = (volatile unsigned int *)(smem + shq_off + 48);
-            __syncthreads();  // every wave is done with the previous item (and has read s_item)
-            if (tid == 0)
-                *s_item = __hip_atomic_fetch_add(a.item_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-            __syncthreads();
-            item = (int)*s_item;
+            if (it == 0 && tid == 0)
+                s_item[0] = __hip_atomic_fetch_add(a.item_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            __syncthreads();  // every wave is done with the previous item; the slot of this one is written
+            item = (int)s_item[it & 1];
             if (item >= n_items) break;
+            if (tid == 0) next_item = __hip_atomic_fetch_add(a.item_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
             tile = item;
             slice = 0;
             slice_begin = a.tile_rows[2 * tile];
             slice_end = a.tile_rows[2 * tile + 1];
-            if (slice_begin < 0) continue;  // unused tile: nobody reads its outputs
+            if (slice_begin < 0) {  // unused tile: nobody reads its outputs
+                if (tid == 0) s_item[(it + 1) & 1] = next_item;
+                continue;
+            }
         } else {
             if (item >= n_items) break;
             if (!item_map(a, item, tile, slice)) continue;
@@ -469,6 +476,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                 shq[tid] = real ? qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]) : (unsigned short)0x7fff;
             }
             for (int idx = tid; idx < QT * 64; idx += NW * 64) lists[idx] = ~0ull;
+            if constexpr (TILES)
+                if (tid == 0) ((volatile unsigned int *)(smem + shq_off + 48))[(it + 1) & 1] = next_item;
         }
         __syncthreads();
 
@@ -545,14 +554,15 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
             vnext = load_valid(row0 + stride + lane);
         }
         if constexpr (TILES) {
-            // Integer seed bound (no separate seed launch, no exact sums): every wave takes the per-query MINIMUM
-            // integer sum S of its first 64 rows; the NW minima belong to distinct rows, so >= k rows have
+            // Integer seed bound (no separate seed launch, no exact sums): every 16-lane row of every wave takes the
+            // per-query MINIMUM integer sum S of its 16 rows; the 4 NW minima belong to distinct rows, so >= k rows have
             // S <= Sk := the k-th smallest of them.  d_exact <= L + step*(S + 1.002 M) + slack32 for every row, so the
             // final k-th distance is <= U = L + step*(Sk + 1.002 M) + slack32, and a row can only be in the top-k if
             // L + step*(S - 0.04) <= d_real <= U + slack32, i.e. S <= Sk + 1.002 M + 0.04 + 2 slack32 / step.
             // Without it every row of the first steps is a candidate (16 waves x 16 queries x 64 exact gathers).
-            if (a.k <= NW) {
-                uint32_t *smin = (uint32_t *)(smem + queue_off);  // [NW][NQ * 4] packed minima (queues are idle)
+            constexpr int NG = NW * 4;  // one minimum per 16-lane row of every wave: NG disjoint groups of 16 rows
+            if (a.k <= NG) {
+                uint32_t *smin = (uint32_t *)(smem + queue_off);  // [NG][NQ * 4] packed minima (queues are idle)
                 u32x4 sacc[NQ];
                 const bool have = row0 < slice_end;
                 bool ok = have && row0 + lane < slice_end;
@@ -567,23 +577,23 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                     for (int w = 0; w < 4; ++w) {
                         uint32_t x = ok ? sacc[h][w] : 0x7fff7fffu;
 #pragma unroll
-                        for (int o = 1; o < 64; o <<= 1) {
+                        for (int o = 1; o < 16; o <<= 1) {
                             const uint32_t y = (uint32_t)__shfl_xor((int)x, o);
                             asm("v_pk_min_u16 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y));
                         }
-                        if (lane == 0) smin[wave * (NQ * 4) + h * 4 + w] = x;
+                        if ((lane & 15) == 0) smin[(wave * 4 + (lane >> 4)) * (NQ * 4) + h * 4 + w] = x;
                     }
                 __syncthreads();
-                if (tid < QT * NW) {
-                    // thread (q, i) ranks minimum i of slot q among the NW (ties by wave); the one of rank k-1 sets the bound
-                    const int q = tid / NW, i = tid - q * NW;
+                if (tid < QT * NG) {
+                    // thread (q, i) ranks minimum i of slot q among the NG (ties by group); the one of rank k-1 sets the bound
+                    const int q = tid / NG, i = tid - q * NG;
                     const int b = tile * QT + q;
                     if (b < a.B && a.vmap[b] >= 0) {
                         const volatile uint16_t *sm16 = (const volatile uint16_t *)smin;
                         const uint32_t vi = sm16[i * (NQ * 8) + q];
                         int rank = 0;
 #pragma unroll 4
-                        for (int j = 0; j < NW; ++j) {
+                        for (int j = 0; j < NG; ++j) {
                             const uint32_t vj = sm16[j * (NQ * 8) + q];
                             rank += (vj < vi) || (vj == vi && j < i);
                         }
@@ -843,19 +853,23 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
         int item = blockIdx.x + it * gridDim.x;
         int tile, slice;
         int64_t slice_begin, slice_end;
+        unsigned int next_item = 0;  // (tile mode, thread 0)
         if constexpr (TILES) {  // (see adc_scan_qfilter_kernel)
             volatile unsigned int *s_item = (volatile unsigned int *)(smem + shq_off + 48);
+            if (it == 0 && tid == 0)
+                s_item[0] = __hip_atomic_fetch_add(a.item_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
             __syncthreads();
-            if (tid == 0)
-                *s_item = __hip_atomic_fetch_add(a.item_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-            __syncthreads();
-            item = (int)*s_item;
+            item = (int)s_item[it & 1];
             if (item >= a.n_items) break;
+            if (tid == 0) next_item = __hip_atomic_fetch_add(a.item_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
             tile = item;
             slice = 0;
             slice_begin = a.tile_rows[2 * tile];
             slice_end = a.tile_rows[2 * tile + 1];
-            if (slice_begin < 0) continue;
+            if (slice_begin < 0) {
+                if (tid == 0) s_item[(it + 1) & 1] = next_item;
+                continue;
+            }
         } else {
             if (item >= a.n_items) break;
             if (!item_map(a, item, tile, slice)) continue;
@@ -892,6 +906,8 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
                 shq[tid] = real ? qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]) : (unsigned short)0x7fff;
             }
             for (int idx = tid; idx < QT * 64; idx += NW * 64) lists[idx] = ~0ull;
+            if constexpr (TILES)
+                if (tid == 0) ((volatile unsigned int *)(smem + shq_off + 48))[(it + 1) & 1] = next_item;
         }
         __syncthreads();
 
@@ -951,8 +967,9 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
         };
         if constexpr (TILES) {
             // integer seed bound from the per-wave minima of the first rows (see adc_scan_qfilter_kernel)
-            if (a.k <= NW) {
-                uint32_t *smin = (uint32_t *)(smem + queue_off);  // [NW][2]
+            constexpr int NG = NW * 4;
+            if (a.k <= NG) {
+                uint32_t *smin = (uint32_t *)(smem + queue_off);  // [NG][2]
                 u32x2 sacc = {0u, 0u};
                 const bool have = row0 < slice_end;
                 bool ok = have && row0 + lane < slice_end;
@@ -962,22 +979,22 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
                 for (int w = 0; w < 2; ++w) {
                     uint32_t x = ok ? (w ? sacc.y : sacc.x) : 0x7fff7fffu;
 #pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
+                    for (int o = 1; o < 16; o <<= 1) {
                         const uint32_t y = (uint32_t)__shfl_xor((int)x, o);
                         asm("v_pk_min_u16 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y));
                     }
-                    if (lane == 0) smin[wave * 2 + w] = x;
+                    if ((lane & 15) == 0) smin[(wave * 4 + (lane >> 4)) * 2 + w] = x;
                 }
                 __syncthreads();
-                if (tid < QT * NW) {
-                    const int q = tid / NW, i = tid - q * NW;
+                if (tid < QT * NG) {
+                    const int q = tid / NG, i = tid - q * NG;
                     const int b = tile * QT + q;
                     if (b < a.B && a.vmap[b] >= 0) {
                         const volatile uint16_t *sm16 = (const volatile uint16_t *)smin;
                         const uint32_t vi = sm16[i * 4 + q];
                         int rank = 0;
 #pragma unroll 4
-                        for (int j = 0; j < NW; ++j) {
+                        for (int j = 0; j < NG; ++j) {
                             const uint32_t vj = sm16[j * 4 + q];
                             rank += (vj < vi) || (vj == vi && j < i);
                         }

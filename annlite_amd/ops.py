@@ -271,6 +271,16 @@ def ivf_rescore(lut_bmk: torch.Tensor, codes_plain: torch.Tensor, cand: torch.Te
     return od, oi
 
 
+def ivf_candidate_ids(cand: torch.Tensor, count: torch.Tensor, slot_of: torch.Tensor, R: int,
+                      row_ids: Optional[torch.Tensor] = None, id_base: int = 0) -> torch.Tensor:
+    """Every query's candidate lists as one dense i64 row [B, R] of external ids, padded with -1."""
+    B, P = slot_of.shape
+    out = torch.empty((B, R), dtype=torch.int64, device=cand.device)
+    check(lib().annlite_ivf_candidate_ids(cand.data_ptr(), cand.shape[1], count.data_ptr(), slot_of.data_ptr(), B, P,
+                                          _ptr(row_ids), id_base, out.data_ptr(), R, stream_ptr()), 'ivf_candidate_ids')
+    return out
+
+
 def topk_merge_packed(packed: torch.Tensor, sqrt: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """[G,B,k,2] i64 (id, distance bits) -> ([B,k] f32, [B,k] i64), same order rule as ``topk_merge``."""
     G, B, k, _ = packed.shape

@@ -337,6 +337,14 @@ ANNLITE_API int annlite_ivf_rescore(const float *lut_bmk_dev, int64_t B, int64_t
                         const int64_t *row_ids_dev, int64_t id_base, int64_t k, float *out_dist_dev,
                         int64_t *out_id_dev, int flags, void *stream);
 
+/* The candidate lists of every query as ONE dense id row: out_ids[b][0..R) = its P lists back to
+ * back (id_base + row_ids[row]), padded with -1 -- the input of annlite_exact_gather_dist when the
+ * index keeps the float vectors (re-rank).  Overflowed lists contribute
+ * nothing and entries beyond R are dropped (the re-rank candidate set is a heuristic). */
+ANNLITE_API int annlite_ivf_candidate_ids(const uint32_t *cand_dev, int64_t cand_cap, const uint32_t *cand_count_dev,
+                              const int32_t *slot_of_dev, int64_t B, int64_t P, const int64_t *row_ids_dev,
+                              int64_t id_base, int64_t *out_ids_dev, int64_t R, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
