@@ -57,6 +57,9 @@ def parse():
                    help='streams the timed batches alternate on (0 = auto: 2 when the exchange runs, else 1)')
     p.add_argument('--layout', choices=['skewed', 'plain'], default='skewed')
     p.add_argument('--no-rerank', action='store_true', help='skip the (untimed-in-value) exact re-rank leg')
+    p.add_argument('--ivf-cells', type=int, default=256,
+                   help='extra leg (N=1, never `value`): pruned search over this many cells; 0 = skip')
+    p.add_argument('--ivf-probe', type=int, default=16)
     return p.parse_args()
 
 
@@ -277,6 +280,56 @@ def main():
             recall_rr = float(np.mean([len(set(got[b]) & set(truth[b])) / k for b in range(nq)]))
             index.rerank = False
 
+    # ---- extra leg, never `value`: the pruned (IVF) search over the same rows (SURVEY.md 8f follow-on) --------
+    ivf_rec = None
+    if world == 1 and args.ivf_cells > 1 and M in (8, 16, 32, 64) and nq > 0:
+        from annlite_amd.core.codec.vq import VQCodec
+        from annlite_amd.core.index.ivf_pq_gpu import IvfPQGpuIndex
+
+        vq = VQCodec(args.ivf_cells, metric=metric, iter=15, n_init=1)
+        vq.seed = 11
+        vq.fit(gen_chunk(0, CH, D, A, dev)[:100_000])
+        ivf = IvfPQGpuIndex(dim=D, metric=metric, pq_codec=codec, vq_codec=vq, initial_size=64, rerank=keep_vectors,
+                            skewed=(args.layout == 'skewed'))
+        # adopt the flat index's storage (same codes, validity, float vectors); add the cell of every row
+        for name in ('_codes', '_valid_bool', '_valid_bits_cache', '_vectors', '_capacity', '_n_rows', '_size'):
+            setattr(ivf, name, getattr(index, name))
+        ivf._cell_of = torch.zeros((index._capacity,), dtype=torch.int32, device=dev)
+        for c in range(c0, c1):
+            rows = min(CH, N - c * CH)
+            x = gen_chunk(c, rows, D, A, dev)
+            a_, b_ = max(lo, c * CH), min(hi, c * CH + rows)
+            ivf._cell_of[a_ - lo: b_ - lo] = vq.encode(x[a_ - c * CH: b_ - c * CH]).to(torch.int32)
+        ivf.rerank = False
+        P = min(args.ivf_probe, args.ivf_cells - 1)
+        for _ in range(2):
+            iv = ivf.search_batch(queries, limit=k, n_probe=P)
+        torch.cuda.synchronize()
+        n_iv = max(3, args.steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(n_iv):
+            iv = ivf.search_batch(queries, limit=k, n_probe=P)
+        torch.cuda.synchronize()
+        iv_qps = B * n_iv / (time.perf_counter() - t0)
+        got_iv = iv[1][:nq].cpu().numpy()
+        adc_ids = out[1][:nq].cpu().numpy()
+        ivf_rec = {'n_cells': args.ivf_cells, 'n_probe': P, 'value': iv_qps, 'unit': 'queries/s',
+                   'recall_at_10': float(np.mean([len(set(got_iv[b]) & set(truth[b])) / k for b in range(nq)])),
+                   'agreement_with_exhaustive_adc_top10': float(np.mean([len(set(got_iv[b]) & set(adc_ids[b])) / k for b in range(nq)]))}
+        if keep_vectors:
+            ivf.rerank = True
+            for _ in range(2):
+                iv = ivf.search_batch(queries, limit=k, n_probe=P, rerank_k=32)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_iv):
+                iv = ivf.search_batch(queries, limit=k, n_probe=P, rerank_k=32)
+            torch.cuda.synchronize()
+            got_iv = iv[1][:nq].cpu().numpy()
+            ivf_rec['rerank'] = {'value': B * n_iv / (time.perf_counter() - t0), 'unit': 'queries/s', 'rerank_k': 32,
+                                 'recall_at_10': float(np.mean([len(set(got_iv[b]) & set(truth[b])) / k for b in range(nq)]))}
+        del ivf
+
     # ---- CPU baseline: the oracle (C port of the reference loops) on a bounded sample, rank 0, N=1 --
     cpu = None
     if rank == 0 and world == 1 and args.cpu_queries > 0:
@@ -333,6 +386,7 @@ def main():
                         'frac': lookups_per_s / (256 * 128 * 2.4e9)},
             },
             'cpu_baseline': cpu,
+            'ivf': ivf_rec,
             'with_host_transfer': {'value': host_qps, 'unit': 'queries/s',
                                    'note': 'numpy queries in, numpy results out per batch (PCIe both ways, synchronous)'},
             'setup': {'train_s': train_s, 'index_s': index_s},
