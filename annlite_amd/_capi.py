@@ -126,8 +126,8 @@ def lib() -> ctypes.CDLL:
     L.annlite_ivf_max_tiles.argtypes = [i64, i64, i64, i64]
     L.annlite_ivf_plan.argtypes = [vp, i64, i64, i64, i64, vp, vp, i64, vp, vp, vp, vp, vp]
     L.annlite_pq_search_tiles_workspace_bytes.argtypes = [i64, i64, i64, i32, i64, i64, ctypes.POINTER(ctypes.c_int64)]
-    L.annlite_pq_search_tiles.argtypes = [i32, vp, i64, i64, vp, vp, i32, i32, i64, i64, i64, vp, i64, vp, vp, vp, i64,
-                                          vp, vp, sz, vp]
+    L.annlite_pq_search_tiles.argtypes = [i32, vp, i64, i64, vp, vp, i32, i32, i64, i64, i64, vp, i64, i64, vp, vp, vp,
+                                          i64, vp, vp, sz, vp]
     L.annlite_ivf_candidate_ids.argtypes = [vp, i64, vp, vp, i64, i64, vp, i64, vp, i64, vp]
     L.annlite_ivf_rescore.argtypes = [vp, i64, i64, i64, vp, i64, vp, vp, i64, vp, vp, i64, vp, i64, vp, i64, i64, vp,
                                       vp, i32, vp]

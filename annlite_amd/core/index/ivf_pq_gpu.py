@@ -18,8 +18,8 @@ Layout in HBM on top of the flat index's storage (codes by offset, validity, opt
       ``_row_ids``   i64 [Nt] offset of every table row (-1: padding)
       ``_cell_rows`` i64 [C, 2] (begin, end) of every cell, ``_cell_order`` i32 [C] cells by descending size
       ``_table_plain`` the same rows in the PLAIN layout (read by the exact re-score)
-Search = ``annlite_ivf_select_cells`` -> ``annlite_ivf_plan`` (query tiles of one cell each) -> gather of the slot
-queries -> ``annlite_pq_search_tiles`` (quantised tables + integer scan: per-slot candidate lists) ->
+Search = ``annlite_ivf_select_cells`` -> ``annlite_ivf_plan`` (query tiles of one cell each) ->
+``annlite_pq_search_tiles`` (quantised tables of the queries + integer scan: per-slot candidate lists) ->
 ``annlite_lut_build`` for the real queries -> ``annlite_ivf_rescore`` (exact sums of the candidates, top-k).
 """
 from typing import Optional, Tuple
@@ -180,8 +180,7 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
         cells = self.probe_cells(q, P)
         qt = scan_plan(self._n_table, self.M, self.Ks, 1, 16, k).qt
         vmap, slot_of, tile_rows, _ = ops.ivf_plan(cells, self.n_cells, qt, self._cell_rows, self._cell_order)
-        slot_q = q.index_select(0, vmap.clamp(min=0).to(torch.int64))
-        kind, xq = self.pq_codec.scan_inputs(slot_q)
+        kind, xq = self.pq_codec.scan_inputs(q)
         bits = self._table_bits(indices)
         cand, count = ops.pq_search_tiles(kind, xq, self.pq_codec.codebooks_dev, self._table, k, self.M, self.Ks,
                                           tile_rows, vmap, valid_bits=bits, n_rows=self._n_table,

@@ -442,6 +442,7 @@ struct TileMode {
     uint32_t *cand;            // [B][cand_cap] out
     uint32_t *cand_count;      // [B] out
     int64_t cand_cap;
+    int64_t n_queries;         // real queries: the tables are built for THEM, slot s uses the tables of query vmap[s]
 };
 
 static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M, int64_t Ks,
@@ -570,8 +571,9 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             // (the q16 table sits behind the small arrays; carve order is irrelevant to the kernels)
             uint16_t *q16 = (uint16_t *)carve(bpad * M * Ks * 2);
             // (tile mode with the fused L2 build: the slots' fp32 tables are never read -- do not store them)
-            rc = launch_lut_quantise(M, Ks, B, bpad, (tm && build) ? nullptr : lut_dev, build, q16, qstep, qlo, smax,
-                                     workspace_dev, fill_bytes, st);
+            const int64_t Bq = tm ? tm->n_queries : B;  // tile mode: tables of the real queries only
+            rc = launch_lut_quantise(M, Ks, Bq, ((Bq + 15) / 16) * 16, (tm && build) ? nullptr : lut_dev, build, q16, qstep,
+                                     qlo, smax, workspace_dev, fill_bytes, st);
             if (rc != ANNLITE_OK) return rc;
             if (share_across_slices && N >= 4096 && !tm) {  // (tile mode seeds inside the scan kernel)
                 int64_t S = 8192;
@@ -695,13 +697,15 @@ static int pq_search_impl(int lut_kind, const float *queries_dev, int64_t B, int
                           const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M, int64_t Ks,
                           const uint32_t *valid_bits_dev, int64_t k, int64_t row_base, float *out_dist_dev,
                           int64_t *out_id_dev, int64_t *out_packed_dev, int flags, void *workspace_dev,
-                          size_t workspace_bytes, void *stream, const TileMode *tm) {
+                          size_t workspace_bytes, void *stream, const TileMode *tm, int64_t n_slots = 0) {
     ANNLITE_REQUIRE(M >= 1 && D >= M && D % M == 0,
                     "input dimension must be dividable by number of sub-space (D=%lld, M=%lld)", (long long)D, (long long)M);
+    // tile mode: B real queries (tables), n_slots >= B scan slots (lists, bounds)
+    const int64_t Bs = tm ? n_slots : B;
     annlite_scan_plan plan;
-    int rc = plan_query_impl(N, M, Ks, code_bytes, B, k, tm ? 1 : 0, &plan);
+    int rc = plan_query_impl(N, M, Ks, code_bytes, Bs, k, tm ? 1 : 0, &plan);
     if (rc != ANNLITE_OK) return rc;
-    if (B == 0) return ANNLITE_OK;
+    if (Bs == 0 || B == 0) return ANNLITE_OK;
     const size_t scan_ws = r256z((size_t)plan.workspace_bytes);
     const size_t need = scan_ws + r256z((size_t)plan.lut_floats * 4);
     if (workspace_bytes < need) {
@@ -709,6 +713,7 @@ static int pq_search_impl(int lut_kind, const float *queries_dev, int64_t B, int
         return ANNLITE_ERR_WORKSPACE;
     }
     ANNLITE_REQUIRE(queries_dev && codebooks_dev && workspace_dev, "null device pointer");
+    ANNLITE_REQUIRE(!tm || B <= Bs, "tile mode: more queries (%lld) than slots (%lld)", (long long)B, (long long)Bs);
     float *lut = (float *)((char *)workspace_dev + scan_ws);
     FastCfg c;
     const bool fuse = N > 0 && plan.fast && fast_cfg(M, Ks, code_bytes, k, &c) && c.mode == 4 && M != 64 &&
@@ -717,11 +722,11 @@ static int pq_search_impl(int lut_kind, const float *queries_dev, int64_t B, int
         rc = annlite_lut_build(lut_kind, queries_dev, B, D, codebooks_dev, M, Ks, lut,
                                plan.fast ? ANNLITE_LAYOUT_TILED : ANNLITE_LAYOUT_BMK, plan.qi, stream);
         if (rc != ANNLITE_OK) return rc;
-        return scan_topk_impl(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut, B, k, row_base,
+        return scan_topk_impl(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut, Bs, k, row_base,
                               out_dist_dev, out_id_dev, out_packed_dev, workspace_dev, scan_ws, stream, nullptr, flags, tm);
     }
     const LutBuild lb = {queries_dev, codebooks_dev, D};
-    return scan_topk_impl(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut, B, k, row_base, out_dist_dev,
+    return scan_topk_impl(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut, Bs, k, row_base, out_dist_dev,
                           out_id_dev, out_packed_dev, workspace_dev, scan_ws, stream, &lb, flags, tm);
 }
 
@@ -745,18 +750,18 @@ extern "C" int annlite_pq_search_tiles_workspace_bytes(int64_t N, int64_t M, int
     return ANNLITE_OK;
 }
 
-extern "C" int annlite_pq_search_tiles(int lut_kind, const float *queries_dev, int64_t V, int64_t D,
+extern "C" int annlite_pq_search_tiles(int lut_kind, const float *queries_dev, int64_t B, int64_t D,
                                        const float *codebooks_dev, const void *codes_dev, int code_bytes, int codes_layout,
                                        int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev, int64_t k,
-                                       const int64_t *tile_rows_dev, const int32_t *vmap_dev, uint32_t *cand_dev,
+                                       int64_t V, const int64_t *tile_rows_dev, const int32_t *vmap_dev, uint32_t *cand_dev,
                                        int64_t cand_cap, uint32_t *cand_count_dev, void *workspace_dev,
                                        size_t workspace_bytes, void *stream) {
     ANNLITE_REQUIRE(V == 0 || (tile_rows_dev && vmap_dev && cand_dev && cand_count_dev), "null tile table / output");
     ANNLITE_REQUIRE(N > 0 || V == 0, "tile mode needs a non-empty code table");
     ANNLITE_REQUIRE(cand_cap >= 64 && cand_cap < (1ll << 30), "cand_cap=%lld outside [64, 2^30)", (long long)cand_cap);
-    const TileMode tm = {tile_rows_dev, vmap_dev, cand_dev, cand_count_dev, cand_cap};
-    return pq_search_impl(lut_kind, queries_dev, V, D, codebooks_dev, codes_dev, code_bytes, codes_layout, N, M, Ks,
-                          valid_bits_dev, k, 0, nullptr, nullptr, nullptr, 0, workspace_dev, workspace_bytes, stream, &tm);
+    const TileMode tm = {tile_rows_dev, vmap_dev, cand_dev, cand_count_dev, cand_cap, B};
+    return pq_search_impl(lut_kind, queries_dev, B, D, codebooks_dev, codes_dev, code_bytes, codes_layout, N, M, Ks,
+                          valid_bits_dev, k, 0, nullptr, nullptr, nullptr, 0, workspace_dev, workspace_bytes, stream, &tm, V);
 }
 
 extern "C" int annlite_adc_scan_candidates(const void *codes_dev, int code_bytes, int codes_layout, int64_t N,

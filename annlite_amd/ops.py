@@ -229,16 +229,18 @@ def ivf_plan(cells: torch.Tensor, n_cells: int, qt: int, cell_rows: torch.Tensor
     return vmap, slot_of, tile_rows, used
 
 
-def pq_search_tiles(lut_kind: int, slot_queries: torch.Tensor, codebooks: torch.Tensor, codes: torch.Tensor, k: int,
+def pq_search_tiles(lut_kind: int, queries: torch.Tensor, codebooks: torch.Tensor, codes: torch.Tensor, k: int,
                     M: int, Ks: int, tile_rows: torch.Tensor, vmap: torch.Tensor,
                     valid_bits: Optional[torch.Tensor] = None, n_rows: Optional[int] = None,
                     codes_layout: int = CODES_PLAIN, workspace: Optional[ScanWorkspace] = None, cand_cap: int = 256
                     ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """``annlite_pq_search_tiles``: slot queries f32 [V, D]; tile t = slots [t*qt, (t+1)*qt) scans rows
-    ``tile_rows[t]`` only, with integer sums.  Returns the per-slot candidate lists
-    ``(cand u32-as-i32 [V, cand_cap] table rows, count i32 [V])`` (count -1: overflow, re-score the whole cell)."""
+    """``annlite_pq_search_tiles``: REAL queries f32 [B, D] (their tables are built once); slot s of the V =
+    ``vmap.numel()`` slots scans rows ``tile_rows[s // qt]`` with the tables of query ``vmap[s]``, integer sums only.
+    Returns the per-slot candidate lists ``(cand i32 [V, cand_cap] table rows, count i32 [V])`` (count -1: overflow,
+    re-score the whole cell)."""
     N = codes.shape[0] if n_rows is None else n_rows
-    V, D = slot_queries.shape
+    B, D = queries.shape
+    V = vmap.numel()
     cb = code_bytes_of(codes)
     need = ctypes.c_int64(0)
     check(lib().annlite_pq_search_tiles_workspace_bytes(N, M, Ks, cb, V, k, ctypes.byref(need)),
@@ -247,8 +249,8 @@ def pq_search_tiles(lut_kind: int, slot_queries: torch.Tensor, codebooks: torch.
     ws = (workspace or ScanWorkspace()).get(int(need.value), dev)
     cand = torch.empty((V, cand_cap), dtype=torch.int32, device=dev)
     count = torch.empty((V,), dtype=torch.int32, device=dev)
-    check(lib().annlite_pq_search_tiles(lut_kind, slot_queries.data_ptr(), V, D, codebooks.data_ptr(), codes.data_ptr(),
-                                        cb, codes_layout, N, M, Ks, _ptr(valid_bits), k, tile_rows.data_ptr(),
+    check(lib().annlite_pq_search_tiles(lut_kind, queries.data_ptr(), B, D, codebooks.data_ptr(), codes.data_ptr(),
+                                        cb, codes_layout, N, M, Ks, _ptr(valid_bits), k, V, tile_rows.data_ptr(),
                                         vmap.data_ptr(), cand.data_ptr(), cand_cap, count.data_ptr(), ws.data_ptr(),
                                         ws.numel(), stream_ptr()), 'pq_search_tiles')
     return cand, count

@@ -311,13 +311,14 @@ ANNLITE_API int annlite_ivf_plan(const int32_t *cells_dev, int64_t B, int64_t P,
  * d_kth <= L + step*(Sk + 1.002 M) + slack) and EMITS every row that can still be in the slot's exact
  * top-k:  cand[v][0..cand_count[v])  (table rows; cand_count 0xffffffff = the list overflowed
  * cand_cap, re-score the whole cell).  annlite_ivf_rescore turns the lists into exact results.
- * V = n_tiles * qt slot queries (queries_dev f32 [V][D]: the probing query of every slot, anything
- * for padding slots).  Quantised-filter plans only (M in {8,16,32,64}, Ks <= 256, uint8 codes). */
+ * queries_dev f32 [B][D]: the REAL queries -- their tables are built and quantised once; slot s of
+ * the V = n_tiles * qt slots scans with the tables of query vmap[s] (-1: padding slot).
+ * Quantised-filter plans only (M in {8,16,32,64}, Ks <= 256, uint8 codes). */
 ANNLITE_API int annlite_pq_search_tiles_workspace_bytes(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t V,
                                             int64_t k, int64_t *bytes);
-ANNLITE_API int annlite_pq_search_tiles(int lut_kind, const float *queries_dev, int64_t V, int64_t D,
+ANNLITE_API int annlite_pq_search_tiles(int lut_kind, const float *queries_dev, int64_t B, int64_t D,
                             const float *codebooks_dev, const void *codes_dev, int code_bytes, int codes_layout,
-                            int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev, int64_t k,
+                            int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev, int64_t k, int64_t V,
                             const int64_t *tile_rows_dev, const int32_t *vmap_dev, uint32_t *cand_dev,
                             int64_t cand_cap, uint32_t *cand_count_dev, void *workspace_dev, size_t workspace_bytes,
                             void *stream);

@@ -24,6 +24,9 @@ def main():
     p.add_argument('--truth-queries', type=int, default=256)
     p.add_argument('--reps', type=int, default=10)
     p.add_argument('--no-rerank', action='store_true')
+    p.add_argument('--dim', type=int, default=128)
+    p.add_argument('--m', type=int, default=16)
+    p.add_argument('--metric', choices=['euclidean', 'cosine', 'inner_product'], default='euclidean')
     args = p.parse_args()
     from annlite_amd import Metric, PQCodec, ops
     from annlite_amd import _capi
@@ -32,21 +35,23 @@ def main():
     from annlite_amd.core.index.ivf_pq_gpu import IvfPQGpuIndex
 
     dev = torch.device('cuda', 0)
-    N, D, M, Ks, B, k, C = args.rows, 128, 16, 256, args.batch, args.k, args.cells
+    N, D, M, Ks, B, k, C = args.rows, args.dim, args.m, 256, args.batch, args.k, args.cells
+    metric = {'euclidean': Metric.EUCLIDEAN, 'cosine': Metric.COSINE, 'inner_product': Metric.INNER_PRODUCT}[args.metric]
+    r_lat = 16 if D <= 128 else 64
     gA = torch.Generator(device=dev)
     gA.manual_seed(99)
-    A = torch.randn((16, D), generator=gA, device=dev)
+    A = torch.randn((r_lat, D), generator=gA, device=dev)
     CH = 250_000
     train = bench.gen_chunk(0, CH, D, A, dev)[:100_000]
-    codec = PQCodec(dim=D, n_subvectors=M, n_clusters=Ks, metric=Metric.EUCLIDEAN, n_init=1)
+    codec = PQCodec(dim=D, n_subvectors=M, n_clusters=Ks, metric=metric, n_init=1)
     codec.seed = 7
     codec.fit(train, iter=10)
-    vq = VQCodec(C, metric=Metric.EUCLIDEAN, iter=15, n_init=1)
+    vq = VQCodec(C, metric=metric, iter=15, n_init=1)
     vq.seed = 11
     t0 = time.time()
     vq.fit(train)
     vq_s = time.time() - t0
-    idx = IvfPQGpuIndex(dim=D, metric=Metric.EUCLIDEAN, pq_codec=codec, vq_codec=vq, initial_size=N,
+    idx = IvfPQGpuIndex(dim=D, metric=metric, pq_codec=codec, vq_codec=vq, initial_size=N,
                         rerank=not args.no_rerank)
     t0 = time.time()
     for c in range((N + CH - 1) // CH):
@@ -62,7 +67,7 @@ def main():
 
     gq = torch.Generator(device=dev)
     gq.manual_seed(4321)
-    zq = torch.randn((B, 16), generator=gq, device=dev)
+    zq = torch.randn((B, r_lat), generator=gq, device=dev)
     eq = torch.randn((B, D), generator=gq, device=dev)
     queries = (zq @ A + 0.05 * eq).contiguous()
 
@@ -110,8 +115,7 @@ def main():
         st['select'], cells = timed(lambda: idx.probe_cells(q, P))
         qt = scan_plan(idx._n_table, M, Ks, 1, 16, k).qt
         st['plan'], (vmap, slot_of, tile_rows, used) = timed(lambda: ops.ivf_plan(cells, C, qt, idx._cell_rows, idx._cell_order))
-        st['gather'], slot_q = timed(lambda: q.index_select(0, vmap.clamp(min=0).to(torch.int64)))
-        kind, xq = codec.scan_inputs(slot_q)
+        kind, xq = codec.scan_inputs(q)
         st['tables_scan'], (cand, count) = timed(lambda: ops.pq_search_tiles(
             kind, xq, codec.codebooks_dev, idx._table, k, M, Ks, tile_rows, vmap, n_rows=idx._n_table,
             codes_layout=CODES_SKEWED, workspace=idx._tws, cand_cap=idx.cand_cap))
