@@ -49,7 +49,8 @@ struct ScanArgs {
     // tile mode (IVF cells, annlite_pq_search_tiles): every query tile scans its OWN row range, one work item per
     // tile (n_slices = 1); the tiles are handed out dynamically, longest first
     const int64_t *tile_rows;    // [n_tiles][2] (begin: multiple of 64, end); begin < 0: unused tile; NULL = slices
-    const int32_t *vmap;         // [n_tiles * QT] >= 0: the slot holds a query; < 0: padding (never passes the filter)
+    const int32_t *vmap;         // [n_tiles * QT] >= 0: the query whose tables the slot scans with (q16 / smax / qstep
+                                 // hold the REAL queries); < 0: padding slot (never passes the filter)
     unsigned int *item_counter;  // starts at 0xffffffff (workspace fill): next item = atomicAdd + 1
     uint32_t *cand;              // [n_tiles * QT][cand_cap] out: table rows of every slot that can be in its top-k
     uint32_t *cand_count;        // [n_tiles * QT] out: entries of the slot's list; 0xffffffff: it overflowed

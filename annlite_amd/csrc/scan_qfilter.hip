@@ -585,12 +585,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
             vnext = load_valid(row0 + stride + lane);
         }
         if constexpr (TILES) {
-            // Integer seed bound (no separate seed launch, no exact sums): every 16-lane row of every wave takes the
-            // per-query MINIMUM integer sum S of its 16 rows; the 4 NW minima belong to distinct rows, so >= k rows have
-            // S <= Sk := the k-th smallest of them.  d_exact <= L + step*(S + 1.002 M) + slack32 for every row, so the
-            // final k-th distance is <= U = L + step*(Sk + 1.002 M) + slack32, and a row can only be in the top-k if
-            // L + step*(S - 0.04) <= d_real <= U + slack32, i.e. S <= Sk + 1.002 M + 0.04 + 2 slack32 / step.
-            // Without it every row of the first steps is a candidate (16 waves x 16 queries x 64 exact gathers).
+            // Integer seed bound (no separate seed launch): every 16-lane row of every wave takes the per-slot MINIMUM
+            // integer sum S of its 16 rows; the 4 NW minima belong to distinct rows, so >= k rows have S <= Sk := the
+            // k-th smallest of them, and the filter starts at S <= Sk + margin (TileState).  Without it every row of
+            // the first steps passes: the slot buffers overflow into the global lists before the first round.
             constexpr int NG = NW * 4;  // one minimum per 16-lane row of every wave: NG disjoint groups of 16 rows
             if (a.k <= NG) {
                 uint32_t *smin = (uint32_t *)(smem + queue_off);  // [NG][NQ * 4] packed minima (queues are idle)
