@@ -364,3 +364,23 @@ def test_annlite_facade_with_cells(tmp_path):
     assert np.allclose([[m[1] for m in r] for r in res['cells']], [[m[1] for m in r] for r in res['flat']], rtol=1e-5)
     agree = np.mean([len({m for m, _ in a} & {m for m, _ in b}) / 10 for a, b in zip(res['pruned'], res['flat'])])
     assert 0.5 <= agree <= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason='needs an AMD GPU')
+def test_pruned_index_behind_the_row_sharded_wrapper(oracle):
+    """sharded.py: a rank's shard may be an IvfPQGpuIndex -- with pruning active the general (non-packed) path runs
+    and ids come back as global rows (row_base + local offset)."""
+    import torch
+
+    from annlite_amd import Metric, ops
+    from annlite_amd.sharded import ShardedPQIndex
+
+    idx, codec, vq, x = _build(9000, 64, 16, 16, Metric.EUCLIDEAN, seed=23, n_probe=4)
+    _, q = _data(np.random.RandomState(24), 1, 64, 31)
+    qd = ops.to_dev(q, torch.float32)
+    assert idx.search_batch_packed(qd, 10, row_base=0) is None
+    d0, i0 = idx.search_batch(qd, limit=10)
+    d1, i1 = ShardedPQIndex(idx, row_base=5000).search_batch(qd, limit=10)
+    assert torch.equal(d0, d1) and torch.equal(torch.where(i0 >= 0, i0 + 5000, i0), i1)
+    _check_against_oracle(oracle, idx, codec, q, 10, 4, d0.cpu().numpy(), i0.cpu().numpy())
