@@ -13,10 +13,10 @@
 namespace annlite {
 
 // ---- cell selection ------------------------------------------------------------------------------
-// One 256-thread workgroup per QB queries: the query vectors sit in LDS (read by broadcast), thread t owns the
+// One 256-thread workgroup per QB = 4 queries: the query vectors sit in LDS (read by broadcast), thread t owns the
 // centroids t, t + 256, ... and keeps QB running sums while it streams a centroid row ONCE; the QB x C distances
 // go to LDS, where one wave per query picks the P nearest under the fixed order (distance asc, cell asc).
-constexpr int kSelQB = 8;
+constexpr int kSelQB = 4;
 template <int KIND>  // 0: squared L2, 1: negative inner product
 __global__ __launch_bounds__(256) void ivf_select_cells_kernel(const float *__restrict__ q, int B, int D,
                                                               const float *__restrict__ cent, int C, int P,
@@ -36,8 +36,7 @@ __global__ __launch_bounds__(256) void ivf_select_cells_kernel(const float *__re
 #pragma unroll
         for (int u = 0; u < kSelQB; ++u) acc[u] = 0.f;
         const float *cr = cent + (int64_t)c * D;
-        for (int j = 0; j < D; ++j) {  // sequential in j: one defined summation order per (query, cell)
-            const float cv = cr[j];
+        auto step = [&](float cv, int j) {  // sequential in j: one defined summation order per (query, cell)
 #pragma unroll
             for (int u = 0; u < kSelQB; ++u) {
                 const float qv = qs[u * D + j];
@@ -48,6 +47,17 @@ __global__ __launch_bounds__(256) void ivf_select_cells_kernel(const float *__re
                     acc[u] = __builtin_fmaf(cv, qv, acc[u]);
                 }
             }
+        };
+        if ((D & 3) == 0) {
+            for (int j = 0; j < D; j += 4) {  // 16-byte loads of the centroid row (threads are D floats apart)
+                const f32x4 cv = *(const f32x4 *)(cr + j);
+                step(cv.x, j);
+                step(cv.y, j + 1);
+                step(cv.z, j + 2);
+                step(cv.w, j + 3);
+            }
+        } else {
+            for (int j = 0; j < D; ++j) step(cr[j], j);
         }
 #pragma unroll
         for (int u = 0; u < kSelQB; ++u) ds[u * C + c] = KIND == 0 ? acc[u] : -acc[u];
