@@ -229,10 +229,11 @@ __device__ __forceinline__ void merge_tile_slices(const ScanArgs &a, int b0, int
 //     EMITS the rows that still pass to the slot's candidate list in global memory;
 //   * the exact distances of the emitted rows are computed afterwards, per QUERY, by ivf_rescore_kernel (ivf.hip)
 //     with the query's fp32 table in LDS.  A list that overflows is flagged: the re-score pass walks that cell.
-// Filter bound from integers: for ANY k distinct rows of the cell with S <= Sk, d_exact <= L + step*(S + 1.002 M)
-// + slack32 holds for each, so the cell's k-th exact distance is <= U = L + step*(Sk + 1.002 M) + slack32, and a
-// row can be in the top-k only if L + step*(S - 0.04) <= d_real <= U + slack32, i.e.
-//     S <= Sk + margin,  margin = floor(1.002 M + 0.04 + 2 slack32 / step) + 1.
+// Filter bound from integers: every entry satisfies lo + step*(Q - 0.002) <= v <= lo + step*(Q + 1.002), so a row's
+// exact-arithmetic sum is L + step*(S - 0.002 M) <= d_real <= L + step*(S + 1.002 M) and its fp32 sum is within
+// slack32 of d_real.  For ANY k distinct rows of the cell with S <= Sk the cell's k-th fp32 distance is therefore
+// <= U = L + step*(Sk + 1.002 M) + slack32, and a row can be in the top-k only if d_real <= U + slack32, i.e.
+//     S <= Sk + margin,  margin = floor(1.004 M + 2 slack32 / step) + 1.
 // The first Sk of a tile (the "seed") is the k-th smallest of the 4 NW minima over the 16-lane rows of every wave's
 // first 64-row block (4 NW disjoint groups of 16 rows).
 // LDS (on top of the streaming layout): [ccnt u32 x QT][cbuf u64 x QT x CAP] behind the wave queues; the gkl slots
@@ -271,7 +272,7 @@ struct TileState {
         uint32_t mg = 0;
         if (real) {
             const double slack = (double)smax_b * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
-            double x = __builtin_floor(1.002 * M + 0.04 + 2.0 * slack / (double)qstep_b) + 1.0;
+            double x = __builtin_floor(1.004 * M + 2.0 * slack / (double)qstep_b) + 1.0;
             if (!(x < 32767.0)) x = 32767.0;
             mg = (uint32_t)x;
         }

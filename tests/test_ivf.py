@@ -384,3 +384,24 @@ def test_pruned_index_behind_the_row_sharded_wrapper(oracle):
     d1, i1 = ShardedPQIndex(idx, row_base=5000).search_batch(qd, limit=10)
     assert torch.equal(d0, d1) and torch.equal(torch.where(i0 >= 0, i0 + 5000, i0), i1)
     _check_against_oracle(oracle, idx, codec, q, 10, 4, d0.cpu().numpy(), i0.cpu().numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason='needs an AMD GPU')
+@pytest.mark.parametrize('M', [16, 64])
+def test_pruned_search_with_skewed_value_ranges(oracle, M):
+    """One sub-space dominates the table range (coarse integer steps for all others), another is constant (zero
+    range): the integer bound must stay valid -- ids and distances still equal the oracle's."""
+    from annlite_amd import Metric
+
+    rng = np.random.RandomState(31)
+    D = 4 * M
+    x, q = _data(rng, 16000, D, 45)
+    x[:, :4] *= 300.0
+    q[:, :4] *= 300.0
+    x[:, 4:8] = 0.25
+    q[:, 4:8] = 0.25
+    idx, codec, vq, _ = _build(x.shape[0], D, M, 24, Metric.EUCLIDEAN, seed=31, x=x)
+    for P, k in ((3, 10), (23, 5)):
+        d, i = idx.search_batch(q, limit=k, n_probe=P)
+        _check_against_oracle(oracle, idx, codec, q, k, P, d, i)
