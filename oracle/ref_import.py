@@ -79,6 +79,7 @@ def load():
     pq = importlib.import_module('annlite.core.codec.pq')
     ns.PQCodec = pq.PQCodec
     ns.DistanceTable = pq.DistanceTable
+    ns.VQCodec = importlib.import_module('annlite.core.codec.vq').VQCodec
     ns.PQIndex = importlib.import_module('annlite.core.index.pq_index').PQIndex
     ns.FlatIndex = importlib.import_module('annlite.core.index.flat_index').FlatIndex
     ns.HnswIndex = None

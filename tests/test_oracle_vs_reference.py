@@ -58,3 +58,67 @@ def test_live_luts_scan_search(oracle, ref, M, dsub, Ks, N, B):
             assert np.array_equal(np.asarray(rd), d[b].astype(np.float64))
             neq = np.asarray(ri) != i[b]
             assert all((np.asarray(rd) == rd[j]).sum() > 1 for j in np.where(neq)[0])
+
+
+def test_live_cells_vq_selection_and_merge(oracle, ref):
+    """The oracle's restatement of the n_cells > 1 structure against the reference's own pieces: VQCodec.encode
+    (vq.py:78-90), cdist + top_k of _cell_selection (index.py:462-465), per-cell PQIndex.search + the
+    concatenate/argsort merge of CellContainer.ivf_search (container.py:101-138, python loop restated here)."""
+    rs = np.random.RandomState(77)
+    N, D, M, Ks, C, B, k = 6000, 32, 8, 256, 12, 9, 10
+    cent = rs.randn(C, D).astype(np.float32)
+    x = (cent[rs.randint(0, C, N)] + 0.7 * rs.randn(N, D)).astype(np.float32)
+    q = (cent[rs.randint(0, C, B)] + 0.7 * rs.randn(B, D)).astype(np.float32)
+
+    # cell assignment: scipy vq (GEMM expansion) vs the fp32 chain -- any mismatch must be a near tie
+    vq = ref.VQCodec(C, metric=ref.Metric.EUCLIDEAN)
+    vq._codebook = cent
+    vq._is_trained = True
+    want = np.asarray(vq.encode(x))
+    got = oracle.assign_cells(x, cent)
+    d2 = oracle.cell_distances(x, cent, 0)
+    for n in np.nonzero(want != got)[0]:
+        assert abs(d2[n, want[n]] - d2[n, got[n]]) <= 1e-5 * d2[n, got[n]]
+
+    # probe selection: the reference ranks by cdist(..., metric) then top_k; same SETS unless the boundary is a near tie
+    for name, kind, qq, cc in (('euclidean', 0, q, cent),
+                               ('cosine', 1, oracle.l2_normalize(q), oracle.l2_normalize(cent))):
+        dists = ref.math.cdist(q, cent, metric=name)
+        _, rcells = ref.math.top_k(dists, k=4)
+        mine = oracle.select_cells(qq, cc, kind, 4)
+        for b in range(B):
+            if set(rcells[b]) != set(mine[b]):
+                s = np.sort(dists[b])
+                assert abs(s[4] - s[3]) <= 1e-4 * max(abs(s[3]), 1e-6)
+
+    # search: one reference PQIndex per cell, merged the way ivf_search does it
+    cb = rs.rand(M, Ks, D // M).astype(np.float32)
+    codec = ref.PQCodec(dim=D, n_subvectors=M, n_clusters=Ks, metric=ref.Metric.EUCLIDEAN)
+    codec._codebooks = cb
+    codec._is_trained = True
+    codes = oracle.encode_c(x, cb)
+    cells_of = got
+    per_cell, offsets = {}, {}
+    for c in range(C):
+        rows = np.nonzero(cells_of == c)[0]
+        offsets[c] = rows
+        idx = ref.PQIndex(D, codec, initial_size=max(len(rows), 1))
+        if len(rows):
+            idx.add_with_ids(x[rows], np.arange(len(rows)))
+        per_cell[c] = idx
+    probe = oracle.select_cells(q, cent, 0, 4)
+    od, oi = oracle.ivf_search(q, cb, codes, cells_of, probe, oracle.EUCLIDEAN, k, sqrt_euclidean=False)
+    for b in range(B):
+        ds, ids = [], []
+        for c in probe[b]:
+            n_c = len(offsets[c])
+            if n_c == 0:
+                continue
+            dd, ii = per_cell[c].search(q[b], limit=min(k, n_c))
+            ds.append(np.asarray(dd, dtype=np.float32))
+            ids.append(offsets[c][np.asarray(ii)])
+        ds, ids = np.concatenate(ds), np.concatenate(ids)
+        order = np.lexsort((ids, ds))[:k]  # ivf_search: argsort of the concatenation (ties: the build's id order)
+        assert np.array_equal(ds[order], od[b])
+        neq = ids[order] != oi[b]
+        assert all((ds == ds[order][j]).sum() > 1 for j in np.where(neq)[0])
