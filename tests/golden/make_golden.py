@@ -131,10 +131,64 @@ def make_case(ref, name, M, dsub, Ks, N, B, seed):
     print('%-16s -> %s  (%.1f KB)' % (name, os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
 
 
+def make_cells_case(ref, name='cells_m16_d64', M=16, dsub=4, Ks=256, N=4000, B=8, C=12, P=4, seed=201):
+    """n_cells > 1 structure (tests/golden/cells/*.npz): VQCodec.encode (vq.py:78-90), cdist + top_k of
+    _cell_selection (index.py:462-465), one reference PQIndex per cell and the concatenate + argsort merge of
+    CellContainer.ivf_search (container.py:101-138; its python loop is restated here, the early-skip of lines
+    120-121 left out -- it is a shortcut, not a result)."""
+    rs = np.random.RandomState(seed)
+    D = M * dsub
+    centroids = rs.randn(C, D).astype(np.float32)
+    x = (centroids[rs.randint(0, C, N)] + 0.7 * rs.randn(N, D)).astype(np.float32)
+    queries = (centroids[rs.randint(0, C, B)] + 0.7 * rs.randn(B, D)).astype(np.float32)
+    codebooks = np.empty((M, Ks, dsub), dtype=np.float32)
+    for m in range(M):
+        codebooks[m] = x[rs.choice(N, size=Ks, replace=False), m * dsub:(m + 1) * dsub]
+    vq = ref.VQCodec(C, metric=ref.Metric.EUCLIDEAN)
+    vq._codebook = centroids
+    vq._is_trained = True
+    cells_of = np.asarray(vq.encode(x)).astype(np.int32)
+    out = dict(centroids=centroids, x=x, queries=queries, codebooks=codebooks, cells_of=cells_of,
+               meta=np.array([M, dsub, Ks, N, B, C, P, K, seed], dtype=np.int64))
+    for metric in ('euclidean', 'cosine'):
+        dists = ref.math.cdist(queries, centroids, metric=metric)
+        out['cdist_' + metric] = np.asarray(dists, dtype=np.float64)
+        out['probe_' + metric] = np.asarray(ref.math.top_k(dists, k=P)[1], dtype=np.int32)
+    codec = ref.PQCodec(dim=D, n_subvectors=M, n_clusters=Ks, metric=ref.Metric.EUCLIDEAN)
+    codec._codebooks = codebooks
+    codec._is_trained = True
+    out['codes'] = codec.encode(x)
+    per_cell, rows_of = {}, {}
+    for c in range(C):
+        rows = np.nonzero(cells_of == c)[0]
+        rows_of[c] = rows
+        per_cell[c] = ref.PQIndex(D, codec, initial_size=max(len(rows), 1))
+        if len(rows):
+            per_cell[c].add_with_ids(x[rows], np.arange(len(rows)))
+    md, mi = np.full((B, K), np.inf, np.float32), np.full((B, K), -1, np.int64)
+    for b in range(B):
+        ds, ids = [], []
+        for c in out['probe_euclidean'][b]:
+            if len(rows_of[c]) == 0:
+                continue
+            dd, ii = per_cell[c].search(queries[b], limit=min(K, len(rows_of[c])))
+            ds.append(np.asarray(dd, dtype=np.float32))
+            ids.append(rows_of[c][np.asarray(ii)])
+        ds, ids = np.concatenate(ds), np.concatenate(ids)
+        order = ds.argsort(axis=0)[:K]
+        md[b, :len(order)], mi[b, :len(order)] = ds[order], ids[order]
+    out['merged_d'], out['merged_i'] = md, mi  # raw ADC sums (PQIndex returns no sqrt)
+    os.makedirs(os.path.join(HERE, 'cells'), exist_ok=True)
+    path = os.path.join(HERE, 'cells', name + '.npz')
+    np.savez_compressed(path, **out)
+    print('%-16s -> %s  (%.1f KB)' % (name, os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
+
+
 def main():
     ref = ref_import.load()
     for name, spec in CASES.items():
         make_case(ref, name, *spec)
+    make_cells_case(ref)
 
 
 if __name__ == '__main__':
