@@ -137,6 +137,8 @@ class AnnLite:
         self._id2offset: Dict[str, int] = {}
         self._tags: List[Optional[dict]] = []
         self._docs: Dict[str, object] = {}
+        if self.is_trained and self.snapshot_path is not None:  # index.py:194-195: restore what `dump()` left
+            self._rebuild_index_from_local()
 
     def _new_index(self) -> PQFlatGpuIndex:
         """The per-cell vector index (container.py:48-59 builds ``HnswIndex(...)`` there).  Default: the exhaustive
@@ -237,6 +239,59 @@ class AnnLite:
         self._pq_codec.dump(self._pq_codec_path)
         if self._vq_codec is not None:
             self._vq_codec.dump(self._vq_codec_path)  # index.py:684-685
+
+    # ------------------------------------------------------------------ snapshots (index.py:600-637, 689-714, 769-777)
+    @property
+    def index_path(self) -> Path:
+        import datetime
+
+        stamp = datetime.datetime.utcnow().isoformat('#', 'seconds')
+        return self.data_path / f'snapshot-{self.params_hash}' / f'{stamp}-SNAPSHOT'
+
+    @property
+    def snapshot_path(self) -> Optional[Path]:
+        paths = sorted((self.data_path / f'snapshot-{self.params_hash}').glob('*-SNAPSHOT'), key=lambda x: x.name)
+        return paths[-1] if paths else None
+
+    def dump_index(self):
+        """index.py:689-710: ``cell_0.hnsw`` = the vector index (own format: codes, validity, cells / graph / float
+        vectors where present), ``cell_0.db`` = the offset <-> document table (in-memory store, pickled)."""
+        import pickle
+        import shutil
+
+        path = self.index_path
+        logger.info(f'Save the indexer to {path}')
+        try:
+            if path.exists():
+                shutil.rmtree(path)
+            path.mkdir(parents=True)
+            self.vec_index(0).dump(path / 'cell_0.hnsw')
+            with open(path / 'cell_0.db', 'wb') as f:
+                pickle.dump({'offset2id': self._offset2id, 'tags': self._tags, 'docs': self._docs}, f, protocol=4)
+        except Exception as ex:
+            logger.error(f'Failed to dump the indexer, {ex!r}')
+            if path.exists():
+                shutil.rmtree(path)
+            raise
+
+    def dump(self):
+        self.dump_model()
+        self.dump_index()
+
+    def _rebuild_index_from_local(self):
+        import pickle
+
+        snap = self.snapshot_path
+        logger.info(f'Load the indexer from snapshot {snap}')
+        self.vec_index(0).load(snap / 'cell_0.hnsw')
+        with open(snap / 'cell_0.db', 'rb') as f:
+            st = pickle.load(f)
+        self._offset2id, self._tags, self._docs = st['offset2id'], st['tags'], st['docs']
+        self._id2offset = {d: o for o, d in enumerate(self._offset2id) if d is not None}
+
+    def restore(self):
+        if self.snapshot_path is not None:
+            self._rebuild_index_from_local()
 
     # ------------------------------------------------------------------ index / update / delete
     def index(self, docs, **kwargs):

@@ -477,3 +477,32 @@ def test_gpu_cells_against_reference_fixture():
         assert np.array_equal(np.sqrt(g['merged_d'][b]), d[b])  # hnsw/index.py:164-165: sqrt for EUCLIDEAN
         assert _same_outside_ties(i[b], g['merged_i'][b], d[b])
     assert sum(same_probe) >= g['B'] - 1
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason='needs an AMD GPU')
+@pytest.mark.parametrize('kw', [{}, dict(n_cells=6, n_probe=2, ivf_prune=True), dict(graph=True)], ids=['flat', 'cells', 'graph'])
+def test_annlite_dump_and_reopen(tmp_path, kw):
+    """index.py:689-714 / 769-777: ``dump()`` writes the codecs and a snapshot; a new AnnLite over the same
+    data_path comes back trained, with its documents, and answers the same."""
+    from annlite_amd import AnnLite
+    from annlite_amd.docarray_compat import Document, DocumentArray
+
+    rs = np.random.RandomState(41)
+    N, D = 3000, 64
+    x, q = _data(rs, N, D, 12)
+    ann = AnnLite(D, metric='euclidean', n_subvectors=8, data_path=str(tmp_path / 'idx'), **kw)
+    ann.train(x[:2048])
+    ann.index(DocumentArray([Document(id=str(i), embedding=x[i], tags={'parity': i % 2}) for i in range(N)]))
+    ann.delete(['5', '6'])
+    d0, i0 = ann.search_numpy(q, limit=10)
+    f0 = ann.search_numpy(q, filter={'parity': {'$eq': 1}}, limit=5)
+    assert ann.snapshot_path is None
+    ann.dump()
+    again = AnnLite(D, metric='euclidean', n_subvectors=8, data_path=str(tmp_path / 'idx'), **kw)
+    assert again.is_trained and again.total_docs == N - 2 and again.index_size == ann.index_size
+    d1, i1 = again.search_numpy(q, limit=10)
+    assert all(np.array_equal(a, b) for a, b in zip(i0, i1)) and all(np.array_equal(a, b) for a, b in zip(d0, d1))
+    f1 = again.search_numpy(q, filter={'parity': {'$eq': 1}}, limit=5)
+    assert all(np.array_equal(a, b) for a, b in zip(f0[1], f1[1]))
+    assert again.get_doc_by_id('7').tags['parity'] == 1 and again.get_doc_by_id('5') is None
