@@ -422,6 +422,28 @@ class AnnLite:
     def get_doc_by_id(self, doc_id: str):
         return self._docs.get(doc_id)
 
+    def filter(self, filter: Optional[dict], limit: int = 10, offset: int = 0, order_by: Optional[str] = None,
+               ascending: bool = True, include_metadata: bool = True):
+        """index.py:389-423 -> CellContainer.filter_cells (container.py:146-199): the documents whose tags satisfy
+        the filter, in insertion order or ordered by a tag, ``offset`` skipped, at most ``limit`` (<= 0: all)."""
+        offs = _filter_select(self._tags, filter or {})
+        if order_by:
+            offs = sorted(offs, key=lambda o: self._tags[o].get(order_by), reverse=not ascending)
+        offs = offs[offset:]
+        if limit > 0:
+            offs = offs[:limit]
+        out = DocumentArray()
+        for o in offs:
+            doc_id = self._offset2id[o]
+            out.append(self._docs[doc_id] if include_metadata else Document(id=doc_id))
+        return out
+
+    def get_docs(self, filter: Optional[dict] = None, limit: int = 10, offset: int = 0, order_by: Optional[str] = None,
+                 ascending: bool = True):
+        """index.py:433-456"""
+        return self.filter(filter=filter, limit=limit, offset=offset, order_by=order_by, ascending=ascending,
+                           include_metadata=True)
+
     # ------------------------------------------------------------------ codec passthrough (index.py:552-572)
     def encode(self, x):
         self._sanity_check(x)

@@ -106,3 +106,24 @@ def test_no_gpu_means_loud_failure():
     c = PQCodec(dim=8, n_subvectors=2, n_clusters=4).set_codebooks(np.zeros((2, 4, 4), np.float32))
     with pytest.raises(RuntimeError):
         c.encode(np.zeros((3, 8), np.float32))
+
+
+def test_annlite_filter_and_get_docs_host_logic(tmp_path):
+    """index.py:389-456: document filtering without a vector search (host-side table only, no GPU)."""
+    from annlite_amd import AnnLite
+    from annlite_amd.index import Document
+
+    ann = AnnLite(64, n_subvectors=8, data_path=tmp_path / 'f')
+    for i in range(10):  # fill the in-memory table the way index() does
+        d = Document(id=str(i), embedding=np.zeros(64, np.float32), tags={'price': 10 - i, 'cat': i % 3})
+        ann._offset2id.append(d.id)
+        ann._id2offset[d.id] = i
+        ann._tags.append(dict(d.tags))
+        ann._docs[d.id] = d
+    got = ann.filter({'cat': {'$eq': 1}}, limit=10)
+    assert [d.id for d in got] == ['1', '4', '7']
+    got = ann.filter({'price': {'$gte': 5}}, limit=2, offset=1, order_by='price', ascending=True)
+    assert [d.id for d in got] == ['4', '3']  # prices 5,6,7,.. -> ids 5,4,3: skip one, take two
+    assert [d.id for d in ann.get_docs(limit=3)] == ['0', '1', '2']
+    assert len(ann.get_docs(limit=-1)) == 10
+    assert [d.id for d in ann.filter({}, limit=2, order_by='price', ascending=False, include_metadata=False)] == ['0', '1']
