@@ -132,6 +132,21 @@ def main():
         cnt = count[vmap >= 0].to(torch.int64)
         st['cand_per_slot_mean_max_overflow'] = [float(cnt[cnt >= 0].float().mean().item()), int(cnt.max().item()),
                                                  int((cnt < 0).sum().item())]
+        # throughput with consecutive batches alternating between two streams (one batch's single-workgroup plan /
+        # selection / re-score launches run beside the other's tile scan)
+        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        for st_ in streams:
+            st_.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(st_):
+                idx.search_batch(queries, limit=k, n_probe=P)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for it in range(2 * args.reps):
+            with torch.cuda.stream(streams[it & 1]):
+                idx.search_batch(queries, limit=k, n_probe=P)
+        torch.cuda.synchronize()
+        ms2 = (time.perf_counter() - t0) / (2 * args.reps) * 1e3
+        st['two_streams_ms_per_batch'] = ms2
         rec = {'n_probe': P, 'ms': ms, 'qps': B / ms * 1e3, 'tiles_used': int(used.item()), 'slots': int(vmap.numel()),
                'recall_vs_exhaustive_adc': recall(r[1], adc_truth),
                'recall_vs_exact': recall(r[1], truth) if idx._vectors is not None else None, 'stages_ms': st}
