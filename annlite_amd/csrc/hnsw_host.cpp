@@ -162,6 +162,17 @@ struct annlite_hnsw {
         }
         for (; i < n; ++i) out[i] = adc(lut, nodes[i]);
     }
+    // is sym(a, b) < bound ?  All terms are >= 0 and fp32 sums of non-negative terms never decrease, so the sum can be
+    // abandoned as soon as a partial sum reaches the bound: same answer as the full sum, most pairs stop after a few terms
+    inline bool sym_below(uint32_t a, uint32_t b, float bound) const {
+        const uint8_t *ca = codes.data() + (size_t)a * M, *cbp = codes.data() + (size_t)b * M;
+        float r = 0.f;
+        for (int64_t m = 0; m < M; ++m) {
+            r += sdc[((size_t)m * Ks + ca[m]) * Ks + cbp[m]];
+            if (!(r < bound)) return false;
+        }
+        return true;
+    }
     inline float sym(uint32_t a, uint32_t b) const {
         const uint8_t *ca = codes.data() + (size_t)a * M, *cbp = codes.data() + (size_t)b * M;
         float r = 0.f;
@@ -289,7 +300,7 @@ struct annlite_hnsw {
             const float to_base = sym(base, c.second);
             bool good = true;
             for (const Cand &k : keep)
-                if (sym(k.second, c.second) < to_base) {
+                if (sym_below(k.second, c.second, to_base)) {
                     good = false;
                     break;
                 }
@@ -343,6 +354,7 @@ struct annlite_hnsw {
         uint32_t ep = (uint32_t)ep0;
         float ep_d = adc(lut, ep);
         std::vector<uint32_t> nb;
+        std::vector<float> hop;
         for (int l = ml; l > lv; --l) {  // greedy descent
             bool changed = true;
             while (changed) {
@@ -351,11 +363,13 @@ struct annlite_hnsw {
                 const uint32_t *ll = links(ep, l);
                 nb.assign(ll + 1, ll + 1 + ll[0]);
                 locks[ep].unlock();
-                for (uint32_t v : nb) {
-                    const float d = adc(lut, v);
-                    if (d < ep_d) {
-                        ep_d = d;
-                        ep = v;
+                for (uint32_t v : nb) __builtin_prefetch(codes.data() + (size_t)v * M);
+                hop.resize(nb.size());
+                adc_many(lut, nb.data(), nb.size(), hop.data());
+                for (size_t i = 0; i < nb.size(); ++i) {
+                    if (hop[i] < ep_d) {
+                        ep_d = hop[i];
+                        ep = nb[i];
                         changed = true;
                     }
                 }
