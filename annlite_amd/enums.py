@@ -1,27 +1,25 @@
-"""Metric / ExpandMode enums -- same names and integer values as the reference
-(annlite/enums.py:4-34); the integers double as the C ABI metric ids (include/annlite_hip.h)."""
-from enum import IntEnum
+"""``Metric`` and ``ExpandMode``: the names and integer values the reference uses (annlite/enums.py) -- the
+integers are also the metric ids of the C ABI (``ANNLITE_METRIC_*`` in include/annlite_hip.h), so a ``Metric``
+can be handed to the library as is."""
+import enum
 
 
-class BetterEnum(IntEnum):
-    def __str__(self):
+class _ByName(enum.IntEnum):
+    """Integer enum that prints as its bare member name and can be looked up by a case-insensitive name."""
+
+    def __str__(self) -> str:
         return self.name
 
     @classmethod
     def from_string(cls, s: str):
-        try:
-            return cls[s.upper()]
-        except KeyError:
-            raise ValueError(f'{s.upper()} is not a valid enum for {cls!r}, must be one of {list(cls)}')
+        key = str(s).strip().upper()
+        member = cls.__members__.get(key)
+        if member is None:
+            raise ValueError(f'{key} is not a valid enum for {cls!r}, must be one of {list(cls)}')
+        return member
 
 
-class Metric(BetterEnum):
-    EUCLIDEAN = 1
-    INNER_PRODUCT = 2
-    COSINE = 3
-
-
-class ExpandMode(BetterEnum):
-    STEP = 1
-    DOUBLE = 2
-    ADAPTIVE = 3
+# (functional API; `module` keeps the members picklable -- codecs are pickled with their metric)
+Metric = _ByName('Metric', (('EUCLIDEAN', 1), ('INNER_PRODUCT', 2), ('COSINE', 3)), module=__name__)
+ExpandMode = _ByName('ExpandMode', (('STEP', 1), ('DOUBLE', 2), ('ADAPTIVE', 3)), module=__name__)
+BetterEnum = _ByName  # the reference's name of the base
