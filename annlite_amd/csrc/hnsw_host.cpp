@@ -433,8 +433,8 @@ int64_t annlite_hnsw_size(const annlite_hnsw *g) { return g ? g->n.load() : 0; }
 
 int annlite_hnsw_reserve(annlite_hnsw *g, int64_t capacity) {
     if (!g || capacity < g->cap) return 0;
-    if (capacity >= (int64_t)1 << 32) {
-        set_error("capacity must be < 2^32");
+    if (capacity >= (int64_t)1 << 31) {  // (bit 31 of a node id is the beam's "expanded" flag)
+        set_error("capacity must be < 2^31");
         return 1;
     }
     g->codes.resize((size_t)capacity * g->M);
