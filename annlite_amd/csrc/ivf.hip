@@ -83,7 +83,9 @@ __global__ __launch_bounds__(256) void ivf_select_cells_kernel(const float *__re
                 const int oi = __shfl_xor(bi, o);
                 if (ov < best || (ov == best && oi < bi)) best = ov, bi = oi;
             }
-            if (lane == 0) cells[(int64_t)(b0 + u) * P + p] = bi;
+            // (a query with NaN / inf components finds no minimum: fall back to cell p so that the plan never sees an
+            // out-of-range cell -- the results of such a query are meaningless either way)
+            if (lane == 0) cells[(int64_t)(b0 + u) * P + p] = bi < C ? bi : p;
             if (bi < C && lane == (bi & 63)) row[bi] = __builtin_inff();  // taken (LDS ops of a wave execute in order)
         }
     }
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *__restric
         tile_rows[2 * i + 1] = -1;
     }
     __syncthreads();
-    for (int i = tid; i < n_pairs; i += 1024) slot_of[i] = atomicAdd(&cnt[cells[i]], 1);  // rank inside the cell
+    for (int i = tid; i < n_pairs; i += 1024) slot_of[i] = atomicAdd(&cnt[(unsigned)cells[i] < (unsigned)C ? cells[i] : 0], 1);  // rank inside the cell
     __syncthreads();
     // exclusive scan of the tile counts in `order`; thread t owns positions [t*per, (t+1)*per)
     const int per = (C + 1023) / 1024;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *__restric
     __syncthreads();
     for (int i = tid; i < n_pairs; i += 1024) {
         const int r = slot_of[i];
-        const int v = (tstart[cells[i]] + r / qt) * qt + r % qt;
+        const int v = (tstart[(unsigned)cells[i] < (unsigned)C ? cells[i] : 0] + r / qt) * qt + r % qt;
         slot_of[i] = v;
         vmap[v] = i / P;
     }
