@@ -127,3 +127,36 @@ def test_annlite_filter_and_get_docs_host_logic(tmp_path):
     assert [d.id for d in ann.get_docs(limit=3)] == ['0', '1', '2']
     assert len(ann.get_docs(limit=-1)) == 10
     assert [d.id for d in ann.filter({}, limit=2, order_by='price', ascending=False, include_metadata=False)] == ['0', '1']
+
+
+def test_filter_grammar_of_the_reference():
+    """tests/test_filter.py:12-110 restated on documents instead of SQL strings: logic operators with dict and
+    list operands, several operators on one field, membership, field-level $or, unsupported operators."""
+    from annlite_amd.filter import match, select
+
+    docs = [{'brand': 0, 'price': 60}, {'brand': 2, 'price': 60}, {'brand': 0, 'price': 10}, {'brand': 5, 'price': 5}, {'price': 70}]
+    assert select(docs, {}) == [0, 1, 2, 3, 4]                                            # test_empty_filter
+    assert select(docs, {'brand': {'$lt': 1}}) == [0, 2]                                  # test_simple_filter (NULL: no)
+    both = [0]
+    assert select(docs, {'$and': {'brand': {'$lt': 1}, 'price': {'$gte': 50}}}) == both   # test_logic_operator
+    assert select(docs, {'brand': {'$lt': 1}, 'price': {'$gte': 50}}) == both
+    assert select(docs, {'$or': {'brand': {'$lt': 1}, 'price': {'$gte': 50}}}) == [0, 1, 2, 4]
+    shoes = [{'brand': 'Nike', 'price': 40}, {'brand': 'Gucci', 'price': 90}, {'brand': 'Puma', 'price': 20}, {'brand': 'Puma', 'price': 55}]
+    assert select(shoes, {'$and': {'brand': {'$in': ['Nike', 'Gucci']}, 'price': {'$gte': 50}}}) == [1]   # test_membership_operator
+    assert select(shoes, {'$or': {'brand': {'$nin': ['Nike', 'Gucci']}, 'price': {'$gte': 50}}}) == [1, 2, 3]
+    cars = [{'price': 30, 'rating': 2, 'year': 2008}, {'price': 60, 'rating': 2, 'year': 2008}, {'price': 30, 'rating': 0, 'year': 2008},
+            {'price': 30, 'rating': 2, 'year': 2012}]
+    rng = {'$and': {'price': {'$gte': 0, '$lte': 54}, 'rating': {'$gte': 1}, 'year': {'$gte': 2007, '$lte': 2010}}}
+    assert select(cars, rng) == [0]                                                       # test_cases
+    either = {'$and': {'price': {'$or': [{'price': {'$gte': 55}}, {'price': {'$lte': 20}}]}, 'rating': {'$gte': 1},
+                       'year': {'$gte': 2007, '$lte': 2010}}}
+    assert select(cars, either) == [1]
+    either2 = {'$and': {'$or': [{'price': {'$gte': 55}}, {'price': {'$lte': 20}}], 'rating': {'$gte': 1}, 'year': {'$gte': 2007, '$lte': 2010}}}
+    assert select(cars, either2) == [1]
+    with pytest.raises(ValueError):                                                       # test_error_filter
+        select(cars, {'$may': {'brand': {'$lt': 1}, 'price': {'$gte': 50}}})
+    with pytest.raises(ValueError):
+        match(cars[0], {'price': {'$between': [1, 2]}})
+    assert not match({}, {'price': {'$neq': 3}}) and not match({}, {'price': {'$nin': [3]}})  # NULL satisfies nothing
+    # SQL precedence of the flat clause: a AND b OR c
+    assert match({'a': 0, 'b': 0, 'c': 1}, {'a': {'$eq': 1}, 'b': {'$eq': 1}, '$or': {'c': {'$eq': 1}}})

@@ -122,3 +122,56 @@ def test_live_cells_vq_selection_and_merge(oracle, ref):
         assert np.array_equal(ds[order], od[b])
         neq = ids[order] != oi[b]
         assert all((ds == ds[order][j]).sum() > 1 for j in np.where(neq)[0])
+
+
+def test_live_filter_semantics_match_reference_sql(ref):
+    """annlite_amd.filter evaluates the filter grammar in memory; the reference compiles it to SQL
+    (annlite/filter.py) and lets SQLite select the offsets (storage/table.py).  Same offsets for every filter,
+    documents with missing tags (NULL) included."""
+    import importlib
+    import sqlite3
+
+    from annlite_amd.filter import select
+
+    Filter = importlib.import_module('annlite.filter').Filter
+    rs = np.random.RandomState(5)
+    brands = ['Nike', 'Gucci', 'Puma', 'Asics']
+    tags = []
+    for i in range(400):
+        t = {'price': int(rs.randint(0, 100)), 'rating': float(np.round(rs.rand() * 5, 2)), 'year': int(rs.randint(2000, 2015)),
+             'brand': brands[rs.randint(0, 4)]}
+        for key in list(t):
+            if rs.rand() < 0.1:
+                del t[key]  # NULL in the table
+        tags.append(t)
+    con = sqlite3.connect(':memory:')
+    con.execute('CREATE TABLE t (_id INTEGER PRIMARY KEY, price INTEGER, rating FLOAT, year INTEGER, brand TEXT)')
+    con.executemany('INSERT INTO t VALUES (?, ?, ?, ?, ?)',
+                    [(i, t.get('price'), t.get('rating'), t.get('year'), t.get('brand')) for i, t in enumerate(tags)])
+    filters = [
+        {},
+        {'brand': {'$eq': 'Nike'}},
+        {'price': {'$lt': 30}},
+        {'price': {'$neq': 30}},
+        {'brand': {'$lt': 'O'}, 'price': {'$gte': 50}},
+        {'$and': {'brand': {'$eq': 'Puma'}, 'price': {'$gte': 50}}},
+        {'$or': {'brand': {'$eq': 'Puma'}, 'price': {'$gte': 90}}},
+        {'$and': {'brand': {'$in': ['Nike', 'Gucci']}, 'price': {'$gte': 50}}},
+        {'$or': {'brand': {'$nin': ['Nike', 'Gucci']}, 'price': {'$gte': 50}}},
+        {'$and': {'price': {'$gte': 0, '$lte': 54}, 'rating': {'$gte': 1}, 'year': {'$gte': 2007, '$lte': 2010}}},
+        {'$and': {'price': {'$or': [{'price': {'$gte': 80}}, {'price': {'$lte': 20}}]}, 'rating': {'$gte': 1},
+                  'year': {'$gte': 2007, '$lte': 2010}}},
+        {'$and': {'$or': [{'price': {'$gte': 80}}, {'price': {'$lte': 20}}], 'rating': {'$gte': 1}}},
+        {'rating': {'$gt': 2.5}, '$or': {'brand': {'$eq': 'Asics'}, 'year': {'$lt': 2003}}},   # AND binds tighter than OR
+        {'$or': {'brand': {'$eq': 'Asics'}, 'year': {'$lt': 2003}}, 'rating': {'$gt': 2.5}},
+        {'$or': [{'price': {'$lt': 10}}, {'brand': {'$eq': 'Nike'}, 'rating': {'$gte': 4}}]},
+    ]
+    for flt in filters:
+        where, params = Filter(flt).parse_where_clause()
+        sql = 'SELECT _id FROM t' + (f' WHERE {where}' if where else '') + ' ORDER BY _id'
+        want = [r[0] for r in con.execute(sql, params)]
+        assert select(tags, flt) == want, flt
+    with pytest.raises(ValueError):
+        select(tags, {'$may': {'brand': {'$lt': 1}}})
+    with pytest.raises(ValueError):
+        Filter({'$may': {'brand': {'$lt': 1}}}).parse_where_clause()
