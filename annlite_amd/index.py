@@ -328,8 +328,10 @@ class AnnLite:
             if d.id in self._id2offset:
                 self.delete([d.id])
                 new_docs.append(d)
-            elif raise_errors_on_not_found:
+            elif raise_errors_on_not_found and not insert_if_not_found:  # container.py:349-365
                 raise Exception(f'The document (id={d.id}) cannot be updated as it is not found in the index')
+            elif not (raise_errors_on_not_found or insert_if_not_found):
+                warnings.warn(f'The document (id={d.id}) cannot be updated as it is not found in the index', RuntimeWarning)
             elif insert_if_not_found:
                 new_docs.append(d)
         if len(new_docs):

@@ -160,3 +160,23 @@ def test_filter_grammar_of_the_reference():
     assert not match({}, {'price': {'$neq': 3}}) and not match({}, {'price': {'$nin': [3]}})  # NULL satisfies nothing
     # SQL precedence of the flat clause: a AND b OR c
     assert match({'a': 0, 'b': 0, 'c': 1}, {'a': {'$eq': 1}, 'b': {'$eq': 1}, '$or': {'c': {'$eq': 1}}})
+
+
+def test_update_and_delete_of_unknown_documents(tmp_path):
+    """tests/test_crud.py:66-105: what update / delete do with ids the index does not hold (container.py:349-365,
+    389-405) -- decided on the host before anything reaches the GPU."""
+    from annlite_amd import AnnLite
+    from annlite_amd.index import Document, DocumentArray
+
+    ann = AnnLite(64, n_subvectors=8, data_path=tmp_path / 'u')
+    ann._pq_codec._is_trained = True  # (host logic only: nothing below touches the codebooks)
+    ghosts = DocumentArray([Document(id=f'{i}_wrong', embedding=np.zeros(64, np.float32)) for i in range(3)])
+    with pytest.raises(Exception):
+        ann.update(ghosts, raise_errors_on_not_found=True, insert_if_not_found=False)
+    with pytest.warns(RuntimeWarning):
+        ann.update(ghosts, raise_errors_on_not_found=False, insert_if_not_found=False)
+    assert ann.total_docs == 0
+    with pytest.raises(Exception):
+        ann.delete(ghosts, raise_errors_on_not_found=True)
+    ann.delete(ghosts)  # silently ignored
+    ann.delete(['nope'])
