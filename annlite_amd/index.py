@@ -292,8 +292,19 @@ class AnnLite:
         self._offset2id, self._tags, self._docs = st['offset2id'], st['tags'], st['docs']
         self._id2offset = {d: o for o, d in enumerate(self._offset2id) if d is not None}
 
-    def restore(self):
+    def backup(self, target_name: Optional[str] = None, token: Optional[str] = None):
+        """index.py:652-664: local backup = ``dump()``; the remote (hub) target is outside this tier."""
+        if target_name:
+            raise NotImplementedError('remote backup (Jina hub artifacts) is out of scope (SURVEY.md section 2 row 22)')
+        logger.info('dump to local ...')
+        self.dump()
+
+    def restore(self, source_name: Optional[str] = None, token: Optional[str] = None):
+        """index.py:666-677"""
+        if source_name:
+            raise NotImplementedError('remote restore (Jina hub artifacts) is out of scope (SURVEY.md section 2 row 22)')
         if self.snapshot_path is not None:
+            logger.info('restore Annlite from local')
             self._rebuild_index_from_local()
 
     # ------------------------------------------------------------------ index / update / delete
