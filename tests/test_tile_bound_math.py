@@ -63,3 +63,35 @@ def test_no_top_k_row_exceeds_the_integer_bound(M, shape):
         top = np.lexsort((np.arange(N), d))[:kk]
         Sk = np.sort(S)[kk - 1]
         assert S[top].max() <= Sk + margin, (M, shape, trial, int(S[top].max()), int(Sk), margin)
+
+
+@pytest.mark.parametrize('M', [8, 16, 32, 64])
+def test_streaming_filter_bound(M):
+    """The exhaustive kernels' bound (scan_common.h `qbound_from_key`): a row whose exact fp32 distance is <= thr has
+    S <= floor((thr + slack32 - L) / step) + 1 with L = sum_m lo_m in double -- no row at or below the k-th distance is
+    filtered out, whatever the table's scale."""
+    rs = np.random.RandomState(1000 + M)
+    Ks = 256
+    for trial in range(12):
+        N = int(rs.choice([500, 5000, 30000]))
+        k = int(rs.choice([1, 10, 64]))
+        lut = (rs.rand(M, Ks).astype(np.float32) ** 2) * np.float32(rs.choice([1e-3, 1.0, 1e4]))
+        if trial % 3 == 1:
+            lut[rs.randint(M)] *= np.float32(1e4)
+        if trial % 3 == 2:
+            lut = (np.float32(1.0 / Ks) - (rs.randn(M, Ks) * 0.3).astype(np.float32)).astype(np.float32)
+        codes = rs.randint(0, Ks, size=(N, M))
+        Q, step, _ = _quantise(lut)
+        S = Q[np.arange(M)[None, :], codes].sum(axis=1)
+        d = _exact_sums(lut, codes)
+        thr = np.sort(d)[min(k, N) - 1]
+        lo = lut.min(axis=1).astype(np.float32)
+        hi = lut.max(axis=1).astype(np.float32)
+        smax = np.float32(0)
+        for m in range(M):
+            smax = np.float32(smax + np.maximum(np.abs(lo[m]), np.abs(hi[m])))
+        slack = float(smax) * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0))
+        L = float(np.sum(lo.astype(np.float64)))
+        qthr = np.floor((float(thr) + slack - L) / float(step)) + 1.0
+        qthr = min(max(qthr, 0.0), 32767.0)
+        assert S[d <= thr].max() <= qthr, (M, trial)
