@@ -175,3 +175,62 @@ def test_live_filter_semantics_match_reference_sql(ref):
         select(tags, {'$may': {'brand': {'$lt': 1}}})
     with pytest.raises(ValueError):
         Filter({'$may': {'brand': {'$lt': 1}}}).parse_where_clause()
+
+
+def test_live_filter_fuzz_against_reference_sql(ref):
+    """random filters from the grammar (nested dict / list logic, several operators per field, field-level logic):
+    same offsets as the reference's SQL on SQLite"""
+    import importlib
+    import sqlite3
+
+    from annlite_amd.filter import select
+
+    Filter = importlib.import_module('annlite.filter').Filter
+    rs = np.random.RandomState(11)
+    tags = []
+    for i in range(300):
+        t = {'a': int(rs.randint(0, 10)), 'b': int(rs.randint(0, 10)), 'c': ['x', 'y', 'z'][rs.randint(0, 3)]}
+        for key in list(t):
+            if rs.rand() < 0.15:
+                del t[key]
+        tags.append(t)
+    con = sqlite3.connect(':memory:')
+    con.execute('CREATE TABLE t (_id INTEGER PRIMARY KEY, a INTEGER, b INTEGER, c TEXT)')
+    con.executemany('INSERT INTO t VALUES (?, ?, ?, ?)', [(i, t.get('a'), t.get('b'), t.get('c')) for i, t in enumerate(tags)])
+
+    def leaf():
+        f = ['a', 'b', 'c'][rs.randint(0, 3)]
+        if f == 'c':
+            op = ['$eq', '$neq', '$in', '$nin'][rs.randint(0, 4)]
+            val = ['x', 'y'][: rs.randint(1, 3)] if op in ('$in', '$nin') else ['x', 'y', 'z'][rs.randint(0, 3)]
+            return {f: {op: val}}
+        ops = {}
+        for _ in range(rs.randint(1, 3)):
+            op = ['$lt', '$gt', '$lte', '$gte', '$eq', '$neq', '$in', '$nin'][rs.randint(0, 8)]
+            ops[op] = [int(v) for v in rs.randint(0, 10, size=rs.randint(1, 4))] if op in ('$in', '$nin') else int(rs.randint(0, 10))
+        return {f: ops}
+
+    def node(depth):
+        r = rs.rand()
+        if depth == 0 or r < 0.3:
+            return leaf()
+        logic = ['$and', '$or'][rs.randint(0, 2)]
+        if r < 0.55:   # logic over a dict of conditions (distinct fields)
+            d = {}
+            for _ in range(rs.randint(1, 4)):
+                d.update(leaf())
+            return {logic: d}
+        if r < 0.8:    # logic over a list of sub-filters
+            return {logic: [node(depth - 1) for _ in range(rs.randint(1, 4))]}
+        d = dict(leaf())  # conditions + a trailing logic group in one dict (flat clause: SQL precedence)
+        d[logic] = [node(depth - 1) for _ in range(rs.randint(1, 3))]
+        return d
+
+    n_checked = 0
+    for _ in range(300):
+        flt = node(3)
+        where, params = Filter(flt).parse_where_clause()
+        want = [r[0] for r in con.execute(f'SELECT _id FROM t WHERE {where} ORDER BY _id', params)]
+        assert select(tags, flt) == want, flt
+        n_checked += 1
+    assert n_checked == 300
