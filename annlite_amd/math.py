@@ -72,3 +72,8 @@ def cosine(x_mat, y_mat, eps: float = np.finfo(np.float32).eps):
 def cdist(x_mat, y_mat, metric: str):
     """annlite/math.py:77-91"""
     return {'cosine': cosine, 'sqeuclidean': sqeuclidean, 'euclidean': euclidean}[metric](x_mat, y_mat)
+
+
+def pdist(x_mat, metric: str):
+    """annlite/math.py:64-74: all pairwise distances of one set"""
+    return cdist(x_mat, x_mat, metric)
