@@ -131,3 +131,46 @@ def test_recall_not_worse_than_reference_hnsw_pq():
     our_rec = np.mean([len(set(ids[b, :10]) & set(ti[b])) / 10 for b in range(len(q))])
     gc.lib().annlite_hnsw_free(g)
     assert our_rec >= ref_rec - 0.03, (our_rec, ref_rec)
+
+
+def test_save_load_delete_and_export_roundtrip(tmp_path):
+    """hnsw/index.py:116-122 analogue (dump / load of the graph), mark_deleted, and the link export the GPU walk
+    consumes: a reloaded graph answers exactly like the one that was saved."""
+    import pq_oracle
+    from annlite_amd import _graph_capi as gc
+
+    x, q, cb = _data(n=6000, nq=40)
+    codes = pq_oracle.encode_c(x, cb)
+    L = gc.lib()
+    g = _graph(gc, cb, 6000)
+    labels = np.arange(6000, dtype=np.int64)
+    gc.check(L.annlite_hnsw_add(g, x.ctypes.data, codes.ctypes.data, labels.ctypes.data, 6000, 1), 'add')  # 1 thread: reproducible
+    assert L.annlite_hnsw_size(g) == 6000
+    ids0, d0 = _search(gc, g, q, 64, threads=2)
+    path = str(tmp_path / 'g.bin').encode()
+    gc.check(L.annlite_hnsw_save(g, path), 'save')
+    h = L.annlite_hnsw_load(path)
+    assert h, L.annlite_hnsw_last_error()
+    g2 = ctypes.c_void_p(h)
+    ids1, d1 = _search(gc, g2, q, 64, threads=2)
+    assert np.array_equal(ids0, ids1) and np.array_equal(d0, d1)
+    # deleted labels never come back, in either copy
+    gone = np.unique(ids0[:, 0])
+    for lab in gone:
+        gc.check(L.annlite_hnsw_mark_deleted(g2, int(lab)), 'mark_deleted')
+    ids2, _ = _search(gc, g2, q, 64)
+    assert not np.isin(ids2, gone).any()
+    # export: (count, ids) per row, counts within the level-0 degree, ids in range, seeds distinct
+    lpn = L.annlite_hnsw_links_per_node(g)
+    links = np.zeros((6000, lpn + 1), np.uint32)
+    seeds = np.full(1024, -1, np.int64)
+    n_seeds = ctypes.c_int64(0)
+    gc.check(L.annlite_hnsw_export(g, 6000, links.ctypes.data, seeds.ctypes.data, 1024, ctypes.byref(n_seeds)), 'export')
+    assert links[:, 0].max() <= lpn and links[:, 0].min() >= 1
+    for r in (0, 17, 5999):
+        row = links[r, 1:1 + links[r, 0]]
+        assert (row < 6000).all() and r not in row and len(set(row.tolist())) == len(row)
+    ns = n_seeds.value
+    assert 1 <= ns <= 1024 and len(set(seeds[:ns].tolist())) == ns and (seeds[:ns] < 6000).all()
+    L.annlite_hnsw_free(g)
+    L.annlite_hnsw_free(g2)
