@@ -29,6 +29,8 @@ SYMBOLS = (
     'annlite_hip_device_count',
     'annlite_hip_device_arch',
     'annlite_scan_plan_query',
+    'annlite_scan_plan_tiles',
+    'annlite_scan_select_variant',
     'annlite_lut_build',
     'annlite_lut_retile',
     'annlite_adc_dist',
@@ -101,6 +103,7 @@ def lib() -> ctypes.CDLL:
     L.annlite_hip_device_count.argtypes = [ctypes.POINTER(i32)]
     L.annlite_hip_device_arch.argtypes = [i32, ctypes.c_char_p, sz]
     L.annlite_scan_plan_query.argtypes = [i64, i64, i64, i32, i64, i64, ctypes.POINTER(ScanPlan)]
+    L.annlite_scan_plan_tiles.argtypes = [i64, i64, i64, i32, i64, i64, ctypes.POINTER(ScanPlan)]
     L.annlite_lut_build.argtypes = [i32, vp, i64, i64, vp, i64, i64, vp, i32, i32, vp]
     L.annlite_lut_retile.argtypes = [vp, i64, i64, i64, vp, i32, vp]
     L.annlite_adc_dist.argtypes = [vp, i64, i64, vp, i32, i64, vp, vp]
@@ -132,6 +135,7 @@ def lib() -> ctypes.CDLL:
     L.annlite_ivf_rescore.argtypes = [vp, i64, i64, i64, vp, i64, vp, vp, i64, vp, vp, i64, vp, i64, vp, i64, i64, vp,
                                       vp, i32, vp]
     L.annlite_profile_enable.argtypes = [i32]
+    L.annlite_scan_select_variant.argtypes = [i32]
     L.annlite_profile_last_scan_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]
     L.annlite_debug_counters.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     for name in SYMBOLS:
@@ -189,6 +193,18 @@ def scan_plan(N: int, M: int, Ks: int, code_bytes: int, B: int, k: int) -> ScanP
     p = ScanPlan()
     check(lib().annlite_scan_plan_query(N, M, Ks, code_bytes, B, k, ctypes.byref(p)), 'scan_plan')
     return p
+
+
+def scan_plan_tiles(N: int, M: int, Ks: int, code_bytes: int, V: int, k: int) -> ScanPlan:
+    """The plan of ``annlite_pq_search_tiles`` (cells): its query tiles hold ``qt`` slots each."""
+    p = ScanPlan()
+    check(lib().annlite_scan_plan_tiles(N, M, Ks, code_bytes, V, k, ctypes.byref(p)), 'scan_plan_tiles')
+    return p
+
+
+def scan_select_variant(variant: int) -> None:
+    """Kernel selection on the calling thread (-1: default / environment); see ``annlite_scan_select_variant``."""
+    check(lib().annlite_scan_select_variant(int(variant)), 'scan_select_variant')
 
 
 def profile_enable(on: bool) -> None:

@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from ... import ops
-from ..._capi import CODES_SKEWED, scan_plan
+from ..._capi import CODES_SKEWED, scan_plan, scan_plan_tiles
 from ...enums import Metric
 from ..codec.pq import PQCodec
 from ..codec.vq import VQCodec
@@ -178,7 +178,7 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
         if rerank:  # the scan keeps the rows that can be in a cell's ADC top-`rerank_k`; all of them are re-ranked
             k = max(k, min(32, int(rerank_k or 16)))
         cells = self.probe_cells(q, P)
-        qt = scan_plan(self._n_table, self.M, self.Ks, 1, 16, k).qt
+        qt = scan_plan_tiles(self._n_table, self.M, self.Ks, 1, 16, k).qt
         vmap, slot_of, tile_rows, _ = ops.ivf_plan(cells, self.n_cells, qt, self._cell_rows, self._cell_order)
         kind, xq = self.pq_codec.scan_inputs(q)
         bits = self._table_bits(indices)

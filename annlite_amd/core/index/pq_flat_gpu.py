@@ -29,7 +29,7 @@ import numpy as np
 import torch
 
 from ... import ops
-from ..._capi import CODES_PLAIN, CODES_SKEWED, scan_plan
+from ..._capi import CODES_PLAIN, CODES_SKEWED, scan_plan, scan_select_variant
 from ...enums import ExpandMode, Metric
 from ..codec.pq import PQCodec
 from .base import BaseIndex
@@ -63,6 +63,7 @@ class PQFlatGpuIndex(BaseIndex):
         self._valid_bits_cache = None
         self._vectors = None
         self._n_rows = 0
+        self._kernel = None  # (variant, rows it was measured at) -- see _with_kernel
         if index_file:
             self.load(index_file)
 
@@ -185,6 +186,7 @@ class PQFlatGpuIndex(BaseIndex):
         self._valid_bits_cache = None
         self._vectors = None
         self._n_rows = 0
+        self._kernel = None
 
     @property
     def size(self):
@@ -197,6 +199,43 @@ class PQFlatGpuIndex(BaseIndex):
         sel = torch.zeros_like(self._valid_bool)
         sel[idx] = True
         return self._pack_bits(sel & self._valid_bool)
+
+    # ------------------------------------------------------------------ kernel choice
+    # The byte-table scan kernel (M = 16, k <= 16: twice the queries per LDS read) filters with 4-bit entries: on
+    # data with structure -- what PQ is for -- a handful of rows per query pass, on data without any (independent
+    # uniform codes, as some tests and micro-benchmarks use) its filter leaks and the u16-table kernel is several
+    # times faster.  Which one serves THIS table is measured, not guessed: the first large batch runs both (their
+    # results are bit-identical) and the faster one is kept until the table has doubled.
+    _CALIBRATE_MIN_ROWS, _CALIBRATE_MIN_BATCH = 200_000, 32
+
+    def _with_kernel(self, run, B: int, N: int, k: int):
+        if not (self.M == 16 and self.code_bytes == 1 and self.Ks <= 256 and k <= 16):
+            return run()
+        if self._kernel is not None and N < 2 * self._kernel[1]:
+            scan_select_variant(self._kernel[0])
+            try:
+                return run()
+            finally:
+                scan_select_variant(-1)
+        if N < self._CALIBRATE_MIN_ROWS or B < self._CALIBRATE_MIN_BATCH:
+            return run()
+        best, out = None, None
+        try:
+            for variant in (50, 31):  # byte tables, u16 tables
+                scan_select_variant(variant)
+                run()  # (first call of a shape: module load, workspace allocation)
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record()
+                res = run()
+                t1.record()
+                t1.synchronize()
+                ms = t0.elapsed_time(t1)
+                if best is None or ms < best[1]:
+                    best, out = (variant, ms), res
+        finally:
+            scan_select_variant(-1)
+        self._kernel = (best[0], N)
+        return out
 
     def search_batch(self, x, limit: int = 10, indices=None, rerank_k: Optional[int] = None, row_base: int = 0
                      ) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -222,9 +261,11 @@ class PQFlatGpuIndex(BaseIndex):
         elif k <= 64:
             # table build + scan + top-k: one C call (annlite_pq_search_topk)
             kind, xq = self.pq_codec.scan_inputs(q)
-            d, i = ops.pq_search_topk(kind, xq, self.pq_codec.codebooks_dev, self._codes, k, self.M, self.Ks,
-                                      valid_bits=valid, n_rows=N, codes_layout=self._layout(), workspace=self._ws,
-                                      row_base=row_base, sqrt=self.metric == Metric.EUCLIDEAN)  # hnsw/index.py:164-165
+            base = row_base
+            d, i = self._with_kernel(lambda: ops.pq_search_topk(
+                kind, xq, self.pq_codec.codebooks_dev, self._codes, k, self.M, self.Ks, valid_bits=valid, n_rows=N,
+                codes_layout=self._layout(), workspace=self._ws, row_base=base,
+                sqrt=self.metric == Metric.EUCLIDEAN), B, N, k)  # hnsw/index.py:164-165
             row_base = 0
         else:
             d, i = self._search_large_k(q, k, valid, N)
@@ -249,9 +290,9 @@ class PQFlatGpuIndex(BaseIndex):
             out[..., 1] = 0x7F800000  # +inf
             return out
         kind, xq = self.pq_codec.scan_inputs(q)
-        return ops.pq_search_topk(kind, xq, self.pq_codec.codebooks_dev, self._codes, k, self.M, self.Ks,
-                                  valid_bits=self._valid, row_base=row_base, n_rows=N, codes_layout=self._layout(),
-                                  workspace=self._ws, packed=True)
+        return self._with_kernel(lambda: ops.pq_search_topk(
+            kind, xq, self.pq_codec.codebooks_dev, self._codes, k, self.M, self.Ks, valid_bits=self._valid,
+            row_base=row_base, n_rows=N, codes_layout=self._layout(), workspace=self._ws, packed=True), B, N, k)
 
     @property
     def sqrt_epilogue(self) -> bool:

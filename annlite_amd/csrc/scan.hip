@@ -262,18 +262,23 @@ __global__ __launch_bounds__(256) void codes_skew_kernel(const uint8_t *__restri
 struct FastCfg {
     int M, QI, NQ, NW, WPS, wg_per_cu, id;
     int mode;  // 0: exec-masked passes, 1/2: weight-fma passes, 3: FILTER kernel (fast fp32 sum + exact
-               // recompute), 4: QFILTER kernel (12-bit integer tables, 8 queries per LDS entry)
-    int qt() const { return (mode == 4 ? (M == 64 ? 4 : 8) : QI) * NQ; }
+               // recompute), 4: QFILTER kernel (12-bit integer tables, 8 queries per LDS entry), 5: byte-table
+               // kernel (scan_q8.hip: 16 queries per LDS entry, tables quantised by the workgroup itself)
+    int qt() const { return (mode == 5 ? 16 : mode == 4 ? (M == 64 ? 4 : 8) : QI) * NQ; }
+    bool qf() const { return mode == 4 || mode == 5; }  // integer filter + exact recompute, shared bounds
 };
 
 // Kernel variants per M.  ANNLITE_SCAN_VARIANT (env, read per call) selects among the M=16
 // instantiations for A/B measurements; variant 0 is the default for every M.
+static thread_local int g_variant_override = -1;  // annlite_scan_select_variant
 static int scan_variant() {
+    if (g_variant_override >= 0) return g_variant_override;
     const char *e = getenv("ANNLITE_SCAN_VARIANT");
     return e ? atoi(e) : 0;
 }
 
-static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *c) {
+// tiles: the plan of annlite_pq_search_tiles (IVF cells) -- the u16 kernels' tile mode
+static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *c, bool tiles = false) {
     if (code_bytes != 1 || Ks > 256 || Ks < 1 || k > 64 || k < 1) return false;
     const int v = scan_variant();
     switch (M) {
@@ -283,7 +288,10 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
             else *c = {8, 4, 2, 16, 4, 1, 830, 4};               // default: qfilter, 16 queries / WG
             return true;
         case 16:
-            if (v == 0) { *c = {16, 4, 2, 16, 4, 1, 1631, 4}; return true; }  // default: qfilter, 16 queries / WG, 16 waves
+            // default: byte tables, 32 queries / WG, 15 scanning waves + 1 consumer (small k: the candidate generator of the
+            // re-rank stage asks for 64 per slice and starts without a seed -- the u16 tables filter that much better)
+            if ((v == 0 && !tiles && k <= 16) || v == 50) { *c = {16, 4, 2, 16, 4, 1, 1650, 5}; return true; }
+            if (v == 0) { *c = {16, 4, 2, 16, 4, 1, 1631, 4}; return true; }  // tile mode: qfilter, 16 queries / WG, 16 waves
             if (v == 8) { *c = {16, 4, 2, 12, 3, 1, 1601, 3}; return true; }  // fp32 filter kernel, 12 waves, single buffer
             if (v == 30) { *c = {16, 4, 2, 12, 3, 1, 1630, 4}; return true; }  // qfilter, 16 queries / WG, 12 waves
             if (v == 31) { *c = {16, 4, 2, 16, 4, 1, 1631, 4}; return true; }  // qfilter, 16 waves
@@ -318,6 +326,11 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
 }
 
 static int round_up(int64_t x, int64_t m) { return (int)(((x + m - 1) / m) * m); }
+// queries the per-query workspace arrays are sized for: whole tiles, at least the 16 the fp32 TILED table is padded to
+static int64_t pad_queries(int64_t B, int qt) {
+    const int64_t p = qt > 16 ? qt : 16;
+    return ((B + p - 1) / p) * p;
+}
 
 static void plan_slices(int64_t N, int n_tiles, int waves, int n_cu, bool xcd8, int *n_slices, int64_t *slice_rows,
                         int64_t B = 0) {
@@ -367,7 +380,7 @@ static int plan_query_impl(int64_t N, int64_t M, int64_t Ks, int code_bytes, int
     const int n_cu = device_cu_count();
     memset(plan, 0, sizeof(*plan));
     plan->max_k = 64;
-    if (fast_cfg(M, Ks, code_bytes, k, &c)) {
+    if (fast_cfg(M, Ks, code_bytes, k, &c, force_ns > 0)) {
         plan->fast = 1;
         plan->qi = c.QI;
         plan->qt = c.qt();
@@ -380,9 +393,9 @@ static int plan_query_impl(int64_t N, int64_t M, int64_t Ks, int code_bytes, int
         plan->n_slices = ns;
         plan->lut_floats = ((B + 15) / 16) * 16 * M * Ks;  // padded to 16 queries
         // [partial keys][Smax f32 x Bpad][qstep f32 x Bpad][qlo f64 x Bpad][lo,hi f32 x Bpad*M][q16 u16 x Bpad*M*Ks]
-        const int64_t bpad = ((B + 15) / 16) * 16;
+        const int64_t bpad = pad_queries(B, plan->qt);
         plan->workspace_bytes = (int64_t)n_tiles * plan->qt * ns * k * 8 + 256 + bpad * 4 + 256;
-        if (c.mode == 4)
+        if (c.qf())
             plan->workspace_bytes += bpad * 4 + 256 + 2 * (bpad * 8 + 256) + (bpad * ns * 8 + 256) + (n_tiles * 4 + 256) +
                                      256 /* item counter */ + bpad * M * Ks * 2 + 256;
     } else {
@@ -404,6 +417,11 @@ static int plan_query_impl(int64_t N, int64_t M, int64_t Ks, int code_bytes, int
 extern "C" int annlite_scan_plan_query(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t k,
                                        annlite_scan_plan *plan) {
     return plan_query_impl(N, M, Ks, code_bytes, B, k, 0, plan);
+}
+
+extern "C" int annlite_scan_plan_tiles(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t V, int64_t k,
+                                       annlite_scan_plan *plan) {
+    return plan_query_impl(N, M, Ks, code_bytes, V, k, 1, plan);
 }
 
 static unsigned long long *g_dbg = nullptr;  // debug only (ANNLITE_DEBUG_COUNTERS): leaked 64-byte device buffer
@@ -457,7 +475,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
     if (B == 0) return ANNLITE_OK;
     if (tm) {
         FastCfg ct;
-        ANNLITE_REQUIRE(plan.fast && fast_cfg(M, Ks, code_bytes, k, &ct) && ct.mode == 4,
+        ANNLITE_REQUIRE(plan.fast && fast_cfg(M, Ks, code_bytes, k, &ct, true) && ct.mode == 4,
                         "tile mode needs the quantised-filter plan (M in {8,16,32,64}, Ks <= 256, uint8 codes)");
         ANNLITE_REQUIRE(B % plan.qt == 0 && tm->tile_rows && tm->vmap && tm->cand && tm->cand_count && tm->cand_cap >= 64,
                         "tile mode: B=%lld must be a multiple of the tile size %d", (long long)B, plan.qt);
@@ -507,15 +525,15 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         // partial lists, and (quantised-filter plan) the shared bounds right behind them; the rest is scratch
         size_t fill = (size_t)plan.workspace_bytes;
         FastCfg c0;
-        if (plan.fast && fast_cfg(M, Ks, code_bytes, k, &c0) && c0.mode == 4) {
-            const size_t bpad = (size_t)((B + 15) / 16) * 16;
+        if (plan.fast && fast_cfg(M, Ks, code_bytes, k, &c0, tm != nullptr) && c0.qf()) {
+            const size_t bpad = (size_t)pad_queries(B, plan.qt);
             auto r256 = [](size_t x) { return (x + 255) / 256 * 256; };
             fill = r256((size_t)a.n_tiles * plan.qt * plan.n_slices * k * 8) + r256(bpad * 8) +
                    r256(bpad * plan.n_slices * 8) + r256((size_t)a.n_tiles * 4) + 256 /* item counter */;
         }
         fill_bytes = fill;
         FastCfg c1;
-        fused_fill = N > 0 && plan.fast && fast_cfg(M, Ks, code_bytes, k, &c1) && c1.mode == 4 && M != 64;  // lut_quantise_fused_kernel
+        fused_fill = N > 0 && plan.fast && fast_cfg(M, Ks, code_bytes, k, &c1, tm != nullptr) && c1.qf() && M != 64;  // lut_quantise_fused_kernel
         if (!fused_fill) ANNLITE_HIP_TRY(hipMemsetAsync(workspace_dev, 0xff, fill, st));
     }
     if (N == 0) return ANNLITE_OK;
@@ -525,12 +543,27 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
     a.n_items = n_items;
     if (plan.fast) {
         FastCfg c;
-        fast_cfg(M, Ks, code_bytes, k, &c);
-        int grid = n_items < n_cu * c.wg_per_cu ? n_items : n_cu * c.wg_per_cu;
+        fast_cfg(M, Ks, code_bytes, k, &c, tm != nullptr);
+        if (c.mode == 5 && a.n_tiles >= 8) a.n_items = 8 * ((a.n_tiles + 7) / 8) * a.n_slices;  // q8_item_map
+        a.q8_epoch0 = 3;
+        a.q8_epoch_mul = 4;
+        a.q8_ring_limit = 384;
+        a.q8_import_mask = 3;
+        if (const char *e = getenv("ANNLITE_Q8_TUNE")) {  // "epoch0,mul,ring_limit,import_mask" (measurements)
+            int e0 = 3, mul = 4, rl = 384, im = 3;
+            // (a ring limit below 192 can deadlock: the consumer waits for entries of a producer the limit holds back)
+            if (sscanf(e, "%d,%d,%d,%d", &e0, &mul, &rl, &im) == 4 && e0 >= 0 && mul >= 2 && rl >= 192 && rl <= 896 && im >= 0) {
+                a.q8_epoch0 = e0;
+                a.q8_epoch_mul = mul;
+                a.q8_ring_limit = rl;
+                a.q8_import_mask = im;
+            }
+        }
+        int grid = a.n_items < n_cu * c.wg_per_cu ? a.n_items : n_cu * c.wg_per_cu;
         const bool sk = codes_layout == ANNLITE_CODES_SKEWED;
-        if (c.mode == 4) {
+        if (c.qf()) {
             // quantise the fp32 tables: min/max -> (step, L, Smax) -> 12-bit codes, all inside the workspace
-            const int64_t bpad = ((B + 15) / 16) * 16;
+            const int64_t bpad = pad_queries(B, plan.qt);
             char *wp = (char *)workspace_dev + (((int64_t)a.n_tiles * plan.qt * plan.n_slices * k * 8 + 255) / 256) * 256;
             auto carve = [&](int64_t bytes) { char *r = wp; wp += ((bytes + 255) / 256) * 256; return r; };
             // [gkey][gk2][tile_done] directly behind the partial lists: the one fill covers exactly these four
@@ -569,11 +602,13 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 if (const char *e = getenv("ANNLITE_FLUSH_MASK")) a.flush_mask = atoi(e);
             }
             // (the q16 table sits behind the small arrays; carve order is irrelevant to the kernels)
-            uint16_t *q16 = (uint16_t *)carve(bpad * M * Ks * 2);
+            // byte-table kernel: no u16 tables, the per-(query, sub-space) minima instead (same region, smaller)
+            uint16_t *q16 = c.mode == 5 ? nullptr : (uint16_t *)carve(bpad * M * Ks * 2);
+            float *qlom = c.mode == 5 ? (float *)carve(bpad * M * 4) : nullptr;
             // (tile mode with the fused L2 build: the slots' fp32 tables are never read -- do not store them)
             const int64_t Bq = tm ? tm->n_queries : B;  // tile mode: tables of the real queries only
             rc = launch_lut_quantise(M, Ks, Bq, ((Bq + 15) / 16) * 16, (tm && build) ? nullptr : lut_dev, build, q16, qstep,
-                                     qlo, smax, workspace_dev, fill_bytes, st);
+                                     qlo, smax, qlom, workspace_dev, fill_bytes, st);
             if (rc != ANNLITE_OK) return rc;
             if (share_across_slices && N >= 4096 && !tm) {  // (tile mode seeds inside the scan kernel)
                 int64_t S = 8192;
@@ -587,6 +622,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             a.qstep = qstep;
             a.qlo = qlo;
             a.q16 = q16;
+            a.qlom = qlom;
         }
         if (c.mode == 3) {
             // rounding slack of the fast filter sum needs Smax[b] = sum_m max_k |lut[b][m][k]|
@@ -598,7 +634,9 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             a.smax = smax;
         }
         prof_begin(st);
-        rc = c.mode == 4 ? launch_qfilter_scan(c.id, sk, a, grid, st) : launch_legacy_scan(c.id, sk, a, grid, st);
+        rc = c.mode == 5   ? launch_q8_scan(c.id, sk, a, grid, st)
+             : c.mode == 4 ? launch_qfilter_scan(c.id, sk, a, grid, st)
+                           : launch_legacy_scan(c.id, sk, a, grid, st);
         prof_end(st);
         return rc;
     }
@@ -613,6 +651,12 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         hipLaunchKernelGGL((adc_scan_generic_kernel<uint32_t, 4>), dim3(grid), dim3(256), lds, st, a, (int)M);
     prof_end(st);
     return launch_status("adc_scan_generic_kernel");
+}
+
+extern "C" int annlite_scan_select_variant(int variant) {
+    ANNLITE_REQUIRE(variant >= -1 && variant < 100, "variant %d outside [-1, 99]", variant);
+    g_variant_override = variant;
+    return ANNLITE_OK;
 }
 
 extern "C" int annlite_debug_counters(uint64_t *out8) {
@@ -716,7 +760,7 @@ static int pq_search_impl(int lut_kind, const float *queries_dev, int64_t B, int
     ANNLITE_REQUIRE(!tm || B <= Bs, "tile mode: more queries (%lld) than slots (%lld)", (long long)B, (long long)Bs);
     float *lut = (float *)((char *)workspace_dev + scan_ws);
     FastCfg c;
-    const bool fuse = N > 0 && plan.fast && fast_cfg(M, Ks, code_bytes, k, &c) && c.mode == 4 && M != 64 &&
+    const bool fuse = N > 0 && plan.fast && fast_cfg(M, Ks, code_bytes, k, &c, tm != nullptr) && c.qf() && M != 64 &&
                       lut_kind == ANNLITE_LUT_L2 && ((D / M) % 4) == 0 && !getenv("ANNLITE_NO_FUSED_LUT");
     if (!fuse) {
         rc = annlite_lut_build(lut_kind, queries_dev, B, D, codebooks_dev, M, Ks, lut,

@@ -29,6 +29,7 @@ struct ScanArgs {
     const uint16_t *q16;     // [ceil16(B)/8][Ks][M][8] u16
     const float *qstep;      // [ceil16(B)]
     const double *qlo;       // [ceil16(B)] sum_m min_k lut[b][m][k]
+    const float *qlom;       // [ceil16(B)][M] min_k lut[b][m][k] (byte-table kernel: it quantises the tables itself)
     unsigned long long *gkey; // [ceil16(B)] best k-th key any workgroup has proven for the query (device-scope
                              // atomic min; lets the 8+ row slices of a query tile share their progress)
     unsigned long long *gk2; // [ceil16(B)][n_slices] j-th key of every (query, slice) list, j = ceil(k/8): the 8
@@ -55,6 +56,9 @@ struct ScanArgs {
     uint32_t *cand;              // [n_tiles * QT][cand_cap] out: table rows of every slot that can be in its top-k
     uint32_t *cand_count;        // [n_tiles * QT] out: entries of the slot's list; 0xffffffff: it overflowed
     int32_t cand_cap;
+    // byte-table kernel (scan_q8.hip): epochs end after steps e0, e0 * mul + (mul - 1), ...; ring_limit = candidates the
+    // scanning waves may be ahead of the consumer wave
+    int32_t q8_epoch0, q8_epoch_mul, q8_ring_limit, q8_import_mask;
 };
 
 // work item -> (query tile, row slice).  item % 8 == blockIdx % 8 == the XCD the block lands on (speed
@@ -327,10 +331,12 @@ struct LutBuild {  // annlite_pq_search_topk: the L2 tables are built by the qua
     int64_t D;
 };
 int launch_qfilter_scan(int id, bool skewed, const ScanArgs &a, int grid, hipStream_t st);
+int launch_q8_scan(int id, bool skewed, const ScanArgs &a, int grid, hipStream_t st);
 int launch_legacy_scan(int id, bool skewed, const ScanArgs &a, int grid, hipStream_t st);
+// q16 == NULL: only the per-query parameters (step, L, Smax, minima) are produced; qlom may be NULL
 int launch_lut_quantise(int64_t M, int64_t Ks, int64_t B, int64_t bpad, const float *lut_dev, const LutBuild *build,
-                        uint16_t *q16, float *qstep, double *qlo, float *smax, void *fill, size_t fill_bytes,
-                        hipStream_t st);
+                        uint16_t *q16, float *qstep, double *qlo, float *smax, float *qlom, void *fill,
+                        size_t fill_bytes, hipStream_t st);
 int launch_seed_bound(int64_t M, bool skewed, const void *codes_dev, int64_t S, const uint32_t *valid_bits_dev,
                       const float *lut_dev, int64_t B, int64_t Ks, int64_t k, unsigned long long *gkey, hipStream_t st);
 int launch_lut_smax(const float *lut_dev, int n_groups, int64_t M, int64_t Ks, int QI, float *smax, hipStream_t st);

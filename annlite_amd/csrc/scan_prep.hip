@@ -296,8 +296,8 @@ template <int M>
 __global__ __launch_bounds__(256) void lut_quantise_fused_kernel(const float *__restrict__ lut, int Ks, int qmax,
                                                                 uint16_t *__restrict__ out,
                                                                 float *__restrict__ qstep, double *__restrict__ qlo,
-                                                                float *__restrict__ smax, u32x4 *__restrict__ fill,
-                                                                int64_t fill_vec16) {
+                                                                float *__restrict__ smax, float *__restrict__ qlom,
+                                                                u32x4 *__restrict__ fill, int64_t fill_vec16) {
     constexpr int KPT = 256 / M;  // codes covered per sweep of the block
     // this launch also resets the scan's result lists and shared bounds to "none" (all-ones): one launch less
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < fill_vec16; i += (int64_t)gridDim.x * 256)
@@ -341,6 +341,7 @@ __global__ __launch_bounds__(256) void lut_quantise_fused_kernel(const float *__
         }
         s_lo[0][mm][i] = l;
         s_hi[0][mm][i] = h;
+        if (qlom) qlom[(int64_t)(g8 * 8 + i) * M + mm] = l;
     }
     __syncthreads();
     if (tid < 8) {
@@ -361,6 +362,7 @@ __global__ __launch_bounds__(256) void lut_quantise_fused_kernel(const float *__
         smax[b] = sm;
     }
     __syncthreads();
+    if (!out) return;  // (the byte-table scan quantises the tables itself)
     float lo_r[8], st_r[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -395,8 +397,8 @@ __global__ __launch_bounds__(1024) void lut_l2_build_quantise_kernel(const float
                                                                     float *__restrict__ lut, int qmax,
                                                                     uint16_t *__restrict__ out,
                                                                     float *__restrict__ qstep, double *__restrict__ qlo,
-                                                                    float *__restrict__ smax, u32x4 *__restrict__ fill,
-                                                                    int64_t fill_vec16) {
+                                                                    float *__restrict__ smax, float *__restrict__ qlom,
+                                                                    u32x4 *__restrict__ fill, int64_t fill_vec16) {
     constexpr int KPT = 1024 / M;   // codes per sweep
     constexpr int NSW = 256 / KPT;  // sweeps (Ks <= 256)
     for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < fill_vec16; i += (int64_t)gridDim.x * 1024)
@@ -484,6 +486,7 @@ __global__ __launch_bounds__(1024) void lut_l2_build_quantise_kernel(const float
         }
         s_lo[0][mm][i] = l;
         s_hi[0][mm][i] = h;
+        if (qlom) qlom[(int64_t)(g8 * 8 + i) * M + mm] = l;
     }
     __syncthreads();
     if (tid < 8) {
@@ -504,6 +507,7 @@ __global__ __launch_bounds__(1024) void lut_l2_build_quantise_kernel(const float
         smax[b] = sm;
     }
     __syncthreads();
+    if (!out) return;  // (the byte-table scan quantises the tables itself)
     float lo_r[8], st_r[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -555,8 +559,8 @@ __global__ __launch_bounds__(256) void lut_smax_kernel(const float *__restrict__
 using namespace annlite;
 
 int annlite::launch_lut_quantise(int64_t M, int64_t Ks, int64_t B, int64_t bpad, const float *lut_dev, const LutBuild *build,
-                                 uint16_t *q16, float *qstep, double *qlo, float *smax, void *fill, size_t fill_bytes,
-                                 hipStream_t st) {
+                                 uint16_t *q16, float *qstep, double *qlo, float *smax, float *qlom, void *fill,
+                                 size_t fill_bytes, hipStream_t st) {
     const int qmax = (int)(32767 / M);
     const unsigned n_g8 = (unsigned)(bpad / 8);
     float *lut_rw = const_cast<float *>(lut_dev);
@@ -566,10 +570,10 @@ int annlite::launch_lut_quantise(int64_t M, int64_t Ks, int64_t B, int64_t bpad,
     if (build)                                                                                                       \
         hipLaunchKernelGGL((lut_l2_build_quantise_kernel<MM>), dim3(n_g8), dim3(1024), (size_t)(8 * build->D * 4), st,  \
                            build->queries, (int)B, (int)build->D, build->codebooks, (int)Ks, lut_rw, qmax, q16, qstep,   \
-                           qlo, smax, fillp, fillv);                                                                 \
+                           qlo, smax, qlom, fillp, fillv);                                                                 \
     else                                                                                                             \
         hipLaunchKernelGGL((lut_quantise_fused_kernel<MM>), dim3(n_g8), dim3(256), 0, st, lut_rw, (int)Ks, qmax, q16,  \
-                           qstep, qlo, smax, fillp, fillv)
+                           qstep, qlo, smax, qlom, fillp, fillv)
     if (M == 64)  // (no fill, no build: the caller memsets and builds the tables itself)
         hipLaunchKernelGGL(lut_quantise64_kernel, dim3((unsigned)(bpad / 4)), dim3(1024), 0, st, lut_dev, (int)Ks, qmax, q16,
                            qstep, qlo, smax);

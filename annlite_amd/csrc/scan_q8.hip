@@ -1,0 +1,777 @@
+// scan_q8.hip -- the ADC scan with BYTE filter tables: 16 queries per 16-byte LDS entry, 32 queries per workgroup.
+//
+// Same discipline as adc_scan_qfilter_kernel (scan_qfilter.hip): a cheap integer LOWER bound of every (query, row)
+// distance from tables in LDS, the exact ascending-m fp32 sum (the reference's arithmetic, pq_bindings.pyx:30-47 ==
+// space_pq.h:32-35) only for the rows whose bound beats the current k-th distance, shared top-k lists, bounds shared
+// across the row slices -- bit-exact results.  What changes is the table:
+//   * entries are BYTES, Q = min(QMAX, floor((lut - lo[q][m]) / step[q])) with M * QMAX <= 240: one ds_read_b128
+//     serves 16 look-ups per lane and one v_add_u32 adds four of them, so the step loop has the SAME instruction
+//     stream as the u16 kernel (32 ds_read_b128 + ~110 VALU per 64 rows) for twice the queries;
+//   * 3-bit entries are enough because the quantisation follows the THRESHOLD, not the table's range: what decides
+//     the number of rows passing the filter is the resolution relative to R = thr - L (L = sum_m lo): with
+//     step = R / 31 a row at the threshold has an integer sum of ~31 and every entry above 7 steps (R / 4.4) is
+//     clipped -- such a row is far outside anyway.  Measured on the bench's data (2M rows, quantile 1e-6 threshold,
+//     scripts/sim_filter_bits.py): 8.6 rows per query pass with (QMAX 7, T 32) against 2 for the u16 tables and 300
+//     for T = 8;
+//   * the threshold tightens ~4x over a 10M-row scan, so the workgroup builds its table ITSELF from the fp32 TILED
+//     table (L2) with the bound it starts from (seed kernel / other slices) and REBUILDS it when the bounds of a
+//     quarter of its queries have fallen below 0.72 of what they were built for (checked at steps 1, 2, 4, 8, ...;
+//     a rebuild costs ~3 us);
+//   * filter: (0x80 | T) - S per byte keeps bit 7 iff S <= T; S <= 112 and T <= 127, so no byte ever borrows.
+// Bound: Q <= (v - lo) / step * (1 + 2^-22) (fp32 subtract, multiply by 1/step, round down), hence
+//     d_real - L >= S * step * (1 - 2^-22);  a row can be in the top-k only if d_fp32 <= thr, i.e.
+//     d_real <= thr + slack32  =>  S <= T := floor((thr + slack32 - L) / step * (1 + 2^-19)) + 1   (double).
+// Clipping (min with QMAX) and a T clamped to 127 (S never exceeds 112) keep the bound valid for ANY step.
+// Candidates are handled by a CONSUMER wave: NW - 1 waves scan and only push (query, row) pairs into a ring in LDS;
+// the last wave of the workgroup pops them in batches of up to 128, computes the exact sums (two dependent global
+// round trips), updates the lists -- it is their only writer: no locks -- and publishes the bounds; it also imports
+// the bounds of the other row slices.  The scanning waves never wait for global memory, the exact path (16 table
+// gathers in flight, list networks) has its own registers instead of being called with ~100 live VGPRs saved to
+// scratch (the u16 kernel's out-of-line flush: 487 MB of scratch writes per 10M-row launch), and inlining it into the
+// step loop made the compiler spill the loop-invariant LDS base registers into the hot path.
+// LDS: [table Ks * 512][T bytes x32 @+0][ring control @+32][gkl u64 x32 @+192][step f32 x32 @+448][inv f32 x32 @+576]
+//      [built-for T x32 @+704][control @+736][lists u64 x32x64 @+768][gjl u64 x32][ring u64 x 1024]
+#include "scan_lists.h"
+
+namespace annlite {
+
+constexpr int kQ8Target = 64;  // T right after a (re)build
+#ifndef ANNLITE_Q8_DEPTH
+#define ANNLITE_Q8_DEPTH 8  // look-ups in flight per lane
+#endif
+
+// Q8Cfg: entries are clipped at QMAX (M * QMAX <= 240: a byte sum never carries); a slot without a bound yet
+// ("open": nothing seeded it) clips at QOPEN, M * QOPEN <= 112, so that T = 127 passes every row.
+template <int M>
+struct Q8Cfg {
+    static constexpr int QMAX = 240 / M, QOPEN = 112 / M;
+};
+
+template <int M>
+__device__ __forceinline__ void q8_slot_params(bool real, unsigned long long key, float range, float smax_b, double L,
+                                               float &step, float &inv, float &clip, unsigned char &tbyte) {
+    clip = (float)Q8Cfg<M>::QOPEN;
+    if (!real) {  // pad slot: all-zero table, never passes (0x7f - 0 has bit 7 clear)
+        step = 1.f;
+        inv = 0.f;
+        tbyte = 0x7f;
+        return;
+    }
+    float open_step = range / (float)Q8Cfg<M>::QOPEN;  // no bound yet: the whole range, everything passes (S <= 112 <= T = 127)
+    if (!(open_step > 1e-30f) || !(open_step < 1e30f)) open_step = 1.f;
+    step = open_step;
+    const uint32_t hi = (uint32_t)(key >> 32);
+    if (hi != kKeyInfHi) {
+        const double thr = (double)ordered_to_f32(hi);
+        const double slack = (double)smax_b * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
+        const double R = thr + slack - L;
+        if (R > 0.0 && R < 1e30) {
+            float s = (float)(R / (double)(kQ8Target - 1));
+            const float smin = open_step * (1.f / 65536.f);
+            if (!(s >= smin)) s = smin;  // (a larger step only lowers T)
+            step = s;
+            clip = (float)Q8Cfg<M>::QMAX;  // T <= kQ8Target now and it only falls: sums above 127 can never pass
+        }
+    }
+    inv = 1.0f / step;
+    tbyte = qbound8_from_key<M>(key, smax_b, step, L);
+}
+
+// The workgroup's byte table from the fp32 TILED tables of its 32 queries: thread (m, h) = (tid % M, (tid / M) % 2)
+// keeps the minima and 1/step of its 16 queries in registers and walks the codes.  RNE(t - 0.5) <= floor(t): the
+// conversion's rounding mode does not matter for the bound.
+// what a (re)build reads of the kernel's arguments (passed by value: a pointer to the kernel's argument block would
+// make the compiler keep a copy of all of it in scratch and read it from there in the step loop)
+struct Q8Build {
+    const float *lut, *qlom, *qstep, *smax;
+    const double *qlo;
+    const unsigned long long *gkey;
+    int32_t Ks, B, k;
+};
+
+template <int M, int NW>
+__device__ __forceinline__ void q8_build_table(const Q8Build &a, int tile, unsigned char *smem, const float *s_inv,
+                                               const float *s_clip, int tid) {
+    constexpr int NQ = 2, RB = M * 16, NT = NW * 64, KHS = NT / M;
+    static_assert(NT % M == 0 && KHS % NQ == 0, "build mapping");
+    const int m = tid % M, kh0 = tid / M, h = kh0 % NQ;
+    const int n_g4 = ((a.B + 15) / 16) * 4;  // fp32 TILED groups that exist (the table is padded to 16 queries)
+    float lo_r[16], inv_r[16], clip_r[16];
+    const float *src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g4 = tile * 8 + h * 4 + i;
+        const bool ok = g4 < n_g4;
+        src[i] = a.lut + ((int64_t)(ok ? g4 : 0) * a.Ks * M + m) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo_r[4 * i + e] = ok ? a.qlom[(int64_t)(g4 * 4 + e) * M + m] : 0.f;
+            inv_r[4 * i + e] = ok ? s_inv[h * 16 + 4 * i + e] : 0.f;
+            clip_r[4 * i + e] = s_clip[h * 16 + 4 * i + e];
+        }
+    }
+#pragma unroll 2
+    for (int kh = kh0; kh < a.Ks * NQ; kh += KHS) {
+        const int k = kh / NQ;
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v = *(const f32x4 *)(src[i] + (int64_t)k * M * 4);
+            uint32_t pk = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = __builtin_fmaf(v[e] - lo_r[4 * i + e], inv_r[4 * i + e], -0.5f);
+                t = __builtin_fminf(t, clip_r[4 * i + e]);
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(t, e, pk);  // saturates below 0
+            }
+            w[i] = pk;
+        }
+        *(u32x4 *)(smem + (k * NQ + h) * RB + m * 16) = (u32x4){w[0], w[1], w[2], w[3]};
+    }
+}
+
+constexpr int kRingSize = 1024;  // candidate ring entries (u64 each)
+
+// ring control words in LDS (u32 each)
+struct Q8Ring {
+    volatile uint32_t *tail;     // entries reserved by the scanning waves
+    volatile uint32_t *head;     // entries consumed
+    volatile uint32_t *arrived;  // scanning waves that finished an epoch (cumulative)
+    unsigned long long *slots;   // [kRingSize], ~0 = not written yet
+};
+
+// What the consumer wave keeps per slot (LDS): the 16 smallest keys (ordered distance << 32 | row) seen so far,
+// ascending -- the kernel serves k <= 16 -- and tau, the k-th key it last published.  Insertions run FOUR AT A TIME, one
+// per 16-lane row of the wave: slot q belongs to row q & 3; in a round every row takes the next pending candidate of
+// one of its slots, its 16 lanes load the slot's list, count the entries in front of the candidate (ballot), shift the
+// tail by one lane (DPP row_shr) and store.  The bounds of the slots that changed are published once per batch, one
+// lane per slot.  (The u16 kernels' offer_to_list -- one slot at a time, 64-lane lists shifted through ds_bpermute,
+// a double-precision division per insertion on one lane -- cost ~0.7 us per inserted candidate: 585 us per workgroup
+// at 1.25M rows against a 290 us scan.  Unsorted bags compacted when full: ~1.5 us per compaction and a bound that
+// lags 22 insertions behind -- 2x the candidates.)
+struct Q8Lists {
+    unsigned long long *list;  // [32][16]
+    unsigned long long *tau;   // [32]
+    const double *c0, *c1;     // [32] T = floor(thr * c1 + c0) + 1 for the slot's current step (q8_bound)
+    unsigned long long *qkey;  // [4][128] insertion queues of the four rows: keys,
+    unsigned char *qslot;      // [4][128] slots
+    unsigned char *chg;        // [32]
+};
+
+// byte filter bound (0x80 | T) of a slot from a k-th key: T = floor((thr + slack32 - L) / step * (1 + 2^-19)) + 1 with the
+// slot's constants folded into c1 = (1 + 2^-19) / step, c0 = (slack32 - L) * c1 (set when the table is built)
+__device__ __forceinline__ unsigned char q8_bound(unsigned long long key, double c0, double c1) {
+    const uint32_t hi = (uint32_t)(key >> 32);
+    if (hi == kKeyInfHi) return 0xff;
+    double qd = __builtin_floor(__builtin_fma((double)ordered_to_f32(hi), c1, c0)) + 1.0;
+    if (!(qd > 0.0)) qd = 0.0;
+    if (!(qd < 127.0)) qd = 127.0;  // (a NaN lands here too: everything passes)
+    return (unsigned char)(0x80u | (uint32_t)qd);
+}
+
+__device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // lane i <- lane i - 1 of its row
+}
+
+// consumer wave: pop up to 128 entries (two per lane).  An entry is (S << 40 | slot << 32 | row): entries whose integer
+// sum no longer passes the slot's CURRENT bound are dropped before any global load (the bound tightens while a backlog
+// waits); the others get their exact sum (the reference's arithmetic) and go into their slot's list.
+template <int M, bool SKEWED>
+__device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Ring &r, const Q8Lists &g, uint32_t head, int n, int lane,
+                                           uint32_t &n_kept, uint32_t &n_offered) {
+    constexpr int CW = M / 4;
+    unsigned long long e[2];
+    bool act[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        act[u] = lane + 64 * u < n;
+        volatile unsigned long long *slot = r.slots + ((head + 64 * u + lane) & (kRingSize - 1));
+        e[u] = ~0ull;
+        // (reserved but not written yet: its producer is between the reservation and the store)
+        while (__ballot(act[u] && e[u] == ~0ull)) {
+            if (act[u] && e[u] == ~0ull) e[u] = *slot;
+        }
+        if (act[u]) *slot = ~0ull;
+    }
+    *r.head = head + (uint32_t)n;  // the producers may overwrite the slots from here on
+    int q[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        q[u] = (int)(e[u] >> 32) & 31;
+        const uint32_t sv = (uint32_t)(e[u] >> 40) & 0xffu;
+        const uint32_t tq = ((volatile unsigned char *)(g_smem + c.shq_off))[q[u]];
+        act[u] = act[u] && ((0x80u | sv) <= tq);  // still passes?  (pad slots, 0x7f, never push)
+    }
+    n_kept += (uint32_t)(__popcll(__ballot(act[0])) + __popcll(__ballot(act[1])));
+    // exact ascending-m fp32 sums of both rows (exact_row_sum's arithmetic; the loads of the two rows interleaved)
+    float ex[2] = {0.f, 0.f};
+    if (!(c.skip & 1)) {
+        uint32_t cp[2][CW];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t *p = (const uint32_t *)(c.codes + (int64_t)(act[u] ? (uint32_t)e[u] : 0u) * M);
+#pragma unroll
+            for (int i = 0; i < CW; ++i) cp[u][i] = p[i];
+        }
+        float vals[2][M];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t rid = act[u] ? (uint32_t)e[u] : 0u;
+            if constexpr (SKEWED) {
+                const int sinv = (M - (int)(rid % M)) % M;
+                bool abit_inv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) abit_inv[i] = (((sinv >> 2) >> i) & 1) != 0;
+                rotate_row<CW>(cp[u], abit_inv, (uint32_t)(sinv & 3));
+            }
+            const int b = c.b0 + (act[u] ? q[u] : 0);
+            const float *lq = c.lut + ((int64_t)(b >> 2) * c.Ks) * (M * 4) + (b & 3);
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const uint32_t code = (cp[u][m / 4] >> (8 * (m % 4))) & 0xffu;
+                vals[u][m] = lq[((int64_t)code * M + m) * 4];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int m = 0; m < M; ++m) ex[u] += vals[u][m];
+    }
+    if (c.skip & 2) return;
+    volatile unsigned long long *gkl = (volatile unsigned long long *)(g_smem + c.gkl_off);
+    volatile unsigned long long *list = (volatile unsigned long long *)g.list;
+    const int row = lane >> 4, li = lane & 15;
+    // the candidates that beat their slot's current bound (own k-th key or the imported one) go to the queue of their
+    // slot's row in LDS; then round t inserts entry t of every queue: no cross-lane traffic inside the loop
+    unsigned long long *qk = g.qkey;                                 // [4][128]
+    volatile unsigned char *qs = (volatile unsigned char *)g.qslot;  // [4][128]
+    volatile unsigned char *chg = (volatile unsigned char *)g.chg;   // [32] slot touched in this batch
+    int cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const unsigned long long key = ((unsigned long long)f32_to_ordered(ex[u]) << 32) | (uint32_t)e[u];
+        bool pend = false;
+        if (act[u]) {
+            unsigned long long kth = list[q[u] * 16 + c.km1];
+            const unsigned long long gk = gkl[q[u]];
+            if (gk < kth) kth = gk;
+            pend = key < kth;
+        }
+        if (pend) chg[q[u]] = 1;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const unsigned long long bm = __ballot(pend && (q[u] & 3) == rr);
+            if (pend && (q[u] & 3) == rr) {
+                const int idx = cnt[rr] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                qk[rr * 128 + idx] = key;
+                qs[rr * 128 + idx] = (unsigned char)q[u];
+            }
+            cnt[rr] += __popcll(bm);
+        }
+    }
+    n_offered += (uint32_t)(cnt[0] + cnt[1] + cnt[2] + cnt[3]);
+    const int mycnt = row == 0 ? cnt[0] : row == 1 ? cnt[1] : row == 2 ? cnt[2] : cnt[3];
+    int rounds = cnt[0] > cnt[1] ? cnt[0] : cnt[1];
+    rounds = rounds > cnt[2] ? rounds : cnt[2];
+    rounds = rounds > cnt[3] ? rounds : cnt[3];
+#pragma unroll 1
+    for (int t = 0; t < rounds; ++t) {
+        const bool valid = t < mycnt;
+        const unsigned long long ckey = ((volatile unsigned long long *)qk)[row * 128 + t];
+        const int cq = qs[row * 128 + t] & 31;
+        const unsigned long long ent = list[cq * 16 + li];
+        const unsigned long long front = __ballot(valid && ent < ckey);  // a prefix of the row (the list is ascending)
+        const int pos = __popc((uint32_t)(front >> (16 * row)) & 0xffffu);
+        const unsigned long long sh = ((unsigned long long)dpp_row_shr1((uint32_t)(ent >> 32)) << 32) | dpp_row_shr1((uint32_t)ent);
+        if (valid && li >= pos) list[cq * 16 + li] = li == pos ? ckey : sh;
+    }
+    const uint32_t changed = (uint32_t)__ballot(lane < 32 && chg[lane & 31] != 0);
+    if (lane < 32) chg[lane] = 0;
+    // publish the bounds of the slots that changed: lane = slot
+    if (lane < 32 && ((changed >> lane) & 1u)) {
+        const int b = c.b0 + lane;
+        const unsigned long long okey = list[lane * 16 + c.km1], jkey = list[lane * 16 + c.jm1];
+        volatile unsigned long long *tau = (volatile unsigned long long *)g.tau;
+        if (okey < tau[lane]) {
+            tau[lane] = okey;
+            if (okey < gkl[lane]) {  // tell the other workgroups of this query (the other row slices)
+                if (c.gkey) __hip_atomic_fetch_min(c.gkey + b, okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gkl[lane] = okey;
+                volatile unsigned char *sp = (volatile unsigned char *)(g_smem + c.shq_off + lane);
+                const unsigned char nb = q8_bound(okey, g.c0[lane], g.c1[lane]);
+                if (nb < *sp) *sp = nb;
+            }
+        }
+        if (c.gk2 && jkey != ~0ull) {  // this slice's j-th key, for the max-of-j-th bound the sibling slices compute
+            volatile unsigned long long *gjl = (volatile unsigned long long *)(g_smem + c.gjl_off + lane * 8);
+            if (jkey < *gjl) {
+                *gjl = jkey;
+                __hip_atomic_store(c.gk2 + (int64_t)b * c.n_slices + c.slice, jkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+// LDS offsets behind the table
+struct Q8Lds {
+    uint32_t shq, ring_ctl, gkl, step, inv, tb, ctl, clip, tau, c0, c1, list, gjl, ring, qkey, qslot, chg;
+    __device__ __forceinline__ explicit Q8Lds(int lut_bytes) {
+        shq = (uint32_t)lut_bytes;
+        ring_ctl = shq + 32;
+        gkl = shq + 192;
+        step = shq + 448;
+        inv = shq + 576;
+        tb = shq + 704;
+        ctl = shq + 736;
+        clip = shq + 768;
+        tau = shq + 896;
+        c0 = shq + 1152;
+        c1 = shq + 1408;
+        list = shq + 1664;
+        gjl = list + 32 * 128;
+        ring = gjl + 32 * 8;
+        qkey = ring + 1024 * 8;
+        qslot = qkey + 4 * 128 * 8;
+        chg = qslot + 4 * 128;
+    }
+};
+
+// (Re)build of a workgroup's table: slot parameters (one thread per slot) from the best bound known for the query, then
+// the byte table.  Out of line on purpose: it runs a dozen times per work item, and inlined into the step loop its 40
+// live registers made the compiler spill the loop-invariant LDS base registers of the look-ups into the hot path.
+template <int M, int NW>
+__device__ __attribute__((noinline)) void q8_rebuild(const Q8Build a, int tile, int first) {
+    constexpr int QT = 32;
+    const int tid = threadIdx.x;
+    const Q8Lds o(a.Ks * 2 * M * 16);
+    unsigned char *smem = g_smem;
+    if (tid < QT) {
+        unsigned long long *gkl = (unsigned long long *)(smem + o.gkl);
+        const int b = tile * QT + tid;
+        const bool real = b < a.B;
+        unsigned long long key = ~0ull;
+        if (first) {
+            if (a.gkey && real) key = __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gkl[tid] = key;
+            ((unsigned long long *)(smem + o.gjl))[tid] = ~0ull;
+            ((unsigned long long *)(smem + o.tau))[tid] = ~0ull;
+            smem[o.chg + tid] = 0;
+        } else {
+            key = ((const unsigned long long *)(smem + o.tau))[tid];
+            const unsigned long long g = gkl[tid];
+            if (g < key) key = g;
+        }
+        float step, inv, clip;
+        unsigned char tb;
+        q8_slot_params<M>(real, key, real ? a.qstep[b] * (float)(32767 / M) : 0.f, real ? a.smax[b] : 0.f,
+                          real ? a.qlo[b] : 0.0, step, inv, clip, tb);
+        ((volatile float *)(smem + o.step))[tid] = step;
+        ((float *)(smem + o.inv))[tid] = inv;
+        ((float *)(smem + o.clip))[tid] = clip;
+        {
+            const double slack = real ? (double)a.smax[b] * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0)) : 0.0;
+            const double c1 = (1.0 + 1.0 / 524288.0) / (double)step;
+            ((double *)(smem + o.c1))[tid] = c1;
+            ((double *)(smem + o.c0))[tid] = (slack - (real ? a.qlo[b] : 0.0)) * c1;
+        }
+        ((volatile unsigned char *)(smem + o.shq))[tid] = tb;
+        ((volatile unsigned char *)(smem + o.tb))[tid] = tb;
+    }
+    __syncthreads();
+    q8_build_table<M, NW>(a, tile, smem, (const float *)(smem + o.inv), (const float *)(smem + o.clip), tid);
+    __syncthreads();
+}
+
+// work item -> (query tile, row slice).  item % 8 == the XCD the block lands on (speed only).  With >= 8 query tiles an
+// XCD owns the tiles congruent to it, for ALL row slices: the fp32 tables the exact sums gather from (16 KB per query,
+// 512 KB per tile) stay in that XCD's 4 MB L2 -- with the slice-per-XCD map of the u16 kernels (item_map) every XCD saw
+// all the tables of the batch (16 MB at 1024 queries) and each of a candidate's 16 gathers was a cache-line fetch from
+// the fabric: ~190 ns per candidate, the consumer wave's whole budget.  The code rows are then read by every XCD
+// (8 x the table per launch, 1.3 GB at 10M rows: a fraction of a ms of HBM / Infinity Cache bandwidth).
+__device__ __forceinline__ bool q8_item_map(const ScanArgs &a, int item, int &tile, int &slice) {
+    if (a.n_tiles < 8) return item_map(a, item, tile, slice);
+    const int xcd = item & 7, j = item >> 3;
+    const int tpx = (a.n_tiles + 7) >> 3;
+    slice = j / tpx;
+    tile = xcd + 8 * (j - slice * tpx);
+    return tile < a.n_tiles && slice < a.n_slices;
+}
+
+template <int M, int NW, bool SKEWED>
+__global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const ScanArgs a) {
+    constexpr int QG = 16, NQ = 2, QT = QG * NQ, CW = M / 4, EB = 16, RB = M * EB, KSTRIDE = NQ * RB;
+    constexpr int NS = NW - 1;  // scanning waves; wave NS is the consumer
+    static_assert(M % 8 == 0 && M <= 32 && (KSTRIDE & (KSTRIDE - 1)) == 0, "unsupported shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int km1 = a.k - 1;
+
+    const int lut_bytes = a.Ks * KSTRIDE;
+    const Q8Lds lds(lut_bytes);
+    const uint32_t shq_off = lds.shq, ring_ctl_off = lds.ring_ctl, gkl_off = lds.gkl, step_off = lds.step, tb_off = lds.tb,
+                   ctl_off = lds.ctl, list_off = lds.list, gjl_off = lds.gjl, ring_off = lds.ring;
+    unsigned long long *gkl = (unsigned long long *)(smem + gkl_off);
+    volatile unsigned char *shq = (volatile unsigned char *)(smem + shq_off);
+    volatile unsigned char *s_tb = (volatile unsigned char *)(smem + tb_off);
+    volatile uint32_t *s_ctl = (volatile uint32_t *)(smem + ctl_off);
+    unsigned long long *lists = (unsigned long long *)(smem + list_off);
+    const Q8Build ba = {a.lut, a.qlom, a.qstep, a.smax, a.qlo, a.gkey, a.Ks, a.B, a.k};
+    Q8Ring ring;
+    ring.tail = (volatile uint32_t *)(smem + ring_ctl_off);
+    ring.head = (volatile uint32_t *)(smem + ring_ctl_off + 4);
+    ring.arrived = (volatile uint32_t *)(smem + ring_ctl_off + 8);
+    ring.slots = (unsigned long long *)(smem + ring_off);
+
+    for (int it = 0;; ++it) {
+        const int item = blockIdx.x + it * gridDim.x;
+        if (item >= a.n_items) break;
+        int tile, slice;
+        if (!q8_item_map(a, item, tile, slice)) continue;
+        const int64_t slice_begin = (int64_t)slice * a.slice_rows;
+        int64_t slice_end = slice_begin + a.slice_rows;
+        if (slice_end > a.N) slice_end = a.N;
+        const int64_t stride = (int64_t)NS * 64;
+        const int n_steps = slice_end > slice_begin ? (int)((slice_end - slice_begin + stride - 1) / stride) : 0;
+
+        __syncthreads();  // every wave is done with the previous item
+        // end of an epoch (all waves): the consumer arrives last, with every pushed candidate in the lists.  Then: have
+        // the bounds outrun the table?  A slot's T falls as its threshold tightens under a fixed step; rebuild when a
+        // quarter of the real slots are below 3/4 of what their table was built for.
+        auto epoch_sync = [&](bool final) {
+            __syncthreads();
+            if (final) return;
+            if (wave == 0) {
+                const int q = lane & 31;
+                const bool real = tile * QT + q < a.B && lane < 32;
+                const uint32_t tn = shq[q] & 0x7fu, tb = s_tb[q] & 0x7fu;
+                const bool need = real && tn * 8u < tb * 7u;
+                const int n_need = __popcll(__ballot(need)), n_real = __popcll(__ballot(real));
+                if (lane == 0) *s_ctl = (n_need > 0 && n_need * 4 >= n_real) ? 1u : 0u;
+            }
+            __syncthreads();
+            if (*s_ctl) {
+                q8_rebuild<M, NW>(ba, tile, 0);
+                if (a.dbg && tid == 0) atomicAdd(a.dbg + 5, 1ull);
+            }
+        };
+        for (int idx = tid; idx < QT * 16; idx += NW * 64) lists[idx] = ~0ull;
+        for (int idx = tid; idx < kRingSize; idx += NW * 64) ring.slots[idx] = ~0ull;
+        if (tid == 0) {
+            *ring.tail = 0;
+            *ring.head = 0;
+            *ring.arrived = 0;
+        }
+        q8_rebuild<M, NW>(ba, tile, 1);  // (its barriers cover the initialisation above)
+
+        // epochs end after steps 1, 3, 7, 15, ... (bounds move on a log scale) and after the last step
+        if (wave == NS) {
+            // ------------------------------------------------------------------------------- consumer wave
+            const FlushCtx fc = {(const uint8_t *)a.codes, a.lut, a.smax, a.qstep, a.qlo, a.gkey, a.gk2, nullptr,
+                                 a.Ks, tile * QT, a.n_slices, slice, km1, a.jm1, a.dbg_skip,
+                                 list_off, 0u, shq_off, gkl_off, gjl_off, step_off};
+            // what the other workgroups of these queries (the other row slices) have proven: the best k-th key any of
+            // them published and, per group of 8 concurrently scanned slices, the MAX of their j-th keys (8 disjoint
+            // slices x j rows >= k rows at or below it; +1: that row itself must still be accepted)
+            auto import_bounds = [&]() {
+                if (!a.gkey) return;
+                // lane = (slot, half): its slot's published k-th key and the j-th keys of four slices, all loads in flight
+                // together -- one global round trip per group of 8 slices for the whole tile
+                const int q = lane & 31, part = lane >> 5;
+                const int b = tile * QT + q;
+                const bool real = b < a.B;
+                unsigned long long bound = ~0ull;
+                if (real) bound = __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.gk2) {
+#pragma unroll 1
+                    for (int g0 = 0; g0 < a.n_slices; g0 += 8) {
+                        unsigned long long v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int sl = g0 + part * 4 + i;
+                            v[i] = 0ull;  // slices beyond n_slices never set the max
+                            if (real && sl < a.n_slices)
+                                v[i] = __hip_atomic_load(a.gk2 + (int64_t)b * a.n_slices + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        unsigned long long m = v[0] > v[1] ? v[0] : v[1];
+                        const unsigned long long m2 = v[2] > v[3] ? v[2] : v[3];
+                        m = m > m2 ? m : m2;
+                        const unsigned long long o = __shfl_xor(m, 32);
+                        m = o > m ? o : m;
+                        if (m != ~0ull && m + 1ull < bound) bound = m + 1ull;
+                    }
+                }
+                if (real && part == 0 && bound < gkl[q]) {
+                    gkl[q] = bound;
+                    const unsigned char nb = q8_bound(bound, ((volatile const double *)(smem + lds.c0))[q], ((volatile const double *)(smem + lds.c1))[q]);
+                    if (nb < shq[q]) shq[q] = nb;
+                }
+            };
+            Q8Lists bags;
+            bags.list = lists;
+            bags.tau = (unsigned long long *)(smem + lds.tau);
+            bags.c0 = (const double *)(smem + lds.c0);
+            bags.c1 = (const double *)(smem + lds.c1);
+            bags.qkey = (unsigned long long *)(smem + lds.qkey);
+            bags.qslot = smem + lds.qslot;
+            bags.chg = smem + lds.chg;
+            uint32_t head = 0, n_kept = 0, n_offered = 0;
+            unsigned long long t_busy = 0;
+            uint32_t n_batches = 0;
+            int epoch = 0, epoch_step = a.q8_epoch0;  // the current epoch ends after step `epoch_step` (the last: after step n_steps - 1)
+            for (;;) {
+                const bool final = epoch_step >= n_steps - 1;
+                const uint32_t want = (uint32_t)NS * (uint32_t)(epoch + 1);  // `arrived` is cumulative over the item
+                int idle = 0;
+                import_bounds();
+                for (;;) {
+                    const uint32_t arrived = *ring.arrived;  // (read BEFORE the tail: a wave pushes, then arrives)
+                    const uint32_t tail = *ring.tail;
+                    const int avail = (int)(tail - head);
+                    if (avail > 0) {
+                        const int n = avail < 128 ? avail : 128;
+                        const unsigned long long t0 = a.dbg ? __builtin_readcyclecounter() : 0ull;
+                        __builtin_amdgcn_s_setprio(3);  // (serial code on a SIMD shared with three or four scanning waves)
+                        q8_consume<M, SKEWED>(fc, ring, bags, head, n, lane, n_kept, n_offered);
+                        __builtin_amdgcn_s_setprio(0);
+                        ++n_batches;
+                        if (a.dbg) t_busy += __builtin_readcyclecounter() - t0;
+                        head += (uint32_t)n;
+                        idle = 0;
+                        if ((n_batches & (uint32_t)a.q8_import_mask) == 0) import_bounds();  // (the other slices' progress)
+                        continue;
+                    }
+                    if (arrived == want) break;
+                    if ((++idle & 15) == 8) import_bounds();
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                epoch_sync(final);
+                if (final) break;
+                ++epoch;
+                epoch_step = a.q8_epoch_mul * epoch_step + (a.q8_epoch_mul - 1);
+            }
+            if (a.dbg && lane == 0) {  // ANNLITE_DEBUG_COUNTERS: [2] exact sums, [3] candidates that went into a list's queue,
+                atomicAdd(a.dbg + 2, (unsigned long long)n_kept);     // [4] consumer cycles inside batches, [6] batches
+                atomicAdd(a.dbg + 3, (unsigned long long)n_offered);
+                atomicAdd(a.dbg + 4, t_busy);
+                atomicAdd(a.dbg + 6, (unsigned long long)n_batches);
+            }
+        } else {
+            // ------------------------------------------------------------------------------- scanning waves
+            const int s = lane % M;
+            const uint32_t bsh = (uint32_t)(s & 3);
+            bool abit[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) abit[i] = (((s >> 2) >> i) & 1) != 0;
+            const unsigned char *mbase[M];
+#pragma unroll
+            for (int t = 0; t < M; ++t) mbase[t] = smem + ((s + t) % M) * EB;
+            const uint32_t *codes32 = (const uint32_t *)a.codes;
+            // rows are < 2^32 per call (plan): 32-bit row arithmetic keeps the loop control in SGPRs
+            const uint32_t s_end = (uint32_t)slice_end, stride32 = (uint32_t)stride, n_rows = (uint32_t)a.N;
+            uint32_t row0 = (uint32_t)slice_begin + (uint32_t)wave * 64u;
+            uint32_t ccur[CW], cnext[CW];
+            const unsigned char *addr[M];
+            auto load_row = [&](uint32_t row, uint32_t (&c)[CW]) {
+                if (row >= n_rows) row = n_rows - 1;
+                const uint32_t *p = codes32 + (int64_t)row * CW;
+                if constexpr (CW == 2) {
+                    const u32x2 v = *(const u32x2 *)p;
+                    c[0] = v.x;
+                    c[1] = v.y;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < CW / 4; ++i) {
+                        const u32x4 v = *(const u32x4 *)(p + 4 * i);
+                        c[4 * i + 0] = v.x;
+                        c[4 * i + 1] = v.y;
+                        c[4 * i + 2] = v.z;
+                        c[4 * i + 3] = v.w;
+                    }
+                }
+            };
+            auto make_addr = [&](const uint32_t (&cc)[CW]) {
+                static_for<0, CW>([&](auto W) {
+                    constexpr int w = decltype(W)::value;
+                    uint32_t o0, o1, o2, o3;
+                    byte_shl4(cc[w], (uint32_t)ilog2_c(KSTRIDE), o0, o1, o2, o3);
+                    addr[4 * w + 0] = mbase[4 * w + 0] + o0;
+                    addr[4 * w + 1] = mbase[4 * w + 1] + o1;
+                    addr[4 * w + 2] = mbase[4 * w + 2] + o2;
+                    addr[4 * w + 3] = mbase[4 * w + 3] + o3;
+                });
+            };
+            // byte sums of the row for both entry groups (4 dwords x 4 x u8 each): the 2 M look-ups run through a ring of
+            // DEPTH landing registers -- look-up i + DEPTH is issued as soon as look-up i has been added (all M look-ups
+            // of a group in flight, as the u16 kernel has them, takes 64 landing VGPRs: with them the allocator spilled
+            // six of the 16 loop-invariant LDS base registers into the step loop)
+            auto row_sums = [&](u32x4 (&acc)[NQ]) {
+                constexpr int DEPTH = ANNLITE_Q8_DEPTH, TOT = NQ * M;
+                u32x4 v[DEPTH];
+                static_for<0, DEPTH>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    v[i] = *(const u32x4 *)(addr[i % M] + (i / M) * RB);
+                });
+                static_for<0, TOT>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    asm volatile("" ::: "memory");
+                    if constexpr (i % M == 0) acc[i / M] = v[i % DEPTH];
+                    else acc[i / M] += v[i % DEPTH];
+                    if constexpr (i + DEPTH < TOT) {
+                        constexpr int j = i + DEPTH;
+                        v[i % DEPTH] = *(const u32x4 *)(addr[j % M] + (j / M) * RB);
+                    }
+                });
+            };
+            u32x4 thp[NQ];  // packed (0x80 | T) of the group's 16 queries
+#pragma unroll
+            for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
+            uint32_t vcur = ~0u, vnext = ~0u;
+            const uint32_t *valid = a.valid;
+            auto load_valid = [&](uint32_t row) -> uint32_t {
+                if (!valid) return ~0u;
+                if (row >= n_rows) row = n_rows - 1;
+                return valid[row >> 5];
+            };
+            if (row0 < s_end) {
+                load_row(row0 + lane, ccur);
+                if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
+                load_row(row0 + stride32 + lane, cnext);
+                vcur = load_valid(row0 + lane);
+                vnext = load_valid(row0 + stride32 + lane);
+            }
+            // Every scanning wave runs the same n_steps iterations, cut into epochs that end after steps 1, 3, 7, 15, ...
+            // and after the last one (the epochs' barriers meet).  The step loop of an epoch contains no call and no
+            // barrier: the loop-invariant registers stay put.
+            int step_no = 0;
+            uint32_t n_slow = 0, n_push = 0;
+            unsigned long long t_wait = 0;
+            for (int epoch_step = a.q8_epoch0;; epoch_step = a.q8_epoch_mul * epoch_step + (a.q8_epoch_mul - 1)) {
+                const bool final = epoch_step >= n_steps - 1;
+                const int epoch_end = final ? n_steps - 1 : epoch_step;  // inclusive
+                for (; step_no <= epoch_end; ++step_no, row0 += stride32) {
+                    if (row0 < s_end) {
+                        unsigned long long vmask = ~0ull;
+                        if (s_end - row0 < 64u) vmask = (1ull << (s_end - row0)) - 1ull;
+                        // validity word of this lane's row, fetched one step ahead with the code bytes
+                        if (valid) vmask &= __ballot((vcur >> (lane & 31)) & 1u);
+                        const uint32_t rid = row0 + (uint32_t)lane;
+                        make_addr(ccur);
+                        u32x4 acc[NQ];
+                        row_sums(acc);
+                        // any (query, lane) with S <= T ?  S < 128 and (0x80 | T) - (S & 0x7f) has bit 7 set (T <= 127: no borrow)
+                        uint32_t anyv = 0;
+#pragma unroll
+                        for (int h = 0; h < NQ; ++h)
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) anyv |= (thp[h][w] - (acc[h][w] & 0x7f7f7f7fu)) & ~acc[h][w];
+                        const unsigned long long anym = __ballot((anyv & 0x80808080u) != 0) & vmask;
+                        if (anym && !(a.dbg_skip & 4)) {
+                            ++n_slow;
+                            // push (slot, row, S) of every lane that passed: dword by dword, byte by byte
+                            static_for<0, NQ * 4>([&](auto HW) {
+                                constexpr int h = decltype(HW)::value / 4, w = decltype(HW)::value % 4;
+                                const uint32_t sw = acc[h][w];
+                                const uint32_t x = (thp[h][w] - (sw & 0x7f7f7f7fu)) & ~sw & 0x80808080u;
+                                if (__ballot(x != 0) & vmask) {
+                                    static_for<0, 4>([&](auto BY) {
+                                        constexpr int by = decltype(BY)::value;
+                                        constexpr uint32_t q0 = h * 16 + w * 4 + by;
+                                        const unsigned long long pm = __ballot((x & (0x80u << (8 * by))) != 0) & vmask;
+                                        if (pm) {
+                                            const int n = __popcll(pm);
+                                            n_push += (uint32_t)n;
+                                            uint32_t pos = 0;
+                                            if (lane == 0) pos = atomicAdd((uint32_t *)ring.tail, (uint32_t)n);
+                                            pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+                                            while ((int)(pos + (uint32_t)n - *ring.head) > a.q8_ring_limit)  // the consumer is behind
+                                                __builtin_amdgcn_s_sleep(8);
+                                            const int rank = __builtin_amdgcn_mbcnt_hi(
+                                                (uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                                            const uint32_t sv = (sw >> (8 * by)) & 0xffu;  // (the consumer re-checks it)
+                                            if ((pm >> lane) & 1ull)
+                                                ring.slots[(pos + (uint32_t)rank) & (kRingSize - 1)] =
+                                                    ((unsigned long long)((sv << 8) | q0) << 32) | rid;
+                                        }
+                                    });
+                                }
+                            });
+                        }
+                        // next row
+#pragma unroll
+                        for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
+                        if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
+                        load_row(row0 + 2 * stride32 + lane, cnext);
+                        vcur = vnext;
+                        vnext = load_valid(row0 + 2 * stride32 + lane);
+                    }
+                    // pick up the workgroup's bounds every 2nd step
+                    if (step_no & 1) {
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
+                    }
+                }
+                if (lane == 0) atomicAdd((uint32_t *)ring.arrived, 1u);
+                const unsigned long long tw = a.dbg ? __builtin_readcyclecounter() : 0ull;
+                epoch_sync(final);
+                if (a.dbg) t_wait += __builtin_readcyclecounter() - tw;
+                if (final) break;
+#pragma unroll
+                for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
+            }
+            if (a.dbg && lane == 0) {  // [0] wave-steps with a candidate, [1] entries pushed, [7] wave 0's cycles at epoch ends
+                atomicAdd(a.dbg + 0, (unsigned long long)n_slow);
+                atomicAdd(a.dbg + 1, (unsigned long long)n_push);
+                if (wave == 0) atomicAdd(a.dbg + 7, t_wait);
+            }
+        }
+
+        // ---- the lists ARE the workgroup's result for this (tile, slice) ----------------------
+        // (the final epoch_sync was the barrier: every candidate is in)
+        for (int q = wave; q < QT; q += NW) {
+            const int b = tile * QT + q;
+            // device-scope stores: the merging workgroup may sit on another XCD (own L2)
+            if (b < a.B && lane <= km1)
+                __hip_atomic_store(a.partial + ((int64_t)b * a.n_slices + slice) * a.k + lane, lists[q * 16 + lane],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (a.tile_done) {
+            // the last of the tile's n_slices workgroups to arrive merges them
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have completed
+            __syncthreads();
+            volatile unsigned int *s_flag = (volatile unsigned int *)(smem + ctl_off + 4);
+            if (tid == 0) {
+                const unsigned int old =
+                    __hip_atomic_fetch_add(a.tile_done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *s_flag = (old + 1u == (unsigned int)(a.n_slices - 1)) ? 1u : 0u;
+            }
+            __syncthreads();
+            if (*s_flag) merge_tile_slices<NW>(a, tile * QT, QT, km1, wave, lane, (unsigned long long *)(smem + ring_off));
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace annlite
+
+using namespace annlite;
+
+template <int M, int NW, bool SKEWED>
+static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
+    constexpr int QT = 32;
+    const size_t need = (size_t)a.Ks * 2 * M * 16 + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32;
+    auto fn = adc_scan_q8_kernel<M, NW, SKEWED>;
+    ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
+    return launch_status("adc_scan_q8_kernel");
+}
+
+int annlite::launch_q8_scan(int id, bool sk, const ScanArgs &a, int grid, hipStream_t st) {
+    switch (id) {
+        case 1650: return sk ? launch_q8<16, 16, true>(a, grid, st) : launch_q8<16, 16, false>(a, grid, st);
+        default: set_error("no byte-table kernel with id %d", id); return ANNLITE_ERR_UNSUPPORTED;
+    }
+}

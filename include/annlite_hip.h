@@ -90,6 +90,9 @@ typedef struct annlite_scan_plan {
 
 ANNLITE_API int annlite_scan_plan_query(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t k,
                             annlite_scan_plan *plan);
+/* the plan annlite_pq_search_tiles() runs with for V scan slots (its query tiles hold plan.qt slots each) */
+ANNLITE_API int annlite_scan_plan_tiles(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t V, int64_t k,
+                            annlite_scan_plan *plan);
 
 /* ------------------------------------------------------------------------------------------------
  * LUT construction.
@@ -205,9 +208,15 @@ ANNLITE_API int annlite_adc_scan_candidates(const void *codes_dev, int code_byte
  * launch stream; annlite_profile_last_scan_ms() waits for the last one and returns its duration. */
 ANNLITE_API int annlite_profile_enable(int on);
 ANNLITE_API int annlite_profile_last_scan_ms(float *ms);
-/* Debug aid: with ANNLITE_DEBUG_COUNTERS=1 in the environment the quantised-filter scan counts
- * [0] slow-block entries [1] (wave,query) candidate events [2] events that inserted [3] bound
- * publications [4] candidate rows; this copies the 8 uint64 counters of the last scan to the host. */
+/* Kernel selection on the calling thread (A/B measurements; the index plug-in's calibration): variant 0 = the
+ * default plan, 31 = u16 filter tables, 50 = byte filter tables (M = 16), others: DESIGN.md; -1 = follow the
+ * ANNLITE_SCAN_VARIANT environment variable (the initial state).  Plans and workspace sizes follow the selection. */
+ANNLITE_API int annlite_scan_select_variant(int variant);
+/* Debug aid: with ANNLITE_DEBUG_COUNTERS=1 in the environment the scan counts events; this copies the 8 uint64
+ * counters of the last scan to the host.  u16 kernels: [0] slow-block entries [1] (wave,query) candidate events
+ * [2] events that inserted [3] bound publications [4] candidate rows.  Byte-table kernel: [0] wave-steps with a
+ * candidate [1] candidates pushed [2] exact sums [3] candidates queued for a list [4] consumer-wave cycles inside
+ * batches [5] table rebuilds [6] consumer batches [7] cycles of wave 0 at epoch ends. */
 ANNLITE_API int annlite_debug_counters(uint64_t *out8);
 
 /* Convert between the PLAIN and the SKEWED code-table layout (uint8 codes).

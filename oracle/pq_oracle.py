@@ -334,6 +334,25 @@ def decode_numpy(codes, codebooks):
     return out
 
 
+def pqindex_search_reference_style(adtable, codes, k):
+    """ONE query the way the reference's flat index materialises it (annlite/core/index/pq_index.py:46-49 on top of
+    bindings/pq_bindings.pyx:75-80): the ADC kernel's result becomes a Python LIST of N floats, `np.expand_dims` turns
+    the list into a float64 array, `math.top_k` (math.py:94-120: argpartition + argsort) selects.  Only used to time
+    that overhead next to the kernel-only figure (bench.py cpu_baseline); tie order follows numpy, as in the reference."""
+    dists = dist_pqcodes_to_codebooks_c(adtable, codes).tolist()   # vector<float> -> list (pyx:75-80)
+    dists = np.expand_dims(dists, axis=0)                          # pq_index.py:47
+    if k >= dists.shape[1]:
+        idx = dists.argsort(axis=1)[:, :k]
+        vals = np.take_along_axis(dists, idx, axis=1)
+    else:
+        idx_ps = dists.argpartition(kth=k, axis=1)[:, :k]
+        vals = np.take_along_axis(dists, idx_ps, axis=1)
+        idx_fs = vals.argsort(axis=1)
+        idx = np.take_along_axis(idx_ps, idx_fs, axis=1)
+        vals = np.take_along_axis(vals, idx_fs, axis=1)
+    return vals[0], idx[0]
+
+
 # ------------------------------------------------------------------------------------------------
 # end-to-end search semantics the drop-in index mirrors
 # ------------------------------------------------------------------------------------------------

@@ -30,7 +30,7 @@ def main():
     args = p.parse_args()
     from annlite_amd import Metric, PQCodec, ops
     from annlite_amd import _capi
-    from annlite_amd._capi import CODES_SKEWED, scan_plan
+    from annlite_amd._capi import CODES_SKEWED, scan_plan, scan_plan_tiles
     from annlite_amd.core.codec.vq import VQCodec
     from annlite_amd.core.index.ivf_pq_gpu import IvfPQGpuIndex
 
@@ -113,7 +113,7 @@ def main():
         q = idx._pre(queries)
         st = {}
         st['select'], cells = timed(lambda: idx.probe_cells(q, P))
-        qt = scan_plan(idx._n_table, M, Ks, 1, 16, k).qt
+        qt = scan_plan_tiles(idx._n_table, M, Ks, 1, 16, k).qt
         st['plan'], (vmap, slot_of, tile_rows, used) = timed(lambda: ops.ivf_plan(cells, C, qt, idx._cell_rows, idx._cell_order))
         kind, xq = codec.scan_inputs(q)
         st['tables_scan'], (cand, count) = timed(lambda: ops.pq_search_tiles(

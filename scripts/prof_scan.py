@@ -24,6 +24,8 @@ p.add_argument('--iters', type=int, default=5)
 p.add_argument('--layout', type=int, default=1)
 p.add_argument('--valid', action='store_true', help='pass an all-ones validity bitmap (what the index plugin does)')
 p.add_argument('--fused', action='store_true', help='annlite_pq_search_topk (tables built inside)')
+p.add_argument('--data', choices=['random', 'lowrank'], default='random',
+               help="random: uniform codes + gaussian codebooks; lowrank: the bench's data (rank-16 latent + noise, trained codec)")
 a = p.parse_args()
 torch.cuda.set_device(0)
 dev = torch.device('cuda', 0)
@@ -31,9 +33,28 @@ g = torch.Generator(device=dev)
 g.manual_seed(0)
 N, M, Ks, B, k = a.rows, a.m, 256, a.batch, a.k
 D = M * 8
-codes = torch.randint(0, 256, (N, M), generator=g, device=dev, dtype=torch.uint8)
-cb = torch.randn((M, Ks, D // M), generator=g, device=dev)
-q = torch.randn((B, D), generator=g, device=dev)
+if a.data == 'random':
+    codes = torch.randint(0, 256, (N, M), generator=g, device=dev, dtype=torch.uint8)
+    cb = torch.randn((M, Ks, D // M), generator=g, device=dev)
+    q = torch.randn((B, D), generator=g, device=dev)
+else:
+    from annlite_amd import Metric, PQCodec
+    A = torch.randn((16, D), generator=g, device=dev)
+
+    def gen(n):
+        return (torch.randn((n, 16), generator=g, device=dev) @ A + 0.05 * torch.randn((n, D), generator=g, device=dev)).contiguous()
+
+    codec = PQCodec(dim=D, n_subvectors=M, n_clusters=Ks, metric=Metric.EUCLIDEAN, n_init=1)
+    codec.seed = 7
+    codec.fit(gen(20480), iter=20)
+    cb = codec.codebooks_dev
+    codes = torch.empty((N, M), dtype=torch.uint8, device=dev)
+    for c0 in range(0, N, 500_000):
+        n = min(500_000, N - c0)
+        codes[c0:c0 + n] = ops.pq_encode(gen(n), cb)
+    q = gen(B)
+    if a.layout == 1:
+        codes = ops.codes_skew(codes)
 plan = scan_plan(N, M, Ks, 1, B, k)
 ws = ops.ScanWorkspace()
 valid = torch.full(((N + 31) // 32 + 1,), -1, dtype=torch.int32, device=dev) if a.valid else None
@@ -50,7 +71,13 @@ torch.cuda.synchronize()
 look = B * N * M
 print('scan kernel ms:', ['%.3f' % x for x in ms], ' lookups/s %.3e' % (look / (min(ms) * 1e-3)), ' alg GB/s %.1f' % (look / (min(ms) * 1e-3) / 1e9))
 
-if os.environ.get('ANNLITE_DEBUG_COUNTERS'):
+if os.environ.get('ANNLITE_DEBUG_COUNTERS') and plan.qt == 32:
+    c = _capi.debug_counters()
+    nwg = 256
+    print('byte-table kernel: wave-steps with candidates %d, pushed %d, exact sums %d, queued for a list %d, table rebuilds %d, consumer batches %d; '
+          'per workgroup: consumer inside batches %.1f us, wave 0 at epoch ends %.1f us' % (c[0], c[1], c[2], c[3], c[5], c[6], c[4] / nwg / 2400., c[7] / nwg / 2400.))
+elif os.environ.get('ANNLITE_DEBUG_COUNTERS'):
     c = _capi.debug_counters()
     n_wave_steps = (N // 64) * ((B + plan.qt - 1) // plan.qt)
-    print('counters: slow-block entries %d, events %d, inserting events %d, publications %d, candidate rows %d ; wave-steps %d' % (c[0], c[1], c[2], c[3], c[4], n_wave_steps))
+    print('counters: slow-block entries %d, events %d, inserting events %d, publications %d, candidate rows %d ; wave-steps %d'
+          ' ; table rebuilds %d, ring-full waits %d, consumer batches %d' % (c[0], c[1], c[2], c[3], c[4], n_wave_steps, c[5], c[6], c[7]))

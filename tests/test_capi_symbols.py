@@ -30,7 +30,7 @@ def test_scan_plan_arithmetic_no_gpu():
     from annlite_amd import _capi
 
     p = _capi.scan_plan(10_000_000, 16, 256, 1, 1024, 10)
-    assert (p.fast, p.qi) == (1, 4) and p.qt in (8, 16) and p.waves in (8, 12, 16) and (p.n_slices in (1, 2, 4) or p.n_slices % 8 == 0)
+    assert (p.fast, p.qi) == (1, 4) and p.qt in (8, 16, 32) and p.waves in (8, 12, 16) and (p.n_slices in (1, 2, 4) or p.n_slices % 8 == 0)
     assert p.lut_floats == 1024 * 16 * 256
     assert p.workspace_bytes >= 1024 * p.n_slices * 10 * 8
     p = _capi.scan_plan(1000, 64, 256, 1, 3, 10)
