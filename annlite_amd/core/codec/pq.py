@@ -134,10 +134,44 @@ class PQCodec(BaseCodec):
             cb[m] = x[idx, m * ds:(m + 1) * ds]
         return cb
 
+    def _kmeanspp_centres(self, x: torch.Tensor, gen: torch.Generator) -> torch.Tensor:
+        """k-means++ seeding (sklearn's default ``init`` behind pq.py:106-110), all M sub-spaces at once: every next
+        centre is drawn with probability proportional to the squared distance to the nearest centre chosen so far,
+        the best of ``2 + log(Ks)`` draws per step (sklearn's greedy variant).  Batched tensor ops on the device, no
+        host synchronisation inside the Ks steps."""
+        N = x.shape[0]
+        M, Ks, ds = self.n_subvectors, self.n_clusters, self.d_subvector
+        assert N >= Ks, f'n_samples={N} should be >= n_clusters={Ks}'  # sklearn raises ValueError here
+        dev = x.device
+        xs = x.reshape(N, M, ds).permute(1, 0, 2).contiguous()  # [M, N, ds]
+        x2 = (xs * xs).sum(2)  # [M, N]
+        cb = torch.empty((M, Ks, ds), dtype=torch.float32, device=dev)
+        ar = torch.arange(M, device=dev)
+        first = torch.randint(0, N, (M,), generator=gen, device=dev)
+        cb[:, 0] = xs[ar, first]
+        d2 = ((xs - cb[:, :1]) ** 2).sum(2)  # [M, N]
+        trials = 2 + int(np.log(Ks))
+        for c in range(1, Ks):
+            total = d2.sum(1, keepdim=True)
+            # (fewer distinct rows than centres: distances all zero -> uniform draws)
+            prob = torch.where(total > 0, d2 / total.clamp(min=1e-30), torch.full_like(d2, 1.0 / N))
+            cand = torch.multinomial(prob, trials, replacement=True, generator=gen)  # [M, trials]
+            xc = torch.gather(xs, 1, cand[:, :, None].expand(M, trials, ds))  # [M, trials, ds]
+            dist = (x2[:, None, :] + (xc * xc).sum(2)[:, :, None] - 2.0 * torch.bmm(xc, xs.transpose(1, 2))).clamp_(min=0.0)
+            dc = torch.minimum(d2[:, None, :], dist)  # [M, trials, N]
+            best = torch.argmin(dc.sum(2), dim=1)  # [M]
+            cb[:, c] = xc[ar, best]
+            d2 = dc[ar, best]
+        return cb
+
+    def _init_centres(self, x: torch.Tensor, gen: torch.Generator) -> torch.Tensor:
+        return self._random_centres(x, gen) if getattr(self, 'init', 'k-means++') == 'random' else self._kmeanspp_centres(x, gen)
+
     def fit(self, x, iter: int = 100):
         """Train one k-means per sub-space (pq.py:89-115: sklearn ``KMeans(n_clusters, max_iter=iter,
         n_init)``).  Lloyd iterations run on the GPU: assignment + accumulation is ONE kernel over all
-        sub-spaces (``annlite_kmeans_assign_accumulate``), the update another.  ``n_init`` restarts,
+        sub-spaces (``annlite_kmeans_assign_accumulate``), the update another.  k-means++ seeding (sklearn's default;
+        ``self.init = 'random'`` for random rows), ``n_init`` restarts,
         best inertia kept per sub-space, early stop on centre shift <= 1e-4 * mean variance (sklearn's
         ``tol``).  Like the reference the result is not bit-reproducible unless ``self.seed`` is set."""
         if _is_np(x):
@@ -163,7 +197,7 @@ class PQCodec(BaseCodec):
         counts = torch.empty((M, Ks), dtype=torch.int32, device=dev)
         inertia = torch.empty((M,), dtype=torch.float64, device=dev)
         for _ in range(max(1, int(self.n_init))):
-            cb = self._random_centres(x, gen)
+            cb = self._init_centres(x, gen)
             for it in range(max(1, int(iter))):
                 sums.zero_(); counts.zero_(); inertia.zero_()
                 ops.kmeans_assign_accumulate(x, cb, sums, counts, inertia)
@@ -205,7 +239,7 @@ class PQCodec(BaseCodec):
                 gen.manual_seed(int(self.seed))
             else:
                 gen.seed()
-            centres = self._random_centres(x, gen)
+            centres = self._init_centres(x, gen)
             sums = torch.zeros((M, Ks, ds), dtype=torch.float32, device=dev)
             counts = torch.zeros((M, Ks), dtype=torch.int32, device=dev)
             self._pf = (centres, sums, counts)
@@ -291,7 +325,14 @@ class PQCodec(BaseCodec):
         assert x.ndim == 2
         N, D = x.shape
         assert D == self.d_subvector * self.n_subvectors, 'input dimension must be Ds * M'
-        out = self._dist_mat_dev(ops.to_dev(x), LAYOUT_BMK)
+        if _is_np(x) and self.normalize_input:
+            # host buffers: the normalisation of pq.py:309-310 in the reference's own numpy arithmetic (bit-equal tables)
+            from ...math import l2_normalize_host
+
+            kind, _ = self.scan_inputs(torch.empty((0, D), dtype=torch.float32, device=ops.device()))
+            out = ops.lut_build(ops.to_dev(l2_normalize_host(x)), self.codebooks_dev, kind, LAYOUT_BMK)
+        else:
+            out = self._dist_mat_dev(ops.to_dev(x), LAYOUT_BMK)
         return np.ascontiguousarray(out.cpu().numpy(), dtype='float32') if _is_np(x) else out
 
     def get_dist_mat_tiled(self, x_dev: torch.Tensor, qi: int) -> torch.Tensor:

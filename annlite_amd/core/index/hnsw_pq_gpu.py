@@ -43,6 +43,7 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
         self.walk = walk  # where the graph is walked at query time: GPU kernel (default) or the host library
         self._graph = None
         self._gpu_graph = None  # (key, links i32 [N, L+1], seeds i32 [S]) exported for the GPU walk
+        self._mutations = 0     # bumped by every add / delete / reset / load: the key of the two device-side caches
 
     # ------------------------------------------------------------------ graph handle
     def _ensure_graph(self):
@@ -74,6 +75,7 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
         if xq.shape[0] == 0:
             return
         super().add_with_ids(x, ids)  # code table / validity / float vectors (the parent pre-processes itself)
+        self._mutations += 1
         # the graph sees what the reference's add_items sees: the pre-processed vectors (+ their code bytes);
         # PQCodec.get_dist_mat would normalise them once more for cosine (pq.py:309-310) -- do the same
         _, xg = self.pq_codec.scan_inputs(xq)
@@ -90,12 +92,17 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
 
     def delete(self, ids: List[int]):
         super().delete(ids)
+        self._mutations += 1
         if self._graph is not None:
             for i in ids:
                 gc.lib().annlite_hnsw_mark_deleted(self._graph, int(i))  # hnsw/index.py:169-171 mark_deleted
 
     def reset(self, capacity: Optional[int] = None):
         super().reset(capacity=capacity)
+        self._mutations += 1
+        self._gpu_graph = None
+        self._plain_cache = None
+        self._plain_cache_key = None
         if self._graph is not None:
             gc.lib().annlite_hnsw_free(self._graph)
             self._graph = None
@@ -103,7 +110,7 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
     # ------------------------------------------------------------------ search
     def _export_graph(self):
         """Level-0 lists + seed set of the host graph on the device (re-exported after inserts / deletes)."""
-        key = (int(gc.lib().annlite_hnsw_size(self._graph)), self._size)
+        key = self._mutations  # (sizes alone collide: clear() + the same number of documents again, restore())
         if self._gpu_graph is None or self._gpu_graph[0] != key:
             n = self._n_rows
             lpn = int(gc.lib().annlite_hnsw_links_per_node(self._graph))
@@ -168,8 +175,8 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
             else:
                 lut = self.pq_codec.get_dist_mat(q)  # [B, M, Ks] on the device
                 dist = ops.adc_gather(lut, self._plain_table(N), cand)
-            kk = min(k, 64, ef)
-            d, pos = ops.topk_rows(dist, kk)
+            kk = min(k, ef)
+            d, pos = self._topk_rows_any(dist, kk)
             i = torch.gather(cand, 1, pos.clamp(min=0))
             i = torch.where((pos < 0) | torch.isinf(d), torch.full_like(i, -1), i)
             if self.metric == Metric.EUCLIDEAN:
@@ -183,7 +190,7 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
 
     def _plain_table(self, N: int) -> torch.Tensor:
         """Code rows in sub-space order for the gather kernel (cached; rebuilt after inserts)."""
-        key = (N, self._size)
+        key = (N, self._mutations)
         if getattr(self, '_plain_cache_key', None) != key:
             self._plain_cache = self._plain_codes(N).contiguous()
             self._plain_cache_key = key
@@ -197,6 +204,7 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
 
     def load(self, index_file: Union[str, Path]):
         super().load(index_file)
+        self._mutations = getattr(self, '_mutations', 0) + 1
         gpath = str(index_file) + '.graph'
         if Path(gpath).exists():
             if self._graph is not None:

@@ -192,8 +192,17 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
                                    sqrt=self.metric == Metric.EUCLIDEAN)
         # float re-rank: every row the integer scan let through (a superset of each probed cell's ADC top-k, 3-4 k
         # rows per list) is scored exactly on the stored vectors
-        R = P * 5 * k  # a list holds ~3-4 k rows
-        ids = ops.ivf_candidate_ids(cand, count, slot_of, R, self._row_ids)
+        cnt = count.to(torch.int64)[slot_of.to(torch.int64)]  # [B, P]; an overflowed list counts 0xffffffff (-1 as int32)
+        overflow = bool((cnt < 0).any().item())
+        if overflow:
+            # a list that overflowed holds only part of its cell (many ties / a loose bound): take the candidates from the
+            # exact path instead -- ivf_rescore walks an overflowed cell completely -- i.e. the ADC top-k of the probed cells
+            lut = self.pq_codec.get_dist_mat(q)
+            _, ids = ops.ivf_rescore(lut, self._table_plain, cand, count, slot_of, tile_rows, qt, k, self._row_ids, bits,
+                                     sqrt=False)
+        else:
+            R = max(int(cnt.sum(dim=1).max().item()), k)  # every emitted row, none dropped
+            ids = ops.ivf_candidate_ids(cand, count, slot_of, R, self._row_ids)
         exact = ops.exact_gather_dist(int(self.metric), q, self._vectors, ids)
         kk = min(k_out, 64)
         d, pos = ops.topk_rows(exact, kk)

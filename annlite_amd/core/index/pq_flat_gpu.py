@@ -31,6 +31,7 @@ import torch
 from ... import ops
 from ..._capi import CODES_PLAIN, CODES_SKEWED, scan_plan, scan_select_variant
 from ...enums import ExpandMode, Metric
+from ...math import l2_normalize_host
 from ..codec.pq import PQCodec
 from .base import BaseIndex
 
@@ -114,6 +115,13 @@ class PQFlatGpuIndex(BaseIndex):
     def _pre(self, x) -> torch.Tensor:
         if not self.pq_codec.is_trained:
             raise RuntimeError('Please train the PQ before using HNSW quantization backend')
+        if isinstance(x, np.ndarray) and self.metric == Metric.COSINE:
+            # host buffers are normalised with the reference's own numpy expression before the upload (bit-equal
+            # vectors => bit-equal codes / tables / ids); device tensors by the kernel
+            xh = np.ascontiguousarray(x.reshape(1, -1) if x.ndim == 1 else x, dtype=np.float32)
+            assert xh.shape[-1] == self.dim, (
+                f'the query embedding dimension does not match with index dimension: {xh.shape[-1]} vs {self.dim}')
+            return ops.to_dev(l2_normalize_host(xh), torch.float32)
         x = ops.to_dev(x, torch.float32)
         if x.ndim == 1:
             x = x.reshape(1, -1)
@@ -122,6 +130,15 @@ class PQFlatGpuIndex(BaseIndex):
         if self.metric == Metric.COSINE:
             x = ops.l2_normalize(x)
         return x
+
+    def _scan_inputs(self, x, q: torch.Tensor):
+        """(LUT kind, queries as the table build sees them): ``PQCodec.get_dist_mat`` normalises cosine queries a second
+        time (pq.py:309-310); for host buffers that happens on the host too, in the reference's arithmetic."""
+        if isinstance(x, np.ndarray) and self.metric == Metric.COSINE:
+            kind, _ = self.pq_codec.scan_inputs(q[:0])
+            return kind, ops.to_dev(l2_normalize_host(l2_normalize_host(
+                np.ascontiguousarray(x.reshape(1, -1) if x.ndim == 1 else x, dtype=np.float32))), torch.float32)
+        return self.pq_codec.scan_inputs(q)
 
     @staticmethod
     def _pack_bits(flags: torch.Tensor) -> torch.Tensor:
@@ -260,7 +277,7 @@ class PQFlatGpuIndex(BaseIndex):
             d, i = self._search_rerank(q, k, valid, N, rerank_k)
         elif k <= 64:
             # table build + scan + top-k: one C call (annlite_pq_search_topk)
-            kind, xq = self.pq_codec.scan_inputs(q)
+            kind, xq = self._scan_inputs(x, q)
             base = row_base
             d, i = self._with_kernel(lambda: ops.pq_search_topk(
                 kind, xq, self.pq_codec.codebooks_dev, self._codes, k, self.M, self.Ks, valid_bits=valid, n_rows=N,
@@ -289,7 +306,7 @@ class PQFlatGpuIndex(BaseIndex):
             out[..., 0] = -1
             out[..., 1] = 0x7F800000  # +inf
             return out
-        kind, xq = self.pq_codec.scan_inputs(q)
+        kind, xq = self._scan_inputs(x, q)
         return self._with_kernel(lambda: ops.pq_search_topk(
             kind, xq, self.pq_codec.codebooks_dev, self._codes, k, self.M, self.Ks, valid_bits=self._valid,
             row_base=row_base, n_rows=N, codes_layout=self._layout(), workspace=self._ws, packed=True), B, N, k)
@@ -328,6 +345,16 @@ class PQFlatGpuIndex(BaseIndex):
             d = torch.sqrt(d)
         return d, i
 
+    @staticmethod
+    def _topk_rows_any(values: torch.Tensor, k: int):
+        """Row-wise k smallest with positions, (value, position) ascending: the wave kernel for k <= 64, a stable device
+        sort beyond (a large `limit` must not be cut to 64 silently)."""
+        if k <= 64:
+            return ops.topk_rows(values, k)
+        sd, si = torch.sort(values, dim=1, stable=True)
+        sd, si = sd[:, :k], si[:, :k]
+        return sd, torch.where(torch.isinf(sd), torch.full_like(si, -1), si)
+
     def _search_rerank(self, q, k, valid, N, rerank_k):
         B = q.shape[0]
         rk = int(rerank_k or 64)
@@ -337,8 +364,8 @@ class PQFlatGpuIndex(BaseIndex):
         _, cand = ops.adc_scan_candidates(self._codes, lut, B, rk, self.M, self.Ks, valid_bits=valid, n_rows=N,
                                           codes_layout=self._layout(), workspace=self._ws)
         exact = ops.exact_gather_dist(int(self.metric), q, self._vectors, cand)  # [B, R]
-        kk = min(k, 64)
-        d, pos = ops.topk_rows(exact, kk)
+        kk = min(k, cand.shape[1])
+        d, pos = self._topk_rows_any(exact, kk)
         i = torch.gather(cand, 1, pos.clamp(min=0))
         i = torch.where(pos < 0, torch.full_like(i, -1), i)
         i = torch.where(torch.isinf(d), torch.full_like(i, -1), i)

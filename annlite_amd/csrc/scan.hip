@@ -5,8 +5,8 @@
 //                      (bindings/pq_bindings.pyx:30-47,52-80 == include/hnswlib/space_pq.h:15-37)
 //   then the k smallest (annlite/math.py:94-120) -- with the build's fixed tie-break (d asc, n asc).
 //
-// The scan kernels live in scan_qfilter.hip (default), scan_legacy.hip (selectable variants) and
-// scan_prep.hip (table quantisation, seed bound); DESIGN.md section 3 describes them.  No fallback to the
+// The scan kernels live in scan_q8.hip (byte filter tables: the default for M = 16, small k), scan_qfilter.hip (u16
+// filter tables, tile mode) and scan_prep.hip (table build, quantisation parameters, seed bound); DESIGN.md section 3.  No fallback to the
 // CPU exists; shapes without a fast kernel use the generic kernel below (tables through L2).
 #include "scan_common.h"
 
@@ -261,15 +261,14 @@ __global__ __launch_bounds__(256) void codes_skew_kernel(const uint8_t *__restri
 // =================================================================================================
 struct FastCfg {
     int M, QI, NQ, NW, WPS, wg_per_cu, id;
-    int mode;  // 0: exec-masked passes, 1/2: weight-fma passes, 3: FILTER kernel (fast fp32 sum + exact
-               // recompute), 4: QFILTER kernel (12-bit integer tables, 8 queries per LDS entry), 5: byte-table
-               // kernel (scan_q8.hip: 16 queries per LDS entry, tables quantised by the workgroup itself)
-    int qt() const { return (mode == 5 ? 16 : mode == 4 ? (M == 64 ? 4 : 8) : QI) * NQ; }
-    bool qf() const { return mode == 4 || mode == 5; }  // integer filter + exact recompute, shared bounds
+    int mode;  // 4: u16 filter tables (scan_qfilter.hip: 8 queries per LDS entry, M = 64: 4), 5: byte filter tables
+               // (scan_q8.hip: 16 queries per LDS entry, tables quantised by the workgroup itself)
+    int qt() const { return (mode == 5 ? 16 : (M == 64 ? 4 : 8)) * NQ; }
+    bool qf() const { return true; }  // integer filter + exact recompute, shared bounds (every fast kernel)
 };
 
-// Kernel variants per M.  ANNLITE_SCAN_VARIANT (env, read per call) selects among the M=16
-// instantiations for A/B measurements; variant 0 is the default for every M.
+// Kernel variants per M.  ANNLITE_SCAN_VARIANT (env, read per call) / annlite_scan_select_variant() select among the
+// instantiations for A/B measurements and the index plug-in's calibration; variant 0 is the default for every M.
 static thread_local int g_variant_override = -1;  // annlite_scan_select_variant
 static int scan_variant() {
     if (g_variant_override >= 0) return g_variant_override;
@@ -282,44 +281,20 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
     if (code_bytes != 1 || Ks > 256 || Ks < 1 || k > 64 || k < 1) return false;
     const int v = scan_variant();
     switch (M) {
-        case 8:
-            if (v >= 20 && v < 30) *c = {8, 4, 2, 8, 2, 1, 80, 0};
-            else if (v == 9) *c = {8, 4, 2, 8, 2, 1, 81, 3};
-            else *c = {8, 4, 2, 16, 4, 1, 830, 4};               // default: qfilter, 16 queries / WG
-            return true;
+        case 8: *c = {8, 4, 2, 16, 4, 1, 830, 4}; return true;  // u16 tables, 16 queries / WG
         case 16:
             // default: byte tables, 32 queries / WG, 15 scanning waves + 1 consumer (small k: the candidate generator of the
             // re-rank stage asks for 64 per slice and starts without a seed -- the u16 tables filter that much better)
-            if ((v == 0 && !tiles && k <= 16) || v == 50) { *c = {16, 4, 2, 16, 4, 1, 1650, 5}; return true; }
-            if (v == 0) { *c = {16, 4, 2, 16, 4, 1, 1631, 4}; return true; }  // tile mode: qfilter, 16 queries / WG, 16 waves
-            if (v == 8) { *c = {16, 4, 2, 12, 3, 1, 1601, 3}; return true; }  // fp32 filter kernel, 12 waves, single buffer
-            if (v == 30) { *c = {16, 4, 2, 12, 3, 1, 1630, 4}; return true; }  // qfilter, 16 queries / WG, 12 waves
-            if (v == 31) { *c = {16, 4, 2, 16, 4, 1, 1631, 4}; return true; }  // qfilter, 16 waves
-            if (v == 32) { *c = {16, 4, 2, 8, 2, 1, 1632, 4}; return true; }   // qfilter, 8 waves
-            if (v == 9) { *c = {16, 4, 2, 8, 2, 1, 1600, 3}; return true; }   // filter kernel, 8 waves, double buffer
-            if (v == 10) { *c = {16, 4, 2, 12, 3, 1, 1601, 3}; return true; }  // filter kernel, 12 waves, single buffer
-            if (v == 11) { *c = {16, 4, 1, 8, 4, 2, 1602, 3}; return true; }   // filter kernel, QT=4, 2 WG / CU
-            if (v == 12) { *c = {16, 4, 2, 16, 4, 1, 1603, 3}; return true; }  // filter kernel, 16 waves, single buffer
-            if (v == 1) *c = {16, 4, 1, 8, 4, 2, 161, 0};        // QT=4, 2 workgroups / CU
-            else if (v == 2) *c = {16, 4, 2, 16, 4, 1, 162, 0};  // QT=8, 16 waves
-            else if (v == 3) *c = {16, 4, 2, 12, 3, 1, 163, 0};  // QT=8, 12 waves (3 / SIMD)
-            else if (v == 4) *c = {16, 4, 2, 8, 2, 1, 164, 1};   // QT=8, 8 waves, weight-fma
-            else if (v == 5) *c = {16, 4, 2, 12, 3, 1, 165, 1};  // QT=8, 12 waves, weight-fma
-            else if (v == 6) *c = {16, 4, 1, 8, 4, 2, 166, 1};   // QT=4, 2 WG / CU, weight-fma
-            else if (v == 7) *c = {16, 4, 2, 8, 2, 1, 167, 2};   // QT=8, 8 waves, scalar weight-fma
-            else if (v == 28) *c = {16, 4, 2, 8, 2, 1, 160, 0};  // QT=8, 8 waves, 1 workgroup / CU
-            else *c = {16, 4, 2, 12, 3, 1, 163, 0};              // (v >= 20) two-pass kernel, QT=8, 12 waves
+            if ((v == 0 && !tiles && k <= 16) || (v == 50 && !tiles && k <= 16)) { *c = {16, 4, 2, 16, 4, 1, 1650, 5}; return true; }
+            if (v == 30) { *c = {16, 4, 2, 12, 3, 1, 1630, 4}; return true; }  // u16 tables, 12 waves
+            if (v == 32) { *c = {16, 4, 2, 8, 2, 1, 1632, 4}; return true; }   // u16 tables, 8 waves
+            *c = {16, 4, 2, 16, 4, 1, 1631, 4};                               // u16 tables, 16 queries / WG, 16 waves (variant 31)
             return true;
-        case 32:
-            if (v >= 20 && v < 30) *c = {32, 4, 1, 8, 2, 1, 320, 0};
-            else if (v == 8 || v == 9) *c = {32, 4, 1, 8, 2, 1, 321, 3};
-            else *c = {32, 4, 1, 12, 3, 1, 3230, 4};             // default: qfilter, 8 queries / WG
-            return true;
+        case 32: *c = {32, 4, 1, 12, 3, 1, 3230, 4}; return true;  // u16 tables, 8 queries / WG
         case 64:
-            if (v >= 20 && v < 30) *c = {64, 2, 1, 8, 2, 1, 640, 0};  // two-pass kernel (PLAIN tables only: SKEWED is wrap-coded)
-            else if (v == 30) *c = {64, 4, 1, 16, 4, 1, 6430, 4};     // qfilter64, 16 waves (spills: 7.4 ms at C4 vs 5.9)
-            else if (v == 32) *c = {64, 4, 1, 8, 2, 1, 6432, 4};      // qfilter64, 8 waves (6.7 ms)
-            else *c = {64, 4, 1, 12, 3, 1, 6431, 4};                  // default: qfilter64, 4 queries / WG, 12 waves
+            if (v == 30) *c = {64, 4, 1, 16, 4, 1, 6430, 4};       // qfilter64, 16 waves (spills: 7.4 ms at C4 vs 5.9)
+            else if (v == 32) *c = {64, 4, 1, 8, 2, 1, 6432, 4};   // qfilter64, 8 waves (6.7 ms)
+            else *c = {64, 4, 1, 12, 3, 1, 6431, 4};               // default: qfilter64, 4 queries / WG, 12 waves
             return true;
         default: return false;
     }
@@ -624,19 +599,8 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             a.q16 = q16;
             a.qlom = qlom;
         }
-        if (c.mode == 3) {
-            // rounding slack of the fast filter sum needs Smax[b] = sum_m max_k |lut[b][m][k]|
-            const int64_t part_bytes = (int64_t)a.n_tiles * plan.qt * plan.n_slices * k * 8;
-            float *smax = (float *)((char *)workspace_dev + ((part_bytes + 255) / 256) * 256);
-            const int n_groups = (int)(((B + 15) / 16) * 16 / c.QI);
-            rc = launch_lut_smax(lut_dev, n_groups, M, Ks, c.QI, smax, st);
-            if (rc != ANNLITE_OK) return rc;
-            a.smax = smax;
-        }
         prof_begin(st);
-        rc = c.mode == 5   ? launch_q8_scan(c.id, sk, a, grid, st)
-             : c.mode == 4 ? launch_qfilter_scan(c.id, sk, a, grid, st)
-                           : launch_legacy_scan(c.id, sk, a, grid, st);
+        rc = c.mode == 5 ? launch_q8_scan(c.id, sk, a, grid, st) : launch_qfilter_scan(c.id, sk, a, grid, st);
         prof_end(st);
         return rc;
     }

@@ -24,7 +24,7 @@ struct ScanArgs {
     int32_t n_slices;        // 1, 2, 4 or a multiple of 8
     int32_t n_items;         // work items (see item_map)
     int64_t slice_rows;      // multiple of 64
-    const float *smax;       // [ceil16(B)] sum_m max_k |lut[b][m][k]|  (filter kernel: rounding slack)
+    const float *smax;       // [ceil16(B)] sum_m max_k |lut[b][m][k]|  (rounding slack of the fp32 sums)
     // quantised filter (qfilter kernel): 12-bit integer tables + the affine map back to distances
     const uint16_t *q16;     // [ceil16(B)/8][Ks][M][8] u16
     const float *qstep;      // [ceil16(B)]
@@ -74,142 +74,6 @@ __device__ __forceinline__ bool item_map(const ScanArgs &a, int item, int &tile,
     slice = xcd % a.n_slices;
     tile = j * (8 / a.n_slices) + xcd / a.n_slices;
     return tile < a.n_tiles;
-}
-
-// ---- compile-time exec masks for the ordered accumulation ---------------------------------------
-template <int M>
-constexpr unsigned long long pass_mask(int t, int pass) {
-    unsigned long long m = 0;
-    for (int l = 0; l < 64; ++l) {
-        const int s = l % M;
-        const bool p1 = (s == 0) || (s >= M - t);
-        if (pass == 0 ? p1 : !p1) m |= 1ull << l;
-    }
-    return m;
-}
-
-template <unsigned long long MASK>
-__device__ __forceinline__ void masked_pk_add2(f32x2 &a0, f32x2 &a1, const f32x2 x0, const f32x2 x1) {
-    if constexpr (MASK == 0ull) {
-        return;
-    } else if constexpr (MASK == ~0ull) {
-        a0 += x0;
-        a1 += x1;
-    } else {
-        unsigned long long sv;
-        asm("s_mov_b64 %[sv], exec\n\t"
-            "s_mov_b32 exec_lo, %[lo]\n\t"
-            "s_mov_b32 exec_hi, %[hi]\n\t"
-            "v_pk_add_f32 %[a0], %[a0], %[x0]\n\t"
-            "v_pk_add_f32 %[a1], %[a1], %[x1]\n\t"
-            "s_mov_b64 exec, %[sv]"
-            : [a0] "+v"(a0), [a1] "+v"(a1), [sv] "=&s"(sv)
-            : [x0] "v"(x0), [x1] "v"(x1), [lo] "i"((int)(uint32_t)(MASK & 0xffffffffull)),
-              [hi] "i"((int)(uint32_t)(MASK >> 32)));
-    }
-}
-
-template <unsigned long long MASK>
-__device__ __forceinline__ void masked_pk_add1(f32x2 &a0, const f32x2 x0) {
-    if constexpr (MASK == 0ull) {
-        return;
-    } else if constexpr (MASK == ~0ull) {
-        a0 += x0;
-    } else {
-        unsigned long long sv;
-        asm("s_mov_b64 %[sv], exec\n\t"
-            "s_mov_b32 exec_lo, %[lo]\n\t"
-            "s_mov_b32 exec_hi, %[hi]\n\t"
-            "v_pk_add_f32 %[a0], %[a0], %[x0]\n\t"
-            "s_mov_b64 exec, %[sv]"
-            : [a0] "+v"(a0), [sv] "=&s"(sv)
-            : [x0] "v"(x0), [lo] "i"((int)(uint32_t)(MASK & 0xffffffffull)),
-              [hi] "i"((int)(uint32_t)(MASK >> 32)));
-    }
-}
-
-
-// ---- ordered accumulation, 8 steps per asm statement --------------------------------------------
-// One statement = 8 x { set exec to the compile-time lane mask of step t ; v_pk_add_f32 ... } and
-// ONE restore of exec to all-ones (the main loop runs with full waves and uniform control flow).
-// v1 of this kernel saved/restored exec around every step (4 SALU per 2 VALU): rocprof showed
-// 343 SALU + 255 VALU per wave-step and the LDS pipe only 21 % busy (profiles/r01_*).
-#define ANNLITE_MASK_LO(M, T, P) ((int)(uint32_t)(pass_mask<M>((T), (P)) & 0xffffffffull))
-#define ANNLITE_MASK_HI(M, T, P) ((int)(uint32_t)(pass_mask<M>((T), (P)) >> 32))
-#define ANNLITE_LOHALF(v) __builtin_shufflevector((v), (v), 0, 1)
-#define ANNLITE_HIHALF(v) __builtin_shufflevector((v), (v), 2, 3)
-
-#define ANNLITE_STEP_Q4(i)                                       \
-    "s_mov_b32 exec_lo, %[m" #i "]\n\t"                          \
-    "s_mov_b32 exec_hi, %[m" #i "]\n\t"                          \
-    "v_pk_add_f32 %[a0], %[a0], %[x" #i "]\n\t"                  \
-    "v_pk_add_f32 %[a1], %[a1], %[y" #i "]\n\t"
-
-template <int M, int T0, int PASS>
-__device__ __forceinline__ void pass8_q4(f32x2 &a0, f32x2 &a1, const f32x4 (&v)[M]) {
-    static_assert(M <= 32 && T0 + 8 <= M, "lo == hi masks need a lane period <= 32");
-    asm(ANNLITE_STEP_Q4(0) ANNLITE_STEP_Q4(1) ANNLITE_STEP_Q4(2) ANNLITE_STEP_Q4(3)
-        ANNLITE_STEP_Q4(4) ANNLITE_STEP_Q4(5) ANNLITE_STEP_Q4(6) ANNLITE_STEP_Q4(7)
-        "s_mov_b64 exec, -1"
-        : [a0] "+v"(a0), [a1] "+v"(a1)
-        : [x0] "v"(ANNLITE_LOHALF(v[T0 + 0])), [y0] "v"(ANNLITE_HIHALF(v[T0 + 0])),
-          [x1] "v"(ANNLITE_LOHALF(v[T0 + 1])), [y1] "v"(ANNLITE_HIHALF(v[T0 + 1])),
-          [x2] "v"(ANNLITE_LOHALF(v[T0 + 2])), [y2] "v"(ANNLITE_HIHALF(v[T0 + 2])),
-          [x3] "v"(ANNLITE_LOHALF(v[T0 + 3])), [y3] "v"(ANNLITE_HIHALF(v[T0 + 3])),
-          [x4] "v"(ANNLITE_LOHALF(v[T0 + 4])), [y4] "v"(ANNLITE_HIHALF(v[T0 + 4])),
-          [x5] "v"(ANNLITE_LOHALF(v[T0 + 5])), [y5] "v"(ANNLITE_HIHALF(v[T0 + 5])),
-          [x6] "v"(ANNLITE_LOHALF(v[T0 + 6])), [y6] "v"(ANNLITE_HIHALF(v[T0 + 6])),
-          [x7] "v"(ANNLITE_LOHALF(v[T0 + 7])), [y7] "v"(ANNLITE_HIHALF(v[T0 + 7])),
-          [m0] "i"(ANNLITE_MASK_LO(M, T0 + 0, PASS)), [m1] "i"(ANNLITE_MASK_LO(M, T0 + 1, PASS)),
-          [m2] "i"(ANNLITE_MASK_LO(M, T0 + 2, PASS)), [m3] "i"(ANNLITE_MASK_LO(M, T0 + 3, PASS)),
-          [m4] "i"(ANNLITE_MASK_LO(M, T0 + 4, PASS)), [m5] "i"(ANNLITE_MASK_LO(M, T0 + 5, PASS)),
-          [m6] "i"(ANNLITE_MASK_LO(M, T0 + 6, PASS)), [m7] "i"(ANNLITE_MASK_LO(M, T0 + 7, PASS)));
-}
-
-#define ANNLITE_STEP_Q2(i)                                       \
-    "s_mov_b32 exec_lo, %[l" #i "]\n\t"                          \
-    "s_mov_b32 exec_hi, %[h" #i "]\n\t"                          \
-    "v_pk_add_f32 %[a0], %[a0], %[x" #i "]\n\t"
-
-template <int M, int T0, int PASS>
-__device__ __forceinline__ void pass8_q2(f32x2 &a0, const f32x2 (&v)[M]) {
-    static_assert(T0 + 8 <= M, "block out of range");
-    asm(ANNLITE_STEP_Q2(0) ANNLITE_STEP_Q2(1) ANNLITE_STEP_Q2(2) ANNLITE_STEP_Q2(3)
-        ANNLITE_STEP_Q2(4) ANNLITE_STEP_Q2(5) ANNLITE_STEP_Q2(6) ANNLITE_STEP_Q2(7)
-        "s_mov_b64 exec, -1"
-        : [a0] "+v"(a0)
-        : [x0] "v"(v[T0 + 0]), [x1] "v"(v[T0 + 1]), [x2] "v"(v[T0 + 2]), [x3] "v"(v[T0 + 3]),
-          [x4] "v"(v[T0 + 4]), [x5] "v"(v[T0 + 5]), [x6] "v"(v[T0 + 6]), [x7] "v"(v[T0 + 7]),
-          [l0] "i"(ANNLITE_MASK_LO(M, T0 + 0, PASS)), [h0] "i"(ANNLITE_MASK_HI(M, T0 + 0, PASS)),
-          [l1] "i"(ANNLITE_MASK_LO(M, T0 + 1, PASS)), [h1] "i"(ANNLITE_MASK_HI(M, T0 + 1, PASS)),
-          [l2] "i"(ANNLITE_MASK_LO(M, T0 + 2, PASS)), [h2] "i"(ANNLITE_MASK_HI(M, T0 + 2, PASS)),
-          [l3] "i"(ANNLITE_MASK_LO(M, T0 + 3, PASS)), [h3] "i"(ANNLITE_MASK_HI(M, T0 + 3, PASS)),
-          [l4] "i"(ANNLITE_MASK_LO(M, T0 + 4, PASS)), [h4] "i"(ANNLITE_MASK_HI(M, T0 + 4, PASS)),
-          [l5] "i"(ANNLITE_MASK_LO(M, T0 + 5, PASS)), [h5] "i"(ANNLITE_MASK_HI(M, T0 + 5, PASS)),
-          [l6] "i"(ANNLITE_MASK_LO(M, T0 + 6, PASS)), [h6] "i"(ANNLITE_MASK_HI(M, T0 + 6, PASS)),
-          [l7] "i"(ANNLITE_MASK_LO(M, T0 + 7, PASS)), [h7] "i"(ANNLITE_MASK_HI(M, T0 + 7, PASS)));
-}
-
-
-// ---- ordered accumulation without touching EXEC: per-lane 0/1 weights -----------------------------
-// fma(v, 1.0f, acc) == acc + v (one rounding, identical to v_add_f32) and fma(v, 0.0f, acc) == acc for
-// finite v, so "lane masked out" becomes "weight 0".  w[t] = (w1, w2) per lane: w1 = 1 if step t
-// belongs to pass 1 for this lane (t >= t0) else 0, w2 = 1 - w1.  op_sel/op_sel_hi broadcast w1
-// (pass 1) or w2 (pass 2) to both halves of the packed op.  No SALU at all: the exec-mask version
-// was bound by the CU's single scalar unit (~180 SALU per 8192 look-ups, profiles/r01 notes).
-__device__ __forceinline__ void wfma_p1(f32x2 &acc, const f32x2 v, const f32x2 w) {
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(v), "v"(w));
-}
-__device__ __forceinline__ void wfma_p2(f32x2 &acc, const f32x2 v, const f32x2 w) {
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(v), "v"(w));
-}
-// MODE 2: the same with scalar (non-packed) v_fma_f32 -- A/B against the packed form
-__device__ __forceinline__ void sfma(f32x2 &acc, const f32x2 v, const float w) {
-    float ax = acc.x, ay = acc.y;
-    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(ax) : "v"(v.x), "v"(w));
-    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(ay) : "v"(v.y), "v"(w));
-    acc.x = ax;
-    acc.y = ay;
 }
 
 // (code byte B of a dword) << SH in ONE VOP2-SDWA op (v_bfe_u32 + v_lshl_add_u32 are two 4.5-cycle VOP3 ops,
@@ -273,17 +137,6 @@ __device__ __forceinline__ void rotate_row(uint32_t (&c)[CW], const bool (&abit)
     for (int i = 0; i < CW; ++i) c[i] = n[i];
 }
 
-template <int QI>
-struct LutVec;
-template <>
-struct LutVec<4> {
-    typedef f32x4 type;
-};
-template <>
-struct LutVec<2> {
-    typedef f32x2 type;
-};
-
 // integer filter bound (0x8000 | qthr) implied by a k-th key (see the kernel header for the derivation)
 template <int M>
 __device__ __forceinline__ unsigned short qbound_from_key(unsigned long long key, float smax_b, float qstep_b,
@@ -323,8 +176,8 @@ __device__ __forceinline__ uint32_t bytes_add(uint32_t x, uint32_t y) {
 
 
 // ---- launchers of the scan kernels, one translation unit per kernel family -----------------------
-// (scan_qfilter.hip: the default quantised-filter kernels; scan_legacy.hip: the exact two-pass and the fp32
-// filter kernels kept as selectable variants; scan_prep.hip: table quantisation / seed bound / Smax)
+// (scan_q8.hip: byte filter tables; scan_qfilter.hip: u16 filter tables, tile mode; scan_prep.hip: table build /
+// quantisation parameters / seed bound)
 struct LutBuild {  // annlite_pq_search_topk: the L2 tables are built by the quantisation launch itself
     const float *queries;
     const float *codebooks;
@@ -332,13 +185,11 @@ struct LutBuild {  // annlite_pq_search_topk: the L2 tables are built by the qua
 };
 int launch_qfilter_scan(int id, bool skewed, const ScanArgs &a, int grid, hipStream_t st);
 int launch_q8_scan(int id, bool skewed, const ScanArgs &a, int grid, hipStream_t st);
-int launch_legacy_scan(int id, bool skewed, const ScanArgs &a, int grid, hipStream_t st);
 // q16 == NULL: only the per-query parameters (step, L, Smax, minima) are produced; qlom may be NULL
 int launch_lut_quantise(int64_t M, int64_t Ks, int64_t B, int64_t bpad, const float *lut_dev, const LutBuild *build,
                         uint16_t *q16, float *qstep, double *qlo, float *smax, float *qlom, void *fill,
                         size_t fill_bytes, hipStream_t st);
 int launch_seed_bound(int64_t M, bool skewed, const void *codes_dev, int64_t S, const uint32_t *valid_bits_dev,
                       const float *lut_dev, int64_t B, int64_t Ks, int64_t k, unsigned long long *gkey, hipStream_t st);
-int launch_lut_smax(const float *lut_dev, int n_groups, int64_t M, int64_t Ks, int QI, float *smax, hipStream_t st);
 
 }  // namespace annlite

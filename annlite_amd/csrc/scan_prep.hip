@@ -1,5 +1,5 @@
 // scan_prep.hip -- what runs before the quantised-filter scan of a batch: quantisation of the fp32 tables
-// (optionally building them in the same launch), the seed bound, and Smax for the fp32 filter variant.
+// (optionally building them in the same launch) and the seed bound.
 #include "scan_common.h"
 
 namespace annlite {
@@ -532,28 +532,6 @@ __global__ __launch_bounds__(1024) void lut_l2_build_quantise_kernel(const float
     }
 }
 
-// Smax[b] = sum_m max_k |lut[b][m][k]| from the TILED table [Bpad/QI][Ks][M][QI]; one wave per group
-__global__ __launch_bounds__(256) void lut_smax_kernel(const float *__restrict__ lut, int n_groups, int M, int Ks,
-                                                      int QI, float *__restrict__ smax) {
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= n_groups) return;
-    const float *base = lut + (int64_t)g * Ks * M * QI;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int m = 0; m < M; ++m) {
-        float mx[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = lane; k < Ks; k += 64)
-            for (int i = 0; i < QI; ++i) mx[i] = fmaxf(mx[i], fabsf(base[((int64_t)k * M + m) * QI + i]));
-        for (int i = 0; i < QI; ++i) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], o));
-            acc[i] += mx[i];
-        }
-    }
-    if (lane == 0)
-        for (int i = 0; i < QI; ++i) smax[g * QI + i] = acc[i];
-}
-
 }  // namespace annlite
 
 using namespace annlite;
@@ -597,10 +575,4 @@ int annlite::launch_seed_bound(int64_t M, bool skw, const void *codes_dev, int64
     else ANNLITE_SEED(64, 2)
 #undef ANNLITE_SEED
     return launch_status("seed_bound_kernel");
-}
-
-int annlite::launch_lut_smax(const float *lut_dev, int n_groups, int64_t M, int64_t Ks, int QI, float *smax, hipStream_t st) {
-    hipLaunchKernelGGL(lut_smax_kernel, dim3((n_groups + 3) / 4), dim3(256), 0, st, lut_dev, n_groups, (int)M, (int)Ks, QI,
-                       smax);
-    return launch_status("lut_smax_kernel");
 }

@@ -25,6 +25,7 @@ evaluated on the host and handed to the GPU scan as a row bitmap (section 8f-3).
 """
 import hashlib
 import logging
+import sqlite3
 import warnings
 from pathlib import Path
 from typing import Dict, List, Optional, Union
@@ -317,15 +318,22 @@ class AnnLite:
             raise RuntimeError('The indexer is not trained, cannot add new documents')
         x = to_numpy_array(docs.embeddings)
         self._sanity_check(x)
-        offsets = []
+        # the reference's cell table declares `_doc_id TEXT NOT NULL UNIQUE` (storage/table.py:203): a document id
+        # that is already indexed -- or twice in this batch -- is an IntegrityError there; nothing is inserted
+        seen = set()
         for d in docs:
-            off = len(self._offset2id)
+            if d.id in self._id2offset or d.id in seen:
+                raise sqlite3.IntegrityError(f'UNIQUE constraint failed: _doc_id (id={d.id})')
+            seen.add(d.id)
+        first = len(self._offset2id)
+        offsets = np.arange(first, first + len(docs), dtype=np.int64)
+        # vectors first: if the device call fails no offset exists without codes
+        self.vec_index(0).add_with_ids(np.ascontiguousarray(x, dtype=np.float32), offsets)
+        for d in docs:
+            self._id2offset[d.id] = len(self._offset2id)
             self._offset2id.append(d.id)
-            self._id2offset[d.id] = off
             self._tags.append(dict(d.tags) if getattr(d, 'tags', None) else {})
             self._docs[d.id] = d
-            offsets.append(off)
-        self.vec_index(0).add_with_ids(np.ascontiguousarray(x, dtype=np.float32), np.asarray(offsets, dtype=np.int64))
 
     def update(self, docs, raise_errors_on_not_found: bool = False, insert_if_not_found: bool = True, **kwargs):
         """index.py:297-332: delete + re-insert under a fresh offset (container.py:323-375)."""
@@ -349,7 +357,8 @@ class AnnLite:
             self.index(new_docs)
 
     def delete(self, docs, raise_errors_on_not_found: bool = False):
-        ids = docs if isinstance(docs, list) else docs[:, 'id']
+        # ids or documents (the reference takes either, index.py:389-414; a DocumentArray may itself be a list subclass)
+        ids = [d if isinstance(d, str) else d.id for d in docs]
         offs = []
         for doc_id in ids:
             off = self._id2offset.pop(doc_id, None)
@@ -444,7 +453,12 @@ class AnnLite:
         the filter, in insertion order or ordered by a tag, ``offset`` skipped, at most ``limit`` (<= 0: all)."""
         offs = _filter_select(self._tags, filter or {})
         if order_by:
-            offs = sorted(offs, key=lambda o: self._tags[o].get(order_by), reverse=not ascending)
+            # documents without the tag sort as NULLs do in the reference's SQL ORDER BY (SQLite: NULLs first ascending,
+            # last descending) instead of raising on a None comparison
+            have = [o for o in offs if self._tags[o].get(order_by) is not None]
+            miss = [o for o in offs if self._tags[o].get(order_by) is None]
+            have = sorted(have, key=lambda o: self._tags[o].get(order_by), reverse=not ascending)
+            offs = miss + have if ascending else have + miss
         offs = offs[offset:]
         if limit > 0:
             offs = offs[:limit]

@@ -1,7 +1,8 @@
 """Device-side mirror of ``annlite/math.py`` (reference lines cited per function).
 
 Inputs may be numpy arrays or torch tensors; numpy in -> numpy out (so the reference's own call
-sites / tests read the same), torch in -> torch out (stays in HBM).  All arithmetic runs on the GPU.
+sites / tests read the same), torch in -> torch out (stays in HBM).  The arithmetic runs on the GPU, except the row
+normalisation of host buffers (see ``l2_normalize_host``).
 """
 from typing import Tuple
 
@@ -16,13 +17,28 @@ def _wrap(x):
     return ops.to_dev(x), is_np
 
 
+def l2_normalize_host(x: np.ndarray, eps: float = np.finfo(np.float32).eps) -> np.ndarray:
+    """annlite/math.py:6-18 on HOST buffers, in the reference's own numpy arithmetic (einsum row sums, in-place sqrt,
+    divide): what a numpy caller's vectors go through before they are uploaded, so that cosine tables and neighbour
+    ids equal the reference's bit for bit -- the order in which einsum adds the squares belongs to the numpy build,
+    the device kernel (one wave per row) adds in another and differs in the last ulp."""
+    norms = np.einsum('ij,ij->i', x, x)
+    np.sqrt(norms, norms)
+    constant_mask = norms < 10 * eps
+    norms[constant_mask] = 1.0
+    return x / norms[:, np.newaxis]
+
+
 def l2_normalize(x, eps: float = np.finfo(np.float32).eps):
-    """annlite/math.py:6-18 -- rows with norm < 10*eps are left unscaled.  (fp32; the row sum runs
-    in a different order than numpy's einsum, so results agree to ~1 ulp, not bitwise.)"""
-    t, is_np = _wrap(x)
+    """annlite/math.py:6-18 -- rows with norm < 10*eps are left unscaled.  numpy in: the reference's arithmetic on the
+    host (``l2_normalize_host``, bit-equal); torch in: the device kernel (fp32, the row sum in a different order than
+    numpy's einsum: ~1 ulp)."""
+    if isinstance(x, np.ndarray):
+        assert x.ndim == 2
+        return l2_normalize_host(x, eps)
+    t, _ = _wrap(x)
     assert t.ndim == 2
-    out = ops.l2_normalize(t.float())
-    return out.cpu().numpy() if is_np else out
+    return ops.l2_normalize(t.float())
 
 
 def top_k(values, k: int, descending: bool = False) -> Tuple:

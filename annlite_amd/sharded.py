@@ -65,13 +65,18 @@ class ShardedPQIndex:
     """Product wiring: a ``PQFlatGpuIndex`` per rank holding rows [row_base, row_base + n_local) of
     the global table; ``search_batch`` returns global row ids on every rank."""
 
-    def __init__(self, index, row_base: int, group: Optional[dist.ProcessGroup] = None):
-        from . import ops
-
+    def __init__(self, index, row_base: int, group: Optional[dist.ProcessGroup] = None,
+                 merge: Optional[Callable] = None, merge_packed: Optional[Callable] = None):
         self.index = index
         self.row_base = int(row_base)
         self.group = group
-        self._merge = ops.topk_merge
+        if merge is None or merge_packed is None:  # the product: the merge kernels (tests inject numpy restatements)
+            from . import ops
+
+            merge = merge or ops.topk_merge
+            merge_packed = merge_packed or ops.topk_merge_packed
+        self._merge = merge
+        self._merge_packed = merge_packed
         self._xstream = None  # side stream of the exchange (all-gather + merge)
 
     def _scan(self, queries, k):
@@ -93,12 +98,14 @@ class ShardedPQIndex:
             return PendingSearch(self, value=ShardedSearcher(self._scan, self._merge, self.group).search(queries, limit))
         # ONE collective per batch: (global id, raw ADC sum) pairs, 16 B each; merged on the raw sums (the
         # single-GPU order), the metric epilogue (sqrt for EUCLIDEAN) comes last
-        from . import ops
-
-        if self._xstream is None:
-            self._xstream = torch.cuda.Stream(device=packed.device)
         G = dist.get_world_size(self.group)
         B, k, _ = packed.shape
+        if not packed.is_cuda:  # host tensors (the gloo tests of this path): same exchange, no streams to overlap
+            gathered = torch.empty((G * B, k, 2), dtype=torch.int64)
+            dist.all_gather_into_tensor(gathered, packed.contiguous(), group=self.group)
+            return PendingSearch(self, value=self._merge_packed(gathered.view(G, B, k, 2), sqrt=self.index.sqrt_epilogue))
+        if self._xstream is None:
+            self._xstream = torch.cuda.Stream(device=packed.device)
         scanned = torch.cuda.Event()
         scanned.record(torch.cuda.current_stream(packed.device))
         with torch.cuda.stream(self._xstream):
@@ -107,7 +114,7 @@ class ShardedPQIndex:
             gathered = torch.empty((G * B, k, 2), dtype=torch.int64, device=packed.device)
             work = dist.all_gather_into_tensor(gathered, packed, group=self.group, async_op=True)
             work.wait()  # the SIDE stream waits for the collective
-            value = ops.topk_merge_packed(gathered.view(G, B, k, 2), sqrt=self.index.sqrt_epilogue)
+            value = self._merge_packed(gathered.view(G, B, k, 2), sqrt=self.index.sqrt_epilogue)
             done = torch.cuda.Event()
             done.record(self._xstream)
         return PendingSearch(self, value=value, done=done, keep=(packed, gathered))
@@ -141,4 +148,23 @@ def numpy_merge(all_d: torch.Tensor, all_i: torch.Tensor):
         key_i = np.where(i[b] < 0, np.iinfo(np.int64).max, i[b])
         order = np.lexsort((key_i, d[b]))[:k]
         od[b], oi[b] = d[b][order], i[b][order]
+    return torch.from_numpy(od), torch.from_numpy(oi)
+
+
+def numpy_merge_packed(gathered: torch.Tensor, sqrt: bool = False):
+    """Restatement of ``annlite_topk_merge_packed`` (merge_lists_kernel) for the CPU (gloo) tests: ``gathered`` is
+    [G, B, k, 2] int64 = (global row id or -1, bits of the raw fp32 ADC sum); merge by (sum, id) ascending, padding
+    entries dropped, then the metric epilogue."""
+    G, B, k, _ = gathered.shape
+    g = gathered.permute(1, 0, 2, 3).reshape(B, G * k, 2).cpu().numpy()
+    ids = g[:, :, 0]
+    d = (g[:, :, 1] & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+    od = np.full((B, k), np.inf, dtype=np.float32)
+    oi = np.full((B, k), -1, dtype=np.int64)
+    for b in range(B):
+        keep = np.nonzero(ids[b] >= 0)[0]
+        order = keep[np.lexsort((ids[b][keep], d[b][keep]))][:k]
+        od[b, :len(order)], oi[b, :len(order)] = d[b][order], ids[b][order]
+    if sqrt:
+        od = np.sqrt(od)
     return torch.from_numpy(od), torch.from_numpy(oi)

@@ -1,12 +1,12 @@
 #!/usr/bin/env bash
 # Build the reference's two native extensions from the sources where they lie
-# under /root/reference into oracle/_ref/ (git-ignored; never committed).
+# under /root/reference into $ANNLITE_REF_BUILD (default $TMPDIR/annlite_oracle_ref): OUTSIDE the repository.
 #
 # TEST INFRASTRUCTURE ONLY.  The outputs are used in THIS container to
 #   (1) pin oracle/pq_oracle.c + oracle/pq_oracle.py against the real reference
 #       (tests/test_oracle_vs_reference.py, skipped when /root/reference is absent), and
 #   (2) generate the committed golden fixtures (tests/golden/make_golden.py).
-# Nothing under oracle/_ref is imported by the product (annlite_amd/), and the GPU
+# Nothing of it is imported by the product (annlite_amd/), and the GPU
 # tests / smoke() / bench.py never touch it.
 #
 # Recipe mirrors the reference's own build flags (setup.py:51-55 compiler
@@ -15,7 +15,8 @@
 set -euo pipefail
 REF=${REF:-/root/reference}
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-OUT="$HERE/_ref"
+# outside the repository (nothing built from the reference ever sits in the tree that is pushed / sent to the GPU box)
+OUT="${ANNLITE_REF_BUILD:-${TMPDIR:-/tmp}/annlite_oracle_ref}"
 if [ ! -d "$REF/bindings" ]; then
   echo "build_ref: $REF not present, skipping (GPU box uses committed golden fixtures)"; exit 0
 fi
@@ -26,7 +27,7 @@ NPINC=$(python3 -c "import numpy; print(numpy.get_include())")
 EXT=$(python3 -c "import sysconfig; print(sysconfig.get_config_var('EXT_SUFFIX'))")
 
 # 1) annlite.pq_bind  <- bindings/pq_bindings.pyx (Cython -> C++); the generated C++ (it quotes the .pyx
-#    lines) is a temporary outside the repo and is deleted: only the .so stays in _ref/
+#    lines) is a temporary and is deleted: only the .so stays
 if [ ! -f "$OUT/pq_bind$EXT" ] || [ "$REF/bindings/pq_bindings.pyx" -nt "$OUT/pq_bind$EXT" ]; then
   TMPCPP=$(mktemp -d)/pq_bind.cpp
   cython -+ -3 --module-name annlite.pq_bind \

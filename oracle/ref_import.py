@@ -3,14 +3,15 @@
 TEST INFRASTRUCTURE ONLY -- never imported by ``annlite_amd`` (the product), by the
 ``-m gpu`` tests, by ``__graft_entry__.smoke()`` or by ``bench.py``.  It only works in the
 build container, where ``/root/reference`` exists and ``oracle/build_ref.sh`` has compiled the
-reference's two native extensions into ``oracle/_ref/``.  On the GPU box ``available()`` is False
+reference's two native extensions into ``$ANNLITE_REF_BUILD`` (default ``$TMPDIR/annlite_oracle_ref``,
+outside the repository).  On the GPU box ``available()`` is False
 and everything that depends on it is skipped; parity there rests on the committed golden
 fixtures (``tests/golden/*.npz``) produced by ``tests/golden/make_golden.py`` through this module.
 
 How it works: ``/root/reference`` is put on ``sys.path`` (bytecode writing
 disabled, the tree is read-only), the packages the reference imports but this image lacks
 (``docarray``, ``loguru``, ``rocksdict``) are replaced by ``MagicMock`` -- none of them is on the
-PQ/ADC path -- and ``annlite.pq_bind`` / ``annlite.hnsw_bind`` are pre-seeded from ``oracle/_ref``.
+PQ/ADC path -- and ``annlite.pq_bind`` / ``annlite.hnsw_bind`` are pre-seeded from that build directory.
 No reference source is copied anywhere.
 """
 import importlib.machinery
@@ -22,7 +23,8 @@ import types
 from unittest.mock import MagicMock
 
 REF_ROOT = os.environ.get('ANNLITE_REFERENCE', '/root/reference')
-_REF_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ref')
+# where oracle/build_ref.sh puts the reference's compiled extensions: outside the repository
+_REF_DIR = os.environ.get('ANNLITE_REF_BUILD') or os.path.join(os.environ.get('TMPDIR') or '/tmp', 'annlite_oracle_ref')
 _EXT = sysconfig.get_config_var('EXT_SUFFIX')
 
 _loaded = None
@@ -52,7 +54,7 @@ def load():
         return _loaded
     if not available():
         raise RuntimeError(
-            'reference not available: need %s and oracle/_ref (run oracle/build_ref.sh)' % REF_ROOT
+            'reference not available: need %s and the build of oracle/build_ref.sh in %s' % (REF_ROOT, _REF_DIR)
         )
     sys.dont_write_bytecode = True
     for name in ('docarray', 'docarray.math', 'docarray.math.ndarray', 'loguru', 'rocksdict'):

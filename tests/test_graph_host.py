@@ -2,7 +2,7 @@
 
 Parity with the reference here is statistical (graph ids are build-order dependent):
 edge distances must be the PQLookup sums bit-for-bit, recall of the candidate lists against the exhaustive
-ADC ranking must be high, and -- when the reference's own hnsw_bind was built into oracle/_ref -- not worse
+ADC ranking must be high, and -- when the reference's own hnsw_bind was built by oracle/build_ref.sh -- not worse
 than the reference's on the same data and parameters."""
 import ctypes
 import os
@@ -103,7 +103,7 @@ def test_candidates_recall_and_pqlookup_bits(kind):
 
 def test_recall_not_worse_than_reference_hnsw_pq():
     """Same data, codebooks, max_connection / ef_construction / ef_search through the reference's own
-    HnswIndex(pq_codec=...) (oracle/_ref build of hnsw_bind; skipped where /root/reference is absent)."""
+    HnswIndex(pq_codec=...) (oracle/build_ref.sh build of hnsw_bind; skipped where /root/reference is absent)."""
     ref = pytest.importorskip('ref_import', reason='reference not available')
     try:
         mods = ref.load()

@@ -233,6 +233,33 @@ def test_candidate_list_overflow_falls_back_to_the_whole_cell(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not has_gpu(), reason='needs an AMD GPU')
+def test_candidate_list_overflow_with_float_rerank_keeps_the_probed_cells(oracle):
+    """Same heavy ties, `rerank=True`: an overflowed list used to contribute NOTHING to the float re-rank (the query
+    lost its nearest cell).  The candidates now come from the exact path (ADC top-k of the probed cells), so the true
+    nearest rows of the probed cells are returned."""
+    from annlite_amd import Metric
+
+    rng = np.random.RandomState(11)
+    base, q = _data(rng, 300, 64, 30)
+    x = np.repeat(base, 40, axis=0)
+    idx, codec, vq, _ = _build(x.shape[0], 64, 16, 6, Metric.EUCLIDEAN, seed=11, x=x, rerank=True)
+    idx.cand_cap = 64
+    P, k = 2, 10
+    d, i = idx.search_batch(q, limit=k, n_probe=P, rerank_k=16)
+    assert (i >= 0).all() and (np.diff(d, axis=1) >= -1e-6).all()
+    # exact distances of the returned rows, and nothing of the probed cells is closer than the k-th returned row
+    # beyond what a 16-row ADC candidate pool can miss: the best returned row must be the true nearest of the probed cells
+    cells = idx.probe_cells(idx._pre(q), P).cpu().numpy()
+    cell_of = idx._cell_of[: idx._n_rows].cpu().numpy()
+    for b in range(q.shape[0]):
+        rows = np.nonzero(np.isin(cell_of, cells[b]))[0]
+        ex = np.sqrt(((x[rows] - q[b]) ** 2).sum(1))
+        np.testing.assert_allclose(d[b], np.sqrt(((x[i[b]] - q[b]) ** 2).sum(1)), rtol=1e-4, atol=1e-5)
+        assert abs(d[b, 0] - ex.min()) <= 1e-4 * max(1.0, ex.min()), (b, d[b, 0], ex.min())
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason='needs an AMD GPU')
 def test_small_and_empty_cells(oracle):
     """more cells than the data has clusters: some cells hold a handful of rows, queries still get exact answers"""
     from annlite_amd import Metric

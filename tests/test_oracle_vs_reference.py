@@ -1,5 +1,5 @@
 """Live pinning of the oracle against the REAL reference, run only where /root/reference and
-oracle/_ref exist (the build container).  Skipped on the GPU box -- parity there rests on the
+the build of oracle/build_ref.sh exist (the build container).  Skipped on the GPU box -- parity there rests on the
 golden fixtures.  Fresh seeds and larger sizes than the fixtures."""
 import os
 import sys
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import ref_import  # noqa: E402
 
-pytestmark = pytest.mark.skipif(not ref_import.available(), reason='reference tree / oracle/_ref not present')
+pytestmark = pytest.mark.skipif(not ref_import.available(), reason='reference tree / its build (oracle/build_ref.sh) not present')
 
 
 @pytest.fixture(scope='module')

@@ -55,6 +55,31 @@ def _worker(rank, world, port, q):
     d2, i2 = ShardedSearcher(scan2, numpy_merge).search(lut, k)
     rd2, ri2 = pq_oracle.adc_search_c(lut, small, k)
     ok = ok and bool(np.array_equal(d2.numpy(), rd2) and np.array_equal(i2.numpy(), ri2))
+    # ---- the PRODUCT's exchange: ShardedPQIndex.search_batch_async's packed path (ONE all-gather of [B, k, 2] int64 =
+    # (global id, bits of the raw ADC sum), merge on the raw sums, sqrt epilogue last) -- the local scan injected
+    from annlite_amd.sharded import ShardedPQIndex, numpy_merge_packed
+
+    class FakeShard:  # what ShardedPQIndex needs of PQFlatGpuIndex
+        sqrt_epilogue = True  # EUCLIDEAN: hnsw/index.py:164-165
+
+        def __init__(self, rows, base):
+            self.rows, self.base = rows, base
+
+        def search_batch_packed(self, queries_lut, kk, row_base):
+            assert row_base == self.base
+            d, i = pq_oracle.adc_search_c(queries_lut.numpy(), self.rows, kk, id_base=row_base)
+            out = np.empty(d.shape + (2,), dtype=np.int64)
+            out[..., 0] = i  # (a shard shorter than k pads with -1 / +inf)
+            out[..., 1] = d.view(np.uint32).astype(np.int64)
+            return torch.from_numpy(out)
+
+    lut_t = torch.from_numpy(lut)
+    for rows_all in (codes, codes[:13]):  # ties across the shard boundary; a shard smaller than k
+        l3, h3 = shard_range(rows_all.shape[0], world, rank)
+        sh = ShardedPQIndex(FakeShard(rows_all[l3:h3], l3), row_base=l3, merge=numpy_merge, merge_packed=numpy_merge_packed)
+        pd, pi = sh.search_batch_async(lut_t, limit=k).result()
+        rd3, ri3 = pq_oracle.adc_search_c(lut, rows_all, k)
+        ok = ok and bool(np.array_equal(pd.numpy(), np.sqrt(rd3)) and np.array_equal(pi.numpy(), ri3))
     q.put((rank, ok))
     dist.destroy_process_group()
 
