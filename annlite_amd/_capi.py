@@ -36,6 +36,7 @@ SYMBOLS = (
     'annlite_adc_dist',
     'annlite_adc_gather',
     'annlite_graph_search',
+    'annlite_graph_search_stats',
     'annlite_adc_scan_topk',
     'annlite_adc_scan_topk_packed',
     'annlite_pq_search_workspace_bytes',
@@ -138,6 +139,7 @@ def lib() -> ctypes.CDLL:
     L.annlite_scan_select_variant.argtypes = [i32]
     L.annlite_profile_last_scan_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]
     L.annlite_debug_counters.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    L.annlite_graph_search_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     for name in SYMBOLS:
         fn = getattr(L, name)  # AttributeError here == the .so does not export a declared symbol
         if name == 'annlite_ivf_max_tiles':
@@ -215,6 +217,13 @@ def profile_last_scan_ms() -> float:
     ms = ctypes.c_float(0.0)
     check(lib().annlite_profile_last_scan_ms(ctypes.byref(ms)), 'profile_last_scan_ms')
     return float(ms.value)
+
+
+def graph_search_stats():
+    """(expansions, rows evaluated) of the last GPU graph walk (ANNLITE_DEBUG_COUNTERS=1)."""
+    out = (ctypes.c_uint64 * 2)()
+    check(lib().annlite_graph_search_stats(out), 'graph_search_stats')
+    return int(out[0]), int(out[1])
 
 
 def debug_counters():

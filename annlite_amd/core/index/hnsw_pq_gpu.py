@@ -173,7 +173,10 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
             if self.rerank and self._vectors is not None:
                 dist = ops.exact_gather_dist(int(self.metric), q, self._vectors, cand)
             else:
-                lut = self.pq_codec.get_dist_mat(q)  # [B, M, Ks] on the device
+                from ..._capi import LAYOUT_BMK
+
+                kind, xq = self._scan_inputs(x, q)  # (host buffers: normalised like the flat index's queries, bit for bit)
+                lut = ops.lut_build(xq, self.pq_codec.codebooks_dev, kind, LAYOUT_BMK)  # [B, M, Ks] on the device
                 dist = ops.adc_gather(lut, self._plain_table(N), cand)
             kk = min(k, ef)
             d, pos = self._topk_rows_any(dist, kk)

@@ -274,7 +274,7 @@ class PQFlatGpuIndex(BaseIndex):
             d = torch.full((B, k), float('inf'), dtype=torch.float32, device=dev)
             i = torch.full((B, k), -1, dtype=torch.int64, device=dev)
         elif self.rerank and self._vectors is not None:
-            d, i = self._search_rerank(q, k, valid, N, rerank_k)
+            d, i = self._search_rerank(q, k, valid, N, rerank_k, self._scan_inputs(x, q))
         elif k <= 64:
             # table build + scan + top-k: one C call (annlite_pq_search_topk)
             kind, xq = self._scan_inputs(x, q)
@@ -285,7 +285,7 @@ class PQFlatGpuIndex(BaseIndex):
                 sqrt=self.metric == Metric.EUCLIDEAN), B, N, k)  # hnsw/index.py:164-165
             row_base = 0
         else:
-            d, i = self._search_large_k(q, k, valid, N)
+            d, i = self._search_large_k(q, k, valid, N, self._scan_inputs(x, q))
         if row_base:
             i = torch.where(i >= 0, i + row_base, i)  # (paths that do not take row_base natively)
         if is_np:
@@ -321,9 +321,12 @@ class PQFlatGpuIndex(BaseIndex):
             return ops.codes_skew(self._codes[:N], inverse=True)
         return self._codes[:N]
 
-    def _search_large_k(self, q, k, valid, N):
+    def _search_large_k(self, q, k, valid, N, scan_in=None):
         """k > 64: all distances per query (adc_dist kernel) + a stable device sort (ties -> id asc)."""
-        lut = self.pq_codec.get_dist_mat(q)
+        from ..._capi import LAYOUT_BMK, LAYOUT_TILED  # noqa: F401
+
+        kind, xq = scan_in if scan_in is not None else self.pq_codec.scan_inputs(q)
+        lut = ops.lut_build(xq, self.pq_codec.codebooks_dev, kind, LAYOUT_BMK)
         codes = self._plain_codes(N)
         shifts = torch.arange(32, device=q.device, dtype=torch.int64)
         vb = (((valid.to(torch.int64) & 0xFFFFFFFF)[:, None] >> shifts[None, :]) & 1).bool().reshape(-1)[:N]  # unpack
@@ -355,12 +358,15 @@ class PQFlatGpuIndex(BaseIndex):
         sd, si = sd[:, :k], si[:, :k]
         return sd, torch.where(torch.isinf(sd), torch.full_like(si, -1), si)
 
-    def _search_rerank(self, q, k, valid, N, rerank_k):
+    def _search_rerank(self, q, k, valid, N, rerank_k, scan_in=None):
         B = q.shape[0]
         rk = int(rerank_k or 64)
         rk = max(1, min(64, rk))
         plan = scan_plan(N, self.M, self.Ks, self.code_bytes, B, rk)
-        lut = self.pq_codec.get_dist_mat_tiled(q, plan.qi) if plan.fast else self.pq_codec.get_dist_mat(q)
+        from ..._capi import LAYOUT_BMK, LAYOUT_TILED
+
+        kind, xq = scan_in if scan_in is not None else self.pq_codec.scan_inputs(q)
+        lut = ops.lut_build(xq, self.pq_codec.codebooks_dev, kind, LAYOUT_TILED if plan.fast else LAYOUT_BMK, plan.qi)
         _, cand = ops.adc_scan_candidates(self._codes, lut, B, rk, self.M, self.Ks, valid_bits=valid, n_rows=N,
                                           codes_layout=self._layout(), workspace=self._ws)
         exact = ops.exact_gather_dist(int(self.metric), q, self._vectors, cand)  # [B, R]

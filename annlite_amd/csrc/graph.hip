@@ -73,8 +73,10 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
                                                                const uint32_t *__restrict__ valid,
                                                                const float *__restrict__ lut_bmk, int B, int Ks, int ef,
                                                                int hash_bits, int64_t *__restrict__ out_ids,
-                                                               float *__restrict__ out_dist) {
+                                                               float *__restrict__ out_dist,
+                                                               unsigned long long *__restrict__ stats) {
     constexpr int CW = M / 4;
+    unsigned int n_expand = 0, n_eval = 0;  // (ANNLITE_DEBUG_COUNTERS: link lists read, rows evaluated)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
         const uint32_t node = have ? seeds[s0 + lane] : 0u;
         const bool mine = have && (int64_t)node < N;
         const float d = mine ? pq_lookup(node) : 0.f;
+        n_eval += (unsigned int)__popcll(__ballot(mine));
         offer(mine, node, d);
     }
 #pragma unroll
@@ -186,6 +189,7 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
             }
         const uint32_t *ll = links + (int64_t)node * (links_per_node + 1);
         const uint32_t cnt = ll[0];
+        ++n_expand;
         bool mine = false;
         uint32_t nb = 0;
         float d = 0.f;
@@ -193,6 +197,7 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
             mine = base + lane < cnt;
             nb = mine ? ll[1 + base + lane] : 0u;
             mine = mine && (int64_t)nb < N && visit(nb);
+            n_eval += (unsigned int)__popcll(__ballot(mine));
             d = mine ? pq_lookup(nb) : 0.f;
             offer(mine, nb, d);
         }
@@ -209,6 +214,10 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
             out_dist[(int64_t)b * ef + i] = none ? __builtin_inff() : ordered_to_f32(L.hi[e]);
         }
     }
+    if (stats && lane == 0) {
+        atomicAdd(stats + 0, (unsigned long long)n_expand);
+        atomicAdd(stats + 1, (unsigned long long)n_eval);
+    }
 }
 
 }  // namespace annlite
@@ -218,7 +227,7 @@ using namespace annlite;
 template <int M, int E>
 static int launch_beam(const uint32_t *links, int lpn, const uint32_t *seeds, int n_seeds, const uint8_t *codes, int64_t N,
                        const uint32_t *valid, const float *lut, int64_t B, int64_t Ks, int ef, int hash_bits,
-                       int64_t *out_ids, float *out_dist, hipStream_t st) {
+                       int64_t *out_ids, float *out_dist, unsigned long long *stats, hipStream_t st) {
     const size_t per_wave = (size_t)M * Ks * 4 + ((size_t)4 << hash_bits);
     int wpb = (int)((size_t)160 * 1024 / per_wave);
     if (wpb > 4) wpb = 4;
@@ -227,8 +236,21 @@ static int launch_beam(const uint32_t *links, int lpn, const uint32_t *seeds, in
     auto fn = graph_beam_search_kernel<M, E>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(fn, dim3((unsigned)((B + wpb - 1) / wpb)), dim3(wpb * 64), lds, st, links, lpn, seeds, n_seeds, codes, N,
-                       valid, lut, (int)B, (int)Ks, ef, hash_bits, out_ids, out_dist);
+                       valid, lut, (int)B, (int)Ks, ef, hash_bits, out_ids, out_dist, stats);
     return launch_status("graph_beam_search_kernel");
+}
+
+static unsigned long long *g_graph_stats = nullptr;  // debug only (ANNLITE_DEBUG_COUNTERS): leaked 16-byte device buffer
+
+extern "C" int annlite_graph_search_stats(uint64_t *out2) {
+    ANNLITE_REQUIRE(out2 != nullptr, "out2 is NULL");
+    if (!g_graph_stats) {
+        set_error("no counters recorded (set ANNLITE_DEBUG_COUNTERS=1 before the walk)");
+        return ANNLITE_ERR_INVALID;
+    }
+    ANNLITE_HIP_TRY(hipDeviceSynchronize());
+    ANNLITE_HIP_TRY(hipMemcpy(out2, g_graph_stats, 16, hipMemcpyDeviceToHost));
+    return ANNLITE_OK;
 }
 
 extern "C" int annlite_graph_search(const uint32_t *links_dev, int links_per_node, const uint32_t *seeds_dev, int64_t n_seeds,
@@ -247,13 +269,19 @@ extern "C" int annlite_graph_search(const uint32_t *links_dev, int links_per_nod
     int hash_bits = ef <= 128 ? 12 : 13;
     if (const char *e = getenv("ANNLITE_GRAPH_HASH_BITS")) hash_bits = atoi(e);
     const uint8_t *codes = (const uint8_t *)codes_dev;
+    unsigned long long *stats = nullptr;
+    if (getenv("ANNLITE_DEBUG_COUNTERS")) {
+        if (!g_graph_stats) ANNLITE_HIP_TRY(hipMalloc((void **)&g_graph_stats, 16));
+        ANNLITE_HIP_TRY(hipMemsetAsync(g_graph_stats, 0, 16, st));
+        stats = g_graph_stats;
+    }
 #define ANNLITE_BEAM(MM)                                                                                                \
     (ef <= 64 ? launch_beam<MM, 1>(links_dev, links_per_node, seeds_dev, (int)n_seeds, codes, N, valid_bits_dev, lut_bmk_dev, \
-                                   B, Ks, ef, hash_bits, out_ids_dev, out_dist_dev, st)                               \
+                                   B, Ks, ef, hash_bits, out_ids_dev, out_dist_dev, stats, st)                        \
      : ef <= 128 ? launch_beam<MM, 2>(links_dev, links_per_node, seeds_dev, (int)n_seeds, codes, N, valid_bits_dev,     \
-                                      lut_bmk_dev, B, Ks, ef, hash_bits, out_ids_dev, out_dist_dev, st)               \
+                                      lut_bmk_dev, B, Ks, ef, hash_bits, out_ids_dev, out_dist_dev, stats, st)        \
                  : launch_beam<MM, 4>(links_dev, links_per_node, seeds_dev, (int)n_seeds, codes, N, valid_bits_dev,     \
-                                      lut_bmk_dev, B, Ks, ef, hash_bits, out_ids_dev, out_dist_dev, st))
+                                      lut_bmk_dev, B, Ks, ef, hash_bits, out_ids_dev, out_dist_dev, stats, st))
     if (M == 8) return ANNLITE_BEAM(8);
     if (M == 16) return ANNLITE_BEAM(16);
     return ANNLITE_BEAM(32);

@@ -145,6 +145,10 @@ ANNLITE_API int annlite_graph_search(const uint32_t *links_dev, int links_per_no
                          int64_t n_seeds, const void *codes_dev, int64_t N, int64_t M, int64_t Ks,
                          const uint32_t *valid_bits_dev, const float *lut_bmk_dev, int64_t B, int ef,
                          int64_t *out_ids_dev, float *out_dist_dev, void *stream);
+/* Debug aid: with ANNLITE_DEBUG_COUNTERS=1 the walk counts [0] expansions (link lists read) and [1] rows evaluated
+ * (PQLookup sums) over the batch; this copies the two counters of the last walk to the host (the roofline of
+ * scripts/bench_hnsw.py: algorithmic bytes = expansions * 4 (links_per_node + 1) + evaluations * M). */
+ANNLITE_API int annlite_graph_search_stats(uint64_t *out2);
 
 /* ------------------------------------------------------------------------------------------------
  * Batched flat ADC scan + top-k: the hot path.

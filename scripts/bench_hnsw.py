@@ -114,7 +114,58 @@ for walk in ('gpu', 'host'):
     torch.cuda.synchronize()
     walks[walk] = B * a.steps / (time.perf_counter() - t)
 walk_qps = walks
+
+# ---- roofline of the dominant kernel (graph_beam_search_kernel): HIP-event time of the walk launch alone, algorithmic
+# bytes from the walk's own counters (expansions x one link list + evaluated rows x M code bytes) against the HBM
+# peak -- a pointer chase is latency-bound, the fraction says how far from streaming it is -----------------------------
+from annlite_amd import _capi, ops  # noqa: E402
+from annlite_amd._capi import LAYOUT_BMK, LUT_L2  # noqa: E402
+
+index.walk = 'gpu'
+qd = index._pre(q)
+_, xg = codec.scan_inputs(qd)
+links, seeds = index._export_graph()
+lut = ops.lut_build(xg, codec.codebooks_dev, LUT_L2, LAYOUT_BMK)
+plain = index._plain_table(index._n_rows)
+os.environ['ANNLITE_DEBUG_COUNTERS'] = '1'
+ops.graph_search(links, seeds, plain, lut, a.ef_search, valid_bits=index._valid, n_rows=index._n_rows)
+n_expand, n_eval = _capi.graph_search_stats()
+del os.environ['ANNLITE_DEBUG_COUNTERS']
+kms = []
+for _ in range(max(3, a.steps)):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.graph_search(links, seeds, plain, lut, a.ef_search, valid_bits=index._valid, n_rows=index._n_rows)
+    e1.record()
+    e1.synchronize()
+    kms.append(e0.elapsed_time(e1))
+kernel_ms = float(np.mean(kms))
+lpn = links.shape[1] - 1
+alg_bytes = n_expand * 4.0 * (lpn + 1) + n_eval * float(M) + B * seeds.numel() * float(M)
+roofline = {'bound': 'hbm', 'achieved': alg_bytes / (kernel_ms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+            'frac': alg_bytes / (kernel_ms * 1e-3) / 1e9 / 8000.0, 'traffic': None,
+            'kernel': 'graph_beam_search_kernel', 'kernel_ms': kernel_ms,
+            'algorithmic_bytes_per_launch': alg_bytes, 'expansions_per_query': n_expand / B, 'rows_evaluated_per_query': n_eval / B,
+            'note': 'every evaluated row is a random 16-byte read (one 64-byte sector): the walk is latency-bound by design'}
+
+# ---- CPU baseline: the same graph walked on the host by libannlite_graph.so (C++ restatement of hnswlib's searchKnn /
+# searchBaseLayerST with PQLookup distances), ONE thread = the reference's execution model (knn_query runs single-threaded
+# for AnnLite's one-query calls, hnsw_bindings.cpp:332-334), bounded sample; all cores beside it ------------------------
+index.walk = 'host'
+nq1 = min(B, 256)
+threads_all = index.n_threads
+index.n_threads = 1
+index.candidates(q[:8], a.ef_search)
+t0 = time.perf_counter()
+index.candidates(q[:nq1], a.ef_search)
+cpu1 = nq1 / (time.perf_counter() - t0)
+index.n_threads = threads_all
+cpu_baseline = {'value': cpu1, 'unit': 'queries/s', 'cores': 1, 'kind': 'port',
+                'sample': f'{nq1} queries, graph walk ef_search={a.ef_search} over {N} rows on the host (candidate lists only)',
+                'all_cores': {'value': walks['host'], 'cores': os.cpu_count(), 'sample': f'{B} queries x {a.steps}'}}
 print(json.dumps({'config': f'HNSW-over-PQ: {N} x {D}-dim, PQ m={M} ks=256, L2, max_connection={a.max_connection}, '
                             f'ef_construction={a.ef_construction}, ef_search={a.ef_search}, batch {B}, k={k}',
+                  'metric': 'queries/sec', 'value': res['hnsw_gpu_walk_exact_rerank']['queries_per_s'], 'unit': 'queries/s',
+                  'recall_at_10': res['hnsw_gpu_walk_exact_rerank']['recall_at_10'],
                   'build_s': build_s, 'build_rows_per_s': N / build_s, 'host_cpus_reported': os.cpu_count(), 'note': 'the graph library starts min(CPUs, affinity, cgroup quota) threads',
-                  'graph_walk_queries_per_s': walk_qps, **res}))
+                  'graph_walk_queries_per_s': walk_qps, 'roofline': roofline, 'cpu_baseline': cpu_baseline, **res}))

@@ -818,6 +818,72 @@ def test_hnsw_pq_candidates_with_gpu_rerank(ops, mname, metric, walk):
     assert rr >= 0.9, rr
 
 
+def test_config5_hnsw_pq_1m_rows_oracle_side(ops, oracle):
+    """BASELINE config 5 at a size the driver can build (1M x 128-d, PQ m=16, ef_search=128; 5M is
+    scripts/bench_hnsw.py): graph walk on the GPU, checked from the ORACLE side --
+      * every distance the walk reports is hnswlib::PQLookup of that row (space_pq.h:15-37): the CPU oracle's
+        adc_gather_c on the walk's candidate ids, bit for bit;
+      * the top-10 of the graph search (ADC ranking) overlaps the oracle's EXHAUSTIVE ADC top-10 >= 0.9;
+      * with the exact re-rank of the 128 candidates recall@10 vs brute force >= 0.9;
+      * result conventions of HnswIndex.search: sqrt for EUCLIDEAN (hnsw/index.py:164-165), closest first
+        (hnswalg.h:1286-1294 pops the heap into ascending order)."""
+    import torch
+
+    from annlite_amd import HnswPQGpuIndex, Metric, PQCodec
+    from annlite_amd._capi import LAYOUT_BMK, LUT_L2
+
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    N, D, M, B, k, ef = 1_000_000, 128, 16, 256, 10, 128
+    A = torch.randn((16, D), generator=g, device=dev)
+
+    def gen(n):
+        return (torch.randn((n, 16), generator=g, device=dev) @ A + 0.05 * torch.randn((n, D), generator=g, device=dev)).contiguous()
+
+    codec = PQCodec(dim=D, n_subvectors=M, n_clusters=256, metric=Metric.EUCLIDEAN, n_init=1)
+    codec.seed = 7
+    x = gen(N)
+    codec.fit(x[:20480], iter=15)
+    hn = HnswPQGpuIndex(dim=D, metric=Metric.EUCLIDEAN, pq_codec=codec, initial_size=N, ef_search=ef, rerank=True)
+    for c0 in range(0, N, 250_000):
+        hn.add_with_ids(x[c0:c0 + 250_000], torch.arange(c0, c0 + 250_000, device=dev, dtype=torch.int64))
+    assert hn.size == N
+    q = gen(B)
+    # -- the walk's candidates against the oracle's PQLookup
+    qd = hn._pre(q)
+    cid, cd = hn.candidates(qd, ef)
+    codes_np = ops.codes_to_numpy(hn._plain_codes(N))
+    lut_np = ops.lut_build(codec.scan_inputs(qd)[1], codec.codebooks_dev, LUT_L2, LAYOUT_BMK).cpu().numpy()
+    cid_np, cd_np = cid.cpu().numpy(), cd.cpu().numpy()
+    assert (cid_np >= 0).all() and (np.diff(cd_np, axis=1) >= 0).all()
+    for b in range(0, B, 4):  # 64 queries x 128 candidates
+        assert np.array_equal(cd_np[b], oracle.adc_gather_c(lut_np[b], codes_np, cid_np[b])), b
+    # -- ADC ranking of the graph search vs the oracle's exhaustive ADC top-10
+    hn.rerank = False
+    hd, hi = hn.search_batch(q, limit=k)
+    hd, hi = hd.cpu().numpy(), hi.cpu().numpy()
+    nq = 64
+    od, oi = oracle.adc_search_c(lut_np[:nq], codes_np, k, threads=oracle.max_threads())
+    overlap = np.mean([len(set(hi[b]) & set(oi[b])) / k for b in range(nq)])
+    assert overlap >= 0.9, overlap
+    assert (np.diff(hd, axis=1) >= 0).all()
+    for b in range(nq):  # same ids => same (sqrt of the) oracle distance
+        pos = {int(i): j for j, i in enumerate(oi[b])}
+        for j, i in enumerate(hi[b]):
+            if int(i) in pos:
+                assert hd[b][j] == np.sqrt(od[b][pos[int(i)]])
+    # -- exact re-rank of the candidates: recall@10 vs brute force
+    hn.rerank = True
+    rd, ri = hn.search_batch(q, limit=k)
+    best = torch.cat([torch.cdist(q, x[c0:c0 + 250_000]) for c0 in range(0, N, 250_000)], dim=1)
+    truth = best.topk(k, largest=False).indices.cpu().numpy()
+    ri = ri.cpu().numpy()
+    rec = np.mean([len(set(ri[b]) & set(truth[b])) / k for b in range(B)])
+    assert rec >= 0.9, rec
+    assert bool((rd[:, 1:] >= rd[:, :-1]).all())
+
+
 def test_annlite_facade_with_graph_index(ops, tmp_path):
     """AnnLite(..., graph=True): same API, HnswPQGpuIndex underneath; its matches agree with the exhaustive facade."""
     from annlite_amd import AnnLite
