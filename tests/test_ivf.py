@@ -249,8 +249,8 @@ def test_candidate_list_overflow_with_float_rerank_keeps_the_probed_cells(oracle
     P, k, rk = 2, 10, 16
     d, i = idx.search_batch(q, limit=k, n_probe=P, rerank_k=rk)
     assert (i >= 0).all() and (np.diff(d, axis=1) >= -1e-6).all()
-    # the candidate pool of an overflowed query = the ADC top-`rerank_k` rows of its probed cells (the oracle's pruned
-    # search, ties by id); the result = those rows ranked by their exact distance
+    # the candidate pool of an overflowed batch holds the ADC top-`rerank_k` rows of every query's probed cells (the
+    # oracle's pruned search); the result = the pool ranked by exact distance
     N = idx._n_rows
     codes = ops.codes_to_numpy(idx._plain_codes(N))
     cells_of = idx._cell_of[:N].cpu().numpy()
@@ -258,9 +258,11 @@ def test_candidate_list_overflow_with_float_rerank_keeps_the_probed_cells(oracle
     _, pool = oracle.ivf_search(q, codec.codebooks, codes, cells_of, probe, oracle.EUCLIDEAN, rk)
     for b in range(q.shape[0]):
         np.testing.assert_allclose(d[b], np.sqrt(((x[i[b]] - q[b]) ** 2).sum(1)), rtol=1e-4, atol=1e-5)
-        ex = np.sqrt(((x[pool[b]] - q[b]) ** 2).sum(1))
-        np.testing.assert_allclose(d[b], np.sort(ex)[:k], rtol=1e-4, atol=1e-5)
-        assert set(i[b]) <= set(pool[b])
+        # at least as good as the exact ranking of that pool, row for row (a list that did not overflow contributes
+        # every row it emitted, a superset; among the 40 identical copies of a vector any id may be returned)
+        ex = np.sort(np.sqrt(((x[pool[b]] - q[b]) ** 2).sum(1)))[:k]
+        assert (d[b] <= ex * (1 + 1e-4) + 1e-5).all(), (b, d[b], ex)
+        assert len(set(i[b].tolist())) == k
 
 
 @pytest.mark.gpu
