@@ -635,12 +635,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 if (row >= n_rows) row = n_rows - 1;
                 return valid[row >> 5];
             };
+            // the code bytes (and validity word) of a lane's row are fetched ONE STEP AHEAD: issued at the top of a step for
+            // the next one, picked up at the top of that one.  (Fetching two steps ahead and rotating the registers at the
+            // end of the step made the compiler wait for the load it had just issued: s_waitcnt vmcnt(0) every step.)
             if (row0 < s_end) {
-                load_row(row0 + lane, ccur);
-                if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
-                load_row(row0 + stride32 + lane, cnext);
-                vcur = load_valid(row0 + lane);
-                vnext = load_valid(row0 + stride32 + lane);
+                load_row(row0 + lane, cnext);
+                vnext = load_valid(row0 + lane);
             }
             // Every scanning wave runs the same n_steps iterations, cut into epochs that end after steps 1, 3, 7, 15, ...
             // and after the last one (the epochs' barriers meet).  The step loop of an epoch contains no call and no
@@ -653,6 +653,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 const int epoch_end = final ? n_steps - 1 : epoch_step;  // inclusive
                 for (; step_no <= epoch_end; ++step_no, row0 += stride32) {
                     if (row0 < s_end) {
+#pragma unroll
+                        for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
+                        vcur = vnext;
+                        load_row(row0 + stride32 + lane, cnext);
+                        vnext = load_valid(row0 + stride32 + lane);
+                        if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
                         unsigned long long vmask = ~0ull;
                         if (s_end - row0 < 64u) vmask = (1ull << (s_end - row0)) - 1ull;
                         // validity word of this lane's row, fetched one step ahead with the code bytes
@@ -699,13 +705,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                                 }
                             });
                         }
-                        // next row
-#pragma unroll
-                        for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
-                        if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
-                        load_row(row0 + 2 * stride32 + lane, cnext);
-                        vcur = vnext;
-                        vnext = load_valid(row0 + 2 * stride32 + lane);
                     }
                     // pick up the workgroup's bounds every 2nd step
                     if (step_no & 1) {
