@@ -364,12 +364,16 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
             if (row >= a.N) row = a.N - 1;
             return a.valid[row >> 5];
         };
+        // the code bytes (and validity word) of a lane's row are fetched ONE STEP AHEAD: issued at the top of a step for the
+        // next one and picked up at the top of that one (fetched two steps ahead and rotated at the END of the step, the
+        // compiler waited for the load it had just issued -- s_waitcnt vmcnt(0) in every step)
         if (row0 < slice_end) {
-            load_row(row0 + lane, ccur);
+            load_row(row0 + lane, cnext);
+            vnext = load_valid(row0 + lane);
+#pragma unroll
+            for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];  // (tile mode: the seed bound below looks at the first row)
+            vcur = vnext;
             if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
-            load_row(row0 + stride + lane, cnext);
-            vcur = load_valid(row0 + lane);
-            vnext = load_valid(row0 + stride + lane);
         }
         if constexpr (TILES) {
             // Integer seed bound (no separate seed launch): every 16-lane row of every wave takes the per-slot MINIMUM
@@ -433,6 +437,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
             const int n_steps = (int)((slice_end - slice_begin + stride - 1) / stride);
             for (; step_no < n_steps; ++step_no, row0 += stride) {
                 if (row0 < slice_end) {
+#pragma unroll
+                    for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
+                    vcur = vnext;
+                    load_row(row0 + stride + lane, cnext);
+                    vnext = load_valid(row0 + stride + lane);
+                    if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
                     unsigned long long vmask = ~0ull;
                     if (slice_end - row0 < 64) vmask = (1ull << (int)(slice_end - row0)) - 1ull;
                     if (a.valid) vmask &= __ballot((vcur >> (lane & 31)) & 1u);
@@ -466,12 +476,6 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                             }
                         }
                     }
-#pragma unroll
-                    for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
-                    if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
-                    load_row(row0 + 2 * stride + lane, cnext);
-                    vcur = vnext;
-                    vnext = load_valid(row0 + 2 * stride + lane);
                 }
                 if (TileState<QT>::is_round(step_no, n_steps)) {
                     __syncthreads();  // every wave's appends are in LDS
@@ -483,6 +487,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
             }
         } else
         for (; row0 < slice_end; row0 += stride, ++step_no) {
+#pragma unroll
+            for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
+            vcur = vnext;
+            load_row(row0 + stride + lane, cnext);
+            vnext = load_valid(row0 + stride + lane);
+            if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
             unsigned long long vmask = ~0ull;
             if (slice_end - row0 < 64) vmask = (1ull << (int)(slice_end - row0)) - 1ull;
             // validity word of this lane's row, fetched one step ahead with the code bytes (a scalar load here
@@ -587,12 +597,6 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                 for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
             }
             // next row
-#pragma unroll
-            for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
-            if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
-            load_row(row0 + 2 * stride + lane, cnext);
-            vcur = vnext;
-            vnext = load_valid(row0 + 2 * stride + lane);
         }
 
         if (qcnt) qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
@@ -783,12 +787,16 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
         uint32_t ccur[CW], cnext[CW];
         uint32_t vcur = ~0u, vnext = ~0u;
         u32x2 thp = *(const u32x2 *)(smem + shq_off);  // packed (0x8000 | qthr) of the 4 queries
+        // the code bytes (and validity word) of a lane's row are fetched ONE STEP AHEAD: issued at the top of a step for the
+        // next one and picked up at the top of that one (fetched two steps ahead and rotated at the END of the step, the
+        // compiler waited for the load it had just issued -- s_waitcnt vmcnt(0) in every step)
         if (row0 < slice_end) {
-            load_row(row0 + lane, ccur);
+            load_row(row0 + lane, cnext);
+            vnext = load_valid(row0 + lane);
+#pragma unroll
+            for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];  // (tile mode: the seed bound below looks at the first row)
+            vcur = vnext;
             if constexpr (!SKEWED) encode_plain(ccur);
-            load_row(row0 + stride + lane, cnext);
-            vcur = load_valid(row0 + lane);
-            vnext = load_valid(row0 + stride + lane);
         }
         // integer sums of this lane's row for the 4 queries (2 dwords x 2 u16), look-ups in 4 chunks of 16
         auto row_sums = [&](const uint32_t (&cc)[CW], u32x2 &acc) {
@@ -857,6 +865,12 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
             const int n_steps = (int)((slice_end - slice_begin + stride - 1) / stride);
             for (; step_no < n_steps; ++step_no, row0 += stride) {
                 if (row0 < slice_end) {
+#pragma unroll
+                    for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
+                    vcur = vnext;
+                    load_row(row0 + stride + lane, cnext);
+                    vnext = load_valid(row0 + stride + lane);
+                    if constexpr (!SKEWED) encode_plain(ccur);
                     unsigned long long vmask = ~0ull;
                     if (slice_end - row0 < 64) vmask = (1ull << (int)(slice_end - row0)) - 1ull;
                     if (a.valid) vmask &= __ballot((vcur >> (lane & 31)) & 1u);
@@ -880,12 +894,6 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
                             }
                         }
                     }
-#pragma unroll
-                    for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
-                    if constexpr (!SKEWED) encode_plain(ccur);
-                    load_row(row0 + 2 * stride + lane, cnext);
-                    vcur = vnext;
-                    vnext = load_valid(row0 + 2 * stride + lane);
                 }
                 if (TileState<QT>::is_round(step_no, n_steps)) {
                     __syncthreads();
@@ -896,6 +904,12 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
             }
         } else
         for (; row0 < slice_end; row0 += stride, ++step_no) {
+#pragma unroll
+            for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
+            vcur = vnext;
+            load_row(row0 + stride + lane, cnext);
+            vnext = load_valid(row0 + stride + lane);
+            if constexpr (!SKEWED) encode_plain(ccur);
             unsigned long long vmask = ~0ull;
             if (slice_end - row0 < 64) vmask = (1ull << (int)(slice_end - row0)) - 1ull;
             if (a.valid) vmask &= __ballot((vcur >> (lane & 31)) & 1u);
@@ -978,12 +992,6 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
                 asm volatile("" ::: "memory");
                 thp = *(const u32x2 *)(smem + shq_off);
             }
-#pragma unroll
-            for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
-            if constexpr (!SKEWED) encode_plain(ccur);
-            load_row(row0 + 2 * stride + lane, cnext);
-            vcur = vnext;
-            vnext = load_valid(row0 + 2 * stride + lane);
         }
         if (qcnt) qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
 
