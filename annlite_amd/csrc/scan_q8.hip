@@ -33,6 +33,10 @@
 //      [built-for T x32 @+704][control @+736][lists u64 x32x64 @+768][gjl u64 x32][ring u64 x 1024]
 #include "scan_lists.h"
 
+#ifndef ANNLITE_Q8_EXP
+#define ANNLITE_Q8_EXP 0  // (timing experiments, results wrong: 1 = look-ups without the adds, 2 = adds without the look-ups)
+#endif
+
 namespace annlite {
 
 constexpr int kQ8Target = 64;  // T right after a (re)build
@@ -397,9 +401,14 @@ __device__ __forceinline__ bool q8_item_map(const ScanArgs &a, int item, int &ti
     return tile < a.n_tiles && slice < a.n_slices;
 }
 
-template <int M, int NW, bool SKEWED>
+// PRE16: the step loop reads the PRESCALED companion of the SKEWED table (u16 [N][M], annlite_codes_prescale): entry j of row n
+// is the LDS entry index (code << 5) | ((n + j) % 16) of its look-up, so an address is ONE SDWA shift of a half-word -- no byte
+// extraction plus add of a per-lane base, and no 16 base registers.  The exact sums of the candidates and the seed keep
+// reading the u8 table.
+template <int M, int NW, bool SKEWED, bool PRE16>
 __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const ScanArgs a) {
-    constexpr int QG = 16, NQ = 2, QT = QG * NQ, CW = M / 4, EB = 16, RB = M * EB, KSTRIDE = NQ * RB;
+    constexpr int QG = 16, NQ = 2, QT = QG * NQ, CW = PRE16 ? M / 2 : M / 4, EB = 16, RB = M * EB, KSTRIDE = NQ * RB;
+    static_assert(!PRE16 || (SKEWED && M == 16), "the prescaled companion exists for the SKEWED M = 16 table");
     constexpr int NS = NW - 1;  // scanning waves; wave NS is the consumer
     static_assert(M % 8 == 0 && M <= 32 && (KSTRIDE & (KSTRIDE - 1)) == 0, "unsupported shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -463,6 +472,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             *ring.tail = 0;
             *ring.head = 0;
             *ring.arrived = 0;
+            *(volatile uint32_t *)(smem + ring_ctl_off + 64) = 0;  // the block counter the scanning waves draw from
         }
         q8_rebuild<M, NW>(ba, tile, 1);  // (its barriers cover the initialisation above)
 
@@ -565,15 +575,34 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             bool abit[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) abit[i] = (((s >> 2) >> i) & 1) != 0;
-            const unsigned char *mbase[M];
+            // LDS byte addresses as integers (the table starts at the workgroup's LDS address lds0: 0 -- all LDS of this kernel
+            // is dynamic --, which the PRE16 path relies on: its addresses come straight out of the code table)
+            typedef const u32x4 __attribute__((address_space(3))) *lds_entry_ptr;
+            const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+            if constexpr (PRE16) {
+                if (lds0 != 0u) __builtin_trap();
+            }
+            uint32_t mbase[PRE16 ? 1 : M];
+            if constexpr (!PRE16) {
 #pragma unroll
-            for (int t = 0; t < M; ++t) mbase[t] = smem + ((s + t) % M) * EB;
-            const uint32_t *codes32 = (const uint32_t *)a.codes;
+                for (int t = 0; t < M; ++t) mbase[t] = lds0 + (uint32_t)(((s + t) % M) * EB);
+            }
+            const uint32_t *codes32 = PRE16 ? (const uint32_t *)a.codes16 : (const uint32_t *)a.codes;
             // rows are < 2^32 per call (plan): 32-bit row arithmetic keeps the loop control in SGPRs
-            const uint32_t s_end = (uint32_t)slice_end, stride32 = (uint32_t)stride, n_rows = (uint32_t)a.N;
-            uint32_t row0 = (uint32_t)slice_begin + (uint32_t)wave * 64u;
+            const uint32_t s_begin = (uint32_t)slice_begin, s_end = (uint32_t)slice_end, n_rows = (uint32_t)a.N;
+            const uint32_t n_blocks = (s_end - s_begin + 63u) >> 6;
+            // The waves DRAW their blocks of 64 rows from a counter in LDS.  (The SIMD's arbiter favours its oldest wave, and
+            // one wave alone issues at about a third of the rate four reach together -- scripts/ubench/valu_cost.hip,
+            // step_loop.hip.  With the rows dealt out statically the favoured waves finished their share of an epoch early
+            // and the last ones ran it out alone: wave 0 sat at the epoch barriers for 45 % of the kernel.)
+            uint32_t *blk_ctr = (uint32_t *)(smem + ring_ctl_off + 64);
+            auto draw = [&]() -> uint32_t {  // (lane 0's value; broadcast a step later, where it is first needed)
+                uint32_t v = 0;
+                if (lane == 0) v = atomicAdd(blk_ctr, 1u);
+                return v;
+            };
             uint32_t ccur[CW], cnext[CW];
-            const unsigned char *addr[M];
+            uint32_t addr[M];
             auto load_row = [&](uint32_t row, uint32_t (&c)[CW]) {
                 if (row >= n_rows) row = n_rows - 1;
                 const uint32_t *p = codes32 + (int64_t)row * CW;
@@ -593,16 +622,29 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 }
             };
             auto make_addr = [&](const uint32_t (&cc)[CW]) {
-                static_for<0, CW>([&](auto W) {
-                    constexpr int w = decltype(W)::value;
-                    uint32_t o0, o1, o2, o3;
-                    byte_shl4(cc[w], (uint32_t)ilog2_c(KSTRIDE), o0, o1, o2, o3);
-                    addr[4 * w + 0] = mbase[4 * w + 0] + o0;
-                    addr[4 * w + 1] = mbase[4 * w + 1] + o1;
-                    addr[4 * w + 2] = mbase[4 * w + 2] + o2;
-                    addr[4 * w + 3] = mbase[4 * w + 3] + o3;
-                });
+                if constexpr (PRE16) {
+                    static_for<0, CW>([&](auto W) {
+                        constexpr int w = decltype(W)::value;
+                        uint32_t o0, o1;
+                        word_shl2(cc[w], 4u, o0, o1);  // entry index -> byte address (16-byte entries)
+                        addr[2 * w + 0] = o0;
+                        addr[2 * w + 1] = o1;
+                    });
+                } else {
+                    static_for<0, CW>([&](auto W) {
+                        constexpr int w = decltype(W)::value;
+                        uint32_t o0, o1, o2, o3;
+                        byte_shl4(cc[w], (uint32_t)ilog2_c(KSTRIDE), o0, o1, o2, o3);
+                        addr[4 * w + 0] = mbase[4 * w + 0] + o0;
+                        addr[4 * w + 1] = mbase[4 * w + 1] + o1;
+                        addr[4 * w + 2] = mbase[4 * w + 2] + o2;
+                        addr[4 * w + 3] = mbase[4 * w + 3] + o3;
+                    });
+                }
             };
+            u32x4 thp[NQ];  // packed (0x80 | T) of the group's 16 queries
+#pragma unroll
+            for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
             // byte sums of the row for both entry groups (4 dwords x 4 x u8 each): the 2 M look-ups run through a ring of
             // DEPTH landing registers -- look-up i + DEPTH is issued as soon as look-up i has been added (all M look-ups
             // of a group in flight, as the u16 kernel has them, takes 64 landing VGPRs: with them the allocator spilled
@@ -610,24 +652,30 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             auto row_sums = [&](u32x4 (&acc)[NQ]) {
                 constexpr int DEPTH = ANNLITE_Q8_DEPTH, TOT = NQ * M;
                 u32x4 v[DEPTH];
+                auto fetch = [&](u32x4 &dst, uint32_t ad) {
+                    if constexpr (ANNLITE_Q8_EXP == 2) asm volatile("" : "=v"(dst) : "v"(ad));
+                    else dst = *(lds_entry_ptr)(uintptr_t)ad;
+                };
                 static_for<0, DEPTH>([&](auto I) {
                     constexpr int i = decltype(I)::value;
-                    v[i] = *(const u32x4 *)(addr[i % M] + (i / M) * RB);
+                    fetch(v[i], addr[i % M] + (uint32_t)((i / M) * RB));
                 });
                 static_for<0, TOT>([&](auto I) {
                     constexpr int i = decltype(I)::value;
                     asm volatile("" ::: "memory");
-                    if constexpr (i % M == 0) acc[i / M] = v[i % DEPTH];
-                    else acc[i / M] += v[i % DEPTH];
+                    if constexpr (ANNLITE_Q8_EXP == 1) {
+                        asm volatile("" ::"v"(v[i % DEPTH]));
+                        if constexpr (i % M == 0) acc[i / M] = thp[i / M];
+                    } else {
+                        if constexpr (i % M == 0) acc[i / M] = v[i % DEPTH];
+                        else acc[i / M] += v[i % DEPTH];
+                    }
                     if constexpr (i + DEPTH < TOT) {
                         constexpr int j = i + DEPTH;
-                        v[i % DEPTH] = *(const u32x4 *)(addr[j % M] + (j / M) * RB);
+                        fetch(v[i % DEPTH], addr[j % M] + (uint32_t)((j / M) * RB));
                     }
                 });
             };
-            u32x4 thp[NQ];  // packed (0x80 | T) of the group's 16 queries
-#pragma unroll
-            for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
             uint32_t vcur = ~0u, vnext = ~0u;
             const uint32_t *valid = a.valid;
             auto load_valid = [&](uint32_t row) -> uint32_t {
@@ -635,83 +683,90 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 if (row >= n_rows) row = n_rows - 1;
                 return valid[row >> 5];
             };
-            // the code bytes (and validity word) of a lane's row are fetched ONE STEP AHEAD: issued at the top of a step for
-            // the next one, picked up at the top of that one.  (Fetching two steps ahead and rotating the registers at the
-            // end of the step made the compiler wait for the load it had just issued: s_waitcnt vmcnt(0) every step.)
-            if (row0 < s_end) {
-                load_row(row0 + lane, cnext);
-                vnext = load_valid(row0 + lane);
-            }
-            // Every scanning wave runs the same n_steps iterations, cut into epochs that end after steps 1, 3, 7, 15, ...
-            // and after the last one (the epochs' barriers meet).  The step loop of an epoch contains no call and no
-            // barrier: the loop-invariant registers stay put.
-            int step_no = 0;
+            // The code bytes (and validity word) of a lane's row are fetched ONE STEP AHEAD: issued at the top of a step for
+            // the next block, picked up at the top of that one; the number of the block after that is drawn in between.
+            // (Fetching two steps ahead and rotating the registers at the end of the step made the compiler wait for the
+            // load it had just issued: s_waitcnt vmcnt(0) every step.)
+            uint32_t b_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)draw());
+            uint32_t pend = draw();
+            load_row(s_begin + b_cur * 64u + lane, cnext);
+            vnext = load_valid(s_begin + b_cur * 64u + lane);
+            uint32_t b_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend);
+            // The blocks are cut into epochs that end after block 15 * 4, 15 * 16, 15 * 64, ... and after the last one (the
+            // epochs' barriers meet).  The step loop of an epoch contains no call and no barrier: the loop-invariant
+            // registers stay put.
+            uint32_t it_no = 0;
             uint32_t n_slow = 0, n_push = 0;
             unsigned long long t_wait = 0;
             for (int epoch_step = a.q8_epoch0;; epoch_step = a.q8_epoch_mul * epoch_step + (a.q8_epoch_mul - 1)) {
                 const bool final = epoch_step >= n_steps - 1;
-                const int epoch_end = final ? n_steps - 1 : epoch_step;  // inclusive
-                for (; step_no <= epoch_end; ++step_no, row0 += stride32) {
-                    if (row0 < s_end) {
+                const uint32_t end_blk = final ? n_blocks : (uint32_t)NS * (uint32_t)(epoch_step + 1);
+                for (; b_cur < end_blk; ++it_no) {
+                    const uint32_t row0 = s_begin + b_cur * 64u;  // (< s_end: b_cur < n_blocks)
+                    pend = draw();
 #pragma unroll
-                        for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
-                        vcur = vnext;
-                        load_row(row0 + stride32 + lane, cnext);
-                        vnext = load_valid(row0 + stride32 + lane);
-                        if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
-                        unsigned long long vmask = ~0ull;
-                        if (s_end - row0 < 64u) vmask = (1ull << (s_end - row0)) - 1ull;
-                        // validity word of this lane's row, fetched one step ahead with the code bytes
-                        if (valid) vmask &= __ballot((vcur >> (lane & 31)) & 1u);
-                        const uint32_t rid = row0 + (uint32_t)lane;
-                        make_addr(ccur);
-                        u32x4 acc[NQ];
-                        row_sums(acc);
-                        // any (query, lane) with S <= T ?  S < 128 and (0x80 | T) - (S & 0x7f) has bit 7 set (T <= 127: no borrow)
-                        uint32_t anyv = 0;
+                    for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
+                    vcur = vnext;
+                    {
+                        const uint32_t row1 = s_begin + b_nxt * 64u + lane;  // (past the slice at its end: clamped, unused)
+                        load_row(row1, cnext);
+                        vnext = load_valid(row1);
+                    }
+                    if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
+                    unsigned long long vmask = ~0ull;
+                    if (s_end - row0 < 64u) vmask = (1ull << (s_end - row0)) - 1ull;
+                    // validity word of this lane's row, fetched one step ahead with the code bytes
+                    if (valid) vmask &= __ballot((vcur >> (lane & 31)) & 1u);
+                    const uint32_t rid = row0 + (uint32_t)lane;
+                    make_addr(ccur);
+                    u32x4 acc[NQ];
+                    row_sums(acc);
+                    // any (query, lane) with S <= T ?  S < 128 and (0x80 | T) - (S & 0x7f) has bit 7 set (T <= 127: no borrow)
+                    uint32_t anyv = 0;
 #pragma unroll
-                        for (int h = 0; h < NQ; ++h)
+                    for (int h = 0; h < NQ; ++h)
 #pragma unroll
-                            for (int w = 0; w < 4; ++w) anyv |= (thp[h][w] - (acc[h][w] & 0x7f7f7f7fu)) & ~acc[h][w];
-                        const unsigned long long anym = __ballot((anyv & 0x80808080u) != 0) & vmask;
-                        if (anym && !(a.dbg_skip & 4)) {
-                            ++n_slow;
-                            // push (slot, row, S) of every lane that passed: dword by dword, byte by byte
-                            static_for<0, NQ * 4>([&](auto HW) {
-                                constexpr int h = decltype(HW)::value / 4, w = decltype(HW)::value % 4;
-                                const uint32_t sw = acc[h][w];
-                                const uint32_t x = (thp[h][w] - (sw & 0x7f7f7f7fu)) & ~sw & 0x80808080u;
-                                if (__ballot(x != 0) & vmask) {
-                                    static_for<0, 4>([&](auto BY) {
-                                        constexpr int by = decltype(BY)::value;
-                                        constexpr uint32_t q0 = h * 16 + w * 4 + by;
-                                        const unsigned long long pm = __ballot((x & (0x80u << (8 * by))) != 0) & vmask;
-                                        if (pm) {
-                                            const int n = __popcll(pm);
-                                            n_push += (uint32_t)n;
-                                            uint32_t pos = 0;
-                                            if (lane == 0) pos = atomicAdd((uint32_t *)ring.tail, (uint32_t)n);
-                                            pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
-                                            while ((int)(pos + (uint32_t)n - *ring.head) > a.q8_ring_limit)  // the consumer is behind
-                                                __builtin_amdgcn_s_sleep(8);
-                                            const int rank = __builtin_amdgcn_mbcnt_hi(
-                                                (uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-                                            const uint32_t sv = (sw >> (8 * by)) & 0xffu;  // (the consumer re-checks it)
-                                            if ((pm >> lane) & 1ull)
-                                                ring.slots[(pos + (uint32_t)rank) & (kRingSize - 1)] =
-                                                    ((unsigned long long)((sv << 8) | q0) << 32) | rid;
-                                        }
-                                    });
-                                }
-                            });
-                        }
+                        for (int w = 0; w < 4; ++w) anyv |= (thp[h][w] - (acc[h][w] & 0x7f7f7f7fu)) & ~acc[h][w];
+                    const unsigned long long anym = __ballot((anyv & 0x80808080u) != 0) & vmask;
+                    if (anym && !(a.dbg_skip & 4)) {
+                        ++n_slow;
+                        // push (slot, row, S) of every lane that passed: dword by dword, byte by byte
+                        static_for<0, NQ * 4>([&](auto HW) {
+                            constexpr int h = decltype(HW)::value / 4, w = decltype(HW)::value % 4;
+                            const uint32_t sw = acc[h][w];
+                            const uint32_t x = (thp[h][w] - (sw & 0x7f7f7f7fu)) & ~sw & 0x80808080u;
+                            if (__ballot(x != 0) & vmask) {
+                                static_for<0, 4>([&](auto BY) {
+                                    constexpr int by = decltype(BY)::value;
+                                    constexpr uint32_t q0 = h * 16 + w * 4 + by;
+                                    const unsigned long long pm = __ballot((x & (0x80u << (8 * by))) != 0) & vmask;
+                                    if (pm) {
+                                        const int n = __popcll(pm);
+                                        n_push += (uint32_t)n;
+                                        uint32_t pos = 0;
+                                        if (lane == 0) pos = atomicAdd((uint32_t *)ring.tail, (uint32_t)n);
+                                        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+                                        while ((int)(pos + (uint32_t)n - *ring.head) > a.q8_ring_limit)  // the consumer is behind
+                                            __builtin_amdgcn_s_sleep(8);
+                                        const int rank = __builtin_amdgcn_mbcnt_hi(
+                                            (uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                                        const uint32_t sv = (sw >> (8 * by)) & 0xffu;  // (the consumer re-checks it)
+                                        if ((pm >> lane) & 1ull)
+                                            ring.slots[(pos + (uint32_t)rank) & (kRingSize - 1)] =
+                                                ((unsigned long long)((sv << 8) | q0) << 32) | rid;
+                                    }
+                                });
+                            }
+                        });
                     }
                     // pick up the workgroup's bounds every 2nd step
-                    if (step_no & 1) {
+                    if (it_no & 1) {
                         asm volatile("" ::: "memory");
 #pragma unroll
                         for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
                     }
+                    b_cur = b_nxt;
+                    b_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend);
                 }
                 if (lane == 0) atomicAdd((uint32_t *)ring.arrived, 1u);
                 const unsigned long long tw = a.dbg ? __builtin_readcyclecounter() : 0ull;
@@ -758,11 +813,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
 
 using namespace annlite;
 
-template <int M, int NW, bool SKEWED>
+template <int M, int NW, bool SKEWED, bool PRE16>
 static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
     constexpr int QT = 32;
     const size_t need = (size_t)a.Ks * 2 * M * 16 + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32;
-    auto fn = adc_scan_q8_kernel<M, NW, SKEWED>;
+    auto fn = adc_scan_q8_kernel<M, NW, SKEWED, PRE16>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
     return launch_status("adc_scan_q8_kernel");
@@ -770,7 +825,9 @@ static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
 
 int annlite::launch_q8_scan(int id, bool sk, const ScanArgs &a, int grid, hipStream_t st) {
     switch (id) {
-        case 1650: return sk ? launch_q8<16, 16, true>(a, grid, st) : launch_q8<16, 16, false>(a, grid, st);
+        case 1650:
+            if (sk && a.codes16) return launch_q8<16, 16, true, true>(a, grid, st);
+            return sk ? launch_q8<16, 16, true, false>(a, grid, st) : launch_q8<16, 16, false, false>(a, grid, st);
         default: set_error("no byte-table kernel with id %d", id); return ANNLITE_ERR_UNSUPPORTED;
     }
 }
