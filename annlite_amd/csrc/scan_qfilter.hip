@@ -294,6 +294,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                 shq[tid] = real ? qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]) : (unsigned short)0x7fff;
             }
             for (int idx = tid; idx < QT * 64; idx += NW * 64) lists[idx] = ~0ull;
+            if (tid == 0) *(volatile uint32_t *)(smem + shq_off + 56) = 0;  // the block counter the waves draw from
             if constexpr (TILES)
                 if (tid == 0) ((volatile unsigned int *)(smem + shq_off + 48))[(it + 1) & 1] = next_item;
         }
@@ -367,7 +368,24 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
         // the code bytes (and validity word) of a lane's row are fetched ONE STEP AHEAD: issued at the top of a step for the
         // next one and picked up at the top of that one (fetched two steps ahead and rotated at the END of the step, the
         // compiler waited for the load it had just issued -- s_waitcnt vmcnt(0) in every step)
-        if (row0 < slice_end) {
+        // Row slices: the waves DRAW their blocks of 64 rows from a counter in LDS (draw_block).  The SIMD's arbiter
+        // favours its oldest wave and one wave alone issues at about a third of the rate four reach together
+        // (scripts/ubench/valu_cost.hip, step_loop.hip): with the rows dealt out statically the favoured waves finished
+        // their share early and the last ones ran the slice out alone.  (Tile mode keeps the static deal: its rounds'
+        // barriers need every wave to run the same number of steps.)
+        uint32_t *blk_ctr = (uint32_t *)(smem + shq_off + 56);
+        auto draw_block = [&]() -> uint32_t {  // (lane 0's value; broadcast a step later, where it is first needed)
+            uint32_t v = 0;
+            if (lane == 0) v = atomicAdd(blk_ctr, 1u);
+            return v;
+        };
+        uint32_t b_cur = 0, b_nxt = 0, b_pend = 0;
+        if constexpr (!TILES) {
+            b_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)draw_block());
+            b_pend = draw_block();
+            row0 = slice_begin + (int64_t)b_cur * 64;
+        }
+        if (TILES ? row0 < slice_end : true) {
             load_row(row0 + lane, cnext);
             vnext = load_valid(row0 + lane);
 #pragma unroll
@@ -375,6 +393,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
             vcur = vnext;
             if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
         }
+        if constexpr (!TILES) b_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_pend);
         if constexpr (TILES) {
             // Integer seed bound (no separate seed launch): every 16-lane row of every wave takes the per-slot MINIMUM
             // integer sum S of its 16 rows; the 4 NW minima belong to distinct rows, so >= k rows have S <= Sk := the
@@ -486,12 +505,17 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                 }
             }
         } else
-        for (; row0 < slice_end; row0 += stride, ++step_no) {
+        for (const uint32_t n_blocks = (uint32_t)((slice_end - slice_begin + 63) >> 6); b_cur < n_blocks; ++step_no) {
+            row0 = slice_begin + (int64_t)b_cur * 64;  // (< slice_end)
+            b_pend = draw_block();
 #pragma unroll
             for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
             vcur = vnext;
-            load_row(row0 + stride + lane, cnext);
-            vnext = load_valid(row0 + stride + lane);
+            {
+                const int64_t row1 = slice_begin + (int64_t)b_nxt * 64 + lane;  // (past the slice at its end: clamped, unused)
+                load_row(row1, cnext);
+                vnext = load_valid(row1);
+            }
             if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
             unsigned long long vmask = ~0ull;
             if (slice_end - row0 < 64) vmask = (1ull << (int)(slice_end - row0)) - 1ull;
@@ -596,7 +620,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
 #pragma unroll
                 for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
             }
-            // next row
+            b_cur = b_nxt;
+            b_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_pend);
         }
 
         if (qcnt) qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
@@ -753,6 +778,7 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
                 shq[tid] = real ? qbound_from_key<M>(gk, a.smax[b], a.qstep[b], a.qlo[b]) : (unsigned short)0x7fff;
             }
             for (int idx = tid; idx < QT * 64; idx += NW * 64) lists[idx] = ~0ull;
+            if (tid == 0) *(volatile uint32_t *)(smem + shq_off + 56) = 0;  // the block counter the waves draw from
             if constexpr (TILES)
                 if (tid == 0) ((volatile unsigned int *)(smem + shq_off + 48))[(it + 1) & 1] = next_item;
         }
@@ -790,7 +816,20 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
         // the code bytes (and validity word) of a lane's row are fetched ONE STEP AHEAD: issued at the top of a step for the
         // next one and picked up at the top of that one (fetched two steps ahead and rotated at the END of the step, the
         // compiler waited for the load it had just issued -- s_waitcnt vmcnt(0) in every step)
-        if (row0 < slice_end) {
+        // row slices: the waves draw their blocks of 64 rows from a counter in LDS (see adc_scan_qfilter_kernel)
+        uint32_t *blk_ctr = (uint32_t *)(smem + shq_off + 56);
+        auto draw_block = [&]() -> uint32_t {
+            uint32_t v = 0;
+            if (lane == 0) v = atomicAdd(blk_ctr, 1u);
+            return v;
+        };
+        uint32_t b_cur = 0, b_nxt = 0, b_pend = 0;
+        if constexpr (!TILES) {
+            b_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)draw_block());
+            b_pend = draw_block();
+            row0 = slice_begin + (int64_t)b_cur * 64;
+        }
+        if (TILES ? row0 < slice_end : true) {
             load_row(row0 + lane, cnext);
             vnext = load_valid(row0 + lane);
 #pragma unroll
@@ -798,6 +837,7 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
             vcur = vnext;
             if constexpr (!SKEWED) encode_plain(ccur);
         }
+        if constexpr (!TILES) b_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_pend);
         // integer sums of this lane's row for the 4 queries (2 dwords x 2 u16), look-ups in 4 chunks of 16
         auto row_sums = [&](const uint32_t (&cc)[CW], u32x2 &acc) {
             static_for<0, 4>([&](auto C) {
@@ -903,12 +943,17 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
                 }
             }
         } else
-        for (; row0 < slice_end; row0 += stride, ++step_no) {
+        for (const uint32_t n_blocks = (uint32_t)((slice_end - slice_begin + 63) >> 6); b_cur < n_blocks; ++step_no) {
+            row0 = slice_begin + (int64_t)b_cur * 64;  // (< slice_end)
+            b_pend = draw_block();
 #pragma unroll
             for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
             vcur = vnext;
-            load_row(row0 + stride + lane, cnext);
-            vnext = load_valid(row0 + stride + lane);
+            {
+                const int64_t row1 = slice_begin + (int64_t)b_nxt * 64 + lane;  // (past the slice at its end: clamped, unused)
+                load_row(row1, cnext);
+                vnext = load_valid(row1);
+            }
             if constexpr (!SKEWED) encode_plain(ccur);
             unsigned long long vmask = ~0ull;
             if (slice_end - row0 < 64) vmask = (1ull << (int)(slice_end - row0)) - 1ull;
@@ -992,6 +1037,8 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
                 asm volatile("" ::: "memory");
                 thp = *(const u32x2 *)(smem + shq_off);
             }
+            b_cur = b_nxt;
+            b_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_pend);
         }
         if (qcnt) qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
 
