@@ -243,16 +243,26 @@ __global__ __launch_bounds__(256) void codes_skew_kernel(const uint8_t *__restri
     const int64_t i = t / M;
     const int j = (int)(t - i * M);
     const int64_t id = ids ? ids[i] : id_base + i;
+    if (M == 64) {  // two independently skewed halves, wrap-coded (see wrap64_mask)
+        const int r = (int)(id % 32), h = j / 32, pp = j % 32;
+        if (!inverse) {
+            uint8_t v = in[i * M + 32 * h + (pp + r) % 32];
+            if (pp + r >= 32) v = (uint8_t)(v - 1);
+            out[id * M + j] = v;
+        } else {
+            const int ps = ((pp - r) % 32 + 32) % 32;  // stored position (within its half) of sub-space j
+            uint8_t v = in[id * M + 32 * h + ps];
+            if (ps + r >= 32) v = (uint8_t)(v + 1);
+            out[i * M + j] = v;
+        }
+        return;
+    }
     const int r = (int)(id % M);
     if (!inverse) {
-        uint8_t v = in[i * M + (j + r) % M];
-        if (M == 64 && j + r >= 64) v = (uint8_t)(v - 1);  // wrap-coded layout of the M = 64 kernel (see wrap64_mask)
-        out[id * M + j] = v;
+        out[id * M + j] = in[i * M + (j + r) % M];
     } else {
         const int jj = ((j - r) % M + M) % M;  // stored position of sub-space j
-        uint8_t v = in[id * M + jj];
-        if (M == 64 && jj + r >= 64) v = (uint8_t)(v + 1);
-        out[i * M + j] = v;
+        out[i * M + j] = in[id * M + jj];
     }
 }
 

@@ -162,15 +162,18 @@ __device__ __forceinline__ unsigned short qbound_from_key(unsigned long long key
 
 
 // ---- M = 64: the "wrap-coded" SKEWED layout ------------------------------------------------------
-// With 64 sub-spaces a lane cannot afford one LDS base pointer per step (64 VGPRs).  Lane l (row n,
-// n % 64 == l) reads sub-space u = l + t at step t; the address is (code << 9) + l*8 + t*8 with t*8 as the
-// instruction's immediate -- correct while u < 64.  For u >= 64 the true entry is (code, u - 64): 512
-// bytes lower, i.e. the SAME offset inside the PREVIOUS table row.  So the stored byte of a wrapped
-// position is code - 1 (mod 256), and LDS carries one extra row 256 = copy of row 0 for code 0 - 1 = 255.
-// stored byte j of row n:  code[(j + n) % 64] - [(j + n % 64) >= 64]   (mod 256)
-// 0x01 in every byte of dword w (positions 4w..4w+3) whose position j satisfies j + r >= 64
+// With 64 sub-spaces a lane cannot afford one LDS base pointer per step (64 VGPRs), and the look-up address should cost
+// ONE instruction.  The LDS table is two half tables of 32 sub-spaces ([257 rows][32 columns][8 B], 256-byte rows,
+// the second one 0x10100 bytes behind the first), and a row is stored as two independently skewed halves: lane l (row n,
+// n % 32 == l % 32) reads, at step t = 32 h + p, sub-space 32 h + (l % 32 + p) % 32.  Its address is
+//     (stored byte << 8) | (l % 32) * 8 [| 0x10000 for h = 1]   -- one v_perm_b32 of the code dword and a lane constant --
+// plus the instruction's immediate p * 8 [+ 0x100 for h = 1]: correct while l % 32 + p < 32.  Past that the true entry
+// is 256 bytes lower, i.e. the SAME offset inside the PREVIOUS table row: the stored byte of a wrapped position is
+// code - 1 (mod 256), and each half table carries one extra row 256 = copy of row 0 for code 0 - 1 = 255.
+// stored byte j = 32 h + p of row n:  code[32 h + (p + n % 32) % 32] - [p + n % 32 >= 32]   (mod 256)
+// 0x01 in every byte of dword w (positions 4w..4w+3) whose position p = j % 32 satisfies p + r >= 32  (r = n % 32)
 __device__ __forceinline__ uint32_t wrap64_mask(int w, int r) {
-    int nb = 4 * w + 4 - (64 - r);  // number of (upper) bytes of the dword that wrap
+    int nb = 4 * (w & 7) + 4 - (32 - r);  // number of (upper) bytes of the dword that wrap
     nb = nb < 0 ? 0 : (nb > 4 ? 4 : nb);
     return nb == 0 ? 0u : (0x01010101u << (8 * (4 - nb)));
 }
@@ -180,6 +183,31 @@ __device__ __forceinline__ uint32_t bytes_sub(uint32_t x, uint32_t y) {
 }
 __device__ __forceinline__ uint32_t bytes_add(uint32_t x, uint32_t y) {
     return ((x & 0x7f7f7f7fu) + y) ^ ((x ^ y) & 0x80808080u);
+}
+
+
+// M = 64 row in registers: PLAIN -> this row's stored form (r = n % 32), and back (ascending sub-space order)
+__device__ __forceinline__ void skew64_rotate_halves(uint32_t (&c)[16], int s) {  // both halves left by s bytes (0..31)
+    bool ab[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ab[i] = (((s >> 2) >> i) & 1) != 0;
+    uint32_t lo[8], hi[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lo[i] = c[i], hi[i] = c[8 + i];
+    rotate_row<8>(lo, ab, (uint32_t)(s & 3));
+    rotate_row<8>(hi, ab, (uint32_t)(s & 3));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c[i] = lo[i], c[8 + i] = hi[i];
+}
+__device__ __forceinline__ void skew64_encode(uint32_t (&c)[16], int r) {
+    skew64_rotate_halves(c, r);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = bytes_sub(c[i], wrap64_mask(i, r));
+}
+__device__ __forceinline__ void skew64_decode(uint32_t (&c)[16], int r) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = bytes_add(c[i], wrap64_mask(i, r));
+    skew64_rotate_halves(c, (32 - r) % 32);
 }
 
 

@@ -51,11 +51,8 @@ __device__ __forceinline__ float exact_row_sum(const FlushCtx &c, int q, uint32_
 #pragma unroll
     for (int i = 0; i < CW; ++i) cp[i] = p[i];
     if constexpr (SKEWED && M == 64) {
-        const int r = (int)(rid % 64);
-#pragma unroll
-        for (int i = 0; i < CW; ++i) cp[i] = bytes_add(cp[i], wrap64_mask(i, r));  // undo the wrap coding
-    }
-    if constexpr (SKEWED) {
+        skew64_decode(cp, (int)(rid % 32));  // two skewed halves, wrap-coded
+    } else if constexpr (SKEWED) {
         // stored byte j of row n is the code of sub-space (j + n) mod M: rotate back by n mod M
         const int sinv = (M - (int)(rid % M)) % M;
         bool abit_inv[8];

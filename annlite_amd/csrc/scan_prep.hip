@@ -153,11 +153,8 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
 #pragma unroll
         for (int i = 0; i < CW; ++i) c[i] = cn[i];
         fetch(r + kSeedWaves * 64, cn, vn);
-        if constexpr (SKEWED && M == 64) {
-#pragma unroll
-            for (int i = 0; i < CW; ++i) c[i] = bytes_add(c[i], wrap64_mask(i, lane));  // undo the wrap coding
-        }
-        if constexpr (SKEWED) rotate_row<CW>(c, abit_inv, bsh_inv);
+        if constexpr (SKEWED && M == 64) skew64_decode(c, lane & 31);  // two skewed halves, wrap-coded
+        else if constexpr (SKEWED) rotate_row<CW>(c, abit_inv, bsh_inv);
         fq d;
 #pragma unroll
         for (int q = 0; q < QPB; ++q) d[q] = 0.f;

@@ -662,10 +662,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
 // =================================================================================================
 // Quantised-filter kernel for M = 64 (BASELINE config 4: 768-d, 12-float sub-spaces).  Same discipline as
 // adc_scan_qfilter_kernel; what differs is dictated by the table size (64 sub-spaces x 256 codes):
-//   * 4 queries per 8-byte LDS entry (u16 each), table [Ks + 1][64][8 B] = 128.5 KB, ds_read_b64; a
-//     half-wave reads sub-spaces (l + t) % 64 for 32 consecutive l: bank pair (l + t) % 32, conflict-free;
-//   * no per-step LDS base registers: the wrap-coded SKEWED layout (wrap64_mask) makes the address
-//     (stored byte << 9) + lane*8 with t*8 as the instruction's immediate -- one SDWA shift + one add;
+//   * 4 queries per 8-byte LDS entry (u16 each), ds_read_b64; two half tables of 32 sub-spaces, [Ks + 1][32][8 B] each
+//     (128.5 KB together): a half-wave reads columns (l + p) % 32 for 32 consecutive l: bank pair (l + p) % 32,
+//     conflict-free;
+//   * no per-step LDS base registers and ONE VALU instruction per look-up address: the wrap-coded SKEWED layout
+//     (wrap64_mask) makes the address v_perm_b32(code dword, lane constant) = (stored byte << 8) | (l % 32) * 8
+//     [| 0x10000], with p * 8 [+ 0x100] as the instruction's immediate;
+//   * PLAIN tables are rotated and wrap-coded on the fly (slow path; the index plugin stores SKEWED).
 //   * QMAX = floor(32767 / 64) = 511 (9-bit entries), look-ups issued in 4 chunks of 16;
 //   * PLAIN tables are rotated and wrap-coded on the fly (slow path; the index plugin stores SKEWED).
 // LDS: [table (Ks+1)*512][shq u16 x 4 @ +0][locks u32 x 4 @ +64][gkl u64 x 4 @ +128][lists u64 x 4 x 64 @ +256]
@@ -679,11 +682,6 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int km1 = a.k - 1;
-    // forward rotation of PLAIN rows by lane bytes
-    const uint32_t bsh = (uint32_t)(lane & 3);
-    bool abit[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) abit[i] = (((lane >> 2) >> i) & 1) != 0;
 
     const int lut_bytes = (a.Ks + 1) * RB;
     const uint32_t shq_off = (uint32_t)lut_bytes, lock_off = shq_off + 64, gkl_off = shq_off + 128,
@@ -692,7 +690,11 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
     volatile uint16_t *shq = (volatile uint16_t *)(smem + shq_off);
     volatile uint32_t *locks = (volatile uint32_t *)(smem + lock_off);
     unsigned long long *lists = (unsigned long long *)(smem + list_off);
-    const unsigned char *lbase = smem + lane * 8;
+    // lane constant of the look-up addresses: byte 0 = (lane % 32) * 8 (the column), byte 2 = 0x01 (second half table).
+    // The addresses are plain LDS byte offsets: the table starts at the workgroup's LDS address 0 (all LDS is dynamic)
+    constexpr uint32_t HALF_B = (256u + 1u) * 256u;  // 0x10100: the second half table
+    const uint32_t lane_k = 0x00010000u | (uint32_t)((lane & 31) * 8);
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
 
     for (int it = 0;; ++it) {
         int item = blockIdx.x + it * gridDim.x;
@@ -743,19 +745,24 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
                 const uint32_t m0 = r0 >= 0 ? 0xffffu : 0u, m1 = r1 >= 0 ? 0xffffu : 0u;
                 const unsigned char *p0 = q16b + (int64_t)((r0 >= 0 ? r0 : 0) >> 2) * group_bytes + m * 8 + ((r0 >= 0 ? r0 : 0) & 3) * 2;
                 const unsigned char *p1 = q16b + (int64_t)((r1 >= 0 ? r1 : 0) >> 2) * group_bytes + m * 8 + ((r1 >= 0 ? r1 : 0) & 3) * 2;
-                unsigned char *dst = smem + m * 8 + sp * 4;
+                unsigned char *dst = smem + (m >> 5) * HALF_B + (m & 31) * 8 + sp * 4;
 #pragma unroll 8
                 for (int kk = k0; kk <= a.Ks; kk += RPI) {  // (row Ks = row 0)
                     const int ks = kk == a.Ks ? 0 : kk;
                     const uint32_t lo = *(const uint16_t *)(p0 + ks * RB) & m0;
                     const uint32_t hi = *(const uint16_t *)(p1 + ks * RB) & m1;
-                    *(uint32_t *)(dst + kk * RB) = lo | (hi << 16);
+                    *(uint32_t *)(dst + kk * 256) = lo | (hi << 16);
                 }
             } else {
+                // global [Ks][64 sub-spaces][4 x u16] -> the two half tables (16-byte chunk c of code k: sub-spaces 2c, 2c + 1)
                 const u32x4 *src = (const u32x4 *)((const unsigned char *)a.q16 + (int64_t)tile * a.Ks * RB);
                 const int total = a.Ks * (RB / 16);
-                for (int idx = tid; idx < total; idx += NW * 64) ((u32x4 *)smem)[idx] = src[idx];
-                for (int idx = tid; idx < RB / 16; idx += NW * 64) ((u32x4 *)(smem + a.Ks * RB))[idx] = src[idx];  // row Ks = row 0
+                for (int idx = tid; idx < total; idx += NW * 64) {
+                    const int kk = idx >> 5, c = idx & 31;
+                    const u32x4 e = src[idx];
+                    *(u32x4 *)(smem + (c >> 4) * HALF_B + kk * 256 + (c & 15) * 16) = e;
+                    if (kk == 0) *(u32x4 *)(smem + (c >> 4) * HALF_B + a.Ks * 256 + (c & 15) * 16) = e;  // row Ks = row 0
+                }
             }
             if (tid < QT) {
                 locks[tid] = 0;
@@ -798,9 +805,7 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
             }
         };
         auto encode_plain = [&](uint32_t (&c)[CW]) {  // PLAIN row -> this lane's wrap-coded SKEWED row
-            rotate_row<CW>(c, abit, bsh);
-#pragma unroll
-            for (int i = 0; i < CW; ++i) c[i] = bytes_sub(c[i], wrap64_mask(i, lane));
+            skew64_encode(c, lane & 31);
         };
         auto load_valid = [&](int64_t row) -> uint32_t {
             if (!a.valid) return ~0u;
@@ -839,18 +844,19 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
         }
         if constexpr (!TILES) b_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_pend);
         // integer sums of this lane's row for the 4 queries (2 dwords x 2 u16), look-ups in 4 chunks of 16
+        // (a ring of 16 landing registers refilled after every add, as the byte-table kernel has it, measured 2 % slower)
+        typedef const u32x2 __attribute__((address_space(3))) *lds_entry_ptr;
         auto row_sums = [&](const uint32_t (&cc)[CW], u32x2 &acc) {
             static_for<0, 4>([&](auto C) {
                 constexpr int c0 = decltype(C)::value * 16;
+                constexpr int half = c0 / 32;
                 u32x2 v[16];
-                static_for<0, 4>([&](auto W) {
-                    constexpr int t = c0 + decltype(W)::value * 4;
-                    uint32_t o0, o1, o2, o3;
-                    byte_shl4(cc[t / 4], 9u, o0, o1, o2, o3);
-                    v[t - c0 + 0] = *(const u32x2 *)(lbase + o0 + (t + 0) * 8);
-                    v[t - c0 + 1] = *(const u32x2 *)(lbase + o1 + (t + 1) * 8);
-                    v[t - c0 + 2] = *(const u32x2 *)(lbase + o2 + (t + 2) * 8);
-                    v[t - c0 + 3] = *(const u32x2 *)(lbase + o3 + (t + 3) * 8);
+                static_for<0, 16>([&](auto T) {
+                    constexpr int t = c0 + decltype(T)::value;
+                    // byte 0 <- lane_k byte 0, byte 1 <- code byte t % 4, byte 2 <- lane_k byte 2 (second half) or 0, byte 3 <- 0
+                    constexpr uint32_t sel = 0x0c000000u | ((half ? 0x02u : 0x0cu) << 16) | ((4u + (uint32_t)(t % 4)) << 8);
+                    const uint32_t ad = __builtin_amdgcn_perm(cc[t / 4], lane_k, sel);
+                    v[t - c0] = *(lds_entry_ptr)(uintptr_t)(ad + (uint32_t)((t % 32) * 8 + half * 0x100));
                 });
                 asm volatile("" ::: "memory");
                 static_for<0, 16>([&](auto I) { acc += v[decltype(I)::value]; });

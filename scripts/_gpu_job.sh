@@ -1,4 +1,5 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_ivf.py -q -m gpu -x 2>&1 | tail -4
-timeout 300 python bench.py --rows 2000000 --dim 768 --m 64 --batch 256 --metric cosine --steps 10 --warmup 3 --ivf-cells 0 --cpu-queries 0 --no-rerank --recall-queries 0 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('config4 ms_per_step %.4f kernel_ms %.4f frac %.3f' % (r['ms_per_step'], r['roofline']['kernel_ms'], r['roofline']['frac']))"
-ANNLITE_SCAN_VARIANT=31 timeout 120 python scripts/prof_scan.py --rows 10000000 --data lowrank --fused --iters 6 2>&1 | grep -i "scan kernel"
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x 2>&1 | tail -2
+for v in 0 30 32; do
+ANNLITE_SCAN_VARIANT=$v timeout 300 python bench.py --rows 2000000 --dim 768 --m 64 --batch 256 --metric cosine --steps 10 --warmup 3 --ivf-cells 0 --cpu-queries 0 --no-rerank --recall-queries 0 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('config4 variant $v ms_per_step %.4f kernel_ms %.4f frac %.3f' % (r['ms_per_step'], r['roofline']['kernel_ms'], r['roofline']['frac']))"
+done
