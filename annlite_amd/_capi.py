@@ -41,8 +41,6 @@ SYMBOLS = (
     'annlite_adc_scan_topk_packed',
     'annlite_pq_search_workspace_bytes',
     'annlite_pq_search_topk',
-    'annlite_pq_search_topk_ex',
-    'annlite_codes_prescale',
     'annlite_adc_scan_candidates',
     'annlite_topk_merge',
     'annlite_topk_merge_packed',
@@ -83,19 +81,6 @@ class ScanPlan(ctypes.Structure):
 _lib: Optional[ctypes.CDLL] = None
 
 
-class SearchArgs(ctypes.Structure):
-    """``annlite_search_args`` (include/annlite_hip.h)"""
-    _fields_ = [
-        ('struct_size', ctypes.c_int32), ('lut_kind', ctypes.c_int32), ('queries_dev', ctypes.c_void_p),
-        ('B', ctypes.c_int64), ('D', ctypes.c_int64), ('codebooks_dev', ctypes.c_void_p), ('codes_dev', ctypes.c_void_p),
-        ('code_bytes', ctypes.c_int32), ('codes_layout', ctypes.c_int32), ('N', ctypes.c_int64), ('M', ctypes.c_int64),
-        ('Ks', ctypes.c_int64), ('valid_bits_dev', ctypes.c_void_p), ('k', ctypes.c_int64), ('row_base', ctypes.c_int64),
-        ('out_dist_dev', ctypes.c_void_p), ('out_id_dev', ctypes.c_void_p), ('out_packed_dev', ctypes.c_void_p),
-        ('flags', ctypes.c_int32), ('reserved', ctypes.c_int32), ('workspace_dev', ctypes.c_void_p),
-        ('workspace_bytes', ctypes.c_size_t), ('stream', ctypes.c_void_p), ('codes_pre16_dev', ctypes.c_void_p),
-    ]
-
-
 def lib() -> ctypes.CDLL:
     """Load the HIP library; raise loudly if it has not been built (``python __graft_entry__.py``)."""
     global _lib
@@ -129,8 +114,6 @@ def lib() -> ctypes.CDLL:
     L.annlite_adc_scan_candidates.argtypes = L.annlite_adc_scan_topk.argtypes
     L.annlite_adc_scan_topk_packed.argtypes = [vp, i32, i32, i64, i64, i64, vp, vp, i64, i64, i64, vp, vp, sz, vp]
     L.annlite_pq_search_workspace_bytes.argtypes = [i64, i64, i64, i32, i64, i64, ctypes.POINTER(ctypes.c_int64)]
-    L.annlite_pq_search_topk_ex.argtypes = [ctypes.POINTER(SearchArgs)]
-    L.annlite_codes_prescale.argtypes = [vp, i64, i64, i64, vp, vp]
     L.annlite_pq_search_topk.argtypes = [i32, vp, i64, i64, vp, vp, i32, i32, i64, i64, i64, vp, i64, i64, vp, vp, vp, i32,
                                          vp, sz, vp]
     L.annlite_topk_merge.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]

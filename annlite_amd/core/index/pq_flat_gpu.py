@@ -51,14 +51,11 @@ class PQFlatGpuIndex(BaseIndex):
         # HNSW-only kwargs the reference forwards (ef_construction, ef_search, max_connection) are accepted and ignored
         for k in ('ef_construction', 'ef_search', 'max_connection'):
             kwargs.pop(k, None)
-        want_pre16 = bool(kwargs.pop('prescaled', True))
         super().__init__(dim, dtype=dtype, metric=metric, **kwargs)
         assert pq_codec is not None, 'PQFlatGpuIndex needs a PQCodec'
         self.pq_codec = pq_codec
         self.rerank = bool(rerank)
         self._want_skew = bool(skewed)
-        self._want_pre16 = want_pre16
-        self._codes16 = None
         self._ws = ops.ScanWorkspace()
         # device storage is allocated on first use so that constructing an index (and the host-side
         # error paths, e.g. "not trained") does not need a GPU
@@ -92,10 +89,6 @@ class PQFlatGpuIndex(BaseIndex):
         dev = ops.device()
         tdt = {1: torch.uint8, 2: torch.int16, 4: torch.int32}[self.code_bytes]
         self._codes = torch.zeros((capacity, self.M), dtype=tdt, device=dev)
-        # prescaled companion of the SKEWED M = 16 table: what the byte-table kernel's step loop reads (one instruction
-        # per look-up address instead of two); twice the code bytes, kept next to the u8 table (exact sums, seed, dump)
-        self._codes16 = (torch.zeros((capacity, self.M), dtype=torch.int16, device=dev)
-                         if (self._layout() == CODES_SKEWED and self.M == 16 and self._want_pre16) else None)
         # validity: bool per row is the source of truth, the uint32 bitmap the kernels read is packed lazily
         self._valid_bool = torch.zeros((((capacity + 31) // 32 + 2) * 32,), dtype=torch.bool, device=dev)
         self._valid_bits_cache: Optional[torch.Tensor] = None
@@ -111,11 +104,8 @@ class PQFlatGpuIndex(BaseIndex):
     def _expand_capacity(self, new_capacity: int):
         self._ensure_alloc()
         old_codes, old_valid, old_vec, n_rows, size = self._codes, self._valid_bool, self._vectors, self._n_rows, self._size
-        old16 = self._codes16
         self._alloc(new_capacity)
         self._codes[: old_codes.shape[0]] = old_codes
-        if old16 is not None and self._codes16 is not None:
-            self._codes16[: old16.shape[0]] = old16
         self._valid_bool[: old_codes.shape[0]] = old_valid[: old_codes.shape[0]]
         if old_vec is not None:
             self._vectors[: old_vec.shape[0]] = old_vec
@@ -185,9 +175,6 @@ class PQFlatGpuIndex(BaseIndex):
         codes = ops.pq_encode(x, self.pq_codec.codebooks_dev)
         if self._layout() == CODES_SKEWED:
             ops.codes_skew(codes, ids_t, out=self._codes)
-            if self._codes16 is not None:
-                lo = int(ids_t.min().item())
-                ops.codes_prescale(self._codes, self._codes16, lo, max_id - lo)  # (the id range: inserts are dense)
         else:
             self._codes[ids_t] = codes
         if self._vectors is not None:
@@ -212,7 +199,6 @@ class PQFlatGpuIndex(BaseIndex):
     def reset(self, capacity: Optional[int] = None):
         super().reset(capacity=capacity)
         self._codes = None
-        self._codes16 = None
         self._valid_bool = None
         self._valid_bits_cache = None
         self._vectors = None
@@ -296,7 +282,7 @@ class PQFlatGpuIndex(BaseIndex):
             d, i = self._with_kernel(lambda: ops.pq_search_topk(
                 kind, xq, self.pq_codec.codebooks_dev, self._codes, k, self.M, self.Ks, valid_bits=valid, n_rows=N,
                 codes_layout=self._layout(), workspace=self._ws, row_base=base,
-                sqrt=self.metric == Metric.EUCLIDEAN, codes_pre16=self._codes16), B, N, k)  # hnsw/index.py:164-165
+                sqrt=self.metric == Metric.EUCLIDEAN), B, N, k)  # hnsw/index.py:164-165
             row_base = 0
         else:
             d, i = self._search_large_k(q, k, valid, N, self._scan_inputs(x, q))
@@ -323,8 +309,7 @@ class PQFlatGpuIndex(BaseIndex):
         kind, xq = self._scan_inputs(x, q)
         return self._with_kernel(lambda: ops.pq_search_topk(
             kind, xq, self.pq_codec.codebooks_dev, self._codes, k, self.M, self.Ks, valid_bits=self._valid,
-            row_base=row_base, n_rows=N, codes_layout=self._layout(), workspace=self._ws, packed=True,
-            codes_pre16=self._codes16), B, N, k)
+            row_base=row_base, n_rows=N, codes_layout=self._layout(), workspace=self._ws, packed=True), B, N, k)
 
     @property
     def sqrt_epilogue(self) -> bool:
@@ -438,8 +423,6 @@ class PQFlatGpuIndex(BaseIndex):
             codes = ops.to_dev(state['codes'])
             if self._layout() == CODES_SKEWED:
                 ops.codes_skew(codes, ids=None, id_base=0, out=self._codes)
-                if self._codes16 is not None:
-                    ops.codes_prescale(self._codes, self._codes16, 0, N)
             else:
                 self._codes[:N] = codes
             if self._vectors is not None and state['vectors'] is not None:

@@ -266,18 +266,6 @@ __global__ __launch_bounds__(256) void codes_skew_kernel(const uint8_t *__restri
     }
 }
 
-// PRESCALED companion of a SKEWED u8 table for the scan's step loop: entry j of row n = the LDS entry index of its look-up,
-// (stored byte << 5) | ((n + j) % 16) for M = 16 (16-byte entries, [code][2 groups][16 sub-spaces])
-__global__ __launch_bounds__(256) void codes_prescale_kernel(const uint8_t *__restrict__ skewed, int64_t row_begin,
-                                                            int64_t n_rows, int M, uint16_t *__restrict__ out) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_rows * M) return;
-    const int64_t n = row_begin + t / M;
-    const int j = (int)(t % M);
-    const uint32_t b = skewed[n * M + j];
-    out[n * M + j] = (uint16_t)((b << 5) | (uint32_t)((n + j) & 15));
-}
-
 // =================================================================================================
 // host side
 // =================================================================================================
@@ -421,7 +409,6 @@ extern "C" int annlite_scan_plan_tiles(int64_t N, int64_t M, int64_t Ks, int cod
     return plan_query_impl(N, M, Ks, code_bytes, V, k, 1, plan);
 }
 
-static thread_local const void *g_codes16 = nullptr;  // annlite_pq_search_topk_ex: prescaled companion of this call's table
 static unsigned long long *g_dbg = nullptr;  // debug only (ANNLITE_DEBUG_COUNTERS): leaked 64-byte device buffer
 static thread_local int g_prof_on = 0;
 static thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
@@ -489,7 +476,6 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
     const int n_cu = device_cu_count();
     ScanArgs a = {};
     a.codes = codes_dev;
-    a.codes16 = (codes_layout == ANNLITE_CODES_SKEWED && M == 16 && !tm) ? (const uint16_t *)g_codes16 : nullptr;
     a.valid = valid_bits_dev;
     a.lut = lut_dev;
     a.partial = (unsigned long long *)workspace_dev;
@@ -551,7 +537,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         if (const char *e = getenv("ANNLITE_Q8_TUNE")) {  // "epoch0,mul,ring_limit,import_mask" (measurements)
             int e0 = 3, mul = 4, rl = 384, im = 3;
             // (a ring limit below 192 can deadlock: the consumer waits for entries of a producer the limit holds back)
-            if (sscanf(e, "%d,%d,%d,%d", &e0, &mul, &rl, &im) == 4 && e0 >= 0 && mul >= 2 && rl >= 192 && rl <= 896 && im >= 0) {
+            if (sscanf(e, "%d,%d,%d,%d", &e0, &mul, &rl, &im) == 4 && e0 >= 0 && mul >= 2 && rl >= 192 && rl <= 448 && im >= 0) {
                 a.q8_epoch0 = e0;
                 a.q8_epoch_mul = mul;
                 a.q8_ring_limit = rl;
@@ -774,31 +760,6 @@ extern "C" int annlite_pq_search_topk(int lut_kind, const float *queries_dev, in
     return pq_search_impl(lut_kind, queries_dev, B, D, codebooks_dev, codes_dev, code_bytes, codes_layout, N, M, Ks,
                           valid_bits_dev, k, row_base, out_dist_dev, out_id_dev, out_packed_dev, flags, workspace_dev,
                           workspace_bytes, stream, nullptr);
-}
-
-extern "C" int annlite_pq_search_topk_ex(const annlite_search_args *x) {
-    ANNLITE_REQUIRE(x != nullptr && x->struct_size == (int32_t)sizeof(annlite_search_args),
-                    "annlite_search_args: struct_size %d != %d (header / library mismatch)", x ? x->struct_size : -1,
-                    (int)sizeof(annlite_search_args));
-    g_codes16 = x->codes_pre16_dev;
-    const int rc = pq_search_impl(x->lut_kind, x->queries_dev, x->B, x->D, x->codebooks_dev, x->codes_dev, x->code_bytes,
-                                  x->codes_layout, x->N, x->M, x->Ks, x->valid_bits_dev, x->k, x->row_base, x->out_dist_dev,
-                                  x->out_id_dev, x->out_packed_dev, x->flags, x->workspace_dev, x->workspace_bytes, x->stream,
-                                  nullptr);
-    g_codes16 = nullptr;
-    return rc;
-}
-
-extern "C" int annlite_codes_prescale(const void *skewed_dev, int64_t M, int64_t row_begin, int64_t n_rows, void *out16_dev,
-                                      void *stream) {
-    ANNLITE_REQUIRE(M == 16, "the prescaled companion exists for M = 16 (got %lld)", (long long)M);
-    ANNLITE_REQUIRE(row_begin >= 0 && n_rows >= 0, "bad row range");
-    if (n_rows == 0) return ANNLITE_OK;
-    ANNLITE_REQUIRE(skewed_dev && out16_dev, "null device pointer");
-    const int64_t total = n_rows * M;
-    hipLaunchKernelGGL(codes_prescale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint8_t *)skewed_dev, row_begin, n_rows, (int)M, (uint16_t *)out16_dev);
-    return launch_status("codes_prescale_kernel");
 }
 
 extern "C" int annlite_pq_search_tiles_workspace_bytes(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t V,

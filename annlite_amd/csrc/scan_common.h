@@ -13,7 +13,6 @@ namespace annlite {
 
 struct ScanArgs {
     const void *codes;       // [N][M] code bytes
-    const uint16_t *codes16; // optional PRESCALED companion of a SKEWED u8 table (annlite_codes_prescale), else NULL
     const uint32_t *valid;   // optional bitmap
     const float *lut;        // tiled or BMK
     unsigned long long *partial;  // [B_pad][NS][k] keys
@@ -101,13 +100,6 @@ __device__ __forceinline__ void byte_shl4(uint32_t dword, uint32_t sh, uint32_t 
         "v_lshlrev_b32_sdwa %2, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
         "v_lshlrev_b32_sdwa %3, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3"
         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-        : "s"(sh), "v"(dword));
-}
-// both half-words of a dword, each << SH, in one asm statement (prescaled code tables)
-__device__ __forceinline__ void word_shl2(uint32_t dword, uint32_t sh, uint32_t &r0, uint32_t &r1) {
-    asm("v_lshlrev_b32_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
-        "v_lshlrev_b32_sdwa %1, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
-        : "=&v"(r0), "=&v"(r1)
         : "s"(sh), "v"(dword));
 }
 constexpr int ilog2_c(int x) { return x <= 1 ? 0 : 1 + ilog2_c(x / 2); }

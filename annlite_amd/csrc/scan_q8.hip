@@ -401,14 +401,9 @@ __device__ __forceinline__ bool q8_item_map(const ScanArgs &a, int item, int &ti
     return tile < a.n_tiles && slice < a.n_slices;
 }
 
-// PRE16: the step loop reads the PRESCALED companion of the SKEWED table (u16 [N][M], annlite_codes_prescale): entry j of row n
-// is the LDS entry index (code << 5) | ((n + j) % 16) of its look-up, so an address is ONE SDWA shift of a half-word -- no byte
-// extraction plus add of a per-lane base, and no 16 base registers.  The exact sums of the candidates and the seed keep
-// reading the u8 table.
-template <int M, int NW, bool SKEWED, bool PRE16>
+template <int M, int NW, bool SKEWED>
 __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const ScanArgs a) {
-    constexpr int QG = 16, NQ = 2, QT = QG * NQ, CW = PRE16 ? M / 2 : M / 4, EB = 16, RB = M * EB, KSTRIDE = NQ * RB;
-    static_assert(!PRE16 || (SKEWED && M == 16), "the prescaled companion exists for the SKEWED M = 16 table");
+    constexpr int QG = 16, NQ = 2, QT = QG * NQ, CW = M / 4, EB = 16, RB = M * EB, KSTRIDE = NQ * RB;
     constexpr int NS = NW - 1;  // scanning waves; wave NS is the consumer
     static_assert(M % 8 == 0 && M <= 32 && (KSTRIDE & (KSTRIDE - 1)) == 0, "unsupported shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -575,19 +570,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             bool abit[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) abit[i] = (((s >> 2) >> i) & 1) != 0;
-            // LDS byte addresses as integers (the table starts at the workgroup's LDS address lds0: 0 -- all LDS of this kernel
-            // is dynamic --, which the PRE16 path relies on: its addresses come straight out of the code table)
+            // LDS byte addresses as integers
             typedef const u32x4 __attribute__((address_space(3))) *lds_entry_ptr;
             const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
-            if constexpr (PRE16) {
-                if (lds0 != 0u) __builtin_trap();
-            }
-            uint32_t mbase[PRE16 ? 1 : M];
-            if constexpr (!PRE16) {
+            uint32_t mbase[M];
 #pragma unroll
-                for (int t = 0; t < M; ++t) mbase[t] = lds0 + (uint32_t)(((s + t) % M) * EB);
-            }
-            const uint32_t *codes32 = PRE16 ? (const uint32_t *)a.codes16 : (const uint32_t *)a.codes;
+            for (int t = 0; t < M; ++t) mbase[t] = lds0 + (uint32_t)(((s + t) % M) * EB);
+            const uint32_t *codes32 = (const uint32_t *)a.codes;
             // rows are < 2^32 per call (plan): 32-bit row arithmetic keeps the loop control in SGPRs
             const uint32_t s_begin = (uint32_t)slice_begin, s_end = (uint32_t)slice_end, n_rows = (uint32_t)a.N;
             const uint32_t n_blocks = (s_end - s_begin + 63u) >> 6;
@@ -622,25 +611,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 }
             };
             auto make_addr = [&](const uint32_t (&cc)[CW]) {
-                if constexpr (PRE16) {
-                    static_for<0, CW>([&](auto W) {
-                        constexpr int w = decltype(W)::value;
-                        uint32_t o0, o1;
-                        word_shl2(cc[w], 4u, o0, o1);  // entry index -> byte address (16-byte entries)
-                        addr[2 * w + 0] = o0;
-                        addr[2 * w + 1] = o1;
-                    });
-                } else {
-                    static_for<0, CW>([&](auto W) {
-                        constexpr int w = decltype(W)::value;
-                        uint32_t o0, o1, o2, o3;
-                        byte_shl4(cc[w], (uint32_t)ilog2_c(KSTRIDE), o0, o1, o2, o3);
-                        addr[4 * w + 0] = mbase[4 * w + 0] + o0;
-                        addr[4 * w + 1] = mbase[4 * w + 1] + o1;
-                        addr[4 * w + 2] = mbase[4 * w + 2] + o2;
-                        addr[4 * w + 3] = mbase[4 * w + 3] + o3;
-                    });
-                }
+                static_for<0, CW>([&](auto W) {
+                    constexpr int w = decltype(W)::value;
+                    uint32_t o0, o1, o2, o3;
+                    byte_shl4(cc[w], (uint32_t)ilog2_c(KSTRIDE), o0, o1, o2, o3);
+                    addr[4 * w + 0] = mbase[4 * w + 0] + o0;
+                    addr[4 * w + 1] = mbase[4 * w + 1] + o1;
+                    addr[4 * w + 2] = mbase[4 * w + 2] + o2;
+                    addr[4 * w + 3] = mbase[4 * w + 3] + o3;
+                });
             };
             u32x4 thp[NQ];  // packed (0x80 | T) of the group's 16 queries
 #pragma unroll
@@ -813,11 +792,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
 
 using namespace annlite;
 
-template <int M, int NW, bool SKEWED, bool PRE16>
+template <int M, int NW, bool SKEWED>
 static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
     constexpr int QT = 32;
     const size_t need = (size_t)a.Ks * 2 * M * 16 + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32;
-    auto fn = adc_scan_q8_kernel<M, NW, SKEWED, PRE16>;
+    auto fn = adc_scan_q8_kernel<M, NW, SKEWED>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
     return launch_status("adc_scan_q8_kernel");
@@ -825,9 +804,7 @@ static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
 
 int annlite::launch_q8_scan(int id, bool sk, const ScanArgs &a, int grid, hipStream_t st) {
     switch (id) {
-        case 1650:
-            if (sk && a.codes16) return launch_q8<16, 16, true, true>(a, grid, st);
-            return sk ? launch_q8<16, 16, true, false>(a, grid, st) : launch_q8<16, 16, false, false>(a, grid, st);
+        case 1650: return sk ? launch_q8<16, 16, true>(a, grid, st) : launch_q8<16, 16, false>(a, grid, st);
         default: set_error("no byte-table kernel with id %d", id); return ANNLITE_ERR_UNSUPPORTED;
     }
 }

@@ -176,11 +176,9 @@ def adc_scan_topk_packed(codes: torch.Tensor, lut: torch.Tensor, B: int, k: int,
 def pq_search_topk(lut_kind: int, queries: torch.Tensor, codebooks: torch.Tensor, codes: torch.Tensor, k: int, M: int,
                    Ks: int, valid_bits: Optional[torch.Tensor] = None, row_base: int = 0, n_rows: Optional[int] = None,
                    codes_layout: int = CODES_PLAIN, workspace: Optional[ScanWorkspace] = None, packed: bool = False,
-                   sqrt: bool = False, codes_pre16: Optional[torch.Tensor] = None):
+                   sqrt: bool = False):
     """LUT build + scan + top-k in one C call (``annlite_pq_search_topk``).  ``queries`` f32 [B, D] already
-    pre-processed (normalised for cosine).  Returns (f32 [B,k], i64 [B,k]) or, with ``packed``, i64 [B,k,2].
-    ``codes_pre16``: the prescaled companion of a SKEWED M=16 table (``codes_prescale``), passed through
-    ``annlite_pq_search_topk_ex``."""
+    pre-processed (normalised for cosine).  Returns (f32 [B,k], i64 [B,k]) or, with ``packed``, i64 [B,k,2]."""
     N = codes.shape[0] if n_rows is None else n_rows
     B, D = queries.shape
     cb = code_bytes_of(codes)
@@ -194,24 +192,10 @@ def pq_search_topk(lut_kind: int, queries: torch.Tensor, codebooks: torch.Tensor
     else:
         od = torch.empty((B, k), dtype=torch.float32, device=dev)
         oi = torch.empty((B, k), dtype=torch.int64, device=dev)
-    if codes_pre16 is not None:
-        a = _capi.SearchArgs(ctypes.sizeof(_capi.SearchArgs), lut_kind, queries.data_ptr(), B, D, codebooks.data_ptr(),
-                             codes.data_ptr(), cb, codes_layout, N, M, Ks, _ptr(valid_bits), k, row_base, _ptr(od), _ptr(oi),
-                             _ptr(op), 1 if sqrt else 0, 0, ws.data_ptr(), ws.numel(), stream_ptr(), codes_pre16.data_ptr())
-        check(lib().annlite_pq_search_topk_ex(ctypes.byref(a)), 'pq_search_topk_ex')
-        return op if packed else (od, oi)
     check(lib().annlite_pq_search_topk(lut_kind, queries.data_ptr(), B, D, codebooks.data_ptr(), codes.data_ptr(), cb,
                                        codes_layout, N, M, Ks, _ptr(valid_bits), k, row_base, _ptr(od), _ptr(oi), _ptr(op),
                                        1 if sqrt else 0, ws.data_ptr(), ws.numel(), stream_ptr()), 'pq_search_topk')
     return op if packed else (od, oi)
-
-
-def codes_prescale(skewed: torch.Tensor, out16: torch.Tensor, row_begin: int, n_rows: int) -> torch.Tensor:
-    """Rows [row_begin, row_begin + n_rows) of the PRESCALED companion (int16 [capacity, M]) of a SKEWED u8 table."""
-    assert skewed.dtype == torch.uint8 and out16.dtype == torch.int16 and out16.shape == skewed.shape
-    check(lib().annlite_codes_prescale(skewed.data_ptr(), skewed.shape[1], int(row_begin), int(n_rows), out16.data_ptr(),
-                                       stream_ptr()), 'codes_prescale')
-    return out16
 
 
 def ivf_select_cells(kind: int, queries: torch.Tensor, centroids: torch.Tensor, n_probe: int) -> torch.Tensor:

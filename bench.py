@@ -57,7 +57,6 @@ def parse():
     p.add_argument('--streams', type=int, choices=[0, 1, 2], default=0,
                    help='streams the timed batches alternate on (0 = auto: 2 when the exchange runs, else 1)')
     p.add_argument('--layout', choices=['skewed', 'plain'], default='skewed')
-    p.add_argument('--no-prescale', action='store_true', help='A/B: without the prescaled u16 companion of the code table')
     p.add_argument('--no-rerank', action='store_true', help='skip the (untimed-in-value) exact re-rank leg')
     p.add_argument('--ivf-cells', type=int, default=256,
                    help='extra leg (N=1, never `value`): pruned search over this many cells; 0 = skip')
@@ -119,8 +118,7 @@ def main():
     n_local = hi - lo
     keep_vectors = not args.no_rerank
     index = PQFlatGpuIndex(dim=D, metric=metric, pq_codec=codec, initial_size=max(n_local, 64),
-                           rerank=keep_vectors, skewed=(args.layout == 'skewed'),
-                           prescaled=not args.no_prescale)
+                           rerank=keep_vectors, skewed=(args.layout == 'skewed'))
     t0 = time.time()
     c0, c1 = lo // CH, (hi + CH - 1) // CH
     for c in range(c0, c1):
@@ -292,7 +290,7 @@ def main():
         ivf = IvfPQGpuIndex(dim=D, metric=metric, pq_codec=codec, vq_codec=vq, initial_size=64, rerank=keep_vectors,
                             skewed=(args.layout == 'skewed'))
         # adopt the flat index's storage (same codes, validity, float vectors); add the cell of every row
-        for name in ('_codes', '_codes16', '_valid_bool', '_valid_bits_cache', '_vectors', '_capacity', '_n_rows', '_size'):
+        for name in ('_codes', '_valid_bool', '_valid_bits_cache', '_vectors', '_capacity', '_n_rows', '_size'):
             setattr(ivf, name, getattr(index, name))
         ivf._cell_of = torch.zeros((index._capacity,), dtype=torch.int32, device=dev)
         for c in range(c0, c1):

@@ -198,37 +198,6 @@ ANNLITE_API int annlite_pq_search_topk(int lut_kind, const float *queries_dev, i
                            int64_t row_base, float *out_dist_dev, int64_t *out_id_dev, int64_t *out_packed_dev,
                            int flags, void *workspace_dev, size_t workspace_bytes, void *stream);
 
-/* The same call with its arguments in a struct, plus what the plain signature has no room for:
- * codes_pre16_dev -- optional PRESCALED companion of a SKEWED M = 16 table (annlite_codes_prescale): u16 [N][M], entry j of
- * row n = (stored byte << 5) | ((n + j) % 16), the LDS entry index of the look-up; the byte-table scan kernel then forms an
- * address with one instruction per code instead of two and needs no per-lane base registers.  NULL: as annlite_pq_search_topk.
- * struct_size must be sizeof(annlite_search_args). */
-typedef struct annlite_search_args {
-    int32_t struct_size;
-    int32_t lut_kind;
-    const float *queries_dev;
-    int64_t B, D;
-    const float *codebooks_dev;
-    const void *codes_dev;
-    int32_t code_bytes, codes_layout;
-    int64_t N, M, Ks;
-    const uint32_t *valid_bits_dev;
-    int64_t k, row_base;
-    float *out_dist_dev;
-    int64_t *out_id_dev;
-    int64_t *out_packed_dev;
-    int32_t flags;
-    int32_t reserved;
-    void *workspace_dev;
-    size_t workspace_bytes;
-    void *stream;
-    const void *codes_pre16_dev;
-} annlite_search_args;
-ANNLITE_API int annlite_pq_search_topk_ex(const annlite_search_args *args);
-/* rows [row_begin, row_begin + n_rows) of the companion table from the SKEWED u8 table (storage step next to annlite_codes_skew) */
-ANNLITE_API int annlite_codes_prescale(const void *skewed_dev, int64_t M, int64_t row_begin, int64_t n_rows, void *out16_dev,
-                           void *stream);
-
 /* Same scan, but return the UNMERGED per-slice lists: plan.n_slices * k candidates per query
  * ([B][n_slices*k], unordered across slices, (+inf,-1) where a slice had fewer rows).  The set is a
  * superset of the exact top-k; it is the candidate generator of the exact re-rank stage

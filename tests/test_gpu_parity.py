@@ -639,52 +639,6 @@ def test_scan_kernel_variants_agree(ops, oracle, variant, monkeypatch):
     assert np.array_equal(d, rd) and np.array_equal(i, ri)
 
 
-def test_prescaled_companion_table(ops, oracle, tmp_path):
-    """The byte-table kernel's step loop reads the PRESCALED u16 companion of the SKEWED table (annlite_codes_prescale,
-    annlite_pq_search_topk_ex): same ids and distances as without it and as the oracle -- through inserts in several
-    batches, a capacity expansion, deletions, an `indices` filter and dump / load."""
-    from annlite_amd import Metric, PQCodec, PQFlatGpuIndex
-
-    rs = np.random.RandomState(9)
-    N, D, M, B, k = 60000, 128, 16, 70, 10
-    A = rs.randn(16, D).astype(np.float32)
-    x = (rs.randn(N, 16).astype(np.float32) @ A + 0.05 * rs.randn(N, D).astype(np.float32)).astype(np.float32)
-    q = (rs.randn(B, 16).astype(np.float32) @ A + 0.05 * rs.randn(B, D).astype(np.float32)).astype(np.float32)
-    codec = PQCodec(dim=D, n_subvectors=M, n_clusters=256, metric=Metric.EUCLIDEAN, n_init=1)
-    codec.seed = 2
-    codec.fit(x[:8192], iter=5)
-    res = {}
-    for pre in (True, False):
-        idx = PQFlatGpuIndex(dim=D, metric=Metric.EUCLIDEAN, pq_codec=codec, initial_size=20000, expand_step_size=16384,
-                             prescaled=pre)
-        idx.add_with_ids(x[:15000], np.arange(15000))
-        idx.add_with_ids(x[15000:45000], np.arange(15000, 45000))   # grows past the initial capacity
-        idx.add_with_ids(x[45000:], np.arange(45000, N))
-        assert (idx._codes16 is not None) == pre
-        idx.delete([3, 77, 40000])
-        d, i = idx.search_batch(q, limit=k)
-        sub = np.arange(0, N, 7)
-        d2, i2 = idx.search_batch(q, limit=k, indices=sub)
-        res[pre] = (d, i, d2, i2)
-        if pre:
-            idx.dump(tmp_path / 'pre.idx')
-            idx3 = PQFlatGpuIndex(dim=D, metric=Metric.EUCLIDEAN, pq_codec=codec, initial_size=64)
-            idx3.load(tmp_path / 'pre.idx')
-            d3, i3 = idx3.search_batch(q, limit=k)
-            assert np.array_equal(d3, d) and np.array_equal(i3, i)
-    for a, b in zip(res[True], res[False]):
-        assert np.array_equal(a, b)
-    codes = oracle.encode_c(x, codec.codebooks)
-    lut = oracle.get_dist_mat_c(q, codec.codebooks, oracle.EUCLIDEAN)
-    valid = np.ones(N, bool)
-    valid[[3, 77, 40000]] = False
-    for b in range(0, B, 5):
-        dist = oracle.dist_pqcodes_to_codebooks_c(lut[b], codes)
-        dist[~valid] = np.inf
-        rd, ri = oracle.top_k_c(dist, k)
-        assert np.array_equal(res[True][0][b], np.sqrt(rd)) and np.array_equal(res[True][1][b], ri)
-
-
 def test_full_size_properties_config2(ops, oracle):
     """BASELINE config 2 at full size (1M x 128-d, PQ m=16, batch 1024, k=10) through size-independent
     properties: ascending order, every returned distance equals the gathered ADC distance of that row
