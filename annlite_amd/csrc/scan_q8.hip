@@ -180,9 +180,24 @@ __device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t x) {
 // consumer wave: pop up to 128 entries (two per lane).  An entry is (S << 40 | slot << 32 | row): entries whose integer
 // sum no longer passes the slot's CURRENT bound are dropped before any global load (the bound tightens while a backlog
 // waits); the others get their exact sum (the reference's arithmetic) and go into their slot's list.
+// The global publication of a batch's bounds (the other row slices' workgroups import them) is DEFERRED to the next batch,
+// behind the issue of its table gathers: the device-scope atomics take microseconds and the wave's memory counter is in
+// order -- issued right away they sat in front of the next batch's gathers.
+__device__ __forceinline__ void q8_publish_global(const FlushCtx &c, int lane, unsigned long long &pend_o, unsigned long long &pend_j) {
+    if (lane < 32) {
+        const int b = c.b0 + lane;
+        if (pend_o != ~0ull && c.gkey) __hip_atomic_fetch_min(c.gkey + b, pend_o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pend_j != ~0ull && c.gk2)
+            __hip_atomic_store(c.gk2 + (int64_t)b * c.n_slices + c.slice, pend_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    pend_o = ~0ull;
+    pend_j = ~0ull;
+}
+
 template <int M, bool SKEWED>
 __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Ring &r, const Q8Lists &g, uint32_t head, int n, int lane,
-                                           uint32_t &n_kept, uint32_t &n_offered) {
+                                           uint32_t &n_kept, uint32_t &n_offered, unsigned long long &pend_o,
+                                           unsigned long long &pend_j) {
     constexpr int CW = M / 4;
     unsigned long long e[2];
     bool act[2];
@@ -236,6 +251,7 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Ring &r, c
                 vals[u][m] = lq[((int64_t)code * M + m) * 4];
             }
         }
+        q8_publish_global(c, lane, pend_o, pend_j);  // (the previous batch's, behind this batch's gathers)
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -293,13 +309,12 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Ring &r, c
     if (lane < 32) chg[lane] = 0;
     // publish the bounds of the slots that changed: lane = slot
     if (lane < 32 && ((changed >> lane) & 1u)) {
-        const int b = c.b0 + lane;
         const unsigned long long okey = list[lane * 16 + c.km1], jkey = list[lane * 16 + c.jm1];
         volatile unsigned long long *tau = (volatile unsigned long long *)g.tau;
         if (okey < tau[lane]) {
             tau[lane] = okey;
             if (okey < gkl[lane]) {  // tell the other workgroups of this query (the other row slices)
-                if (c.gkey) __hip_atomic_fetch_min(c.gkey + b, okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pend_o = okey;  // (keys only fall)
                 gkl[lane] = okey;
                 volatile unsigned char *sp = (volatile unsigned char *)(g_smem + c.shq_off + lane);
                 const unsigned char nb = q8_bound(okey, g.c0[lane], g.c1[lane]);
@@ -310,7 +325,7 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Ring &r, c
             volatile unsigned long long *gjl = (volatile unsigned long long *)(g_smem + c.gjl_off + lane * 8);
             if (jkey < *gjl) {
                 *gjl = jkey;
-                __hip_atomic_store(c.gk2 + (int64_t)b * c.n_slices + c.slice, jkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pend_j = jkey;
             }
         }
     }
@@ -523,6 +538,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             bags.qslot = smem + lds.qslot;
             bags.chg = smem + lds.chg;
             uint32_t head = 0, n_kept = 0, n_offered = 0;
+            unsigned long long pend_o = ~0ull, pend_j = ~0ull;  // bounds not yet published to the other workgroups (lane = slot)
             unsigned long long t_busy = 0;
             uint32_t n_batches = 0;
             int epoch = 0, epoch_step = a.q8_epoch0;  // the current epoch ends after step `epoch_step` (the last: after step n_steps - 1)
@@ -539,7 +555,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                         const int n = avail < 128 ? avail : 128;
                         const unsigned long long t0 = a.dbg ? __builtin_readcyclecounter() : 0ull;
                         __builtin_amdgcn_s_setprio(3);  // (serial code on a SIMD shared with three or four scanning waves)
-                        q8_consume<M, SKEWED>(fc, ring, bags, head, n, lane, n_kept, n_offered);
+                        q8_consume<M, SKEWED>(fc, ring, bags, head, n, lane, n_kept, n_offered, pend_o, pend_j);
                         __builtin_amdgcn_s_setprio(0);
                         ++n_batches;
                         if (a.dbg) t_busy += __builtin_readcyclecounter() - t0;
@@ -552,6 +568,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     if ((++idle & 15) == 8) import_bounds();
                     __builtin_amdgcn_s_sleep(4);
                 }
+                q8_publish_global(fc, lane, pend_o, pend_j);
                 epoch_sync(final);
                 if (final) break;
                 ++epoch;

@@ -1,15 +1,8 @@
 cd /root/repo
-cp annlite_amd/libannlite_hip.so /tmp/lib_orig.so
-cp build_exp/lib_exp5.so annlite_amd/libannlite_hip.so
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x 2>&1 | tail -2
+for it in 1 2; do
 for rows in 1250000 10000000; do
-ANNLITE_DEBUG_COUNTERS=1 timeout 120 python - <<PY
-import sys, os
-sys.argv=['prof_scan.py','--rows','$rows','--data','lowrank','--fused','--iters','5']
-sys.path.insert(0,'scripts'); sys.path.insert(0,'.')
-exec(open('scripts/prof_scan.py').read().split("if os.environ.get('ANNLITE_DEBUG_COUNTERS')")[0])
-from annlite_amd import _capi
-c=_capi.debug_counters()
-print('rows $rows phases per WG (us): pop %.1f exact %.1f queues %.1f rounds %.1f publish %.1f | total inside %.1f batches %d' % tuple([c[i]/256/2400. for i in (0,1,2,3,5,4)]+[c[6]]))
-PY
-done
-cp /tmp/lib_orig.so annlite_amd/libannlite_hip.so
+  timeout 120 python bench.py --rows $rows --steps 40 --warmup 8 --ivf-cells 0 --cpu-queries 0 --no-rerank --recall-queries 0 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('rows $rows ms_per_step %.4f kernel_ms %.4f frac %.3f' % (r['ms_per_step'], r['roofline']['kernel_ms'], r['roofline']['frac']))"
+done; done
+ANNLITE_DEBUG_COUNTERS=1 timeout 120 python scripts/prof_scan.py --rows 1250000 --data lowrank --fused --iters 6 2>&1 | grep -i "byte-table"
+ANNLITE_DEBUG_COUNTERS=1 timeout 120 python scripts/prof_scan.py --rows 10000000 --data lowrank --fused --iters 6 2>&1 | grep -i "byte-table"
