@@ -225,9 +225,10 @@ ANNLITE_API int annlite_debug_counters(uint64_t *out8);
 
 /* Convert between the PLAIN and the SKEWED code-table layout (uint8 codes).
  * forward (inverse=0): table_out[id][j] = codes_in[i][(j + id) mod M]   -- scatter rows i -> id
- *                      (M = 64 only: minus 1 mod 256 where j + id mod 64 >= 64 -- the "wrap-coded" form the
- *                      M = 64 scan kernel addresses without per-step base registers; SKEWED is an opaque,
- *                      per-M storage format: always produce and undo it with this function)
+ *                      (M = 64: each 32-byte half is rotated by id mod 32 on its own and "wrap-coded" -- minus 1 mod 256
+ *                      where j mod 32 + id mod 32 >= 32 -- the form the M = 64 scan kernel turns into an LDS address with
+ *                      one byte permute; SKEWED is an opaque, per-M storage format: always produce and undo it with this
+ *                      function)
  * inverse (inverse=1): codes_out[i][j]  = table_in[id][(j - id) mod M]  -- gather rows id -> i
  * id = ids_dev[i] if ids_dev != NULL else id_base + i.  This is the storage step of the index
  * plugin's add_with_ids (annlite/core/index/pq_index.py:25-27 -> flat_index.py:41-50 `_data[ids] = x`). */
