@@ -604,7 +604,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 if (const char *e = getenv("ANNLITE_SEED_ROWS")) S = atoll(e);
                 if (S > N) S = N;
                 rc = launch_seed_bound(M, codes_layout == ANNLITE_CODES_SKEWED, codes_dev, S, valid_bits_dev, lut_dev, B, Ks, k,
-                                       gk, st);
+                                       smax, gk, st);
                 if (rc != ANNLITE_OK) return rc;
             }
             a.smax = smax;

@@ -218,6 +218,7 @@ int launch_lut_quantise(int64_t M, int64_t Ks, int64_t B, int64_t bpad, const fl
                         uint16_t *q16, float *qstep, double *qlo, float *smax, float *qlom, void *fill,
                         size_t fill_bytes, hipStream_t st);
 int launch_seed_bound(int64_t M, bool skewed, const void *codes_dev, int64_t S, const uint32_t *valid_bits_dev,
-                      const float *lut_dev, int64_t B, int64_t Ks, int64_t k, unsigned long long *gkey, hipStream_t st);
+                      const float *lut_dev, int64_t B, int64_t Ks, int64_t k, const float *smax, unsigned long long *gkey,
+                      hipStream_t st);
 
 }  // namespace annlite

@@ -86,8 +86,14 @@ __global__ __launch_bounds__(1024) void lut_quantise64_kernel(const float *__res
 // filter that passes ~k/S of the rows instead of all of them (the cold-start "flood" cost 16 waves x 16
 // queries x 64 uncoalesced gathers per work item).
 // One 16-wave workgroup per group of 4 queries: their fp32 TILED rows [Ks][M][4] (64 KB at M=16) are
-// staged in LDS, so ONE ds_read_b128 per (row, m) feeds the four exact ascending-m sums (gathering the
-// same entries from L2 cost a 64-byte request per 4 useful bytes: 150 us for 4096 rows x 1024 queries).
+// staged in LDS, so ONE ds_read_b128 per (row, m) feeds the four sums (gathering the same entries from L2
+// cost a 64-byte request per 4 useful bytes: 150 us for 4096 rows x 1024 queries).
+// The sums run in the lane's SKEWED order -- sub-space (lane + t) mod M at step t, as the scan kernels read
+// -- so that the 16 lanes of an LDS access group hit 16 different 16-byte bank groups whatever the codes
+// are.  (In ascending m all lanes read the same sub-space and the bank group was (code + m) mod 16: random
+// codes, ~2.7-way conflicts, 59 us for 32768 rows against 13 us of look-ups.)  A rotated fp32 sum differs
+// from the reference's ascending one by rounding only, at most slack32 = 2 M 2^-24 sum_m max|lut| -- the
+// scan's own margin --, which is added to the bound.
 // Selection without sorting networks: every lane keeps the MIN distance of the rows it saw; the 1024
 // (wave, lane) groups are disjoint, so the k-th smallest of their minima has >= k distinct rows at or
 // below it -- a valid bound, and equal to the exact k-th distance of the S rows unless two of the k best
@@ -101,16 +107,16 @@ template <int M, bool SKEWED, int QPB>
 __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8_t *__restrict__ codes, int64_t S,
                                                                     const uint32_t *__restrict__ valid,
                                                                     const float *__restrict__ lut, int B, int Ks, int k,
+                                                                    const float *__restrict__ smax,
                                                                     unsigned long long *__restrict__ gkey) {
     constexpr int CW = M / 4;
     constexpr int CH = M < 16 ? M : 16;  // look-ups in flight
     typedef float fq __attribute__((ext_vector_type(QPB)));
     static_assert(QPB == 4 || QPB == 2, "queries per block");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [Ks][M + 1] x QPB queries: the pad entry spreads a fixed m over the banks (slot (code*(M+1) + m) % 16 =
-    // (code + m) % 16); unpadded, all 64 lanes of a look-up hit ONE slot-bank (16-way conflict)
+    // [Ks][M] x QPB queries: entry (code, m) sits in bank group m mod 16 (QPB = 4; bank pair m mod 32 for QPB = 2)
     fq *tab = (fq *)smem;
-    unsigned long long *cand = (unsigned long long *)(smem + (size_t)Ks * (M + 1) * sizeof(fq));  // [kSeedWaves][k]
+    unsigned long long *cand = (unsigned long long *)(smem + (size_t)Ks * M * sizeof(fq));  // [kSeedWaves][k]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -120,17 +126,33 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
         const f32x4 *src = (const f32x4 *)lut + (int64_t)g4 * Ks * M;
         for (int i = tid; i < Ks * M; i += kSeedWaves * 64) {
             const f32x4 e = src[i];
-            if constexpr (QPB == 4) tab[i + i / M] = e;
-            else tab[i + i / M] = h ? (fq){e.z, e.w} : (fq){e.x, e.y};
+            if constexpr (QPB == 4) tab[i] = e;
+            else tab[i] = h ? (fq){e.z, e.w} : (fq){e.x, e.y};
         }
     }
+    // the waves draw their blocks of 64 rows from this counter (see adc_scan_q8_kernel: a static deal leaves the waves the
+    // SIMD's arbiter does not favour to finish alone, at a third of the issue rate)
+    uint32_t *blk_ctr = (uint32_t *)((unsigned char *)cand + 12288);  // (cand / minima use the first 8 KB of their 16)
+    if (tid == 0) *blk_ctr = 0;
     __syncthreads();
-    // inverse skew rotation of this lane's rows (row % M == lane % M: the rows of a wave start at a multiple of 64)
-    const int sinv = (M - lane % M) % M;
-    const uint32_t bsh_inv = (uint32_t)(sinv & 3);
-    bool abit_inv[8];
+    // forward skew rotation of PLAIN rows (row % M == lane % M: the rows of a wave start at a multiple of 64); SKEWED
+    // rows are stored that way
+    const int sfw = lane % M;
+    const uint32_t bsh_fw = (uint32_t)(sfw & 3);
+    bool abit_fw[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) abit_inv[i] = (((sinv >> 2) >> i) & 1) != 0;
+    for (int i = 0; i < 8; ++i) abit_fw[i] = (((sfw >> 2) >> i) & 1) != 0;
+    // sub-space of stored byte t of this lane's rows, as an element offset into a table row
+    uint32_t moff[M];
+#pragma unroll
+    for (int t = 0; t < M; ++t) {
+        if constexpr (M == 64) moff[t] = (uint32_t)(32 * (t / 32) + ((lane & 31) + t) % 32);  // two skewed halves
+        else moff[t] = (uint32_t)((lane + t) % M);
+        if constexpr (M == 16 && QPB == 4) moff[t] <<= 4;  // (as a byte offset: the permute addressing below)
+    }
+    if constexpr (M == 16 && QPB == 4) {
+        if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();  // (all LDS is dynamic)
+    }
 
     uint32_t best[QPB];  // ordered distance keys
 #pragma unroll
@@ -145,35 +167,63 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
         vw = valid ? valid[rr >> 5] : ~0u;
     };
     uint32_t cn[CW], vn;
-    fetch((int64_t)wave * 64 + lane, cn, vn);
-    for (int64_t r0 = (int64_t)wave * 64; r0 < S; r0 += kSeedWaves * 64) {
-        const int64_t r = r0 + lane;
+    auto draw_block = [&]() -> uint32_t {  // (lane 0's value; broadcast a step later)
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(blk_ctr, 1u);
+        return v;
+    };
+    const uint32_t n_blocks = (uint32_t)((S + 63) >> 6);
+    uint32_t b_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)draw_block());
+    uint32_t b_pend = draw_block();
+    fetch((int64_t)b_cur * 64 + lane, cn, vn);
+    uint32_t b_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_pend);
+    while (b_cur < n_blocks) {
+        const int64_t r = (int64_t)b_cur * 64 + lane;
+        b_pend = draw_block();
         bool ok = r < S && ((vn >> (r & 31)) & 1u);
         uint32_t c[CW];
 #pragma unroll
         for (int i = 0; i < CW; ++i) c[i] = cn[i];
-        fetch(r + kSeedWaves * 64, cn, vn);
-        if constexpr (SKEWED && M == 64) skew64_decode(c, lane & 31);  // two skewed halves, wrap-coded
-        else if constexpr (SKEWED) rotate_row<CW>(c, abit_inv, bsh_inv);
+        fetch((int64_t)b_nxt * 64 + lane, cn, vn);
+        if constexpr (M == 64) {
+            if constexpr (SKEWED) {
+#pragma unroll
+                for (int i = 0; i < CW; ++i) c[i] = bytes_add(c[i], wrap64_mask(i, lane & 31));  // undo the wrap coding only
+            } else {
+                skew64_rotate_halves(c, lane & 31);
+            }
+        } else if constexpr (!SKEWED) {
+            rotate_row<CW>(c, abit_fw, bsh_fw);
+        }
         fq d;
 #pragma unroll
         for (int q = 0; q < QPB; ++q) d[q] = 0.f;
         static_for<0, M / CH>([&](auto C) {
-            constexpr int m0 = decltype(C)::value * CH;
+            constexpr int t0 = decltype(C)::value * CH;
             fq v[CH];
+            static_for<0, CH>([&](auto I) {
+                constexpr int i = decltype(I)::value, t = t0 + i;
+                if constexpr (M == 16 && QPB == 4) {
+                    // 256-byte table rows: the LDS address (code << 8) | (sub-space << 4) is one byte permute of the code
+                    // dword with the step's constant (byte 0 <- moff16 byte 0, byte 1 <- code byte t % 4, rest 0)
+                    typedef const fq __attribute__((address_space(3))) *lds_fq_ptr;
+                    const uint32_t ad = __builtin_amdgcn_perm(c[t / 4], moff[t], 0x0c0c0000u | ((4u + (uint32_t)(t % 4)) << 8));
+                    v[i] = *(lds_fq_ptr)(uintptr_t)ad;
+                } else {
+                    const uint32_t code = (c[t / 4] >> (8 * (t % 4))) & 0xffu;
+                    v[i] = tab[code * M + moff[t]];
+                }
+            });
 #pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const uint32_t code = (c[(m0 + i) / 4] >> (8 * ((m0 + i) % 4))) & 0xffu;
-                v[i] = tab[code * (M + 1) + m0 + i];
-            }
-#pragma unroll
-            for (int i = 0; i < CH; ++i) d += v[i];  // ascending m: the reference's order
+            for (int i = 0; i < CH; ++i) d += v[i];  // (the lane's skewed order: see the kernel's header)
         });
 #pragma unroll
         for (int q = 0; q < QPB; ++q) {
             const uint32_t key = f32_to_ordered(d[q]);
             if (ok && key < best[q]) best[q] = key;
         }
+        b_cur = b_nxt;
+        b_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_pend);
     }
     // Selection keys: the low 10 bits of the ordered distance are replaced by (wave, lane), which makes the
     // 1024 keys of a query unique (rank = number of smaller keys, no tie handling) and costs at most 1023
@@ -207,8 +257,14 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
             const int b = g4 * 4 + h * QPB + q;
             // the bound admits every row at or below (me | 1023), whatever its id; +1 in the distance field
             // because the seed rows are in nobody's list: the scan must still ACCEPT the rows that set it
-            if (rk == k - 1 && b < B && (me | 1023u) != 0xffffffffu)
-                gkey[b] = ((unsigned long long)(me | 1023u) + 1ull) << 32;
+            if (rk == k - 1 && b < B && (me | 1023u) != 0xffffffffu) {
+                // + the rounding margin between this sum order and the reference's, rounded up
+                const float slack = smax[b] * (float)(2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
+                float thr = ordered_to_f32(me | 1023u);
+                thr = thr + slack;
+                const uint32_t key = f32_to_ordered(thr) + 1u;
+                gkey[b] = ((unsigned long long)key + 1ull) << 32;
+            }
         }
         __syncthreads();
     }
@@ -566,15 +622,15 @@ int annlite::launch_lut_quantise(int64_t M, int64_t Ks, int64_t B, int64_t bpad,
 }
 
 int annlite::launch_seed_bound(int64_t M, bool skw, const void *codes_dev, int64_t S, const uint32_t *valid_bits_dev,
-                               const float *lut_dev, int64_t B, int64_t Ks, int64_t k, unsigned long long *gk,
-                               hipStream_t st) {
+                               const float *lut_dev, int64_t B, int64_t Ks, int64_t k, const float *smax,
+                               unsigned long long *gk, hipStream_t st) {
 #define ANNLITE_SEED(MM, QPB_)                                                                                    \
     {                                                                                                             \
         auto fn = skw ? seed_bound_kernel<MM, true, QPB_> : seed_bound_kernel<MM, false, QPB_>;                   \
-        const size_t lds = (size_t)Ks * (MM + 1) * 4 * QPB_ + (size_t)2 * kSeedWaves * 64 * 8; /* cand + minima */ \
+        const size_t lds = (size_t)Ks * MM * 4 * QPB_ + (size_t)2 * kSeedWaves * 64 * 8; /* cand + minima */         \
         ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(fn, dim3((unsigned)(((B + 3) / 4) * (4 / QPB_))), dim3(kSeedWaves * 64), lds, st,      \
-                           (const uint8_t *)codes_dev, S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, gk);   \
+                           (const uint8_t *)codes_dev, S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, smax, gk);   \
     }
     if (M == 8) ANNLITE_SEED(8, 4) else if (M == 16) ANNLITE_SEED(16, 4) else if (M == 32) ANNLITE_SEED(32, 4)
     else ANNLITE_SEED(64, 2)
