@@ -534,6 +534,15 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         a.q8_epoch_mul = 4;
         a.q8_ring_limit = 384;
         a.q8_import_mask = 3;
+        a.q8_min_batch = 1;
+        a.q8_min_wait = 0;
+        if (const char *e = getenv("ANNLITE_Q8_BATCH")) {  // "min_batch,min_wait" (measurements)
+            int mb = 1, mw = 0;
+            if (sscanf(e, "%d,%d", &mb, &mw) == 2 && mb >= 1 && mb <= 128 && mw >= 0) {
+                a.q8_min_batch = mb;
+                a.q8_min_wait = mw;
+            }
+        }
         if (const char *e = getenv("ANNLITE_Q8_TUNE")) {  // "epoch0,mul,ring_limit,import_mask" (measurements)
             int e0 = 3, mul = 4, rl = 384, im = 3;
             // (a ring limit below 192 can deadlock: the consumer waits for entries of a producer the limit holds back)

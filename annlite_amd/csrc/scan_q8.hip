@@ -551,7 +551,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     const uint32_t arrived = *ring.arrived;  // (read BEFORE the tail: a wave pushes, then arrives)
                     const uint32_t tail = *ring.tail;
                     const int avail = (int)(tail - head);
-                    if (avail > 0) {
+                    // a batch costs ~4 us whatever it holds (its chains of dependent LDS accesses wait out the scanning
+                    // waves' look-ups): take small ones only when nothing more has come for a while, or at the epoch's end
+                    // A non-final epoch does not wait for the backlog: the scanning waves stand at the barrier, what is in the
+                    // ring is taken in the next epoch (only the last epoch's end needs every candidate in the lists)
+                    if (arrived == want && !final) break;
+                    if (avail >= a.q8_min_batch || (avail > 0 && (arrived == want || idle >= a.q8_min_wait))) {
                         const int n = avail < 128 ? avail : 128;
                         const unsigned long long t0 = a.dbg ? __builtin_readcyclecounter() : 0ull;
                         __builtin_amdgcn_s_setprio(3);  // (serial code on a SIMD shared with three or four scanning waves)
@@ -569,8 +574,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     __builtin_amdgcn_s_sleep(4);
                 }
                 q8_publish_global(fc, lane, pend_o, pend_j);
+                const uint32_t tail_now = *ring.tail;  // (every scanning wave has arrived: its pushes are complete)
                 epoch_sync(final);
                 if (final) break;
+                if (*s_ctl) {
+                    // the table was rebuilt: the integer sums of the waiting candidates are in the OLD table's steps --
+                    // clear them, so that the stale-candidate check lets them through to the exact sum
+                    for (uint32_t i = head + (uint32_t)lane; (int)(tail_now - i) > 0; i += 64u)
+                        ring.slots[i & (kRingSize - 1)] &= ~(0xffull << 40);
+                }
                 ++epoch;
                 epoch_step = a.q8_epoch_mul * epoch_step + (a.q8_epoch_mul - 1);
             }
