@@ -530,11 +530,25 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         FastCfg c;
         fast_cfg(M, Ks, code_bytes, k, &c, tm != nullptr);
         if (c.mode == 5 && a.n_tiles >= 8) a.n_items = 8 * ((a.n_tiles + 7) / 8) * a.n_slices;  // q8_item_map
-        a.q8_epoch0 = 3;
-        a.q8_epoch_mul = 4;
+        // epochs end after steps 15, 255, 4095 (x 15 blocks of 64 rows) and a slot asks for a new table when its T has halved:
+        // 10M rows x 1024 queries 1.497 ms per launch with {3, 15, 63, ...} / T 64 / rebuild at 7/8, 1.445 with this, 1.441 with no
+        // epoch at all (1.25M rows: 0.284 / 0.261 / 0.254) -- on the bench's data a barrier of all 16 waves costs more than a
+        // finer table saves; the sparse schedule stays as the guard against a seed bound that is far off
+        a.q8_epoch0 = 15;
+        a.q8_epoch_mul = 16;
         a.q8_ring_limit = 384;
         a.q8_import_mask = 3;
         a.q8_min_batch = 1;
+        a.q8_target = 96;
+        a.q8_rebuild_8ths = 4;
+        if (const char *e = getenv("ANNLITE_Q8_REBUILD")) {
+            const int t = atoi(e);
+            if (t >= 0 && t <= 8) a.q8_rebuild_8ths = t;
+        }
+        if (const char *e = getenv("ANNLITE_Q8_TARGET")) {
+            const int t = atoi(e);
+            if (t >= 16 && t <= 127) a.q8_target = t;
+        }
         a.q8_min_wait = 0;
         if (const char *e = getenv("ANNLITE_Q8_BATCH")) {  // "min_batch,min_wait" (measurements)
             int mb = 1, mw = 0;
@@ -544,7 +558,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             }
         }
         if (const char *e = getenv("ANNLITE_Q8_TUNE")) {  // "epoch0,mul,ring_limit,import_mask" (measurements)
-            int e0 = 3, mul = 4, rl = 384, im = 3;
+            int e0 = 15, mul = 16, rl = 384, im = 3;
             // (a ring limit below 192 can deadlock: the consumer waits for entries of a producer the limit holds back)
             if (sscanf(e, "%d,%d,%d,%d", &e0, &mul, &rl, &im) == 4 && e0 >= 0 && mul >= 2 && rl >= 192 && rl <= 448 && im >= 0) {
                 a.q8_epoch0 = e0;

@@ -39,7 +39,6 @@
 
 namespace annlite {
 
-constexpr int kQ8Target = 64;  // T right after a (re)build
 #ifndef ANNLITE_Q8_DEPTH
 #define ANNLITE_Q8_DEPTH 8  // look-ups in flight per lane
 #endif
@@ -52,7 +51,7 @@ struct Q8Cfg {
 };
 
 template <int M>
-__device__ __forceinline__ void q8_slot_params(bool real, unsigned long long key, float range, float smax_b, double L,
+__device__ __forceinline__ void q8_slot_params(bool real, unsigned long long key, float range, float smax_b, double L, int target,
                                                float &step, float &inv, float &clip, unsigned char &tbyte) {
     clip = (float)Q8Cfg<M>::QOPEN;
     if (!real) {  // pad slot: all-zero table, never passes (0x7f - 0 has bit 7 clear)
@@ -70,11 +69,11 @@ __device__ __forceinline__ void q8_slot_params(bool real, unsigned long long key
         const double slack = (double)smax_b * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
         const double R = thr + slack - L;
         if (R > 0.0 && R < 1e30) {
-            float s = (float)(R / (double)(kQ8Target - 1));
+            float s = (float)(R / (double)(target - 1));  // T = target right after a (re)build
             const float smin = open_step * (1.f / 65536.f);
             if (!(s >= smin)) s = smin;  // (a larger step only lowers T)
             step = s;
-            clip = (float)Q8Cfg<M>::QMAX;  // T <= kQ8Target now and it only falls: sums above 127 can never pass
+            clip = (float)Q8Cfg<M>::QMAX;  // T <= target <= 127 now and it only falls: sums above 127 can never pass
         }
     }
     inv = 1.0f / step;
@@ -90,7 +89,7 @@ struct Q8Build {
     const float *lut, *qlom, *qstep, *smax;
     const double *qlo;
     const unsigned long long *gkey;
-    int32_t Ks, B, k;
+    int32_t Ks, B, k, target;
 };
 
 template <int M, int NW>
@@ -383,7 +382,7 @@ __device__ __attribute__((noinline)) void q8_rebuild(const Q8Build a, int tile, 
         float step, inv, clip;
         unsigned char tb;
         q8_slot_params<M>(real, key, real ? a.qstep[b] * (float)(32767 / M) : 0.f, real ? a.smax[b] : 0.f,
-                          real ? a.qlo[b] : 0.0, step, inv, clip, tb);
+                          real ? a.qlo[b] : 0.0, a.target, step, inv, clip, tb);
         ((volatile float *)(smem + o.step))[tid] = step;
         ((float *)(smem + o.inv))[tid] = inv;
         ((float *)(smem + o.clip))[tid] = clip;
@@ -437,7 +436,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
     volatile unsigned char *s_tb = (volatile unsigned char *)(smem + tb_off);
     volatile uint32_t *s_ctl = (volatile uint32_t *)(smem + ctl_off);
     unsigned long long *lists = (unsigned long long *)(smem + list_off);
-    const Q8Build ba = {a.lut, a.qlom, a.qstep, a.smax, a.qlo, a.gkey, a.Ks, a.B, a.k};
+    const Q8Build ba = {a.lut, a.qlom, a.qstep, a.smax, a.qlo, a.gkey, a.Ks, a.B, a.k, a.q8_target};
     Q8Ring ring;
     ring.tail = (volatile uint32_t *)(smem + ring_ctl_off);
     ring.head = (volatile uint32_t *)(smem + ring_ctl_off + 4);
@@ -458,7 +457,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
         __syncthreads();  // every wave is done with the previous item
         // end of an epoch (all waves): the consumer arrives last, with every pushed candidate in the lists.  Then: have
         // the bounds outrun the table?  A slot's T falls as its threshold tightens under a fixed step; rebuild when a
-        // quarter of the real slots are below 3/4 of what their table was built for.
+        // quarter of the real slots are below q8_rebuild_8ths / 8 of what their table was built for.
         auto epoch_sync = [&](bool final) {
             __syncthreads();
             if (final) return;
@@ -466,7 +465,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 const int q = lane & 31;
                 const bool real = tile * QT + q < a.B && lane < 32;
                 const uint32_t tn = shq[q] & 0x7fu, tb = s_tb[q] & 0x7fu;
-                const bool need = real && tn * 8u < tb * 7u;
+                const bool need = real && tn * 8u < tb * (uint32_t)a.q8_rebuild_8ths;
                 const int n_need = __popcll(__ballot(need)), n_real = __popcll(__ballot(real));
                 if (lane == 0) *s_ctl = (n_need > 0 && n_need * 4 >= n_real) ? 1u : 0u;
             }
@@ -486,7 +485,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
         }
         q8_rebuild<M, NW>(ba, tile, 1);  // (its barriers cover the initialisation above)
 
-        // epochs end after steps 1, 3, 7, 15, ... (bounds move on a log scale) and after the last step
+        // epochs end after steps q8_epoch0, q8_epoch0 * mul + (mul - 1), ... and after the last step
         if (wave == NS) {
             // ------------------------------------------------------------------------------- consumer wave
             const FlushCtx fc = {(const uint8_t *)a.codes, a.lut, a.smax, a.qstep, a.qlo, a.gkey, a.gk2, nullptr,
@@ -700,7 +699,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             load_row(s_begin + b_cur * 64u + lane, cnext);
             vnext = load_valid(s_begin + b_cur * 64u + lane);
             uint32_t b_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend);
-            // The blocks are cut into epochs that end after block 15 * 4, 15 * 16, 15 * 64, ... and after the last one (the
+            // The blocks are cut into epochs that end after block 15 * 16, 15 * 256, ... (q8_epoch0, q8_epoch_mul) and after the last one (the
             // epochs' barriers meet).  The step loop of an epoch contains no call and no barrier: the loop-invariant
             // registers stay put.
             uint32_t it_no = 0;

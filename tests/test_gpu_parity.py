@@ -639,6 +639,38 @@ def test_scan_kernel_variants_agree(ops, oracle, variant, monkeypatch):
     assert np.array_equal(d, rd) and np.array_equal(i, ri)
 
 
+@pytest.mark.parametrize('tune', [('1,2,192,0', '64', '7'), ('3,4,448,3', '127', '8'), ('100000,2,384,3', '96', '4')])
+def test_byte_table_kernel_epochs_and_rebuilds(ops, oracle, tune, monkeypatch):
+    """The byte-table kernel's epoch schedule, ring limit, table resolution and rebuild rule are tunable through the
+    environment (ANNLITE_Q8_TUNE / _TARGET / _REBUILD: DESIGN 3.1).  Whatever they are the result is the oracle's, bit for
+    bit -- including a schedule that ends an epoch every other step and rebuilds the tables as soon as a bound moves
+    (the default schedule is sparse: small tables never reach its first epoch end), and one without any epoch."""
+    from annlite_amd import Metric, PQCodec, _capi
+
+    rs = np.random.RandomState(21)
+    N, D, M, B, k = 200_000, 128, 16, 96, 10
+    A = rs.randn(16, D).astype(np.float32)
+    x = (rs.randn(N, 16).astype(np.float32) @ A + 0.05 * rs.randn(N, D).astype(np.float32)).astype(np.float32)
+    q = (rs.randn(B, 16).astype(np.float32) @ A + 0.05 * rs.randn(B, D).astype(np.float32)).astype(np.float32)
+    codec = PQCodec(dim=D, n_subvectors=M, n_clusters=256, metric=Metric.EUCLIDEAN, n_init=1)
+    codec.seed = 4
+    codec.fit(x[:8192], iter=5)
+    codes = oracle.encode_c(x, codec.codebooks)
+    lut = oracle.get_dist_mat_c(q, codec.codebooks, oracle.EUCLIDEAN)
+    rd, ri = oracle.adc_search_c(lut, codes, k)
+    monkeypatch.setenv('ANNLITE_Q8_TUNE', tune[0])
+    monkeypatch.setenv('ANNLITE_Q8_TARGET', tune[1])
+    monkeypatch.setenv('ANNLITE_Q8_REBUILD', tune[2])
+    monkeypatch.setenv('ANNLITE_DEBUG_COUNTERS', '1')
+    monkeypatch.setenv('ANNLITE_SEED_ROWS', '4096')  # (a loose first bound: the tables have something to follow)
+    assert _capi.scan_plan(N, M, 256, 1, B, k).qt == 32
+    for layout in (0, 1):
+        d, i, _ = _scan(ops, codes, lut, k, layout)
+        assert np.array_equal(d, rd) and np.array_equal(i, ri)
+        if tune[0].startswith('1,2'):
+            assert _capi.debug_counters()[5] > 0  # tables were rebuilt
+
+
 def test_full_size_properties_config2(ops, oracle):
     """BASELINE config 2 at full size (1M x 128-d, PQ m=16, batch 1024, k=10) through size-independent
     properties: ascending order, every returned distance equals the gathered ADC distance of that row
