@@ -55,7 +55,8 @@ def parse():
     p.add_argument('--metric', choices=['euclidean', 'cosine', 'inner_product'], default='euclidean',
                    help="BASELINE config 2/3: euclidean; config 4 (10M x 768, m=64, batch 256): cosine")
     p.add_argument('--streams', type=int, choices=[0, 1, 2], default=0,
-                   help='streams the timed batches alternate on (0 = auto: 2 when the exchange runs, else 1)')
+                   help='streams the timed batches alternate on (0 = auto: 2 -- the next batch\'s table build and seed fill the CUs the '
+                        'previous scan\'s tail leaves idle, and the exchange of a multi-GPU batch overlaps the next scan)')
     p.add_argument('--layout', choices=['skewed', 'plain'], default='skewed')
     p.add_argument('--no-rerank', action='store_true', help='skip the (untimed-in-value) exact re-rank leg')
     p.add_argument('--ivf-cells', type=int, default=256,
@@ -147,7 +148,7 @@ def main():
     def step():
         return sharded.search_batch(queries, limit=k)
 
-    n_streams = args.streams or (2 if (world > 1 or os.environ.get('ANNLITE_FORCE_GATHER')) else 1)
+    n_streams = args.streams or 2
     streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)] if n_streams == 2 else [torch.cuda.current_stream(dev)]
     for st in streams:
         st.wait_stream(torch.cuda.current_stream(dev))
@@ -412,6 +413,8 @@ def main():
                 # what torch.distributed itself reports (one process per GPU over RCCL); 1 / None without a process group
                 'n_ranks': dist.get_world_size() if use_dist else 1,
                 'backend': (dist.get_backend() + ' (RCCL)') if use_dist else None,
+                # independent batches alternate between this many HIP streams (each batch's kernels in order on its own)
+                'streams': n_streams,
             },
             'recall_at_10': recall_adc,
             # `value` is the reference's own search semantics (plain ADC top-k, the parity quantity); the north-star's
