@@ -206,6 +206,10 @@ __device__ __forceinline__ void skew64_decode(uint32_t (&c)[16], int r) {
 }
 
 
+// gk2: kGk2Keys u64 per (query, row slice).  The u16 kernels store one key there, the slice's j-th (j = ceil(k / G), G = the
+// slices scanned concurrently); the byte-table kernel stores its j smallest keys (j <= kGk2Keys) -- see import_bounds.
+constexpr int kGk2Keys = 4;
+
 // ---- launchers of the scan kernels, one translation unit per kernel family -----------------------
 // (scan_q8.hip: byte filter tables; scan_qfilter.hip: u16 filter tables, tile mode; scan_prep.hip: table build /
 // quantisation parameters / seed bound)

@@ -186,8 +186,18 @@ __device__ __forceinline__ void q8_publish_global(const FlushCtx &c, int lane, u
     if (lane < 32) {
         const int b = c.b0 + lane;
         if (pend_o != ~0ull && c.gkey) __hip_atomic_fetch_min(c.gkey + b, pend_o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (pend_j != ~0ull && c.gk2)
-            __hip_atomic_store(c.gk2 + (int64_t)b * c.n_slices + c.slice, pend_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pend_j != ~0ull && c.gk2) {
+            unsigned long long *cell = c.gk2 + ((int64_t)b * c.n_slices + c.slice) * kGk2Keys;
+            if (c.jm1 < 2) {
+                // this slice's j smallest keys as they are NOW (keys only fall; a reader may see a mix of two versions:
+                // each key belongs to a row of this slice, and it drops a duplicate)
+                const volatile unsigned long long *lst = (const volatile unsigned long long *)(g_smem + c.list_off) + lane * 16;
+                __hip_atomic_store(cell, lst[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c.jm1 == 1) __hip_atomic_store(cell + 1, lst[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __hip_atomic_store(cell, pend_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the j-th key alone
+            }
+        }
     }
     pend_o = ~0ull;
     pend_j = ~0ull;
@@ -496,14 +506,53 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             // slices x j rows >= k rows at or below it; +1: that row itself must still be accepted)
             auto import_bounds = [&]() {
                 if (!a.gkey) return;
-                // lane = (slot, half): its slot's published k-th key and the j-th keys of four slices, all loads in flight
-                // together -- one global round trip per group of 8 slices for the whole tile
+                // lane = (slot, half): all loads in flight together -- one global round trip per group of 8 slices for the
+                // whole tile
                 const int q = lane & 31, part = lane >> 5;
                 const int b = tile * QT + q;
                 const bool real = b < a.B;
                 unsigned long long bound = ~0ull;
                 if (real) bound = __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (a.gk2) {
+                if (a.gk2 && a.jm1 < 2) {
+                    // The G <= 8 concurrently scanned slices publish their j = ceil(k / G) <= 2 smallest keys: G j >= k keys
+                    // of distinct rows, so the k-th smallest of them has k rows at or below it (+1: that row itself must
+                    // still be accepted).  (The MAX of the slices' j-th keys, what the u16 kernels use, is the LARGEST of
+                    // these keys: with 8 slices and k = 10 it sits near global rank 36, the 10th smallest of the 16 near
+                    // rank 13 -- the candidates that pass the imported bound are in proportion.)
+#pragma unroll 1
+                    for (int g0 = 0; g0 < a.n_slices; g0 += 8) {
+                        unsigned long long k0[8], k1[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            k0[i] = ~0ull;
+                            k1[i] = ~0ull;
+                            if (real && g0 + i < a.n_slices) {
+                                const unsigned long long *cell = a.gk2 + ((int64_t)b * a.n_slices + g0 + i) * kGk2Keys;
+                                k0[i] = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (a.jm1 == 1) k1[i] = __hip_atomic_load(cell + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            if (k1[i] == k0[i]) k1[i] = ~0ull;  // (two versions of the slice's list mixed: the same row twice)
+                        // half 0 ranks the first keys, half 1 the second ones, each against all 16 (keys of distinct rows
+                        // are distinct); the one of rank k - 1 is the bound
+                        unsigned long long found = ~0ull;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const unsigned long long me = part ? k1[i] : k0[i];
+                            int rank = 0;
+#pragma unroll
+                            for (int jj = 0; jj < 8; ++jj) rank += (k0[jj] < me) + (k1[jj] < me);
+                            if (rank == km1 && me != ~0ull) found = me;
+                        }
+                        const unsigned long long o = __shfl_xor(found, 32);
+                        found = o < found ? o : found;
+                        if (found != ~0ull && found + 1ull < bound) bound = found + 1ull;
+                    }
+                } else if (a.gk2) {
+                    // j > 2 (fewer than 8 slices): the MAX of the slices' j-th keys (G disjoint slices x j rows >= k rows at
+                    // or below it; +1 as above)
 #pragma unroll 1
                     for (int g0 = 0; g0 < a.n_slices; g0 += 8) {
                         unsigned long long v[4];
@@ -512,7 +561,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                             const int sl = g0 + part * 4 + i;
                             v[i] = 0ull;  // slices beyond n_slices never set the max
                             if (real && sl < a.n_slices)
-                                v[i] = __hip_atomic_load(a.gk2 + (int64_t)b * a.n_slices + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                v[i] = __hip_atomic_load(a.gk2 + ((int64_t)b * a.n_slices + sl) * kGk2Keys, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
                         }
                         unsigned long long m = v[0] > v[1] ? v[0] : v[1];
                         const unsigned long long m2 = v[2] > v[3] ? v[2] : v[3];
