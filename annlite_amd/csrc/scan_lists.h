@@ -41,6 +41,62 @@ __device__ __forceinline__ unsigned char qbound8_from_key(unsigned long long key
     return (unsigned char)(0x80u | (uint32_t)qd);
 }
 
+// The bound the concurrently scanned sibling slices of a query have proven, from what they published in gk2 (cells of
+// kGk2Keys keys per (query, slice)).  8 lanes per query, lane & 7 = slice within the group of 8; every lane returns the
+// group's bound (~0: none).  With j = ceil(k / G) <= kGk2Keys a slice publishes its j smallest keys: G j >= k keys of distinct
+// rows, so the k-th smallest of them has k rows at or below it.  (The MAX of the slices' j-th keys -- the fallback for
+// larger j -- is the LARGEST of these keys: with 8 slices and k = 10 near global rank 36, the 10th smallest near rank 13;
+// the candidates that pass the imported bound are in proportion.)
+__device__ __forceinline__ unsigned long long sibling_bound(const unsigned long long *gk2, int64_t b, int n_slices, int g0,
+                                                           int jm1, int km1, int lane) {
+    const int sl = g0 + (lane & 7);
+    const unsigned long long *cell = gk2 + (b * n_slices + sl) * kGk2Keys;
+    if (jm1 < kGk2Keys) {
+        unsigned long long kk[kGk2Keys];
+#pragma unroll
+        for (int i = 0; i < kGk2Keys; ++i) {
+            kk[i] = ~0ull;
+            if (sl < n_slices && i <= jm1) kk[i] = __hip_atomic_load(cell + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // (a reader may see two versions of a slice's list mixed: the same row twice -- keys of distinct rows are distinct)
+#pragma unroll
+        for (int i = 1; i < kGk2Keys; ++i)
+#pragma unroll
+            for (int j = 0; j < i; ++j)
+                if (kk[i] == kk[j]) kk[i] = ~0ull;
+        int rk[kGk2Keys];
+#pragma unroll
+        for (int i = 0; i < kGk2Keys; ++i) rk[i] = 0;
+#pragma unroll 1
+        for (int o = 0; o < 8; ++o) {
+#pragma unroll
+            for (int t = 0; t < kGk2Keys; ++t) {
+                const unsigned long long other = __shfl(kk[t], (lane & ~7) + o);
+#pragma unroll
+                for (int i = 0; i < kGk2Keys; ++i) rk[i] += other < kk[i];
+            }
+        }
+        unsigned long long found = ~0ull;
+#pragma unroll
+        for (int i = 0; i < kGk2Keys; ++i)
+            if (rk[i] == km1 && kk[i] != ~0ull) found = kk[i];
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            const unsigned long long p = __shfl_xor(found, o);
+            found = p < found ? p : found;
+        }
+        return found;
+    }
+    unsigned long long v = 0ull;  // slots beyond n_slices never set the max
+    if (sl < n_slices) v = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const unsigned long long p = __shfl_xor(v, o);
+        v = p > v ? p : v;
+    }
+    return v;
+}
+
 // exact ascending-m fp32 sum of table row `rid` for query slot q (the reference's order, space_pq.h:32-35): re-reads
 // the row's code bytes and gathers its M entries from the fp32 TILED table in global memory
 template <int M, bool SKEWED>
@@ -140,10 +196,17 @@ __device__ __forceinline__ void offer_to_list(const FlushCtx &c, int q0, unsigne
             const uint32_t jlo = __builtin_amdgcn_readlane(L.lo, c.jm1);
             const unsigned long long jkey = ((unsigned long long)jhi << 32) | jlo;
             volatile unsigned long long *gjl = (volatile unsigned long long *)(g_smem + c.gjl_off + q0 * 8);
-            if (lane == 0 && jhi != kKeyInfHi && jkey < *gjl) {
-                *gjl = jkey;
-                __hip_atomic_store(c.gk2 + (int64_t)b * c.n_slices + c.slice, jkey, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            if (jhi != kKeyInfHi && jkey < *gjl) {  // (wave-uniform)
+                unsigned long long *cell = c.gk2 + ((int64_t)b * c.n_slices + c.slice) * kGk2Keys;
+                if (c.jm1 < kGk2Keys) {  // the j smallest keys (sibling_bound)
+                    if (lane <= c.jm1)
+                        __hip_atomic_store(cell + lane, ((unsigned long long)L.hi << 32) | L.lo, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                } else if (lane == 0) {
+                    __hip_atomic_store(cell, jkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("" ::: "memory");
+                if (lane == 0) *gjl = jkey;
             }
         }
     }

@@ -575,9 +575,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                 flushed = true;
             }
             // Import what the other workgroups of these queries (the other row slices) have proven: the best
-            // k-th key any of them published and, per group of 8 concurrently scanned slices, the MAX of
-            // their j-th keys (8 disjoint slices x j rows >= k rows at or below it; +1: that row itself must
-            // still be accepted).  Bounds move on a log scale, so: steps 0, 1, 3, 7, ... then every 64th.
+            // k-th key any of them published and, per group of 8 concurrently scanned slices, the k-th smallest
+            // of their j smallest keys (sibling_bound; +1: that row itself must still be accepted).  Bounds
+            // move on a log scale, so: steps 0, 1, 3, 7, ... then every 64th.
             if (!TILES && a.gkey) {  // (tile mode: one slice per tile, nothing to import)
                 const bool pow2 = ((step_no + 1) & step_no) == 0;
                 if (pow2 || (step_no & 63) == 63) {
@@ -592,15 +592,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                             if (a.gk2) {
 #pragma unroll 1
                                 for (int g0 = 0; g0 < a.n_slices; g0 += 8) {
-                                    unsigned long long v = 0ull;  // slots beyond n_slices never set the max
-                                    if (g0 + (lane & 7) < a.n_slices)
-                                        v = __hip_atomic_load(a.gk2 + (int64_t)b * a.n_slices + g0 + (lane & 7),
-                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                                    for (int o = 1; o < 8; o <<= 1) {
-                                        const unsigned long long p = __shfl_xor(v, o);
-                                        v = p > v ? p : v;
-                                    }
+                                    const unsigned long long v = sibling_bound(a.gk2, b, a.n_slices, g0, a.jm1, km1, lane);
                                     if (v != ~0ull && v + 1ull < bound) bound = v + 1ull;
                                 }
                             }
@@ -1017,15 +1009,7 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
                             if (a.gk2) {
 #pragma unroll 1
                                 for (int g0 = 0; g0 < a.n_slices; g0 += 8) {
-                                    unsigned long long v = 0ull;
-                                    if (g0 + (lane & 7) < a.n_slices)
-                                        v = __hip_atomic_load(a.gk2 + (int64_t)b * a.n_slices + g0 + (lane & 7),
-                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                                    for (int o = 1; o < 8; o <<= 1) {
-                                        const unsigned long long p = __shfl_xor(v, o);
-                                        v = p > v ? p : v;
-                                    }
+                                    const unsigned long long v = sibling_bound(a.gk2, b, a.n_slices, g0, a.jm1, km1, lane);
                                     if (v != ~0ull && v + 1ull < bound) bound = v + 1ull;
                                 }
                             }
