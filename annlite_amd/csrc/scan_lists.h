@@ -198,7 +198,7 @@ __device__ __forceinline__ void offer_to_list(const FlushCtx &c, int q0, unsigne
             volatile unsigned long long *gjl = (volatile unsigned long long *)(g_smem + c.gjl_off + q0 * 8);
             if (jhi != kKeyInfHi && jkey < *gjl) {  // (wave-uniform)
                 unsigned long long *cell = c.gk2 + ((int64_t)b * c.n_slices + c.slice) * kGk2Keys;
-                if (c.jm1 < kGk2Keys) {  // the j smallest keys (sibling_bound)
+                if (M != 64 && c.jm1 < kGk2Keys) {  // the j smallest keys (sibling_bound; M = 64: see its import)
                     if (lane <= c.jm1)
                         __hip_atomic_store(cell + lane, ((unsigned long long)L.hi << 32) | L.lo, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
