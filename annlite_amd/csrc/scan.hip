@@ -381,7 +381,7 @@ static int plan_query_impl(int64_t N, int64_t M, int64_t Ks, int code_bytes, int
         const int64_t bpad = pad_queries(B, plan->qt);
         plan->workspace_bytes = (int64_t)n_tiles * plan->qt * ns * k * 8 + 256 + bpad * 4 + 256;
         if (c.qf())
-            plan->workspace_bytes += bpad * 4 + 256 + 2 * (bpad * 8 + 256) + (bpad * ns * 8 * kGk2Keys + 256) + (n_tiles * 4 + 256) +
+            plan->workspace_bytes += bpad * 4 + 256 + 2 * (bpad * 8 + 256) + (bpad * ns * 8 * gk2_cell_keys(M) + 256) + (n_tiles * 4 + 256) +
                                      256 /* item counter */ + bpad * M * Ks * 2 + 256;
     } else {
         plan->fast = 0;
@@ -514,7 +514,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             const size_t bpad = (size_t)pad_queries(B, plan.qt);
             auto r256 = [](size_t x) { return (x + 255) / 256 * 256; };
             fill = r256((size_t)a.n_tiles * plan.qt * plan.n_slices * k * 8) + r256(bpad * 8) +
-                   r256(bpad * plan.n_slices * 8 * kGk2Keys) + r256((size_t)a.n_tiles * 4) + 256 /* item counter */;
+                   r256(bpad * plan.n_slices * 8 * gk2_cell_keys(M)) + r256((size_t)a.n_tiles * 4) + 256 /* item counter */;
         }
         fill_bytes = fill;
         FastCfg c1;
@@ -576,7 +576,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             auto carve = [&](int64_t bytes) { char *r = wp; wp += ((bytes + 255) / 256) * 256; return r; };
             // [gkey][gk2][tile_done] directly behind the partial lists: the one fill covers exactly these four
             unsigned long long *gk = (unsigned long long *)carve(bpad * 8);
-            unsigned long long *gk2 = (unsigned long long *)carve(bpad * plan.n_slices * 8 * kGk2Keys);
+            unsigned long long *gk2 = (unsigned long long *)carve(bpad * plan.n_slices * 8 * gk2_cell_keys(M));
             unsigned int *tile_done = (unsigned int *)carve((int64_t)a.n_tiles * 4);
             unsigned int *item_counter = (unsigned int *)carve(4);
             if (tm) {

@@ -208,7 +208,13 @@ __device__ __forceinline__ void skew64_decode(uint32_t (&c)[16], int r) {
 
 // gk2: kGk2Keys u64 per (query, row slice).  The u16 kernels store one key there, the slice's j-th (j = ceil(k / G), G = the
 // slices scanned concurrently); the byte-table kernel stores its j smallest keys (j <= kGk2Keys) -- see import_bounds.
-constexpr int kGk2Keys = 4;
+#ifndef ANNLITE_GK2_KEYS
+#define ANNLITE_GK2_KEYS 4
+#endif
+constexpr int kGk2Keys = ANNLITE_GK2_KEYS;
+// (M = 64 keeps one key per cell: its kernel does not use the union rule, and the 4x larger array in front of its tables
+// measured 5 % on the config-4 shape -- 0.95 against 0.90 ms per launch)
+__host__ __device__ constexpr int gk2_cell_keys(int64_t M) { return M == 64 ? 1 : kGk2Keys; }
 
 // ---- launchers of the scan kernels, one translation unit per kernel family -----------------------
 // (scan_q8.hip: byte filter tables; scan_qfilter.hip: u16 filter tables, tile mode; scan_prep.hip: table build /

@@ -47,11 +47,12 @@ __device__ __forceinline__ unsigned char qbound8_from_key(unsigned long long key
 // rows, so the k-th smallest of them has k rows at or below it.  (The MAX of the slices' j-th keys -- the fallback for
 // larger j -- is the LARGEST of these keys: with 8 slices and k = 10 near global rank 36, the 10th smallest near rank 13;
 // the candidates that pass the imported bound are in proportion.)
+template <int CELL>  // keys per cell (gk2_cell_keys(M))
 __device__ __forceinline__ unsigned long long sibling_bound(const unsigned long long *gk2, int64_t b, int n_slices, int g0,
                                                            int jm1, int km1, int lane) {
     const int sl = g0 + (lane & 7);
-    const unsigned long long *cell = gk2 + (b * n_slices + sl) * kGk2Keys;
-    if (jm1 < kGk2Keys) {
+    const unsigned long long *cell = gk2 + (b * n_slices + sl) * CELL;
+    if (CELL == kGk2Keys && jm1 < kGk2Keys) {
         unsigned long long kk[kGk2Keys];
 #pragma unroll
         for (int i = 0; i < kGk2Keys; ++i) {
@@ -197,8 +198,8 @@ __device__ __forceinline__ void offer_to_list(const FlushCtx &c, int q0, unsigne
             const unsigned long long jkey = ((unsigned long long)jhi << 32) | jlo;
             volatile unsigned long long *gjl = (volatile unsigned long long *)(g_smem + c.gjl_off + q0 * 8);
             if (jhi != kKeyInfHi && jkey < *gjl) {  // (wave-uniform)
-                unsigned long long *cell = c.gk2 + ((int64_t)b * c.n_slices + c.slice) * kGk2Keys;
-                if (M != 64 && c.jm1 < kGk2Keys) {  // the j smallest keys (sibling_bound; M = 64: see its import)
+                unsigned long long *cell = c.gk2 + ((int64_t)b * c.n_slices + c.slice) * gk2_cell_keys(M);
+                if (gk2_cell_keys(M) == kGk2Keys && c.jm1 < kGk2Keys) {  // the j smallest keys (sibling_bound; M = 64: see its import)
                     if (lane <= c.jm1)
                         __hip_atomic_store(cell + lane, ((unsigned long long)L.hi << 32) | L.lo, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);

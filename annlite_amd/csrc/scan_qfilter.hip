@@ -592,7 +592,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                             if (a.gk2) {
 #pragma unroll 1
                                 for (int g0 = 0; g0 < a.n_slices; g0 += 8) {
-                                    const unsigned long long v = sibling_bound(a.gk2, b, a.n_slices, g0, a.jm1, km1, lane);
+                                    const unsigned long long v = sibling_bound<gk2_cell_keys(M)>(a.gk2, b, a.n_slices, g0, a.jm1, km1, lane);
                                     if (v != ~0ull && v + 1ull < bound) bound = v + 1ull;
                                 }
                             }
@@ -1009,9 +1009,8 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_qfilter64_kernel(const ScanA
                             if (a.gk2) {
 #pragma unroll 1
                                 for (int g0 = 0; g0 < a.n_slices; g0 += 8) {
-                                    // (the j-th key alone, the MAX over the slices: with the union rule's 4 keys per lane this kernel ran 3 % slower --
-                                    // candidates are not what limits it)
-                                    const unsigned long long v = sibling_bound(a.gk2, b, a.n_slices, g0, kGk2Keys, km1, lane);
+                                    // (the j-th key alone, the MAX over the slices: candidates are not what limits this kernel)
+                                    const unsigned long long v = sibling_bound<1>(a.gk2, b, a.n_slices, g0, a.jm1, km1, lane);
                                     if (v != ~0ull && v + 1ull < bound) bound = v + 1ull;
                                 }
                             }
