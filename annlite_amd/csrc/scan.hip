@@ -538,7 +538,6 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         a.q8_epoch_mul = 16;
         a.q8_ring_limit = 384;
         a.q8_import_mask = 3;
-        a.q8_min_batch = 1;
         a.q8_target = 96;
         a.q8_rebuild_8ths = 4;
         if (const char *e = getenv("ANNLITE_Q8_REBUILD")) {
@@ -548,14 +547,6 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         if (const char *e = getenv("ANNLITE_Q8_TARGET")) {
             const int t = atoi(e);
             if (t >= 16 && t <= 127) a.q8_target = t;
-        }
-        a.q8_min_wait = 0;
-        if (const char *e = getenv("ANNLITE_Q8_BATCH")) {  // "min_batch,min_wait" (measurements)
-            int mb = 1, mw = 0;
-            if (sscanf(e, "%d,%d", &mb, &mw) == 2 && mb >= 1 && mb <= 128 && mw >= 0) {
-                a.q8_min_batch = mb;
-                a.q8_min_wait = mw;
-            }
         }
         if (const char *e = getenv("ANNLITE_Q8_TUNE")) {  // "epoch0,mul,ring_limit,import_mask" (measurements)
             int e0 = 15, mul = 16, rl = 384, im = 3;

@@ -59,7 +59,6 @@ struct ScanArgs {
     // byte-table kernel (scan_q8.hip): epochs end after steps e0, e0 * mul + (mul - 1), ...; ring_limit = candidates the
     // scanning waves may be ahead of the consumer wave
     int32_t q8_epoch0, q8_epoch_mul, q8_ring_limit, q8_import_mask;
-    int32_t q8_min_batch, q8_min_wait;  // the consumer takes fewer than min_batch candidates only after min_wait idle polls
     int32_t q8_target;                  // T of a slot right after its table is (re)built (<= 127)
     int32_t q8_rebuild_8ths;            // a slot wants a new table when its T has fallen below this many eighths of that
 };

@@ -1,5 +1,4 @@
 cd /root/repo
-timeout 600 bash scripts/gpu_profile.sh m64 --rows 2000000 --m 64 --batch 256 --data lowrank --fused --iters 4 > /dev/null 2>&1
-find gpurun_out -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' ! -name 'summary.txt' -delete
-for f in $(find gpurun_out -name '*counter_collection.csv'); do (head -1 $f; grep annlite $f) > $f.tmp; mv $f.tmp $f; done
-grep -A10 "adc_scan_qfilter64" gpurun_out/prof_m64/summary.txt | head -60
+timeout 1200 python -m pytest tests -q -m gpu -x 2>&1 | tail -2
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 120 python bench.py --rows 10000000 --ivf-cells 0 --cpu-queries 0 --no-rerank --recall-queries 0 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('10M ms_per_step %.4f kernel_ms %.4f frac %.3f' % (r['ms_per_step'], r['roofline']['kernel_ms'], r['roofline']['frac']))"
