@@ -288,7 +288,16 @@ static int scan_variant() {
 
 // tiles: the plan of annlite_pq_search_tiles (IVF cells) -- the u16 kernels' tile mode
 static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *c, bool tiles = false) {
-    if (code_bytes != 1 || Ks > 256 || Ks < 1 || k > 64 || k < 1) return false;
+    if (Ks < 1 || k > 64 || k < 1) return false;
+    if (code_bytes == 2) {
+        // uint16 codes (Ks > 256; the reference's PQ tests run Ks = 512 and 768 at M = 8): the u16-table kernel with 8 queries
+        // per workgroup, as many codes as fit the LDS, PLAIN layout, row slices only
+        if (tiles || getenv("ANNLITE_NO_FAST_CODE16")) return false;  // (the switch: A/B against the generic kernel)
+        if (M == 8 && Ks <= 1024) { *c = {8, 4, 1, 16, 4, 1, 8216, 4}; return true; }
+        if (M == 16 && Ks <= 512) { *c = {16, 4, 1, 16, 4, 1, 16216, 4}; return true; }
+        return false;
+    }
+    if (code_bytes != 1 || Ks > 256) return false;
     const int v = scan_variant();
     switch (M) {
         case 8: *c = {8, 4, 2, 16, 4, 1, 830, 4}; return true;  // u16 tables, 16 queries / WG
@@ -465,8 +474,8 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         ANNLITE_REQUIRE(B % plan.qt == 0 && tm->tile_rows && tm->vmap && tm->cand && tm->cand_count && tm->cand_cap >= 64,
                         "tile mode: B=%lld must be a multiple of the tile size %d", (long long)B, plan.qt);
     }
-    ANNLITE_REQUIRE(codes_layout == ANNLITE_CODES_PLAIN || (codes_layout == ANNLITE_CODES_SKEWED && plan.fast),
-                    "codes_layout %d not supported by this plan (SKEWED needs the fast plan)", codes_layout);
+    ANNLITE_REQUIRE(codes_layout == ANNLITE_CODES_PLAIN || (codes_layout == ANNLITE_CODES_SKEWED && plan.fast && code_bytes == 1),
+                    "codes_layout %d not supported by this plan (SKEWED needs the fast plan and uint8 codes)", codes_layout);
     ANNLITE_REQUIRE(lut_dev && workspace_dev, "null device pointer");
     ANNLITE_REQUIRE(N == 0 || codes_dev, "codes_dev is NULL");
     if (workspace_bytes < (size_t)plan.workspace_bytes) {
@@ -609,7 +618,8 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             rc = launch_lut_quantise(M, Ks, Bq, ((Bq + 15) / 16) * 16, (tm && build) ? nullptr : lut_dev, build, q16, qstep,
                                      qlo, smax, qlom, workspace_dev, fill_bytes, st);
             if (rc != ANNLITE_OK) return rc;
-            if (share_across_slices && N >= 4096 && !tm) {  // (tile mode seeds inside the scan kernel)
+            if (share_across_slices && N >= 4096 && !tm && code_bytes == 1) {  // (tile mode seeds inside the scan kernel; uint16
+                                                                                // codes start unseeded)
                 int64_t S = 8192;
                 // byte-table kernel: its candidate transient shrinks with a tighter first bound faster than the seed launch
                 // grows (12 us per 8192 rows): 1.25M rows x 1024 queries 0.425 / 0.407 / 0.405 / 0.437 ms per batch at
@@ -752,7 +762,7 @@ static int pq_search_impl(int lut_kind, const float *queries_dev, int64_t B, int
     ANNLITE_REQUIRE(!tm || B <= Bs, "tile mode: more queries (%lld) than slots (%lld)", (long long)B, (long long)Bs);
     float *lut = (float *)((char *)workspace_dev + scan_ws);
     FastCfg c;
-    const bool fuse = N > 0 && plan.fast && fast_cfg(M, Ks, code_bytes, k, &c, tm != nullptr) && c.qf() && M != 64 &&
+    const bool fuse = N > 0 && plan.fast && fast_cfg(M, Ks, code_bytes, k, &c, tm != nullptr) && c.qf() && M != 64 && Ks <= 256 &&
                       lut_kind == ANNLITE_LUT_L2 && ((D / M) % 4) == 0 && !getenv("ANNLITE_NO_FUSED_LUT");
     if (!fuse) {
         rc = annlite_lut_build(lut_kind, queries_dev, B, D, codebooks_dev, M, Ks, lut,

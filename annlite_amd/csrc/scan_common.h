@@ -104,6 +104,11 @@ __device__ __forceinline__ void byte_shl4(uint32_t dword, uint32_t sh, uint32_t 
         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
         : "s"(sh), "v"(dword));
 }
+// both half-words of a dword, each << sh (SDWA word select): the address part of two uint16 codes
+__device__ __forceinline__ void word_shl2(uint32_t x, uint32_t sh, uint32_t &o0, uint32_t &o1) {
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(o0) : "s"(sh), "v"(x));
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(o1) : "s"(sh), "v"(x));
+}
 constexpr int ilog2_c(int x) { return x <= 1 ? 0 : 1 + ilog2_c(x / 2); }
 
 // ---- compile-time loops -------------------------------------------------------------------------

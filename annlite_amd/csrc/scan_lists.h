@@ -100,11 +100,13 @@ __device__ __forceinline__ unsigned long long sibling_bound(const unsigned long 
 
 // exact ascending-m fp32 sum of table row `rid` for query slot q (the reference's order, space_pq.h:32-35): re-reads
 // the row's code bytes and gathers its M entries from the fp32 TILED table in global memory
-template <int M, bool SKEWED>
+// CODE16: uint16 codes (Ks > 256), PLAIN layout only
+template <int M, bool SKEWED, bool CODE16 = false>
 __device__ __forceinline__ float exact_row_sum(const FlushCtx &c, int q, uint32_t rid) {
-    constexpr int CW = M / 4;
+    static_assert(!(CODE16 && SKEWED), "uint16 code tables are PLAIN");
+    constexpr int CW = CODE16 ? M / 2 : M / 4;
     uint32_t cp[CW];
-    const uint32_t *p = (const uint32_t *)(c.codes + (int64_t)rid * M);
+    const uint32_t *p = (const uint32_t *)(c.codes + (int64_t)rid * M * (CODE16 ? 2 : 1));
 #pragma unroll
     for (int i = 0; i < CW; ++i) cp[i] = p[i];
     if constexpr (SKEWED && M == 64) {
@@ -122,7 +124,7 @@ __device__ __forceinline__ float exact_row_sum(const FlushCtx &c, int q, uint32_
     float vals[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-        const uint32_t code = (cp[m / 4] >> (8 * (m % 4))) & 0xffu;
+        const uint32_t code = CODE16 ? (cp[m / 2] >> (16 * (m % 2))) & 0xffffu : (cp[m / 4] >> (8 * (m % 4))) & 0xffu;
         vals[m] = lq[((int64_t)code * M + m) * 4];
     }
     float ex = 0.f;
@@ -221,7 +223,7 @@ __device__ __forceinline__ void offer_to_list(const FlushCtx &c, int q0, unsigne
 // fp32 table in global memory, then the candidates are offered query by query to the shared lists.
 // Batching matters: one candidate at a time paid the gather latency, the call and the lock ~3.6 us each
 // (46 times per wave at 1.25M rows); a flush pays them once for everything queued since the last one.
-template <int M, bool SKEWED>
+template <int M, bool SKEWED, bool CODE16 = false>
 __device__ __forceinline__ void qfilter_flush_inline(const FlushCtx &c, uint32_t queue_off, int qcnt) {
     const int lane = threadIdx.x & 63;
     const bool act = lane < qcnt;
@@ -229,7 +231,7 @@ __device__ __forceinline__ void qfilter_flush_inline(const FlushCtx &c, uint32_t
     const uint32_t rid = (uint32_t)e;
     const int q = (int)(e >> 32);
     float ex = 0.f;
-    if (act && !(c.skip & 1)) ex = exact_row_sum<M, SKEWED>(c, q, rid);
+    if (act && !(c.skip & 1)) ex = exact_row_sum<M, SKEWED, CODE16>(c, q, rid);
     const uint32_t khi = f32_to_ordered(ex);
     unsigned long long rem = __ballot(act);
     while (rem) {
@@ -241,9 +243,9 @@ __device__ __forceinline__ void qfilter_flush_inline(const FlushCtx &c, uint32_t
 }
 
 // out of line, one copy per kernel: the u16 kernels call it from three places of their step loop
-template <int M, bool SKEWED>
+template <int M, bool SKEWED, bool CODE16 = false>
 __device__ __attribute__((noinline)) void qfilter_flush(const FlushCtx c, uint32_t queue_off, int qcnt) {
-    qfilter_flush_inline<M, SKEWED>(c, queue_off, qcnt);
+    qfilter_flush_inline<M, SKEWED, CODE16>(c, queue_off, qcnt);
 }
 
 // Final merge of a tile by the last workgroup to arrive.  The NW waves are dealt out over the tile's REAL

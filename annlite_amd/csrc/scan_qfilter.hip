@@ -158,11 +158,14 @@ struct TileState {
 // LDS: [Q tile Ks*KSTRIDE][shq16 u16 x QT (0x8000|qthr) @ +0][locks u32 x QT @ +64][gkl u64 x QT @ +128]
 //      [lists u64 x QT x 64 @ +256]
 // =================================================================================================
-template <int M, int NQ, int NW, int WPS, bool SKEWED, bool TILES>
+// CODE16: uint16 codes (Ks up to 1024 at M = 8, 512 at M = 16: what fits the LDS with 8 queries per workgroup), PLAIN layout,
+// row slices only -- the reference's own PQ tests run Ks = 512 and 768 (tests/test_pq_index.py:80-163)
+template <int M, int NQ, int NW, int WPS, bool SKEWED, bool TILES, bool CODE16 = false>
 __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const ScanArgs a) {
+    static_assert(!CODE16 || (!SKEWED && !TILES), "uint16 code tables: PLAIN layout, row slices");
     constexpr int QG = 8;                 // queries per LDS entry
     constexpr int QT = QG * NQ;           // queries per workgroup
-    constexpr int CW = M / 4;
+    constexpr int CW = CODE16 ? M / 2 : M / 4;  // dwords of a code row
     constexpr int EB = 16;
     constexpr int RB = M * EB;
     constexpr int KSTRIDE = NQ * RB;
@@ -175,11 +178,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int km1 = a.k - 1;
     const int s = lane % M;
-    // forward rotation (PLAIN tables) and its inverse (to read a row's bytes in true sub-space order)
-    const uint32_t bsh = (uint32_t)(s & 3);
+    // forward rotation (PLAIN tables) by s codes = sb bytes
+    const int sb = CODE16 ? 2 * s : s;
+    const uint32_t bsh = (uint32_t)(sb & 3);
     bool abit[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) abit[i] = (((s >> 2) >> i) & 1) != 0;
+    for (int i = 0; i < 8; ++i) abit[i] = (((sb >> 2) >> i) & 1) != 0;
     const unsigned char *mbase[M];
 #pragma unroll
     for (int t = 0; t < M; ++t) mbase[t] = smem + ((s + t) % M) * EB;
@@ -327,12 +331,19 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
         auto make_addr = [&](const uint32_t (&cc)[CW]) {
             static_for<0, CW>([&](auto W) {
                 constexpr int w = decltype(W)::value;
-                uint32_t o0, o1, o2, o3;
-                byte_shl4(cc[w], (uint32_t)ilog2_c(KSTRIDE), o0, o1, o2, o3);
-                addr[4 * w + 0] = mbase[4 * w + 0] + o0;
-                addr[4 * w + 1] = mbase[4 * w + 1] + o1;
-                addr[4 * w + 2] = mbase[4 * w + 2] + o2;
-                addr[4 * w + 3] = mbase[4 * w + 3] + o3;
+                if constexpr (CODE16) {
+                    uint32_t o0, o1;
+                    word_shl2(cc[w], (uint32_t)ilog2_c(KSTRIDE), o0, o1);
+                    addr[2 * w + 0] = mbase[2 * w + 0] + o0;
+                    addr[2 * w + 1] = mbase[2 * w + 1] + o1;
+                } else {
+                    uint32_t o0, o1, o2, o3;
+                    byte_shl4(cc[w], (uint32_t)ilog2_c(KSTRIDE), o0, o1, o2, o3);
+                    addr[4 * w + 0] = mbase[4 * w + 0] + o0;
+                    addr[4 * w + 1] = mbase[4 * w + 1] + o1;
+                    addr[4 * w + 2] = mbase[4 * w + 2] + o2;
+                    addr[4 * w + 3] = mbase[4 * w + 3] + o3;
+                }
             });
         };
         // integer sums of one entry group: 4 dwords x (2 x u16)
@@ -551,7 +562,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
                                 if (pm) {
                                     const int n = __popcll(pm);
                                     if (qcnt + n > 64) {
-                                        qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
+                                        qfilter_flush<M, SKEWED, CODE16>(fc, queue_off + wave * 512, qcnt);
                                         qcnt = 0;
                                         flushed = true;
                                     }
@@ -570,7 +581,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
             // dependent global round trips + the list update), so waves flush rarely but staggered -- every few
             // steps SOME wave of the workgroup tightens the shared bound
             if (qcnt && (qcnt >= 32 || ((step_no + wave * 4) & a.flush_mask) == a.flush_mask)) {
-                qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
+                qfilter_flush<M, SKEWED, CODE16>(fc, queue_off + wave * 512, qcnt);
                 qcnt = 0;
                 flushed = true;
             }
@@ -616,7 +627,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const Sc
             b_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_pend);
         }
 
-        if (qcnt) qfilter_flush<M, SKEWED>(fc, queue_off + wave * 512, qcnt);
+        if (qcnt) qfilter_flush<M, SKEWED, CODE16>(fc, queue_off + wave * 512, qcnt);
 
         // ---- the shared lists ARE the workgroup's result for this (tile, slice) ----------------------
         __syncthreads();
@@ -1076,6 +1087,16 @@ static int launch_qfilter(const ScanArgs &a, int grid, hipStream_t st) {
     return launch_status("adc_scan_qfilter_kernel");
 }
 
+template <int M, int NQ, int NW, int WPS>
+static int launch_qfilter_code16(const ScanArgs &a, int grid, hipStream_t st) {
+    const size_t lds_lut = (size_t)a.Ks * NQ * M * 16;
+    const size_t need = lds_lut + 256 + (size_t)8 * NQ * 64 * 8 + 128 + (size_t)NW * 512;
+    auto fn = adc_scan_qfilter_kernel<M, NQ, NW, WPS, false, false, true>;
+    ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
+    return launch_status("adc_scan_qfilter_kernel (uint16 codes)");
+}
+
 template <int NW, bool SKEWED>
 static int launch_qfilter64(const ScanArgs &a, int grid, hipStream_t st) {
     const size_t need = (size_t)(a.Ks + 1) * 512 + 256 + (size_t)4 * 512 + 128 + (size_t)NW * 512 +
@@ -1095,6 +1116,8 @@ int annlite::launch_qfilter_scan(int id, bool sk, const ScanArgs &a, int grid, h
         case 1630: return ANNLITE_LAUNCH_Q(16, 2, 12, 3);
         case 1631: return ANNLITE_LAUNCH_Q(16, 2, 16, 4);
         case 1632: return ANNLITE_LAUNCH_Q(16, 2, 8, 2);
+        case 8216: return launch_qfilter_code16<8, 1, 16, 4>(a, grid, st);    // uint16 codes, Ks <= 1024
+        case 16216: return launch_qfilter_code16<16, 1, 16, 4>(a, grid, st);  // uint16 codes, Ks <= 512
         case 6430: return sk ? launch_qfilter64<16, true>(a, grid, st) : launch_qfilter64<16, false>(a, grid, st);
         case 6431: return sk ? launch_qfilter64<12, true>(a, grid, st) : launch_qfilter64<12, false>(a, grid, st);
         case 6432: return sk ? launch_qfilter64<8, true>(a, grid, st) : launch_qfilter64<8, false>(a, grid, st);

@@ -388,12 +388,13 @@ def main():
         # tile and stays in L2): its roof is the LDS look-up rate.  One ds_read_b128 (4 LDS cycles per wave64) serves
         # 64 lanes x 16 byte entries (byte-table kernel) or x 8 u16 entries (u16 kernels); M=64: ds_read_b64, 2 cycles,
         # 64 x 4.  256 CUs at 2.4 GHz (MI355X_MICROARCH.md: 256 B / clk / CU).
-        plan_k = _capi.scan_plan(n_local, M, Ks, 1, B, k)
+        plan_k = _capi.scan_plan(n_local, M, Ks, index.code_bytes, B, k)
         variant = index._kernel[0] if getattr(index, '_kernel', None) else 0
         byte_tables = plan_k.qt == 32 and variant in (0, 50)
         per_clk = 256 if byte_tables else 128
         lds_peak = 256 * per_clk * 2.4e9
-        kernel_name = 'adc_scan_qfilter64_kernel' if M == 64 else ('adc_scan_q8_kernel' if byte_tables else 'adc_scan_qfilter_kernel')
+        kernel_name = ('adc_scan_generic_kernel' if not plan_k.fast else 'adc_scan_qfilter64_kernel' if M == 64 else
+                       'adc_scan_q8_kernel' if byte_tables else 'adc_scan_qfilter_kernel')
         traffic = traffic_table.get(f'{kernel_name}:{n_local}x{M}x{B}', {}).get('hbm_bytes_per_launch')
         roof = {
             'bound': 'lds', 'achieved': lookups_per_s, 'peak': lds_peak, 'unit': 'look-ups/s', 'frac': lookups_per_s / lds_peak,

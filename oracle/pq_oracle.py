@@ -252,6 +252,16 @@ def top_k_numpy(values, k, id_base=0):
 # ------------------------------------------------------------------------------------------------
 def adc_search_c(lut, codes, k, id_base=0, threads=1):
     lut = _f32c(lut)
+    codes = np.ascontiguousarray(codes)
+    if codes.dtype.itemsize != 1:  # uint16 / uint32 codes (n_clusters > 256, pq.py:56-60): per query, the same two kernels
+        if codes.dtype.kind != 'u':
+            codes = codes.view({2: np.uint16, 4: np.uint32}[codes.dtype.itemsize])
+        ds, is_ = [], []
+        for b in range(lut.shape[0]):
+            d, i = top_k_c(dist_pqcodes_to_codebooks_c(lut[b], codes, threads=threads), k, id_base)
+            ds.append(d)
+            is_.append(i)
+        return np.stack(ds), np.stack(is_)
     codes = np.ascontiguousarray(codes, dtype=np.uint8)
     B, M, Ks = lut.shape
     N = codes.shape[0]

@@ -231,15 +231,26 @@ def test_scan_ties_and_valid_bits(ops, oracle, M):
     assert (np.sort(i[:, :3], axis=1) == np.array([5, 77, 4000])).all()
 
 
-def test_scan_uint16_generic(ops, oracle):
+@pytest.mark.parametrize('shape', [(8, 768, 3000, 7, 10, True), (8, 512, 120_000, 37, 50, True), (16, 512, 90_000, 20, 10, True),
+                                   (8, 1024, 50_000, 9, 10, True), (16, 768, 4000, 5, 10, False), (4, 512, 4000, 5, 10, False)])
+def test_scan_uint16_codes(ops, oracle, shape):
+    """uint16 codes (n_clusters > 256; the reference's own PQ tests run 512 and 768 at n_subvectors = 8,
+    tests/test_pq_index.py:80-163): M = 8 up to Ks = 1024 and M = 16 up to Ks = 512 run the u16-table kernel with the tables
+    in LDS (adc_scan_qfilter_kernel<.., CODE16>), what does not fit runs the generic kernel; all bit-exact."""
+    M, Ks, N, B, k, fast = shape
     rs = np.random.RandomState(5)
-    M, Ks, N, B, k = 8, 768, 3000, 7, 10
     lut = rs.rand(B, M, Ks).astype(np.float32)
     codes = rs.randint(0, Ks, size=(N, M)).astype(np.uint16)
-    d, i, plan = _scan(ops, codes, lut, k)
-    assert not plan.fast
-    rd, ri = oracle.adc_search_numpy(lut, codes, k)
-    assert np.array_equal(d, rd) and np.array_equal(i, ri)
+    codes[100:164] = codes[100]  # a wave-step of exact ties
+    valid = np.ones(N, dtype=bool)
+    valid[[3, 100, 101, N - 1]] = False
+    d, i, plan = _scan(ops, codes, lut, k, valid=valid)
+    assert bool(plan.fast) == fast
+    dist = np.stack([oracle.dist_pqcodes_to_codebooks_c(lut[b], codes) for b in range(B)])
+    dist[:, ~valid] = np.inf
+    for b in range(B):
+        rd, ri = oracle.top_k_c(dist[b], k)
+        assert np.array_equal(d[b], rd) and np.array_equal(i[b], ri)
 
 
 def test_candidates_superset_and_gather(ops, oracle):

@@ -170,3 +170,19 @@ def test_c_and_numpy_agree_random(oracle):
     dn, in_ = oracle.adc_search_numpy(lut, codes, 60)
     assert np.array_equal(d, dn) and np.array_equal(i, in_)
     assert np.isinf(d[:, 57:]).all() and (i[:, 57:] == -1).all()
+
+
+def test_adc_search_wide_codes(oracle):
+    """n_clusters > 256 means uint16 codes (pq.py:56-60): the C search helper must not narrow them (it once cast every code
+    table to uint8 -- a checker that was wrong exactly where the reference's own PQ tests run, Ks = 512 / 768)."""
+    import numpy as np
+
+    rs = np.random.RandomState(0)
+    lut = rs.rand(3, 8, 768).astype(np.float32)
+    codes = rs.randint(0, 768, size=(5000, 8)).astype(np.uint16)
+    codes[7] = codes[9]  # a tie
+    d, i = oracle.adc_search_c(lut, codes, 10)
+    d2, i2 = oracle.adc_search_numpy(lut, codes, 10)
+    assert np.array_equal(d, d2) and np.array_equal(i, i2)
+    d3, i3 = oracle.adc_search_c(lut, codes.view(np.int16), 10)  # (torch hands uint16 tables over as int16)
+    assert np.array_equal(d, d3) and np.array_equal(i, i3)
