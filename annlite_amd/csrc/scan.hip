@@ -618,8 +618,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             rc = launch_lut_quantise(M, Ks, Bq, ((Bq + 15) / 16) * 16, (tm && build) ? nullptr : lut_dev, build, q16, qstep,
                                      qlo, smax, qlom, workspace_dev, fill_bytes, st);
             if (rc != ANNLITE_OK) return rc;
-            if (share_across_slices && N >= 4096 && !tm && code_bytes == 1) {  // (tile mode seeds inside the scan kernel; uint16
-                                                                                // codes start unseeded)
+            if (share_across_slices && N >= 4096 && !tm) {  // (tile mode seeds inside the scan kernel)
                 int64_t S = 8192;
                 // byte-table kernel: its candidate transient shrinks with a tighter first bound faster than the seed launch
                 // grows (12 us per 8192 rows): 1.25M rows x 1024 queries 0.425 / 0.407 / 0.405 / 0.437 ms per batch at
@@ -627,7 +626,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 if (c.mode == 5) S = N / 32 < 8192 ? 8192 : N / 32 > 32768 ? 32768 : ((N / 32 + 1023) / 1024) * 1024;
                 if (const char *e = getenv("ANNLITE_SEED_ROWS")) S = atoll(e);
                 if (S > N) S = N;
-                rc = launch_seed_bound(M, codes_layout == ANNLITE_CODES_SKEWED, codes_dev, S, valid_bits_dev, lut_dev, B, Ks, k,
+                rc = launch_seed_bound(M, codes_layout == ANNLITE_CODES_SKEWED, codes_dev, code_bytes, S, valid_bits_dev, lut_dev, B, Ks, k,
                                        smax, gk, st);
                 if (rc != ANNLITE_OK) return rc;
             }

@@ -234,7 +234,7 @@ int launch_q8_scan(int id, bool skewed, const ScanArgs &a, int grid, hipStream_t
 int launch_lut_quantise(int64_t M, int64_t Ks, int64_t B, int64_t bpad, const float *lut_dev, const LutBuild *build,
                         uint16_t *q16, float *qstep, double *qlo, float *smax, float *qlom, void *fill,
                         size_t fill_bytes, hipStream_t st);
-int launch_seed_bound(int64_t M, bool skewed, const void *codes_dev, int64_t S, const uint32_t *valid_bits_dev,
+int launch_seed_bound(int64_t M, bool skewed, const void *codes_dev, int code_bytes, int64_t S, const uint32_t *valid_bits_dev,
                       const float *lut_dev, int64_t B, int64_t Ks, int64_t k, const float *smax, unsigned long long *gkey,
                       hipStream_t st);
 

@@ -103,14 +103,17 @@ __global__ __launch_bounds__(1024) void lut_quantise64_kernel(const float *__res
 // The seed rows are scanned again by the main kernel: only the bound leaves this kernel.
 constexpr int kSeedWaves = 16;
 // QPB queries per workgroup: 4 (one fp32 TILED group) where their rows fit the LDS, 2 for M = 64
-template <int M, bool SKEWED, int QPB>
+// CODE16: uint16 codes (PLAIN tables)
+template <int M, bool SKEWED, int QPB, bool CODE16 = false>
 __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8_t *__restrict__ codes, int64_t S,
                                                                     const uint32_t *__restrict__ valid,
                                                                     const float *__restrict__ lut, int B, int Ks, int k,
                                                                     const float *__restrict__ smax,
                                                                     unsigned long long *__restrict__ gkey) {
-    constexpr int CW = M / 4;
+    static_assert(!(CODE16 && SKEWED), "uint16 code tables are PLAIN");
+    constexpr int CW = CODE16 ? M / 2 : M / 4;
     constexpr int CH = M < 16 ? M : 16;  // look-ups in flight
+    constexpr bool PERM = M == 16 && QPB == 4 && !CODE16;  // one byte permute per look-up address (see below)
     typedef float fq __attribute__((ext_vector_type(QPB)));
     static_assert(QPB == 4 || QPB == 2, "queries per block");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
     __syncthreads();
     // forward skew rotation of PLAIN rows (row % M == lane % M: the rows of a wave start at a multiple of 64); SKEWED
     // rows are stored that way
-    const int sfw = lane % M;
+    const int sfw = (lane % M) * (CODE16 ? 2 : 1);  // bytes
     const uint32_t bsh_fw = (uint32_t)(sfw & 3);
     bool abit_fw[8];
 #pragma unroll
@@ -148,9 +151,9 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
     for (int t = 0; t < M; ++t) {
         if constexpr (M == 64) moff[t] = (uint32_t)(32 * (t / 32) + ((lane & 31) + t) % 32);  // two skewed halves
         else moff[t] = (uint32_t)((lane + t) % M);
-        if constexpr (M == 16 && QPB == 4) moff[t] <<= 4;  // (as a byte offset: the permute addressing below)
+        if constexpr (PERM) moff[t] <<= 4;  // (as a byte offset: the permute addressing below)
     }
-    if constexpr (M == 16 && QPB == 4) {
+    if constexpr (PERM) {
         if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();  // (all LDS is dynamic)
     }
 
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
     // bound by one dependent global round trip per iteration (12.7 us per 8192 rows; the look-ups need ~4)
     auto fetch = [&](int64_t r, uint32_t (&cc)[CW], uint32_t &vw) {
         const int64_t rr = r < S ? r : S - 1;
-        const uint32_t *p = (const uint32_t *)(codes + rr * M);
+        const uint32_t *p = (const uint32_t *)(codes + rr * M * (CODE16 ? 2 : 1));
 #pragma unroll
         for (int i = 0; i < CW; ++i) cc[i] = p[i];
         vw = valid ? valid[rr >> 5] : ~0u;
@@ -203,14 +206,14 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
             fq v[CH];
             static_for<0, CH>([&](auto I) {
                 constexpr int i = decltype(I)::value, t = t0 + i;
-                if constexpr (M == 16 && QPB == 4) {
+                if constexpr (PERM) {
                     // 256-byte table rows: the LDS address (code << 8) | (sub-space << 4) is one byte permute of the code
                     // dword with the step's constant (byte 0 <- moff16 byte 0, byte 1 <- code byte t % 4, rest 0)
                     typedef const fq __attribute__((address_space(3))) *lds_fq_ptr;
                     const uint32_t ad = __builtin_amdgcn_perm(c[t / 4], moff[t], 0x0c0c0000u | ((4u + (uint32_t)(t % 4)) << 8));
                     v[i] = *(lds_fq_ptr)(uintptr_t)ad;
                 } else {
-                    const uint32_t code = (c[t / 4] >> (8 * (t % 4))) & 0xffu;
+                    const uint32_t code = CODE16 ? (c[t / 2] >> (16 * (t % 2))) & 0xffffu : (c[t / 4] >> (8 * (t % 4))) & 0xffu;
                     v[i] = tab[code * M + moff[t]];
                 }
             });
@@ -621,7 +624,7 @@ int annlite::launch_lut_quantise(int64_t M, int64_t Ks, int64_t B, int64_t bpad,
     return launch_status("lut_quantise_fused_kernel");
 }
 
-int annlite::launch_seed_bound(int64_t M, bool skw, const void *codes_dev, int64_t S, const uint32_t *valid_bits_dev,
+int annlite::launch_seed_bound(int64_t M, bool skw, const void *codes_dev, int code_bytes, int64_t S, const uint32_t *valid_bits_dev,
                                const float *lut_dev, int64_t B, int64_t Ks, int64_t k, const float *smax,
                                unsigned long long *gk, hipStream_t st) {
 #define ANNLITE_SEED(MM, QPB_)                                                                                    \
@@ -631,6 +634,19 @@ int annlite::launch_seed_bound(int64_t M, bool skw, const void *codes_dev, int64
         ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(fn, dim3((unsigned)(((B + 3) / 4) * (4 / QPB_))), dim3(kSeedWaves * 64), lds, st,      \
                            (const uint8_t *)codes_dev, S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, smax, gk);   \
+    }
+    if (code_bytes == 2) {  // uint16 codes: PLAIN tables, M = 8 / 16 (what the u16-table scan kernel takes)
+#define ANNLITE_SEED16(MM)                                                                                         \
+    {                                                                                                             \
+        auto fn = seed_bound_kernel<MM, false, 4, true>;                                                          \
+        const size_t lds = (size_t)Ks * MM * 16 + (size_t)2 * kSeedWaves * 64 * 8;                                 \
+        ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(fn, dim3((unsigned)((B + 3) / 4)), dim3(kSeedWaves * 64), lds, st, (const uint8_t *)codes_dev, \
+                           S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, smax, gk);                           \
+    }
+        if (M == 8) ANNLITE_SEED16(8) else ANNLITE_SEED16(16)
+#undef ANNLITE_SEED16
+        return launch_status("seed_bound_kernel (uint16 codes)");
     }
     if (M == 8) ANNLITE_SEED(8, 4) else if (M == 16) ANNLITE_SEED(16, 4) else if (M == 32) ANNLITE_SEED(32, 4)
     else ANNLITE_SEED(64, 2)
