@@ -293,6 +293,7 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
         // uint16 codes (Ks > 256; the reference's PQ tests run Ks = 512 and 768 at M = 8): the u16-table kernel with 8 queries
         // per workgroup, as many codes as fit the LDS, PLAIN layout, row slices only
         if (tiles || getenv("ANNLITE_NO_FAST_CODE16")) return false;  // (the switch: A/B against the generic kernel)
+        if (M == 8 && Ks <= 512) { *c = {8, 4, 2, 16, 4, 1, 8217, 4}; return true; }   // 16 queries per workgroup
         if (M == 8 && Ks <= 1024) { *c = {8, 4, 1, 16, 4, 1, 8216, 4}; return true; }
         if (M == 16 && Ks <= 512) { *c = {16, 4, 1, 16, 4, 1, 16216, 4}; return true; }
         return false;

@@ -1116,6 +1116,7 @@ int annlite::launch_qfilter_scan(int id, bool sk, const ScanArgs &a, int grid, h
         case 1630: return ANNLITE_LAUNCH_Q(16, 2, 12, 3);
         case 1631: return ANNLITE_LAUNCH_Q(16, 2, 16, 4);
         case 1632: return ANNLITE_LAUNCH_Q(16, 2, 8, 2);
+        case 8217: return launch_qfilter_code16<8, 2, 16, 4>(a, grid, st);    // uint16 codes, Ks <= 512, 16 queries / WG
         case 8216: return launch_qfilter_code16<8, 1, 16, 4>(a, grid, st);    // uint16 codes, Ks <= 1024
         case 16216: return launch_qfilter_code16<16, 1, 16, 4>(a, grid, st);  // uint16 codes, Ks <= 512
         case 6430: return sk ? launch_qfilter64<16, true>(a, grid, st) : launch_qfilter64<16, false>(a, grid, st);

@@ -1,6 +1,5 @@
 cd /root/repo
 timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "uint16 or wide" 2>&1 | tail -3
-timeout 300 python bench.py --rows 2000000 --m 8 --ks 768 --steps 20 --warmup 5 --ivf-cells 0 > gpurun_out/bench_code16_m8_ks768_2m_n1.json 2> gpurun_out/err2.txt
 timeout 300 python bench.py --rows 2000000 --m 8 --ks 512 --steps 20 --warmup 5 --ivf-cells 0 > gpurun_out/bench_code16_m8_ks512_2m_n1.json 2> gpurun_out/err1.txt
 python - <<'PY'
 import json,glob

@@ -36,6 +36,8 @@ def test_scan_plan_arithmetic_no_gpu():
     p = _capi.scan_plan(1000, 64, 256, 1, 3, 10)
     assert (p.fast, p.qi, p.qt) == (1, 4, 4) and p.lut_floats == 16 * 64 * 256
     p = _capi.scan_plan(1000, 8, 512, 2, 5, 10)  # uint16 codes that fit the LDS -> u16-table kernel, 8 queries per workgroup
+    assert (p.fast, p.qi, p.qt) == (1, 4, 16)
+    p = _capi.scan_plan(1000, 8, 768, 2, 5, 10)
     assert (p.fast, p.qi, p.qt) == (1, 4, 8)
     p = _capi.scan_plan(1000, 16, 768, 2, 5, 10)  # uint16 codes that do not -> generic kernel
     assert p.fast == 0 and p.qt == 1
