@@ -360,7 +360,7 @@ class PQFlatGpuIndex(BaseIndex):
 
     def _search_rerank(self, q, k, valid, N, rerank_k, scan_in=None):
         B = q.shape[0]
-        rk = int(rerank_k or 64)
+        rk = int(rerank_k or getattr(self, 'rerank_k', None) or 64)
         rk = max(1, min(64, rk))
         plan = scan_plan(N, self.M, self.Ks, self.code_bytes, B, rk)
         from ..._capi import LAYOUT_BMK, LAYOUT_TILED

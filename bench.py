@@ -60,6 +60,7 @@ def parse():
                         'batch\'s table build and seed fill the CUs the previous scan\'s tail leaves idle, -1.4 %% / -4 %% per '
                         'batch at 10M / 1.25M rows)')
     p.add_argument('--layout', choices=['skewed', 'plain'], default='skewed')
+    p.add_argument('--rerank-k', type=int, default=0, help='ADC candidates per row slice of the exact re-rank leg (0 = the index default, 64)')
     p.add_argument('--no-rerank', action='store_true', help='skip the (untimed-in-value) exact re-rank leg')
     p.add_argument('--ivf-cells', type=int, default=256,
                    help='extra leg (N=1, never `value`): pruned search over this many cells; 0 = skip')
@@ -261,6 +262,7 @@ def main():
         recall_adc = float(np.mean([len(set(got[b]) & set(truth[b])) / k for b in range(nq)]))
         if keep_vectors:
             index.rerank = True
+            index.rerank_k = args.rerank_k or None
             for _ in range(2):
                 rr = sharded.search_batch(queries, limit=k)
             torch.cuda.synchronize()
