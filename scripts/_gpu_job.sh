@@ -1,3 +1,7 @@
 cd /root/repo
-(echo "# scripts/ubench/valu_cost.hip (hipcc --offload-arch=gfx950 -O2): cycles per wave64 VALU instruction per SIMD"; timeout 60 ./build_exp/valu_cost) > gpurun_out/ubench_valu_cost.txt 2>&1
-(echo "# scripts/ubench/step_loop.hip (hipcc --offload-arch=gfx950 -O3 -D...): the byte-table kernel's step loop in isolation, 256 workgroups x 16 waves, 2000 steps"; for v in base dyn dyn_noreads dyn_noadds dyn_addr0 dyn_filt2 dyn_d4 dyn_d12; do timeout 30 ./build_exp/sl_$v 2000 256; done) > gpurun_out/ubench_step_loop.txt 2>&1
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x 2>&1 | tail -2
+for it in 1 2; do
+for rows in 1250000 10000000; do
+  timeout 120 python bench.py --rows $rows --ivf-cells 0 --cpu-queries 0 --no-rerank --recall-queries 0 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('rows $rows ms_per_step %.4f kernel_ms %.4f frac %.3f' % (r['ms_per_step'], r['roofline']['kernel_ms'], r['roofline']['frac']))"
+done; done
+ANNLITE_DEBUG_COUNTERS=1 timeout 120 python scripts/prof_scan.py --rows 1250000 --data lowrank --fused --iters 6 2>&1 | grep -i "byte-table"
