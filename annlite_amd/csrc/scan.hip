@@ -627,9 +627,11 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 if (c.mode == 5) S = N / 32 < 8192 ? 8192 : N / 32 > 32768 ? 32768 : ((N / 32 + 1023) / 1024) * 1024;
                 if (const char *e = getenv("ANNLITE_SEED_ROWS")) S = atoll(e);
                 if (S > N) S = N;
-                rc = launch_seed_bound(M, codes_layout == ANNLITE_CODES_SKEWED, codes_dev, code_bytes, S, valid_bits_dev, lut_dev, B, Ks, k,
-                                       smax, gk, st);
-                if (rc != ANNLITE_OK) return rc;
+                if (S > 0) {  // (ANNLITE_SEED_ROWS=0: the scan starts without a bound)
+                    rc = launch_seed_bound(M, codes_layout == ANNLITE_CODES_SKEWED, codes_dev, code_bytes, S, valid_bits_dev, lut_dev,
+                                           B, Ks, k, smax, gk, st);
+                    if (rc != ANNLITE_OK) return rc;
+                }
             }
             a.smax = smax;
             a.qstep = qstep;
