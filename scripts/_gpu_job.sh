@@ -1,3 +1,4 @@
-# scratch: the command of the last gpurun call of a work session (see scripts/gpu_profile*.sh for the kept recipes)
 cd /root/repo
-timeout 1200 python -m pytest tests -q -m gpu -x 2>&1 | tail -2
+timeout 300 bash scripts/gpu_pmc_traffic.sh q8_1p25m --rows 1250000 --data lowrank --fused 2>&1 | tail -8
+find gpurun_out -type f ! -name '*counter_collection.csv' -delete
+for f in $(find gpurun_out -name '*counter_collection.csv'); do (head -1 $f; grep annlite $f) > $f.tmp; mv $f.tmp $f; done
