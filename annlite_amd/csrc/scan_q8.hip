@@ -1,36 +1,36 @@
-// scan_q8.hip -- the ADC scan with BYTE filter tables: 16 queries per 16-byte LDS entry, 32 queries per workgroup.
+// scan_q8.hip -- the ADC scan with BYTE filter tables: 16 queries per 16-byte LDS entry, 32 queries per workgroup
+// (DESIGN.md section 3.1 has the measurements behind every choice below).
 //
 // Same discipline as adc_scan_qfilter_kernel (scan_qfilter.hip): a cheap integer LOWER bound of every (query, row)
 // distance from tables in LDS, the exact ascending-m fp32 sum (the reference's arithmetic, pq_bindings.pyx:30-47 ==
 // space_pq.h:32-35) only for the rows whose bound beats the current k-th distance, shared top-k lists, bounds shared
 // across the row slices -- bit-exact results.  What changes is the table:
-//   * entries are BYTES, Q = min(QMAX, floor((lut - lo[q][m]) / step[q])) with M * QMAX <= 240: one ds_read_b128
-//     serves 16 look-ups per lane and one v_add_u32 adds four of them, so the step loop has the SAME instruction
-//     stream as the u16 kernel (32 ds_read_b128 + ~110 VALU per 64 rows) for twice the queries;
-//   * 3-bit entries are enough because the quantisation follows the THRESHOLD, not the table's range: what decides
-//     the number of rows passing the filter is the resolution relative to R = thr - L (L = sum_m lo): with
-//     step = R / 31 a row at the threshold has an integer sum of ~31 and every entry above 7 steps (R / 4.4) is
-//     clipped -- such a row is far outside anyway.  Measured on the bench's data (2M rows, quantile 1e-6 threshold,
-//     scripts/sim_filter_bits.py): 8.6 rows per query pass with (QMAX 7, T 32) against 2 for the u16 tables and 300
-//     for T = 8;
-//   * the threshold tightens ~4x over a 10M-row scan, so the workgroup builds its table ITSELF from the fp32 TILED
-//     table (L2) with the bound it starts from (seed kernel / other slices) and REBUILDS it when the bounds of a
-//     quarter of its queries have fallen below 0.72 of what they were built for (checked at steps 1, 2, 4, 8, ...;
-//     a rebuild costs ~3 us);
-//   * filter: (0x80 | T) - S per byte keeps bit 7 iff S <= T; S <= 112 and T <= 127, so no byte ever borrows.
+//   * entries are BYTES, Q = min(QMAX, floor((lut - lo[q][m]) / step[q])), QMAX = 15 (M * QMAX <= 240: a byte sum never
+//     carries): one ds_read_b128 serves 16 look-ups per lane and one v_add_u32 adds four of them, so the step loop has
+//     the SAME instruction stream as the u16 kernel (32 ds_read_b128 + ~146 VALU per 64 rows) for twice the queries;
+//   * 4-bit entries are enough because the quantisation follows the THRESHOLD, not the table's range: what decides the
+//     number of rows passing the filter is the resolution relative to R = thr - L (L = sum_m lo): step = R / (T - 1) with
+//     T = q8_target (96) when the table is built, entries above QMAX steps are clipped -- such a row is far outside;
+//   * the threshold tightens over a scan, so the workgroup builds its table ITSELF from the fp32 TILED table (L2) with the
+//     bound it starts from (seed kernel / other slices) and rebuilds it at an epoch end when the bounds of a quarter of its
+//     queries have halved their T (epochs end after blocks 15 * 16, 15 * 256, ...: a barrier of all waves costs more than
+//     a finer table saves, the sparse schedule is the guard against a seed bound that is far off);
+//   * filter: ((0x80 | T) - (S & 0x7f)) & ~S keeps bit 7 of a byte iff S <= T (T <= 127: no borrow crosses a byte).
 // Bound: Q <= (v - lo) / step * (1 + 2^-22) (fp32 subtract, multiply by 1/step, round down), hence
 //     d_real - L >= S * step * (1 - 2^-22);  a row can be in the top-k only if d_fp32 <= thr, i.e.
 //     d_real <= thr + slack32  =>  S <= T := floor((thr + slack32 - L) / step * (1 + 2^-19)) + 1   (double).
-// Clipping (min with QMAX) and a T clamped to 127 (S never exceeds 112) keep the bound valid for ANY step.
-// Candidates are handled by a CONSUMER wave: NW - 1 waves scan and only push (query, row) pairs into a ring in LDS;
-// the last wave of the workgroup pops them in batches of up to 128, computes the exact sums (two dependent global
-// round trips), updates the lists -- it is their only writer: no locks -- and publishes the bounds; it also imports
-// the bounds of the other row slices.  The scanning waves never wait for global memory, the exact path (16 table
-// gathers in flight, list networks) has its own registers instead of being called with ~100 live VGPRs saved to
-// scratch (the u16 kernel's out-of-line flush: 487 MB of scratch writes per 10M-row launch), and inlining it into the
-// step loop made the compiler spill the loop-invariant LDS base registers into the hot path.
-// LDS: [table Ks * 512][T bytes x32 @+0][ring control @+32][gkl u64 x32 @+192][step f32 x32 @+448][inv f32 x32 @+576]
-//      [built-for T x32 @+704][control @+736][lists u64 x32x64 @+768][gjl u64 x32][ring u64 x 1024]
+// Clipping (min with QMAX) and a T clamped to 127 keep the bound valid for ANY step.
+// The waves DRAW their 64-row blocks from a counter in LDS (the SIMD's arbiter favours its oldest wave and one wave alone
+// issues at a third of the rate four reach together: a static deal left the last waves to run an epoch out alone).
+// Candidates are handled by a CONSUMER wave: NW - 1 waves scan and only push (S, query, row) into a ring in LDS; the last
+// wave of the workgroup pops them in batches of up to 128, drops those whose S no longer passes, computes the exact sums,
+// updates the lists -- it is their only writer: no locks -- and publishes the bounds (to the other workgroups one batch
+// later, behind the next batch's gathers); it imports the sibling slices' bound: the k-th smallest of their j smallest
+// keys.  The scanning waves never wait for global memory, the exact path has its own registers instead of being called
+// with ~100 live VGPRs saved to scratch (the u16 kernel's out-of-line flush), and inlining it into the step loop made
+// the compiler spill the loop-invariant LDS base registers into the hot path.
+// LDS: [table Ks * 512][Q8Lds: bounds, ring control, block counter, slot parameters, lists u64 x32x16, ring u64 x1024,
+//      insertion queues]
 #include "scan_lists.h"
 
 #ifndef ANNLITE_Q8_EXP
