@@ -194,7 +194,8 @@ __device__ __forceinline__ void offer_to_list(const FlushCtx &c, int q0, unsigne
             }
         }
         if (c.gk2) {
-            // this slice's j-th key, for the max-of-j-th bound the sibling slices compute
+            // the slice's j smallest keys changed (or, with one key per cell, its j-th): what the sibling slices compute their
+            // bound from (sibling_bound)
             const uint32_t jhi = __builtin_amdgcn_readlane(L.hi, c.jm1);
             const uint32_t jlo = __builtin_amdgcn_readlane(L.lo, c.jm1);
             const unsigned long long jkey = ((unsigned long long)jhi << 32) | jlo;

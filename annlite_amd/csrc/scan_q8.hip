@@ -330,7 +330,7 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Ring &r, c
                 if (nb < *sp) *sp = nb;
             }
         }
-        if (c.gk2 && jkey != ~0ull) {  // this slice's j-th key, for the max-of-j-th bound the sibling slices compute
+        if (c.gk2 && jkey != ~0ull) {  // the slice's j smallest keys changed: the sibling slices compute their bound from them
             volatile unsigned long long *gjl = (volatile unsigned long long *)(g_smem + c.gjl_off + lane * 8);
             if (jkey < *gjl) {
                 *gjl = jkey;
@@ -502,8 +502,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                                  a.Ks, tile * QT, a.n_slices, slice, km1, a.jm1, a.dbg_skip,
                                  list_off, 0u, shq_off, gkl_off, gjl_off, step_off};
             // what the other workgroups of these queries (the other row slices) have proven: the best k-th key any of
-            // them published and, per group of 8 concurrently scanned slices, the MAX of their j-th keys (8 disjoint
-            // slices x j rows >= k rows at or below it; +1: that row itself must still be accepted)
+            // them published and, per group of 8 concurrently scanned slices, the k-th smallest of the keys they published
+            // (below; +1: that row itself must still be accepted)
             auto import_bounds = [&]() {
                 if (!a.gkey) return;
                 // lane = (slot, half): all loads in flight together -- one global round trip per group of 8 slices for the
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 if (a.gk2 && a.jm1 < 2) {
                     // The G <= 8 concurrently scanned slices publish their j = ceil(k / G) <= 2 smallest keys: G j >= k keys
                     // of distinct rows, so the k-th smallest of them has k rows at or below it (+1: that row itself must
-                    // still be accepted).  (The MAX of the slices' j-th keys, what the u16 kernels use, is the LARGEST of
+                    // still be accepted).  (The MAX of the slices' j-th keys, round 1's rule and the M = 64 kernel's, is the LARGEST of
                     // these keys: with 8 slices and k = 10 it sits near global rank 36, the 10th smallest of the 16 near
                     // rank 13 -- the candidates that pass the imported bound are in proportion.)
 #pragma unroll 1
