@@ -13,7 +13,8 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = 'libannlite_hip.so'
-LIB_PATH = os.path.join(_HERE, LIB_NAME)
+# ANNLITE_HIP_LIB: another build of the same library (A/B measurements of compile-time variants); default: the in-tree one
+LIB_PATH = os.environ.get('ANNLITE_HIP_LIB') or os.path.join(_HERE, LIB_NAME)
 
 ANNLITE_OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE = 1, 2, 3, 4
@@ -62,6 +63,7 @@ SYMBOLS = (
     'annlite_profile_enable',
     'annlite_profile_last_scan_ms',
     'annlite_debug_counters',
+    'annlite_debug_timeline',
 )
 
 
@@ -139,6 +141,7 @@ def lib() -> ctypes.CDLL:
     L.annlite_scan_select_variant.argtypes = [i32]
     L.annlite_profile_last_scan_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]
     L.annlite_debug_counters.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    L.annlite_debug_timeline.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     L.annlite_graph_search_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     for name in SYMBOLS:
         fn = getattr(L, name)  # AttributeError here == the .so does not export a declared symbol
@@ -224,6 +227,18 @@ def graph_search_stats():
     out = (ctypes.c_uint64 * 2)()
     check(lib().annlite_graph_search_stats(out), 'graph_search_stats')
     return int(out[0]), int(out[1])
+
+
+def debug_timeline():
+    """Phase stamps of the byte-table kernel's workgroups (see ``annlite_debug_timeline``), as microseconds:
+    dict(span, start_spread, build, scan, wait, merge) -- per-work-item averages except the span."""
+    out = (ctypes.c_uint64 * 8)()
+    check(lib().annlite_debug_timeline(out), 'debug_timeline')
+    v = [int(x) for x in out]
+    n = max(v[7], 1)
+    t0 = (1 << 62) - v[0]
+    return {'items': v[7], 'span_us': (v[1] - t0) / 100.0, 'avg_start_us': (v[2] / n - t0) / 100.0,
+            'build_us': v[3] / n / 100.0, 'scan_us': v[4] / n / 100.0, 'wait_us': v[5] / n / 100.0, 'merge_us': v[6] / n / 100.0}
 
 
 def debug_counters():

@@ -419,7 +419,7 @@ extern "C" int annlite_scan_plan_tiles(int64_t N, int64_t M, int64_t Ks, int cod
     return plan_query_impl(N, M, Ks, code_bytes, V, k, 1, plan);
 }
 
-static unsigned long long *g_dbg = nullptr;  // debug only (ANNLITE_DEBUG_COUNTERS): leaked 64-byte device buffer
+static unsigned long long *g_dbg = nullptr;  // debug only (ANNLITE_DEBUG_COUNTERS): leaked 128-byte device buffer
 static thread_local int g_prof_on = 0;
 static thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 static thread_local int g_ev_valid = 0;
@@ -503,8 +503,8 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
     a.dbg = nullptr;
     a.dbg_skip = getenv("ANNLITE_DEBUG_SKIP") ? atoi(getenv("ANNLITE_DEBUG_SKIP")) : 0;
     if (getenv("ANNLITE_DEBUG_COUNTERS")) {
-        if (!g_dbg) ANNLITE_HIP_TRY(hipMalloc((void **)&g_dbg, 64));
-        ANNLITE_HIP_TRY(hipMemsetAsync(g_dbg, 0, 64, st));
+        if (!g_dbg) ANNLITE_HIP_TRY(hipMalloc((void **)&g_dbg, 128));
+        ANNLITE_HIP_TRY(hipMemsetAsync(g_dbg, 0, 128, st));
         a.dbg = g_dbg;
     }
     {
@@ -671,6 +671,17 @@ extern "C" int annlite_debug_counters(uint64_t *out8) {
     }
     ANNLITE_HIP_TRY(hipDeviceSynchronize());
     ANNLITE_HIP_TRY(hipMemcpy(out8, g_dbg, 64, hipMemcpyDeviceToHost));
+    return ANNLITE_OK;
+}
+
+extern "C" int annlite_debug_timeline(uint64_t *out8) {
+    ANNLITE_REQUIRE(out8 != nullptr, "out8 is NULL");
+    if (!g_dbg) {
+        set_error("no counters recorded (set ANNLITE_DEBUG_COUNTERS=1 before the scan)");
+        return ANNLITE_ERR_INVALID;
+    }
+    ANNLITE_HIP_TRY(hipDeviceSynchronize());
+    ANNLITE_HIP_TRY(hipMemcpy(out8, g_dbg + 8, 64, hipMemcpyDeviceToHost));
     return ANNLITE_OK;
 }
 

@@ -45,6 +45,26 @@ namespace annlite {
 
 // Q8Cfg: entries are clipped at QMAX (M * QMAX <= 240: a byte sum never carries); a slot without a bound yet
 // ("open": nothing seeded it) clips at QOPEN, M * QOPEN <= 112, so that T = 127 passes every row.
+// LDS accesses by BYTE ADDRESS in the LDS address space.  (Through generic pointers -- struct members, lambda captures --
+// the compiler lost the address space and emitted FLAT instructions for the ring, the lists and the bounds: a flat access
+// counts on the vector-memory counter as well, so every one of them made its wave wait for ALL its outstanding global
+// loads -- the scanning waves' prefetched code rows, the consumer's table gathers.)
+#define ANNLITE_LDS __attribute__((address_space(3)))
+template <class T>
+__device__ __forceinline__ T ldsv(uint32_t ad) {  // volatile load (another wave may have written it)
+    return *(volatile ANNLITE_LDS T *)(uintptr_t)ad;
+}
+template <class T>
+__device__ __forceinline__ void ldsv_st(uint32_t ad, T v) {
+    *(volatile ANNLITE_LDS T *)(uintptr_t)ad = v;
+}
+__device__ __forceinline__ uint32_t lds_add_u32(uint32_t ad, uint32_t v) {
+    return __hip_atomic_fetch_add((ANNLITE_LDS uint32_t *)(uintptr_t)ad, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t lds_base_addr() {
+    return (uint32_t)(uintptr_t)(ANNLITE_LDS unsigned char *)g_smem;
+}
+
 template <int M>
 struct Q8Cfg {
     static constexpr int QMAX = 240 / M, QOPEN = 112 / M;
@@ -93,8 +113,8 @@ struct Q8Build {
 };
 
 template <int M, int NW>
-__device__ __forceinline__ void q8_build_table(const Q8Build &a, int tile, unsigned char *smem, const float *s_inv,
-                                               const float *s_clip, int tid) {
+__device__ __forceinline__ void q8_build_table(const Q8Build &a, int tile, uint32_t tab_ad, uint32_t inv_ad, uint32_t clip_ad,
+                                               int tid) {
     constexpr int NQ = 2, RB = M * 16, NT = NW * 64, KHS = NT / M;
     static_assert(NT % M == 0 && KHS % NQ == 0, "build mapping");
     const int m = tid % M, kh0 = tid / M, h = kh0 % NQ;
@@ -109,8 +129,8 @@ __device__ __forceinline__ void q8_build_table(const Q8Build &a, int tile, unsig
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             lo_r[4 * i + e] = ok ? a.qlom[(int64_t)(g4 * 4 + e) * M + m] : 0.f;
-            inv_r[4 * i + e] = ok ? s_inv[h * 16 + 4 * i + e] : 0.f;
-            clip_r[4 * i + e] = s_clip[h * 16 + 4 * i + e];
+            inv_r[4 * i + e] = ok ? ldsv<float>(inv_ad + 4u * (uint32_t)(h * 16 + 4 * i + e)) : 0.f;
+            clip_r[4 * i + e] = ldsv<float>(clip_ad + 4u * (uint32_t)(h * 16 + 4 * i + e));
         }
     }
 #pragma unroll 2
@@ -129,18 +149,47 @@ __device__ __forceinline__ void q8_build_table(const Q8Build &a, int tile, unsig
             }
             w[i] = pk;
         }
-        *(u32x4 *)(smem + (k * NQ + h) * RB + m * 16) = (u32x4){w[0], w[1], w[2], w[3]};
+        *(ANNLITE_LDS u32x4 *)(uintptr_t)(tab_ad + (uint32_t)((k * NQ + h) * RB + m * 16)) = (u32x4){w[0], w[1], w[2], w[3]};
     }
 }
 
 constexpr int kRingSize = 1024;  // candidate ring entries (u64 each)
 
-// ring control words in LDS (u32 each)
-struct Q8Ring {
-    volatile uint32_t *tail;     // entries reserved by the scanning waves
-    volatile uint32_t *head;     // entries consumed
-    volatile uint32_t *arrived;  // scanning waves that finished an epoch (cumulative)
-    unsigned long long *slots;   // [kRingSize], ~0 = not written yet
+// LDS map of a workgroup (absolute LDS byte addresses): [table Ks * 512][what follows]
+//   shq      u8 [32]   current filter bound (0x80 | T) of every slot -- what the scanning waves load as thp
+//   ring_ctl u32: +0 tail (entries reserved by the scanning waves), +4 head (entries consumed), +8 arrived (scanning waves that
+//            finished an epoch, cumulative), +64 the block counter the scanning waves draw from
+//   gkl      u64 [32]  best bound known for the slot (own k-th key or imported)
+//   step / inv / clip f32 [32], tb u8 [32] (T the table was built for), ctl u32 (+0 rebuild flag, +4 merge flag)
+//   tau      u64 [32]  the k-th key the consumer last published; c0, c1 f64 [32]: T = floor(thr * c1 + c0) + 1 (q8_bound)
+//   list     u64 [32][16] the 16 smallest keys of every slot, ascending; gjl u64 [32] the j-th key last published
+//   ring     u64 [kRingSize] (~0 = not written yet); qkey u64 [4][128], qslot u8 [4][128] insertion queues; chg u8 [32]
+struct Q8Lds {
+    uint32_t tab, shq, ring_ctl, gkl, step, inv, tb, ctl, clip, tau, c0, c1, list, gjl, ring, qkey, qslot, chg;
+    __device__ __forceinline__ explicit Q8Lds(int lut_bytes) {
+        tab = lds_base_addr();
+        shq = tab + (uint32_t)lut_bytes;
+        ring_ctl = shq + 32;
+        gkl = shq + 192;
+        step = shq + 448;
+        inv = shq + 576;
+        tb = shq + 704;
+        ctl = shq + 736;
+        clip = shq + 768;
+        tau = shq + 896;
+        c0 = shq + 1152;
+        c1 = shq + 1408;
+        list = shq + 1664;
+        gjl = list + 32 * 128;
+        ring = gjl + 32 * 8;
+        qkey = ring + kRingSize * 8;
+        qslot = qkey + 4 * 128 * 8;
+        chg = qslot + 4 * 128;
+    }
+    __device__ __forceinline__ uint32_t tail() const { return ring_ctl; }
+    __device__ __forceinline__ uint32_t head() const { return ring_ctl + 4; }
+    __device__ __forceinline__ uint32_t arrived() const { return ring_ctl + 8; }
+    __device__ __forceinline__ uint32_t blk_ctr() const { return ring_ctl + 64; }
 };
 
 // What the consumer wave keeps per slot (LDS): the 16 smallest keys (ordered distance << 32 | row) seen so far,
@@ -152,14 +201,6 @@ struct Q8Ring {
 // a double-precision division per insertion on one lane -- cost ~0.7 us per inserted candidate: 585 us per workgroup
 // at 1.25M rows against a 290 us scan.  Unsorted bags compacted when full: ~1.5 us per compaction and a bound that
 // lags 22 insertions behind -- 2x the candidates.)
-struct Q8Lists {
-    unsigned long long *list;  // [32][16]
-    unsigned long long *tau;   // [32]
-    const double *c0, *c1;     // [32] T = floor(thr * c1 + c0) + 1 for the slot's current step (q8_bound)
-    unsigned long long *qkey;  // [4][128] insertion queues of the four rows: keys,
-    unsigned char *qslot;      // [4][128] slots
-    unsigned char *chg;        // [32]
-};
 
 // byte filter bound (0x80 | T) of a slot from a k-th key: T = floor((thr + slack32 - L) / step * (1 + 2^-19)) + 1 with the
 // slot's constants folded into c1 = (1 + 2^-19) / step, c0 = (slack32 - L) * c1 (set when the table is built)
@@ -182,7 +223,8 @@ __device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t x) {
 // The global publication of a batch's bounds (the other row slices' workgroups import them) is DEFERRED to the next batch,
 // behind the issue of its table gathers: the device-scope atomics take microseconds and the wave's memory counter is in
 // order -- issued right away they sat in front of the next batch's gathers.
-__device__ __forceinline__ void q8_publish_global(const FlushCtx &c, int lane, unsigned long long &pend_o, unsigned long long &pend_j) {
+__device__ __forceinline__ void q8_publish_global(const FlushCtx &c, const Q8Lds &o, int lane, unsigned long long &pend_o,
+                                                  unsigned long long &pend_j) {
     if (lane < 32) {
         const int b = c.b0 + lane;
         if (pend_o != ~0ull && c.gkey) __hip_atomic_fetch_min(c.gkey + b, pend_o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -191,9 +233,9 @@ __device__ __forceinline__ void q8_publish_global(const FlushCtx &c, int lane, u
             if (c.jm1 < 2) {
                 // this slice's j smallest keys as they are NOW (keys only fall; a reader may see a mix of two versions:
                 // each key belongs to a row of this slice, and it drops a duplicate)
-                const volatile unsigned long long *lst = (const volatile unsigned long long *)(g_smem + c.list_off) + lane * 16;
-                __hip_atomic_store(cell, lst[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (c.jm1 == 1) __hip_atomic_store(cell + 1, lst[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t lst = o.list + (uint32_t)lane * 128u;
+                __hip_atomic_store(cell, ldsv<unsigned long long>(lst), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c.jm1 == 1) __hip_atomic_store(cell + 1, ldsv<unsigned long long>(lst + 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 __hip_atomic_store(cell, pend_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the j-th key alone
             }
@@ -204,30 +246,29 @@ __device__ __forceinline__ void q8_publish_global(const FlushCtx &c, int lane, u
 }
 
 template <int M, bool SKEWED>
-__device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Ring &r, const Q8Lists &g, uint32_t head, int n, int lane,
-                                           uint32_t &n_kept, uint32_t &n_offered, unsigned long long &pend_o,
-                                           unsigned long long &pend_j) {
+__device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, uint32_t head, int n, int lane, uint32_t &n_kept,
+                                           uint32_t &n_offered, unsigned long long &pend_o, unsigned long long &pend_j) {
     constexpr int CW = M / 4;
     unsigned long long e[2];
     bool act[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         act[u] = lane + 64 * u < n;
-        volatile unsigned long long *slot = r.slots + ((head + 64 * u + lane) & (kRingSize - 1));
+        const uint32_t slot = o.ring + 8u * ((head + 64u * u + (uint32_t)lane) & (kRingSize - 1));
         e[u] = ~0ull;
         // (reserved but not written yet: its producer is between the reservation and the store)
         while (__ballot(act[u] && e[u] == ~0ull)) {
-            if (act[u] && e[u] == ~0ull) e[u] = *slot;
+            if (act[u] && e[u] == ~0ull) e[u] = ldsv<unsigned long long>(slot);
         }
-        if (act[u]) *slot = ~0ull;
+        if (act[u]) ldsv_st<unsigned long long>(slot, ~0ull);
     }
-    *r.head = head + (uint32_t)n;  // the producers may overwrite the slots from here on
+    ldsv_st<uint32_t>(o.head(), head + (uint32_t)n);  // the producers may overwrite the slots from here on
     int q[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         q[u] = (int)(e[u] >> 32) & 31;
         const uint32_t sv = (uint32_t)(e[u] >> 40) & 0xffu;
-        const uint32_t tq = ((volatile unsigned char *)(g_smem + c.shq_off))[q[u]];
+        const uint32_t tq = ldsv<unsigned char>(o.shq + (uint32_t)q[u]);
         act[u] = act[u] && ((0x80u | sv) <= tq);  // still passes?  (pad slots, 0x7f, never push)
     }
     n_kept += (uint32_t)(__popcll(__ballot(act[0])) + __popcll(__ballot(act[1])));
@@ -260,40 +301,35 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Ring &r, c
                 vals[u][m] = lq[((int64_t)code * M + m) * 4];
             }
         }
-        q8_publish_global(c, lane, pend_o, pend_j);  // (the previous batch's, behind this batch's gathers)
+        q8_publish_global(c, o, lane, pend_o, pend_j);  // (the previous batch's, behind this batch's gathers)
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int m = 0; m < M; ++m) ex[u] += vals[u][m];
     }
     if (c.skip & 2) return;
-    volatile unsigned long long *gkl = (volatile unsigned long long *)(g_smem + c.gkl_off);
-    volatile unsigned long long *list = (volatile unsigned long long *)g.list;
     const int row = lane >> 4, li = lane & 15;
     // the candidates that beat their slot's current bound (own k-th key or the imported one) go to the queue of their
     // slot's row in LDS; then round t inserts entry t of every queue: no cross-lane traffic inside the loop
-    unsigned long long *qk = g.qkey;                                 // [4][128]
-    volatile unsigned char *qs = (volatile unsigned char *)g.qslot;  // [4][128]
-    volatile unsigned char *chg = (volatile unsigned char *)g.chg;   // [32] slot touched in this batch
     int cnt[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const unsigned long long key = ((unsigned long long)f32_to_ordered(ex[u]) << 32) | (uint32_t)e[u];
         bool pend = false;
         if (act[u]) {
-            unsigned long long kth = list[q[u] * 16 + c.km1];
-            const unsigned long long gk = gkl[q[u]];
+            unsigned long long kth = ldsv<unsigned long long>(o.list + 8u * (uint32_t)(q[u] * 16 + c.km1));
+            const unsigned long long gk = ldsv<unsigned long long>(o.gkl + 8u * (uint32_t)q[u]);
             if (gk < kth) kth = gk;
             pend = key < kth;
         }
-        if (pend) chg[q[u]] = 1;
+        if (pend) ldsv_st<unsigned char>(o.chg + (uint32_t)q[u], 1);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const unsigned long long bm = __ballot(pend && (q[u] & 3) == rr);
             if (pend && (q[u] & 3) == rr) {
                 const int idx = cnt[rr] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-                qk[rr * 128 + idx] = key;
-                qs[rr * 128 + idx] = (unsigned char)q[u];
+                ldsv_st<unsigned long long>(o.qkey + 8u * (uint32_t)(rr * 128 + idx), key);
+                ldsv_st<unsigned char>(o.qslot + (uint32_t)(rr * 128 + idx), (unsigned char)q[u]);
             }
             cnt[rr] += __popcll(bm);
         }
@@ -306,63 +342,40 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Ring &r, c
 #pragma unroll 1
     for (int t = 0; t < rounds; ++t) {
         const bool valid = t < mycnt;
-        const unsigned long long ckey = ((volatile unsigned long long *)qk)[row * 128 + t];
-        const int cq = qs[row * 128 + t] & 31;
-        const unsigned long long ent = list[cq * 16 + li];
+        const unsigned long long ckey = ldsv<unsigned long long>(o.qkey + 8u * (uint32_t)(row * 128 + t));
+        const int cq = ldsv<unsigned char>(o.qslot + (uint32_t)(row * 128 + t)) & 31;
+        const uint32_t ent_ad = o.list + 8u * (uint32_t)(cq * 16 + li);
+        const unsigned long long ent = ldsv<unsigned long long>(ent_ad);
         const unsigned long long front = __ballot(valid && ent < ckey);  // a prefix of the row (the list is ascending)
         const int pos = __popc((uint32_t)(front >> (16 * row)) & 0xffffu);
         const unsigned long long sh = ((unsigned long long)dpp_row_shr1((uint32_t)(ent >> 32)) << 32) | dpp_row_shr1((uint32_t)ent);
-        if (valid && li >= pos) list[cq * 16 + li] = li == pos ? ckey : sh;
+        if (valid && li >= pos) ldsv_st<unsigned long long>(ent_ad, li == pos ? ckey : sh);
     }
-    const uint32_t changed = (uint32_t)__ballot(lane < 32 && chg[lane & 31] != 0);
-    if (lane < 32) chg[lane] = 0;
+    const uint32_t changed = (uint32_t)__ballot(lane < 32 && ldsv<unsigned char>(o.chg + (uint32_t)(lane & 31)) != 0);
+    if (lane < 32) ldsv_st<unsigned char>(o.chg + (uint32_t)lane, 0);
     // publish the bounds of the slots that changed: lane = slot
     if (lane < 32 && ((changed >> lane) & 1u)) {
-        const unsigned long long okey = list[lane * 16 + c.km1], jkey = list[lane * 16 + c.jm1];
-        volatile unsigned long long *tau = (volatile unsigned long long *)g.tau;
-        if (okey < tau[lane]) {
-            tau[lane] = okey;
-            if (okey < gkl[lane]) {  // tell the other workgroups of this query (the other row slices)
+        const unsigned long long okey = ldsv<unsigned long long>(o.list + 8u * (uint32_t)(lane * 16 + c.km1));
+        const unsigned long long jkey = ldsv<unsigned long long>(o.list + 8u * (uint32_t)(lane * 16 + c.jm1));
+        const uint32_t tau_ad = o.tau + 8u * (uint32_t)lane, gkl_ad = o.gkl + 8u * (uint32_t)lane;
+        if (okey < ldsv<unsigned long long>(tau_ad)) {
+            ldsv_st<unsigned long long>(tau_ad, okey);
+            if (okey < ldsv<unsigned long long>(gkl_ad)) {  // tell the other workgroups of this query (the other row slices)
                 pend_o = okey;  // (keys only fall)
-                gkl[lane] = okey;
-                volatile unsigned char *sp = (volatile unsigned char *)(g_smem + c.shq_off + lane);
-                const unsigned char nb = q8_bound(okey, g.c0[lane], g.c1[lane]);
-                if (nb < *sp) *sp = nb;
+                ldsv_st<unsigned long long>(gkl_ad, okey);
+                const unsigned char nb = q8_bound(okey, ldsv<double>(o.c0 + 8u * (uint32_t)lane), ldsv<double>(o.c1 + 8u * (uint32_t)lane));
+                if (nb < ldsv<unsigned char>(o.shq + (uint32_t)lane)) ldsv_st<unsigned char>(o.shq + (uint32_t)lane, nb);
             }
         }
         if (c.gk2 && jkey != ~0ull) {  // the slice's j smallest keys changed: the sibling slices compute their bound from them
-            volatile unsigned long long *gjl = (volatile unsigned long long *)(g_smem + c.gjl_off + lane * 8);
-            if (jkey < *gjl) {
-                *gjl = jkey;
+            const uint32_t gjl_ad = o.gjl + 8u * (uint32_t)lane;
+            if (jkey < ldsv<unsigned long long>(gjl_ad)) {
+                ldsv_st<unsigned long long>(gjl_ad, jkey);
                 pend_j = jkey;
             }
         }
     }
 }
-
-// LDS offsets behind the table
-struct Q8Lds {
-    uint32_t shq, ring_ctl, gkl, step, inv, tb, ctl, clip, tau, c0, c1, list, gjl, ring, qkey, qslot, chg;
-    __device__ __forceinline__ explicit Q8Lds(int lut_bytes) {
-        shq = (uint32_t)lut_bytes;
-        ring_ctl = shq + 32;
-        gkl = shq + 192;
-        step = shq + 448;
-        inv = shq + 576;
-        tb = shq + 704;
-        ctl = shq + 736;
-        clip = shq + 768;
-        tau = shq + 896;
-        c0 = shq + 1152;
-        c1 = shq + 1408;
-        list = shq + 1664;
-        gjl = list + 32 * 128;
-        ring = gjl + 32 * 8;
-        qkey = ring + 1024 * 8;
-        qslot = qkey + 4 * 128 * 8;
-        chg = qslot + 4 * 128;
-    }
-};
 
 // (Re)build of a workgroup's table: slot parameters (one thread per slot) from the best bound known for the query, then
 // the byte table.  Out of line on purpose: it runs a dozen times per work item, and inlined into the step loop its 40
@@ -372,41 +385,40 @@ __device__ __attribute__((noinline)) void q8_rebuild(const Q8Build a, int tile, 
     constexpr int QT = 32;
     const int tid = threadIdx.x;
     const Q8Lds o(a.Ks * 2 * M * 16);
-    unsigned char *smem = g_smem;
     if (tid < QT) {
-        unsigned long long *gkl = (unsigned long long *)(smem + o.gkl);
+        const uint32_t t8 = 8u * (uint32_t)tid, t4 = 4u * (uint32_t)tid;
         const int b = tile * QT + tid;
         const bool real = b < a.B;
         unsigned long long key = ~0ull;
         if (first) {
             if (a.gkey && real) key = __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            gkl[tid] = key;
-            ((unsigned long long *)(smem + o.gjl))[tid] = ~0ull;
-            ((unsigned long long *)(smem + o.tau))[tid] = ~0ull;
-            smem[o.chg + tid] = 0;
+            ldsv_st<unsigned long long>(o.gkl + t8, key);
+            ldsv_st<unsigned long long>(o.gjl + t8, ~0ull);
+            ldsv_st<unsigned long long>(o.tau + t8, ~0ull);
+            ldsv_st<unsigned char>(o.chg + (uint32_t)tid, 0);
         } else {
-            key = ((const unsigned long long *)(smem + o.tau))[tid];
-            const unsigned long long g = gkl[tid];
+            key = ldsv<unsigned long long>(o.tau + t8);
+            const unsigned long long g = ldsv<unsigned long long>(o.gkl + t8);
             if (g < key) key = g;
         }
         float step, inv, clip;
         unsigned char tb;
         q8_slot_params<M>(real, key, real ? a.qstep[b] * (float)(32767 / M) : 0.f, real ? a.smax[b] : 0.f,
                           real ? a.qlo[b] : 0.0, a.target, step, inv, clip, tb);
-        ((volatile float *)(smem + o.step))[tid] = step;
-        ((float *)(smem + o.inv))[tid] = inv;
-        ((float *)(smem + o.clip))[tid] = clip;
+        ldsv_st<float>(o.step + t4, step);
+        ldsv_st<float>(o.inv + t4, inv);
+        ldsv_st<float>(o.clip + t4, clip);
         {
             const double slack = real ? (double)a.smax[b] * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0)) : 0.0;
             const double c1 = (1.0 + 1.0 / 524288.0) / (double)step;
-            ((double *)(smem + o.c1))[tid] = c1;
-            ((double *)(smem + o.c0))[tid] = (slack - (real ? a.qlo[b] : 0.0)) * c1;
+            ldsv_st<double>(o.c1 + t8, c1);
+            ldsv_st<double>(o.c0 + t8, (slack - (real ? a.qlo[b] : 0.0)) * c1);
         }
-        ((volatile unsigned char *)(smem + o.shq))[tid] = tb;
-        ((volatile unsigned char *)(smem + o.tb))[tid] = tb;
+        ldsv_st<unsigned char>(o.shq + (uint32_t)tid, tb);
+        ldsv_st<unsigned char>(o.tb + (uint32_t)tid, tb);
     }
     __syncthreads();
-    q8_build_table<M, NW>(a, tile, smem, (const float *)(smem + o.inv), (const float *)(smem + o.clip), tid);
+    q8_build_table<M, NW>(a, tile, o.tab, o.inv, o.clip, tid);
     __syncthreads();
 }
 
@@ -430,7 +442,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
     constexpr int QG = 16, NQ = 2, QT = QG * NQ, CW = M / 4, EB = 16, RB = M * EB, KSTRIDE = NQ * RB;
     constexpr int NS = NW - 1;  // scanning waves; wave NS is the consumer
     static_assert(M % 8 == 0 && M <= 32 && (KSTRIDE & (KSTRIDE - 1)) == 0, "unsupported shape");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -439,19 +450,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
 
     const int lut_bytes = a.Ks * KSTRIDE;
     const Q8Lds lds(lut_bytes);
-    const uint32_t shq_off = lds.shq, ring_ctl_off = lds.ring_ctl, gkl_off = lds.gkl, step_off = lds.step, tb_off = lds.tb,
-                   ctl_off = lds.ctl, list_off = lds.list, gjl_off = lds.gjl, ring_off = lds.ring;
-    unsigned long long *gkl = (unsigned long long *)(smem + gkl_off);
-    volatile unsigned char *shq = (volatile unsigned char *)(smem + shq_off);
-    volatile unsigned char *s_tb = (volatile unsigned char *)(smem + tb_off);
-    volatile uint32_t *s_ctl = (volatile uint32_t *)(smem + ctl_off);
-    unsigned long long *lists = (unsigned long long *)(smem + list_off);
     const Q8Build ba = {a.lut, a.qlom, a.qstep, a.smax, a.qlo, a.gkey, a.Ks, a.B, a.k, a.q8_target};
-    Q8Ring ring;
-    ring.tail = (volatile uint32_t *)(smem + ring_ctl_off);
-    ring.head = (volatile uint32_t *)(smem + ring_ctl_off + 4);
-    ring.arrived = (volatile uint32_t *)(smem + ring_ctl_off + 8);
-    ring.slots = (unsigned long long *)(smem + ring_off);
 
     for (int it = 0;; ++it) {
         const int item = blockIdx.x + it * gridDim.x;
@@ -465,6 +464,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
         const int n_steps = slice_end > slice_begin ? (int)((slice_end - slice_begin + stride - 1) / stride) : 0;
 
         __syncthreads();  // every wave is done with the previous item
+        // ANNLITE_DEBUG_COUNTERS: phase stamps of thread 0 (100 MHz wall clock), summed over the work items in dbg[8..15]
+        const unsigned long long t_item = (a.dbg && tid == 0) ? wall_clock64() : 0ull;
+        unsigned long long t_built = 0, t_scanned = 0, t_synced = 0;
         // end of an epoch (all waves): the consumer arrives last, with every pushed candidate in the lists.  Then: have
         // the bounds outrun the table?  A slot's T falls as its threshold tightens under a fixed step; rebuild when a
         // quarter of the real slots are below q8_rebuild_8ths / 8 of what their table was built for.
@@ -474,33 +476,34 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             if (wave == 0) {
                 const int q = lane & 31;
                 const bool real = tile * QT + q < a.B && lane < 32;
-                const uint32_t tn = shq[q] & 0x7fu, tb = s_tb[q] & 0x7fu;
+                const uint32_t tn = ldsv<unsigned char>(lds.shq + (uint32_t)q) & 0x7fu, tb = ldsv<unsigned char>(lds.tb + (uint32_t)q) & 0x7fu;
                 const bool need = real && tn * 8u < tb * (uint32_t)a.q8_rebuild_8ths;
                 const int n_need = __popcll(__ballot(need)), n_real = __popcll(__ballot(real));
-                if (lane == 0) *s_ctl = (n_need > 0 && n_need * 4 >= n_real) ? 1u : 0u;
+                if (lane == 0) ldsv_st<uint32_t>(lds.ctl, (n_need > 0 && n_need * 4 >= n_real) ? 1u : 0u);
             }
             __syncthreads();
-            if (*s_ctl) {
+            if (ldsv<uint32_t>(lds.ctl)) {
                 q8_rebuild<M, NW>(ba, tile, 0);
                 if (a.dbg && tid == 0) atomicAdd(a.dbg + 5, 1ull);
             }
         };
-        for (int idx = tid; idx < QT * 16; idx += NW * 64) lists[idx] = ~0ull;
-        for (int idx = tid; idx < kRingSize; idx += NW * 64) ring.slots[idx] = ~0ull;
+        for (int idx = tid; idx < QT * 16; idx += NW * 64) ldsv_st<unsigned long long>(lds.list + 8u * (uint32_t)idx, ~0ull);
+        for (int idx = tid; idx < kRingSize; idx += NW * 64) ldsv_st<unsigned long long>(lds.ring + 8u * (uint32_t)idx, ~0ull);
         if (tid == 0) {
-            *ring.tail = 0;
-            *ring.head = 0;
-            *ring.arrived = 0;
-            *(volatile uint32_t *)(smem + ring_ctl_off + 64) = 0;  // the block counter the scanning waves draw from
+            ldsv_st<uint32_t>(lds.tail(), 0);
+            ldsv_st<uint32_t>(lds.head(), 0);
+            ldsv_st<uint32_t>(lds.arrived(), 0);
+            ldsv_st<uint32_t>(lds.blk_ctr(), 0);  // the block counter the scanning waves draw from
         }
         q8_rebuild<M, NW>(ba, tile, 1);  // (its barriers cover the initialisation above)
+        if (a.dbg && tid == 0) t_built = wall_clock64();
 
         // epochs end after steps q8_epoch0, q8_epoch0 * mul + (mul - 1), ... and after the last step
         if (wave == NS) {
             // ------------------------------------------------------------------------------- consumer wave
             const FlushCtx fc = {(const uint8_t *)a.codes, a.lut, a.smax, a.qstep, a.qlo, a.gkey, a.gk2, nullptr,
                                  a.Ks, tile * QT, a.n_slices, slice, km1, a.jm1, a.dbg_skip,
-                                 list_off, 0u, shq_off, gkl_off, gjl_off, step_off};
+                                 0u, 0u, 0u, 0u, 0u, 0u};
             // what the other workgroups of these queries (the other row slices) have proven: the best k-th key any of
             // them published and, per group of 8 concurrently scanned slices, the k-th smallest of the keys they published
             // (below; +1: that row itself must still be accepted)
@@ -572,20 +575,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                         if (m != ~0ull && m + 1ull < bound) bound = m + 1ull;
                     }
                 }
-                if (real && part == 0 && bound < gkl[q]) {
-                    gkl[q] = bound;
-                    const unsigned char nb = q8_bound(bound, ((volatile const double *)(smem + lds.c0))[q], ((volatile const double *)(smem + lds.c1))[q]);
-                    if (nb < shq[q]) shq[q] = nb;
+                const uint32_t gkl_ad = lds.gkl + 8u * (uint32_t)q;
+                if (real && part == 0 && bound < ldsv<unsigned long long>(gkl_ad)) {
+                    ldsv_st<unsigned long long>(gkl_ad, bound);
+                    const unsigned char nb = q8_bound(bound, ldsv<double>(lds.c0 + 8u * (uint32_t)q), ldsv<double>(lds.c1 + 8u * (uint32_t)q));
+                    if (nb < ldsv<unsigned char>(lds.shq + (uint32_t)q)) ldsv_st<unsigned char>(lds.shq + (uint32_t)q, nb);
                 }
             };
-            Q8Lists bags;
-            bags.list = lists;
-            bags.tau = (unsigned long long *)(smem + lds.tau);
-            bags.c0 = (const double *)(smem + lds.c0);
-            bags.c1 = (const double *)(smem + lds.c1);
-            bags.qkey = (unsigned long long *)(smem + lds.qkey);
-            bags.qslot = smem + lds.qslot;
-            bags.chg = smem + lds.chg;
             uint32_t head = 0, n_kept = 0, n_offered = 0;
             unsigned long long pend_o = ~0ull, pend_j = ~0ull;  // bounds not yet published to the other workgroups (lane = slot)
             unsigned long long t_busy = 0;
@@ -597,8 +593,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 int idle = 0;
                 import_bounds();
                 for (;;) {
-                    const uint32_t arrived = *ring.arrived;  // (read BEFORE the tail: a wave pushes, then arrives)
-                    const uint32_t tail = *ring.tail;
+                    const uint32_t arrived = ldsv<uint32_t>(lds.arrived());  // (read BEFORE the tail: a wave pushes, then arrives)
+                    const uint32_t tail = ldsv<uint32_t>(lds.tail());
                     const int avail = (int)(tail - head);
                     // A non-final epoch does not wait for the backlog: the scanning waves stand at the barrier, what is in the
                     // ring is taken in the next epoch (only the last epoch's end needs every candidate in the lists)
@@ -607,7 +603,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                         const int n = avail < 128 ? avail : 128;
                         const unsigned long long t0 = a.dbg ? __builtin_readcyclecounter() : 0ull;
                         __builtin_amdgcn_s_setprio(3);  // (serial code on a SIMD shared with three or four scanning waves)
-                        q8_consume<M, SKEWED>(fc, ring, bags, head, n, lane, n_kept, n_offered, pend_o, pend_j);
+                        q8_consume<M, SKEWED>(fc, lds, head, n, lane, n_kept, n_offered, pend_o, pend_j);
                         __builtin_amdgcn_s_setprio(0);
                         ++n_batches;
                         if (a.dbg) t_busy += __builtin_readcyclecounter() - t0;
@@ -620,15 +616,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     if ((++idle & 15) == 8) import_bounds();
                     __builtin_amdgcn_s_sleep(4);
                 }
-                q8_publish_global(fc, lane, pend_o, pend_j);
-                const uint32_t tail_now = *ring.tail;  // (every scanning wave has arrived: its pushes are complete)
+                q8_publish_global(fc, lds, lane, pend_o, pend_j);
+                const uint32_t tail_now = ldsv<uint32_t>(lds.tail());  // (every scanning wave has arrived: its pushes are complete)
                 epoch_sync(final);
                 if (final) break;
-                if (*s_ctl) {
+                if (ldsv<uint32_t>(lds.ctl)) {
                     // the table was rebuilt: the integer sums of the waiting candidates are in the OLD table's steps --
                     // clear them, so that the stale-candidate check lets them through to the exact sum
-                    for (uint32_t i = head + (uint32_t)lane; (int)(tail_now - i) > 0; i += 64u)
-                        ring.slots[i & (kRingSize - 1)] &= ~(0xffull << 40);
+                    for (uint32_t i = head + (uint32_t)lane; (int)(tail_now - i) > 0; i += 64u) {
+                        const uint32_t ad = lds.ring + 8u * (i & (kRingSize - 1));
+                        ldsv_st<unsigned long long>(ad, ldsv<unsigned long long>(ad) & ~(0xffull << 40));
+                    }
                 }
                 ++epoch;
                 epoch_step = a.q8_epoch_mul * epoch_step + (a.q8_epoch_mul - 1);
@@ -647,8 +645,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
 #pragma unroll
             for (int i = 0; i < 8; ++i) abit[i] = (((s >> 2) >> i) & 1) != 0;
             // LDS byte addresses as integers
-            typedef const u32x4 __attribute__((address_space(3))) *lds_entry_ptr;
-            const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+            typedef const ANNLITE_LDS u32x4 *lds_entry_ptr;
+            const uint32_t lds0 = lds.tab;
             uint32_t mbase[M];
 #pragma unroll
             for (int t = 0; t < M; ++t) mbase[t] = lds0 + (uint32_t)(((s + t) % M) * EB);
@@ -660,10 +658,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             // one wave alone issues at about a third of the rate four reach together -- scripts/ubench/valu_cost.hip,
             // step_loop.hip.  With the rows dealt out statically the favoured waves finished their share of an epoch early
             // and the last ones ran it out alone: wave 0 sat at the epoch barriers for 45 % of the kernel.)
-            uint32_t *blk_ctr = (uint32_t *)(smem + ring_ctl_off + 64);
             auto draw = [&]() -> uint32_t {  // (lane 0's value; broadcast a step later, where it is first needed)
                 uint32_t v = 0;
-                if (lane == 0) v = atomicAdd(blk_ctr, 1u);
+                if (lane == 0) v = lds_add_u32(lds.blk_ctr(), 1u);
                 return v;
             };
             uint32_t ccur[CW], cnext[CW];
@@ -697,9 +694,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     addr[4 * w + 3] = mbase[4 * w + 3] + o3;
                 });
             };
-            u32x4 thp[NQ];  // packed (0x80 | T) of the group's 16 queries
+            auto load_thp = [&](u32x4 (&t)[NQ]) {
 #pragma unroll
-            for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
+                for (int h = 0; h < NQ; ++h) t[h] = *(volatile ANNLITE_LDS u32x4 *)(uintptr_t)(lds.shq + 16u * (uint32_t)h);
+            };
+            u32x4 thp[NQ];  // packed (0x80 | T) of the group's 16 queries
+            load_thp(thp);
             // byte sums of the row for both entry groups (4 dwords x 4 x u8 each): the 2 M look-ups run through a ring of
             // DEPTH landing registers -- look-up i + DEPTH is issued as soon as look-up i has been added (all M look-ups
             // of a group in flight, as the u16 kernel has them, takes 64 landing VGPRs: with them the allocator spilled
@@ -772,7 +772,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     if (s_end - row0 < 64u) vmask = (1ull << (s_end - row0)) - 1ull;
                     // validity word of this lane's row, fetched one step ahead with the code bytes
                     if (valid) vmask &= __ballot((vcur >> (lane & 31)) & 1u);
-                    const uint32_t rid = row0 + (uint32_t)lane;
                     make_addr(ccur);
                     u32x4 acc[NQ];
                     row_sums(acc);
@@ -782,54 +781,70 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     for (int h = 0; h < NQ; ++h)
 #pragma unroll
                         for (int w = 0; w < 4; ++w) anyv |= (thp[h][w] - (acc[h][w] & 0x7f7f7f7fu)) & ~acc[h][w];
-                    const unsigned long long anym = __ballot((anyv & 0x80808080u) != 0) & vmask;
-                    if (anym && !(a.dbg_skip & 4)) {
+                    unsigned long long rem = __ballot((anyv & 0x80808080u) != 0) & vmask;
+                    if (rem && !(a.dbg_skip & 4)) {
                         ++n_slow;
-                        // push (slot, row, S) of every lane that passed: dword by dword, byte by byte
-                        static_for<0, NQ * 4>([&](auto HW) {
-                            constexpr int h = decltype(HW)::value / 4, w = decltype(HW)::value % 4;
-                            const uint32_t sw = acc[h][w];
-                            const uint32_t x = (thp[h][w] - (sw & 0x7f7f7f7fu)) & ~sw & 0x80808080u;
-                            if (__ballot(x != 0) & vmask) {
-                                static_for<0, 4>([&](auto BY) {
-                                    constexpr int by = decltype(BY)::value;
-                                    constexpr uint32_t q0 = h * 16 + w * 4 + by;
-                                    const unsigned long long pm = __ballot((x & (0x80u << (8 * by))) != 0) & vmask;
-                                    if (pm) {
-                                        const int n = __popcll(pm);
-                                        n_push += (uint32_t)n;
-                                        uint32_t pos = 0;
-                                        if (lane == 0) pos = atomicAdd((uint32_t *)ring.tail, (uint32_t)n);
-                                        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
-                                        while ((int)(pos + (uint32_t)n - *ring.head) > a.q8_ring_limit)  // the consumer is behind
-                                            __builtin_amdgcn_s_sleep(8);
-                                        const int rank = __builtin_amdgcn_mbcnt_hi(
-                                            (uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-                                        const uint32_t sv = (sw >> (8 * by)) & 0xffu;  // (the consumer re-checks it)
-                                        if ((pm >> lane) & 1ull)
-                                            ring.slots[(pos + (uint32_t)rank) & (kRingSize - 1)] =
-                                                ((unsigned long long)((sv << 8) | q0) << 32) | rid;
-                                    }
-                                });
+                        // The step's candidates -- (lane, query) pairs with S <= T -- are few (one or two lanes of a step that has
+                        // any), so they are enumerated in SCALAR code: a hit lane's byte sums are read into SGPRs (v_readlane), the
+                        // filter is redone there, the entries (S << 40 | slot << 32 | row) are staged lane by lane and
+                        // pushed with ONE ring reservation.  (Per dword and byte with ballots and one reservation per hit byte --
+                        // 32 unrolled copies, ~19 KB of code -- this path cost ~110 VALU instructions per step with a candidate, on
+                        // top of the ~120 of the step itself: a quarter of the wave-steps at 1.25M rows x 1024 queries take it.)
+                        uint32_t ts[NQ * 4];
+#pragma unroll
+                        for (int i = 0; i < NQ * 4; ++i) ts[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)thp[i / 4][i % 4]);
+                        uint32_t e_lo = 0, e_hi = 0;  // lane j: staged entry j
+                        int n = 0;
+                        for (;;) {
+                            if (n > 32 || (n > 0 && !rem)) {  // (a lane adds at most 32 entries)
+                                uint32_t pos = 0;
+                                if (lane == 0) pos = lds_add_u32(lds.tail(), (uint32_t)n);
+                                pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+                                while ((int)(pos + (uint32_t)n - ldsv<uint32_t>(lds.head())) > a.q8_ring_limit)  // the consumer is behind
+                                    __builtin_amdgcn_s_sleep(8);
+                                if (lane < n)
+                                    ldsv_st<unsigned long long>(lds.ring + 8u * ((pos + (uint32_t)lane) & (kRingSize - 1)),
+                                                                ((unsigned long long)e_hi << 32) | e_lo);
+                                n_push += (uint32_t)n;
+                                n = 0;
                             }
-                        });
+                            if (!rem) break;
+                            const int L = __builtin_ctzll(rem);
+                            rem &= rem - 1ull;
+                            const uint32_t rid = row0 + (uint32_t)L;
+                            static_for<0, NQ * 4>([&](auto I) {
+                                constexpr int i = decltype(I)::value;
+                                const uint32_t ss = (uint32_t)__builtin_amdgcn_readlane((int)acc[i / 4][i % 4], L);
+                                uint32_t bits = (ts[i] - (ss & 0x7f7f7f7fu)) & ~ss & 0x80808080u;
+                                while (bits) {
+                                    const uint32_t by = (uint32_t)__builtin_ctz(bits) >> 3;
+                                    bits &= bits - 1u;
+                                    const uint32_t sv = (ss >> (8u * by)) & 0xffu;  // (the consumer re-checks it)
+                                    if (lane == n) {  // (scalar values into lane n: one compare, two conditional moves)
+                                        e_hi = (sv << 8) | ((uint32_t)(4 * i) + by);
+                                        e_lo = rid;
+                                    }
+                                    ++n;
+                                }
+                            });
+                        }
                     }
                     // pick up the workgroup's bounds every 2nd step
                     if (it_no & 1) {
                         asm volatile("" ::: "memory");
-#pragma unroll
-                        for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
+                        load_thp(thp);
                     }
                     b_cur = b_nxt;
                     b_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend);
                 }
-                if (lane == 0) atomicAdd((uint32_t *)ring.arrived, 1u);
+                if (lane == 0) lds_add_u32(lds.arrived(), 1u);
                 const unsigned long long tw = a.dbg ? __builtin_readcyclecounter() : 0ull;
+                if (a.dbg && tid == 0 && final) t_scanned = wall_clock64();
                 epoch_sync(final);
                 if (a.dbg) t_wait += __builtin_readcyclecounter() - tw;
+                if (a.dbg && tid == 0 && final) t_synced = wall_clock64();
                 if (final) break;
-#pragma unroll
-                for (int h = 0; h < NQ; ++h) thp[h] = *(const u32x4 *)(smem + lut_bytes + h * 16);
+                load_thp(thp);
             }
             if (a.dbg && lane == 0) {  // [0] wave-steps with a candidate, [1] entries pushed, [7] wave 0's cycles at epoch ends
                 atomicAdd(a.dbg + 0, (unsigned long long)n_slow);
@@ -844,22 +859,37 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             const int b = tile * QT + q;
             // device-scope stores: the merging workgroup may sit on another XCD (own L2)
             if (b < a.B && lane <= km1)
-                __hip_atomic_store(a.partial + ((int64_t)b * a.n_slices + slice) * a.k + lane, lists[q * 16 + lane],
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.partial + ((int64_t)b * a.n_slices + slice) * a.k + lane,
+                                   ldsv<unsigned long long>(lds.list + 8u * (uint32_t)(q * 16 + lane)), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         }
         if (a.tile_done) {
             // the last of the tile's n_slices workgroups to arrive merges them
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have completed
             __syncthreads();
-            volatile unsigned int *s_flag = (volatile unsigned int *)(smem + ctl_off + 4);
             if (tid == 0) {
                 const unsigned int old =
                     __hip_atomic_fetch_add(a.tile_done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                *s_flag = (old + 1u == (unsigned int)(a.n_slices - 1)) ? 1u : 0u;
+                ldsv_st<uint32_t>(lds.ctl + 4, (old + 1u == (unsigned int)(a.n_slices - 1)) ? 1u : 0u);
             }
             __syncthreads();
-            if (*s_flag) merge_tile_slices<NW>(a, tile * QT, QT, km1, wave, lane, (unsigned long long *)(smem + ring_off));
+            if (ldsv<uint32_t>(lds.ctl + 4))
+                merge_tile_slices<NW>(a, tile * QT, QT, km1, wave, lane, (unsigned long long *)(g_smem + (lds.ring - lds.tab)));
             __syncthreads();
+        }
+        if (a.dbg && tid == 0) {
+            // [8] 2^62 - earliest start, [9] latest end, sums over the work items: [10] start, [11] init + first table build,
+            // [12] thread 0's step loop, [13] its wait at the last barrier (the consumer's backlog, the slower waves),
+            // [14] list store + merge, [15] work items
+            const unsigned long long t_end = wall_clock64();
+            atomicMax(a.dbg + 8, (1ull << 62) - t_item);
+            atomicMax(a.dbg + 9, t_end);
+            atomicAdd(a.dbg + 10, t_item);
+            atomicAdd(a.dbg + 11, t_built - t_item);
+            atomicAdd(a.dbg + 12, t_scanned - t_built);
+            atomicAdd(a.dbg + 13, t_synced - t_scanned);
+            atomicAdd(a.dbg + 14, t_end - t_synced);
+            atomicAdd(a.dbg + 15, 1ull);
         }
     }
 }

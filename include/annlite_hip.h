@@ -222,6 +222,10 @@ ANNLITE_API int annlite_scan_select_variant(int variant);
  * candidate [1] candidates pushed [2] exact sums [3] candidates queued for a list [4] consumer-wave cycles inside
  * batches [5] table rebuilds [6] consumer batches [7] cycles of wave 0 at epoch ends. */
 ANNLITE_API int annlite_debug_counters(uint64_t *out8);
+/* Debug aid, same switch: phase stamps of the byte-table kernel's workgroups (thread 0, 100 MHz wall clock): [0] 2^62 -
+ * earliest start, [1] latest end; sums over the work items of [2] start stamp, [3] initialisation + first table build,
+ * [4] step loop, [5] wait at the last barrier, [6] list store + merge; [7] work items. */
+ANNLITE_API int annlite_debug_timeline(uint64_t *out8);
 
 /* Convert between the PLAIN and the SKEWED code-table layout (uint8 codes).
  * forward (inverse=0): table_out[id][j] = codes_in[i][(j + id) mod M]   -- scatter rows i -> id

@@ -69,13 +69,16 @@ for it in range(a.iters):
     ms.append(_capi.profile_last_scan_ms())
 torch.cuda.synchronize()
 look = B * N * M
-print('scan kernel ms:', ['%.3f' % x for x in ms], ' lookups/s %.3e' % (look / (min(ms) * 1e-3)), ' alg GB/s %.1f' % (look / (min(ms) * 1e-3) / 1e9))
+med = float(np.median(ms[len(ms) // 2:]))  # (the first iterations include module load and the clock ramp)
+print('scan kernel ms: median of the last %d: %.4f  min %.4f  first %.3f' % (len(ms) - len(ms) // 2, med, min(ms), ms[0]),
+      ' lookups/s %.3e' % (look / (med * 1e-3)), ' alg GB/s %.1f' % (look / (med * 1e-3) / 1e9))
 
 if os.environ.get('ANNLITE_DEBUG_COUNTERS') and plan.qt == 32:
     c = _capi.debug_counters()
     nwg = 256
     print('byte-table kernel: wave-steps with candidates %d, pushed %d, exact sums %d, queued for a list %d, table rebuilds %d, consumer batches %d; '
           'per workgroup: consumer inside batches %.1f us, wave 0 at epoch ends %.1f us' % (c[0], c[1], c[2], c[3], c[5], c[6], c[4] / nwg / 2400., c[7] / nwg / 2400.))
+    print('byte-table kernel timeline (us; per-work-item averages but the span):', _capi.debug_timeline())
 elif os.environ.get('ANNLITE_DEBUG_COUNTERS'):
     c = _capi.debug_counters()
     n_wave_steps = (N // 64) * ((B + plan.qt - 1) // plan.qt)
