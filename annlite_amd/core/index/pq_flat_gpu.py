@@ -360,7 +360,10 @@ class PQFlatGpuIndex(BaseIndex):
 
     def _search_rerank(self, q, k, valid, N, rerank_k, scan_in=None):
         B = q.shape[0]
-        rk = int(rerank_k or getattr(self, 'rerank_k', None) or 64)
+        # candidates per row slice: 16 where the byte-table kernel generates them (M = 16: 8 slices x 16 keys = 128 per query
+        # at 1024 queries; its lists hold 16 keys), 64 otherwise (u16-table kernels)
+        byte_tables = self.M == 16 and self.code_bytes == 1 and self.Ks <= 256
+        rk = int(rerank_k or getattr(self, 'rerank_k', None) or (16 if byte_tables else 64))
         rk = max(1, min(64, rk))
         plan = scan_plan(N, self.M, self.Ks, self.code_bytes, B, rk)
         from ..._capi import LAYOUT_BMK, LAYOUT_TILED

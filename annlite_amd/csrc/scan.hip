@@ -506,6 +506,8 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         if (!g_dbg) ANNLITE_HIP_TRY(hipMalloc((void **)&g_dbg, 128));
         ANNLITE_HIP_TRY(hipMemsetAsync(g_dbg, 0, 128, st));
         a.dbg = g_dbg;
+        if (atoi(getenv("ANNLITE_DEBUG_COUNTERS")) == 2) a.dbg_skip |= 8;  // phase stamps only (annlite_debug_timeline): the
+                                                                           // per-wave event counters cost tens of microseconds
     }
     {
         int ns;
@@ -631,6 +633,21 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                     rc = launch_seed_bound(M, codes_layout == ANNLITE_CODES_SKEWED, codes_dev, code_bytes, S, valid_bits_dev, lut_dev,
                                            B, Ks, k, smax, gk, st);
                     if (rc != ANNLITE_OK) return rc;
+                }
+            }
+            if (!share_across_slices && c.mode == 5 && !tm && N >= 4096) {
+                // the byte-table kernel as the candidate generator of the re-rank stage: every slice keeps its own complete
+                // list, so every (query, slice) gets its own first bound -- the k-th of the slice's first rows (the gk2 array,
+                // unused without sharing and reset by the fill, holds them).  Without one the slice's table would start "open"
+                // (everything passes until the first epoch end: 15k rows x 32 queries through the consumer wave).
+                int64_t S = a.slice_rows / 64 < 2048 ? 2048 : a.slice_rows / 64 > 8192 ? 8192 : ((a.slice_rows / 64 + 1023) / 1024) * 1024;
+                if (const char *e = getenv("ANNLITE_SEED_ROWS")) S = atoll(e);
+                if (S > a.slice_rows) S = a.slice_rows;
+                if (S > 0) {
+                    rc = launch_seed_bound(M, codes_layout == ANNLITE_CODES_SKEWED, codes_dev, code_bytes, S, valid_bits_dev, lut_dev,
+                                           B, Ks, k, smax, gk2, st, N, plan.n_slices, a.slice_rows, (int64_t)a.n_tiles * plan.qt);
+                    if (rc != ANNLITE_OK) return rc;
+                    a.gseed = gk2;
                 }
             }
             a.smax = smax;

@@ -36,6 +36,8 @@ struct ScanArgs {
                              // concurrently scanned slices of a query hold >= k rows at or below the MAX of
                              // their j-th keys, a bound ~k/j times tighter than any single slice's own k-th
     int32_t jm1;             // j - 1
+    const unsigned long long *gseed;  // [n_slices][n_tiles * 32] per-slice first bounds (byte-table kernel as the candidate
+                             // generator of the re-rank stage: every slice keeps its OWN complete list, nothing is shared)
     // final merge inside the scan (shared mode): the LAST workgroup of a query tile to finish merges its slices
     unsigned int *tile_done; // [n_tiles] arrival counters, start at 0xffffffff (workspace fill); NULL = no in-kernel merge
     float *out_d;            // [B][k]   (or NULL with out_packed)
@@ -234,8 +236,9 @@ int launch_q8_scan(int id, bool skewed, const ScanArgs &a, int grid, hipStream_t
 int launch_lut_quantise(int64_t M, int64_t Ks, int64_t B, int64_t bpad, const float *lut_dev, const LutBuild *build,
                         uint16_t *q16, float *qstep, double *qlo, float *smax, float *qlom, void *fill,
                         size_t fill_bytes, hipStream_t st);
+// n_seed_slices > 1: one bound per (query, row slice) -- rows [y * seed_stride, + S) of slice y, bound in gkey[y * gkey_stride + b]
 int launch_seed_bound(int64_t M, bool skewed, const void *codes_dev, int code_bytes, int64_t S, const uint32_t *valid_bits_dev,
                       const float *lut_dev, int64_t B, int64_t Ks, int64_t k, const float *smax, unsigned long long *gkey,
-                      hipStream_t st);
+                      hipStream_t st, int64_t N = 0, int n_seed_slices = 1, int64_t seed_stride = 0, int64_t gkey_stride = 0);
 
 }  // namespace annlite

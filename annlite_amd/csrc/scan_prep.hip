@@ -109,8 +109,19 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
                                                                     const uint32_t *__restrict__ valid,
                                                                     const float *__restrict__ lut, int B, int Ks, int k,
                                                                     const float *__restrict__ smax,
-                                                                    unsigned long long *__restrict__ gkey) {
+                                                                    unsigned long long *__restrict__ gkey,
+                                                                    int64_t seed_stride, int64_t N, int gkey_stride) {
     static_assert(!(CODE16 && SKEWED), "uint16 code tables are PLAIN");
+    // blockIdx.y = row slice (per-slice bounds of the candidate generator: rows [y * seed_stride, + S), bound ->
+    // gkey[y * gkey_stride + b]; seed_stride is a multiple of 64, so the lanes keep their skew residues); one slice: the first S rows
+    {
+        const int64_t base = (int64_t)blockIdx.y * seed_stride;
+        if (base + S > N) S = N - base;
+        if (S <= 0) return;
+        codes += base * M * (CODE16 ? 2 : 1);
+        if (valid) valid += base >> 5;
+        gkey += (int64_t)blockIdx.y * gkey_stride;
+    }
     constexpr int CW = CODE16 ? M / 2 : M / 4;
     constexpr int CH = M < 16 ? M : 16;  // look-ups in flight
     constexpr bool PERM = M == 16 && QPB == 4 && !CODE16;  // one byte permute per look-up address (see below)
@@ -626,14 +637,19 @@ int annlite::launch_lut_quantise(int64_t M, int64_t Ks, int64_t B, int64_t bpad,
 
 int annlite::launch_seed_bound(int64_t M, bool skw, const void *codes_dev, int code_bytes, int64_t S, const uint32_t *valid_bits_dev,
                                const float *lut_dev, int64_t B, int64_t Ks, int64_t k, const float *smax,
-                               unsigned long long *gk, hipStream_t st) {
+                               unsigned long long *gk, hipStream_t st, int64_t N, int n_seed_slices, int64_t seed_stride,
+                               int64_t gkey_stride) {
+    const unsigned ny = (unsigned)(n_seed_slices > 0 ? n_seed_slices : 1);
+    const int gstride = (int)gkey_stride;
+    if (N <= 0) N = S;
 #define ANNLITE_SEED(MM, QPB_)                                                                                    \
     {                                                                                                             \
         auto fn = skw ? seed_bound_kernel<MM, true, QPB_> : seed_bound_kernel<MM, false, QPB_>;                   \
         const size_t lds = (size_t)Ks * MM * 4 * QPB_ + (size_t)2 * kSeedWaves * 64 * 8; /* cand + minima */         \
         ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(fn, dim3((unsigned)(((B + 3) / 4) * (4 / QPB_))), dim3(kSeedWaves * 64), lds, st,      \
-                           (const uint8_t *)codes_dev, S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, smax, gk);   \
+        hipLaunchKernelGGL(fn, dim3((unsigned)(((B + 3) / 4) * (4 / QPB_)), ny), dim3(kSeedWaves * 64), lds, st,  \
+                           (const uint8_t *)codes_dev, S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, smax, gk,    \
+                           seed_stride, N, gstride);                                                                    \
     }
     if (code_bytes == 2) {  // uint16 codes: PLAIN tables, M = 8 / 16 (what the u16-table scan kernel takes)
 #define ANNLITE_SEED16(MM)                                                                                         \
@@ -641,8 +657,8 @@ int annlite::launch_seed_bound(int64_t M, bool skw, const void *codes_dev, int c
         auto fn = seed_bound_kernel<MM, false, 4, true>;                                                          \
         const size_t lds = (size_t)Ks * MM * 16 + (size_t)2 * kSeedWaves * 64 * 8;                                 \
         ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(fn, dim3((unsigned)((B + 3) / 4)), dim3(kSeedWaves * 64), lds, st, (const uint8_t *)codes_dev, \
-                           S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, smax, gk);                           \
+        hipLaunchKernelGGL(fn, dim3((unsigned)((B + 3) / 4), ny), dim3(kSeedWaves * 64), lds, st, (const uint8_t *)codes_dev, \
+                           S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, smax, gk, seed_stride, N, gstride);   \
     }
         if (M == 8) ANNLITE_SEED16(8) else ANNLITE_SEED16(16)
 #undef ANNLITE_SEED16

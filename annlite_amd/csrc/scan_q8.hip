@@ -34,7 +34,8 @@
 #include "scan_lists.h"
 
 #ifndef ANNLITE_Q8_EXP
-#define ANNLITE_Q8_EXP 0  // (timing experiments, results wrong: 1 = look-ups without the adds, 2 = adds without the look-ups)
+#define ANNLITE_Q8_EXP 0  // (timing experiments, results wrong: 1 = look-ups without the adds, 2 = adds without the look-ups,
+                          // 3 = code rows computed instead of loaded)
 #endif
 
 namespace annlite {
@@ -108,7 +109,7 @@ __device__ __forceinline__ void q8_slot_params(bool real, unsigned long long key
 struct Q8Build {
     const float *lut, *qlom, *qstep, *smax;
     const double *qlo;
-    const unsigned long long *gkey;
+    const unsigned long long *gkey;  // first bounds: the shared array, or this slice's row of the per-slice seeds, or NULL
     int32_t Ks, B, k, target;
 };
 
@@ -158,7 +159,7 @@ constexpr int kRingSize = 1024;  // candidate ring entries (u64 each)
 // LDS map of a workgroup (absolute LDS byte addresses): [table Ks * 512][what follows]
 //   shq      u8 [32]   current filter bound (0x80 | T) of every slot -- what the scanning waves load as thp
 //   ring_ctl u32: +0 tail (entries reserved by the scanning waves), +4 head (entries consumed), +8 arrived (scanning waves that
-//            finished an epoch, cumulative), +64 the block counter the scanning waves draw from
+//            finished an epoch, cumulative), +64 the block counter the scanning waves draw from, +96 u64 [4] debug phase stamps
 //   gkl      u64 [32]  best bound known for the slot (own k-th key or imported)
 //   step / inv / clip f32 [32], tb u8 [32] (T the table was built for), ctl u32 (+0 rebuild flag, +4 merge flag)
 //   tau      u64 [32]  the k-th key the consumer last published; c0, c1 f64 [32]: T = floor(thr * c1 + c0) + 1 (q8_bound)
@@ -450,7 +451,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
 
     const int lut_bytes = a.Ks * KSTRIDE;
     const Q8Lds lds(lut_bytes);
-    const Q8Build ba = {a.lut, a.qlom, a.qstep, a.smax, a.qlo, a.gkey, a.Ks, a.B, a.k, a.q8_target};
 
     for (int it = 0;; ++it) {
         const int item = blockIdx.x + it * gridDim.x;
@@ -463,10 +463,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
         const int64_t stride = (int64_t)NS * 64;
         const int n_steps = slice_end > slice_begin ? (int)((slice_end - slice_begin + stride - 1) / stride) : 0;
 
+        // first bounds of the item's queries: what the seed launch left in the shared array, or -- candidate generator, nothing
+        // shared between the slices -- in this slice's row of the per-slice seeds ([n_slices][n_tiles * 32])
+        const Q8Build ba = {a.lut, a.qlom, a.qstep, a.smax, a.qlo,
+                            a.gkey ? a.gkey : (a.gseed ? a.gseed + (int64_t)slice * (a.n_tiles * QT) : nullptr),
+                            a.Ks, a.B, a.k, a.q8_target};
+
         __syncthreads();  // every wave is done with the previous item
-        // ANNLITE_DEBUG_COUNTERS: phase stamps of thread 0 (100 MHz wall clock), summed over the work items in dbg[8..15]
-        const unsigned long long t_item = (a.dbg && tid == 0) ? wall_clock64() : 0ull;
-        unsigned long long t_built = 0, t_scanned = 0, t_synced = 0;
+        // ANNLITE_DEBUG_COUNTERS: phase stamps of thread 0 (100 MHz wall clock; kept in LDS: four live 64-bit values pushed the
+        // step loop over its register budget), summed over the work items in dbg[8..15]
+        const uint32_t stamp_ad = lds.ring_ctl + 96;  // u64 [4] in the unused part of the ring-control block
+        auto stamp = [&](int i) {
+            if (a.dbg && tid == 0) ldsv_st<unsigned long long>(stamp_ad + 8u * (uint32_t)i, wall_clock64());
+        };
+        stamp(0);
         // end of an epoch (all waves): the consumer arrives last, with every pushed candidate in the lists.  Then: have
         // the bounds outrun the table?  A slot's T falls as its threshold tightens under a fixed step; rebuild when a
         // quarter of the real slots are below q8_rebuild_8ths / 8 of what their table was built for.
@@ -496,7 +506,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             ldsv_st<uint32_t>(lds.blk_ctr(), 0);  // the block counter the scanning waves draw from
         }
         q8_rebuild<M, NW>(ba, tile, 1);  // (its barriers cover the initialisation above)
-        if (a.dbg && tid == 0) t_built = wall_clock64();
+        stamp(1);
 
         // epochs end after steps q8_epoch0, q8_epoch0 * mul + (mul - 1), ... and after the last step
         if (wave == NS) {
@@ -631,7 +641,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 ++epoch;
                 epoch_step = a.q8_epoch_mul * epoch_step + (a.q8_epoch_mul - 1);
             }
-            if (a.dbg && lane == 0) {  // ANNLITE_DEBUG_COUNTERS: [2] exact sums, [3] candidates that went into a list's queue,
+            if (a.dbg && lane == 0 && !(a.dbg_skip & 8)) {  // ANNLITE_DEBUG_COUNTERS=1: [2] exact sums, [3] candidates that went into a list's queue,
                 atomicAdd(a.dbg + 2, (unsigned long long)n_kept);     // [4] consumer cycles inside batches, [6] batches
                 atomicAdd(a.dbg + 3, (unsigned long long)n_offered);
                 atomicAdd(a.dbg + 4, t_busy);
@@ -666,6 +676,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             uint32_t ccur[CW], cnext[CW];
             uint32_t addr[M];
             auto load_row = [&](uint32_t row, uint32_t (&c)[CW]) {
+                if constexpr (ANNLITE_Q8_EXP == 3) {  // (timing experiment: no code rows from memory)
+#pragma unroll
+                    for (int i = 0; i < CW; ++i) c[i] = row * 0x9E3779B1u + (uint32_t)i * 0x85EBCA77u;
+                    return;
+                }
                 if (row >= n_rows) row = n_rows - 1;
                 const uint32_t *p = codes32 + (int64_t)row * CW;
                 if constexpr (CW == 2) {
@@ -839,14 +854,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 }
                 if (lane == 0) lds_add_u32(lds.arrived(), 1u);
                 const unsigned long long tw = a.dbg ? __builtin_readcyclecounter() : 0ull;
-                if (a.dbg && tid == 0 && final) t_scanned = wall_clock64();
+                if (final) stamp(2);
                 epoch_sync(final);
                 if (a.dbg) t_wait += __builtin_readcyclecounter() - tw;
-                if (a.dbg && tid == 0 && final) t_synced = wall_clock64();
+                if (final) stamp(3);
                 if (final) break;
                 load_thp(thp);
             }
-            if (a.dbg && lane == 0) {  // [0] wave-steps with a candidate, [1] entries pushed, [7] wave 0's cycles at epoch ends
+            if (a.dbg && lane == 0 && !(a.dbg_skip & 8)) {  // [0] wave-steps with a candidate, [1] entries pushed, [7] wave 0's cycles at epoch ends
                 atomicAdd(a.dbg + 0, (unsigned long long)n_slow);
                 atomicAdd(a.dbg + 1, (unsigned long long)n_push);
                 if (wave == 0) atomicAdd(a.dbg + 7, t_wait);
@@ -882,6 +897,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             // [12] thread 0's step loop, [13] its wait at the last barrier (the consumer's backlog, the slower waves),
             // [14] list store + merge, [15] work items
             const unsigned long long t_end = wall_clock64();
+            const unsigned long long t_item = ldsv<unsigned long long>(stamp_ad), t_built = ldsv<unsigned long long>(stamp_ad + 8),
+                                     t_scanned = ldsv<unsigned long long>(stamp_ad + 16), t_synced = ldsv<unsigned long long>(stamp_ad + 24);
             atomicMax(a.dbg + 8, (1ull << 62) - t_item);
             atomicMax(a.dbg + 9, t_end);
             atomicAdd(a.dbg + 10, t_item);

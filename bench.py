@@ -12,16 +12,23 @@ queries, k=10.  The code table is row-sharded over the N ranks (STRONG scaling: 
 fixed), every rank scans its shard, one RCCL all-gather of [B,k] + a merge kernel gives every rank
 the global top-k.
 
-One "step" = the whole hot path for one batch: LUT build (tiled layout) -> ADC scan + per-shard
-top-k -> (N>1: all-gather + merge).  Inputs (queries, codebooks, codes) are resident in HBM before
-the timed region.  Prints ONE JSON line on rank 0 with the driver's contract fields plus
-`roofline` (dominant kernel = adc_scan_qfilter_kernel, algorithmic bytes B*N_local*M per launch over
-its HIP-event duration, vs the 8 TB/s HBM peak -- the kernel actually runs out of LDS)
-and `cpu_baseline` (the C oracle, single thread = the reference's execution model, bounded sample).
+One "step" = the whole hot path for one batch: LUT build (tiled layout) -> seed bound -> ADC scan +
+per-shard top-k -> (N>1: all-gather + merge).  Inputs (queries, codebooks, codes) are resident in HBM
+before the timed region.  Prints ONE JSON line on rank 0 with the driver's contract fields plus
+`roofline` (dominant kernel = adc_scan_q8_kernel at the headline shape: B*N_local*M table look-ups per
+launch over its HIP-event duration against the LDS look-up rate the kernel's entry width allows --
+the code rows are shared by the 32 queries of a tile, so the scan runs out of LDS, not HBM; the
+algorithmic code bytes per second and the measured HBM traffic are reported beside it, DESIGN.md
+section 7) and `cpu_baseline` (the C oracle, single thread = the reference's execution model,
+bounded sample).  Extra legs (rank 0, N=1, never `value`): `rerank` (recall target), `ivf`, and --
+with the default workload only -- `c2`, `c4`, `c5` (the other BASELINE configurations, each a
+sub-run with its own `roofline` and `cpu_baseline`) and `uniform` (the reference's own test
+distribution); `--legs` selects them.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -49,9 +56,15 @@ def parse():
     p.add_argument('--train-rows', type=int, default=20480)
     p.add_argument('--train-iters', type=int, default=20)
     p.add_argument('--recall-queries', type=int, default=128, help='queries used for recall@10 (0 = skip)')
-    p.add_argument('--cpu-queries', type=int, default=128,
-                   help='queries of the bounded single-thread CPU-baseline sample (0 = skip); 128 x 10M rows = ~5 s per run')
-    p.add_argument('--cpu-repeats', type=int, default=3, help='timed runs of the single-thread sample (median reported)')
+    p.add_argument('--cpu-queries', type=int, default=64,
+                   help='queries of the bounded single-thread CPU-baseline sample (0 = skip); 64 x 10M rows = ~2.5 s per run')
+    p.add_argument('--cpu-repeats', type=int, default=5, help='timed runs of the single-thread sample (median reported; BASELINE.md section 3: >= 5)')
+    p.add_argument('--data', choices=['lowrank', 'uniform'], default='lowrank',
+                   help='database / query distribution (SURVEY.md section 8d): lowrank = rank-16 (rank-64 above 128-d) latent Gaussian '
+                        '+ noise; uniform = U[0,1)^D, the reference\'s own test distribution (tests/test_pq_bind.py:19)')
+    p.add_argument('--legs', default='auto',
+                   help='comma list of extra legs (rank 0, N=1, never `value`): rerank, ivf, uniform, c2, c4, c5; "none"; "auto" = all '
+                        'of them for the default workload, rerank + ivf otherwise')
     p.add_argument('--metric', choices=['euclidean', 'cosine', 'inner_product'], default='euclidean',
                    help="BASELINE config 2/3: euclidean; config 4 (10M x 768, m=64, batch 256): cosine")
     p.add_argument('--streams', type=int, choices=[0, 1, 2], default=0,
@@ -68,17 +81,37 @@ def parse():
     return p.parse_args()
 
 
+UNIFORM = False  # --data uniform
+
+
 def gen_chunk(chunk: int, rows: int, D: int, A: torch.Tensor, dev) -> torch.Tensor:
     """x = z.A + 0.05 eps, z ~ N(0, I_r): identical for any number of ranks (seeded per chunk)."""
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + chunk)
+    if UNIFORM:
+        return torch.rand((rows, D), generator=g, device=dev)
     z = torch.randn((rows, A.shape[0]), generator=g, device=dev)
     e = torch.randn((rows, D), generator=g, device=dev)
     return (z @ A + 0.05 * e).contiguous()
 
 
+def sub_run(cmd, timeout_s):
+    """One of the other BASELINE configurations as a sub-run of this file / scripts/bench_hnsw.py: its JSON line, or the
+    reason it is missing."""
+    try:
+        r = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        if r.returncode != 0 or not lines:
+            return {'error': f'rc={r.returncode}', 'stderr_tail': r.stderr[-400:]}
+        return json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {'error': f'timeout after {timeout_s} s'}
+
+
 def main():
+    global UNIFORM
     args = parse()
+    UNIFORM = args.data == 'uniform'
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -96,6 +129,15 @@ def main():
 
     N, D, M, Ks, B, k = args.rows, args.dim, args.m, args.ks, args.batch, args.k
     r_lat = 16 if D <= 128 else 64
+    default_workload = (N, D, M, Ks, B, k, args.metric, args.data) == (10_000_000, 128, 16, 256, 1024, 10, 'euclidean', 'lowrank')
+    legs = args.legs.split(',') if args.legs not in ('auto', 'none') else (
+        [] if args.legs == 'none' else ['rerank', 'ivf'] + (['uniform', 'c2', 'c4', 'c5'] if default_workload else []))
+    if args.no_rerank and 'rerank' in legs:
+        legs.remove('rerank')
+    if args.ivf_cells <= 1 and 'ivf' in legs:
+        legs.remove('ivf')
+    if world > 1:
+        legs = []  # (the extra legs are single-GPU figures)
     gA = torch.Generator(device=dev)
     gA.manual_seed(99)
     A = torch.randn((r_lat, D), generator=gA, device=dev)
@@ -120,7 +162,7 @@ def main():
     # ---- build this rank's shard --------------------------------------------------------------------
     lo, hi = shard_range(N, world, rank)
     n_local = hi - lo
-    keep_vectors = not args.no_rerank
+    keep_vectors = 'rerank' in legs or world > 1 and not args.no_rerank
     index = PQFlatGpuIndex(dim=D, metric=metric, pq_codec=codec, initial_size=max(n_local, 64),
                            rerank=keep_vectors, skewed=(args.layout == 'skewed'))
     t0 = time.time()
@@ -137,9 +179,12 @@ def main():
 
     gq = torch.Generator(device=dev)
     gq.manual_seed(4321)
-    zq = torch.randn((B, r_lat), generator=gq, device=dev)
-    eq = torch.randn((B, D), generator=gq, device=dev)
-    queries = (zq @ A + 0.05 * eq).contiguous()
+    if UNIFORM:
+        queries = torch.rand((B, D), generator=gq, device=dev)
+    else:
+        zq = torch.randn((B, r_lat), generator=gq, device=dev)
+        eq = torch.randn((B, D), generator=gq, device=dev)
+        queries = (zq @ A + 0.05 * eq).contiguous()
 
     def barrier():
         if world > 1:
@@ -285,7 +330,7 @@ def main():
 
     # ---- extra leg, never `value`: the pruned (IVF) search over the same rows (SURVEY.md 8f follow-on) --------
     ivf_rec = None
-    if world == 1 and args.ivf_cells > 1 and M in (8, 16, 32, 64) and nq > 0:
+    if world == 1 and 'ivf' in legs and M in (8, 16, 32, 64) and nq > 0:
         from annlite_amd.core.codec.vq import VQCodec
         from annlite_amd.core.index.ivf_pq_gpu import IvfPQGpuIndex
 
@@ -385,6 +430,23 @@ def main():
             'gpu_matches_cpu_bit_exact': parity,
         }
 
+    # ---- the other BASELINE configurations and the reference's own test distribution, as sub-runs (rank 0, N=1) ------------
+    sub = {}
+    if rank == 0 and world == 1:
+        me = os.path.join(ROOT, 'bench.py')
+        common = ['--legs', 'none', '--gpus', '1']
+        if 'c2' in legs:  # config 2: 1M x 128, m=16, L2, batch 1024
+            sub['c2'] = sub_run([me, '--rows', '1000000', '--steps', '40', '--warmup', '10'] + common, 240)
+        if 'c4' in legs:  # config 4: 10M x 768, m=64, cosine, batch 256
+            sub['c4'] = sub_run([me, '--rows', '10000000', '--dim', '768', '--m', '64', '--batch', '256', '--metric', 'cosine',
+                                 '--steps', '20', '--warmup', '5', '--cpu-queries', '16', '--cpu-repeats', '3',
+                                 '--recall-queries', '32'] + common, 400)
+        if 'c5' in legs:  # config 5: HNSW-over-PQ, 5M x 128, ef_search 128, GPU walk + exact re-rank
+            sub['c5'] = sub_run([os.path.join(ROOT, 'scripts', 'bench_hnsw.py'), '--rows', '5000000', '--steps', '5'], 600)
+        if 'uniform' in legs:  # U[0,1)^D: unstructured codes -- the kernel the library picks for them
+            sub['uniform'] = sub_run([me, '--data', 'uniform', '--steps', '10', '--warmup', '3', '--cpu-queries', '0',
+                                      '--recall-queries', '32'] + common, 300)
+
     if rank == 0:
         # The scan does not stream its algorithmic bytes from HBM (every code row is shared by the 16 / 32 queries of a
         # tile and stays in L2): its roof is the LDS look-up rate.  One ds_read_b128 (4 LDS cycles per wave64) serves
@@ -402,6 +464,9 @@ def main():
             'bound': 'lds', 'achieved': lookups_per_s, 'peak': lds_peak, 'unit': 'look-ups/s', 'frac': lookups_per_s / lds_peak,
             'traffic': traffic,
             'kernel': kernel_name, 'kernel_ms': kernel_ms, 'lookups_per_clk_per_cu': per_clk,
+            'peak_note': 'design-relative: one ds_read_b128 (ds_read_b64 at M=64) per wave64 per 4 (2) LDS cycles x 64 lanes x the '
+                         'entries this kernel packs per read (16 one-byte entries; u16 kernels 8; M=64 4) x 256 CUs x 2.4 GHz: the '
+                         'roof of THIS table format, not a chip constant',
             # SURVEY.md 8(d)'s per-unit figure: M code bytes per (query, row) evaluation -- what a one-query-at-a-time scan
             # (the reference) streams; reported for comparison, not a fraction of anything
             'algorithmic': {'bytes_per_launch': scan_bytes, 'GB_per_s': achieved},
@@ -410,7 +475,7 @@ def main():
         rec = {
             'metric': 'queries/sec', 'value': qps, 'unit': 'queries/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic' if args.data == 'lowrank' else 'synthetic (uniform)',
             'config': {
                 'workload': f'{N} x {D}-dim float32, PQ m={M} ks={Ks}, {args.metric}, batch {B}, k={k}, exhaustive ADC scan + exact top-k',
                 'rows_total': N, 'rows_per_gpu': n_local, 'batch': B, 'k': k, 'parallelism': f'row-shard x{world}',
@@ -434,6 +499,15 @@ def main():
                                    'note': 'numpy queries in, numpy results out per batch (PCIe both ways, synchronous)'},
             'setup': {'train_s': train_s, 'index_s': index_s},
         }
+        for name, r in sub.items():  # (never `value`: the other configurations, each with its own roofline / cpu_baseline)
+            if 'error' in r:
+                rec[name] = r
+            elif name == 'c5':
+                rec[name] = {kk: r[kk] for kk in ('config', 'value', 'unit', 'recall_at_10', 'build_s', 'graph_walk_queries_per_s',
+                                                 'roofline', 'cpu_baseline', 'hnsw_gpu_walk_adc', 'exhaustive_exact_rerank') if kk in r}
+            else:
+                rec[name] = {'config': r['config']['workload'], 'value': r['value'], 'unit': r['unit'], 'ms_per_step': r['ms_per_step'],
+                             'recall_at_10': r.get('recall_at_10'), 'roofline': r['roofline'], 'cpu_baseline': r['cpu_baseline']}
         print(json.dumps(rec))
     if use_dist:
         dist.destroy_process_group()

@@ -279,6 +279,48 @@ def test_candidates_superset_and_gather(ops, oracle):
         assert np.array_equal(gd[b], want)
 
 
+@pytest.mark.parametrize('layout', [0, 1])
+def test_byte_table_candidate_lists_with_slice_bounds(ops, oracle, layout):
+    """The byte-table kernel as the candidate generator of the re-rank stage (k <= 16 per row slice, nothing shared between
+    the slices): every (query, slice) starts from its OWN first bound -- the k-th of the slice's first rows, seed_bound_kernel
+    with blockIdx.y = slice -- and its list is the exact top-k of that slice's rows, ascending, bit for bit the oracle's."""
+    import torch
+    from annlite_amd import Metric, PQCodec
+    from annlite_amd._capi import scan_plan
+
+    rs = np.random.RandomState(33)
+    N, D, M, B, k = 300_000, 128, 16, 70, 16
+    A = rs.randn(16, D).astype(np.float32)
+    x = (rs.randn(N, 16).astype(np.float32) @ A + 0.05 * rs.randn(N, D).astype(np.float32)).astype(np.float32)
+    q = (rs.randn(B, 16).astype(np.float32) @ A + 0.05 * rs.randn(B, D).astype(np.float32)).astype(np.float32)
+    codec = PQCodec(dim=D, n_subvectors=M, n_clusters=256, metric=Metric.EUCLIDEAN, n_init=1)
+    codec.seed = 4
+    codec.fit(x[:8192], iter=5)
+    codes = oracle.encode_c(x, codec.codebooks)
+    lut = oracle.get_dist_mat_c(q, codec.codebooks, oracle.EUCLIDEAN)
+    plan = scan_plan(N, M, 256, 1, B, k)
+    assert plan.qt == 32 and plan.n_slices >= 8
+    codes_d = ops.to_dev(codes)
+    if layout == 1:
+        codes_d = ops.codes_skew(codes_d)
+    lut_t = ops.lut_retile(ops.to_dev(lut), plan.qi)
+    valid = np.ones(N, dtype=bool)
+    valid[rs.randint(0, N, size=N // 50)] = False  # deleted rows: inside the seed rows of the slices too
+    bits = np.packbits(np.concatenate([valid, np.zeros((-N) % 32 + 64, dtype=bool)]), bitorder='little').view(np.int32)
+    cd, ci = ops.adc_scan_candidates(codes_d, lut_t, B, k, M, 256, valid_bits=ops.to_dev(bits), codes_layout=layout)
+    torch.cuda.synchronize()
+    cd, ci = cd.cpu().numpy(), ci.cpu().numpy()
+    ns = plan.n_slices
+    assert ci.shape == (B, ns * k)
+    rows = ((N + ns - 1) // ns + 63) // 64 * 64
+    for sl in range(ns):
+        a, b = sl * rows, min(N, (sl + 1) * rows)
+        keep = np.nonzero(valid[a:b])[0]
+        rd, ri = oracle.adc_search_c(lut, codes[a:b][keep], k)
+        assert np.array_equal(cd[:, sl * k:(sl + 1) * k], rd), sl
+        assert np.array_equal(ci[:, sl * k:(sl + 1) * k], keep[ri] + a), sl
+
+
 def test_topk_merge_and_rows(ops, oracle):
     rs = np.random.RandomState(8)
     G, B, k = 8, 33, 10
