@@ -154,19 +154,22 @@ __device__ __forceinline__ void q8_build_table(const Q8Build &a, int tile, uint3
     }
 }
 
-constexpr int kRingSize = 1024;  // candidate ring entries (u64 each)
+constexpr int kRingSize = 1024;   // candidate ring entries (u64 each): one private ring of kWaveRing entries per scanning wave
+constexpr int kWaveRing = 64;     // (a wave-step pushes at most 64 entries at a time)
+constexpr int kPopPerRing = 8;    // entries the consumer takes from one wave's ring per batch (8 x 15 rings <= 128 = two per lane)
 
 // LDS map of a workgroup (absolute LDS byte addresses): [table Ks * 512][what follows]
 //   shq      u8 [32]   current filter bound (0x80 | T) of every slot -- what the scanning waves load as thp
-//   ring_ctl u32: +0 tail (entries reserved by the scanning waves), +4 head (entries consumed), +8 arrived (scanning waves that
-//            finished an epoch, cumulative), +64 the block counter the scanning waves draw from, +96 u64 [4] debug phase stamps
+//   ring_ctl u32: +0 arrived (scanning waves that finished an epoch, cumulative), +4 the block counter the scanning waves draw
+//            from, +16 tails [16] (entries wave w has pushed, mod 2^16: written by wave w only), +80 heads [16] (entries of wave
+//            w's ring consumed: written by the consumer only)
 //   gkl      u64 [32]  best bound known for the slot (own k-th key or imported)
 //   step / inv / clip f32 [32], tb u8 [32] (T the table was built for), ctl u32 (+0 rebuild flag, +4 merge flag)
 //   tau      u64 [32]  the k-th key the consumer last published; c0, c1 f64 [32]: T = floor(thr * c1 + c0) + 1 (q8_bound)
 //   list     u64 [32][16] the 16 smallest keys of every slot, ascending; gjl u64 [32] the j-th key last published
-//   ring     u64 [kRingSize] (~0 = not written yet); qkey u64 [4][128], qslot u8 [4][128] insertion queues; chg u8 [32]
+//   ring     u64 [16][kWaveRing]; qkey u64 [4][128], qslot u8 [4][128] insertion queues; chg u8 [32]; stamps u64 [4] (debug)
 struct Q8Lds {
-    uint32_t tab, shq, ring_ctl, gkl, step, inv, tb, ctl, clip, tau, c0, c1, list, gjl, ring, qkey, qslot, chg;
+    uint32_t tab, shq, ring_ctl, gkl, step, inv, tb, ctl, clip, tau, c0, c1, list, gjl, ring, qkey, qslot, chg, stamps;
     __device__ __forceinline__ explicit Q8Lds(int lut_bytes) {
         tab = lds_base_addr();
         shq = tab + (uint32_t)lut_bytes;
@@ -186,11 +189,12 @@ struct Q8Lds {
         qkey = ring + kRingSize * 8;
         qslot = qkey + 4 * 128 * 8;
         chg = qslot + 4 * 128;
+        stamps = chg + 32;
     }
-    __device__ __forceinline__ uint32_t tail() const { return ring_ctl; }
-    __device__ __forceinline__ uint32_t head() const { return ring_ctl + 4; }
-    __device__ __forceinline__ uint32_t arrived() const { return ring_ctl + 8; }
-    __device__ __forceinline__ uint32_t blk_ctr() const { return ring_ctl + 64; }
+    __device__ __forceinline__ uint32_t arrived() const { return ring_ctl; }
+    __device__ __forceinline__ uint32_t blk_ctr() const { return ring_ctl + 4; }
+    __device__ __forceinline__ uint32_t tails() const { return ring_ctl + 16; }
+    __device__ __forceinline__ uint32_t heads() const { return ring_ctl + 80; }
 };
 
 // What the consumer wave keeps per slot (LDS): the 16 smallest keys (ordered distance << 32 | row) seen so far,
@@ -247,23 +251,10 @@ __device__ __forceinline__ void q8_publish_global(const FlushCtx &c, const Q8Lds
 }
 
 template <int M, bool SKEWED>
-__device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, uint32_t head, int n, int lane, uint32_t &n_kept,
-                                           uint32_t &n_offered, unsigned long long &pend_o, unsigned long long &pend_j) {
+__device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, const unsigned long long (&e)[2], bool (&act)[2],
+                                           int lane, uint32_t &n_kept, uint32_t &n_offered, unsigned long long &pend_o,
+                                           unsigned long long &pend_j) {
     constexpr int CW = M / 4;
-    unsigned long long e[2];
-    bool act[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        act[u] = lane + 64 * u < n;
-        const uint32_t slot = o.ring + 8u * ((head + 64u * u + (uint32_t)lane) & (kRingSize - 1));
-        e[u] = ~0ull;
-        // (reserved but not written yet: its producer is between the reservation and the store)
-        while (__ballot(act[u] && e[u] == ~0ull)) {
-            if (act[u] && e[u] == ~0ull) e[u] = ldsv<unsigned long long>(slot);
-        }
-        if (act[u]) ldsv_st<unsigned long long>(slot, ~0ull);
-    }
-    ldsv_st<uint32_t>(o.head(), head + (uint32_t)n);  // the producers may overwrite the slots from here on
     int q[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -472,7 +463,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
         __syncthreads();  // every wave is done with the previous item
         // ANNLITE_DEBUG_COUNTERS: phase stamps of thread 0 (100 MHz wall clock; kept in LDS: four live 64-bit values pushed the
         // step loop over its register budget), summed over the work items in dbg[8..15]
-        const uint32_t stamp_ad = lds.ring_ctl + 96;  // u64 [4] in the unused part of the ring-control block
+        const uint32_t stamp_ad = lds.stamps;
         auto stamp = [&](int i) {
             if (a.dbg && tid == 0) ldsv_st<unsigned long long>(stamp_ad + 8u * (uint32_t)i, wall_clock64());
         };
@@ -498,10 +489,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             }
         };
         for (int idx = tid; idx < QT * 16; idx += NW * 64) ldsv_st<unsigned long long>(lds.list + 8u * (uint32_t)idx, ~0ull);
-        for (int idx = tid; idx < kRingSize; idx += NW * 64) ldsv_st<unsigned long long>(lds.ring + 8u * (uint32_t)idx, ~0ull);
+        if (tid < 16) {
+            ldsv_st<uint32_t>(lds.tails() + 4u * (uint32_t)tid, 0);
+            ldsv_st<uint32_t>(lds.heads() + 4u * (uint32_t)tid, 0);
+        }
         if (tid == 0) {
-            ldsv_st<uint32_t>(lds.tail(), 0);
-            ldsv_st<uint32_t>(lds.head(), 0);
             ldsv_st<uint32_t>(lds.arrived(), 0);
             ldsv_st<uint32_t>(lds.blk_ctr(), 0);  // the block counter the scanning waves draw from
         }
@@ -592,7 +584,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     if (nb < ldsv<unsigned char>(lds.shq + (uint32_t)q)) ldsv_st<unsigned char>(lds.shq + (uint32_t)q, nb);
                 }
             };
-            uint32_t head = 0, n_kept = 0, n_offered = 0;
+            // Every scanning wave pushes into its OWN ring of kWaveRing entries (it alone writes the ring and its tail, the
+            // consumer alone the head): no reservation, no atomics -- with one shared ring a push was an LDS atomic with return
+            // plus a read of the head, two round trips through an LDS queue full of look-ups, during which the pushing wave
+            // issued nothing (a quarter of the wave-steps at 1.25M rows x 1024 queries push).  Lane j < 60 serves ring j % 15,
+            // entries j / 15 and j / 15 + 4 past the head: up to kPopPerRing entries per ring and batch, no cross-lane traffic.
+            const int my_ring = lane % NS, my_i = lane / NS;  // (lanes >= 4 * NS: no ring)
+            const bool has_ring = lane < 4 * NS;
+            uint32_t head_v = 0;  // consumed entries of my_ring (the same value in the four lanes that serve it)
+            uint32_t n_kept = 0, n_offered = 0;
             unsigned long long pend_o = ~0ull, pend_j = ~0ull;  // bounds not yet published to the other workgroups (lane = slot)
             unsigned long long t_busy = 0;
             uint32_t n_batches = 0;
@@ -603,21 +603,31 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 int idle = 0;
                 import_bounds();
                 for (;;) {
-                    const uint32_t arrived = ldsv<uint32_t>(lds.arrived());  // (read BEFORE the tail: a wave pushes, then arrives)
-                    const uint32_t tail = ldsv<uint32_t>(lds.tail());
-                    const int avail = (int)(tail - head);
+                    const uint32_t arrived = ldsv<uint32_t>(lds.arrived());  // (read BEFORE the tails: a wave pushes, then arrives)
+                    const uint32_t tail_v = has_ring ? ldsv<uint32_t>(lds.tails() + 4u * (uint32_t)my_ring) : 0u;
+                    const uint32_t avail = has_ring ? ((tail_v - head_v) & 0xffffu) : 0u;
+                    const bool any = __ballot(avail > 0) != 0;
                     // A non-final epoch does not wait for the backlog: the scanning waves stand at the barrier, what is in the
-                    // ring is taken in the next epoch (only the last epoch's end needs every candidate in the lists)
+                    // rings is taken in the next epoch (only the last epoch's end needs every candidate in the lists)
                     if (arrived == want && !final) break;
-                    if (avail > 0) {  // (waiting for fuller batches -- 32 .. 128 candidates -- changed nothing: +-1 %)
-                        const int n = avail < 128 ? avail : 128;
+                    if (any) {
                         const unsigned long long t0 = a.dbg ? __builtin_readcyclecounter() : 0ull;
                         __builtin_amdgcn_s_setprio(3);  // (serial code on a SIMD shared with three or four scanning waves)
-                        q8_consume<M, SKEWED>(fc, lds, head, n, lane, n_kept, n_offered, pend_o, pend_j);
+                        unsigned long long e[2];
+                        bool act[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const uint32_t i = (uint32_t)(my_i + 4 * u);
+                            act[u] = i < avail;
+                            e[u] = 0ull;
+                            if (act[u]) e[u] = ldsv<unsigned long long>(lds.ring + 8u * ((uint32_t)my_ring * kWaveRing + ((head_v + i) & (kWaveRing - 1))));
+                        }
+                        head_v = (head_v + (avail < (uint32_t)kPopPerRing ? avail : (uint32_t)kPopPerRing)) & 0xffffu;
+                        if (lane < NS) ldsv_st<uint32_t>(lds.heads() + 4u * (uint32_t)lane, head_v);  // the wave may reuse the entries
+                        q8_consume<M, SKEWED>(fc, lds, e, act, lane, n_kept, n_offered, pend_o, pend_j);
                         __builtin_amdgcn_s_setprio(0);
                         ++n_batches;
                         if (a.dbg) t_busy += __builtin_readcyclecounter() - t0;
-                        head += (uint32_t)n;
                         idle = 0;
                         if ((n_batches & (uint32_t)a.q8_import_mask) == 0) import_bounds();  // (the other slices' progress)
                         continue;
@@ -627,15 +637,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     __builtin_amdgcn_s_sleep(4);
                 }
                 q8_publish_global(fc, lds, lane, pend_o, pend_j);
-                const uint32_t tail_now = ldsv<uint32_t>(lds.tail());  // (every scanning wave has arrived: its pushes are complete)
                 epoch_sync(final);
                 if (final) break;
                 if (ldsv<uint32_t>(lds.ctl)) {
                     // the table was rebuilt: the integer sums of the waiting candidates are in the OLD table's steps --
-                    // clear them, so that the stale-candidate check lets them through to the exact sum
-                    for (uint32_t i = head + (uint32_t)lane; (int)(tail_now - i) > 0; i += 64u) {
-                        const uint32_t ad = lds.ring + 8u * (i & (kRingSize - 1));
-                        ldsv_st<unsigned long long>(ad, ldsv<unsigned long long>(ad) & ~(0xffull << 40));
+                    // clear them, so that the stale-candidate check lets them through to the exact sum (every scanning wave has
+                    // arrived: its pushes are complete)
+                    if (has_ring) {
+                        const uint32_t tail_v = ldsv<uint32_t>(lds.tails() + 4u * (uint32_t)my_ring);
+                        for (uint32_t i = (uint32_t)my_i; i < ((tail_v - head_v) & 0xffffu); i += 4u) {
+                            const uint32_t ad = lds.ring + 8u * ((uint32_t)my_ring * kWaveRing + ((head_v + i) & (kWaveRing - 1)));
+                            ldsv_st<unsigned long long>(ad, ldsv<unsigned long long>(ad) & ~(0xffull << 40));
+                        }
                     }
                 }
                 ++epoch;
@@ -766,6 +779,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             // epochs' barriers meet).  The step loop of an epoch contains no call and no barrier: the loop-invariant
             // registers stay put.
             uint32_t it_no = 0;
+            uint32_t rs = 0;  // (pushed entries) | (consumed entries, as last read) << 16 of this wave's ring, both mod 2^16
             uint32_t n_slow = 0, n_push = 0;
             unsigned long long t_wait = 0;
             for (int epoch_step = a.q8_epoch0;; epoch_step = a.q8_epoch_mul * epoch_step + (a.q8_epoch_mul - 1)) {
@@ -812,14 +826,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                         int n = 0;
                         for (;;) {
                             if (n > 32 || (n > 0 && !rem)) {  // (a lane adds at most 32 entries)
-                                uint32_t pos = 0;
-                                if (lane == 0) pos = lds_add_u32(lds.tail(), (uint32_t)n);
-                                pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
-                                while ((int)(pos + (uint32_t)n - ldsv<uint32_t>(lds.head())) > a.q8_ring_limit)  // the consumer is behind
+                                // into the wave's own ring: entries [tail, tail + n), then the new tail (LDS executes a wave's
+                                // instructions in order).  The head is re-read only when the cached one says the ring is full.
+                                uint32_t tl = rs & 0xffffu, hd = rs >> 16;
+                                while (((tl + (uint32_t)n - hd) & 0xffffu) > (uint32_t)kWaveRing) {  // the consumer is behind
+                                    hd = ldsv<uint32_t>(lds.heads() + 4u * (uint32_t)wave) & 0xffffu;
+                                    if (((tl + (uint32_t)n - hd) & 0xffffu) <= (uint32_t)kWaveRing) break;
                                     __builtin_amdgcn_s_sleep(8);
+                                }
                                 if (lane < n)
-                                    ldsv_st<unsigned long long>(lds.ring + 8u * ((pos + (uint32_t)lane) & (kRingSize - 1)),
+                                    ldsv_st<unsigned long long>(lds.ring + 8u * ((uint32_t)wave * kWaveRing + ((tl + (uint32_t)lane) & (kWaveRing - 1))),
                                                                 ((unsigned long long)e_hi << 32) | e_lo);
+                                tl = (tl + (uint32_t)n) & 0xffffu;
+                                if (lane == 0) ldsv_st<uint32_t>(lds.tails() + 4u * (uint32_t)wave, tl);
+                                rs = tl | (hd << 16);
                                 n_push += (uint32_t)n;
                                 n = 0;
                             }
@@ -918,7 +938,7 @@ using namespace annlite;
 template <int M, int NW, bool SKEWED>
 static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
     constexpr int QT = 32;
-    const size_t need = (size_t)a.Ks * 2 * M * 16 + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32;
+    const size_t need = (size_t)a.Ks * 2 * M * 16 + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32 + 32;
     auto fn = adc_scan_q8_kernel<M, NW, SKEWED>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
