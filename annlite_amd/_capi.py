@@ -31,7 +31,10 @@ SYMBOLS = (
     'annlite_hip_device_arch',
     'annlite_scan_plan_query',
     'annlite_scan_plan_tiles',
-    'annlite_scan_select_variant',
+    'annlite_scan_state_create',
+    'annlite_scan_state_destroy',
+    'annlite_scan_state_reset',
+    'annlite_scan_state_info',
     'annlite_lut_build',
     'annlite_lut_retile',
     'annlite_adc_dist',
@@ -42,6 +45,7 @@ SYMBOLS = (
     'annlite_adc_scan_topk_packed',
     'annlite_pq_search_workspace_bytes',
     'annlite_pq_search_topk',
+    'annlite_pq_search_topk_ex',
     'annlite_adc_scan_candidates',
     'annlite_topk_merge',
     'annlite_topk_merge_packed',
@@ -64,6 +68,7 @@ SYMBOLS = (
     'annlite_profile_last_scan_ms',
     'annlite_debug_counters',
     'annlite_debug_timeline',
+    'annlite_debug_items',
 )
 
 
@@ -118,6 +123,12 @@ def lib() -> ctypes.CDLL:
     L.annlite_pq_search_workspace_bytes.argtypes = [i64, i64, i64, i32, i64, i64, ctypes.POINTER(ctypes.c_int64)]
     L.annlite_pq_search_topk.argtypes = [i32, vp, i64, i64, vp, vp, i32, i32, i64, i64, i64, vp, i64, i64, vp, vp, vp, i32,
                                          vp, sz, vp]
+    L.annlite_pq_search_topk_ex.argtypes = L.annlite_pq_search_topk.argtypes + [vp]
+    L.annlite_scan_state_create.argtypes = [ctypes.POINTER(vp)]
+    L.annlite_scan_state_destroy.argtypes = [vp]
+    L.annlite_scan_state_reset.argtypes = [vp]
+    L.annlite_scan_state_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64),
+                                          ctypes.POINTER(ctypes.c_uint64)]
     L.annlite_topk_merge.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
     L.annlite_topk_merge_packed.argtypes = [vp, i64, i64, i64, vp, vp, i32, vp]
     L.annlite_topk_rows.argtypes = [vp, i64, i64, i64, i64, vp, vp, vp]
@@ -138,10 +149,10 @@ def lib() -> ctypes.CDLL:
     L.annlite_ivf_rescore.argtypes = [vp, i64, i64, i64, vp, i64, vp, vp, i64, vp, vp, i64, vp, i64, vp, i64, i64, vp,
                                       vp, i32, vp]
     L.annlite_profile_enable.argtypes = [i32]
-    L.annlite_scan_select_variant.argtypes = [i32]
     L.annlite_profile_last_scan_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]
     L.annlite_debug_counters.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     L.annlite_debug_timeline.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    L.annlite_debug_items.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
     L.annlite_graph_search_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     for name in SYMBOLS:
         fn = getattr(L, name)  # AttributeError here == the .so does not export a declared symbol
@@ -207,9 +218,41 @@ def scan_plan_tiles(N: int, M: int, Ks: int, code_bytes: int, V: int, k: int) ->
     return p
 
 
-def scan_select_variant(variant: int) -> None:
-    """Kernel selection on the calling thread (-1: default / environment); see ``annlite_scan_select_variant``."""
-    check(lib().annlite_scan_select_variant(int(variant)), 'scan_select_variant')
+class ScanState:
+    """The caller-owned, per-code-table memory of the library's kernel choice (``annlite_scan_state``): which of the two
+    M = 16 scan kernels suits the table is measured by the launches themselves and read back from host-mapped memory by
+    the next calls.  One per index; not for two threads at once."""
+
+    KERNELS = {0: 'undecided', 1: 'byte tables', 2: 'u16 tables'}
+
+    def __init__(self):
+        p = ctypes.c_void_p()
+        check(lib().annlite_scan_state_create(ctypes.byref(p)), 'scan_state_create')
+        self._p = p
+
+    @property
+    def ptr(self):
+        return self._p
+
+    def reset(self):
+        check(lib().annlite_scan_state_reset(self._p), 'scan_state_reset')
+
+    def info(self):
+        """(kernel: 0 undecided / 1 byte tables / 2 u16 tables, rows it was decided at, candidates of the deciding launch)"""
+        kern, rows, cand = ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_uint64(0)
+        check(lib().annlite_scan_state_info(self._p, ctypes.byref(kern), ctypes.byref(rows), ctypes.byref(cand)), 'scan_state_info')
+        return int(kern.value), int(rows.value), int(cand.value)
+
+    def __del__(self):
+        try:
+            if self._p:
+                import torch
+
+                torch.cuda.synchronize()  # (launches that were given the state may still write its block)
+                lib().annlite_scan_state_destroy(self._p)
+                self._p = None
+        except Exception:
+            pass
 
 
 def profile_enable(on: bool) -> None:
@@ -239,6 +282,17 @@ def debug_timeline():
     t0 = (1 << 62) - v[0]
     return {'items': v[7], 'span_us': (v[1] - t0) / 100.0, 'avg_start_us': (v[2] / n - t0) / 100.0,
             'build_us': v[3] / n / 100.0, 'scan_us': v[4] / n / 100.0, 'wait_us': v[5] / n / 100.0, 'merge_us': v[6] / n / 100.0}
+
+
+def debug_items():
+    """Per-work-item records of the byte-table kernel (``annlite_debug_items``): int64 array [n, 8] = tile, slice, five
+    100 MHz stamps (start, table built, step loop left, last barrier passed, end), block index."""
+    import numpy as np
+
+    buf = (ctypes.c_uint64 * (4096 * 8))()
+    n = ctypes.c_int64(0)
+    check(lib().annlite_debug_items(buf, 4096, ctypes.byref(n)), 'debug_items')
+    return np.frombuffer(buf, dtype=np.uint64)[: n.value * 8].reshape(-1, 8).astype(np.int64)
 
 
 def debug_counters():

@@ -45,6 +45,8 @@ class PQCodec(BaseCodec):
     :param n_init: number of k-means restarts in :meth:`fit`; the best run per sub-space is kept
     """
 
+    SEED_ROWS_PER_CENTRE = 256  # k-means++ seeding looks at no more than this many rows per centre (see _kmeanspp_centres)
+
     def __init__(
         self,
         dim: int,
@@ -127,7 +129,8 @@ class PQCodec(BaseCodec):
     def _random_centres(self, x: torch.Tensor, gen: torch.Generator) -> torch.Tensor:
         N = x.shape[0]
         M, Ks, ds = self.n_subvectors, self.n_clusters, self.d_subvector
-        assert N >= Ks, f'n_samples={N} should be >= n_clusters={Ks}'  # sklearn raises ValueError here
+        if N < Ks:  # sklearn: ValueError (pq.py:106-110 -> KMeans.fit)
+            raise ValueError(f'n_samples={N} should be >= n_clusters={Ks}.')
         cb = torch.empty((M, Ks, ds), dtype=torch.float32, device=x.device)
         for m in range(M):
             idx = torch.randperm(N, generator=gen, device=x.device)[:Ks]
@@ -138,10 +141,17 @@ class PQCodec(BaseCodec):
         """k-means++ seeding (sklearn's default ``init`` behind pq.py:106-110), all M sub-spaces at once: every next
         centre is drawn with probability proportional to the squared distance to the nearest centre chosen so far,
         the best of ``2 + log(Ks)`` draws per step (sklearn's greedy variant).  Batched tensor ops on the device, no
-        host synchronisation inside the Ks steps."""
-        N = x.shape[0]
+        host synchronisation inside the Ks steps.  Seeding runs on at most ``SEED_ROWS_PER_CENTRE * Ks`` rows drawn at
+        random (65 536 at Ks = 256): every step materialises [M, trials, rows] temporaries -- on the whole of a large training
+        set that was gigabytes per step, 255 times, and ``torch.multinomial`` refuses more than 2^24 categories; a seeding
+        only needs to see every region of the data, Lloyd's iterations then run on ALL rows."""
         M, Ks, ds = self.n_subvectors, self.n_clusters, self.d_subvector
-        assert N >= Ks, f'n_samples={N} should be >= n_clusters={Ks}'  # sklearn raises ValueError here
+        if x.shape[0] < Ks:  # sklearn: ValueError (pq.py:106-110 -> KMeans.fit)
+            raise ValueError(f'n_samples={x.shape[0]} should be >= n_clusters={Ks}.')
+        cap = self.SEED_ROWS_PER_CENTRE * Ks
+        if x.shape[0] > cap:
+            x = x[torch.randperm(x.shape[0], generator=gen, device=x.device)[:cap]]
+        N = x.shape[0]
         dev = x.device
         xs = x.reshape(N, M, ds).permute(1, 0, 2).contiguous()  # [M, N, ds]
         x2 = (xs * xs).sum(2)  # [M, N]

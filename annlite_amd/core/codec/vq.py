@@ -123,7 +123,8 @@ class VQCodec(BaseCodec):
         x = ops.to_dev(x, torch.float32)
         N, D = x.shape
         C = self.n_clusters
-        assert N >= C, f'n_samples={N} should be >= n_clusters={C}'
+        if N < C:  # sklearn: ValueError
+            raise ValueError(f'n_samples={N} should be >= n_clusters={C}.')
         gen = torch.Generator(device=x.device)
         if self.seed is not None:
             gen.manual_seed(int(self.seed))

@@ -36,6 +36,7 @@ from .pq_flat_gpu import PQFlatGpuIndex
 
 
 class IvfPQGpuIndex(PQFlatGpuIndex):
+    R_CAP = 4096  # rows a query re-ranks at most (float re-rank of a pruned search)
     def __init__(self, dim: int, pq_codec: Optional[PQCodec] = None, vq_codec: Optional[VQCodec] = None,
                  n_probe: Optional[int] = None, **kwargs):
         super().__init__(dim, pq_codec=pq_codec, **kwargs)
@@ -193,23 +194,40 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
         # float re-rank: every row the integer scan let through (a superset of each probed cell's ADC top-k, 3-4 k
         # rows per list) is scored exactly on the stored vectors
         cnt = count.to(torch.int64)[slot_of.to(torch.int64)]  # [B, P]; an overflowed list counts 0xffffffff (-1 as int32)
-        overflow = bool((cnt < 0).any().item())
-        if overflow:
-            # a list that overflowed holds only part of its cell (many ties / a loose bound): take the candidates from the
-            # exact path instead -- ivf_rescore walks an overflowed cell completely -- i.e. the ADC top-k of the probed cells
+        over_rows = (cnt < 0).any(dim=1)                      # queries with a list that holds only part of its cell
+        per_query = torch.where(cnt < 0, torch.zeros_like(cnt), cnt).sum(dim=1)
+        # ONE host round trip per batch: the widest candidate row and whether any list overflowed.  R is bounded: a query
+        # re-ranks at most R_CAP rows (default 4096 = 8 x the ~540 a 16-cell probe emits at k = 10; beyond it the lists of
+        # the later cells are cut, never the exact ADC top-k of the affected rows below)
+        stats = torch.stack([per_query.max(), over_rows.any().to(torch.int64)]).cpu()
+        R = max(min(int(stats[0]), self.R_CAP), k)
+        ids = ops.ivf_candidate_ids(cand, count, slot_of, R, self._row_ids)  # (an overflowed list contributes nothing)
+        if bool(stats[1]):
+            # a list that overflowed (many ties / a loose bound): THOSE QUERIES take their candidates from the exact path
+            # as well -- ivf_rescore walks an overflowed cell completely: the ADC top-k of the probed cells -- merged into
+            # their row; the other queries of the batch keep their wide candidate set (recall does not depend on who shares
+            # the batch)
             lut = self.pq_codec.get_dist_mat(q)
-            _, ids = ops.ivf_rescore(lut, self._table_plain, cand, count, slot_of, tile_rows, qt, k, self._row_ids, bits,
-                                     sqrt=False)
-        else:
-            R = max(int(cnt.sum(dim=1).max().item()), k)  # every emitted row, none dropped
-            ids = ops.ivf_candidate_ids(cand, count, slot_of, R, self._row_ids)
+            _, ids_x = ops.ivf_rescore(lut, self._table_plain, cand, count, slot_of, tile_rows, qt, k, self._row_ids, bits,
+                                       sqrt=False)
+            kx = ids_x.shape[1]
+            if R < kx + 1:
+                ids = torch.cat([ids, torch.full((ids.shape[0], kx + 1 - R), -1, dtype=ids.dtype, device=ids.device)], dim=1)
+            # the exact ids go in front; what the lists emitted follows (duplicates are harmless for a top-k by position:
+            # equal distances, the first position wins; they are dropped below)
+            merged = torch.cat([ids_x, ids], dim=1)
+            dup = (merged[:, kx:, None] == ids_x[:, None, :]).any(dim=2)
+            merged[:, kx:] = torch.where(dup, torch.full_like(merged[:, kx:], -1), merged[:, kx:])
+            ids = torch.where(over_rows[:, None], merged, torch.cat([ids, torch.full_like(ids_x, -1)], dim=1))
         exact = ops.exact_gather_dist(int(self.metric), q, self._vectors, ids)
-        kk = min(k_out, 64)
-        d, pos = ops.topk_rows(exact, kk)
+        d, pos = self._topk_rows_any(exact, min(k_out, ids.shape[1]))  # (k_out > 64: a stable device sort, never cut silently)
         i = torch.gather(ids, 1, pos.clamp(min=0))
         i = torch.where((pos < 0) | torch.isinf(d), torch.full_like(i, -1), i)
         if self.metric == Metric.EUCLIDEAN:
             d = torch.sqrt(d)
+        if d.shape[1] < k_out:
+            d = torch.cat([d, torch.full((d.shape[0], k_out - d.shape[1]), float('inf'), device=d.device)], dim=1)
+            i = torch.cat([i, torch.full((i.shape[0], k_out - i.shape[1]), -1, dtype=torch.int64, device=i.device)], dim=1)
         return d, i
 
     # ------------------------------------------------------------------ persistence

@@ -29,7 +29,7 @@ import numpy as np
 import torch
 
 from ... import ops
-from ..._capi import CODES_PLAIN, CODES_SKEWED, scan_plan, scan_select_variant
+from ..._capi import CODES_PLAIN, CODES_SKEWED, ScanState, scan_plan
 from ...enums import ExpandMode, Metric
 from ...math import l2_normalize_host
 from ..codec.pq import PQCodec
@@ -64,7 +64,7 @@ class PQFlatGpuIndex(BaseIndex):
         self._valid_bits_cache = None
         self._vectors = None
         self._n_rows = 0
-        self._kernel = None  # (variant, rows it was measured at) -- see _with_kernel
+        self._scan_state = None  # the library's per-table kernel choice (created with the device storage)
         if index_file:
             self.load(index_file)
 
@@ -134,7 +134,8 @@ class PQFlatGpuIndex(BaseIndex):
     def _scan_inputs(self, x, q: torch.Tensor):
         """(LUT kind, queries as the table build sees them): ``PQCodec.get_dist_mat`` normalises cosine queries a second
         time (pq.py:309-310); for host buffers that happens on the host too, in the reference's arithmetic."""
-        if isinstance(x, np.ndarray) and self.metric == Metric.COSINE:
+        # (what the table build normalises is the CODEC's business -- pq.py:67-69 normalize_input --, not the index metric's)
+        if isinstance(x, np.ndarray) and self.pq_codec.normalize_input:
             kind, _ = self.pq_codec.scan_inputs(q[:0])
             return kind, ops.to_dev(l2_normalize_host(l2_normalize_host(
                 np.ascontiguousarray(x.reshape(1, -1) if x.ndim == 1 else x, dtype=np.float32))), torch.float32)
@@ -203,7 +204,8 @@ class PQFlatGpuIndex(BaseIndex):
         self._valid_bits_cache = None
         self._vectors = None
         self._n_rows = 0
-        self._kernel = None
+        if self._scan_state is not None:
+            self._scan_state.reset()
 
     @property
     def size(self):
@@ -218,41 +220,21 @@ class PQFlatGpuIndex(BaseIndex):
         return self._pack_bits(sel & self._valid_bool)
 
     # ------------------------------------------------------------------ kernel choice
-    # The byte-table scan kernel (M = 16, k <= 16: twice the queries per LDS read) filters with 4-bit entries: on
-    # data with structure -- what PQ is for -- a handful of rows per query pass, on data without any (independent
-    # uniform codes, as some tests and micro-benchmarks use) its filter leaks and the u16-table kernel is several
-    # times faster.  Which one serves THIS table is measured, not guessed: the first large batch runs both (their
-    # results are bit-identical) and the faster one is kept until the table has doubled.
-    _CALIBRATE_MIN_ROWS, _CALIBRATE_MIN_BATCH = 200_000, 32
+    # Which M = 16 scan kernel serves this table -- byte filter tables (data with structure: what PQ is for) or u16 filter
+    # tables (independent uniform codes: the byte filter leaks) -- is decided INSIDE the library, from what its own launches
+    # measure (annlite_hip.h: annlite_scan_state): the first call(s) run the byte-table kernel guarded, later calls read
+    # the verdict from the state's host-mapped block.  No calibration runs, no extra latency on a user's query, and
+    # ANNLITE_SCAN_VARIANT in the environment still overrides everything for A/B measurements.
+    @property
+    def scan_state(self) -> ScanState:
+        if self._scan_state is None:
+            self._scan_state = ScanState()
+        return self._scan_state
 
-    def _with_kernel(self, run, B: int, N: int, k: int):
-        if not (self.M == 16 and self.code_bytes == 1 and self.Ks <= 256 and k <= 16):
-            return run()
-        if self._kernel is not None and N < 2 * self._kernel[1]:
-            scan_select_variant(self._kernel[0])
-            try:
-                return run()
-            finally:
-                scan_select_variant(-1)
-        if N < self._CALIBRATE_MIN_ROWS or B < self._CALIBRATE_MIN_BATCH:
-            return run()
-        best, out = None, None
-        try:
-            for variant in (50, 31):  # byte tables, u16 tables
-                scan_select_variant(variant)
-                run()  # (first call of a shape: module load, workspace allocation)
-                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                t0.record()
-                res = run()
-                t1.record()
-                t1.synchronize()
-                ms = t0.elapsed_time(t1)
-                if best is None or ms < best[1]:
-                    best, out = (variant, ms), res
-        finally:
-            scan_select_variant(-1)
-        self._kernel = (best[0], N)
-        return out
+    @property
+    def scan_kernel(self) -> str:
+        """'undecided' | 'byte tables' | 'u16 tables' -- what the library has settled on for this table"""
+        return ScanState.KERNELS[self.scan_state.info()[0]] if self._scan_state is not None else 'undecided'
 
     def search_batch(self, x, limit: int = 10, indices=None, rerank_k: Optional[int] = None, row_base: int = 0
                      ) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -279,10 +261,11 @@ class PQFlatGpuIndex(BaseIndex):
             # table build + scan + top-k: one C call (annlite_pq_search_topk)
             kind, xq = self._scan_inputs(x, q)
             base = row_base
-            d, i = self._with_kernel(lambda: ops.pq_search_topk(
+            d, i = ops.pq_search_topk(
                 kind, xq, self.pq_codec.codebooks_dev, self._codes, k, self.M, self.Ks, valid_bits=valid, n_rows=N,
                 codes_layout=self._layout(), workspace=self._ws, row_base=base,
-                sqrt=self.metric == Metric.EUCLIDEAN), B, N, k)  # hnsw/index.py:164-165
+                sqrt=self.metric == Metric.EUCLIDEAN,  # hnsw/index.py:164-165
+                state=self.scan_state if indices is None else None)  # (a filtered call says nothing about the table)
             row_base = 0
         else:
             d, i = self._search_large_k(q, k, valid, N, self._scan_inputs(x, q))
@@ -307,9 +290,9 @@ class PQFlatGpuIndex(BaseIndex):
             out[..., 1] = 0x7F800000  # +inf
             return out
         kind, xq = self._scan_inputs(x, q)
-        return self._with_kernel(lambda: ops.pq_search_topk(
+        return ops.pq_search_topk(
             kind, xq, self.pq_codec.codebooks_dev, self._codes, k, self.M, self.Ks, valid_bits=self._valid,
-            row_base=row_base, n_rows=N, codes_layout=self._layout(), workspace=self._ws, packed=True), B, N, k)
+            row_base=row_base, n_rows=N, codes_layout=self._layout(), workspace=self._ws, packed=True, state=self.scan_state)
 
     @property
     def sqrt_epilogue(self) -> bool:
@@ -362,7 +345,7 @@ class PQFlatGpuIndex(BaseIndex):
         B = q.shape[0]
         # candidates per row slice: 16 where the byte-table kernel generates them (M = 16: 8 slices x 16 keys = 128 per query
         # at 1024 queries; its lists hold 16 keys), 64 otherwise (u16-table kernels)
-        byte_tables = self.M == 16 and self.code_bytes == 1 and self.Ks <= 256
+        byte_tables = self.M == 16 and self.code_bytes == 1 and self.Ks <= 256 and self.scan_kernel != 'u16 tables'
         rk = int(rerank_k or getattr(self, 'rerank_k', None) or (16 if byte_tables else 64))
         rk = max(1, min(64, rk))
         plan = scan_plan(N, self.M, self.Ks, self.code_bytes, B, rk)
@@ -434,3 +417,5 @@ class PQFlatGpuIndex(BaseIndex):
         self._valid_bool[: v.numel()] = v
         self._valid_bits_cache = None
         self._n_rows, self._size = N, int(state['size'])
+        if self._scan_state is not None:
+            self._scan_state.reset()  # (another table: what was measured no longer applies)

@@ -277,13 +277,24 @@ struct FastCfg {
     bool qf() const { return true; }  // integer filter + exact recompute, shared bounds (every fast kernel)
 };
 
-// Kernel variants per M.  ANNLITE_SCAN_VARIANT (env, read per call) / annlite_scan_select_variant() select among the
-// instantiations for A/B measurements and the index plug-in's calibration; variant 0 is the default for every M.
-static thread_local int g_variant_override = -1;  // annlite_scan_select_variant
-static int scan_variant() {
-    if (g_variant_override >= 0) return g_variant_override;
+// Kernel variants per M.  ANNLITE_SCAN_VARIANT (environment, read per call: A/B measurements) selects among the
+// instantiations; variant 0 is the default plan for every M.  Which of the two M = 16 kernels serves a table -- byte or u16
+// filter tables -- is otherwise decided inside the library, per call (search_policy below): the entry points scope their
+// choice to the call through this thread-local (never visible to the caller, never left set).
+static thread_local int g_variant_scope = -1;
+struct VariantScope {
+    int prev;
+    explicit VariantScope(int v) : prev(g_variant_scope) { g_variant_scope = v; }
+    ~VariantScope() { g_variant_scope = prev; }
+};
+static int env_variant() {
     const char *e = getenv("ANNLITE_SCAN_VARIANT");
-    return e ? atoi(e) : 0;
+    return e ? atoi(e) : -1;
+}
+static int scan_variant() {
+    if (g_variant_scope >= 0) return g_variant_scope;
+    const int e = env_variant();
+    return e >= 0 ? e : 0;
 }
 
 // tiles: the plan of annlite_pq_search_tiles (IVF cells) -- the u16 kernels' tile mode
@@ -361,6 +372,9 @@ static void plan_slices(int64_t N, int n_tiles, int waves, int n_cu, bool xcd8, 
 
 using namespace annlite;
 
+static int plan_query_impl(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t k, int force_ns,
+                           annlite_scan_plan *plan);
+
 // force_ns > 0: tile mode (every query tile scans its own row range as ONE work item)
 static int plan_query_impl(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t k, int force_ns,
                            annlite_scan_plan *plan) {
@@ -392,7 +406,15 @@ static int plan_query_impl(int64_t N, int64_t M, int64_t Ks, int code_bytes, int
         plan->workspace_bytes = (int64_t)n_tiles * plan->qt * ns * k * 8 + 256 + bpad * 4 + 256;
         if (c.qf())
             plan->workspace_bytes += bpad * 4 + 256 + 2 * (bpad * 8 + 256) + (bpad * ns * 8 * gk2_cell_keys(M) + 256) + (n_tiles * 4 + 256) +
-                                     256 /* item counter */ + bpad * M * Ks * 2 + 256;
+                                     256 /* item counter */ + 256 /* guard block */ + bpad * M * Ks * 2 + 256;
+        // byte-table plan chosen by default: the gated u16-table launch that redoes the scan if the byte-table launch gives
+        // up (search_policy) works in its own region behind this one
+        if (c.mode == 5 && g_variant_scope < 0 && env_variant() < 0) {
+            annlite_scan_plan p2;
+            VariantScope vs(31);
+            if (plan_query_impl(N, M, Ks, code_bytes, B, k, force_ns, &p2) == ANNLITE_OK)
+                plan->workspace_bytes = ((plan->workspace_bytes + 255) / 256) * 256 + p2.workspace_bytes;
+        }
     } else {
         plan->fast = 0;
         plan->qi = 1;
@@ -419,7 +441,7 @@ extern "C" int annlite_scan_plan_tiles(int64_t N, int64_t M, int64_t Ks, int cod
     return plan_query_impl(N, M, Ks, code_bytes, V, k, 1, plan);
 }
 
-static unsigned long long *g_dbg = nullptr;  // debug only (ANNLITE_DEBUG_COUNTERS): leaked 128-byte device buffer
+static unsigned long long *g_dbg = nullptr;  // debug only (ANNLITE_DEBUG_COUNTERS): leaked device buffer: 16 counters + 4096 per-item records of 8
 static thread_local int g_prof_on = 0;
 static thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 static thread_local int g_ev_valid = 0;
@@ -458,11 +480,20 @@ struct TileMode {
     int64_t n_queries;         // real queries: the tables are built for THEM, slot s uses the tables of query vmap[s]
 };
 
+// kernel choice inside the library (search_policy): what a scan launch takes part in
+struct GuardOpt {
+    int abort_enabled;            // byte-table launch: it may give up (a gated u16 launch is queued behind it)
+    unsigned int *host_stats;     // byte-table launch: the caller's host-mapped statistics block (or NULL)
+    uint32_t seq;                 // ... and the sequence number its last workgroup leaves there
+    const unsigned int *gate;     // u16 launch: run only if *gate == 0 (every kernel of the launch: quantisation, seed, scan)
+    unsigned int *guard_out;      // out: the byte-table launch's guard block (the gate of the launch behind it)
+};
+
 static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M, int64_t Ks,
                         const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B, int64_t k,
                         void *workspace_dev, size_t workspace_bytes, hipStream_t st, annlite_scan_plan *plan_out,
                         bool share_across_slices, const LutBuild *build = nullptr, ScanOut *outp = nullptr,
-                        const TileMode *tm = nullptr) {
+                        const TileMode *tm = nullptr, GuardOpt *gopt = nullptr) {
     annlite_scan_plan plan;
     int rc = plan_query_impl(N, M, Ks, code_bytes, B, k, tm ? 1 : 0, &plan);
     if (rc != ANNLITE_OK) return rc;
@@ -502,8 +533,8 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
     a.gkey = nullptr;
     a.dbg = nullptr;
     a.dbg_skip = getenv("ANNLITE_DEBUG_SKIP") ? atoi(getenv("ANNLITE_DEBUG_SKIP")) : 0;
-    if (getenv("ANNLITE_DEBUG_COUNTERS")) {
-        if (!g_dbg) ANNLITE_HIP_TRY(hipMalloc((void **)&g_dbg, 128));
+    if (getenv("ANNLITE_DEBUG_COUNTERS") && !(gopt && gopt->gate)) {  // (the gated pass leaves the first launch's counters alone)
+        if (!g_dbg) ANNLITE_HIP_TRY(hipMalloc((void **)&g_dbg, 128 + 4096 * 64));
         ANNLITE_HIP_TRY(hipMemsetAsync(g_dbg, 0, 128, st));
         a.dbg = g_dbg;
         if (atoi(getenv("ANNLITE_DEBUG_COUNTERS")) == 2) a.dbg_skip |= 8;  // phase stamps only (annlite_debug_timeline): the
@@ -526,7 +557,8 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             const size_t bpad = (size_t)pad_queries(B, plan.qt);
             auto r256 = [](size_t x) { return (x + 255) / 256 * 256; };
             fill = r256((size_t)a.n_tiles * plan.qt * plan.n_slices * k * 8) + r256(bpad * 8) +
-                   r256(bpad * plan.n_slices * 8 * gk2_cell_keys(M)) + r256((size_t)a.n_tiles * 4) + 256 /* item counter */;
+                   r256(bpad * plan.n_slices * 8 * gk2_cell_keys(M)) + r256((size_t)a.n_tiles * 4) + 256 /* item counter */ +
+                   256 /* guard block */;
         }
         fill_bytes = fill;
         FastCfg c1;
@@ -582,6 +614,20 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             unsigned long long *gk2 = (unsigned long long *)carve(bpad * plan.n_slices * 8 * gk2_cell_keys(M));
             unsigned int *tile_done = (unsigned int *)carve((int64_t)a.n_tiles * 4);
             unsigned int *item_counter = (unsigned int *)carve(4);
+            unsigned int *guard_blk = (unsigned int *)carve(64);  // (reset to all-ones by the fill, like the counters)
+            if (gopt) {
+                if (c.mode == 5) {
+                    a.guard = guard_blk;
+                    a.guard_abort = gopt->abort_enabled;
+                    a.guard_base = 1024;
+                    if (const char *e = getenv("ANNLITE_GUARD_BASE")) a.guard_base = (uint32_t)atoll(e);  // (tests: force the give-up path)
+                    a.host_stats = gopt->host_stats;
+                    a.stats_seq = gopt->seq;
+                    gopt->guard_out = guard_blk;
+                } else {
+                    a.gate = gopt->gate;
+                }
+            }
             if (tm) {
                 a.tile_rows = tm->tile_rows;
                 a.vmap = tm->vmap;
@@ -618,20 +664,33 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             float *qlom = c.mode == 5 ? (float *)carve(bpad * M * 4) : nullptr;
             // (tile mode with the fused L2 build: the slots' fp32 tables are never read -- do not store them)
             const int64_t Bq = tm ? tm->n_queries : B;  // tile mode: tables of the real queries only
-            rc = launch_lut_quantise(M, Ks, Bq, ((Bq + 15) / 16) * 16, (tm && build) ? nullptr : lut_dev, build, q16, qstep,
-                                     qlo, smax, qlom, workspace_dev, fill_bytes, st);
-            if (rc != ANNLITE_OK) return rc;
-            if (share_across_slices && N >= 4096 && !tm) {  // (tile mode seeds inside the scan kernel)
-                int64_t S = 8192;
+            // seed rows of the shared first bound (tile mode seeds inside the scan kernel)
+            int64_t S = 0;
+            if (share_across_slices && N >= 4096 && !tm) {
+                S = 8192;
                 // byte-table kernel: its candidate transient shrinks with a tighter first bound faster than the seed launch
                 // grows (12 us per 8192 rows): 1.25M rows x 1024 queries 0.425 / 0.407 / 0.405 / 0.437 ms per batch at
                 // 8k / 16k / 32k / 64k seed rows, 10M rows 1.852 / 1.838 / 1.831 / 1.857
                 if (c.mode == 5) S = N / 32 < 8192 ? 8192 : N / 32 > 32768 ? 32768 : ((N / 32 + 1023) / 1024) * 1024;
                 if (const char *e = getenv("ANNLITE_SEED_ROWS")) S = atoll(e);
                 if (S > N) S = N;
-                if (S > 0) {  // (ANNLITE_SEED_ROWS=0: the scan starts without a bound)
+                if (S < 0) S = 0;  // (ANNLITE_SEED_ROWS=0: the scan starts without a bound)
+            }
+            // byte-table plan behind annlite_pq_search_topk: tables, parameters, reset and seed bound in ONE launch
+            const bool one_prep = c.mode == 5 && build && S > 0 && M == 16 && build->D <= 256 && ((build->D / M) % 4) == 0 &&
+                                  !getenv("ANNLITE_NO_FUSED_SEED");
+            if (one_prep) {
+                rc = launch_seed_build(codes_layout == ANNLITE_CODES_SKEWED, codes_dev, S, valid_bits_dev, *build, const_cast<float *>(lut_dev),
+                                       B, Ks, k, qstep, qlo, smax, qlom, gk, workspace_dev, fill_bytes, (size_t)(((bpad * 8 + 255) / 256) * 256), st);
+                if (rc != ANNLITE_OK) return rc;
+            } else {
+                const unsigned int *gate = (gopt && c.mode != 5) ? gopt->gate : nullptr;
+                rc = launch_lut_quantise(M, Ks, Bq, ((Bq + 15) / 16) * 16, (tm && build) ? nullptr : lut_dev, build, q16, qstep,
+                                         qlo, smax, qlom, workspace_dev, fill_bytes, st, gate);
+                if (rc != ANNLITE_OK) return rc;
+                if (S > 0) {
                     rc = launch_seed_bound(M, codes_layout == ANNLITE_CODES_SKEWED, codes_dev, code_bytes, S, valid_bits_dev, lut_dev,
-                                           B, Ks, k, smax, gk, st);
+                                           B, Ks, k, smax, gk, st, 0, 1, 0, 0, gate);
                     if (rc != ANNLITE_OK) return rc;
                 }
             }
@@ -656,9 +715,10 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             a.q16 = q16;
             a.qlom = qlom;
         }
-        prof_begin(st);
+        const bool bracket = !(gopt && gopt->gate);  // (measurement hooks: the launch that does the work, not the gated pass)
+        if (bracket) prof_begin(st);
         rc = c.mode == 5 ? launch_q8_scan(c.id, sk, a, grid, st) : launch_qfilter_scan(c.id, sk, a, grid, st);
-        prof_end(st);
+        if (bracket) prof_end(st);
         return rc;
     }
     const int grid = n_items < n_cu * 8 ? n_items : n_cu * 8;
@@ -672,12 +732,6 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         hipLaunchKernelGGL((adc_scan_generic_kernel<uint32_t, 4>), dim3(grid), dim3(256), lds, st, a, (int)M);
     prof_end(st);
     return launch_status("adc_scan_generic_kernel");
-}
-
-extern "C" int annlite_scan_select_variant(int variant) {
-    ANNLITE_REQUIRE(variant >= -1 && variant < 100, "variant %d outside [-1, 99]", variant);
-    g_variant_override = variant;
-    return ANNLITE_OK;
 }
 
 extern "C" int annlite_debug_counters(uint64_t *out8) {
@@ -702,6 +756,22 @@ extern "C" int annlite_debug_timeline(uint64_t *out8) {
     return ANNLITE_OK;
 }
 
+extern "C" int annlite_debug_items(uint64_t *out, int64_t max_items, int64_t *n_items) {
+    ANNLITE_REQUIRE(out != nullptr && n_items != nullptr && max_items >= 0, "null output");
+    if (!g_dbg) {
+        set_error("no counters recorded (set ANNLITE_DEBUG_COUNTERS=1 before the scan)");
+        return ANNLITE_ERR_INVALID;
+    }
+    ANNLITE_HIP_TRY(hipDeviceSynchronize());
+    unsigned long long n = 0;
+    ANNLITE_HIP_TRY(hipMemcpy(&n, g_dbg + 15, 8, hipMemcpyDeviceToHost));
+    if (n > 4096) n = 4096;
+    if ((int64_t)n > max_items) n = (unsigned long long)max_items;
+    if (n) ANNLITE_HIP_TRY(hipMemcpy(out, g_dbg + 16, n * 64, hipMemcpyDeviceToHost));
+    *n_items = (int64_t)n;
+    return ANNLITE_OK;
+}
+
 extern "C" int annlite_profile_enable(int on) {
     g_prof_on = on ? 1 : 0;
     g_ev_valid = 0;
@@ -719,17 +789,158 @@ extern "C" int annlite_profile_last_scan_ms(float *ms) {
     return ANNLITE_OK;
 }
 
+// =================================================================================================
+// Which M = 16 kernel serves a table: byte filter tables (scan_q8.hip: 32 queries per workgroup, the default) or u16 filter
+// tables (scan_qfilter.hip).  The byte filter is built for code tables with structure -- what PQ is for: a handful of rows
+// per query pass it.  On tables without any (independent uniform codes) it leaks and the u16 kernel is ~10x faster.  The
+// choice is made HERE, per call, from what earlier launches measured -- no process-wide switch, nothing the caller sets:
+//   * no state (a plain C-ABI consumer): the byte-table launch runs GUARDED -- its consumer waves count the candidates and
+//     give the launch up when they exceed a budget (a few microseconds into a leaking scan); a u16-table pass whose three
+//     launches are GATED on that flag is queued behind it and redoes the scan.  Without a leak the gated launches return at
+//     once (~10 us per batch).
+//   * with an annlite_scan_state (one per code table; the Python index owns one): every byte-table launch leaves its
+//     candidate count in the state's host-mapped block; the next calls read it (plain host memory, no synchronisation)
+//     and, once a launch has completed, run the byte-table kernel unguarded or the u16 kernel directly, until the table has
+//     doubled.  The first call(s) run guarded.
+// Results are identical whatever is chosen (both kernels are bit-exact).
+// =================================================================================================
+struct annlite_scan_state {
+    unsigned int *host;   // hipHostMalloc'ed, mapped: [0] seq of the last completed byte-table launch, [1] gave up,
+    unsigned int *dev;    //   [2..3] candidates seen, [4] B, [5] N  -- and its device address
+    uint32_t seq;         // launches issued with this state
+    uint32_t seen_seq;    // ... and the last one whose statistics were read
+    int kernel;           // 0 undecided, 1 byte tables, 2 u16 tables
+    int64_t rows;         // table size the decision was taken at (it is taken again when the table has doubled)
+    uint64_t candidates;  // of the launch the decision rests on
+};
+
+enum SearchMode { kModePlain, kModeGuarded, kModeByteStats, kModeU16 };
+
+static SearchMode search_policy(annlite_scan_state *s, int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t k,
+                                bool tiles) {
+    if (tiles || M != 16 || code_bytes != 1 || Ks > 256 || k > 16 || N <= 0 || B <= 0) return kModePlain;
+    if (g_variant_scope >= 0 || env_variant() >= 0) return kModePlain;        // (an explicit variant: A/B measurements)
+    if (getenv("ANNLITE_NO_INKERNEL_MERGE")) return kModePlain;                // (debug switch: no guarded pass)
+    if (!s) return kModeGuarded;
+    const uint32_t seq = __atomic_load_n(s->host, __ATOMIC_ACQUIRE);
+    if (seq != s->seen_seq && seq != 0) {  // a byte-table launch has completed since the last look
+        s->seen_seq = seq;
+        const bool gave_up = s->host[1] != 0;
+        const uint64_t cand = (uint64_t)s->host[2] | ((uint64_t)s->host[3] << 32);
+        const uint64_t b = s->host[4] ? s->host[4] : 1;
+        // with structure: ~300 candidates per query at 10M rows; without: tens of thousands
+        const bool leaks = gave_up || cand / b > 4096;
+        if (s->kernel == 0 || (s->kernel == 1 && leaks)) {
+            s->kernel = leaks ? 2 : 1;
+            s->rows = (int64_t)s->host[5];
+            s->candidates = cand;
+        }
+    }
+    if (s->kernel != 0 && (N >= 2 * s->rows || N * 2 < s->rows)) s->kernel = 0;  // the table has changed size: measure again
+    if (s->kernel == 2) return kModeU16;
+    if (s->kernel == 1) return kModeByteStats;
+    return kModeGuarded;
+}
+
+extern "C" int annlite_scan_state_create(annlite_scan_state **out) {
+    ANNLITE_REQUIRE(out != nullptr, "out is NULL");
+    annlite_scan_state *s = (annlite_scan_state *)calloc(1, sizeof(annlite_scan_state));
+    ANNLITE_REQUIRE(s != nullptr, "out of memory");
+    hipError_t e = hipHostMalloc((void **)&s->host, 64, hipHostMallocMapped);
+    if (e == hipSuccess) {
+        memset(s->host, 0, 64);
+        e = hipHostGetDevicePointer((void **)&s->dev, s->host, 0);
+    }
+    if (e != hipSuccess) {
+        if (s->host) (void)hipHostFree(s->host);
+        free(s);
+        return hip_fail(e, "annlite_scan_state_create");
+    }
+    *out = s;
+    return ANNLITE_OK;
+}
+
+extern "C" int annlite_scan_state_destroy(annlite_scan_state *s) {
+    if (!s) return ANNLITE_OK;
+    if (s->host) (void)hipHostFree(s->host);  // (waits for the device work that may still write it)
+    free(s);
+    return ANNLITE_OK;
+}
+
+extern "C" int annlite_scan_state_reset(annlite_scan_state *s) {
+    ANNLITE_REQUIRE(s != nullptr, "state is NULL");
+    s->kernel = 0;
+    s->rows = 0;
+    s->candidates = 0;
+    s->seen_seq = __atomic_load_n(s->host, __ATOMIC_ACQUIRE);  // (what earlier launches left no longer counts)
+    return ANNLITE_OK;
+}
+
+extern "C" int annlite_scan_state_info(annlite_scan_state *s, int32_t *kernel, int64_t *rows, uint64_t *candidates) {
+    ANNLITE_REQUIRE(s != nullptr, "state is NULL");
+    if (kernel) *kernel = s->kernel;
+    if (rows) *rows = s->rows;
+    if (candidates) *candidates = s->candidates;
+    return ANNLITE_OK;
+}
+
 static int scan_topk_impl(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M, int64_t Ks,
                           const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B, int64_t k, int64_t row_base,
                           float *out_dist_dev, int64_t *out_id_dev, int64_t *out_packed_dev, void *workspace_dev,
                           size_t workspace_bytes, void *stream, const LutBuild *build = nullptr, int flags = 0,
-                          const TileMode *tm = nullptr) {
+                          const TileMode *tm = nullptr, annlite_scan_state *state = nullptr) {
     annlite_scan_plan plan;
     hipStream_t st = (hipStream_t)stream;
     ANNLITE_REQUIRE(B == 0 || tm || out_packed_dev || (out_dist_dev && out_id_dev), "null output pointer");
     const int sqrt_out = (flags & ANNLITE_FLAG_SQRT) && !out_packed_dev ? 1 : 0;
     ScanOut so = {out_dist_dev, out_id_dev, out_packed_dev, row_base, sqrt_out, false};
     if (getenv("ANNLITE_NO_INKERNEL_MERGE") && !tm) so.d = nullptr, so.i = nullptr, so.packed = nullptr;
+    const SearchMode mode = search_policy(state, N, M, Ks, code_bytes, B, k, tm != nullptr);
+    if (mode != kModePlain) {
+        // (workspace: the public plan's size = byte-table region + u16 region; each pass checks its own)
+        annlite_scan_plan pub;
+        int rc0 = plan_query_impl(N, M, Ks, code_bytes, B, k, 0, &pub);
+        if (rc0 != ANNLITE_OK) return rc0;
+        if (workspace_bytes < (size_t)pub.workspace_bytes) {
+            set_error("workspace %zu B < required %lld B", workspace_bytes, (long long)pub.workspace_bytes);
+            return ANNLITE_ERR_WORKSPACE;
+        }
+        if (mode == kModeU16) {
+            VariantScope vs(31);
+            return scan_topk_impl(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut_dev, B, k, row_base, out_dist_dev,
+                                  out_id_dev, out_packed_dev, workspace_dev, workspace_bytes, stream, build, flags, tm, nullptr);
+        }
+        GuardOpt g = {};
+        g.abort_enabled = mode == kModeGuarded ? 1 : 0;
+        if (state) {
+            g.host_stats = state->dev;
+            g.seq = ++state->seq ? state->seq : ++state->seq;  // (0 means "nothing completed yet")
+        }
+        int rc;
+        size_t used;
+        {
+            VariantScope vs(50);
+            annlite_scan_plan p1;
+            rc = scan_partial(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut_dev, B, k, workspace_dev,
+                              workspace_bytes, st, &p1, true, build, &so, nullptr, &g);
+            if (rc != ANNLITE_OK || B == 0) return rc;
+            ANNLITE_REQUIRE(so.merged, "the byte-table launch did not merge in-kernel");
+            used = ((size_t)p1.workspace_bytes + 255) / 256 * 256;
+        }
+        if (mode == kModeGuarded && g.guard_out) {
+            // the same scan through the u16-table kernel, every launch of it gated on the byte-table launch having given up
+            VariantScope vs(31);
+            annlite_scan_plan p2;
+            GuardOpt g2 = {};
+            g2.gate = g.guard_out;
+            ScanOut so2 = {out_dist_dev, out_id_dev, out_packed_dev, row_base, sqrt_out, false};
+            rc = scan_partial(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut_dev, B, k, (char *)workspace_dev + used,
+                              workspace_bytes - used, st, &p2, true, nullptr, &so2, nullptr, &g2);
+            if (rc != ANNLITE_OK) return rc;
+            ANNLITE_REQUIRE(so2.merged, "the gated u16-table launch did not merge in-kernel");
+        }
+        return ANNLITE_OK;
+    }
     int rc = scan_partial(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut_dev, B, k, workspace_dev,
                           workspace_bytes, st, &plan, true, build, &so, tm);
     if (rc != ANNLITE_OK || B == 0 || so.merged) return rc;
@@ -773,7 +984,8 @@ static int pq_search_impl(int lut_kind, const float *queries_dev, int64_t B, int
                           const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M, int64_t Ks,
                           const uint32_t *valid_bits_dev, int64_t k, int64_t row_base, float *out_dist_dev,
                           int64_t *out_id_dev, int64_t *out_packed_dev, int flags, void *workspace_dev,
-                          size_t workspace_bytes, void *stream, const TileMode *tm, int64_t n_slots = 0) {
+                          size_t workspace_bytes, void *stream, const TileMode *tm, int64_t n_slots = 0,
+                          annlite_scan_state *state = nullptr) {
     ANNLITE_REQUIRE(M >= 1 && D >= M && D % M == 0,
                     "input dimension must be dividable by number of sub-space (D=%lld, M=%lld)", (long long)D, (long long)M);
     // tile mode: B real queries (tables), n_slots >= B scan slots (lists, bounds)
@@ -799,11 +1011,22 @@ static int pq_search_impl(int lut_kind, const float *queries_dev, int64_t B, int
                                plan.fast ? ANNLITE_LAYOUT_TILED : ANNLITE_LAYOUT_BMK, plan.qi, stream);
         if (rc != ANNLITE_OK) return rc;
         return scan_topk_impl(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut, Bs, k, row_base,
-                              out_dist_dev, out_id_dev, out_packed_dev, workspace_dev, scan_ws, stream, nullptr, flags, tm);
+                              out_dist_dev, out_id_dev, out_packed_dev, workspace_dev, scan_ws, stream, nullptr, flags, tm, state);
     }
     const LutBuild lb = {queries_dev, codebooks_dev, D};
     return scan_topk_impl(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut, Bs, k, row_base, out_dist_dev,
-                          out_id_dev, out_packed_dev, workspace_dev, scan_ws, stream, &lb, flags, tm);
+                          out_id_dev, out_packed_dev, workspace_dev, scan_ws, stream, &lb, flags, tm, state);
+}
+
+extern "C" int annlite_pq_search_topk_ex(int lut_kind, const float *queries_dev, int64_t B, int64_t D,
+                                         const float *codebooks_dev, const void *codes_dev, int code_bytes, int codes_layout,
+                                         int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev, int64_t k,
+                                         int64_t row_base, float *out_dist_dev, int64_t *out_id_dev, int64_t *out_packed_dev,
+                                         int flags, void *workspace_dev, size_t workspace_bytes, void *stream,
+                                         annlite_scan_state *state) {
+    return pq_search_impl(lut_kind, queries_dev, B, D, codebooks_dev, codes_dev, code_bytes, codes_layout, N, M, Ks,
+                          valid_bits_dev, k, row_base, out_dist_dev, out_id_dev, out_packed_dev, flags, workspace_dev,
+                          workspace_bytes, stream, nullptr, 0, state);
 }
 
 extern "C" int annlite_pq_search_topk(int lut_kind, const float *queries_dev, int64_t B, int64_t D,

@@ -63,6 +63,15 @@ struct ScanArgs {
     int32_t q8_epoch0, q8_epoch_mul, q8_ring_limit, q8_import_mask;
     int32_t q8_target;                  // T of a slot right after its table is (re)built (<= 127)
     int32_t q8_rebuild_8ths;            // a slot wants a new table when its T has fallen below this many eighths of that
+    // Kernel choice inside the library (scan.hip: byte-table launch with a guard, u16-table launch behind a gate):
+    unsigned int *guard;                // byte-table kernel: [0] 0xffffffff = run, 0 = the launch gave up (its candidate rate
+                                        // says the tables are not byte-table material: the gated u16 launch behind it redoes the
+                                        // scan); [1] workgroups done; [2..3] u64 candidates seen (- 1).  All-ones from the fill.
+    int32_t guard_abort;                // the launch may give up (a fallback launch is queued behind it)
+    uint32_t guard_base;                // ... when a workgroup has seen more than guard_base + rows drawn / 32 candidates
+    const unsigned int *gate;           // u16 kernels: run only if *gate == 0 (NULL: always)
+    unsigned int *host_stats;           // host-mapped, optional: the last workgroup writes [1] gave up, [2..3] candidates, [4] B,
+    uint32_t stats_seq;                 // [5] N (low 32 bits), then [0] = stats_seq
 };
 
 // work item -> (query tile, row slice).  item % 8 == blockIdx % 8 == the XCD the block lands on (speed
@@ -235,10 +244,16 @@ int launch_q8_scan(int id, bool skewed, const ScanArgs &a, int grid, hipStream_t
 // q16 == NULL: only the per-query parameters (step, L, Smax, minima) are produced; qlom may be NULL
 int launch_lut_quantise(int64_t M, int64_t Ks, int64_t B, int64_t bpad, const float *lut_dev, const LutBuild *build,
                         uint16_t *q16, float *qstep, double *qlo, float *smax, float *qlom, void *fill,
-                        size_t fill_bytes, hipStream_t st);
+                        size_t fill_bytes, hipStream_t st, const unsigned int *gate = nullptr);
 // n_seed_slices > 1: one bound per (query, row slice) -- rows [y * seed_stride, + S) of slice y, bound in gkey[y * gkey_stride + b]
 int launch_seed_bound(int64_t M, bool skewed, const void *codes_dev, int code_bytes, int64_t S, const uint32_t *valid_bits_dev,
                       const float *lut_dev, int64_t B, int64_t Ks, int64_t k, const float *smax, unsigned long long *gkey,
-                      hipStream_t st, int64_t N = 0, int n_seed_slices = 1, int64_t seed_stride = 0, int64_t gkey_stride = 0);
+                      hipStream_t st, int64_t N = 0, int n_seed_slices = 1, int64_t seed_stride = 0, int64_t gkey_stride = 0,
+                      const unsigned int *gate = nullptr);
+
+// byte-table plan: table build + quantisation parameters + workspace reset + seed bound in one launch (scan_prep.hip)
+int launch_seed_build(bool skewed, const void *codes_dev, int64_t S, const uint32_t *valid_bits_dev, const LutBuild &build,
+                      float *lut_out, int64_t B, int64_t Ks, int64_t k, float *qstep, double *qlo, float *smax, float *qlom,
+                      unsigned long long *gkey, void *fill, size_t fill_bytes, size_t gkey_bytes, hipStream_t st);
 
 }  // namespace annlite

@@ -102,16 +102,34 @@ __global__ __launch_bounds__(1024) void lut_quantise64_kernel(const float *__res
 // 16*k candidates per query.  (Sorted wave lists + a 4-level merge tree: 52 of 62 us in bitonic networks.)
 // The seed rows are scanned again by the main kernel: only the bound leaves this kernel.
 constexpr int kSeedWaves = 16;
+// BUILD: the workgroup BUILDS the L2 tables of its 4 queries itself -- straight into the LDS image the seed scan reads, and
+// into the fp32 TILED table in global memory for the scan kernel -- and leaves their quantisation parameters; it also resets
+// the scan's result lists / shared bounds (fill).  One launch instead of lut_l2_build_quantise_kernel + this kernel: no
+// second launch boundary (kernel-end write-back, dispatch: ~10 us) and no read-back of the 16 MB the first one wrote.
+struct SeedBuild {
+    const float *queries;  // [B][D]
+    const float *cb;       // [M][Ks][dsub]
+    float *lut_out;        // fp32 TILED [ceil16(B) / 4][Ks][M][4]
+    float *qstep, *smax, *qlom;
+    double *qlo;
+    u32x4 *fill;           // reset to all-ones: [0, fill_vec16) without [skip_lo, skip_hi) (the bounds this kernel writes itself)
+    int64_t fill_vec16, skip_lo, skip_hi;
+    int32_t D, qmax;
+    const unsigned int *gate;  // (any launch) run only if *gate == 0: the u16-table pass behind a byte-table launch that may give up
+};
 // QPB queries per workgroup: 4 (one fp32 TILED group) where their rows fit the LDS, 2 for M = 64
 // CODE16: uint16 codes (PLAIN tables)
-template <int M, bool SKEWED, int QPB, bool CODE16 = false>
+template <int M, bool SKEWED, int QPB, bool CODE16 = false, bool BUILD = false>
 __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8_t *__restrict__ codes, int64_t S,
                                                                     const uint32_t *__restrict__ valid,
                                                                     const float *__restrict__ lut, int B, int Ks, int k,
                                                                     const float *__restrict__ smax,
                                                                     unsigned long long *__restrict__ gkey,
-                                                                    int64_t seed_stride, int64_t N, int gkey_stride) {
+                                                                    int64_t seed_stride, int64_t N, int gkey_stride,
+                                                                    const SeedBuild sb) {
     static_assert(!(CODE16 && SKEWED), "uint16 code tables are PLAIN");
+    static_assert(!BUILD || (QPB == 4 && !CODE16 && M <= 16), "the fused build serves the byte-table plan");
+    if (sb.gate && __hip_atomic_load(sb.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     // blockIdx.y = row slice (per-slice bounds of the candidate generator: rows [y * seed_stride, + S), bound ->
     // gkey[y * gkey_stride + b]; seed_stride is a multiple of 64, so the lanes keep their skew residues); one slice: the first S rows
     {
@@ -136,7 +154,98 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int BPG = 4 / QPB;                 // blocks per fp32 TILED group of 4 queries
     const int g4 = blockIdx.x / BPG, h = blockIdx.x % BPG;
-    {
+    float smax_built[4] = {0.f, 0.f, 0.f, 0.f};  // (BUILD: the rounding slack of this workgroup's queries)
+    if constexpr (BUILD) {
+        // ---- reset of the scan's lists / bounds (all but the bounds this kernel writes) ----------------------------------
+        for (int64_t i = (int64_t)blockIdx.x * (kSeedWaves * 64) + tid; i < sb.fill_vec16; i += (int64_t)gridDim.x * (kSeedWaves * 64))
+            if (i < sb.skip_lo || i >= sb.skip_hi) sb.fill[i] = (u32x4){~0u, ~0u, ~0u, ~0u};
+        // ---- the tables: thread (kr, m) = (tid / M, tid % M) owns sub-space m of codes kr, kr + 1024 / M, ...; entry = the
+        // reference's j-ascending fmaf chain over (codeword - query) (pq_bindings.pyx:204-206): lut_l2_tiled_kernel's bits --------
+        constexpr int KPT = kSeedWaves * 64 / M, NSW = 256 / KPT;
+        float *s_q = (float *)cand;                                  // [4][D]
+        float *s_lo = (float *)((unsigned char *)cand + 4096);       // [16 waves][M][4]
+        float *s_hi = s_lo + kSeedWaves * M * 4;
+        float *s_par = s_hi + kSeedWaves * M * 4 + 4;                // [4] smax (behind the block counter)
+        const int D = sb.D, dsub = D / M;
+        for (int i = tid; i < 4 * D; i += kSeedWaves * 64) {
+            const int b = g4 * 4 + i / D;
+            s_q[i] = b < B ? sb.queries[(int64_t)b * D + i % D] : 0.f;
+        }
+        __syncthreads();
+        const int m = tid % M, kr = tid / M;
+        f32x4 *gout = (f32x4 *)sb.lut_out + (int64_t)g4 * Ks * M;
+        float mn[4], mx[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mn[i] = __builtin_inff(), mx[i] = -__builtin_inff();
+#pragma unroll
+        for (int sw = 0; sw < NSW; ++sw) {
+            const int kk = kr + sw * KPT;
+            if (kk < Ks) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                const float *cw = sb.cb + ((int64_t)m * Ks + kk) * dsub;
+                for (int j = 0; j < dsub; j += 4) {
+                    const f32x4 cj = *(const f32x4 *)(cw + j);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 qj = *(const f32x4 *)(s_q + i * D + m * dsub + j);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float c = cj[e] - qj[e];
+                            acc[i] = __builtin_fmaf(c, c, acc[i]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (g4 * 4 + i >= B) acc[i] = 0.f;  // pad queries -> 0, like lut_l2_tiled_kernel
+                const f32x4 v = {acc[0], acc[1], acc[2], acc[3]};
+                tab[kk * M + m] = v;
+                gout[(int64_t)kk * M + m] = v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mn[i] = fminf(mn[i], acc[i]), mx[i] = fmaxf(mx[i], acc[i]);
+            }
+        }
+        // lanes l, l + M, ... of a wave share m
+#pragma unroll
+        for (int o = M; o < 64; o <<= 1)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mn[i] = fminf(mn[i], __shfl_xor(mn[i], o)), mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], o));
+        if (lane < M)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_lo[(wave * M + m) * 4 + i] = mn[i], s_hi[(wave * M + m) * 4 + i] = mx[i];
+        __syncthreads();
+        if (tid < M * 4) {
+            const int mm = tid / 4, i = tid % 4;
+            float l = s_lo[mm * 4 + i], hh = s_hi[mm * 4 + i];
+            for (int r = 1; r < kSeedWaves; ++r) l = fminf(l, s_lo[(r * M + mm) * 4 + i]), hh = fmaxf(hh, s_hi[(r * M + mm) * 4 + i]);
+            s_lo[mm * 4 + i] = l;
+            s_hi[mm * 4 + i] = hh;
+            sb.qlom[(int64_t)(g4 * 4 + i) * M + mm] = l;
+        }
+        __syncthreads();
+        if (tid < 4) {
+            float range = 0.f, sm = 0.f;
+            double Lsum = 0.0;
+            for (int mm = 0; mm < M; ++mm) {
+                const float l = s_lo[mm * 4 + tid], hh = s_hi[mm * 4 + tid];
+                range = fmaxf(range, hh - l);
+                sm += fmaxf(fabsf(l), fabsf(hh));
+                Lsum += (double)l;
+            }
+            float step = range / (float)sb.qmax;
+            if (!(step > 0.f)) step = 1.f;
+            const int b = g4 * 4 + tid;
+            sb.qstep[b] = step;
+            sb.qlo[b] = Lsum;
+            sb.smax[b] = sm;
+            s_par[tid] = sm;
+            gkey[b] = ~0ull;  // (the fill leaves the bounds to this kernel; the selection below overwrites it)
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) smax_built[i] = s_par[i];
+        __syncthreads();  // (cand is reused by the selection)
+    } else {
         const f32x4 *src = (const f32x4 *)lut + (int64_t)g4 * Ks * M;
         for (int i = tid; i < Ks * M; i += kSeedWaves * 64) {
             const f32x4 e = src[i];
@@ -273,7 +382,10 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
             // because the seed rows are in nobody's list: the scan must still ACCEPT the rows that set it
             if (rk == k - 1 && b < B && (me | 1023u) != 0xffffffffu) {
                 // + the rounding margin between this sum order and the reference's, rounded up
-                const float slack = smax[b] * (float)(2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
+                float sm_b;
+                if constexpr (BUILD) sm_b = q == 0 ? smax_built[0] : q == 1 ? smax_built[1] : q == 2 ? smax_built[2] : smax_built[3];
+                else sm_b = smax[b];
+                const float slack = sm_b * (float)(2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
                 float thr = ordered_to_f32(me | 1023u);
                 thr = thr + slack;
                 const uint32_t key = f32_to_ordered(thr) + 1u;
@@ -372,7 +484,9 @@ __global__ __launch_bounds__(256) void lut_quantise_fused_kernel(const float *__
                                                                 uint16_t *__restrict__ out,
                                                                 float *__restrict__ qstep, double *__restrict__ qlo,
                                                                 float *__restrict__ smax, float *__restrict__ qlom,
-                                                                u32x4 *__restrict__ fill, int64_t fill_vec16) {
+                                                                u32x4 *__restrict__ fill, int64_t fill_vec16,
+                                                                const unsigned int *__restrict__ gate) {
+    if (gate && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;  // (see ScanArgs::gate)
     constexpr int KPT = 256 / M;  // codes covered per sweep of the block
     // this launch also resets the scan's result lists and shared bounds to "none" (all-ones): one launch less
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < fill_vec16; i += (int64_t)gridDim.x * 256)
@@ -613,7 +727,7 @@ using namespace annlite;
 
 int annlite::launch_lut_quantise(int64_t M, int64_t Ks, int64_t B, int64_t bpad, const float *lut_dev, const LutBuild *build,
                                  uint16_t *q16, float *qstep, double *qlo, float *smax, float *qlom, void *fill,
-                                 size_t fill_bytes, hipStream_t st) {
+                                 size_t fill_bytes, hipStream_t st, const unsigned int *gate) {
     const int qmax = (int)(32767 / M);
     const unsigned n_g8 = (unsigned)(bpad / 8);
     float *lut_rw = const_cast<float *>(lut_dev);
@@ -626,7 +740,7 @@ int annlite::launch_lut_quantise(int64_t M, int64_t Ks, int64_t B, int64_t bpad,
                            qlo, smax, qlom, fillp, fillv);                                                                 \
     else                                                                                                             \
         hipLaunchKernelGGL((lut_quantise_fused_kernel<MM>), dim3(n_g8), dim3(256), 0, st, lut_rw, (int)Ks, qmax, q16,  \
-                           qstep, qlo, smax, qlom, fillp, fillv)
+                           qstep, qlo, smax, qlom, fillp, fillv, gate)
     if (M == 64)  // (no fill, no build: the caller memsets and builds the tables itself)
         hipLaunchKernelGGL(lut_quantise64_kernel, dim3((unsigned)(bpad / 4)), dim3(1024), 0, st, lut_dev, (int)Ks, qmax, q16,
                            qstep, qlo, smax);
@@ -638,7 +752,9 @@ int annlite::launch_lut_quantise(int64_t M, int64_t Ks, int64_t B, int64_t bpad,
 int annlite::launch_seed_bound(int64_t M, bool skw, const void *codes_dev, int code_bytes, int64_t S, const uint32_t *valid_bits_dev,
                                const float *lut_dev, int64_t B, int64_t Ks, int64_t k, const float *smax,
                                unsigned long long *gk, hipStream_t st, int64_t N, int n_seed_slices, int64_t seed_stride,
-                               int64_t gkey_stride) {
+                               int64_t gkey_stride, const unsigned int *gate) {
+    SeedBuild nob = {};
+    nob.gate = gate;
     const unsigned ny = (unsigned)(n_seed_slices > 0 ? n_seed_slices : 1);
     const int gstride = (int)gkey_stride;
     if (N <= 0) N = S;
@@ -649,7 +765,7 @@ int annlite::launch_seed_bound(int64_t M, bool skw, const void *codes_dev, int c
         ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(fn, dim3((unsigned)(((B + 3) / 4) * (4 / QPB_)), ny), dim3(kSeedWaves * 64), lds, st,  \
                            (const uint8_t *)codes_dev, S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, smax, gk,    \
-                           seed_stride, N, gstride);                                                                    \
+                           seed_stride, N, gstride, nob);                                                       \
     }
     if (code_bytes == 2) {  // uint16 codes: PLAIN tables, M = 8 / 16 (what the u16-table scan kernel takes)
 #define ANNLITE_SEED16(MM)                                                                                         \
@@ -658,7 +774,7 @@ int annlite::launch_seed_bound(int64_t M, bool skw, const void *codes_dev, int c
         const size_t lds = (size_t)Ks * MM * 16 + (size_t)2 * kSeedWaves * 64 * 8;                                 \
         ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(fn, dim3((unsigned)((B + 3) / 4), ny), dim3(kSeedWaves * 64), lds, st, (const uint8_t *)codes_dev, \
-                           S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, smax, gk, seed_stride, N, gstride);   \
+                           S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, smax, gk, seed_stride, N, gstride, nob); \
     }
         if (M == 8) ANNLITE_SEED16(8) else ANNLITE_SEED16(16)
 #undef ANNLITE_SEED16
@@ -668,4 +784,35 @@ int annlite::launch_seed_bound(int64_t M, bool skw, const void *codes_dev, int c
     else ANNLITE_SEED(64, 2)
 #undef ANNLITE_SEED
     return launch_status("seed_bound_kernel");
+}
+
+// The byte-table plan's whole preparation in ONE launch (M = 16, L2 tables, sub-vectors of a multiple of 4 floats, D <= 256):
+// tables of every group of 4 queries built into LDS + global memory, quantisation parameters, reset of the lists / bounds,
+// seed bound from the first S rows.
+int annlite::launch_seed_build(bool skw, const void *codes_dev, int64_t S, const uint32_t *valid_bits_dev, const LutBuild &build,
+                               float *lut_out, int64_t B, int64_t Ks, int64_t k, float *qstep, double *qlo, float *smax, float *qlom,
+                               unsigned long long *gk, void *fill, size_t fill_bytes, size_t gk_bytes, hipStream_t st) {
+    constexpr int M = 16;
+    SeedBuild sb;
+    sb.queries = build.queries;
+    sb.cb = build.codebooks;
+    sb.lut_out = lut_out;
+    sb.qstep = qstep;
+    sb.smax = smax;
+    sb.qlom = qlom;
+    sb.qlo = qlo;
+    sb.fill = (u32x4 *)fill;
+    sb.fill_vec16 = (int64_t)(fill_bytes / 16);
+    sb.skip_lo = (int64_t)(((char *)gk - (char *)fill) / 16);
+    sb.skip_hi = sb.skip_lo + (int64_t)(gk_bytes / 16);
+    sb.D = (int32_t)build.D;
+    sb.qmax = 32767 / M;
+    sb.gate = nullptr;
+    auto fn = skw ? seed_bound_kernel<M, true, 4, false, true> : seed_bound_kernel<M, false, 4, false, true>;
+    const size_t lds = (size_t)Ks * M * 16 + (size_t)2 * kSeedWaves * 64 * 8;
+    ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned n_g4 = (unsigned)(((B + 15) / 16) * 4);
+    hipLaunchKernelGGL(fn, dim3(n_g4, 1), dim3(kSeedWaves * 64), lds, st, (const uint8_t *)codes_dev, S, valid_bits_dev,
+                       (const float *)nullptr, (int)B, (int)Ks, (int)k, (const float *)nullptr, gk, (int64_t)0, S, 0, sb);
+    return launch_status("seed_bound_kernel (fused table build)");
 }

@@ -104,9 +104,15 @@ __device__ __forceinline__ void q8_slot_params(bool real, unsigned long long key
 // The workgroup's byte table from the fp32 TILED tables of its 32 queries: thread (m, h) = (tid % M, (tid / M) % 2)
 // keeps the minima and 1/step of its 16 queries in registers and walks the codes.  RNE(t - 0.5) <= floor(t): the
 // conversion's rounding mode does not matter for the bound.
-// what a (re)build reads of the kernel's arguments (passed by value: a pointer to the kernel's argument block would
-// make the compiler keep a copy of all of it in scratch and read it from there in the step loop)
-struct Q8Build {
+// What the out-of-line parts of the kernel (table (re)build, end of a work item) read of the kernel's arguments comes
+// straight from the KERNARG SEGMENT (constant memory, scalar loads at the point of use).  As fields of the by-value kernel
+// parameter they are loaded at the kernel's entry and stay live in SGPRs across the step loop -- which sits at the register
+// limit: a dozen SGPRs more spill into VGPR lanes and from there into scratch reloads inside the loop.  (The address of
+// the parameter itself would make the compiler keep a copy of the whole block in scratch.)
+typedef const ScanArgs __attribute__((address_space(4))) *q8_kernarg_ptr;
+// (taken in the KERNEL and handed down: inside an out-of-line function the builtin returned a null pointer)
+__device__ __forceinline__ q8_kernarg_ptr q8_kernarg() { return (q8_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr(); }
+struct Q8Build {  // what a (re)build needs, gathered from the kernarg segment inside q8_rebuild
     const float *lut, *qlom, *qstep, *smax;
     const double *qlo;
     const unsigned long long *gkey;  // first bounds: the shared array, or this slice's row of the per-slice seeds, or NULL
@@ -169,7 +175,7 @@ constexpr int kPopPerRing = 8;    // entries the consumer takes from one wave's 
 //   list     u64 [32][16] the 16 smallest keys of every slot, ascending; gjl u64 [32] the j-th key last published
 //   ring     u64 [16][kWaveRing]; qkey u64 [4][128], qslot u8 [4][128] insertion queues; chg u8 [32]; stamps u64 [4] (debug)
 struct Q8Lds {
-    uint32_t tab, shq, ring_ctl, gkl, step, inv, tb, ctl, clip, tau, c0, c1, list, gjl, ring, qkey, qslot, chg, stamps;
+    uint32_t tab, shq, ring_ctl, gkl, step, inv, tb, ctl, clip, tau, c0, c1, list, gjl, ring, qkey, qslot, chg, stamps, seen;
     __device__ __forceinline__ explicit Q8Lds(int lut_bytes) {
         tab = lds_base_addr();
         shq = tab + (uint32_t)lut_bytes;
@@ -190,6 +196,7 @@ struct Q8Lds {
         qslot = qkey + 4 * 128 * 8;
         chg = qslot + 4 * 128;
         stamps = chg + 32;
+        seen = stamps + 32;  // u32: candidates this workgroup has seen (guard statistics), u32: abort flag of later items
     }
     __device__ __forceinline__ uint32_t arrived() const { return ring_ctl; }
     __device__ __forceinline__ uint32_t blk_ctr() const { return ring_ctl + 4; }
@@ -373,8 +380,13 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
 // the byte table.  Out of line on purpose: it runs a dozen times per work item, and inlined into the step loop its 40
 // live registers made the compiler spill the loop-invariant LDS base registers of the look-ups into the hot path.
 template <int M, int NW>
-__device__ __attribute__((noinline)) void q8_rebuild(const Q8Build a, int tile, int first) {
+__device__ __attribute__((noinline)) void q8_rebuild(q8_kernarg_ptr ka, int tile, int first, int slice) {
     constexpr int QT = 32;
+    // first bounds of the item's queries: what the seed launch left in the shared array, or -- candidate generator, nothing
+    // shared between the slices -- in this slice's row of the per-slice seeds ([n_slices][n_tiles * 32])
+    const Q8Build a = {ka->lut, ka->qlom, ka->qstep, ka->smax, ka->qlo,
+                       ka->gkey ? ka->gkey : (ka->gseed ? ka->gseed + (int64_t)slice * (ka->n_tiles * QT) : nullptr),
+                       ka->Ks, ka->B, ka->k, ka->q8_target};
     const int tid = threadIdx.x;
     const Q8Lds o(a.Ks * 2 * M * 16);
     if (tid < QT) {
@@ -414,6 +426,79 @@ __device__ __attribute__((noinline)) void q8_rebuild(const Q8Build a, int tile, 
     __syncthreads();
 }
 
+// Final merge of a tile by the last of its workgroups to arrive (k <= 16): the k smallest of the n_slices * k keys the slices
+// left in `partial`, by RANK COUNTING.  One wave per query; the keys of a query are contiguous, 64 per chunk (lane = key);
+// a chunk is first cut down to the keys below the running k-th one, then every survivor and every entry of the running
+// list learns its rank in the union from broadcasts (v_readlane of the few survivors) and writes itself to that slot of a
+// 16-entry LDS scratch.  (merge_tile_slices folds one slice at a time through 64-lane bitonic merges, ds_bpermute chains:
+// 19 us for 32 queries x 8 slices -- on the critical path of every launch, the merging workgroup is the last to leave.)
+template <int NW>
+__device__ __forceinline__ void q8_merge_tile(const ScanArgs &a, int b0, int QT, int km1, int wave, int lane, uint32_t scratch_ad) {
+    int nq = a.B - b0;
+    if (nq > QT) nq = QT;
+    const int k = km1 + 1;
+    const int total = a.n_slices * k;
+    const uint32_t my_scratch = scratch_ad + (uint32_t)wave * 128u;  // u64 [16]
+    auto rd64 = [&](unsigned long long v, int l) -> unsigned long long {
+        return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) |
+               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    };
+    // (query, chunk) pairs of this wave, in order; the keys of pair p + 2 are requested before pair p is processed: the
+    // loads are device-scope (another XCD's L2 does not see them sooner) and take ~2.5 us each -- chained, 4 of them were
+    // most of the merging workgroup's 15-25 us
+    const int nch = (total + 63) / 64;
+    const int n_mine = wave < nq ? (nq - wave + NW - 1) / NW : 0;
+    const int n_pairs = n_mine * nch;
+    auto load_pair = [&](int p) -> unsigned long long {
+        if (p >= n_pairs) return ~0ull;
+        const int b = b0 + wave + NW * (p / nch), idx = 64 * (p % nch) + lane;
+        if (idx >= total) return ~0ull;
+        return __hip_atomic_load(a.partial + (int64_t)b * total + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    unsigned long long n1 = load_pair(0), n2 = load_pair(1);
+    unsigned long long best = ~0ull;  // lane j < k: the j-th smallest key so far
+#pragma unroll 1
+    for (int p = 0; p < n_pairs; ++p) {
+        unsigned long long key = n1;
+        n1 = n2;
+        n2 = load_pair(p + 2);
+        const int c = p % nch;
+        if (c == 0) best = ~0ull;  // a new query
+        const unsigned long long thr = rd64(best, km1);
+        if (!(key < thr)) key = ~0ull;
+        unsigned long long m = __ballot(key != ~0ull);
+        if (m) {
+            int r_c = 0, r_b = lane;  // ranks in the union of my chunk key / my list entry
+            while (m) {
+                const int L = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const unsigned long long ck = rd64(key, L);
+                r_c += ck < key ? 1 : 0;
+                r_b += ck < best ? 1 : 0;
+            }
+#pragma unroll 1
+            for (int j = 0; j < k; ++j) r_c += rd64(best, j) < key ? 1 : 0;
+            if (lane < k && r_b < k) ldsv_st<unsigned long long>(my_scratch + 8u * (uint32_t)r_b, best);
+            if (key != ~0ull && r_c < k) ldsv_st<unsigned long long>(my_scratch + 8u * (uint32_t)r_c, key);
+            best = lane < k ? ldsv<unsigned long long>(my_scratch + 8u * (uint32_t)lane) : ~0ull;
+        }
+        if (c == nch - 1 && lane <= km1) {  // the query is complete
+            const int b = b0 + wave + NW * (p / nch);
+            const uint32_t hi = (uint32_t)(best >> 32), lo = (uint32_t)best;
+            const bool none = (hi == kKeyInfHi && lo == kIdNone);
+            const float d = none ? __builtin_inff() : ordered_to_f32(hi);
+            const int64_t id = none ? (int64_t)-1 : a.row_base + (int64_t)lo;
+            if (a.out_packed) {
+                a.out_packed[((int64_t)b * a.k + lane) * 2 + 0] = id;
+                a.out_packed[((int64_t)b * a.k + lane) * 2 + 1] = (int64_t)__float_as_uint(d);
+            } else {
+                a.out_d[(int64_t)b * a.k + lane] = a.sqrt_out ? __builtin_sqrtf(d) : d;
+                a.out_i[(int64_t)b * a.k + lane] = id;
+            }
+        }
+    }
+}
+
 // work item -> (query tile, row slice).  item % 8 == the XCD the block lands on (speed only).  With >= 8 query tiles an
 // XCD owns the tiles congruent to it, for ALL row slices: the fp32 tables the exact sums gather from (16 KB per query,
 // 512 KB per tile) stay in that XCD's 4 MB L2 -- with the slice-per-XCD map of the u16 kernels (item_map) every XCD saw
@@ -429,6 +514,43 @@ __device__ __forceinline__ bool q8_item_map(const ScanArgs &a, int item, int &ti
     return tile < a.n_tiles && slice < a.n_slices;
 }
 
+// End of a work item: the lists ARE the workgroup's result for this (tile, slice) -- the final epoch_sync was the barrier:
+// every candidate is in --; the last of the tile's workgroups to arrive merges the slices.  Out of line, arguments from the
+// kernarg segment (see q8_kernarg).
+template <int M, int NW>
+__device__ __attribute__((noinline)) void q8_finish_item(q8_kernarg_ptr ka, int tile, int slice) {
+    constexpr int QT = 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int km1 = ka->k - 1, B = ka->B, n_slices = ka->n_slices, k = ka->k;
+    const Q8Lds lds(ka->Ks * 2 * M * 16);
+    unsigned long long *partial = ka->partial;
+    for (int q = wave; q < QT; q += NW) {
+        const int b = tile * QT + q;
+        // device-scope stores: the merging workgroup may sit on another XCD (own L2)
+        if (b < B && lane <= km1)
+            __hip_atomic_store(partial + ((int64_t)b * n_slices + slice) * k + lane,
+                               ldsv<unsigned long long>(lds.list + 8u * (uint32_t)(q * 16 + lane)), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned int *tile_done = ka->tile_done;
+    if (tile_done) {
+        // the last of the tile's n_slices workgroups to arrive merges them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have completed
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned int old = __hip_atomic_fetch_add(tile_done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ldsv_st<uint32_t>(lds.ctl + 4, (old + 1u == (unsigned int)(n_slices - 1)) ? 1u : 0u);
+        }
+        __syncthreads();
+        if (ldsv<uint32_t>(lds.ctl + 4)) {
+            ScanArgs a;  // (cold path: the merging workgroup reads the block once)
+            __builtin_memcpy(&a, (const void *)ka, sizeof(ScanArgs));
+            q8_merge_tile<NW>(a, tile * QT, QT, km1, wave, lane, lds.ring);
+        }
+        __syncthreads();
+    }
+}
+
 template <int M, int NW, bool SKEWED>
 __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const ScanArgs a) {
     constexpr int QG = 16, NQ = 2, QT = QG * NQ, CW = M / 4, EB = 16, RB = M * EB, KSTRIDE = NQ * RB;
@@ -442,23 +564,25 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
 
     const int lut_bytes = a.Ks * KSTRIDE;
     const Q8Lds lds(lut_bytes);
+    const q8_kernarg_ptr ka = q8_kernarg();
 
+    if (a.guard && tid == 0) ldsv_st<uint32_t>(lds.seen, 0u);
     for (int it = 0;; ++it) {
         const int item = blockIdx.x + it * gridDim.x;
         if (item >= a.n_items) break;
         int tile, slice;
         if (!q8_item_map(a, item, tile, slice)) continue;
+        if (a.guard && it > 0) {  // a launch that gave up (below) is redone by the launch behind it: no further items
+            __syncthreads();
+            if (tid == 0) ldsv_st<uint32_t>(lds.seen + 4, __hip_atomic_load(a.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            __syncthreads();
+            if (ldsv<uint32_t>(lds.seen + 4) == 0u) break;
+        }
         const int64_t slice_begin = (int64_t)slice * a.slice_rows;
         int64_t slice_end = slice_begin + a.slice_rows;
         if (slice_end > a.N) slice_end = a.N;
         const int64_t stride = (int64_t)NS * 64;
         const int n_steps = slice_end > slice_begin ? (int)((slice_end - slice_begin + stride - 1) / stride) : 0;
-
-        // first bounds of the item's queries: what the seed launch left in the shared array, or -- candidate generator, nothing
-        // shared between the slices -- in this slice's row of the per-slice seeds ([n_slices][n_tiles * 32])
-        const Q8Build ba = {a.lut, a.qlom, a.qstep, a.smax, a.qlo,
-                            a.gkey ? a.gkey : (a.gseed ? a.gseed + (int64_t)slice * (a.n_tiles * QT) : nullptr),
-                            a.Ks, a.B, a.k, a.q8_target};
 
         __syncthreads();  // every wave is done with the previous item
         // ANNLITE_DEBUG_COUNTERS: phase stamps of thread 0 (100 MHz wall clock; kept in LDS: four live 64-bit values pushed the
@@ -484,7 +608,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             }
             __syncthreads();
             if (ldsv<uint32_t>(lds.ctl)) {
-                q8_rebuild<M, NW>(ba, tile, 0);
+                q8_rebuild<M, NW>(ka, tile, 0, slice);
                 if (a.dbg && tid == 0) atomicAdd(a.dbg + 5, 1ull);
             }
         };
@@ -497,7 +621,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             ldsv_st<uint32_t>(lds.arrived(), 0);
             ldsv_st<uint32_t>(lds.blk_ctr(), 0);  // the block counter the scanning waves draw from
         }
-        q8_rebuild<M, NW>(ba, tile, 1);  // (its barriers cover the initialisation above)
+        q8_rebuild<M, NW>(ka, tile, 1, slice);  // (its barriers cover the initialisation above)
         stamp(1);
 
         // epochs end after steps q8_epoch0, q8_epoch0 * mul + (mul - 1), ... and after the last step
@@ -593,6 +717,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             const bool has_ring = lane < 4 * NS;
             uint32_t head_v = 0;  // consumed entries of my_ring (the same value in the four lanes that serve it)
             uint32_t n_kept = 0, n_offered = 0;
+            // Guard (a.guard): the byte filter is made for tables with structure -- a handful of rows per query pass.  On
+            // tables without any (independent uniform codes) rows with a few clipped entries pass in their millions and the
+            // u16-table kernel is an order of magnitude faster.  The consumer counts what it sees; past a budget that grows
+            // with the rows scanned it declares the launch lost: the flag stops every workgroup (their block counters jump
+            // past the slice: the scanning waves run out of blocks and meet at the barriers as usual; the rings are emptied
+            // unprocessed), and the gated u16 launch queued behind this one redoes the scan.
+            bool aborted = false;
+            uint32_t n_seen = 0;
+            auto give_up = [&]() {
+                aborted = true;
+                if (lane == 0) lds_add_u32(lds.blk_ctr(), 0x40000000u);
+            };
+            auto poll_guard = [&]() {
+                if (a.guard && a.guard_abort && !aborted &&
+                    __hip_atomic_load(a.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+                    give_up();
+            };
             unsigned long long pend_o = ~0ull, pend_j = ~0ull;  // bounds not yet published to the other workgroups (lane = slot)
             unsigned long long t_busy = 0;
             uint32_t n_batches = 0;
@@ -610,6 +751,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     // A non-final epoch does not wait for the backlog: the scanning waves stand at the barrier, what is in the
                     // rings is taken in the next epoch (only the last epoch's end needs every candidate in the lists)
                     if (arrived == want && !final) break;
+                    if (any && aborted) {  // (the scan is lost: free the rings, nothing is processed)
+                        uint32_t av = lane < NS ? avail : 0u;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) av += __shfl_xor(av, o);
+                        n_seen += av;
+                        head_v = tail_v;
+                        if (lane < NS) ldsv_st<uint32_t>(lds.heads() + 4u * (uint32_t)lane, head_v);
+                        continue;
+                    }
                     if (any) {
                         const unsigned long long t0 = a.dbg ? __builtin_readcyclecounter() : 0ull;
                         __builtin_amdgcn_s_setprio(3);  // (serial code on a SIMD shared with three or four scanning waves)
@@ -622,6 +772,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                             e[u] = 0ull;
                             if (act[u]) e[u] = ldsv<unsigned long long>(lds.ring + 8u * ((uint32_t)my_ring * kWaveRing + ((head_v + i) & (kWaveRing - 1))));
                         }
+                        n_seen += (uint32_t)(__popcll(__ballot(act[0])) + __popcll(__ballot(act[1])));
                         head_v = (head_v + (avail < (uint32_t)kPopPerRing ? avail : (uint32_t)kPopPerRing)) & 0xffffu;
                         if (lane < NS) ldsv_st<uint32_t>(lds.heads() + 4u * (uint32_t)lane, head_v);  // the wave may reuse the entries
                         q8_consume<M, SKEWED>(fc, lds, e, act, lane, n_kept, n_offered, pend_o, pend_j);
@@ -629,11 +780,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                         ++n_batches;
                         if (a.dbg) t_busy += __builtin_readcyclecounter() - t0;
                         idle = 0;
-                        if ((n_batches & (uint32_t)a.q8_import_mask) == 0) import_bounds();  // (the other slices' progress)
+                        if ((n_batches & (uint32_t)a.q8_import_mask) == 0) {
+                            import_bounds();  // (the other slices' progress)
+                            poll_guard();
+                        }
+                        // budget: guard_base (1024) candidates + one per 32 rows the workgroup has drawn (with structure: ~1 per 1000 rows;
+                        // past ~1 per 32 the u16-table kernel is the faster one)
+                        if (a.guard && a.guard_abort && !aborted && n_seen > a.guard_base + (ldsv<uint32_t>(lds.blk_ctr()) << 1)) {
+                            if (lane == 0) __hip_atomic_store(a.guard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            give_up();
+                        }
                         continue;
                     }
                     if (arrived == want) break;
-                    if ((++idle & 15) == 8) import_bounds();
+                    if ((++idle & 15) == 8) {
+                        import_bounds();
+                        poll_guard();
+                    }
                     __builtin_amdgcn_s_sleep(4);
                 }
                 q8_publish_global(fc, lds, lane, pend_o, pend_j);
@@ -654,6 +817,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 ++epoch;
                 epoch_step = a.q8_epoch_mul * epoch_step + (a.q8_epoch_mul - 1);
             }
+            if (a.guard && lane == 0) ldsv_st<uint32_t>(lds.seen, ldsv<uint32_t>(lds.seen) + n_seen);
             if (a.dbg && lane == 0 && !(a.dbg_skip & 8)) {  // ANNLITE_DEBUG_COUNTERS=1: [2] exact sums, [3] candidates that went into a list's queue,
                 atomicAdd(a.dbg + 2, (unsigned long long)n_kept);     // [4] consumer cycles inside batches, [6] batches
                 atomicAdd(a.dbg + 3, (unsigned long long)n_offered);
@@ -888,30 +1052,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             }
         }
 
-        // ---- the lists ARE the workgroup's result for this (tile, slice) ----------------------
-        // (the final epoch_sync was the barrier: every candidate is in)
-        for (int q = wave; q < QT; q += NW) {
-            const int b = tile * QT + q;
-            // device-scope stores: the merging workgroup may sit on another XCD (own L2)
-            if (b < a.B && lane <= km1)
-                __hip_atomic_store(a.partial + ((int64_t)b * a.n_slices + slice) * a.k + lane,
-                                   ldsv<unsigned long long>(lds.list + 8u * (uint32_t)(q * 16 + lane)), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (a.tile_done) {
-            // the last of the tile's n_slices workgroups to arrive merges them
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have completed
-            __syncthreads();
-            if (tid == 0) {
-                const unsigned int old =
-                    __hip_atomic_fetch_add(a.tile_done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ldsv_st<uint32_t>(lds.ctl + 4, (old + 1u == (unsigned int)(a.n_slices - 1)) ? 1u : 0u);
-            }
-            __syncthreads();
-            if (ldsv<uint32_t>(lds.ctl + 4))
-                merge_tile_slices<NW>(a, tile * QT, QT, km1, wave, lane, (unsigned long long *)(g_smem + (lds.ring - lds.tab)));
-            __syncthreads();
-        }
+        q8_finish_item<M, NW>(ka, tile, slice);
         if (a.dbg && tid == 0) {
             // [8] 2^62 - earliest start, [9] latest end, sums over the work items: [10] start, [11] init + first table build,
             // [12] thread 0's step loop, [13] its wait at the last barrier (the consumer's backlog, the slower waves),
@@ -926,7 +1067,39 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             atomicAdd(a.dbg + 12, t_scanned - t_built);
             atomicAdd(a.dbg + 13, t_synced - t_scanned);
             atomicAdd(a.dbg + 14, t_end - t_synced);
-            atomicAdd(a.dbg + 15, 1ull);
+            const unsigned long long rec = atomicAdd(a.dbg + 15, 1ull);
+            if (rec < 4096ull) {  // per-item record (annlite_debug_items): tile, slice, the five stamps
+                unsigned long long *r = a.dbg + 16 + rec * 8;
+                r[0] = (unsigned long long)tile;
+                r[1] = (unsigned long long)slice;
+                r[2] = t_item;
+                r[3] = t_built;
+                r[4] = t_scanned;
+                r[5] = t_synced;
+                r[6] = t_end;
+                r[7] = (unsigned long long)blockIdx.x;
+            }
+        }
+    }
+    // ---- guard statistics: candidates seen by the whole launch, written to the caller's host-mapped block by the last
+    // workgroup to leave (the library's kernel choice for the next calls: scan.hip) ----------------------------------------
+    if (a.guard) {
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add((unsigned long long *)(a.guard + 2), (unsigned long long)ldsv<uint32_t>(lds.seen), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int old = __hip_atomic_fetch_add(a.guard + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1u == gridDim.x - 1u && a.host_stats) {
+                const unsigned long long seen =
+                    __hip_atomic_load((unsigned long long *)(a.guard + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+                const unsigned int gave_up = __hip_atomic_load(a.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u ? 1u : 0u;
+                __hip_atomic_store(a.host_stats + 1, gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(a.host_stats + 2, (unsigned int)seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(a.host_stats + 3, (unsigned int)(seen >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(a.host_stats + 4, (unsigned int)a.B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(a.host_stats + 5, (unsigned int)a.N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(a.host_stats + 0, a.stats_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
@@ -938,7 +1111,7 @@ using namespace annlite;
 template <int M, int NW, bool SKEWED>
 static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
     constexpr int QT = 32;
-    const size_t need = (size_t)a.Ks * 2 * M * 16 + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32 + 32;
+    const size_t need = (size_t)a.Ks * 2 * M * 16 + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32 + 32 + 16;
     auto fn = adc_scan_q8_kernel<M, NW, SKEWED>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);

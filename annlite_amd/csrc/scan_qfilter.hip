@@ -162,6 +162,8 @@ struct TileState {
 // row slices only -- the reference's own PQ tests run Ks = 512 and 768 (tests/test_pq_index.py:80-163)
 template <int M, int NQ, int NW, int WPS, bool SKEWED, bool TILES, bool CODE16 = false>
 __global__ __launch_bounds__(NW * 64, WPS) void adc_scan_qfilter_kernel(const ScanArgs a) {
+    // (the u16-table pass behind a byte-table launch that may give up: ScanArgs::gate)
+    if (a.gate && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     static_assert(!CODE16 || (!SKEWED && !TILES), "uint16 code tables: PLAIN layout, row slices");
     constexpr int QG = 8;                 // queries per LDS entry
     constexpr int QT = QG * NQ;           // queries per workgroup

@@ -102,6 +102,10 @@ class AnnLite:
         self.n_probe = max(n_probe, n_cells)  # index.py:94: the reference visits every cell
         self._n_probe_arg = n_probe
         self._ivf_prune = bool(kwargs.pop('ivf_prune', False))
+        # devices=[0, 1, ...]: the code table row-sharded over these GPUs behind this ONE object (MultiGpuPQIndex: one
+        # process, one stream per device, packed per-shard top-k merged on the first device); default: the current device
+        self._devices = kwargs.pop('devices', None)
+        self._shard_block = int(kwargs.pop('shard_block', 65536))
         self.n_cells = n_cells
         if isinstance(metric, str):
             metric = Metric.from_string(metric)
@@ -159,6 +163,11 @@ class AnnLite:
             from .core.index.hnsw_pq_gpu import HnswPQGpuIndex
 
             return HnswPQGpuIndex(dim=self.n_dim, metric=self.metric, pq_codec=self._pq_codec, **kw)
+        if self._devices is not None and len(self._devices) > 1:
+            from .core.index.multi_gpu import MultiGpuPQIndex
+
+            return MultiGpuPQIndex(dim=self.n_dim, metric=self.metric, pq_codec=self._pq_codec, devices=self._devices,
+                                   block=self._shard_block, **kw)
         return PQFlatGpuIndex(dim=self.n_dim, metric=self.metric, pq_codec=self._pq_codec, **kw)
 
     # ------------------------------------------------------------------ bookkeeping (index.py:574-599, 952-963)

@@ -176,9 +176,10 @@ def adc_scan_topk_packed(codes: torch.Tensor, lut: torch.Tensor, B: int, k: int,
 def pq_search_topk(lut_kind: int, queries: torch.Tensor, codebooks: torch.Tensor, codes: torch.Tensor, k: int, M: int,
                    Ks: int, valid_bits: Optional[torch.Tensor] = None, row_base: int = 0, n_rows: Optional[int] = None,
                    codes_layout: int = CODES_PLAIN, workspace: Optional[ScanWorkspace] = None, packed: bool = False,
-                   sqrt: bool = False):
-    """LUT build + scan + top-k in one C call (``annlite_pq_search_topk``).  ``queries`` f32 [B, D] already
-    pre-processed (normalised for cosine).  Returns (f32 [B,k], i64 [B,k]) or, with ``packed``, i64 [B,k,2]."""
+                   sqrt: bool = False, state=None):
+    """LUT build + scan + top-k in one C call (``annlite_pq_search_topk_ex``).  ``queries`` f32 [B, D] already
+    pre-processed (normalised for cosine).  Returns (f32 [B,k], i64 [B,k]) or, with ``packed``, i64 [B,k,2].
+    ``state``: the table's ``_capi.ScanState`` (the library's kernel choice remembers what earlier launches measured)."""
     N = codes.shape[0] if n_rows is None else n_rows
     B, D = queries.shape
     cb = code_bytes_of(codes)
@@ -192,9 +193,10 @@ def pq_search_topk(lut_kind: int, queries: torch.Tensor, codebooks: torch.Tensor
     else:
         od = torch.empty((B, k), dtype=torch.float32, device=dev)
         oi = torch.empty((B, k), dtype=torch.int64, device=dev)
-    check(lib().annlite_pq_search_topk(lut_kind, queries.data_ptr(), B, D, codebooks.data_ptr(), codes.data_ptr(), cb,
-                                       codes_layout, N, M, Ks, _ptr(valid_bits), k, row_base, _ptr(od), _ptr(oi), _ptr(op),
-                                       1 if sqrt else 0, ws.data_ptr(), ws.numel(), stream_ptr()), 'pq_search_topk')
+    check(lib().annlite_pq_search_topk_ex(lut_kind, queries.data_ptr(), B, D, codebooks.data_ptr(), codes.data_ptr(), cb,
+                                          codes_layout, N, M, Ks, _ptr(valid_bits), k, row_base, _ptr(od), _ptr(oi), _ptr(op),
+                                          1 if sqrt else 0, ws.data_ptr(), ws.numel(), stream_ptr(),
+                                          state.ptr if state is not None else None), 'pq_search_topk')
     return op if packed else (od, oi)
 
 

@@ -453,8 +453,8 @@ def main():
         # 64 lanes x 16 byte entries (byte-table kernel) or x 8 u16 entries (u16 kernels); M=64: ds_read_b64, 2 cycles,
         # 64 x 4.  256 CUs at 2.4 GHz (MI355X_MICROARCH.md: 256 B / clk / CU).
         plan_k = _capi.scan_plan(n_local, M, Ks, index.code_bytes, B, k)
-        variant = index._kernel[0] if getattr(index, '_kernel', None) else 0
-        byte_tables = plan_k.qt == 32 and variant in (0, 50)
+        # (which M = 16 kernel served the table is the library's choice, from what its launches measured: index.scan_kernel)
+        byte_tables = plan_k.qt == 32 and index.scan_kernel != 'u16 tables' and os.environ.get('ANNLITE_SCAN_VARIANT', '0') in ('0', '50')
         per_clk = 256 if byte_tables else 128
         lds_peak = 256 * per_clk * 2.4e9
         kernel_name = ('adc_scan_generic_kernel' if not plan_k.fast else 'adc_scan_qfilter64_kernel' if M == 64 else
@@ -464,6 +464,7 @@ def main():
             'bound': 'lds', 'achieved': lookups_per_s, 'peak': lds_peak, 'unit': 'look-ups/s', 'frac': lookups_per_s / lds_peak,
             'traffic': traffic,
             'kernel': kernel_name, 'kernel_ms': kernel_ms, 'lookups_per_clk_per_cu': per_clk,
+            'kernel_choice': index.scan_kernel,
             'peak_note': 'design-relative: one ds_read_b128 (ds_read_b64 at M=64) per wave64 per 4 (2) LDS cycles x 64 lanes x the '
                          'entries this kernel packs per read (16 one-byte entries; u16 kernels 8; M=64 4) x 256 CUs x 2.4 GHz: the '
                          'roof of THIS table format, not a chip constant',

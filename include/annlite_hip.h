@@ -16,7 +16,10 @@
  *   - all launches are asynchronous on `stream`; the caller synchronises.
  *   - no shared mutable state inside the library: calls on different streams / host threads are
  *     independent (the reference's pq_bind is serial under the GIL, hnsw_bind attaches the LUT to a
- *     shared space object and is not re-entrant: include/hnswlib/space_pq.h:55-64).
+ *     shared space object and is not re-entrant: include/hnswlib/space_pq.h:55-64).  What a call
+ *     remembers for the next one -- which scan kernel suits a code table -- lives in an
+ *     annlite_scan_state the CALLER owns (one per table), never in the process.  The thread-local
+ *     items are the last-error message and the measurement hooks (annlite_profile_*).
  *   - there is NO CPU fallback in this library: if no gfx950 device is present the launches fail
  *     with ANNLITE_ERR_HIP.
  *
@@ -34,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ANNLITE_HIP_ABI_VERSION 1
+#define ANNLITE_HIP_ABI_VERSION 2
 
 /* exported symbols (the library is built with -fvisibility=hidden) */
 #define ANNLITE_API __attribute__((visibility("default")))
@@ -197,6 +200,14 @@ ANNLITE_API int annlite_pq_search_topk(int lut_kind, const float *queries_dev, i
                            int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev, int64_t k,
                            int64_t row_base, float *out_dist_dev, int64_t *out_id_dev, int64_t *out_packed_dev,
                            int flags, void *workspace_dev, size_t workspace_bytes, void *stream);
+/* ... with the caller's per-table state (see annlite_scan_state below; NULL = annlite_pq_search_topk) */
+struct annlite_scan_state;
+ANNLITE_API int annlite_pq_search_topk_ex(int lut_kind, const float *queries_dev, int64_t B, int64_t D,
+                              const float *codebooks_dev, const void *codes_dev, int code_bytes, int codes_layout,
+                              int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev, int64_t k,
+                              int64_t row_base, float *out_dist_dev, int64_t *out_id_dev, int64_t *out_packed_dev,
+                              int flags, void *workspace_dev, size_t workspace_bytes, void *stream,
+                              struct annlite_scan_state *state);
 
 /* Same scan, but return the UNMERGED per-slice lists: plan.n_slices * k candidates per query
  * ([B][n_slices*k], unordered across slices, (+inf,-1) where a slice had fewer rows).  The set is a
@@ -212,10 +223,22 @@ ANNLITE_API int annlite_adc_scan_candidates(const void *codes_dev, int code_byte
  * launch stream; annlite_profile_last_scan_ms() waits for the last one and returns its duration. */
 ANNLITE_API int annlite_profile_enable(int on);
 ANNLITE_API int annlite_profile_last_scan_ms(float *ms);
-/* Kernel selection on the calling thread (A/B measurements; the index plug-in's calibration): variant 0 = the
- * default plan, 31 = u16 filter tables, 50 = byte filter tables (M = 16), others: DESIGN.md; -1 = follow the
- * ANNLITE_SCAN_VARIANT environment variable (the initial state).  Plans and workspace sizes follow the selection. */
-ANNLITE_API int annlite_scan_select_variant(int variant);
+/* Kernel choice (M = 16, k <= 16): byte filter tables (the default) or u16 filter tables -- made INSIDE the library, per
+ * call, never by a process-wide switch.  Without a state every byte-table launch is guarded: it gives up when its
+ * candidate rate says the code table has no structure (independent uniform codes: the byte filter leaks) and a gated
+ * u16-table pass queued behind it redoes the scan (~10 us per batch of gated launches that return at once otherwise).
+ * With a state -- ONE PER CODE TABLE, created once, passed to annlite_pq_search_topk_ex -- every byte-table launch leaves
+ * its candidate count in the state's host-mapped block; later calls read it without synchronising and run the right
+ * kernel directly (unguarded), until the table has doubled or halved.  Results are identical whatever runs.  A state must
+ * not be used by two host threads at once (one searcher per index, as the reference has: SURVEY.md section 8b);
+ * destroy it only after the launches that were given it have completed.
+ * annlite_scan_state_info: kernel = 0 undecided, 1 byte tables, 2 u16 tables; rows / candidates of the deciding launch.
+ * (ANNLITE_SCAN_VARIANT in the environment, read per call, still forces one instantiation for A/B measurements.) */
+typedef struct annlite_scan_state annlite_scan_state;
+ANNLITE_API int annlite_scan_state_create(annlite_scan_state **out);
+ANNLITE_API int annlite_scan_state_destroy(annlite_scan_state *state);
+ANNLITE_API int annlite_scan_state_reset(annlite_scan_state *state);
+ANNLITE_API int annlite_scan_state_info(annlite_scan_state *state, int32_t *kernel, int64_t *rows, uint64_t *candidates);
 /* Debug aid: with ANNLITE_DEBUG_COUNTERS=1 in the environment the scan counts events; this copies the 8 uint64
  * counters of the last scan to the host.  u16 kernels: [0] slow-block entries [1] (wave,query) candidate events
  * [2] events that inserted [3] bound publications [4] candidate rows.  Byte-table kernel: [0] wave-steps with a
@@ -226,6 +249,9 @@ ANNLITE_API int annlite_debug_counters(uint64_t *out8);
  * earliest start, [1] latest end; sums over the work items of [2] start stamp, [3] initialisation + first table build,
  * [4] step loop, [5] wait at the last barrier, [6] list store + merge; [7] work items. */
 ANNLITE_API int annlite_debug_timeline(uint64_t *out8);
+/* ... and per work item (up to 4096 records of 8 uint64): query tile, row slice, the stamps start / table built / step loop
+ * left / last barrier passed / end, block index. */
+ANNLITE_API int annlite_debug_items(uint64_t *out, int64_t max_items, int64_t *n_items);
 
 /* Convert between the PLAIN and the SKEWED code-table layout (uint8 codes).
  * forward (inverse=0): table_out[id][j] = codes_in[i][(j + id) mod M]   -- scatter rows i -> id

@@ -1,6 +1,7 @@
 #!/usr/bin/env bash
 # Build the reference's two native extensions from the sources where they lie
-# under /root/reference into $ANNLITE_REF_BUILD (default $TMPDIR/annlite_oracle_ref): OUTSIDE the repository.
+# under /root/reference into oracle/_ref/ ($ANNLITE_REF_BUILD overrides): git-ignored binaries only -- no reference source or
+# generated code stays anywhere; the directory is the repository's own (not a shared world-writable /tmp path).
 #
 # TEST INFRASTRUCTURE ONLY.  The outputs are used in THIS container to
 #   (1) pin oracle/pq_oracle.c + oracle/pq_oracle.py against the real reference
@@ -15,12 +16,14 @@
 set -euo pipefail
 REF=${REF:-/root/reference}
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-# outside the repository (nothing built from the reference ever sits in the tree that is pushed / sent to the GPU box)
-OUT="${ANNLITE_REF_BUILD:-${TMPDIR:-/tmp}/annlite_oracle_ref}"
+# oracle/_ref/: .gitignore'd (stays out of history), NOT .gpurunignore'd (the two .so files travel to the GPU box like the
+# library's own); only extension modules land here, generated C/C++ is deleted right after compiling
+OUT="${ANNLITE_REF_BUILD:-$HERE/_ref}"
 if [ ! -d "$REF/bindings" ]; then
   echo "build_ref: $REF not present, skipping (GPU box uses committed golden fixtures)"; exit 0
 fi
 mkdir -p "$OUT"
+chmod 700 "$OUT"
 rm -f "$OUT"/*.cpp "$OUT"/*.c  # never keep generated sources (they quote the reference)
 PYINC=$(python3 -c "import sysconfig; print(sysconfig.get_paths()['include'])")
 NPINC=$(python3 -c "import numpy; print(numpy.get_include())")

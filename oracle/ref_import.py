@@ -3,8 +3,7 @@
 TEST INFRASTRUCTURE ONLY -- never imported by ``annlite_amd`` (the product), by the
 ``-m gpu`` tests, by ``__graft_entry__.smoke()`` or by ``bench.py``.  It only works in the
 build container, where ``/root/reference`` exists and ``oracle/build_ref.sh`` has compiled the
-reference's two native extensions into ``$ANNLITE_REF_BUILD`` (default ``$TMPDIR/annlite_oracle_ref``,
-outside the repository).  On the GPU box ``available()`` is False
+reference's two native extensions into ``oracle/_ref/`` (git-ignored; ``$ANNLITE_REF_BUILD`` overrides).  On the GPU box ``available()`` is False
 and everything that depends on it is skipped; parity there rests on the committed golden
 fixtures (``tests/golden/*.npz``) produced by ``tests/golden/make_golden.py`` through this module.
 
@@ -23,22 +22,34 @@ import types
 from unittest.mock import MagicMock
 
 REF_ROOT = os.environ.get('ANNLITE_REFERENCE', '/root/reference')
-# where oracle/build_ref.sh puts the reference's compiled extensions: outside the repository
-_REF_DIR = os.environ.get('ANNLITE_REF_BUILD') or os.path.join(os.environ.get('TMPDIR') or '/tmp', 'annlite_oracle_ref')
+# where oracle/build_ref.sh puts the reference's compiled extensions: the repository's own, git-ignored oracle/_ref/ (a
+# predictable world-writable /tmp path would let another local user plant a module this process then executes)
+_REF_DIR = os.environ.get('ANNLITE_REF_BUILD') or os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ref')
 _EXT = sysconfig.get_config_var('EXT_SUFFIX')
 
 _loaded = None
 
 
+def _trusted(path: str) -> bool:
+    """the module file and its directory belong to this user and are not writable by anyone else"""
+    try:
+        for p in (path, os.path.dirname(path)):
+            st = os.stat(p)
+            if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+                return False
+        return True
+    except OSError:
+        return False
+
+
 def available() -> bool:
-    return os.path.isdir(os.path.join(REF_ROOT, 'annlite')) and os.path.isfile(
-        os.path.join(_REF_DIR, 'pq_bind' + _EXT)
-    )
+    path = os.path.join(_REF_DIR, 'pq_bind' + _EXT)
+    return os.path.isdir(os.path.join(REF_ROOT, 'annlite')) and os.path.isfile(path) and _trusted(path)
 
 
 def _load_ext(fullname: str, filename: str):
     path = os.path.join(_REF_DIR, filename + _EXT)
-    if not os.path.isfile(path):
+    if not os.path.isfile(path) or not _trusted(path):
         return None
     loader = importlib.machinery.ExtensionFileLoader(fullname, path)
     spec = importlib.util.spec_from_file_location(fullname, path, loader=loader)

@@ -57,12 +57,13 @@ else:
         codes = ops.codes_skew(codes)
 plan = scan_plan(N, M, Ks, 1, B, k)
 ws = ops.ScanWorkspace()
+state = _capi.ScanState()  # (as the index plug-in does: the library settles on a kernel after the first launches)
 valid = torch.full(((N + 31) // 32 + 1,), -1, dtype=torch.int32, device=dev) if a.valid else None
 _capi.profile_enable(True)
 ms = []
 for it in range(a.iters):
     if a.fused:
-        d, i = ops.pq_search_topk(LUT_L2, q, cb, codes, k, M, Ks, codes_layout=a.layout, workspace=ws, valid_bits=valid)
+        d, i = ops.pq_search_topk(LUT_L2, q, cb, codes, k, M, Ks, codes_layout=a.layout, workspace=ws, valid_bits=valid, state=state)
     else:
         lut = ops.lut_build(q, cb, LUT_L2, LAYOUT_TILED, plan.qi)
         d, i = ops.adc_scan_topk(codes, lut, B, k, M, Ks, codes_layout=a.layout, workspace=ws, valid_bits=valid)
@@ -70,6 +71,7 @@ for it in range(a.iters):
 torch.cuda.synchronize()
 look = B * N * M
 med = float(np.median(ms[len(ms) // 2:]))  # (the first iterations include module load and the clock ramp)
+print('kernel choice:', _capi.ScanState.KERNELS[state.info()[0]], state.info())
 print('scan kernel ms: median of the last %d: %.4f  min %.4f  first %.3f' % (len(ms) - len(ms) // 2, med, min(ms), ms[0]),
       ' lookups/s %.3e' % (look / (med * 1e-3)), ' alg GB/s %.1f' % (look / (med * 1e-3) / 1e9))
 
@@ -79,6 +81,24 @@ if os.environ.get('ANNLITE_DEBUG_COUNTERS') and plan.qt == 32:
     print('byte-table kernel: wave-steps with candidates %d, pushed %d, exact sums %d, queued for a list %d, table rebuilds %d, consumer batches %d; '
           'per workgroup: consumer inside batches %.1f us, wave 0 at epoch ends %.1f us' % (c[0], c[1], c[2], c[3], c[5], c[6], c[4] / nwg / 2400., c[7] / nwg / 2400.))
     print('byte-table kernel timeline (us; per-work-item averages but the span):', _capi.debug_timeline())
+    it = _capi.debug_items()
+    if len(it):
+        t0 = it[:, 2].min()
+        tot = (it[:, 6] - it[:, 2]) / 100.0
+        scan = (it[:, 4] - it[:, 3]) / 100.0
+        print('items: total us min %.1f mean %.1f max %.1f; step loop us min %.1f mean %.1f max %.1f; last end %.1f' %
+              (tot.min(), tot.mean(), tot.max(), scan.min(), scan.mean(), scan.max(), (it[:, 6].max() - t0) / 100.0))
+        order = np.argsort(-it[:, 6])[:6]
+        print('  the last to end (tile, slice: build / loop / wait / merge us, end at):',
+              ['%d,%d: %.1f/%.1f/%.1f/%.1f @%.1f' % (it[j, 0], it[j, 1], (it[j, 3] - it[j, 2]) / 100., (it[j, 4] - it[j, 3]) / 100.,
+                                                   (it[j, 5] - it[j, 4]) / 100., (it[j, 6] - it[j, 5]) / 100., (it[j, 6] - t0) / 100.) for j in order])
+        mg = (it[:, 6] - it[:, 5]) / 100.0
+        print('  merge phase us: median %.1f, the 32 longest mean %.1f max %.1f' % (np.median(mg), np.sort(mg)[-32:].mean(), mg.max()))
+        for name, col in (('tile', 0), ('slice', 1), ('xcd', None)):
+            key = it[:, 7] % 8 if col is None else it[:, col]
+            means = [(int(v), float(scan[key == v].mean())) for v in np.unique(key)]
+            means.sort(key=lambda x: x[1])
+            print('  step loop by %s: fastest %s ... slowest %s' % (name, ['%d:%.1f' % m for m in means[:4]], ['%d:%.1f' % m for m in means[-4:]]))
 elif os.environ.get('ANNLITE_DEBUG_COUNTERS'):
     c = _capi.debug_counters()
     n_wave_steps = (N // 64) * ((B + plan.qt - 1) // plan.qt)

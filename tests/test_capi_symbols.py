@@ -23,7 +23,7 @@ def test_header_symbols_are_exported_and_bound():
     out = subprocess.check_output(['nm', '-D', '--defined-only', _capi.LIB_PATH]).decode()
     exported = set(re.findall(r'\bT (annlite_\w+)', out))
     assert exported == set(declared), exported ^ set(declared)
-    assert lib.annlite_hip_abi_version() == 1
+    assert lib.annlite_hip_abi_version() == 2
 
 
 def test_scan_plan_arithmetic_no_gpu():

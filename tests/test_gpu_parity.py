@@ -33,7 +33,7 @@ def untile(lut_tiled: np.ndarray, B, M, Ks, qi):
 def test_native_library_is_loaded(ops):
     from annlite_amd import _capi
 
-    assert _capi.lib().annlite_hip_abi_version() == 1
+    assert _capi.lib().annlite_hip_abi_version() == 2
     assert _capi.device_count() >= 1
     assert 'gfx950' in _capi.device_arch(0)
     with open('/proc/self/maps') as f:
@@ -671,7 +671,8 @@ def test_pad_queries_of_a_ragged_batch_generate_no_candidates(ops, oracle, monke
 @pytest.mark.parametrize('variant', ['0', '50', '31', '30', '32'])
 def test_scan_kernel_variants_agree(ops, oracle, variant, monkeypatch):
     """every selectable M=16 scan kernel (byte filter tables = the default / 50; u16 filter tables with 16 / 12 / 8 waves)
-    is bit-exact; selected through the environment and through annlite_scan_select_variant"""
+    is bit-exact; selected through the environment (ANNLITE_SCAN_VARIANT: A/B measurements).  Without the variable the
+    library chooses itself (test_library_picks_the_scan_kernel)."""
     from annlite_amd import _capi
 
     rs = np.random.RandomState(3)
@@ -681,15 +682,106 @@ def test_scan_kernel_variants_agree(ops, oracle, variant, monkeypatch):
     rd, ri = oracle.adc_search_c(lut, codes, k)
     monkeypatch.setenv('ANNLITE_SCAN_VARIANT', variant)
     assert _capi.scan_plan(N, M, Ks, 1, B, k).qt == (32 if variant in ('0', '50') else 16)
-    d, i, _ = _scan(ops, codes, lut, k, 1)
-    assert np.array_equal(d, rd) and np.array_equal(i, ri)
+    for layout in (1, 0):
+        d, i, _ = _scan(ops, codes, lut, k, layout)
+        assert np.array_equal(d, rd) and np.array_equal(i, ri)
+
+
+def _event_ms(fn, reps=5):
+    import torch
+
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts))
+
+
+def test_library_picks_the_scan_kernel(ops, oracle, monkeypatch):
+    """Kernel choice inside the library (annlite_hip.h: annlite_scan_state).  2M rows of independent
+    uniform codes -- the byte filter leaks on them (~38 ms per 1024-query batch at 10M rows against 3.4 for the u16 kernel):
+      * a plain C-ABI call (no variant, no state) must stay within 1.3x of the u16 kernel forced through the environment:
+        its guarded byte-table launch gives up within microseconds and the gated u16 pass behind it redoes the scan;
+      * with a per-table state the library settles on the u16 kernel after the first launch has completed;
+      * data with structure settles on byte tables;
+      * all of it bit-identical to the CPU oracle on a sample of the queries."""
+    import torch
+    from annlite_amd import Metric, PQCodec, _capi
+    from annlite_amd._capi import LUT_L2
+
+    monkeypatch.delenv('ANNLITE_SCAN_VARIANT', raising=False)
+    torch.manual_seed(5)
+    N, M, Ks, B, k, D = 2_000_000, 16, 256, 1024, 10, 128
+    codes = torch.randint(0, 256, (N, M), dtype=torch.uint8, device='cuda')
+    cb = torch.randn((M, Ks, D // M), device='cuda')
+    q = torch.randn((B, D), device='cuda')
+    sk = ops.codes_skew(codes)
+    ws = ops.ScanWorkspace()
+
+    def run(state=None):
+        return ops.pq_search_topk(LUT_L2, q, cb, sk, k, M, Ks, codes_layout=1, workspace=ws, state=state)
+
+    monkeypatch.setenv('ANNLITE_SCAN_VARIANT', '31')
+    ms_u16 = _event_ms(run)
+    d31, i31 = run()
     monkeypatch.delenv('ANNLITE_SCAN_VARIANT')
-    _capi.scan_select_variant(int(variant))
-    try:
-        d, i, _ = _scan(ops, codes, lut, k, 0)
-    finally:
-        _capi.scan_select_variant(-1)
-    assert np.array_equal(d, rd) and np.array_equal(i, ri)
+    ms_plain = _event_ms(run)
+    d0, i0 = run()
+    assert torch.equal(d0, d31) and torch.equal(i0, i31)
+    assert ms_plain <= 1.3 * ms_u16, (ms_plain, ms_u16)
+    st = _capi.ScanState()
+    assert st.info()[0] == 0
+    for _ in range(3):
+        ds, is_ = run(st)
+        torch.cuda.synchronize()
+    assert st.info()[0] in (1, 2), st.info()  # settled (which kernel depends on how badly THIS table leaks)
+    ms_state = _event_ms(lambda: run(st))
+    assert ms_state <= 1.3 * ms_u16, (ms_state, ms_u16, st.info())
+    assert torch.equal(ds, d31) and torch.equal(is_, i31)
+    # the give-up path itself, forced: a budget of 8 candidates per workgroup trips at once -- the gated u16 pass must deliver
+    # the same bits, and a state must settle on the u16 kernel
+    monkeypatch.setenv('ANNLITE_GUARD_BASE', '8')
+    dg, ig = run()
+    assert torch.equal(dg, d31) and torch.equal(ig, i31)
+    st3 = _capi.ScanState()
+    for _ in range(3):
+        dg, ig = run(st3)
+        torch.cuda.synchronize()
+        assert torch.equal(dg, d31) and torch.equal(ig, i31)
+    assert st3.info()[0] == 2, st3.info()
+    monkeypatch.delenv('ANNLITE_GUARD_BASE')
+    import os
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/kernel_choice_2m_uniform_codes.txt', 'w') as f:
+        f.write('2M x 16 uniform codes, 1024 queries, ms per batch: u16 forced %.3f, stateless (guarded) %.3f, with state %.3f (%s)\n'
+                % (ms_u16, ms_plain, ms_state, st.info()))
+    lut = ops.lut_build(q[:4], cb, LUT_L2).cpu().numpy()
+    rd, ri = oracle.adc_search_c(lut, codes.cpu().numpy(), k)
+    assert np.array_equal(d0[:4].cpu().numpy(), rd) and np.array_equal(i0[:4].cpu().numpy(), ri)
+    # data with structure: byte tables stay
+    rs = np.random.RandomState(21)
+    A = rs.randn(16, D).astype(np.float32)
+    x = (rs.randn(400_000, 16).astype(np.float32) @ A + 0.05 * rs.randn(400_000, D).astype(np.float32)).astype(np.float32)
+    qs = (rs.randn(64, 16).astype(np.float32) @ A + 0.05 * rs.randn(64, D).astype(np.float32)).astype(np.float32)
+    codec = PQCodec(dim=D, n_subvectors=M, n_clusters=256, metric=Metric.EUCLIDEAN, n_init=1)
+    codec.seed = 4
+    codec.fit(x[:8192], iter=5)
+    codes2 = oracle.encode_c(x, codec.codebooks)
+    st2 = _capi.ScanState()
+    sk2 = ops.codes_skew(ops.to_dev(codes2))
+    for _ in range(3):
+        d2, i2 = ops.pq_search_topk(LUT_L2, ops.to_dev(qs), codec.codebooks_dev, sk2, k, M, Ks, codes_layout=1, workspace=ws, state=st2)
+        torch.cuda.synchronize()
+    assert st2.info()[0] == 1, st2.info()  # byte tables
+    lut2 = oracle.get_dist_mat_c(qs, codec.codebooks, oracle.EUCLIDEAN)
+    rd2, ri2 = oracle.adc_search_c(lut2, codes2, k)
+    assert np.array_equal(d2.cpu().numpy(), rd2) and np.array_equal(i2.cpu().numpy(), ri2)
 
 
 @pytest.mark.parametrize('tune', [('1,2,192,0', '64', '7'), ('3,4,448,3', '127', '8'), ('100000,2,384,3', '96', '4')])
@@ -991,3 +1083,51 @@ def test_annlite_facade_with_graph_index(ops, tmp_path):
         res.append([[m.id for m in d.matches] for d in docs])
     agree = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(*res)])
     assert agree >= 0.9, agree
+
+
+@pytest.mark.parametrize('mname,metric', [('euclidean', 'EUCLIDEAN'), ('cosine', 'COSINE')])
+def test_multi_gpu_index_on_one_device(ops, oracle, mname, metric, tmp_path):
+    """``AnnLite(..., devices=[0, 0])`` -- the single-process multi-GPU index with both shards on the one device of the box --
+    against the flat index: identical ids AND distances (the packed per-shard results are merged on the raw sums by the
+    kernel the multi-process path uses, metric epilogue last), through index / search / delete / filter / dump + reopen."""
+    import torch
+    from annlite_amd import AnnLite, Metric
+    from annlite_amd.core.index.multi_gpu import MultiGpuPQIndex
+    from annlite_amd.index import Document, DocumentArray
+
+    rs = np.random.RandomState(12)
+    D, M, N, B, k = 64, 16, 20_000, 33, 10
+    A = rs.randn(8, D).astype(np.float32)
+    x = (rs.randn(N, 8).astype(np.float32) @ A + 0.05 * rs.randn(N, D).astype(np.float32)).astype(np.float32)
+    x[5000:5040] = x[17]  # ties across shard blocks (block = 1024 rows)
+    q = np.concatenate([x[17:18], (rs.randn(B - 1, 8).astype(np.float32) @ A).astype(np.float32)])
+    flat = AnnLite(D, metric=mname, n_subvectors=M, data_path=tmp_path / 'flat')
+    flat.train(x[:8192])
+    multi = AnnLite(D, metric=mname, n_subvectors=M, data_path=tmp_path / 'multi', devices=[0, 0], shard_block=1024)
+    multi._pq_codec.set_codebooks(flat._pq_codec.codebooks)
+    assert isinstance(multi.vec_index(0), MultiGpuPQIndex)
+    docs = lambda: DocumentArray([Document(id=str(i), embedding=x[i], tags={'price': i % 11}) for i in range(N)])
+    flat.index(docs())
+    multi.index(docs())
+    assert multi.index_size == flat.index_size == N
+    for filt in (None, {'price': {'$lt': 3}}):
+        fd, fi = flat.search_numpy(q, filter=filt or {}, limit=k)
+        md, mi = multi.search_numpy(q, filter=filt or {}, limit=k)
+        for b in range(B):
+            assert np.array_equal(fi[b], mi[b]) and np.array_equal(fd[b], md[b]), (filt, b)
+    gone = [str(int(i)) for i in fi[0][:3]] + ['17', '5001']
+    flat.delete(gone)
+    multi.delete(gone)
+    fd, fi = flat.search_numpy(q, limit=k)
+    md, mi = multi.search_numpy(q, limit=k)
+    for b in range(B):
+        assert np.array_equal(fi[b], mi[b]) and np.array_equal(fd[b], md[b])
+    # device tensors in -> device tensors out
+    td, ti = multi.vec_index(0).search_batch(ops.to_dev(q), limit=k)
+    assert td.is_cuda and ti.shape == (B, k)
+    # snapshot + reopen onto the same number of shards
+    multi.dump()
+    again = AnnLite(D, metric=mname, n_subvectors=M, data_path=tmp_path / 'multi', devices=[0, 0], shard_block=1024)
+    ad, ai = again.search_numpy(q, limit=k)
+    for b in range(B):
+        assert np.array_equal(ai[b], mi[b]) and np.array_equal(ad[b], md[b])
