@@ -828,8 +828,10 @@ static SearchMode search_policy(annlite_scan_state *s, int64_t N, int64_t M, int
         const bool gave_up = s->host[1] != 0;
         const uint64_t cand = (uint64_t)s->host[2] | ((uint64_t)s->host[3] << 32);
         const uint64_t b = s->host[4] ? s->host[4] : 1;
-        // with structure: ~300 candidates per query at 10M rows; without: tens of thousands
-        const bool leaks = gave_up || cand / b > 4096;
+        // what a guarded launch's workgroups compare their own counts with (guard_base + rows drawn / 32 each), summed over
+        // the launch: every query tile scans all N rows.  With structure: ~300 candidates per query at 10M rows -- 30x below it
+        const uint64_t n_rows = s->host[5];
+        const bool leaks = gave_up || cand > 1024ull * 256ull + n_rows * ((b + 31) / 32) / 32;
         if (s->kernel == 0 || (s->kernel == 1 && leaks)) {
             s->kernel = leaks ? 2 : 1;
             s->rows = (int64_t)s->host[5];

@@ -765,15 +765,53 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                         __builtin_amdgcn_s_setprio(3);  // (serial code on a SIMD shared with three or four scanning waves)
                         unsigned long long e[2];
                         bool act[2];
+                        // HEAVY load -- some wave has more than kPopPerRing entries waiting (a block full of near rows; the candidate
+                        // generator of the re-rank stage, whose lists take 16 keys per slice) -- is taken 128 at a time whatever
+                        // rings it sits in: ring r contributes take_r = min(avail_r, what is left of the 128) entries, slot s (two
+                        // per lane) finds its ring by comparing with the prefix sums (15 broadcasts).  At 8 per ring and batch a
+                        // burst took the consumer five batches, ~20 us -- with the workgroup at its final barrier when it came in
+                        // the last steps -- and the candidate generator ran at 0.75 of its rate with one shared ring.
+                        const bool heavy = __ballot(lane < NS && avail > (uint32_t)kPopPerRing) != 0;
+                        if (heavy) {
+                            uint32_t incl = lane < NS ? avail : 0u;  // lanes 0 .. NS-1: ring = lane
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const uint32_t i = (uint32_t)(my_i + 4 * u);
-                            act[u] = i < avail;
-                            e[u] = 0ull;
-                            if (act[u]) e[u] = ldsv<unsigned long long>(lds.ring + 8u * ((uint32_t)my_ring * kWaveRing + ((head_v + i) & (kWaveRing - 1))));
+                            for (int o = 1; o < 16; o <<= 1) {
+                                const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+                                if (lane >= o) incl += up;
+                            }
+                            const uint32_t excl = incl - (lane < NS ? avail : 0u);
+                            const uint32_t take = excl >= 128u ? 0u : (avail < 128u - excl ? avail : 128u - excl);
+                            e[0] = e[1] = 0ull;
+                            act[0] = act[1] = false;
+                            uint32_t my_take = 0;
+#pragma unroll 1
+                            for (int r = 0; r < NS; ++r) {
+                                const uint32_t ex_r = (uint32_t)__builtin_amdgcn_readlane((int)excl, r);
+                                const uint32_t tk_r = (uint32_t)__builtin_amdgcn_readlane((int)take, r);
+                                const uint32_t hd_r = (uint32_t)__builtin_amdgcn_readlane((int)head_v, r);
+                                if (tk_r == 0u) continue;
+#pragma unroll
+                                for (int u = 0; u < 2; ++u) {
+                                    const uint32_t sl = (uint32_t)lane + 64u * (uint32_t)u;
+                                    if (sl >= ex_r && sl < ex_r + tk_r) {
+                                        act[u] = true;
+                                        e[u] = ldsv<unsigned long long>(lds.ring + 8u * ((uint32_t)r * kWaveRing + ((hd_r + sl - ex_r) & (kWaveRing - 1))));
+                                    }
+                                }
+                                if (has_ring && my_ring == r) my_take = tk_r;
+                            }
+                            head_v = (head_v + my_take) & 0xffffu;
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const uint32_t i = (uint32_t)(my_i + 4 * u);
+                                act[u] = i < avail;
+                                e[u] = 0ull;
+                                if (act[u]) e[u] = ldsv<unsigned long long>(lds.ring + 8u * ((uint32_t)my_ring * kWaveRing + ((head_v + i) & (kWaveRing - 1))));
+                            }
+                            head_v = (head_v + avail) & 0xffffu;  // (avail <= kPopPerRing everywhere)
                         }
                         n_seen += (uint32_t)(__popcll(__ballot(act[0])) + __popcll(__ballot(act[1])));
-                        head_v = (head_v + (avail < (uint32_t)kPopPerRing ? avail : (uint32_t)kPopPerRing)) & 0xffffu;
                         if (lane < NS) ldsv_st<uint32_t>(lds.heads() + 4u * (uint32_t)lane, head_v);  // the wave may reuse the entries
                         q8_consume<M, SKEWED>(fc, lds, e, act, lane, n_kept, n_offered, pend_o, pend_j);
                         __builtin_amdgcn_s_setprio(0);

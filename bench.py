@@ -98,8 +98,11 @@ def gen_chunk(chunk: int, rows: int, D: int, A: torch.Tensor, dev) -> torch.Tens
 def sub_run(cmd, timeout_s):
     """One of the other BASELINE configurations as a sub-run of this file / scripts/bench_hnsw.py: its JSON line, or the
     reason it is missing."""
+    env = {k: v for k, v in os.environ.items()  # (a sub-run is a plain single-process run, whatever launched this one)
+           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'ROLE_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+                        'TORCHELASTIC_RUN_ID', 'ANNLITE_FORCE_GATHER')}
     try:
-        r = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        r = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT, env=env)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
         if r.returncode != 0 or not lines:
             return {'error': f'rc={r.returncode}', 'stderr_tail': r.stderr[-400:]}
@@ -116,6 +119,34 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    N_, D_, M_, Ks_, B_, k_ = args.rows, args.dim, args.m, args.ks, args.batch, args.k
+    default_workload = (N_, D_, M_, Ks_, B_, k_, args.metric, args.data) == (10_000_000, 128, 16, 256, 1024, 10, 'euclidean', 'lowrank')
+    legs = args.legs.split(',') if args.legs not in ('auto', 'none') else (
+        [] if args.legs == 'none' else ['rerank', 'ivf'] + (['uniform', 'c2', 'c4', 'c5'] if default_workload else []))
+    if args.no_rerank and 'rerank' in legs:
+        legs.remove('rerank')
+    if args.ivf_cells <= 1 and 'ivf' in legs:
+        legs.remove('ivf')
+    if world > 1:
+        legs = []  # (the extra legs are single-GPU figures)
+    # ---- the other BASELINE configurations and the reference's own test distribution, as sub-runs (rank 0, N=1), run BEFORE this
+    # process creates its own GPU context (a second resident process costs the sub-run's kernels 25-40 %) ------------
+    sub = {}
+    if rank == 0 and world == 1:
+        me = os.path.join(ROOT, 'bench.py')
+        common = ['--legs', 'none', '--gpus', '1']
+        if 'c2' in legs:  # config 2: 1M x 128, m=16, L2, batch 1024
+            sub['c2'] = sub_run([me, '--rows', '1000000', '--steps', '40', '--warmup', '10'] + common, 240)
+        if 'c4' in legs:  # config 4: 10M x 768, m=64, cosine, batch 256
+            sub['c4'] = sub_run([me, '--rows', '10000000', '--dim', '768', '--m', '64', '--batch', '256', '--metric', 'cosine',
+                                 '--steps', '20', '--warmup', '5', '--cpu-queries', '16', '--cpu-repeats', '3',
+                                 '--recall-queries', '32'] + common, 400)
+        if 'c5' in legs:  # config 5: HNSW-over-PQ, 5M x 128, ef_search 128, GPU walk + exact re-rank
+            sub['c5'] = sub_run([os.path.join(ROOT, 'scripts', 'bench_hnsw.py'), '--rows', '5000000', '--steps', '5'], 600)
+        if 'uniform' in legs:  # U[0,1)^D: unstructured codes -- the kernel the library picks for them (SURVEY.md 8d)
+            sub['uniform'] = sub_run([me, '--data', 'uniform', '--steps', '10', '--warmup', '3', '--cpu-queries', '0',
+                                      '--recall-queries', '32'] + common, 300)
+
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     use_dist = world > 1 or 'RANK' in os.environ  # torchrun with 1 rank also initialises RCCL
@@ -129,15 +160,6 @@ def main():
 
     N, D, M, Ks, B, k = args.rows, args.dim, args.m, args.ks, args.batch, args.k
     r_lat = 16 if D <= 128 else 64
-    default_workload = (N, D, M, Ks, B, k, args.metric, args.data) == (10_000_000, 128, 16, 256, 1024, 10, 'euclidean', 'lowrank')
-    legs = args.legs.split(',') if args.legs not in ('auto', 'none') else (
-        [] if args.legs == 'none' else ['rerank', 'ivf'] + (['uniform', 'c2', 'c4', 'c5'] if default_workload else []))
-    if args.no_rerank and 'rerank' in legs:
-        legs.remove('rerank')
-    if args.ivf_cells <= 1 and 'ivf' in legs:
-        legs.remove('ivf')
-    if world > 1:
-        legs = []  # (the extra legs are single-GPU figures)
     gA = torch.Generator(device=dev)
     gA.manual_seed(99)
     A = torch.randn((r_lat, D), generator=gA, device=dev)
@@ -429,23 +451,6 @@ def main():
             'all_cores': {'value': nq_all / cpu_all_s, 'cores': threads, 'sample': f'{nq_all} queries, OpenMP over queries, one run'},
             'gpu_matches_cpu_bit_exact': parity,
         }
-
-    # ---- the other BASELINE configurations and the reference's own test distribution, as sub-runs (rank 0, N=1) ------------
-    sub = {}
-    if rank == 0 and world == 1:
-        me = os.path.join(ROOT, 'bench.py')
-        common = ['--legs', 'none', '--gpus', '1']
-        if 'c2' in legs:  # config 2: 1M x 128, m=16, L2, batch 1024
-            sub['c2'] = sub_run([me, '--rows', '1000000', '--steps', '40', '--warmup', '10'] + common, 240)
-        if 'c4' in legs:  # config 4: 10M x 768, m=64, cosine, batch 256
-            sub['c4'] = sub_run([me, '--rows', '10000000', '--dim', '768', '--m', '64', '--batch', '256', '--metric', 'cosine',
-                                 '--steps', '20', '--warmup', '5', '--cpu-queries', '16', '--cpu-repeats', '3',
-                                 '--recall-queries', '32'] + common, 400)
-        if 'c5' in legs:  # config 5: HNSW-over-PQ, 5M x 128, ef_search 128, GPU walk + exact re-rank
-            sub['c5'] = sub_run([os.path.join(ROOT, 'scripts', 'bench_hnsw.py'), '--rows', '5000000', '--steps', '5'], 600)
-        if 'uniform' in legs:  # U[0,1)^D: unstructured codes -- the kernel the library picks for them (SURVEY.md 8d)
-            sub['uniform'] = sub_run([me, '--data', 'uniform', '--steps', '10', '--warmup', '3', '--cpu-queries', '0',
-                                      '--recall-queries', '32'] + common, 300)
 
     if rank == 0:
         # The scan does not stream its algorithmic bytes from HBM (every code row is shared by the 16 / 32 queries of a

@@ -437,6 +437,11 @@ def test_index_plugin_vs_oracle_and_hnsw_fixture(ops, oracle, name, mname, metri
     sub = np.arange(0, g['N'], 3)
     d3, i3 = idx.search(g['queries'][1], limit=5, indices=sub)
     assert set(i3).issubset(set(sub))
+    # ... against the oracle ON THE SUBSET (minus the row deleted above): ids and distances, not just membership
+    live = sub[sub != int(i[0][0])]
+    my_codes = mine if metric == 3 else ref_codes
+    rd3, ri3 = oracle.index_search(g['queries'][1:2], cb, my_codes[live], metric, 5)
+    assert np.array_equal(i3, live[ri3[0]]) and np.array_equal(d3, rd3[0])
 
 
 def test_index_untrained_raises(ops):
@@ -816,6 +821,54 @@ def test_byte_table_kernel_epochs_and_rebuilds(ops, oracle, tune, monkeypatch):
             assert _capi.debug_counters()[5] > 0  # tables were rebuilt
 
 
+def test_byte_table_kernel_on_the_bench_distribution_2m_rows(ops, oracle, monkeypatch):
+    """The headline kernel on the bench's own data (rank-16 latent Gaussian + noise, trained codec) at 2M rows, DEFAULT epoch
+    schedule / table resolution / rebuild rule, 256 queries, bit for bit against the CPU oracle -- and the debug counters
+    must show that the machinery the small tests never reach has run: an epoch end (all waves met at the barrier) and a
+    table rebuild.  The two knobs changed to make a rebuild certain at this size: the first bound is made loose (512 seed rows)
+    and a slot asks for a new table when its T has fallen below 6/8 (default 4/8) of what the table was built for -- 8 tiles x
+    32 slices of 62 500 rows: at the epoch end after step 15 the slices have seen 491k rows, 960x the seed's.  (With the
+    defaults a rebuild is rare: 10-20 of a 10M-row launch's 256 workgroups.)"""
+    import torch
+    from annlite_amd import Metric, PQCodec, _capi
+    from annlite_amd._capi import LUT_L2
+
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    N, D, M, Ks, B, k = 2_000_000, 128, 16, 256, 256, 10
+    A = torch.randn((16, D), generator=g, device=dev)
+    gen = lambda n: (torch.randn((n, 16), generator=g, device=dev) @ A + 0.05 * torch.randn((n, D), generator=g, device=dev)).contiguous()
+    codec = PQCodec(dim=D, n_subvectors=M, n_clusters=Ks, metric=Metric.EUCLIDEAN, n_init=1)
+    codec.seed = 7
+    codec.fit(gen(20480), iter=20)
+    cb = codec.codebooks_dev
+    codes = torch.cat([ops.pq_encode(gen(500_000), cb) for _ in range(4)])
+    q = gen(B)
+    monkeypatch.delenv('ANNLITE_SCAN_VARIANT', raising=False)
+    for name in ('ANNLITE_Q8_TUNE', 'ANNLITE_Q8_TARGET'):
+        monkeypatch.delenv(name, raising=False)
+    monkeypatch.setenv('ANNLITE_SEED_ROWS', '512')
+    monkeypatch.setenv('ANNLITE_Q8_REBUILD', '6')
+    monkeypatch.setenv('ANNLITE_DEBUG_COUNTERS', '1')
+    assert _capi.scan_plan(N, M, Ks, 1, B, k).qt == 32
+    st = _capi.ScanState()
+    d, i = ops.pq_search_topk(LUT_L2, q, cb, ops.codes_skew(codes), k, M, Ks, codes_layout=1, state=st)
+    torch.cuda.synchronize()
+    c = _capi.debug_counters()
+    assert c[7] > 0, c   # wave 0 spent cycles at epoch ends: the barriers were reached
+    assert c[5] > 0, c   # tables were rebuilt
+    monkeypatch.delenv('ANNLITE_DEBUG_COUNTERS')
+    lut = ops.lut_build(q, cb, LUT_L2).cpu().numpy()
+    rd, ri = oracle.adc_search_c(lut, codes.cpu().numpy(), k, threads=oracle.max_threads())
+    assert np.array_equal(d.cpu().numpy(), rd) and np.array_equal(i.cpu().numpy(), ri)
+    # the defaults too, PLAIN layout
+    monkeypatch.delenv('ANNLITE_SEED_ROWS')
+    monkeypatch.delenv('ANNLITE_Q8_REBUILD')
+    d, i = ops.pq_search_topk(LUT_L2, q, cb, codes, k, M, Ks, codes_layout=0, state=st)
+    assert np.array_equal(d.cpu().numpy(), rd) and np.array_equal(i.cpu().numpy(), ri)
+
+
 def test_full_size_properties_config2(ops, oracle):
     """BASELINE config 2 at full size (1M x 128-d, PQ m=16, batch 1024, k=10) through size-independent
     properties: ascending order, every returned distance equals the gathered ADC distance of that row
@@ -995,9 +1048,11 @@ def test_hnsw_pq_candidates_with_gpu_rerank(ops, mname, metric, walk):
     assert rr >= 0.9, rr
 
 
-def test_config5_hnsw_pq_1m_rows_oracle_side(ops, oracle):
-    """BASELINE config 5 at a size the driver can build (1M x 128-d, PQ m=16, ef_search=128; 5M is
-    scripts/bench_hnsw.py): graph walk on the GPU, checked from the ORACLE side --
+@pytest.mark.parametrize('N,min_overlap,min_recall', [(1_000_000, 0.9, 0.9), (5_000_000, 0.85, 0.88)])
+def test_config5_hnsw_pq_oracle_side(ops, oracle, N, min_overlap, min_recall):
+    """BASELINE config 5 (HNSW-over-PQ, 128-d, PQ m=16, ef_search=128) at 1M rows and at its STATED size, 5M rows (graph
+    construction ~60 s on the box's host cores; measured there: candidate overlap 0.95+, re-rank recall 0.92 -- the
+    thresholds leave room for the sample of 256 queries): graph walk on the GPU, checked from the ORACLE side --
       * every distance the walk reports is hnswlib::PQLookup of that row (space_pq.h:15-37): the CPU oracle's
         adc_gather_c on the walk's candidate ids, bit for bit;
       * the top-10 of the graph search (ADC ranking) overlaps the oracle's EXHAUSTIVE ADC top-10 >= 0.9;
@@ -1012,7 +1067,7 @@ def test_config5_hnsw_pq_1m_rows_oracle_side(ops, oracle):
     dev = torch.device('cuda', 0)
     g = torch.Generator(device=dev)
     g.manual_seed(99)
-    N, D, M, B, k, ef = 1_000_000, 128, 16, 256, 10, 128
+    D, M, B, k, ef = 128, 16, 256, 10, 128
     A = torch.randn((16, D), generator=g, device=dev)
 
     def gen(n):
@@ -1043,7 +1098,7 @@ def test_config5_hnsw_pq_1m_rows_oracle_side(ops, oracle):
     nq = 64
     od, oi = oracle.adc_search_c(lut_np[:nq], codes_np, k, threads=oracle.max_threads())
     overlap = np.mean([len(set(hi[b]) & set(oi[b])) / k for b in range(nq)])
-    assert overlap >= 0.9, overlap
+    assert overlap >= min_overlap, overlap
     assert (np.diff(hd, axis=1) >= 0).all()
     for b in range(nq):  # same ids => same (sqrt of the) oracle distance
         pos = {int(i): j for j, i in enumerate(oi[b])}
@@ -1057,7 +1112,7 @@ def test_config5_hnsw_pq_1m_rows_oracle_side(ops, oracle):
     truth = best.topk(k, largest=False).indices.cpu().numpy()
     ri = ri.cpu().numpy()
     rec = np.mean([len(set(ri[b]) & set(truth[b])) / k for b in range(B)])
-    assert rec >= 0.9, rec
+    assert rec >= min_recall, rec
     assert bool((rd[:, 1:] >= rd[:, :-1]).all())
 
 
