@@ -114,6 +114,12 @@ __global__ __launch_bounds__(256) void merge_partial_kernel(const unsigned long 
     }
 }
 
+// reset of the scan's result lists / shared bounds / counters to all-ones where no launch of the plan does it on the way
+__global__ __launch_bounds__(256) void fill_ones_kernel(u32x4 *p, int64_t n16) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) p[i] = (u32x4){~0u, ~0u, ~0u, ~0u};
+}
+
 // Unmerged candidates: partial keys [B][NS][k] -> (dist, id) [B][NS*k]  (rerank candidate generator)
 __global__ __launch_bounds__(256) void export_partial_kernel(const unsigned long long *partial, int64_t total,
                                                             int64_t row_base, float *out_d, int64_t *out_i) {
@@ -273,7 +279,7 @@ struct FastCfg {
     int M, QI, NQ, NW, WPS, wg_per_cu, id;
     int mode;  // 4: u16 filter tables (scan_qfilter.hip: 8 queries per LDS entry, M = 64: 4), 5: byte filter tables
                // (scan_q8.hip: 16 queries per LDS entry, tables quantised by the workgroup itself)
-    int qt() const { return (mode == 5 ? 16 : (M == 64 ? 4 : 8)) * NQ; }
+    int qt() const { return mode == 5 ? (M == 64 ? 8 : 16 * NQ) : (M == 64 ? 4 : 8) * NQ; }
     bool qf() const { return true; }  // integer filter + exact recompute, shared bounds (every fast kernel)
 };
 
@@ -323,6 +329,9 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
             return true;
         case 32: *c = {32, 4, 1, 12, 3, 1, 3230, 4}; return true;  // u16 tables, 8 queries / WG
         case 64:
+            // default: byte tables (scan_q8.hip, WIDE: 8 queries per 8-byte entry, u16 sums), 15 scanning waves + 1 consumer;
+            // k > 16, tile mode and variant 31: the u16-table kernel (4 queries per entry, 12 waves)
+            if ((v == 0 || v == 50) && !tiles && k <= 16 && Ks == 256) { *c = {64, 4, 1, 16, 4, 1, 6450, 5}; return true; }
             if (v == 30) *c = {64, 4, 1, 16, 4, 1, 6430, 4};       // qfilter64, 16 waves (spills: 7.4 ms at C4 vs 5.9)
             else if (v == 32) *c = {64, 4, 1, 8, 2, 1, 6432, 4};   // qfilter64, 8 waves (6.7 ms)
             else *c = {64, 4, 1, 12, 3, 1, 6431, 4};               // default: qfilter64, 4 queries / WG, 12 waves
@@ -405,7 +414,7 @@ static int plan_query_impl(int64_t N, int64_t M, int64_t Ks, int code_bytes, int
         const int64_t bpad = pad_queries(B, plan->qt);
         plan->workspace_bytes = (int64_t)n_tiles * plan->qt * ns * k * 8 + 256 + bpad * 4 + 256;
         if (c.qf())
-            plan->workspace_bytes += bpad * 4 + 256 + 2 * (bpad * 8 + 256) + (bpad * ns * 8 * gk2_cell_keys(M) + 256) + (n_tiles * 4 + 256) +
+            plan->workspace_bytes += bpad * 4 + 256 + 2 * (bpad * 8 + 256) + (bpad * ns * 8 * (c.mode == 5 ? kGk2Keys : gk2_cell_keys(M)) + 256) + (n_tiles * 4 + 256) +
                                      256 /* item counter */ + 256 /* guard block */ + bpad * M * Ks * 2 + 256;
         // byte-table plan chosen by default: the gated u16-table launch that redoes the scan if the byte-table launch gives
         // up (search_policy) works in its own region behind this one
@@ -557,13 +566,17 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             const size_t bpad = (size_t)pad_queries(B, plan.qt);
             auto r256 = [](size_t x) { return (x + 255) / 256 * 256; };
             fill = r256((size_t)a.n_tiles * plan.qt * plan.n_slices * k * 8) + r256(bpad * 8) +
-                   r256(bpad * plan.n_slices * 8 * gk2_cell_keys(M)) + r256((size_t)a.n_tiles * 4) + 256 /* item counter */ +
+                   r256(bpad * plan.n_slices * 8 * (c0.mode == 5 ? kGk2Keys : gk2_cell_keys(M))) + r256((size_t)a.n_tiles * 4) + 256 /* item counter */ +
                    256 /* guard block */;
         }
         fill_bytes = fill;
         FastCfg c1;
         fused_fill = N > 0 && plan.fast && fast_cfg(M, Ks, code_bytes, k, &c1, tm != nullptr) && c1.qf() && M != 64;  // lut_quantise_fused_kernel
-        if (!fused_fill) ANNLITE_HIP_TRY(hipMemsetAsync(workspace_dev, 0xff, fill, st));
+        // (own kernel: one launch like any other of the plan, no second mechanism on the stream)
+        if (!fused_fill) {
+            const int64_t n16 = (int64_t)((fill + 15) / 16);
+            hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (u32x4 *)workspace_dev, n16);
+        }
     }
     if (N == 0) return ANNLITE_OK;
     const int n_items = tm ? a.n_tiles
@@ -582,7 +595,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         a.q8_epoch_mul = 16;
         a.q8_ring_limit = 384;
         a.q8_import_mask = 3;
-        a.q8_target = 96;
+        a.q8_target = M == 64 ? 384 : 96;  // (M = 64: u16 sums of 64 entries clipped at 15 -- simulated: 6x the u16 tables' candidates)
         a.q8_rebuild_8ths = 4;
         if (const char *e = getenv("ANNLITE_Q8_REBUILD")) {
             const int t = atoi(e);
@@ -590,7 +603,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         }
         if (const char *e = getenv("ANNLITE_Q8_TARGET")) {
             const int t = atoi(e);
-            if (t >= 16 && t <= 127) a.q8_target = t;
+            if (t >= 16 && t <= (M == 64 ? 960 : 127)) a.q8_target = t;
         }
         if (const char *e = getenv("ANNLITE_Q8_TUNE")) {  // "epoch0,mul,ring_limit,import_mask" (measurements)
             int e0 = 15, mul = 16, rl = 384, im = 3;
@@ -611,7 +624,8 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             auto carve = [&](int64_t bytes) { char *r = wp; wp += ((bytes + 255) / 256) * 256; return r; };
             // [gkey][gk2][tile_done] directly behind the partial lists: the one fill covers exactly these four
             unsigned long long *gk = (unsigned long long *)carve(bpad * 8);
-            unsigned long long *gk2 = (unsigned long long *)carve(bpad * plan.n_slices * 8 * gk2_cell_keys(M));
+            // (the byte-table kernel publishes up to kGk2Keys keys per (query, slice) cell whatever M is)
+            unsigned long long *gk2 = (unsigned long long *)carve(bpad * plan.n_slices * 8 * (c.mode == 5 ? kGk2Keys : gk2_cell_keys(M)));
             unsigned int *tile_done = (unsigned int *)carve((int64_t)a.n_tiles * 4);
             unsigned int *item_counter = (unsigned int *)carve(4);
             unsigned int *guard_blk = (unsigned int *)carve(64);  // (reset to all-ones by the fill, like the counters)
@@ -671,7 +685,8 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 // byte-table kernel: its candidate transient shrinks with a tighter first bound faster than the seed launch
                 // grows (12 us per 8192 rows): 1.25M rows x 1024 queries 0.425 / 0.407 / 0.405 / 0.437 ms per batch at
                 // 8k / 16k / 32k / 64k seed rows, 10M rows 1.852 / 1.838 / 1.831 / 1.857
-                if (c.mode == 5) S = N / 32 < 8192 ? 8192 : N / 32 > 32768 ? 32768 : ((N / 32 + 1023) / 1024) * 1024;
+                if (c.mode == 5 && M != 64)  // (M = 64: two queries per seed workgroup, 63 us per 8192 rows)
+                    S = N / 32 < 8192 ? 8192 : N / 32 > 32768 ? 32768 : ((N / 32 + 1023) / 1024) * 1024;
                 if (const char *e = getenv("ANNLITE_SEED_ROWS")) S = atoll(e);
                 if (S > N) S = N;
                 if (S < 0) S = 0;  // (ANNLITE_SEED_ROWS=0: the scan starts without a bound)

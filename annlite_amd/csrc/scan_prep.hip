@@ -8,7 +8,9 @@ namespace annlite {
 // queries; entries [g4][Ks][64][4 x u16] (8 bytes)
 __global__ __launch_bounds__(1024) void lut_quantise64_kernel(const float *__restrict__ lut, int Ks, int qmax,
                                                             uint16_t *__restrict__ out, float *__restrict__ qstep,
-                                                            double *__restrict__ qlo, float *__restrict__ smax) {
+                                                            double *__restrict__ qlo, float *__restrict__ smax,
+                                                            float *__restrict__ qlom, const unsigned int *__restrict__ gate) {
+    if (gate && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;  // (see ScanArgs::gate)
     constexpr int M = 64, KPT = 16;  // 1024 threads: 16 codes per sweep
     __shared__ float s_lo[KPT][M][4], s_hi[KPT][M][4];
     __shared__ float s_step[4];
@@ -41,6 +43,7 @@ __global__ __launch_bounds__(1024) void lut_quantise64_kernel(const float *__res
         }
         s_lo[0][mm][i] = l;
         s_hi[0][mm][i] = h;
+        if (qlom) qlom[(int64_t)(g4 * 4 + i) * M + mm] = l;  // (the byte-table scan quantises the tables itself)
     }
     __syncthreads();
     if (tid < 4) {
@@ -61,6 +64,7 @@ __global__ __launch_bounds__(1024) void lut_quantise64_kernel(const float *__res
         smax[b] = sm;
     }
     __syncthreads();
+    if (!out) return;  // (byte-table plan: parameters only)
     float lo_r[4], st_r[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -743,7 +747,7 @@ int annlite::launch_lut_quantise(int64_t M, int64_t Ks, int64_t B, int64_t bpad,
                            qstep, qlo, smax, qlom, fillp, fillv, gate)
     if (M == 64)  // (no fill, no build: the caller memsets and builds the tables itself)
         hipLaunchKernelGGL(lut_quantise64_kernel, dim3((unsigned)(bpad / 4)), dim3(1024), 0, st, lut_dev, (int)Ks, qmax, q16,
-                           qstep, qlo, smax);
+                           qstep, qlo, smax, qlom, gate);
     else if (M == 8) { ANNLITE_QUANT(8); } else if (M == 16) { ANNLITE_QUANT(16); } else { ANNLITE_QUANT(32); }
 #undef ANNLITE_QUANT
     return launch_status("lut_quantise_fused_kernel");

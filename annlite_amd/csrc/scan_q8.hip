@@ -66,22 +66,48 @@ __device__ __forceinline__ uint32_t lds_base_addr() {
     return (uint32_t)(uintptr_t)(ANNLITE_LDS unsigned char *)g_smem;
 }
 
+// Q8Cfg: entries are clipped at QMAX; a slot without a bound yet ("open": nothing seeded it) clips at QOPEN so that its T
+// passes every row.  M <= 32: the byte sums ARE the filter sums (M * QMAX <= 240: a byte sum never carries), bounds are bytes
+// (0x80 | T, T <= 127), 32 queries per workgroup.  M = 64 (WIDE): 8 queries per 8-byte entry, the byte sums of 16 look-ups
+// (16 * 15 = 240) are widened into u16 sums four times per row, bounds are half-words (0x8000 | T), 8 queries per workgroup.
 template <int M>
 struct Q8Cfg {
-    static constexpr int QMAX = 240 / M, QOPEN = 112 / M;
+    static constexpr bool WIDE = M == 64;
+    static constexpr int QT = WIDE ? 8 : 32;
+    static constexpr int QMAX = WIDE ? 15 : 240 / M, QOPEN = WIDE ? 7 : 112 / M;
+    static constexpr uint32_t TMAX = WIDE ? 32767u : 127u, TFLAG = TMAX + 1u;
 };
+template <int M>
+__device__ __forceinline__ int q8_table_bytes(int Ks) {
+    return Q8Cfg<M>::WIDE ? (Ks + 1) * 512 : Ks * 2 * M * 16;  // WIDE: two half tables of 32 sub-spaces, [Ks + 1][32][8 B] each
+}
+
+// filter bound (TFLAG | T) implied by a k-th key for a table quantised with `step`:
+// T = floor((thr + slack32 - L) / step * (1 + 2^-19)) + 1, clamped to TMAX (a NaN lands there too: everything passes)
+template <int M>
+__device__ __forceinline__ uint32_t q8_bound_from_key(unsigned long long key, float smax_b, float step, double qlo_b) {
+    const uint32_t hi = (uint32_t)(key >> 32);
+    if (hi == kKeyInfHi) return 2u * Q8Cfg<M>::TFLAG - 1u;
+    const double thr = (double)ordered_to_f32(hi);
+    const double slack = (double)smax_b * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
+    double qd = (thr + slack - qlo_b) / (double)step * (1.0 + 1.0 / 524288.0);
+    qd = __builtin_floor(qd) + 1.0;
+    if (!(qd > 0.0)) qd = 0.0;
+    if (!(qd < (double)Q8Cfg<M>::TMAX)) qd = (double)Q8Cfg<M>::TMAX;
+    return Q8Cfg<M>::TFLAG | (uint32_t)qd;
+}
 
 template <int M>
 __device__ __forceinline__ void q8_slot_params(bool real, unsigned long long key, float range, float smax_b, double L, int target,
-                                               float &step, float &inv, float &clip, unsigned char &tbyte) {
+                                               float &step, float &inv, float &clip, uint32_t &tbits) {
     clip = (float)Q8Cfg<M>::QOPEN;
-    if (!real) {  // pad slot: all-zero table, never passes (0x7f - 0 has bit 7 clear)
+    if (!real) {  // pad slot: all-zero table, never passes (TMAX - 0 has the flag bit clear)
         step = 1.f;
         inv = 0.f;
-        tbyte = 0x7f;
+        tbits = Q8Cfg<M>::TMAX;
         return;
     }
-    float open_step = range / (float)Q8Cfg<M>::QOPEN;  // no bound yet: the whole range, everything passes (S <= 112 <= T = 127)
+    float open_step = range / (float)Q8Cfg<M>::QOPEN;  // no bound yet: the whole range, everything passes (S <= M * QOPEN <= TMAX)
     if (!(open_step > 1e-30f) || !(open_step < 1e30f)) open_step = 1.f;
     step = open_step;
     const uint32_t hi = (uint32_t)(key >> 32);
@@ -94,11 +120,11 @@ __device__ __forceinline__ void q8_slot_params(bool real, unsigned long long key
             const float smin = open_step * (1.f / 65536.f);
             if (!(s >= smin)) s = smin;  // (a larger step only lowers T)
             step = s;
-            clip = (float)Q8Cfg<M>::QMAX;  // T <= target <= 127 now and it only falls: sums above 127 can never pass
+            clip = (float)Q8Cfg<M>::QMAX;  // T <= target now and it only falls
         }
     }
     inv = 1.0f / step;
-    tbyte = qbound8_from_key<M>(key, smax_b, step, L);
+    tbits = q8_bound_from_key<M>(key, smax_b, step, L);
 }
 
 // The workgroup's byte table from the fp32 TILED tables of its 32 queries: thread (m, h) = (tid % M, (tid / M) % 2)
@@ -160,6 +186,52 @@ __device__ __forceinline__ void q8_build_table(const Q8Build &a, int tile, uint3
     }
 }
 
+// M = 64: the workgroup's byte table of its 8 queries (two fp32 TILED groups of 4) in the layout of the M = 64 u16 kernel
+// -- two half tables of 32 sub-spaces, [Ks + 1][32 columns][8 B], the second HALF_B = (Ks + 1) * 256 bytes behind the first,
+// row Ks a copy of row 0 (the wrap-coded SKEWED rows address one row down where a lane's column wraps: wrap64_mask) -- with
+// byte entries.  Thread (kr, m) = (tid / 64, tid % 64) walks the codes kr, kr + NT / 64, ...
+template <int NW>
+__device__ __forceinline__ void q8_build_table_wide(const Q8Build &a, int tile, uint32_t tab_ad, uint32_t inv_ad, uint32_t clip_ad,
+                                                    int tid) {
+    constexpr int M = 64, NT = NW * 64, KPT = NT / M;
+    const int m = tid % M, kr = tid / M;
+    const int n_g4 = ((a.B + 15) / 16) * 4;
+    const uint32_t half_b = (uint32_t)(a.Ks + 1) * 256u;
+    float lo_r[8], inv_r[8], clip_r[8];
+    const float *src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int g4 = tile * 2 + i;
+        const bool ok = g4 < n_g4;
+        src[i] = a.lut + ((int64_t)(ok ? g4 : 0) * a.Ks * M + m) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo_r[4 * i + e] = ok ? a.qlom[(int64_t)(g4 * 4 + e) * M + m] : 0.f;
+            inv_r[4 * i + e] = ok ? ldsv<float>(inv_ad + 4u * (uint32_t)(4 * i + e)) : 0.f;
+            clip_r[4 * i + e] = ldsv<float>(clip_ad + 4u * (uint32_t)(4 * i + e));
+        }
+    }
+    const uint32_t col = tab_ad + (uint32_t)(m >> 5) * half_b + (uint32_t)(m & 31) * 8u;
+#pragma unroll 2
+    for (int k = kr; k < a.Ks; k += KPT) {
+        uint32_t w[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f32x4 v = *(const f32x4 *)(src[i] + (int64_t)k * M * 4);
+            uint32_t pk = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = __builtin_fmaf(v[e] - lo_r[4 * i + e], inv_r[4 * i + e], -0.5f);
+                t = __builtin_fminf(t, clip_r[4 * i + e]);
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(t, e, pk);  // saturates below 0
+            }
+            w[i] = pk;
+        }
+        *(ANNLITE_LDS u32x2 *)(uintptr_t)(col + (uint32_t)k * 256u) = (u32x2){w[0], w[1]};
+        if (k == 0) *(ANNLITE_LDS u32x2 *)(uintptr_t)(col + (uint32_t)a.Ks * 256u) = (u32x2){w[0], w[1]};  // row Ks = row 0
+    }
+}
+
 constexpr int kRingSize = 1024;   // candidate ring entries (u64 each): one private ring of kWaveRing entries per scanning wave
 constexpr int kWaveRing = 64;     // (a wave-step pushes at most 64 entries at a time)
 constexpr int kPopPerRing = 8;    // entries the consumer takes from one wave's ring per batch (8 x 15 rings <= 128 = two per lane)
@@ -214,15 +286,38 @@ struct Q8Lds {
 // at 1.25M rows against a 290 us scan.  Unsorted bags compacted when full: ~1.5 us per compaction and a bound that
 // lags 22 insertions behind -- 2x the candidates.)
 
-// byte filter bound (0x80 | T) of a slot from a k-th key: T = floor((thr + slack32 - L) / step * (1 + 2^-19)) + 1 with the
+// filter bound (TFLAG | T) of a slot from a k-th key: T = floor((thr + slack32 - L) / step * (1 + 2^-19)) + 1 with the
 // slot's constants folded into c1 = (1 + 2^-19) / step, c0 = (slack32 - L) * c1 (set when the table is built)
-__device__ __forceinline__ unsigned char q8_bound(unsigned long long key, double c0, double c1) {
+template <int M>
+__device__ __forceinline__ uint32_t q8_bound(unsigned long long key, double c0, double c1) {
     const uint32_t hi = (uint32_t)(key >> 32);
-    if (hi == kKeyInfHi) return 0xff;
+    if (hi == kKeyInfHi) return 2u * Q8Cfg<M>::TFLAG - 1u;
     double qd = __builtin_floor(__builtin_fma((double)ordered_to_f32(hi), c1, c0)) + 1.0;
     if (!(qd > 0.0)) qd = 0.0;
-    if (!(qd < 127.0)) qd = 127.0;  // (a NaN lands here too: everything passes)
-    return (unsigned char)(0x80u | (uint32_t)qd);
+    if (!(qd < (double)Q8Cfg<M>::TMAX)) qd = (double)Q8Cfg<M>::TMAX;  // (a NaN lands here too: everything passes)
+    return Q8Cfg<M>::TFLAG | (uint32_t)qd;
+}
+// where the scanning waves load a slot's bound from: a byte per slot; WIDE: half-words, slots 1 and 2 (5 and 6) swapped -- the
+// order the widened sums come out in ((q0, q2), (q1, q3), (q4, q6), (q5, q7) per dword)
+template <int M>
+__device__ __forceinline__ uint32_t q8_bound_ad(const Q8Lds &o, int q) {
+    if constexpr (Q8Cfg<M>::WIDE) return o.shq + 2u * (uint32_t)((q & 4) | ((q & 1) << 1) | ((q >> 1) & 1));
+    else return o.shq + (uint32_t)q;
+}
+template <int M>
+__device__ __forceinline__ uint32_t q8_ld_bound(const Q8Lds &o, int q) {
+    if constexpr (Q8Cfg<M>::WIDE) return ldsv<unsigned short>(q8_bound_ad<M>(o, q));
+    else return ldsv<unsigned char>(q8_bound_ad<M>(o, q));
+}
+template <int M>
+__device__ __forceinline__ void q8_st_bound(const Q8Lds &o, int q, uint32_t v) {
+    if constexpr (Q8Cfg<M>::WIDE) ldsv_st<unsigned short>(q8_bound_ad<M>(o, q), (unsigned short)v);
+    else ldsv_st<unsigned char>(q8_bound_ad<M>(o, q), (unsigned char)v);
+}
+template <int M>
+__device__ __forceinline__ uint32_t q8_ld_built(const Q8Lds &o, int q) {  // T the slot's table was built for
+    if constexpr (Q8Cfg<M>::WIDE) return ldsv<unsigned short>(o.tb + 2u * (uint32_t)q);
+    else return ldsv<unsigned char>(o.tb + (uint32_t)q);
 }
 
 __device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t x) {
@@ -235,9 +330,10 @@ __device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t x) {
 // The global publication of a batch's bounds (the other row slices' workgroups import them) is DEFERRED to the next batch,
 // behind the issue of its table gathers: the device-scope atomics take microseconds and the wave's memory counter is in
 // order -- issued right away they sat in front of the next batch's gathers.
+template <int QT>
 __device__ __forceinline__ void q8_publish_global(const FlushCtx &c, const Q8Lds &o, int lane, unsigned long long &pend_o,
                                                   unsigned long long &pend_j) {
-    if (lane < 32) {
+    if (lane < QT) {  // (slots beyond QT never change; their cells do not exist)
         const int b = c.b0 + lane;
         if (pend_o != ~0ull && c.gkey) __hip_atomic_fetch_min(c.gkey + b, pend_o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (pend_j != ~0ull && c.gk2) {
@@ -266,13 +362,47 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         q[u] = (int)(e[u] >> 32) & 31;
-        const uint32_t sv = (uint32_t)(e[u] >> 40) & 0xffu;
-        const uint32_t tq = ldsv<unsigned char>(o.shq + (uint32_t)q[u]);
-        act[u] = act[u] && ((0x80u | sv) <= tq);  // still passes?  (pad slots, 0x7f, never push)
+        const uint32_t sv = (uint32_t)(e[u] >> 40) & 0xffffu;
+        const uint32_t tq = q8_ld_bound<M>(o, q[u]);
+        act[u] = act[u] && ((Q8Cfg<M>::TFLAG | sv) <= tq);  // still passes?  (pad slots, TMAX, never push)
     }
     n_kept += (uint32_t)(__popcll(__ballot(act[0])) + __popcll(__ballot(act[1])));
     // exact ascending-m fp32 sums of both rows (exact_row_sum's arithmetic; the loads of the two rows interleaved)
     float ex[2] = {0.f, 0.f};
+    if constexpr (Q8Cfg<M>::WIDE) {
+        // M = 64: one row at a time, its 64 table entries in four rounds of 16 gathers (the sum stays the ascending-m chain)
+        if (!(c.skip & 1)) {
+#pragma unroll 1
+            for (int u = 0; u < 2; ++u) {
+                if (!__ballot(act[u])) continue;
+                const uint32_t rid = act[u] ? (uint32_t)e[u] : 0u;
+                uint32_t cp[CW];
+                const uint32_t *p = (const uint32_t *)(c.codes + (int64_t)rid * M);
+#pragma unroll
+                for (int i = 0; i < CW; ++i) cp[i] = p[i];
+                if constexpr (SKEWED) skew64_decode(cp, (int)(rid % 32));  // two skewed halves, wrap-coded
+                const int b = c.b0 + (act[u] ? q[u] : 0);
+                const float *lq = c.lut + ((int64_t)(b >> 2) * c.Ks) * (M * 4) + (b & 3);
+                float sum = 0.f;
+                static_for<0, 4>([&](auto C) {
+                    constexpr int m0 = decltype(C)::value * 16;
+                    float vals[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int m = m0 + j;
+                        const uint32_t code = (cp[m / 4] >> (8 * (m % 4))) & 0xffu;
+                        vals[j] = lq[((int64_t)code * M + m) * 4];
+                    }
+                    if constexpr (m0 == 0) {
+                        if (u == 0) q8_publish_global<Q8Cfg<M>::QT>(c, o, lane, pend_o, pend_j);  // (the previous batch's, behind these gathers)
+                    }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) sum += vals[j];
+                });
+                ex[u] = sum;
+            }
+        }
+    } else
     if (!(c.skip & 1)) {
         uint32_t cp[2][CW];
 #pragma unroll
@@ -300,7 +430,7 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
                 vals[u][m] = lq[((int64_t)code * M + m) * 4];
             }
         }
-        q8_publish_global(c, o, lane, pend_o, pend_j);  // (the previous batch's, behind this batch's gathers)
+        q8_publish_global<Q8Cfg<M>::QT>(c, o, lane, pend_o, pend_j);  // (the previous batch's, behind this batch's gathers)
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -362,8 +492,8 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
             if (okey < ldsv<unsigned long long>(gkl_ad)) {  // tell the other workgroups of this query (the other row slices)
                 pend_o = okey;  // (keys only fall)
                 ldsv_st<unsigned long long>(gkl_ad, okey);
-                const unsigned char nb = q8_bound(okey, ldsv<double>(o.c0 + 8u * (uint32_t)lane), ldsv<double>(o.c1 + 8u * (uint32_t)lane));
-                if (nb < ldsv<unsigned char>(o.shq + (uint32_t)lane)) ldsv_st<unsigned char>(o.shq + (uint32_t)lane, nb);
+                const uint32_t nb = q8_bound<M>(okey, ldsv<double>(o.c0 + 8u * (uint32_t)lane), ldsv<double>(o.c1 + 8u * (uint32_t)lane));
+                if (nb < q8_ld_bound<M>(o, lane)) q8_st_bound<M>(o, lane, nb);
             }
         }
         if (c.gk2 && jkey != ~0ull) {  // the slice's j smallest keys changed: the sibling slices compute their bound from them
@@ -381,18 +511,18 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
 // live registers made the compiler spill the loop-invariant LDS base registers of the look-ups into the hot path.
 template <int M, int NW>
 __device__ __attribute__((noinline)) void q8_rebuild(q8_kernarg_ptr ka, int tile, int first, int slice) {
-    constexpr int QT = 32;
+    constexpr int QT = Q8Cfg<M>::QT;
     // first bounds of the item's queries: what the seed launch left in the shared array, or -- candidate generator, nothing
     // shared between the slices -- in this slice's row of the per-slice seeds ([n_slices][n_tiles * 32])
     const Q8Build a = {ka->lut, ka->qlom, ka->qstep, ka->smax, ka->qlo,
                        ka->gkey ? ka->gkey : (ka->gseed ? ka->gseed + (int64_t)slice * (ka->n_tiles * QT) : nullptr),
                        ka->Ks, ka->B, ka->k, ka->q8_target};
     const int tid = threadIdx.x;
-    const Q8Lds o(a.Ks * 2 * M * 16);
-    if (tid < QT) {
+    const Q8Lds o(q8_table_bytes<M>(a.Ks));
+    if (tid < 32) {  // (the control block has 32 slots whatever QT is: the consumer's lanes 0 .. 31 look at all of them)
         const uint32_t t8 = 8u * (uint32_t)tid, t4 = 4u * (uint32_t)tid;
         const int b = tile * QT + tid;
-        const bool real = b < a.B;
+        const bool real = tid < QT && b < a.B;
         unsigned long long key = ~0ull;
         if (first) {
             if (a.gkey && real) key = __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -406,7 +536,7 @@ __device__ __attribute__((noinline)) void q8_rebuild(q8_kernarg_ptr ka, int tile
             if (g < key) key = g;
         }
         float step, inv, clip;
-        unsigned char tb;
+        uint32_t tb;
         q8_slot_params<M>(real, key, real ? a.qstep[b] * (float)(32767 / M) : 0.f, real ? a.smax[b] : 0.f,
                           real ? a.qlo[b] : 0.0, a.target, step, inv, clip, tb);
         ldsv_st<float>(o.step + t4, step);
@@ -418,11 +548,15 @@ __device__ __attribute__((noinline)) void q8_rebuild(q8_kernarg_ptr ka, int tile
             ldsv_st<double>(o.c1 + t8, c1);
             ldsv_st<double>(o.c0 + t8, (slack - (real ? a.qlo[b] : 0.0)) * c1);
         }
-        ldsv_st<unsigned char>(o.shq + (uint32_t)tid, tb);
-        ldsv_st<unsigned char>(o.tb + (uint32_t)tid, tb);
+        if (tid < QT) {
+            q8_st_bound<M>(o, tid, tb);
+            if constexpr (Q8Cfg<M>::WIDE) ldsv_st<unsigned short>(o.tb + 2u * (uint32_t)tid, (unsigned short)tb);
+            else ldsv_st<unsigned char>(o.tb + (uint32_t)tid, (unsigned char)tb);
+        }
     }
     __syncthreads();
-    q8_build_table<M, NW>(a, tile, o.tab, o.inv, o.clip, tid);
+    if constexpr (Q8Cfg<M>::WIDE) q8_build_table_wide<NW>(a, tile, o.tab, o.inv, o.clip, tid);
+    else q8_build_table<M, NW>(a, tile, o.tab, o.inv, o.clip, tid);
     __syncthreads();
 }
 
@@ -519,10 +653,10 @@ __device__ __forceinline__ bool q8_item_map(const ScanArgs &a, int item, int &ti
 // kernarg segment (see q8_kernarg).
 template <int M, int NW>
 __device__ __attribute__((noinline)) void q8_finish_item(q8_kernarg_ptr ka, int tile, int slice) {
-    constexpr int QT = 32;
+    constexpr int QT = Q8Cfg<M>::QT;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int km1 = ka->k - 1, B = ka->B, n_slices = ka->n_slices, k = ka->k;
-    const Q8Lds lds(ka->Ks * 2 * M * 16);
+    const Q8Lds lds(q8_table_bytes<M>(ka->Ks));
     unsigned long long *partial = ka->partial;
     for (int q = wave; q < QT; q += NW) {
         const int b = tile * QT + q;
@@ -553,16 +687,17 @@ __device__ __attribute__((noinline)) void q8_finish_item(q8_kernarg_ptr ka, int 
 
 template <int M, int NW, bool SKEWED>
 __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const ScanArgs a) {
-    constexpr int QG = 16, NQ = 2, QT = QG * NQ, CW = M / 4, EB = 16, RB = M * EB, KSTRIDE = NQ * RB;
+    constexpr bool WIDE = Q8Cfg<M>::WIDE;
+    constexpr int NQ = 2, QT = Q8Cfg<M>::QT, CW = M / 4, EB = 16, RB = M * EB, KSTRIDE = NQ * RB;
     constexpr int NS = NW - 1;  // scanning waves; wave NS is the consumer
-    static_assert(M % 8 == 0 && M <= 32 && (KSTRIDE & (KSTRIDE - 1)) == 0, "unsupported shape");
+    static_assert(M % 8 == 0 && (M <= 32 || WIDE) && (KSTRIDE & (KSTRIDE - 1)) == 0, "unsupported shape");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int km1 = a.k - 1;
 
-    const int lut_bytes = a.Ks * KSTRIDE;
+    const int lut_bytes = q8_table_bytes<M>(a.Ks);
     const Q8Lds lds(lut_bytes);
     const q8_kernarg_ptr ka = q8_kernarg();
 
@@ -599,9 +734,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             __syncthreads();
             if (final) return;
             if (wave == 0) {
-                const int q = lane & 31;
-                const bool real = tile * QT + q < a.B && lane < 32;
-                const uint32_t tn = ldsv<unsigned char>(lds.shq + (uint32_t)q) & 0x7fu, tb = ldsv<unsigned char>(lds.tb + (uint32_t)q) & 0x7fu;
+                const int q = lane & (QT - 1);
+                const bool real = tile * QT + q < a.B && lane < QT;
+                const uint32_t tn = q8_ld_bound<M>(lds, q) & Q8Cfg<M>::TMAX, tb = q8_ld_built<M>(lds, q) & Q8Cfg<M>::TMAX;
                 const bool need = real && tn * 8u < tb * (uint32_t)a.q8_rebuild_8ths;
                 const int n_need = __popcll(__ballot(need)), n_real = __popcll(__ballot(real));
                 if (lane == 0) ldsv_st<uint32_t>(lds.ctl, (n_need > 0 && n_need * 4 >= n_real) ? 1u : 0u);
@@ -612,7 +747,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 if (a.dbg && tid == 0) atomicAdd(a.dbg + 5, 1ull);
             }
         };
-        for (int idx = tid; idx < QT * 16; idx += NW * 64) ldsv_st<unsigned long long>(lds.list + 8u * (uint32_t)idx, ~0ull);
+        for (int idx = tid; idx < 32 * 16; idx += NW * 64) ldsv_st<unsigned long long>(lds.list + 8u * (uint32_t)idx, ~0ull);  // (all 32 slots)
         if (tid < 16) {
             ldsv_st<uint32_t>(lds.tails() + 4u * (uint32_t)tid, 0);
             ldsv_st<uint32_t>(lds.heads() + 4u * (uint32_t)tid, 0);
@@ -639,7 +774,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 // whole tile
                 const int q = lane & 31, part = lane >> 5;
                 const int b = tile * QT + q;
-                const bool real = b < a.B;
+                const bool real = q < QT && b < a.B;
                 unsigned long long bound = ~0ull;
                 if (real) bound = __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (a.gk2 && a.jm1 < 2) {
@@ -704,8 +839,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 const uint32_t gkl_ad = lds.gkl + 8u * (uint32_t)q;
                 if (real && part == 0 && bound < ldsv<unsigned long long>(gkl_ad)) {
                     ldsv_st<unsigned long long>(gkl_ad, bound);
-                    const unsigned char nb = q8_bound(bound, ldsv<double>(lds.c0 + 8u * (uint32_t)q), ldsv<double>(lds.c1 + 8u * (uint32_t)q));
-                    if (nb < ldsv<unsigned char>(lds.shq + (uint32_t)q)) ldsv_st<unsigned char>(lds.shq + (uint32_t)q, nb);
+                    const uint32_t nb = q8_bound<M>(bound, ldsv<double>(lds.c0 + 8u * (uint32_t)q), ldsv<double>(lds.c1 + 8u * (uint32_t)q));
+                    if (nb < q8_ld_bound<M>(lds, q)) q8_st_bound<M>(lds, q, nb);
                 }
             };
             // Every scanning wave pushes into its OWN ring of kWaveRing entries (it alone writes the ring and its tail, the
@@ -837,7 +972,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     }
                     __builtin_amdgcn_s_sleep(4);
                 }
-                q8_publish_global(fc, lds, lane, pend_o, pend_j);
+                q8_publish_global<QT>(fc, lds, lane, pend_o, pend_j);
                 epoch_sync(final);
                 if (final) break;
                 if (ldsv<uint32_t>(lds.ctl)) {
@@ -848,7 +983,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                         const uint32_t tail_v = ldsv<uint32_t>(lds.tails() + 4u * (uint32_t)my_ring);
                         for (uint32_t i = (uint32_t)my_i; i < ((tail_v - head_v) & 0xffffu); i += 4u) {
                             const uint32_t ad = lds.ring + 8u * ((uint32_t)my_ring * kWaveRing + ((head_v + i) & (kWaveRing - 1)));
-                            ldsv_st<unsigned long long>(ad, ldsv<unsigned long long>(ad) & ~(0xffull << 40));
+                            ldsv_st<unsigned long long>(ad, ldsv<unsigned long long>(ad) & ~(0xffffull << 40));
                         }
                     }
                 }
@@ -864,17 +999,27 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             }
         } else {
             // ------------------------------------------------------------------------------- scanning waves
-            const int s = lane % M;
+            constexpr int NF = WIDE ? 4 : 8;  // filter words per row: 8 dwords of byte sums (32 queries) / 4 dwords of u16 sums (8)
+            const int s = lane % (WIDE ? 32 : M);
             const uint32_t bsh = (uint32_t)(s & 3);
             bool abit[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) abit[i] = (((s >> 2) >> i) & 1) != 0;
             // LDS byte addresses as integers
             typedef const ANNLITE_LDS u32x4 *lds_entry_ptr;
+            typedef const ANNLITE_LDS u32x2 *lds_entry8_ptr;
             const uint32_t lds0 = lds.tab;
-            uint32_t mbase[M];
+            uint32_t mbase[WIDE ? 1 : M];
+            if constexpr (!WIDE) {
 #pragma unroll
-            for (int t = 0; t < M; ++t) mbase[t] = lds0 + (uint32_t)(((s + t) % M) * EB);
+                for (int t = 0; t < M; ++t) mbase[t] = lds0 + (uint32_t)(((s + t) % M) * EB);
+            }
+            // WIDE: lane constant of the look-up addresses (the M = 64 u16 kernel's scheme): byte 0 = (lane % 32) * 8 (the column),
+            // byte 2 = 0x01 (second half table); the table starts at LDS address 0 (all LDS is dynamic)
+            const uint32_t lane_k = 0x00010000u | (uint32_t)((lane & 31) * 8);
+            if constexpr (WIDE) {
+                if (lds0 != 0u || a.Ks != 256) __builtin_trap();
+            }
             const uint32_t *codes32 = (const uint32_t *)a.codes;
             // rows are < 2^32 per call (plan): 32-bit row arithmetic keeps the loop control in SGPRs
             const uint32_t s_begin = (uint32_t)slice_begin, s_end = (uint32_t)slice_end, n_rows = (uint32_t)a.N;
@@ -889,7 +1034,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 return v;
             };
             uint32_t ccur[CW], cnext[CW];
-            uint32_t addr[M];
+            uint32_t addr[WIDE ? 1 : M];
             auto load_row = [&](uint32_t row, uint32_t (&c)[CW]) {
                 if constexpr (ANNLITE_Q8_EXP == 3) {  // (timing experiment: no code rows from memory)
 #pragma unroll
@@ -914,52 +1059,97 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 }
             };
             auto make_addr = [&](const uint32_t (&cc)[CW]) {
-                static_for<0, CW>([&](auto W) {
-                    constexpr int w = decltype(W)::value;
-                    uint32_t o0, o1, o2, o3;
-                    byte_shl4(cc[w], (uint32_t)ilog2_c(KSTRIDE), o0, o1, o2, o3);
-                    addr[4 * w + 0] = mbase[4 * w + 0] + o0;
-                    addr[4 * w + 1] = mbase[4 * w + 1] + o1;
-                    addr[4 * w + 2] = mbase[4 * w + 2] + o2;
-                    addr[4 * w + 3] = mbase[4 * w + 3] + o3;
-                });
+                if constexpr (!WIDE)
+                    static_for<0, CW>([&](auto W) {
+                        constexpr int w = decltype(W)::value;
+                        uint32_t o0, o1, o2, o3;
+                        byte_shl4(cc[w], (uint32_t)ilog2_c(KSTRIDE), o0, o1, o2, o3);
+                        addr[4 * w + 0] = mbase[4 * w + 0] + o0;
+                        addr[4 * w + 1] = mbase[4 * w + 1] + o1;
+                        addr[4 * w + 2] = mbase[4 * w + 2] + o2;
+                        addr[4 * w + 3] = mbase[4 * w + 3] + o3;
+                    });
             };
-            auto load_thp = [&](u32x4 (&t)[NQ]) {
+            // the slots' bounds as the filter words see them: (0x80 | T) bytes of 32 queries / (0x8000 | T) half-words of 8
+            auto load_thw = [&](uint32_t (&t)[NF]) {
+                if constexpr (WIDE) {
+                    const u32x4 v = *(volatile ANNLITE_LDS u32x4 *)(uintptr_t)lds.shq;
+                    t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
+                } else {
 #pragma unroll
-                for (int h = 0; h < NQ; ++h) t[h] = *(volatile ANNLITE_LDS u32x4 *)(uintptr_t)(lds.shq + 16u * (uint32_t)h);
+                    for (int h = 0; h < NQ; ++h) {
+                        const u32x4 v = *(volatile ANNLITE_LDS u32x4 *)(uintptr_t)(lds.shq + 16u * (uint32_t)h);
+                        t[4 * h + 0] = v.x, t[4 * h + 1] = v.y, t[4 * h + 2] = v.z, t[4 * h + 3] = v.w;
+                    }
+                }
             };
-            u32x4 thp[NQ];  // packed (0x80 | T) of the group's 16 queries
-            load_thp(thp);
+            uint32_t thw[NF];
+            load_thw(thw);
             // byte sums of the row for both entry groups (4 dwords x 4 x u8 each): the 2 M look-ups run through a ring of
             // DEPTH landing registers -- look-up i + DEPTH is issued as soon as look-up i has been added (all M look-ups
             // of a group in flight, as the u16 kernel has them, takes 64 landing VGPRs: with them the allocator spilled
             // six of the 16 loop-invariant LDS base registers into the step loop)
-            auto row_sums = [&](u32x4 (&acc)[NQ]) {
-                constexpr int DEPTH = ANNLITE_Q8_DEPTH, TOT = NQ * M;
-                u32x4 v[DEPTH];
-                auto fetch = [&](u32x4 &dst, uint32_t ad) {
-                    if constexpr (ANNLITE_Q8_EXP == 2) asm volatile("" : "=v"(dst) : "v"(ad));
-                    else dst = *(lds_entry_ptr)(uintptr_t)ad;
-                };
-                static_for<0, DEPTH>([&](auto I) {
-                    constexpr int i = decltype(I)::value;
-                    fetch(v[i], addr[i % M] + (uint32_t)((i / M) * RB));
-                });
-                static_for<0, TOT>([&](auto I) {
-                    constexpr int i = decltype(I)::value;
-                    asm volatile("" ::: "memory");
-                    if constexpr (ANNLITE_Q8_EXP == 1) {
-                        asm volatile("" ::"v"(v[i % DEPTH]));
-                        if constexpr (i % M == 0) acc[i / M] = thp[i / M];
-                    } else {
-                        if constexpr (i % M == 0) acc[i / M] = v[i % DEPTH];
-                        else acc[i / M] += v[i % DEPTH];
-                    }
-                    if constexpr (i + DEPTH < TOT) {
-                        constexpr int j = i + DEPTH;
-                        fetch(v[i % DEPTH], addr[j % M] + (uint32_t)((j / M) * RB));
-                    }
-                });
+            auto row_sums = [&](const uint32_t (&cc)[CW], uint32_t (&sums)[NF]) {
+                if constexpr (WIDE) {
+                    // M = 64: four chunks of 16 look-ups (ds_read_b64: 8 byte entries, ONE v_perm per address -- the wrap-coded
+                    // SKEWED layout), their byte sums (<= 16 * 15 = 240) widened into the row's u16 sums: dword 0 = queries
+                    // (0, 2), 1 = (1, 3), 2 = (4, 6), 3 = (5, 7)
+                    sums[0] = sums[1] = sums[2] = sums[3] = 0u;
+                    static_for<0, 4>([&](auto C) {
+                        constexpr int c0 = decltype(C)::value * 16;
+                        constexpr int half = c0 / 32;
+                        u32x2 v[16];
+                        static_for<0, 16>([&](auto T) {
+                            constexpr int t = c0 + decltype(T)::value;
+                            // byte 0 <- lane_k byte 0, byte 1 <- code byte t % 4, byte 2 <- lane_k byte 2 (second half) or 0, byte 3 <- 0
+                            constexpr uint32_t sel = 0x0c000000u | ((half ? 0x02u : 0x0cu) << 16) | ((4u + (uint32_t)(t % 4)) << 8);
+                            const uint32_t ad = __builtin_amdgcn_perm(cc[t / 4], lane_k, sel);
+                            v[t - c0] = *(lds_entry8_ptr)(uintptr_t)(ad + (uint32_t)((t % 32) * 8 + half * 0x100));
+                        });
+                        asm volatile("" ::: "memory");
+                        u32x2 bs = v[0];
+                        static_for<1, 16>([&](auto I) { bs += v[decltype(I)::value]; });
+                        sums[0] += bs.x & 0x00ff00ffu;
+                        sums[1] += __builtin_amdgcn_perm(0u, bs.x, 0x0c030c01u);  // (bytes 1, 3 -> half-words)
+                        sums[2] += bs.y & 0x00ff00ffu;
+                        sums[3] += __builtin_amdgcn_perm(0u, bs.y, 0x0c030c01u);
+                    });
+                } else {
+                    constexpr int DEPTH = ANNLITE_Q8_DEPTH, TOT = NQ * M;
+                    u32x4 acc[NQ];
+                    u32x4 v[DEPTH];
+                    auto fetch = [&](u32x4 &dst, uint32_t ad) {
+                        if constexpr (ANNLITE_Q8_EXP == 2) asm volatile("" : "=v"(dst) : "v"(ad));
+                        else dst = *(lds_entry_ptr)(uintptr_t)ad;
+                    };
+                    static_for<0, DEPTH>([&](auto I) {
+                        constexpr int i = decltype(I)::value;
+                        fetch(v[i], addr[i % M] + (uint32_t)((i / M) * RB));
+                    });
+                    static_for<0, TOT>([&](auto I) {
+                        constexpr int i = decltype(I)::value;
+                        asm volatile("" ::: "memory");
+                        if constexpr (ANNLITE_Q8_EXP == 1) {
+                            asm volatile("" ::"v"(v[i % DEPTH]));
+                            if constexpr (i % M == 0) acc[i / M] = (u32x4){thw[4 * (i / M)], thw[4 * (i / M) + 1], thw[4 * (i / M) + 2], thw[4 * (i / M) + 3]};
+                        } else {
+                            if constexpr (i % M == 0) acc[i / M] = v[i % DEPTH];
+                            else acc[i / M] += v[i % DEPTH];
+                        }
+                        if constexpr (i + DEPTH < TOT) {
+                            constexpr int j = i + DEPTH;
+                            fetch(v[i % DEPTH], addr[j % M] + (uint32_t)((j / M) * RB));
+                        }
+                    });
+#pragma unroll
+                    for (int h = 0; h < NQ; ++h) sums[4 * h + 0] = acc[h].x, sums[4 * h + 1] = acc[h].y, sums[4 * h + 2] = acc[h].z, sums[4 * h + 3] = acc[h].w;
+                }
+            };
+            // bit per passing (query) field of filter word i: S <= T  <=>  (flag | T) - S keeps the flag bit (no borrow crosses a
+            // field: S <= 127 resp. <= 960 < 0x8000)
+            auto hits = [&](uint32_t th, uint32_t sm) -> uint32_t {
+                if constexpr (WIDE) return (th - sm) & 0x80008000u;
+                else return (th - (sm & 0x7f7f7f7fu)) & ~sm & 0x80808080u;
             };
             uint32_t vcur = ~0u, vnext = ~0u;
             const uint32_t *valid = a.valid;
@@ -998,21 +1188,30 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                         load_row(row1, cnext);
                         vnext = load_valid(row1);
                     }
-                    if constexpr (!SKEWED) rotate_row<CW>(ccur, abit, bsh);
+                    if constexpr (!SKEWED) {
+                        if constexpr (WIDE) skew64_encode(ccur, lane & 31);  // PLAIN row -> this lane's wrap-coded SKEWED row
+                        else rotate_row<CW>(ccur, abit, bsh);
+                    }
                     unsigned long long vmask = ~0ull;
                     if (s_end - row0 < 64u) vmask = (1ull << (s_end - row0)) - 1ull;
                     // validity word of this lane's row, fetched one step ahead with the code bytes
                     if (valid) vmask &= __ballot((vcur >> (lane & 31)) & 1u);
                     make_addr(ccur);
-                    u32x4 acc[NQ];
-                    row_sums(acc);
-                    // any (query, lane) with S <= T ?  S < 128 and (0x80 | T) - (S & 0x7f) has bit 7 set (T <= 127: no borrow)
+                    uint32_t sums[NF];
+                    row_sums(ccur, sums);
+                    // any (query, lane) with S <= T ?
                     uint32_t anyv = 0;
+                    if constexpr (WIDE) {
 #pragma unroll
-                    for (int h = 0; h < NQ; ++h)
+                        for (int w = 0; w < NF; ++w) anyv |= thw[w] - sums[w];
+                        anyv &= 0x80008000u;
+                    } else {
+                        // S < 128 and (0x80 | T) - (S & 0x7f) has bit 7 set (T <= 127: no borrow)
 #pragma unroll
-                        for (int w = 0; w < 4; ++w) anyv |= (thp[h][w] - (acc[h][w] & 0x7f7f7f7fu)) & ~acc[h][w];
-                    unsigned long long rem = __ballot((anyv & 0x80808080u) != 0) & vmask;
+                        for (int w = 0; w < NF; ++w) anyv |= (thw[w] - (sums[w] & 0x7f7f7f7fu)) & ~sums[w];
+                        anyv &= 0x80808080u;
+                    }
+                    unsigned long long rem = __ballot(anyv != 0) & vmask;
                     if (rem && !(a.dbg_skip & 4)) {
                         ++n_slow;
                         // The step's candidates -- (lane, query) pairs with S <= T -- are few (one or two lanes of a step that has
@@ -1021,9 +1220,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                         // pushed with ONE ring reservation.  (Per dword and byte with ballots and one reservation per hit byte --
                         // 32 unrolled copies, ~19 KB of code -- this path cost ~110 VALU instructions per step with a candidate, on
                         // top of the ~120 of the step itself: a quarter of the wave-steps at 1.25M rows x 1024 queries take it.)
-                        uint32_t ts[NQ * 4];
+                        uint32_t ts[NF];
 #pragma unroll
-                        for (int i = 0; i < NQ * 4; ++i) ts[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)thp[i / 4][i % 4]);
+                        for (int i = 0; i < NF; ++i) ts[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)thw[i]);
                         uint32_t e_lo = 0, e_hi = 0;  // lane j: staged entry j
                         int n = 0;
                         for (;;) {
@@ -1049,16 +1248,24 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                             const int L = __builtin_ctzll(rem);
                             rem &= rem - 1ull;
                             const uint32_t rid = row0 + (uint32_t)L;
-                            static_for<0, NQ * 4>([&](auto I) {
+                            static_for<0, NF>([&](auto I) {
                                 constexpr int i = decltype(I)::value;
-                                const uint32_t ss = (uint32_t)__builtin_amdgcn_readlane((int)acc[i / 4][i % 4], L);
-                                uint32_t bits = (ts[i] - (ss & 0x7f7f7f7fu)) & ~ss & 0x80808080u;
+                                const uint32_t ss = (uint32_t)__builtin_amdgcn_readlane((int)sums[i], L);
+                                uint32_t bits = hits(ts[i], ss);
                                 while (bits) {
-                                    const uint32_t by = (uint32_t)__builtin_ctz(bits) >> 3;
+                                    uint32_t sv, slot;  // (the consumer re-checks the sum)
+                                    if constexpr (WIDE) {
+                                        const uint32_t hf = (uint32_t)__builtin_ctz(bits) >> 4;  // half-word of dword i
+                                        sv = (ss >> (16u * hf)) & 0xffffu;
+                                        slot = (uint32_t)((i & 2) << 1) | (hf << 1) | (uint32_t)(i & 1);
+                                    } else {
+                                        const uint32_t by = (uint32_t)__builtin_ctz(bits) >> 3;
+                                        sv = (ss >> (8u * by)) & 0xffu;
+                                        slot = (uint32_t)(4 * i) + by;
+                                    }
                                     bits &= bits - 1u;
-                                    const uint32_t sv = (ss >> (8u * by)) & 0xffu;  // (the consumer re-checks it)
                                     if (lane == n) {  // (scalar values into lane n: one compare, two conditional moves)
-                                        e_hi = (sv << 8) | ((uint32_t)(4 * i) + by);
+                                        e_hi = (sv << 8) | slot;
                                         e_lo = rid;
                                     }
                                     ++n;
@@ -1069,7 +1276,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     // pick up the workgroup's bounds every 2nd step
                     if (it_no & 1) {
                         asm volatile("" ::: "memory");
-                        load_thp(thp);
+                        load_thw(thw);
                     }
                     b_cur = b_nxt;
                     b_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend);
@@ -1081,7 +1288,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 if (a.dbg) t_wait += __builtin_readcyclecounter() - tw;
                 if (final) stamp(3);
                 if (final) break;
-                load_thp(thp);
+                load_thw(thw);
             }
             if (a.dbg && lane == 0 && !(a.dbg_skip & 8)) {  // [0] wave-steps with a candidate, [1] entries pushed, [7] wave 0's cycles at epoch ends
                 atomicAdd(a.dbg + 0, (unsigned long long)n_slow);
@@ -1148,8 +1355,8 @@ using namespace annlite;
 
 template <int M, int NW, bool SKEWED>
 static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
-    constexpr int QT = 32;
-    const size_t need = (size_t)a.Ks * 2 * M * 16 + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32 + 32 + 16;
+    constexpr int QT = 32;  // (the control block is laid out for 32 slots whatever the kernel uses)
+    const size_t need = (size_t)(M == 64 ? (a.Ks + 1) * 512 : a.Ks * 2 * M * 16) + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32 + 32 + 16;
     auto fn = adc_scan_q8_kernel<M, NW, SKEWED>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
@@ -1159,6 +1366,7 @@ static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
 int annlite::launch_q8_scan(int id, bool sk, const ScanArgs &a, int grid, hipStream_t st) {
     switch (id) {
         case 1650: return sk ? launch_q8<16, 16, true>(a, grid, st) : launch_q8<16, 16, false>(a, grid, st);
+        case 6450: return sk ? launch_q8<64, 16, true>(a, grid, st) : launch_q8<64, 16, false>(a, grid, st);
         default: set_error("no byte-table kernel with id %d", id); return ANNLITE_ERR_UNSUPPORTED;
     }
 }

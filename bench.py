@@ -459,11 +459,12 @@ def main():
         # 64 x 4.  256 CUs at 2.4 GHz (MI355X_MICROARCH.md: 256 B / clk / CU).
         plan_k = _capi.scan_plan(n_local, M, Ks, index.code_bytes, B, k)
         # (which M = 16 kernel served the table is the library's choice, from what its launches measured: index.scan_kernel)
-        byte_tables = plan_k.qt == 32 and index.scan_kernel != 'u16 tables' and os.environ.get('ANNLITE_SCAN_VARIANT', '0') in ('0', '50')
+        byte_tables = (plan_k.qt == 32 or (M == 64 and plan_k.qt == 8)) and index.scan_kernel != 'u16 tables' and \
+            os.environ.get('ANNLITE_SCAN_VARIANT', '0') in ('0', '50')
         per_clk = 256 if byte_tables else 128
         lds_peak = 256 * per_clk * 2.4e9
-        kernel_name = ('adc_scan_generic_kernel' if not plan_k.fast else 'adc_scan_qfilter64_kernel' if M == 64 else
-                       'adc_scan_q8_kernel' if byte_tables else 'adc_scan_qfilter_kernel')
+        kernel_name = ('adc_scan_generic_kernel' if not plan_k.fast else 'adc_scan_q8_kernel' if byte_tables else
+                       'adc_scan_qfilter64_kernel' if M == 64 else 'adc_scan_qfilter_kernel')
         traffic = traffic_table.get(f'{kernel_name}:{n_local}x{M}x{B}', {}).get('hbm_bytes_per_launch')
         roof = {
             'bound': 'lds', 'achieved': lookups_per_s, 'peak': lds_peak, 'unit': 'look-ups/s', 'frac': lookups_per_s / lds_peak,

@@ -692,6 +692,39 @@ def test_scan_kernel_variants_agree(ops, oracle, variant, monkeypatch):
         assert np.array_equal(d, rd) and np.array_equal(i, ri)
 
 
+@pytest.mark.parametrize('variant', ['0', '31'])
+def test_m64_scan_kernels_agree(ops, oracle, variant, monkeypatch):
+    """M = 64 (BASELINE config 4): the byte-table kernel (the default for k <= 16: 8 queries per 8-byte entry, byte sums widened
+    into u16 sums) and the u16-table kernel, on random tables / codes and on structured data, both layouts, ragged batch --
+    bit for bit the oracle's."""
+    from annlite_amd import Metric, PQCodec, _capi
+
+    monkeypatch.setenv('ANNLITE_SCAN_VARIANT', variant)
+    rs = np.random.RandomState(13)
+    M, Ks, N, B, k = 64, 256, 60000, 21, 10
+    assert _capi.scan_plan(N, M, Ks, 1, B, k).qt == (8 if variant == '0' else 4)
+    lut = rs.rand(B, M, Ks).astype(np.float32)
+    codes = rs.randint(0, Ks, size=(N, M)).astype(np.uint8)
+    codes[1000:1040] = codes[17]  # ties
+    rd, ri = oracle.adc_search_c(lut, codes, k)
+    for layout in (1, 0):
+        d, i, _ = _scan(ops, codes, lut, k, layout)
+        assert np.array_equal(d, rd) and np.array_equal(i, ri), layout
+    D = 768
+    A = rs.randn(64, D).astype(np.float32)
+    x = (rs.randn(120_000, 64).astype(np.float32) @ A + 0.05 * rs.randn(120_000, D).astype(np.float32)).astype(np.float32)
+    q = (rs.randn(40, 64).astype(np.float32) @ A + 0.05 * rs.randn(40, D).astype(np.float32)).astype(np.float32)
+    codec = PQCodec(dim=D, n_subvectors=M, n_clusters=256, metric=Metric.EUCLIDEAN, n_init=1)
+    codec.seed = 4
+    codec.fit(x[:8192], iter=4)
+    codes = oracle.encode_c(x, codec.codebooks)
+    lut = oracle.get_dist_mat_c(q, codec.codebooks, oracle.EUCLIDEAN)
+    rd, ri = oracle.adc_search_c(lut, codes, k)
+    for layout in (1, 0):
+        d, i, _ = _scan(ops, codes, lut, k, layout)
+        assert np.array_equal(d, rd) and np.array_equal(i, ri), layout
+
+
 def _event_ms(fn, reps=5):
     import torch
 
