@@ -40,6 +40,9 @@
 
 namespace annlite {
 
+#ifndef ANNLITE_Q8_WDEPTH
+#define ANNLITE_Q8_WDEPTH 16  // M = 64: landing registers (8-byte entries) of the look-up ring
+#endif
 #ifndef ANNLITE_Q8_DEPTH
 #define ANNLITE_Q8_DEPTH 8  // look-ups in flight per lane
 #endif
@@ -1021,6 +1024,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 if (lds0 != 0u || a.Ks != 256) __builtin_trap();
             }
             const uint32_t *codes32 = (const uint32_t *)a.codes;
+            // WIDE: the table's base sits in a VGPR pair (made opaque to the compiler: as an SGPR pair it was spilled and
+            // re-read from the kernarg segment in every step -- an s_load whose s_waitcnt lgkmcnt(0) also waited for the
+            // block-counter atomic issued just before it)
+            unsigned long long codes_v = (unsigned long long)(uintptr_t)a.codes, valid_v = (unsigned long long)(uintptr_t)a.valid;
+            if constexpr (WIDE) asm volatile("" : "+v"(codes_v), "+v"(valid_v));
             // rows are < 2^32 per call (plan): 32-bit row arithmetic keeps the loop control in SGPRs
             const uint32_t s_begin = (uint32_t)slice_begin, s_end = (uint32_t)slice_end, n_rows = (uint32_t)a.N;
             const uint32_t n_blocks = (s_end - s_begin + 63u) >> 6;
@@ -1042,15 +1050,22 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     return;
                 }
                 if (row >= n_rows) row = n_rows - 1;
-                const uint32_t *p = codes32 + (int64_t)row * CW;
+                typedef const uint32_t __attribute__((address_space(1))) *gptr_t;  // (global, not flat: a flat load also counts in lgkmcnt)
+                const gptr_t p = (WIDE ? (gptr_t)codes_v : (gptr_t)(uintptr_t)codes32) + (int64_t)row * CW;
                 if constexpr (CW == 2) {
-                    const u32x2 v = *(const u32x2 *)p;
+                    const u32x2 v = *(const u32x2 __attribute__((address_space(1))) *)p;
                     c[0] = v.x;
                     c[1] = v.y;
                 } else {
 #pragma unroll
                     for (int i = 0; i < CW / 4; ++i) {
-                        const u32x4 v = *(const u32x4 *)(p + 4 * i);
+                        if constexpr (ANNLITE_Q8_EXP == 4) {  // (timing experiment: the 16-byte pieces of 64 rows interleaved -- coalesced, wrong rows)
+                            const gptr_t pb = (gptr_t)codes_v + (int64_t)(row & ~63u) * CW + (row & 63u) * 4 + i * 256;
+                            const u32x4 v = *(const u32x4 __attribute__((address_space(1))) *)pb;
+                            c[4 * i + 0] = v.x, c[4 * i + 1] = v.y, c[4 * i + 2] = v.z, c[4 * i + 3] = v.w;
+                            continue;
+                        }
+                        const u32x4 v = *(const u32x4 __attribute__((address_space(1))) *)(p + 4 * i);
                         c[4 * i + 0] = v.x;
                         c[4 * i + 1] = v.y;
                         c[4 * i + 2] = v.z;
@@ -1095,24 +1110,38 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     // SKEWED layout), their byte sums (<= 16 * 15 = 240) widened into the row's u16 sums: dword 0 = queries
                     // (0, 2), 1 = (1, 3), 2 = (4, 6), 3 = (5, 7)
                     sums[0] = sums[1] = sums[2] = sums[3] = 0u;
-                    static_for<0, 4>([&](auto C) {
-                        constexpr int c0 = decltype(C)::value * 16;
-                        constexpr int half = c0 / 32;
-                        u32x2 v[16];
-                        static_for<0, 16>([&](auto T) {
-                            constexpr int t = c0 + decltype(T)::value;
-                            // byte 0 <- lane_k byte 0, byte 1 <- code byte t % 4, byte 2 <- lane_k byte 2 (second half) or 0, byte 3 <- 0
-                            constexpr uint32_t sel = 0x0c000000u | ((half ? 0x02u : 0x0cu) << 16) | ((4u + (uint32_t)(t % 4)) << 8);
-                            const uint32_t ad = __builtin_amdgcn_perm(cc[t / 4], lane_k, sel);
-                            v[t - c0] = *(lds_entry8_ptr)(uintptr_t)(ad + (uint32_t)((t % 32) * 8 + half * 0x100));
-                        });
+                    // The 64 look-ups run through ONE ring of WDEPTH landing registers, pairs at a time (a pair = one
+                    // v_add3 per dword): look-ups i + WDEPTH, i + WDEPTH + 1 are issued as soon as pair i has been added, so
+                    // the wave's LDS queue never drains at a chunk boundary (four separate chunks of 16, each waited out
+                    // before the next was issued, ran at 0.47 of the look-up roof; the step is VALU/LDS co-bound at 0.89)
+                    constexpr int WDEPTH = ANNLITE_Q8_WDEPTH;
+                    static_assert(WDEPTH % 2 == 0 && WDEPTH >= 2 && WDEPTH <= 64, "pairs");
+                    u32x2 v[WDEPTH];
+                    auto fetch = [&](u32x2 &dst, auto T) {
+                        constexpr int t = decltype(T)::value;
+                        constexpr int half = t / 32;
+                        // byte 0 <- lane_k byte 0, byte 1 <- code byte t % 4, byte 2 <- lane_k byte 2 (second half) or 0, byte 3 <- 0
+                        constexpr uint32_t sel = 0x0c000000u | ((half ? 0x02u : 0x0cu) << 16) | ((4u + (uint32_t)(t % 4)) << 8);
+                        const uint32_t ad = __builtin_amdgcn_perm(cc[t / 4], lane_k, sel);
+                        dst = *(lds_entry8_ptr)(uintptr_t)(ad + (uint32_t)((t % 32) * 8 + half * 0x100));
+                    };
+                    static_for<0, WDEPTH>([&](auto I) { fetch(v[decltype(I)::value], I); });
+                    u32x2 bs = {0u, 0u};
+                    static_for<0, 32>([&](auto P) {
+                        constexpr int i = 2 * decltype(P)::value;
                         asm volatile("" ::: "memory");
-                        u32x2 bs = v[0];
-                        static_for<1, 16>([&](auto I) { bs += v[decltype(I)::value]; });
-                        sums[0] += bs.x & 0x00ff00ffu;
-                        sums[1] += __builtin_amdgcn_perm(0u, bs.x, 0x0c030c01u);  // (bytes 1, 3 -> half-words)
-                        sums[2] += bs.y & 0x00ff00ffu;
-                        sums[3] += __builtin_amdgcn_perm(0u, bs.y, 0x0c030c01u);
+                        if constexpr (i % 16 == 0) bs = v[i % WDEPTH] + v[(i + 1) % WDEPTH];
+                        else bs += v[i % WDEPTH] + v[(i + 1) % WDEPTH];
+                        if constexpr (i + WDEPTH < 64) {
+                            fetch(v[i % WDEPTH], std::integral_constant<int, i + WDEPTH>{});
+                            fetch(v[(i + 1) % WDEPTH], std::integral_constant<int, i + WDEPTH + 1>{});
+                        }
+                        if constexpr (i % 16 == 14) {
+                            sums[0] += bs.x & 0x00ff00ffu;
+                            sums[1] += __builtin_amdgcn_perm(0u, bs.x, 0x0c030c01u);  // (bytes 1, 3 -> half-words)
+                            sums[2] += bs.y & 0x00ff00ffu;
+                            sums[3] += __builtin_amdgcn_perm(0u, bs.y, 0x0c030c01u);
+                        }
                     });
                 } else {
                     constexpr int DEPTH = ANNLITE_Q8_DEPTH, TOT = NQ * M;
@@ -1156,7 +1185,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             auto load_valid = [&](uint32_t row) -> uint32_t {
                 if (!valid) return ~0u;
                 if (row >= n_rows) row = n_rows - 1;
-                return valid[row >> 5];
+                if constexpr (WIDE) return ((const uint32_t __attribute__((address_space(1))) *)valid_v)[row >> 5];
+                else return valid[row >> 5];
             };
             // The code bytes (and validity word) of a lane's row are fetched ONE STEP AHEAD: issued at the top of a step for
             // the next block, picked up at the top of that one; the number of the block after that is drawn in between.
