@@ -305,25 +305,39 @@ class PQFlatGpuIndex(BaseIndex):
         return self._codes[:N]
 
     def _search_large_k(self, q, k, valid, N, scan_in=None):
-        """k > 64: all distances per query (adc_dist kernel) + a stable device sort (ties -> id asc)."""
+        """k > 64 (beyond the scan kernels' lists): the distances of a CHUNK of queries to every row (adc_dist launches into one
+        [chunk, N] buffer) -> i64 keys (order-preserving bits of the f32 sum << 32 | row: unique, so the k smallest keys ARE
+        the (distance, id)-ordered top-k) -> one batched ``torch.topk`` per chunk.  No per-query sort, no host round trip."""
         from ..._capi import LAYOUT_BMK, LAYOUT_TILED  # noqa: F401
 
         kind, xq = scan_in if scan_in is not None else self.pq_codec.scan_inputs(q)
         lut = ops.lut_build(xq, self.pq_codec.codebooks_dev, kind, LAYOUT_BMK)
         codes = self._plain_codes(N)
-        shifts = torch.arange(32, device=q.device, dtype=torch.int64)
+        dev = q.device
+        shifts = torch.arange(32, device=dev, dtype=torch.int64)
         vb = (((valid.to(torch.int64) & 0xFFFFFFFF)[:, None] >> shifts[None, :]) & 1).bool().reshape(-1)[:N]  # unpack
         kk = min(k, N)
+        B = q.shape[0]
+        chunk = max(1, min(B, (1 << 26) // max(N, 1)))  # <= 64M keys (512 MB) + their f32 sums per chunk
+        rows = torch.arange(N, device=dev, dtype=torch.int64)
+        inf = torch.tensor(float('inf'), device=dev)
         ds, is_ = [], []
-        for b in range(q.shape[0]):
-            dist = ops.adc_dist(lut[b], codes)
-            dist = torch.where(vb, dist, torch.full_like(dist, float('inf')))
-            sd, si = torch.sort(dist, stable=True)
-            sd, si = sd[:kk], si[:kk]
+        for b0 in range(0, B, chunk):
+            nb = min(chunk, B - b0)
+            dist = torch.empty((nb, N), dtype=torch.float32, device=dev)
+            for j in range(nb):
+                ops.adc_dist(lut[b0 + j], codes, out=dist[j])
+            dist = torch.where(vb[None, :], dist + 0.0, inf)  # (-0.0 -> +0.0: equal VALUES tie-break by id)
+            bits = dist.view(torch.int32)
+            bits = bits ^ ((bits >> 31) & 0x7FFFFFFF)  # signed-comparable image of the float order
+            keys = (bits.to(torch.int64) << 32) | rows[None, :]
+            top = torch.topk(keys, kk, dim=1, largest=False, sorted=True).values
+            si = top & 0xFFFFFFFF
+            sd = torch.gather(dist, 1, si)
             si = torch.where(torch.isinf(sd) & ~vb[si], torch.full_like(si, -1), si)
             ds.append(sd)
             is_.append(si)
-        d, i = torch.stack(ds), torch.stack(is_)
+        d, i = torch.cat(ds), torch.cat(is_)
         if kk < k:
             d = torch.cat([d, torch.full((d.shape[0], k - kk), float('inf'), device=d.device)], dim=1)
             i = torch.cat([i, torch.full((i.shape[0], k - kk), -1, dtype=torch.int64, device=i.device)], dim=1)

@@ -80,13 +80,15 @@ def lut_retile(lut_bmk: torch.Tensor, qi: int) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------------------------- ADC
-def adc_dist(adtable: torch.Tensor, codes: torch.Tensor) -> torch.Tensor:
-    """pq_bind.dist_pqcodes_to_codebooks on device: f32 [M,Ks], codes [N,M] -> f32 [N]."""
+def adc_dist(adtable: torch.Tensor, codes: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pq_bind.dist_pqcodes_to_codebooks on device: f32 [M,Ks], codes [N,M] -> f32 [N] (into ``out`` when given)."""
     assert adtable.ndim == 2 and codes.ndim == 2 and adtable.dtype == torch.float32
     M, Ks = adtable.shape
     N = codes.shape[0]
     assert codes.shape[1] == M
-    out = torch.empty((N,), dtype=torch.float32, device=codes.device)
+    if out is None:
+        out = torch.empty((N,), dtype=torch.float32, device=codes.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == N and out.device == codes.device
     check(lib().annlite_adc_dist(adtable.data_ptr(), M, Ks, codes.data_ptr(), code_bytes_of(codes), N,
                                  out.data_ptr(), stream_ptr()), 'adc_dist')
     return out

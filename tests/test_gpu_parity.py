@@ -484,6 +484,37 @@ def test_index_dump_load_large_k_and_rerank(ops, oracle, tmp_path):
     np.testing.assert_allclose(dr, np.take_along_axis(exact, ir, axis=1), rtol=1e-4)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('metric_name', ['EUCLIDEAN', 'INNER_PRODUCT'])
+def test_large_k_batched_path_ties_and_deletes(ops, oracle, metric_name):
+    """limit > 64 (pq_flat_gpu._search_large_k: chunked distance matrix + one batched top-k over (sum, row) keys): heavy ties
+    (50 distinct code rows among 3000), deleted rows, negative sums (inner product) -- ids and distances = the oracle's."""
+    from annlite_amd import Metric, PQCodec, PQFlatGpuIndex
+
+    g = load_golden('c2_m16_d128')
+    metric = getattr(Metric, metric_name)
+    rs = np.random.RandomState(11)
+    N = 3000
+    base = g['x'][:50]
+    x = base[rs.randint(0, 50, N)]
+    codec = PQCodec(dim=g['D'], n_subvectors=g['M'], n_clusters=g['Ks'], metric=metric).set_codebooks(g['codebooks'])
+    idx = PQFlatGpuIndex(dim=g['D'], metric=metric, pq_codec=codec, initial_size=4096)
+    idx.add_with_ids(x, np.arange(N))
+    gone = rs.choice(N, 300, replace=False)
+    idx.delete(gone.tolist())
+    keep = np.setdiff1d(np.arange(N), gone)
+    codes = ops.codes_to_numpy(ops.pq_encode(ops.to_dev(x), codec.codebooks_dev))
+    q = g['queries'][:7]
+    for k in (65, 200, 2900):
+        d, i = idx.search_batch(q, limit=k)
+        rd, ri = oracle.index_search(q, g['codebooks'], codes[keep], int(metric), k)
+        ri = np.where(ri >= 0, keep[np.clip(ri, 0, len(keep) - 1)], -1)
+        assert np.array_equal(i, ri), (metric_name, k)
+        fin = np.isfinite(rd)
+        assert np.array_equal(np.isfinite(d), fin)
+        np.testing.assert_array_equal(d[fin], rd[fin])
+
+
 # ------------------------------------------------------------------------------------ AnnLite facade
 def test_annlite_facade_end_to_end(ops, tmp_path):
     """tests/test_pq_index.py:52-77 restated + result shape of AnnLite.search (container.py:226-233)."""
@@ -1079,6 +1110,47 @@ def test_hnsw_pq_candidates_with_gpu_rerank(ops, mname, metric, walk):
     truth = torch.cdist(qt, xt).topk(k + 1, largest=False).indices.cpu().numpy()
     rr = np.mean([len(set(ri[b]) & (set(truth[b]) - {int(i1[0])} if b == 0 else set(truth[b][:k]))) / k for b in range(B)])
     assert rr >= 0.9, rr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mname,metric', [('inner_product', 2), ('cosine', 3)])
+def test_hnsw_pq_ip_cosine_pinned_to_the_reference_fixture(ops, oracle, mname, metric):
+    """PQ_Space semantics for IP / cosine graphs (include/hnswlib/space_pq.h:15-37, hnsw/index.py:20-48): this build walks a
+    graph built with L2 tables for every metric -- a departure.  What is pinned against the REFERENCE's own
+    HnswIndex(PQ) run (tests/golden: hnsw_<metric>_i / _d): every distance reported is the metric's own PQLookup sum of that
+    row (= the reference's number for every id both return: bit for bit for IP, 1e-5 for cosine -- another numpy build
+    normalised the fixture's rows), the result is ranked by it, and against the exhaustive ADC top-k under the metric's tables
+    it is at least as complete as the reference's graph was."""
+    from annlite_amd import HnswPQGpuIndex, Metric, PQCodec
+
+    g = load_golden('c2_m16_d128')
+    cb = g['codebooks_cos'] if metric == 3 else g['codebooks']
+    K, N, B = int(g['K']), int(g['N']), int(g['B'])
+    codec = PQCodec(dim=g['D'], n_subvectors=g['M'], n_clusters=g['Ks'], metric=Metric(metric)).set_codebooks(cb)
+    hn = HnswPQGpuIndex(dim=g['D'], metric=Metric(metric), pq_codec=codec, initial_size=N, ef_search=128, rerank=False)
+    hn.add_with_ids(g['x'], np.arange(N))
+    d, i = hn.search_batch(g['queries'], limit=K)
+    ref_i, ref_d = g['hnsw_%s_i' % mname], g['hnsw_%s_d' % mname]
+    codes = oracle.encode_c(oracle.l2_normalize(g['x']), cb) if metric == 3 else g['codes']
+    full_d, full_i = oracle.index_search(g['queries'], cb, codes, metric, N)  # every row's distance, (distance, id) order
+    tol = 1e-5 if metric == 3 else 0.0
+    n_common = 0
+    for b in range(B):
+        mine = {int(r): float(x) for r, x in zip(i[b], d[b]) if r >= 0}
+        assert len(mine) == K
+        row_d = dict(zip(full_i[b].tolist(), full_d[b].tolist()))
+        for r, x in mine.items():  # the metric's own PQLookup sum of that row
+            assert x == row_d[r], (b, r, x, row_d[r])
+        assert list(d[b]) == sorted(d[b])
+        for r, x in zip(ref_i[b], ref_d[b]):  # the reference's number for the ids both return
+            if int(r) in mine:
+                n_common += 1
+                assert abs(mine[int(r)] - float(x)) <= tol, (b, int(r), mine[int(r)], float(x))
+    assert n_common >= 0.8 * B * K, n_common
+    top = full_i[:, :K]
+    mine_rec = np.mean([len(set(i[b]) & set(top[b])) / K for b in range(B)])
+    ref_rec = np.mean([len(set(ref_i[b]) & set(top[b])) / K for b in range(B)])
+    assert mine_rec >= ref_rec - 1e-9 and mine_rec >= 0.9, (mine_rec, ref_rec)
 
 
 @pytest.mark.parametrize('N,min_overlap,min_recall', [(1_000_000, 0.9, 0.9), (5_000_000, 0.85, 0.88)])
