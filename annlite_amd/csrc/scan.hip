@@ -310,7 +310,10 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
         // uint16 codes (Ks > 256; the reference's PQ tests run Ks = 512 and 768 at M = 8): the u16-table kernel with 8 queries
         // per workgroup, as many codes as fit the LDS, PLAIN layout, row slices only
         if (tiles || getenv("ANNLITE_NO_FAST_CODE16")) return false;  // (the switch: A/B against the generic kernel)
-        if (M == 8 && Ks <= 512) { *c = {8, 4, 2, 16, 4, 1, 8217, 4}; return true; }   // 16 queries per workgroup
+        // M = 8, Ks <= 512, k <= 16: the byte-table kernel (scan_q8.hip, C16: table [Ks][2][8][16 B], 32 queries per workgroup,
+        // conflict-free); ANNLITE_SCAN_VARIANT=31: the u16-table kernel (A/B)
+        if (M == 8 && Ks <= 512 && k <= 16 && (scan_variant() == 0 || scan_variant() == 50)) { *c = {8, 4, 2, 16, 4, 1, 850, 5}; return true; }
+        if (M == 8 && Ks <= 512) { *c = {8, 4, 2, 16, 4, 1, 8217, 4}; return true; }   // u16 tables, 16 queries per workgroup
         if (M == 8 && Ks <= 1024) { *c = {8, 4, 1, 16, 4, 1, 8216, 4}; return true; }
         if (M == 16 && Ks <= 512) { *c = {16, 4, 1, 16, 4, 1, 16216, 4}; return true; }
         return false;
@@ -833,7 +836,9 @@ enum SearchMode { kModePlain, kModeGuarded, kModeByteStats, kModeU16 };
 
 static SearchMode search_policy(annlite_scan_state *s, int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t k,
                                 bool tiles) {
-    if (tiles || M != 16 || code_bytes != 1 || Ks > 256 || k > 16 || N <= 0 || B <= 0) return kModePlain;
+    // the shapes with both a byte-table and a u16-table kernel: M = 16 / u8 codes, M = 8 / u16 codes up to Ks = 512
+    const bool both = (M == 16 && code_bytes == 1 && Ks <= 256) || (M == 8 && code_bytes == 2 && Ks <= 512);
+    if (tiles || !both || k > 16 || N <= 0 || B <= 0) return kModePlain;
     if (g_variant_scope >= 0 || env_variant() >= 0) return kModePlain;        // (an explicit variant: A/B measurements)
     if (getenv("ANNLITE_NO_INKERNEL_MERGE")) return kModePlain;                // (debug switch: no guarded pass)
     if (!s) return kModeGuarded;

@@ -76,6 +76,8 @@ __device__ __forceinline__ uint32_t lds_base_addr() {
 template <int M>
 struct Q8Cfg {
     static constexpr bool WIDE = M == 64;
+    static constexpr bool C16 = M == 8;  // M = 8: uint16 codes (256 < Ks <= 512: table [Ks][2][8][16 B] = Ks * 256 bytes), PLAIN rows only
+    static constexpr int CW = C16 ? M / 2 : M / 4;  // dwords of a code row
     static constexpr int QT = WIDE ? 8 : 32;
     static constexpr int QMAX = WIDE ? 15 : 240 / M, QOPEN = WIDE ? 7 : 112 / M;
     static constexpr uint32_t TMAX = WIDE ? 32767u : 127u, TFLAG = TMAX + 1u;
@@ -360,7 +362,9 @@ template <int M, bool SKEWED>
 __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, const unsigned long long (&e)[2], bool (&act)[2],
                                            int lane, uint32_t &n_kept, uint32_t &n_offered, unsigned long long &pend_o,
                                            unsigned long long &pend_j) {
-    constexpr int CW = M / 4;
+    constexpr int CW = Q8Cfg<M>::CW;
+    constexpr bool C16 = Q8Cfg<M>::C16;
+    static_assert(!(C16 && SKEWED), "uint16 codes: PLAIN rows");
     int q[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -410,7 +414,7 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
         uint32_t cp[2][CW];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const uint32_t *p = (const uint32_t *)(c.codes + (int64_t)(act[u] ? (uint32_t)e[u] : 0u) * M);
+            const uint32_t *p = (const uint32_t *)(c.codes + (int64_t)(act[u] ? (uint32_t)e[u] : 0u) * (CW * 4));
 #pragma unroll
             for (int i = 0; i < CW; ++i) cp[u][i] = p[i];
         }
@@ -429,7 +433,7 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
             const float *lq = c.lut + ((int64_t)(b >> 2) * c.Ks) * (M * 4) + (b & 3);
 #pragma unroll
             for (int m = 0; m < M; ++m) {
-                const uint32_t code = (cp[u][m / 4] >> (8 * (m % 4))) & 0xffu;
+                const uint32_t code = C16 ? (cp[u][m / 2] >> (16 * (m % 2))) & 0xffffu : (cp[u][m / 4] >> (8 * (m % 4))) & 0xffu;
                 vals[u][m] = lq[((int64_t)code * M + m) * 4];
             }
         }
@@ -691,9 +695,10 @@ __device__ __attribute__((noinline)) void q8_finish_item(q8_kernarg_ptr ka, int 
 template <int M, int NW, bool SKEWED>
 __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const ScanArgs a) {
     constexpr bool WIDE = Q8Cfg<M>::WIDE;
-    constexpr int NQ = 2, QT = Q8Cfg<M>::QT, CW = M / 4, EB = 16, RB = M * EB, KSTRIDE = NQ * RB;
+    constexpr bool C16 = Q8Cfg<M>::C16;
+    constexpr int NQ = 2, QT = Q8Cfg<M>::QT, CW = Q8Cfg<M>::CW, EB = 16, RB = M * EB, KSTRIDE = NQ * RB;
     constexpr int NS = NW - 1;  // scanning waves; wave NS is the consumer
-    static_assert(M % 8 == 0 && (M <= 32 || WIDE) && (KSTRIDE & (KSTRIDE - 1)) == 0, "unsupported shape");
+    static_assert(M % 8 == 0 && (M <= 32 || WIDE) && (KSTRIDE & (KSTRIDE - 1)) == 0 && !(C16 && SKEWED), "unsupported shape");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1004,18 +1009,38 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             // ------------------------------------------------------------------------------- scanning waves
             constexpr int NF = WIDE ? 4 : 8;  // filter words per row: 8 dwords of byte sums (32 queries) / 4 dwords of u16 sums (8)
             const int s = lane % (WIDE ? 32 : M);
-            const uint32_t bsh = (uint32_t)(s & 3);
+            const int rot_bytes = C16 ? 2 * s : s;  // PLAIN rows are rotated in registers: element (s + t) mod M to position t
+            const uint32_t bsh = (uint32_t)(rot_bytes & 3);
             bool abit[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) abit[i] = (((s >> 2) >> i) & 1) != 0;
+            for (int i = 0; i < 8; ++i) abit[i] = (((rot_bytes >> 2) >> i) & 1) != 0;
+            const unsigned long long rmask0 = __ballot(abit[0]), rmask1 = __ballot(abit[1]);  // (C16: see the step loop)
             // LDS byte addresses as integers
             typedef const ANNLITE_LDS u32x4 *lds_entry_ptr;
             typedef const ANNLITE_LDS u32x2 *lds_entry8_ptr;
             const uint32_t lds0 = lds.tab;
-            uint32_t mbase[WIDE ? 1 : M];
-            if constexpr (!WIDE) {
+            uint32_t mbase[(WIDE || C16) ? 1 : M];
+            if constexpr (!WIDE && !C16) {
 #pragma unroll
                 for (int t = 0; t < M; ++t) mbase[t] = lds0 + (uint32_t)(((s + t) % M) * EB);
+            }
+            // C16 (M = 8, uint16 codes): a code row of the table is 256 bytes = [2 entry groups][8 sub-spaces][16 B], the address of
+            // look-up t is (code << 8) | column byte -- ONE v_perm_b32 of the code dword with a lane constant (kx / ky: byte t of
+            // the pair = the column of look-up t in the lane's FIRST / SECOND entry group).  Eight sub-spaces cover only half of
+            // the 16 bank slots a ds_read_b128 lane group spans, and every hardware lane group holds each s = lane % 8 twice (lanes
+            // l and l ^ 24 resp. l ^ 8 ... : they differ in lane bit 4): the lanes with bit 4 set read the entry groups in the
+            // OTHER order -- 16 distinct slots per lane group, conflict-free.  Their sums[0..3] then belong to queries 16..31:
+            // they load the filter words swapped (load_thw) and the candidate path un-swaps the slot.
+            const uint32_t f16 = C16 ? ((uint32_t)lane >> 4) & 1u : 0u;
+            uint32_t kx[2] = {0u, 0u}, ky[2] = {0u, 0u};
+            if constexpr (C16) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const uint32_t col = (uint32_t)(((s + t) % 8) * 16) + f16 * 128u;
+                    kx[t / 4] |= col << (8 * (t % 4));
+                    ky[t / 4] |= (col ^ 128u) << (8 * (t % 4));
+                }
+                if (lds0 != 0u || a.Ks > 512) __builtin_trap();
             }
             // WIDE: lane constant of the look-up addresses (the M = 64 u16 kernel's scheme): byte 0 = (lane % 32) * 8 (the column),
             // byte 2 = 0x01 (second half table); the table starts at LDS address 0 (all LDS is dynamic)
@@ -1042,7 +1067,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 return v;
             };
             uint32_t ccur[CW], cnext[CW];
-            uint32_t addr[WIDE ? 1 : M];
+            uint32_t addr[(WIDE || C16) ? 1 : M];
             auto load_row = [&](uint32_t row, uint32_t (&c)[CW]) {
                 if constexpr (ANNLITE_Q8_EXP == 3) {  // (timing experiment: no code rows from memory)
 #pragma unroll
@@ -1074,7 +1099,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 }
             };
             auto make_addr = [&](const uint32_t (&cc)[CW]) {
-                if constexpr (!WIDE)
+                if constexpr (!WIDE && !C16)
                     static_for<0, CW>([&](auto W) {
                         constexpr int w = decltype(W)::value;
                         uint32_t o0, o1, o2, o3;
@@ -1093,7 +1118,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 } else {
 #pragma unroll
                     for (int h = 0; h < NQ; ++h) {
-                        const u32x4 v = *(volatile ANNLITE_LDS u32x4 *)(uintptr_t)(lds.shq + 16u * (uint32_t)h);
+                        const u32x4 v = *(volatile ANNLITE_LDS u32x4 *)(uintptr_t)(lds.shq + 16u * ((uint32_t)h ^ f16));
                         t[4 * h + 0] = v.x, t[4 * h + 1] = v.y, t[4 * h + 2] = v.z, t[4 * h + 3] = v.w;
                     }
                 }
@@ -1143,6 +1168,28 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                             sums[3] += __builtin_amdgcn_perm(0u, bs.y, 0x0c030c01u);
                         }
                     });
+                } else if constexpr (C16) {
+                    // 8 look-ups in the lane's first entry group, then 8 in its second, through a ring of DEPTH landing registers
+                    constexpr int DEPTH = ANNLITE_Q8_DEPTH, TOT = NQ * M;
+                    u32x4 acc[NQ];
+                    u32x4 v[DEPTH];
+                    auto fetch = [&](u32x4 &dst, auto I) {
+                        constexpr int i = decltype(I)::value, t = i % M, g = i / M;
+                        // byte 0 <- column byte t % 4 of the lane constant, bytes 1..2 <- the 16-bit code, byte 3 <- 0
+                        constexpr uint32_t sel = 0x0c000000u | ((uint32_t)(4 + 2 * (t % 2) + 1) << 16) | ((uint32_t)(4 + 2 * (t % 2)) << 8) | (uint32_t)(t % 4);
+                        const uint32_t ad = __builtin_amdgcn_perm(cc[t / 2], g ? ky[t / 4] : kx[t / 4], sel);
+                        dst = *(lds_entry_ptr)(uintptr_t)ad;
+                    };
+                    static_for<0, DEPTH>([&](auto I) { fetch(v[decltype(I)::value], I); });
+                    static_for<0, TOT>([&](auto I) {
+                        constexpr int i = decltype(I)::value;
+                        asm volatile("" ::: "memory");
+                        if constexpr (i % M == 0) acc[i / M] = v[i % DEPTH];
+                        else acc[i / M] += v[i % DEPTH];
+                        if constexpr (i + DEPTH < TOT) fetch(v[i % DEPTH], std::integral_constant<int, i + DEPTH>{});
+                    });
+#pragma unroll
+                    for (int h = 0; h < NQ; ++h) sums[4 * h + 0] = acc[h].x, sums[4 * h + 1] = acc[h].y, sums[4 * h + 2] = acc[h].z, sums[4 * h + 3] = acc[h].w;
                 } else {
                     constexpr int DEPTH = ANNLITE_Q8_DEPTH, TOT = NQ * M;
                     u32x4 acc[NQ];
@@ -1210,8 +1257,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 for (; b_cur < end_blk; ++it_no) {
                     const uint32_t row0 = s_begin + b_cur * 64u;  // (< s_end: b_cur < n_blocks)
                     pend = draw();
+                    uint32_t rot1[C16 ? CW : 1];  // (C16: first rotation stage straight from the landing registers -- no copy)
+                    if constexpr (C16) {
 #pragma unroll
-                    for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
+                        for (int i = 0; i < CW; ++i)
+                            asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(rot1[i]) : "v"(cnext[i]), "v"(cnext[(i + 1) % CW]), "s"(rmask0));
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < CW; ++i) ccur[i] = cnext[i];
+                    }
                     vcur = vnext;
                     {
                         const uint32_t row1 = s_begin + b_nxt * 64u + lane;  // (past the slice at its end: clamped, unused)
@@ -1220,7 +1274,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     }
                     if constexpr (!SKEWED) {
                         if constexpr (WIDE) skew64_encode(ccur, lane & 31);  // PLAIN row -> this lane's wrap-coded SKEWED row
-                        else rotate_row<CW>(ccur, abit, bsh);
+                        else if constexpr (C16) {
+                            // rotate_row with the two stage conditions as LANE MASKS in SGPR pairs (as `bool`s the allocator kept
+                            // them as 0/1 VGPRs and re-compared before every select: 14 v_cmp + 15 s_nop per step)
+                            uint32_t n[CW];
+#pragma unroll
+                            for (int i = 0; i < CW; ++i)
+                                asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(n[i]) : "v"(rot1[i]), "v"(rot1[(i + 2) % CW]), "s"(rmask1));
+#pragma unroll
+                            for (int i = 0; i < CW; ++i) ccur[i] = __builtin_amdgcn_alignbyte(n[(i + 1) % CW], n[i], bsh);
+                        } else rotate_row<CW>(ccur, abit, bsh);
                     }
                     unsigned long long vmask = ~0ull;
                     if (s_end - row0 < 64u) vmask = (1ull << (s_end - row0)) - 1ull;
@@ -1250,7 +1313,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                         // pushed with ONE ring reservation.  (Per dword and byte with ballots and one reservation per hit byte --
                         // 32 unrolled copies, ~19 KB of code -- this path cost ~110 VALU instructions per step with a candidate, on
                         // top of the ~120 of the step itself: a quarter of the wave-steps at 1.25M rows x 1024 queries take it.)
-                        uint32_t ts[NF];
+                        uint32_t ts[NF];  // (C16: the filter words differ between the two lane halves -- read from the hit lane below)
 #pragma unroll
                         for (int i = 0; i < NF; ++i) ts[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)thw[i]);
                         uint32_t e_lo = 0, e_hi = 0;  // lane j: staged entry j
@@ -1278,9 +1341,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                             const int L = __builtin_ctzll(rem);
                             rem &= rem - 1ull;
                             const uint32_t rid = row0 + (uint32_t)L;
+                            const uint32_t fL = C16 ? ((uint32_t)L >> 4) & 1u : 0u;  // that lane's sums[0..3] are of entry group fL
                             static_for<0, NF>([&](auto I) {
                                 constexpr int i = decltype(I)::value;
                                 const uint32_t ss = (uint32_t)__builtin_amdgcn_readlane((int)sums[i], L);
+                                if constexpr (C16) ts[i] = (uint32_t)__builtin_amdgcn_readlane((int)thw[i], L);
                                 uint32_t bits = hits(ts[i], ss);
                                 while (bits) {
                                     uint32_t sv, slot;  // (the consumer re-checks the sum)
@@ -1292,6 +1357,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                                         const uint32_t by = (uint32_t)__builtin_ctz(bits) >> 3;
                                         sv = (ss >> (8u * by)) & 0xffu;
                                         slot = (uint32_t)(4 * i) + by;
+                                        if constexpr (C16) slot ^= fL << 4;
                                     }
                                     bits &= bits - 1u;
                                     if (lane == n) {  // (scalar values into lane n: one compare, two conditional moves)
@@ -1397,6 +1463,9 @@ int annlite::launch_q8_scan(int id, bool sk, const ScanArgs &a, int grid, hipStr
     switch (id) {
         case 1650: return sk ? launch_q8<16, 16, true>(a, grid, st) : launch_q8<16, 16, false>(a, grid, st);
         case 6450: return sk ? launch_q8<64, 16, true>(a, grid, st) : launch_q8<64, 16, false>(a, grid, st);
+        case 850:  // M = 8, uint16 codes (PLAIN rows)
+            if (sk) { set_error("uint16 codes: PLAIN rows only"); return ANNLITE_ERR_UNSUPPORTED; }
+            return launch_q8<8, 16, false>(a, grid, st);
         default: set_error("no byte-table kernel with id %d", id); return ANNLITE_ERR_UNSUPPORTED;
     }
 }
