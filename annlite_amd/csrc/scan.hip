@@ -830,9 +830,16 @@ struct annlite_scan_state {
     int kernel;           // 0 undecided, 1 byte tables, 2 u16 tables
     int64_t rows;         // table size the decision was taken at (it is taken again when the table has doubled)
     uint64_t candidates;  // of the launch the decision rests on
+    // grey zone (the byte-table launch completed, but with many candidates: e.g. uniform vectors -- 10^4 per query at 10M rows,
+    // where it is still 2x the u16-table kernel, while independent random codes -- 8 * 10^4 -- are 10x slower): both kernels are
+    // TIMED, one call each, with events in the caller's stream that are read without waiting
+    hipEvent_t ev[2][2];  // [0 byte tables, 1 u16 tables][start, stop]
+    int probe;            // 0 none, 1 the byte-table call is being timed, 2 waiting for it / the u16 call comes next, 3 waiting for the u16 call
+    double work[2];       // tiles x rows of the timed calls (the two may see different batches)
+    float ms[2];
 };
 
-enum SearchMode { kModePlain, kModeGuarded, kModeByteStats, kModeU16 };
+enum SearchMode { kModePlain, kModeGuarded, kModeByteStats, kModeU16, kModeU16Probe };
 
 static SearchMode search_policy(annlite_scan_state *s, int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t k,
                                 bool tiles) {
@@ -848,17 +855,43 @@ static SearchMode search_policy(annlite_scan_state *s, int64_t N, int64_t M, int
         const bool gave_up = s->host[1] != 0;
         const uint64_t cand = (uint64_t)s->host[2] | ((uint64_t)s->host[3] << 32);
         const uint64_t b = s->host[4] ? s->host[4] : 1;
-        // what a guarded launch's workgroups compare their own counts with (guard_base + rows drawn / 32 each), summed over
+        // what a guarded launch's workgroups compare their own counts with (guard_base + rows drawn / 16 each), summed over
         // the launch: every query tile scans all N rows.  With structure: ~300 candidates per query at 10M rows -- 30x below it
         const uint64_t n_rows = s->host[5];
-        const bool leaks = gave_up || cand > 1024ull * 256ull + n_rows * ((b + 31) / 32) / 32;
-        if (s->kernel == 0 || (s->kernel == 1 && leaks)) {
-            s->kernel = leaks ? 2 : 1;
+        const uint64_t budget = 1024ull * 256ull + n_rows * ((b + 31) / 32) / 16;
+        if (s->kernel == 0 && s->probe == 0) {
+            s->rows = (int64_t)s->host[5];
+            s->candidates = cand;
+            if (gave_up) s->kernel = 2;                // the cliff: no need to time anything
+            else if (cand <= budget / 16 + 1024ull * b) s->kernel = 1;  // clean: the transient from the seed bound to the converged one (a few
+                                                                        // hundred candidates per query whatever N) + structured data's ~1 per 1000 rows and tile
+            else s->probe = 1;                          // grey zone: time this kernel now, the other one next
+        } else if (s->kernel == 1 && gave_up) {
+            s->kernel = 2;
             s->rows = (int64_t)s->host[5];
             s->candidates = cand;
         }
     }
-    if (s->kernel != 0 && (N >= 2 * s->rows || N * 2 < s->rows)) s->kernel = 0;  // the table has changed size: measure again
+    if (s->kernel != 0 && (N >= 2 * s->rows || N * 2 < s->rows)) s->kernel = 0, s->probe = 0;  // the table has changed size: measure again
+    if (s->kernel == 0 && s->probe >= 2) {
+        // timed calls: pick up what has completed (never wait)
+        const int which = s->probe == 2 ? 0 : 1;
+        if (hipEventQuery(s->ev[which][1]) == hipSuccess) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, s->ev[which][0], s->ev[which][1]) == hipSuccess && ms > 0.f) {
+                s->ms[which] = ms;
+                if (which == 0) return kModeU16Probe;  // (probe -> 3 when that call has been issued)
+                const double r0 = (double)s->ms[0] / s->work[0], r1 = (double)s->ms[1] / s->work[1];
+                s->kernel = r1 < r0 ? 2 : 1;
+                s->probe = 0;
+            } else {
+                s->kernel = 1, s->probe = 0;  // (timing unavailable: the launch that completed within its budget stays)
+            }
+        } else if (which == 1) {
+            return kModeU16;  // (until the timed u16 call has completed: results are the same either way)
+        }
+    }
+    (void)hipGetLastError();  // (hipEventQuery's hipErrorNotReady is not an error of this call)
     if (s->kernel == 2) return kModeU16;
     if (s->kernel == 1) return kModeByteStats;
     return kModeGuarded;
@@ -873,6 +906,7 @@ extern "C" int annlite_scan_state_create(annlite_scan_state **out) {
         memset(s->host, 0, 64);
         e = hipHostGetDevicePointer((void **)&s->dev, s->host, 0);
     }
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&s->ev[i / 2][i % 2]);
     if (e != hipSuccess) {
         if (s->host) (void)hipHostFree(s->host);
         free(s);
@@ -885,6 +919,8 @@ extern "C" int annlite_scan_state_create(annlite_scan_state **out) {
 extern "C" int annlite_scan_state_destroy(annlite_scan_state *s) {
     if (!s) return ANNLITE_OK;
     if (s->host) (void)hipHostFree(s->host);  // (waits for the device work that may still write it)
+    for (int i = 0; i < 4; ++i)
+        if (s->ev[i / 2][i % 2]) (void)hipEventDestroy(s->ev[i / 2][i % 2]);
     free(s);
     return ANNLITE_OK;
 }
@@ -892,6 +928,7 @@ extern "C" int annlite_scan_state_destroy(annlite_scan_state *s) {
 extern "C" int annlite_scan_state_reset(annlite_scan_state *s) {
     ANNLITE_REQUIRE(s != nullptr, "state is NULL");
     s->kernel = 0;
+    s->probe = 0;
     s->rows = 0;
     s->candidates = 0;
     s->seen_seq = __atomic_load_n(s->host, __ATOMIC_ACQUIRE);  // (what earlier launches left no longer counts)
@@ -927,11 +964,22 @@ static int scan_topk_impl(const void *codes_dev, int code_bytes, int codes_layou
             set_error("workspace %zu B < required %lld B", workspace_bytes, (long long)pub.workspace_bytes);
             return ANNLITE_ERR_WORKSPACE;
         }
-        if (mode == kModeU16) {
+        const double work = (double)((B + 31) / 32) * (double)N;
+        if (mode == kModeU16 || mode == kModeU16Probe) {
             VariantScope vs(31);
-            return scan_topk_impl(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut_dev, B, k, row_base, out_dist_dev,
-                                  out_id_dev, out_packed_dev, workspace_dev, workspace_bytes, stream, build, flags, tm, nullptr);
+            const bool timed = mode == kModeU16Probe;
+            if (timed) ANNLITE_HIP_TRY(hipEventRecord(state->ev[1][0], st));
+            const int rc = scan_topk_impl(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut_dev, B, k, row_base, out_dist_dev,
+                                          out_id_dev, out_packed_dev, workspace_dev, workspace_bytes, stream, build, flags, tm, nullptr);
+            if (timed && rc == ANNLITE_OK) {
+                ANNLITE_HIP_TRY(hipEventRecord(state->ev[1][1], st));
+                state->work[1] = work;
+                state->probe = 3;
+            }
+            return rc;
         }
+        const bool timed = state && state->kernel == 0 && state->probe == 1;
+        if (timed) ANNLITE_HIP_TRY(hipEventRecord(state->ev[0][0], st));
         GuardOpt g = {};
         g.abort_enabled = mode == kModeGuarded ? 1 : 0;
         if (state) {
@@ -960,6 +1008,11 @@ static int scan_topk_impl(const void *codes_dev, int code_bytes, int codes_layou
                               workspace_bytes - used, st, &p2, true, nullptr, &so2, nullptr, &g2);
             if (rc != ANNLITE_OK) return rc;
             ANNLITE_REQUIRE(so2.merged, "the gated u16-table launch did not merge in-kernel");
+        }
+        if (timed) {
+            ANNLITE_HIP_TRY(hipEventRecord(state->ev[0][1], st));
+            state->work[0] = work;
+            state->probe = 2;
         }
         return ANNLITE_OK;
     }

@@ -965,9 +965,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                             import_bounds();  // (the other slices' progress)
                             poll_guard();
                         }
-                        // budget: guard_base (1024) candidates + one per 32 rows the workgroup has drawn (with structure: ~1 per 1000 rows;
-                        // past ~1 per 32 the u16-table kernel is the faster one)
-                        if (a.guard && a.guard_abort && !aborted && n_seen > a.guard_base + (ldsv<uint32_t>(lds.blk_ctr()) << 1)) {
+                        // budget: guard_base (1024) candidates + one per 16 rows the workgroup has drawn.  Measured per 32-query tile: data
+                        // with structure ~1 per 1000 rows; uniform vectors through a trained codec ~1 per 31 (the byte tables are still
+                        // 2x the u16 tables there); independent random codes ~1 per 4 (10x slower)
+                        if (a.guard && a.guard_abort && !aborted && n_seen > a.guard_base + (ldsv<uint32_t>(lds.blk_ctr()) << 2)) {
                             if (lane == 0) __hip_atomic_store(a.guard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             give_up();
                         }

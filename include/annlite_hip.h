@@ -223,13 +223,15 @@ ANNLITE_API int annlite_adc_scan_candidates(const void *codes_dev, int code_byte
  * launch stream; annlite_profile_last_scan_ms() waits for the last one and returns its duration. */
 ANNLITE_API int annlite_profile_enable(int on);
 ANNLITE_API int annlite_profile_last_scan_ms(float *ms);
-/* Kernel choice (M = 16, k <= 16): byte filter tables (the default) or u16 filter tables -- made INSIDE the library, per
- * call, never by a process-wide switch.  Without a state every byte-table launch is guarded: it gives up when its
- * candidate rate says the code table has no structure (independent uniform codes: the byte filter leaks) and a gated
- * u16-table pass queued behind it redoes the scan (~10 us per batch of gated launches that return at once otherwise).
- * With a state -- ONE PER CODE TABLE, created once, passed to annlite_pq_search_topk_ex -- every byte-table launch leaves
- * its candidate count in the state's host-mapped block; later calls read it without synchronising and run the right
- * kernel directly (unguarded), until the table has doubled or halved.  Results are identical whatever runs.  A state must
+/* Kernel choice (M = 16 with uint8 codes, M = 8 with uint16 codes up to Ks = 512; k <= 16): byte filter tables (the default)
+ * or u16 filter tables -- made INSIDE the library, per call, never by a process-wide switch.  Without a state every
+ * byte-table launch is guarded: it gives up when a workgroup has seen more than 1024 + (rows it has drawn) / 16 candidates
+ * (a byte filter that leaks) and a gated u16-table pass queued behind it redoes the scan (~10 us per batch of gated
+ * launches that return at once otherwise).  With a state -- ONE PER CODE TABLE, created once, passed to
+ * annlite_pq_search_topk_ex -- every byte-table launch leaves its candidate count in the state's host-mapped block; later
+ * calls read it without synchronising: a launch that gave up settles the table on the u16 kernel, one with few candidates
+ * on the byte tables, and in between the state times ONE call of each kernel (events in the caller's stream, queried,
+ * never waited for) and keeps the faster -- until the table has doubled or halved.  Results are identical whatever runs.  A state must
  * not be used by two host threads at once (one searcher per index, as the reference has: SURVEY.md section 8b);
  * destroy it only after the launches that were given it have completed.
  * annlite_scan_state_info: kernel = 0 undecided, 1 byte tables, 2 u16 tables; rows / candidates of the deciding launch.
