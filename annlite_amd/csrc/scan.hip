@@ -314,6 +314,9 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
         // conflict-free); ANNLITE_SCAN_VARIANT=31: the u16-table kernel (A/B)
         if (M == 8 && Ks <= 512 && k <= 16 && (scan_variant() == 0 || scan_variant() == 50)) { *c = {8, 4, 2, 16, 4, 1, 850, 5}; return true; }
         if (M == 8 && Ks <= 512) { *c = {8, 4, 2, 16, 4, 1, 8217, 4}; return true; }   // u16 tables, 16 queries per workgroup
+        // 512 < Ks <= 1024: byte tables of ONE entry group (16 queries per workgroup; 2-way bank conflicts, inherent -- still
+        // half the LDS time per query of the u16 tables' 8)
+        if (M == 8 && Ks <= 1024 && k <= 16 && (scan_variant() == 0 || scan_variant() == 50)) { *c = {8, 4, 1, 16, 4, 1, 851, 5}; return true; }
         if (M == 8 && Ks <= 1024) { *c = {8, 4, 1, 16, 4, 1, 8216, 4}; return true; }
         if (M == 16 && Ks <= 512) { *c = {16, 4, 1, 16, 4, 1, 16216, 4}; return true; }
         return false;
@@ -844,7 +847,7 @@ enum SearchMode { kModePlain, kModeGuarded, kModeByteStats, kModeU16, kModeU16Pr
 static SearchMode search_policy(annlite_scan_state *s, int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t k,
                                 bool tiles) {
     // the shapes with both a byte-table and a u16-table kernel: M = 16 / u8 codes, M = 8 / u16 codes up to Ks = 512
-    const bool both = (M == 16 && code_bytes == 1 && Ks <= 256) || (M == 8 && code_bytes == 2 && Ks <= 512);
+    const bool both = (M == 16 && code_bytes == 1 && Ks <= 256) || (M == 8 && code_bytes == 2 && Ks <= 1024);
     if (tiles || !both || k > 16 || N <= 0 || B <= 0) return kModePlain;
     if (g_variant_scope >= 0 || env_variant() >= 0) return kModePlain;        // (an explicit variant: A/B measurements)
     if (getenv("ANNLITE_NO_INKERNEL_MERGE")) return kModePlain;                // (debug switch: no guarded pass)

@@ -78,13 +78,16 @@ struct Q8Cfg {
     static constexpr bool WIDE = M == 64;
     static constexpr bool C16 = M == 8;  // M = 8: uint16 codes (256 < Ks <= 512: table [Ks][2][8][16 B] = Ks * 256 bytes), PLAIN rows only
     static constexpr int CW = C16 ? M / 2 : M / 4;  // dwords of a code row
-    static constexpr int QT = WIDE ? 8 : 32;
     static constexpr int QMAX = WIDE ? 15 : 240 / M, QOPEN = WIDE ? 7 : 112 / M;
     static constexpr uint32_t TMAX = WIDE ? 32767u : 127u, TFLAG = TMAX + 1u;
 };
-template <int M>
+// NQ = entry groups of 16 queries per workgroup (the second shape parameter): 2 everywhere but M = 8 with 512 < Ks <= 1024,
+// where only one group's table fits the LDS (WIDE: 8 queries whatever NQ says)
+template <int M, int NQ>
+constexpr int q8_qt() { return Q8Cfg<M>::WIDE ? 8 : 16 * NQ; }
+template <int M, int NQ>
 __device__ __forceinline__ int q8_table_bytes(int Ks) {
-    return Q8Cfg<M>::WIDE ? (Ks + 1) * 512 : Ks * 2 * M * 16;  // WIDE: two half tables of 32 sub-spaces, [Ks + 1][32][8 B] each
+    return Q8Cfg<M>::WIDE ? (Ks + 1) * 512 : Ks * NQ * M * 16;  // WIDE: two half tables of 32 sub-spaces, [Ks + 1][32][8 B] each
 }
 
 // filter bound (TFLAG | T) implied by a k-th key for a table quantised with `step`:
@@ -150,10 +153,10 @@ struct Q8Build {  // what a (re)build needs, gathered from the kernarg segment i
     int32_t Ks, B, k, target;
 };
 
-template <int M, int NW>
+template <int M, int NW, int NQ>
 __device__ __forceinline__ void q8_build_table(const Q8Build &a, int tile, uint32_t tab_ad, uint32_t inv_ad, uint32_t clip_ad,
                                                int tid) {
-    constexpr int NQ = 2, RB = M * 16, NT = NW * 64, KHS = NT / M;
+    constexpr int RB = M * 16, NT = NW * 64, KHS = NT / M;
     static_assert(NT % M == 0 && KHS % NQ == 0, "build mapping");
     const int m = tid % M, kh0 = tid / M, h = kh0 % NQ;
     const int n_g4 = ((a.B + 15) / 16) * 4;  // fp32 TILED groups that exist (the table is padded to 16 queries)
@@ -161,7 +164,7 @@ __device__ __forceinline__ void q8_build_table(const Q8Build &a, int tile, uint3
     const float *src[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int g4 = tile * 8 + h * 4 + i;
+        const int g4 = tile * (4 * NQ) + h * 4 + i;
         const bool ok = g4 < n_g4;
         src[i] = a.lut + ((int64_t)(ok ? g4 : 0) * a.Ks * M + m) * 4;
 #pragma unroll
@@ -358,7 +361,7 @@ __device__ __forceinline__ void q8_publish_global(const FlushCtx &c, const Q8Lds
     pend_j = ~0ull;
 }
 
-template <int M, bool SKEWED>
+template <int M, bool SKEWED, int QT>
 __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, const unsigned long long (&e)[2], bool (&act)[2],
                                            int lane, uint32_t &n_kept, uint32_t &n_offered, unsigned long long &pend_o,
                                            unsigned long long &pend_j) {
@@ -401,7 +404,7 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
                         vals[j] = lq[((int64_t)code * M + m) * 4];
                     }
                     if constexpr (m0 == 0) {
-                        if (u == 0) q8_publish_global<Q8Cfg<M>::QT>(c, o, lane, pend_o, pend_j);  // (the previous batch's, behind these gathers)
+                        if (u == 0) q8_publish_global<QT>(c, o, lane, pend_o, pend_j);  // (the previous batch's, behind these gathers)
                     }
 #pragma unroll
                     for (int j = 0; j < 16; ++j) sum += vals[j];
@@ -437,7 +440,7 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
                 vals[u][m] = lq[((int64_t)code * M + m) * 4];
             }
         }
-        q8_publish_global<Q8Cfg<M>::QT>(c, o, lane, pend_o, pend_j);  // (the previous batch's, behind this batch's gathers)
+        q8_publish_global<QT>(c, o, lane, pend_o, pend_j);  // (the previous batch's, behind this batch's gathers)
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -516,16 +519,16 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
 // (Re)build of a workgroup's table: slot parameters (one thread per slot) from the best bound known for the query, then
 // the byte table.  Out of line on purpose: it runs a dozen times per work item, and inlined into the step loop its 40
 // live registers made the compiler spill the loop-invariant LDS base registers of the look-ups into the hot path.
-template <int M, int NW>
+template <int M, int NW, int NQ>
 __device__ __attribute__((noinline)) void q8_rebuild(q8_kernarg_ptr ka, int tile, int first, int slice) {
-    constexpr int QT = Q8Cfg<M>::QT;
+    constexpr int QT = q8_qt<M, NQ>();
     // first bounds of the item's queries: what the seed launch left in the shared array, or -- candidate generator, nothing
     // shared between the slices -- in this slice's row of the per-slice seeds ([n_slices][n_tiles * 32])
     const Q8Build a = {ka->lut, ka->qlom, ka->qstep, ka->smax, ka->qlo,
                        ka->gkey ? ka->gkey : (ka->gseed ? ka->gseed + (int64_t)slice * (ka->n_tiles * QT) : nullptr),
                        ka->Ks, ka->B, ka->k, ka->q8_target};
     const int tid = threadIdx.x;
-    const Q8Lds o(q8_table_bytes<M>(a.Ks));
+    const Q8Lds o(q8_table_bytes<M, NQ>(a.Ks));
     if (tid < 32) {  // (the control block has 32 slots whatever QT is: the consumer's lanes 0 .. 31 look at all of them)
         const uint32_t t8 = 8u * (uint32_t)tid, t4 = 4u * (uint32_t)tid;
         const int b = tile * QT + tid;
@@ -563,7 +566,7 @@ __device__ __attribute__((noinline)) void q8_rebuild(q8_kernarg_ptr ka, int tile
     }
     __syncthreads();
     if constexpr (Q8Cfg<M>::WIDE) q8_build_table_wide<NW>(a, tile, o.tab, o.inv, o.clip, tid);
-    else q8_build_table<M, NW>(a, tile, o.tab, o.inv, o.clip, tid);
+    else q8_build_table<M, NW, NQ>(a, tile, o.tab, o.inv, o.clip, tid);
     __syncthreads();
 }
 
@@ -658,12 +661,12 @@ __device__ __forceinline__ bool q8_item_map(const ScanArgs &a, int item, int &ti
 // End of a work item: the lists ARE the workgroup's result for this (tile, slice) -- the final epoch_sync was the barrier:
 // every candidate is in --; the last of the tile's workgroups to arrive merges the slices.  Out of line, arguments from the
 // kernarg segment (see q8_kernarg).
-template <int M, int NW>
+template <int M, int NW, int NQ>
 __device__ __attribute__((noinline)) void q8_finish_item(q8_kernarg_ptr ka, int tile, int slice) {
-    constexpr int QT = Q8Cfg<M>::QT;
+    constexpr int QT = q8_qt<M, NQ>();
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int km1 = ka->k - 1, B = ka->B, n_slices = ka->n_slices, k = ka->k;
-    const Q8Lds lds(q8_table_bytes<M>(ka->Ks));
+    const Q8Lds lds(q8_table_bytes<M, NQ>(ka->Ks));
     unsigned long long *partial = ka->partial;
     for (int q = wave; q < QT; q += NW) {
         const int b = tile * QT + q;
@@ -692,11 +695,12 @@ __device__ __attribute__((noinline)) void q8_finish_item(q8_kernarg_ptr ka, int 
     }
 }
 
-template <int M, int NW, bool SKEWED>
+template <int M, int NW, bool SKEWED, int NQ>
 __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const ScanArgs a) {
     constexpr bool WIDE = Q8Cfg<M>::WIDE;
     constexpr bool C16 = Q8Cfg<M>::C16;
-    constexpr int NQ = 2, QT = Q8Cfg<M>::QT, CW = Q8Cfg<M>::CW, EB = 16, RB = M * EB, KSTRIDE = NQ * RB;
+    constexpr int QT = q8_qt<M, NQ>(), CW = Q8Cfg<M>::CW, EB = 16, RB = M * EB, KSTRIDE = NQ * RB;
+    static_assert(NQ == 2 || (NQ == 1 && C16), "one entry group: the M = 8 / uint16 shape above Ks = 512");
     constexpr int NS = NW - 1;  // scanning waves; wave NS is the consumer
     static_assert(M % 8 == 0 && (M <= 32 || WIDE) && (KSTRIDE & (KSTRIDE - 1)) == 0 && !(C16 && SKEWED), "unsupported shape");
 
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int km1 = a.k - 1;
 
-    const int lut_bytes = q8_table_bytes<M>(a.Ks);
+    const int lut_bytes = q8_table_bytes<M, NQ>(a.Ks);
     const Q8Lds lds(lut_bytes);
     const q8_kernarg_ptr ka = q8_kernarg();
 
@@ -751,7 +755,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             }
             __syncthreads();
             if (ldsv<uint32_t>(lds.ctl)) {
-                q8_rebuild<M, NW>(ka, tile, 0, slice);
+                q8_rebuild<M, NW, NQ>(ka, tile, 0, slice);
                 if (a.dbg && tid == 0) atomicAdd(a.dbg + 5, 1ull);
             }
         };
@@ -764,7 +768,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             ldsv_st<uint32_t>(lds.arrived(), 0);
             ldsv_st<uint32_t>(lds.blk_ctr(), 0);  // the block counter the scanning waves draw from
         }
-        q8_rebuild<M, NW>(ka, tile, 1, slice);  // (its barriers cover the initialisation above)
+        q8_rebuild<M, NW, NQ>(ka, tile, 1, slice);  // (its barriers cover the initialisation above)
         stamp(1);
 
         // epochs end after steps q8_epoch0, q8_epoch0 * mul + (mul - 1), ... and after the last step
@@ -956,7 +960,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                         }
                         n_seen += (uint32_t)(__popcll(__ballot(act[0])) + __popcll(__ballot(act[1])));
                         if (lane < NS) ldsv_st<uint32_t>(lds.heads() + 4u * (uint32_t)lane, head_v);  // the wave may reuse the entries
-                        q8_consume<M, SKEWED>(fc, lds, e, act, lane, n_kept, n_offered, pend_o, pend_j);
+                        q8_consume<M, SKEWED, QT>(fc, lds, e, act, lane, n_kept, n_offered, pend_o, pend_j);
                         __builtin_amdgcn_s_setprio(0);
                         ++n_batches;
                         if (a.dbg) t_busy += __builtin_readcyclecounter() - t0;
@@ -1008,7 +1012,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             }
         } else {
             // ------------------------------------------------------------------------------- scanning waves
-            constexpr int NF = WIDE ? 4 : 8;  // filter words per row: 8 dwords of byte sums (32 queries) / 4 dwords of u16 sums (8)
+            constexpr int NF = WIDE ? 4 : 4 * NQ;  // filter words per row: 4 dwords of byte sums per entry group (16 queries) / 4 dwords of u16 sums (WIDE: 8)
             const int s = lane % (WIDE ? 32 : M);
             const int rot_bytes = C16 ? 2 * s : s;  // PLAIN rows are rotated in registers: element (s + t) mod M to position t
             const uint32_t bsh = (uint32_t)(rot_bytes & 3);
@@ -1032,7 +1036,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             // l and l ^ 24 resp. l ^ 8 ... : they differ in lane bit 4): the lanes with bit 4 set read the entry groups in the
             // OTHER order -- 16 distinct slots per lane group, conflict-free.  Their sums[0..3] then belong to queries 16..31:
             // they load the filter words swapped (load_thw) and the candidate path un-swaps the slot.
-            const uint32_t f16 = C16 ? ((uint32_t)lane >> 4) & 1u : 0u;
+            const uint32_t f16 = (C16 && NQ == 2) ? ((uint32_t)lane >> 4) & 1u : 0u;
             uint32_t kx[2] = {0u, 0u}, ky[2] = {0u, 0u};
             if constexpr (C16) {
 #pragma unroll
@@ -1041,7 +1045,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     kx[t / 4] |= col << (8 * (t % 4));
                     ky[t / 4] |= (col ^ 128u) << (8 * (t % 4));
                 }
-                if (lds0 != 0u || a.Ks > 512) __builtin_trap();
+                if ((NQ == 2 && lds0 != 0u) || a.Ks > 1024 / NQ) __builtin_trap();
+            }
+            // C16 with ONE entry group (512 < Ks <= 1024): a code row of the table is 128 bytes = [8 sub-spaces][16 B] -- two code
+            // rows per bank line, so two lanes of a lane group with the same sub-space collide whenever their codes have the
+            // same parity (2-way conflicts, inherent: 160 KB do not hold a 256-byte row per code); address = (code << 7) + column
+            uint32_t mcol[(C16 && NQ == 1) ? M : 1];
+            if constexpr (C16 && NQ == 1) {
+#pragma unroll
+                for (int t = 0; t < M; ++t) mcol[t] = lds0 + (uint32_t)(((s + t) % M) * EB);
             }
             // WIDE: lane constant of the look-up addresses (the M = 64 u16 kernel's scheme): byte 0 = (lane % 32) * 8 (the column),
             // byte 2 = 0x01 (second half table); the table starts at LDS address 0 (all LDS is dynamic)
@@ -1178,7 +1190,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                         constexpr int i = decltype(I)::value, t = i % M, g = i / M;
                         // byte 0 <- column byte t % 4 of the lane constant, bytes 1..2 <- the 16-bit code, byte 3 <- 0
                         constexpr uint32_t sel = 0x0c000000u | ((uint32_t)(4 + 2 * (t % 2) + 1) << 16) | ((uint32_t)(4 + 2 * (t % 2)) << 8) | (uint32_t)(t % 4);
-                        const uint32_t ad = __builtin_amdgcn_perm(cc[t / 2], g ? ky[t / 4] : kx[t / 4], sel);
+                        uint32_t ad;
+                        if constexpr (NQ == 2) ad = __builtin_amdgcn_perm(cc[t / 2], g ? ky[t / 4] : kx[t / 4], sel);
+                        else ad = (((t % 2) ? cc[t / 2] >> 16 : cc[t / 2] & 0xffffu) << 7) + mcol[t];
                         dst = *(lds_entry_ptr)(uintptr_t)ad;
                     };
                     static_for<0, DEPTH>([&](auto I) { fetch(v[decltype(I)::value], I); });
@@ -1346,7 +1360,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                             static_for<0, NF>([&](auto I) {
                                 constexpr int i = decltype(I)::value;
                                 const uint32_t ss = (uint32_t)__builtin_amdgcn_readlane((int)sums[i], L);
-                                if constexpr (C16) ts[i] = (uint32_t)__builtin_amdgcn_readlane((int)thw[i], L);
+                                if constexpr (C16 && NQ == 2) ts[i] = (uint32_t)__builtin_amdgcn_readlane((int)thw[i], L);
                                 uint32_t bits = hits(ts[i], ss);
                                 while (bits) {
                                     uint32_t sv, slot;  // (the consumer re-checks the sum)
@@ -1358,7 +1372,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                                         const uint32_t by = (uint32_t)__builtin_ctz(bits) >> 3;
                                         sv = (ss >> (8u * by)) & 0xffu;
                                         slot = (uint32_t)(4 * i) + by;
-                                        if constexpr (C16) slot ^= fL << 4;
+                                        if constexpr (C16 && NQ == 2) slot ^= fL << 4;
                                     }
                                     bits &= bits - 1u;
                                     if (lane == n) {  // (scalar values into lane n: one compare, two conditional moves)
@@ -1394,7 +1408,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             }
         }
 
-        q8_finish_item<M, NW>(ka, tile, slice);
+        q8_finish_item<M, NW, NQ>(ka, tile, slice);
         if (a.dbg && tid == 0) {
             // [8] 2^62 - earliest start, [9] latest end, sums over the work items: [10] start, [11] init + first table build,
             // [12] thread 0's step loop, [13] its wait at the last barrier (the consumer's backlog, the slower waves),
@@ -1450,11 +1464,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
 
 using namespace annlite;
 
-template <int M, int NW, bool SKEWED>
+template <int M, int NW, bool SKEWED, int NQ>
 static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
     constexpr int QT = 32;  // (the control block is laid out for 32 slots whatever the kernel uses)
-    const size_t need = (size_t)(M == 64 ? (a.Ks + 1) * 512 : a.Ks * 2 * M * 16) + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32 + 32 + 16;
-    auto fn = adc_scan_q8_kernel<M, NW, SKEWED>;
+    const size_t need = (size_t)(M == 64 ? (a.Ks + 1) * 512 : a.Ks * NQ * M * 16) + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32 + 32 + 16;
+    auto fn = adc_scan_q8_kernel<M, NW, SKEWED, NQ>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
     return launch_status("adc_scan_q8_kernel");
@@ -1462,11 +1476,12 @@ static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
 
 int annlite::launch_q8_scan(int id, bool sk, const ScanArgs &a, int grid, hipStream_t st) {
     switch (id) {
-        case 1650: return sk ? launch_q8<16, 16, true>(a, grid, st) : launch_q8<16, 16, false>(a, grid, st);
-        case 6450: return sk ? launch_q8<64, 16, true>(a, grid, st) : launch_q8<64, 16, false>(a, grid, st);
-        case 850:  // M = 8, uint16 codes (PLAIN rows)
+        case 1650: return sk ? launch_q8<16, 16, true, 2>(a, grid, st) : launch_q8<16, 16, false, 2>(a, grid, st);
+        case 6450: return sk ? launch_q8<64, 16, true, 2>(a, grid, st) : launch_q8<64, 16, false, 2>(a, grid, st);
+        case 850:  // M = 8, uint16 codes (PLAIN rows): two entry groups (Ks <= 512)
+        case 851:  // ... one (Ks <= 1024)
             if (sk) { set_error("uint16 codes: PLAIN rows only"); return ANNLITE_ERR_UNSUPPORTED; }
-            return launch_q8<8, 16, false>(a, grid, st);
+            return id == 851 ? launch_q8<8, 16, false, 1>(a, grid, st) : launch_q8<8, 16, false, 2>(a, grid, st);
         default: set_error("no byte-table kernel with id %d", id); return ANNLITE_ERR_UNSUPPORTED;
     }
 }

@@ -459,7 +459,8 @@ def main():
         # 64 x 4.  256 CUs at 2.4 GHz (MI355X_MICROARCH.md: 256 B / clk / CU).
         plan_k = _capi.scan_plan(n_local, M, Ks, index.code_bytes, B, k)
         # (which M = 16 kernel served the table is the library's choice, from what its launches measured: index.scan_kernel)
-        byte_tables = (plan_k.qt == 32 or (M == 64 and plan_k.qt == 8)) and index.scan_kernel != 'u16 tables' and \
+        byte_tables = (plan_k.qt == 32 or (M == 64 and plan_k.qt == 8) or (M == 8 and index.code_bytes == 2 and plan_k.qt == 16)) and \
+            index.scan_kernel != 'u16 tables' and \
             os.environ.get('ANNLITE_SCAN_VARIANT', '0') in ('0', '50')
         per_clk = 256 if byte_tables else 128
         lds_peak = 256 * per_clk * 2.4e9

@@ -39,7 +39,9 @@ def test_scan_plan_arithmetic_no_gpu():
     assert (p.fast, p.qi, p.qt) == (1, 4, 32)
     p = _capi.scan_plan(1000, 8, 512, 2, 5, 50)  # ... k > 16 -> u16-table kernel, 16 queries per workgroup
     assert (p.fast, p.qi, p.qt) == (1, 4, 16)
-    p = _capi.scan_plan(1000, 8, 768, 2, 5, 10)
+    p = _capi.scan_plan(1000, 8, 768, 2, 5, 10)  # 512 < Ks <= 1024: byte tables of one entry group, 16 queries per workgroup
+    assert (p.fast, p.qi, p.qt) == (1, 4, 16)
+    p = _capi.scan_plan(1000, 8, 768, 2, 5, 40)  # ... k > 16: u16 tables, 8 queries per workgroup
     assert (p.fast, p.qi, p.qt) == (1, 4, 8)
     p = _capi.scan_plan(1000, 16, 768, 2, 5, 10)  # uint16 codes that do not -> generic kernel
     assert p.fast == 0 and p.qt == 1

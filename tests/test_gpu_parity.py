@@ -236,7 +236,9 @@ def test_scan_ties_and_valid_bits(ops, oracle, M):
 @pytest.mark.parametrize('shape', [(8, 768, 3000, 7, 10, True), (8, 512, 120_000, 37, 50, True), (16, 512, 90_000, 20, 10, True),
                                    (8, 1024, 50_000, 9, 10, True), (16, 768, 4000, 5, 10, False), (4, 512, 4000, 5, 10, False),
                                    # M = 8, Ks <= 512, k <= 16: the byte-table kernel's uint16-code shape (scan_q8.hip, C16)
-                                   (8, 512, 300_000, 70, 10, True), (8, 300, 100_000, 33, 16, True), (8, 512, 5000, 3, 1, True)])
+                                   (8, 512, 300_000, 70, 10, True), (8, 300, 100_000, 33, 16, True), (8, 512, 5000, 3, 1, True),
+                                   # ... and 512 < Ks <= 1024: one entry group, 16 queries per workgroup
+                                   (8, 768, 300_000, 70, 10, True), (8, 1024, 100_000, 21, 16, True), (8, 600, 5000, 3, 1, True)])
 def test_scan_uint16_codes(ops, oracle, shape):
     """uint16 codes (n_clusters > 256; the reference's own PQ tests run 512 and 768 at n_subvectors = 8,
     tests/test_pq_index.py:80-163): M = 8 up to Ks = 512 with k <= 16 runs the byte-table kernel (adc_scan_q8_kernel<8,..>), M = 8
