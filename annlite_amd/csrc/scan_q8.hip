@@ -31,11 +31,18 @@
 // the compiler spill the loop-invariant LDS base registers into the hot path.
 // LDS: [table Ks * 512][Q8Lds: bounds, ring control, block counter, slot parameters, lists u64 x32x16, ring u64 x1024,
 //      insertion queues]
+// Shapes (template <M, NW, SKEWED, NQ>; launch_q8_scan ids):
+//   1650  M = 16, uint8 codes, NQ = 2 entry groups = 32 queries per workgroup -- everything above; the headline kernel;
+//   6450  M = 64 ("WIDE"): 8 queries per 8-BYTE entry (ds_read_b64), byte sums of 16 look-ups widened into u16 sums (T up to
+//         960), two half tables [Ks + 1][32][8 B] with wrap-coded SKEWED rows and one v_perm_b32 per address;
+//   850   M = 8, uint16 codes, Ks <= 512, NQ = 2: table [Ks][2][8][16 B], one v_perm_b32 per address, the two entry groups
+//         read in lane-dependent order (conflict-free), PLAIN rows rotated in registers;
+//   851   M = 8, uint16 codes, Ks <= 1024, NQ = 1: 16 queries per workgroup (2-way bank conflicts, inherent).
 #include "scan_lists.h"
 
 #ifndef ANNLITE_Q8_EXP
 #define ANNLITE_Q8_EXP 0  // (timing experiments, results wrong: 1 = look-ups without the adds, 2 = adds without the look-ups,
-                          // 3 = code rows computed instead of loaded)
+                          // 3 = code rows computed instead of loaded, 4 = M = 64 rows read as interleaved 16-byte pieces)
 #endif
 
 namespace annlite {
