@@ -20,6 +20,8 @@ p.add_argument('--rows', type=int, default=1_000_000)
 p.add_argument('--m', type=int, default=16)
 p.add_argument('--batch', type=int, default=1024)
 p.add_argument('--k', type=int, default=10)
+p.add_argument('--ks', type=int, default=256, help='codewords per sub-space (> 256: uint16 codes, PLAIN layout)')
+p.add_argument('--dsub', type=int, default=8, help='floats per sub-vector (D = m * dsub)')
 p.add_argument('--iters', type=int, default=5)
 p.add_argument('--layout', type=int, default=1)
 p.add_argument('--valid', action='store_true', help='pass an all-ones validity bitmap (what the index plugin does)')
@@ -31,10 +33,12 @@ torch.cuda.set_device(0)
 dev = torch.device('cuda', 0)
 g = torch.Generator(device=dev)
 g.manual_seed(0)
-N, M, Ks, B, k = a.rows, a.m, 256, a.batch, a.k
-D = M * 8
+N, M, Ks, B, k = a.rows, a.m, a.ks, a.batch, a.k
+D = M * a.dsub
+if Ks > 256:
+    a.layout = 0
 if a.data == 'random':
-    codes = torch.randint(0, 256, (N, M), generator=g, device=dev, dtype=torch.uint8)
+    codes = torch.randint(0, Ks, (N, M), generator=g, device=dev, dtype=torch.int32).to(torch.uint8 if Ks <= 256 else torch.int16)
     cb = torch.randn((M, Ks, D // M), generator=g, device=dev)
     q = torch.randn((B, D), generator=g, device=dev)
 else:
@@ -48,14 +52,14 @@ else:
     codec.seed = 7
     codec.fit(gen(20480), iter=20)
     cb = codec.codebooks_dev
-    codes = torch.empty((N, M), dtype=torch.uint8, device=dev)
+    codes = torch.empty((N, M), dtype=torch.uint8 if Ks <= 256 else torch.int16, device=dev)
     for c0 in range(0, N, 500_000):
         n = min(500_000, N - c0)
         codes[c0:c0 + n] = ops.pq_encode(gen(n), cb)
     q = gen(B)
     if a.layout == 1:
         codes = ops.codes_skew(codes)
-plan = scan_plan(N, M, Ks, 1, B, k)
+plan = scan_plan(N, M, Ks, 1 if Ks <= 256 else 2, B, k)
 ws = ops.ScanWorkspace()
 state = _capi.ScanState()  # (as the index plug-in does: the library settles on a kernel after the first launches)
 valid = torch.full(((N + 31) // 32 + 1,), -1, dtype=torch.int32, device=dev) if a.valid else None
