@@ -231,7 +231,8 @@ ANNLITE_API int annlite_profile_last_scan_ms(float *ms);
  * annlite_pq_search_topk_ex -- every byte-table launch leaves its candidate count in the state's host-mapped block; later
  * calls read it without synchronising: a launch that gave up settles the table on the u16 kernel, one with few candidates
  * on the byte tables, and in between the state times ONE call of each kernel (events in the caller's stream, queried,
- * never waited for) and keeps the faster -- until the table has doubled or halved.  Results are identical whatever runs.  A state must
+ * never waited for) and keeps the faster -- until the table has doubled or halved.  Results are identical whatever runs.  (Calls
+ * that carry a state record events and read a host-mapped block: do not issue them inside a stream capture.)  A state must
  * not be used by two host threads at once (one searcher per index, as the reference has: SURVEY.md section 8b);
  * destroy it only after the launches that were given it have completed.
  * annlite_scan_state_info: kernel = 0 undecided, 1 byte tables, 2 u16 tables; rows / candidates of the deciding launch.
