@@ -608,13 +608,30 @@ __device__ __forceinline__ void q8_merge_tile(const ScanArgs &a, int b0, int QT,
     };
     unsigned long long n1 = load_pair(0), n2 = load_pair(1);
     unsigned long long best = ~0ull;  // lane j < k: the j-th smallest key so far
+    // (first cut, see below: whole slices in the first chunk, and the smallest j with n_full * j >= k)
+    const int n_full = (total < 64 ? total : 64) / k;
+    const int cut_j = n_full > 0 ? (k + n_full - 1) / n_full : 0;  // (<= k whenever n_full >= 1)
 #pragma unroll 1
     for (int p = 0; p < n_pairs; ++p) {
         unsigned long long key = n1;
         n1 = n2;
         n2 = load_pair(p + 2);
         const int c = p % nch;
-        if (c == 0) best = ~0ull;  // a new query
+        if (c == 0) {
+            best = ~0ull;  // a new query
+            // First cut of the first chunk (nothing to compare with yet: all 64 keys would go through the serial ranking
+            // below, ~3 us per query on the critical path of the launch).  The slices' lists are ascending and n_full of them
+            // lie wholly in this chunk: their j smallest keys, n_full * j >= k keys of distinct rows, are all <= the largest
+            // j-th key -- so is the k-th smallest of the union.
+            if (cut_j > 0) {
+                unsigned long long cut = 0ull;
+                for (int sl = 0; sl < n_full; ++sl) {
+                    const unsigned long long v = rd64(key, sl * k + cut_j - 1);
+                    cut = v > cut ? v : cut;
+                }
+                if (key > cut) key = ~0ull;
+            }
+        }
         const unsigned long long thr = rd64(best, km1);
         if (!(key < thr)) key = ~0ull;
         unsigned long long m = __ballot(key != ~0ull);
