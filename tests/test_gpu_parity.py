@@ -260,6 +260,43 @@ def test_scan_uint16_codes(ops, oracle, shape):
         assert np.array_equal(d[b], rd) and np.array_equal(i[b], ri)
 
 
+@pytest.mark.parametrize('seed', range(8))
+def test_scan_uint16_codes_byte_tables_random_shapes(ops, oracle, seed):
+    """The byte-table kernel's two uint16-code shapes (M = 8; Ks <= 512: 32 queries per workgroup, the two entry groups read in
+    lane-dependent order; Ks <= 1024: 16 queries) on random sizes: ragged N (not a multiple of 64), B (not a multiple of a tile),
+    k = 1 .. 16, heavy exact ties, negative table entries, a validity bitmap, a row base -- ids and distances = the oracle's."""
+    from annlite_amd._capi import scan_plan
+
+    rs = np.random.RandomState(1000 + seed)
+    M = 8
+    Ks = int(rs.choice([257, 300, 512, 513, 700, 1024]))
+    N = int(rs.choice([1, 63, 64, 65, 1000, 4097, 30_000, 70_001, 200_000]))
+    B = int(rs.choice([1, 15, 16, 17, 31, 33, 70]))
+    k = int(rs.randint(1, 17))
+    plan = scan_plan(N, M, Ks, 2, B, k)
+    assert plan.fast == 1 and plan.qt == (32 if Ks <= 512 else 16)
+    lut = rs.rand(B, M, Ks).astype(np.float32)
+    lut[B // 2] -= 0.5
+    if seed % 2:  # few distinct rows: exact ties everywhere
+        base = rs.randint(0, Ks, size=(17, M)).astype(np.uint16)
+        codes = base[rs.randint(0, 17, size=N)]
+    else:
+        codes = rs.randint(0, Ks, size=(N, M)).astype(np.uint16)
+    valid = rs.rand(N) < 0.8 if seed % 3 == 0 else None
+    d, i, _ = _scan(ops, codes, lut, k, 0, valid=valid, row_base=77)
+    if valid is None:
+        rd, ri = oracle.adc_search_c(lut, codes, k, id_base=77)
+    else:
+        idx = np.where(valid)[0]
+        if len(idx):
+            rd, ri = oracle.adc_search_c(lut, codes[idx], k)
+            ri = np.where(ri >= 0, idx[np.clip(ri, 0, len(idx) - 1)] + 77, -1)
+        else:
+            rd, ri = np.full((B, k), np.inf, np.float32), np.full((B, k), -1, np.int64)
+    assert np.array_equal(d, rd), (Ks, N, B, k)
+    assert np.array_equal(i, ri), (Ks, N, B, k)
+
+
 def test_candidates_superset_and_gather(ops, oracle):
     import torch
     from annlite_amd._capi import scan_plan
