@@ -50,6 +50,10 @@ namespace annlite {
 #ifndef ANNLITE_Q8_WDEPTH
 #define ANNLITE_Q8_WDEPTH 16  // M = 64: landing registers (8-byte entries) of the look-up ring
 #endif
+#ifndef ANNLITE_Q8_BUILD_UNROLL
+#define ANNLITE_Q8_BUILD_UNROLL 2  // codes per thread whose table loads are in flight together in the (re)build (4 / 8: the build no
+                                   // faster -- 15 -> 16 us -- and the allocator then spilled into the step loop: +12 %)
+#endif
 #ifndef ANNLITE_Q8_DEPTH
 #define ANNLITE_Q8_DEPTH 8  // look-ups in flight per lane
 #endif
@@ -181,7 +185,7 @@ __device__ __forceinline__ void q8_build_table(const Q8Build &a, int tile, uint3
             clip_r[4 * i + e] = ldsv<float>(clip_ad + 4u * (uint32_t)(h * 16 + 4 * i + e));
         }
     }
-#pragma unroll 2
+#pragma unroll ANNLITE_Q8_BUILD_UNROLL
     for (int kh = kh0; kh < a.Ks * NQ; kh += KHS) {
         const int k = kh / NQ;
         uint32_t w[4];
