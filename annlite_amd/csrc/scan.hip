@@ -879,7 +879,9 @@ static SearchMode search_policy(annlite_scan_state *s, int64_t N, int64_t M, int
     if (s->kernel == 0 && s->probe >= 2) {
         // timed calls: pick up what has completed (never wait)
         const int which = s->probe == 2 ? 0 : 1;
-        if (hipEventQuery(s->ev[which][1]) == hipSuccess) {
+        const hipError_t ready = hipEventQuery(s->ev[which][1]);
+        if (ready == hipErrorNotReady) (void)hipGetLastError();  // (not an error of this call: do not leave it behind)
+        if (ready == hipSuccess) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, s->ev[which][0], s->ev[which][1]) == hipSuccess && ms > 0.f) {
                 s->ms[which] = ms;
@@ -894,7 +896,6 @@ static SearchMode search_policy(annlite_scan_state *s, int64_t N, int64_t M, int
             return kModeU16;  // (until the timed u16 call has completed: results are the same either way)
         }
     }
-    (void)hipGetLastError();  // (hipEventQuery's hipErrorNotReady is not an error of this call)
     if (s->kernel == 2) return kModeU16;
     if (s->kernel == 1) return kModeByteStats;
     return kModeGuarded;
