@@ -324,7 +324,12 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
     if (code_bytes != 1 || Ks > 256) return false;
     const int v = scan_variant();
     switch (M) {
-        case 8: *c = {8, 4, 2, 16, 4, 1, 830, 4}; return true;  // u16 tables, 16 queries / WG
+        case 8:
+            // default: byte tables (scan_q8.hip, M8 shape: table [Ks][2][8][16 B] = 64 KB, 32 queries / WG); k > 16, tile mode and
+            // variant 31: u16 tables, 16 queries / WG
+            if ((v == 0 || v == 50) && !tiles && k <= 16) { *c = {8, 4, 2, 16, 4, 1, 852, 5}; return true; }
+            *c = {8, 4, 2, 16, 4, 1, 830, 4};
+            return true;
         case 16:
             // default: byte tables, 32 queries / WG, 15 scanning waves + 1 consumer (small k: the candidate generator of the
             // re-rank stage asks for 64 per slice and starts without a seed -- the u16 tables filter that much better)
@@ -847,7 +852,7 @@ enum SearchMode { kModePlain, kModeGuarded, kModeByteStats, kModeU16, kModeU16Pr
 static SearchMode search_policy(annlite_scan_state *s, int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t k,
                                 bool tiles) {
     // the shapes with both a byte-table and a u16-table kernel: M = 16 / u8 codes, M = 8 / u16 codes up to Ks = 512
-    const bool both = (M == 16 && code_bytes == 1 && Ks <= 256) || (M == 8 && code_bytes == 2 && Ks <= 1024);
+    const bool both = ((M == 16 || M == 8) && code_bytes == 1 && Ks <= 256) || (M == 8 && code_bytes == 2 && Ks <= 1024);
     if (tiles || !both || k > 16 || N <= 0 || B <= 0) return kModePlain;
     if (g_variant_scope >= 0 || env_variant() >= 0) return kModePlain;        // (an explicit variant: A/B measurements)
     if (getenv("ANNLITE_NO_INKERNEL_MERGE")) return kModePlain;                // (debug switch: no guarded pass)

@@ -31,13 +31,14 @@
 // the compiler spill the loop-invariant LDS base registers into the hot path.
 // LDS: [table Ks * 512][Q8Lds: bounds, ring control, block counter, slot parameters, lists u64 x32x16, ring u64 x1024,
 //      insertion queues]
-// Shapes (template <M, NW, SKEWED, NQ>; launch_q8_scan ids):
+// Shapes (template <M, NW, SKEWED, NQ, CB = bytes per code>; launch_q8_scan ids):
 //   1650  M = 16, uint8 codes, NQ = 2 entry groups = 32 queries per workgroup -- everything above; the headline kernel;
 //   6450  M = 64 ("WIDE"): 8 queries per 8-BYTE entry (ds_read_b64), byte sums of 16 look-ups widened into u16 sums (T up to
 //         960), two half tables [Ks + 1][32][8 B] with wrap-coded SKEWED rows and one v_perm_b32 per address;
 //   850   M = 8, uint16 codes, Ks <= 512, NQ = 2: table [Ks][2][8][16 B], one v_perm_b32 per address, the two entry groups
 //         read in lane-dependent order (conflict-free), PLAIN rows rotated in registers;
 //   851   M = 8, uint16 codes, Ks <= 1024, NQ = 1: 16 queries per workgroup (2-way bank conflicts, inherent).
+//   852   M = 8, uint8 codes (Ks <= 256), NQ = 2: the 850 shape with a 64 KB table; SKEWED rows need no rotation.
 #include "scan_lists.h"
 
 #ifndef ANNLITE_Q8_EXP
@@ -87,8 +88,7 @@ __device__ __forceinline__ uint32_t lds_base_addr() {
 template <int M>
 struct Q8Cfg {
     static constexpr bool WIDE = M == 64;
-    static constexpr bool C16 = M == 8;  // M = 8: uint16 codes (256 < Ks <= 512: table [Ks][2][8][16 B] = Ks * 256 bytes), PLAIN rows only
-    static constexpr int CW = C16 ? M / 2 : M / 4;  // dwords of a code row
+    static constexpr bool M8 = M == 8;  // M = 8: table [Ks][NQ entry groups][8 sub-spaces][16 B], permute addressing (see the kernel)
     static constexpr int QMAX = WIDE ? 15 : 240 / M, QOPEN = WIDE ? 7 : 112 / M;
     static constexpr uint32_t TMAX = WIDE ? 32767u : 127u, TFLAG = TMAX + 1u;
 };
@@ -372,13 +372,13 @@ __device__ __forceinline__ void q8_publish_global(const FlushCtx &c, const Q8Lds
     pend_j = ~0ull;
 }
 
-template <int M, bool SKEWED, int QT>
+template <int M, bool SKEWED, int QT, int CB>
 __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, const unsigned long long (&e)[2], bool (&act)[2],
                                            int lane, uint32_t &n_kept, uint32_t &n_offered, unsigned long long &pend_o,
                                            unsigned long long &pend_j) {
-    constexpr int CW = Q8Cfg<M>::CW;
-    constexpr bool C16 = Q8Cfg<M>::C16;
-    static_assert(!(C16 && SKEWED), "uint16 codes: PLAIN rows");
+    constexpr int CW = M * CB / 4;  // dwords of a code row (CB = bytes per code: 1, or 2 for uint16 codes)
+    constexpr bool C16 = CB == 2;
+    static_assert(CB == 1 || (CB == 2 && !SKEWED), "uint16 codes: PLAIN rows");
     int q[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -723,12 +723,13 @@ __device__ __attribute__((noinline)) void q8_finish_item(q8_kernarg_ptr ka, int 
     }
 }
 
-template <int M, int NW, bool SKEWED, int NQ>
+template <int M, int NW, bool SKEWED, int NQ, int CB>
 __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const ScanArgs a) {
     constexpr bool WIDE = Q8Cfg<M>::WIDE;
-    constexpr bool C16 = Q8Cfg<M>::C16;
-    constexpr int QT = q8_qt<M, NQ>(), CW = Q8Cfg<M>::CW, EB = 16, RB = M * EB, KSTRIDE = NQ * RB;
-    static_assert(NQ == 2 || (NQ == 1 && C16), "one entry group: the M = 8 / uint16 shape above Ks = 512");
+    constexpr bool M8 = Q8Cfg<M>::M8, C16 = CB == 2;
+    constexpr int QT = q8_qt<M, NQ>(), CW = M * CB / 4, EB = 16, RB = M * EB, KSTRIDE = NQ * RB;
+    static_assert(CB == 1 || (CB == 2 && M8), "uint16 codes: the M = 8 shapes");
+    static_assert(NQ == 2 || (NQ == 1 && M8 && C16), "one entry group: the M = 8 / uint16 shape above Ks = 512");
     constexpr int NS = NW - 1;  // scanning waves; wave NS is the consumer
     static_assert(M % 8 == 0 && (M <= 32 || WIDE) && (KSTRIDE & (KSTRIDE - 1)) == 0 && !(C16 && SKEWED), "unsupported shape");
 
@@ -988,7 +989,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                         }
                         n_seen += (uint32_t)(__popcll(__ballot(act[0])) + __popcll(__ballot(act[1])));
                         if (lane < NS) ldsv_st<uint32_t>(lds.heads() + 4u * (uint32_t)lane, head_v);  // the wave may reuse the entries
-                        q8_consume<M, SKEWED, QT>(fc, lds, e, act, lane, n_kept, n_offered, pend_o, pend_j);
+                        q8_consume<M, SKEWED, QT, CB>(fc, lds, e, act, lane, n_kept, n_offered, pend_o, pend_j);
                         __builtin_amdgcn_s_setprio(0);
                         ++n_batches;
                         if (a.dbg) t_busy += __builtin_readcyclecounter() - t0;
@@ -1042,7 +1043,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             // ------------------------------------------------------------------------------- scanning waves
             constexpr int NF = WIDE ? 4 : 4 * NQ;  // filter words per row: 4 dwords of byte sums per entry group (16 queries) / 4 dwords of u16 sums (WIDE: 8)
             const int s = lane % (WIDE ? 32 : M);
-            const int rot_bytes = C16 ? 2 * s : s;  // PLAIN rows are rotated in registers: element (s + t) mod M to position t
+            const int rot_bytes = CB * s;  // PLAIN rows are rotated in registers: element (s + t) mod M to position t
             const uint32_t bsh = (uint32_t)(rot_bytes & 3);
             bool abit[8];
 #pragma unroll
@@ -1052,34 +1053,34 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             typedef const ANNLITE_LDS u32x4 *lds_entry_ptr;
             typedef const ANNLITE_LDS u32x2 *lds_entry8_ptr;
             const uint32_t lds0 = lds.tab;
-            uint32_t mbase[(WIDE || C16) ? 1 : M];
-            if constexpr (!WIDE && !C16) {
+            uint32_t mbase[(WIDE || M8) ? 1 : M];
+            if constexpr (!WIDE && !M8) {
 #pragma unroll
                 for (int t = 0; t < M; ++t) mbase[t] = lds0 + (uint32_t)(((s + t) % M) * EB);
             }
-            // C16 (M = 8, uint16 codes): a code row of the table is 256 bytes = [2 entry groups][8 sub-spaces][16 B], the address of
+            // M8 (M = 8; uint16 codes, or uint8 ones up to Ks = 256): a code row of the table is 256 bytes = [2 entry groups][8 sub-spaces][16 B], the address of
             // look-up t is (code << 8) | column byte -- ONE v_perm_b32 of the code dword with a lane constant (kx / ky: byte t of
             // the pair = the column of look-up t in the lane's FIRST / SECOND entry group).  Eight sub-spaces cover only half of
             // the 16 bank slots a ds_read_b128 lane group spans, and every hardware lane group holds each s = lane % 8 twice (lanes
             // l and l ^ 24 resp. l ^ 8 ... : they differ in lane bit 4): the lanes with bit 4 set read the entry groups in the
             // OTHER order -- 16 distinct slots per lane group, conflict-free.  Their sums[0..3] then belong to queries 16..31:
             // they load the filter words swapped (load_thw) and the candidate path un-swaps the slot.
-            const uint32_t f16 = (C16 && NQ == 2) ? ((uint32_t)lane >> 4) & 1u : 0u;
+            const uint32_t f16 = (M8 && NQ == 2) ? ((uint32_t)lane >> 4) & 1u : 0u;
             uint32_t kx[2] = {0u, 0u}, ky[2] = {0u, 0u};
-            if constexpr (C16) {
+            if constexpr (M8) {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     const uint32_t col = (uint32_t)(((s + t) % 8) * 16) + f16 * 128u;
                     kx[t / 4] |= col << (8 * (t % 4));
                     ky[t / 4] |= (col ^ 128u) << (8 * (t % 4));
                 }
-                if ((NQ == 2 && lds0 != 0u) || a.Ks > 1024 / NQ) __builtin_trap();
+                if ((NQ == 2 && lds0 != 0u) || a.Ks > (C16 ? 1024 / NQ : 256)) __builtin_trap();
             }
             // C16 with ONE entry group (512 < Ks <= 1024): a code row of the table is 128 bytes = [8 sub-spaces][16 B] -- two code
             // rows per bank line, so two lanes of a lane group with the same sub-space collide whenever their codes have the
             // same parity (2-way conflicts, inherent: 160 KB do not hold a 256-byte row per code); address = (code << 7) + column
-            uint32_t mcol[(C16 && NQ == 1) ? M : 1];
-            if constexpr (C16 && NQ == 1) {
+            uint32_t mcol[(M8 && NQ == 1) ? M : 1];
+            if constexpr (M8 && NQ == 1) {
 #pragma unroll
                 for (int t = 0; t < M; ++t) mcol[t] = lds0 + (uint32_t)(((s + t) % M) * EB);
             }
@@ -1108,7 +1109,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 return v;
             };
             uint32_t ccur[CW], cnext[CW];
-            uint32_t addr[(WIDE || C16) ? 1 : M];
+            uint32_t addr[(WIDE || M8) ? 1 : M];
             auto load_row = [&](uint32_t row, uint32_t (&c)[CW]) {
                 if constexpr (ANNLITE_Q8_EXP == 3) {  // (timing experiment: no code rows from memory)
 #pragma unroll
@@ -1140,7 +1141,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 }
             };
             auto make_addr = [&](const uint32_t (&cc)[CW]) {
-                if constexpr (!WIDE && !C16)
+                if constexpr (!WIDE && !M8)
                     static_for<0, CW>([&](auto W) {
                         constexpr int w = decltype(W)::value;
                         uint32_t o0, o1, o2, o3;
@@ -1209,7 +1210,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                             sums[3] += __builtin_amdgcn_perm(0u, bs.y, 0x0c030c01u);
                         }
                     });
-                } else if constexpr (C16) {
+                } else if constexpr (M8) {
                     // 8 look-ups in the lane's first entry group, then 8 in its second, through a ring of DEPTH landing registers
                     constexpr int DEPTH = ANNLITE_Q8_DEPTH, TOT = NQ * M;
                     u32x4 acc[NQ];
@@ -1217,9 +1218,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     auto fetch = [&](u32x4 &dst, auto I) {
                         constexpr int i = decltype(I)::value, t = i % M, g = i / M;
                         // byte 0 <- column byte t % 4 of the lane constant, bytes 1..2 <- the 16-bit code, byte 3 <- 0
-                        constexpr uint32_t sel = 0x0c000000u | ((uint32_t)(4 + 2 * (t % 2) + 1) << 16) | ((uint32_t)(4 + 2 * (t % 2)) << 8) | (uint32_t)(t % 4);
+                        // (uint8 codes: byte 1 <- code byte t % 4, byte 2 <- 0)
+                        constexpr uint32_t sel = C16 ? 0x0c000000u | ((uint32_t)(4 + 2 * (t % 2) + 1) << 16) | ((uint32_t)(4 + 2 * (t % 2)) << 8) | (uint32_t)(t % 4)
+                                                     : 0x0c0c0000u | ((uint32_t)(4 + t % 4) << 8) | (uint32_t)(t % 4);
                         uint32_t ad;
-                        if constexpr (NQ == 2) ad = __builtin_amdgcn_perm(cc[t / 2], g ? ky[t / 4] : kx[t / 4], sel);
+                        if constexpr (NQ == 2) ad = __builtin_amdgcn_perm(cc[C16 ? t / 2 : t / 4], g ? ky[t / 4] : kx[t / 4], sel);
                         else ad = (((t % 2) ? cc[t / 2] >> 16 : cc[t / 2] & 0xffffu) << 7) + mcol[t];
                         dst = *(lds_entry_ptr)(uintptr_t)ad;
                     };
@@ -1300,7 +1303,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 for (; b_cur < end_blk; ++it_no) {
                     const uint32_t row0 = s_begin + b_cur * 64u;  // (< s_end: b_cur < n_blocks)
                     pend = draw();
-                    uint32_t rot1[C16 ? CW : 1];  // (C16: first rotation stage straight from the landing registers -- no copy)
+                    uint32_t rot1[C16 ? CW : 1];  // (uint16 codes: first rotation stage straight from the landing registers -- no copy)
                     if constexpr (C16) {
 #pragma unroll
                         for (int i = 0; i < CW; ++i)
@@ -1384,11 +1387,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                             const int L = __builtin_ctzll(rem);
                             rem &= rem - 1ull;
                             const uint32_t rid = row0 + (uint32_t)L;
-                            const uint32_t fL = C16 ? ((uint32_t)L >> 4) & 1u : 0u;  // that lane's sums[0..3] are of entry group fL
+                            const uint32_t fL = M8 ? ((uint32_t)L >> 4) & 1u : 0u;  // that lane's sums[0..3] are of entry group fL
                             static_for<0, NF>([&](auto I) {
                                 constexpr int i = decltype(I)::value;
                                 const uint32_t ss = (uint32_t)__builtin_amdgcn_readlane((int)sums[i], L);
-                                if constexpr (C16 && NQ == 2) ts[i] = (uint32_t)__builtin_amdgcn_readlane((int)thw[i], L);
+                                if constexpr (M8 && NQ == 2) ts[i] = (uint32_t)__builtin_amdgcn_readlane((int)thw[i], L);
                                 uint32_t bits = hits(ts[i], ss);
                                 while (bits) {
                                     uint32_t sv, slot;  // (the consumer re-checks the sum)
@@ -1400,7 +1403,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                                         const uint32_t by = (uint32_t)__builtin_ctz(bits) >> 3;
                                         sv = (ss >> (8u * by)) & 0xffu;
                                         slot = (uint32_t)(4 * i) + by;
-                                        if constexpr (C16 && NQ == 2) slot ^= fL << 4;
+                                        if constexpr (M8 && NQ == 2) slot ^= fL << 4;
                                     }
                                     bits &= bits - 1u;
                                     if (lane == n) {  // (scalar values into lane n: one compare, two conditional moves)
@@ -1492,11 +1495,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
 
 using namespace annlite;
 
-template <int M, int NW, bool SKEWED, int NQ>
+template <int M, int NW, bool SKEWED, int NQ, int CB>
 static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
     constexpr int QT = 32;  // (the control block is laid out for 32 slots whatever the kernel uses)
     const size_t need = (size_t)(M == 64 ? (a.Ks + 1) * 512 : a.Ks * NQ * M * 16) + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32 + 32 + 16;
-    auto fn = adc_scan_q8_kernel<M, NW, SKEWED, NQ>;
+    auto fn = adc_scan_q8_kernel<M, NW, SKEWED, NQ, CB>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
     return launch_status("adc_scan_q8_kernel");
@@ -1504,12 +1507,14 @@ static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
 
 int annlite::launch_q8_scan(int id, bool sk, const ScanArgs &a, int grid, hipStream_t st) {
     switch (id) {
-        case 1650: return sk ? launch_q8<16, 16, true, 2>(a, grid, st) : launch_q8<16, 16, false, 2>(a, grid, st);
-        case 6450: return sk ? launch_q8<64, 16, true, 2>(a, grid, st) : launch_q8<64, 16, false, 2>(a, grid, st);
+        case 1650: return sk ? launch_q8<16, 16, true, 2, 1>(a, grid, st) : launch_q8<16, 16, false, 2, 1>(a, grid, st);
+        case 6450: return sk ? launch_q8<64, 16, true, 2, 1>(a, grid, st) : launch_q8<64, 16, false, 2, 1>(a, grid, st);
         case 850:  // M = 8, uint16 codes (PLAIN rows): two entry groups (Ks <= 512)
         case 851:  // ... one (Ks <= 1024)
             if (sk) { set_error("uint16 codes: PLAIN rows only"); return ANNLITE_ERR_UNSUPPORTED; }
-            return id == 851 ? launch_q8<8, 16, false, 1>(a, grid, st) : launch_q8<8, 16, false, 2>(a, grid, st);
+            return id == 851 ? launch_q8<8, 16, false, 1, 2>(a, grid, st) : launch_q8<8, 16, false, 2, 2>(a, grid, st);
+        case 852:  // M = 8, uint8 codes (Ks <= 256): two entry groups, 64 KB table
+            return sk ? launch_q8<8, 16, true, 2, 1>(a, grid, st) : launch_q8<8, 16, false, 2, 1>(a, grid, st);
         default: set_error("no byte-table kernel with id %d", id); return ANNLITE_ERR_UNSUPPORTED;
     }
 }

@@ -6,8 +6,8 @@ set -eu
 cd "$(dirname "$0")/../annlite_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-atomic-optimizer-strategy=None "$@" -S --cuda-device-only scan_q8.hip -o /tmp/q8_check.s 2>/dev/null
 for sk in Lb1E Lb0E; do
-  a=$(grep -n "^_ZN7annlite18adc_scan_q8_kernelILi16ELi16E${sk}Li2EEEvNS_8ScanArgsE:" /tmp/q8_check.s | cut -d: -f1)
-  b=$(grep -n "amdhsa_kernel _ZN7annlite18adc_scan_q8_kernelILi16ELi16E${sk}Li2E" /tmp/q8_check.s | cut -d: -f1)
+  a=$(grep -n "^_ZN7annlite18adc_scan_q8_kernelILi16ELi16E${sk}Li2ELi1EEEvNS_8ScanArgsE:" /tmp/q8_check.s | cut -d: -f1)
+  b=$(grep -n "amdhsa_kernel _ZN7annlite18adc_scan_q8_kernelILi16ELi16E${sk}Li2ELi1E" /tmp/q8_check.s | cut -d: -f1)
   sed -n "${a},${b}p" /tmp/q8_check.s > /tmp/q8_check_k.s
   lo=$(grep -n "ds_read_b128 .* offset:256" /tmp/q8_check_k.s | head -1 | cut -d: -f1)
   hi=$(grep -n "ds_read_b128 .* offset:256" /tmp/q8_check_k.s | tail -1 | cut -d: -f1)

@@ -35,6 +35,8 @@ def test_scan_plan_arithmetic_no_gpu():
     assert p.workspace_bytes >= 1024 * p.n_slices * 10 * 8
     p = _capi.scan_plan(1000, 64, 256, 1, 3, 10)
     assert (p.fast, p.qi, p.qt) == (1, 4, 8) and p.lut_floats == 16 * 64 * 256  # (M = 64, k <= 16: byte tables, 8 queries per workgroup)
+    p = _capi.scan_plan(1000, 8, 256, 1, 5, 10)  # M = 8, uint8 codes, k <= 16 -> byte tables, 32 queries per workgroup (k > 16: u16 tables, 16)
+    assert (p.fast, p.qi, p.qt) == (1, 4, 32) and _capi.scan_plan(1000, 8, 256, 1, 5, 40).qt == 16
     p = _capi.scan_plan(1000, 8, 512, 2, 5, 10)  # uint16 codes, M = 8, Ks <= 512, k <= 16 -> byte-table kernel, 32 queries per workgroup
     assert (p.fast, p.qi, p.qt) == (1, 4, 32)
     p = _capi.scan_plan(1000, 8, 512, 2, 5, 50)  # ... k > 16 -> u16-table kernel, 16 queries per workgroup
