@@ -45,8 +45,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=40)
-    p.add_argument('--warmup', type=int, default=10)
+    p.add_argument('--steps', type=int, default=200)
+    p.add_argument('--warmup', type=int, default=20)
     p.add_argument('--rows', type=int, default=10_000_000)
     p.add_argument('--dim', type=int, default=128)
     p.add_argument('--m', type=int, default=16)
