@@ -38,6 +38,7 @@ CASES = {
     'c4_m64_d768': (64, 12, 256, 192, 3, 103),     # config 4 shape
     't_m32_d128': (32, 4, 256, 1024, 5, 104),      # tests/test_pq_bind.py shape
     'ks512_m8_d64': (8, 8, 512, 1000, 5, 105),     # tests/test_pq_index.py:80 (uint16 codes)
+    'ks768_m8_d64': (8, 8, 768, 1000, 5, 106),     # tests/test_pq_index.py:80, the third n_clusters (round 3: 16-query byte tables)
 }
 K = 10
 
@@ -186,9 +187,12 @@ def make_cells_case(ref, name='cells_m16_d64', M=16, dsub=4, Ks=256, N=4000, B=8
 
 def main():
     ref = ref_import.load()
+    only = set(sys.argv[1:])  # (no arguments: every fixture; names: only those -- e.g. a case added later)
     for name, spec in CASES.items():
-        make_case(ref, name, *spec)
-    make_cells_case(ref)
+        if not only or name in only:
+            make_case(ref, name, *spec)
+    if not only or 'cells' in only:
+        make_cells_case(ref)
 
 
 if __name__ == '__main__':
