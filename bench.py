@@ -24,6 +24,11 @@ bounded sample).  Extra legs (rank 0, N=1, never `value`): `rerank` (recall targ
 with the default workload only -- `c2`, `c4`, `c5` (the other BASELINE configurations, each a
 sub-run with its own `roofline` and `cpu_baseline`) and `uniform` (the reference's own test
 distribution); `--legs` selects them.
+
+Set-up before the W warm-up steps includes `--prewarm-steps` (64) untimed steps: a GPU that idled through index
+construction needs milliseconds of work to reach its sustained clock -- at a 0.27 ms step (one rank's shard of 8) W = 2 /
+K = 20 measured 0.311 ms per step without it and 0.266 with it (K = 200: 0.265 / 0.257).  The timed region is unchanged:
+exactly K steps between two synchronisations (+ barriers), max over ranks.
 """
 import argparse
 import json
@@ -72,6 +77,7 @@ def parse():
                         'durations rocprofv3 reports for this command are not inflated by overlap; 2 on one GPU: the next '
                         'batch\'s table build and seed fill the CUs the previous scan\'s tail leaves idle, -1.4 %% / -4 %% per '
                         'batch at 10M / 1.25M rows)')
+    p.add_argument('--prewarm-steps', type=int, default=64, help='untimed steps of set-up before the W warm-up steps (clock ramp); 0 = none')
     p.add_argument('--layout', choices=['skewed', 'plain'], default='skewed')
     p.add_argument('--rerank-k', type=int, default=0, help='ADC candidates per row slice of the exact re-rank leg (0 = the index default, 64)')
     p.add_argument('--no-rerank', action='store_true', help='skip the (untimed-in-value) exact re-rank leg')
@@ -222,6 +228,13 @@ def main():
     streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)] if n_streams == 2 else [torch.cuda.current_stream(dev)]
     for st in streams:
         st.wait_stream(torch.cuda.current_stream(dev))
+    # clocks: a GPU that has idled through index construction and host-side set-up takes milliseconds of work to reach its
+    # sustained clock -- at a 0.27 ms step a short warm-up (W = 10) left the first timed steps 8 % slow.  Untimed set-up work,
+    # before the W warm-up steps the contract asks for:
+    # (a fixed number of steps, not a time: with the exchange every rank must run the same collectives)
+    for _ in range(args.prewarm_steps):
+        step()
+    torch.cuda.synchronize()
     for w_i in range(max(args.warmup, len(streams))):  # (every stream warms its own scratch buffer up)
         with torch.cuda.stream(streams[w_i % len(streams)]):
             step()
@@ -493,6 +506,7 @@ def main():
                 'backend': (dist.get_backend() + ' (RCCL)') if use_dist else None,
                 # independent batches alternate between this many HIP streams (each batch's kernels in order on its own)
                 'streams': n_streams,
+                'prewarm_steps': args.prewarm_steps,  # untimed set-up steps BEFORE the W warm-up steps (clock ramp)
             },
             'recall_at_10': recall_adc,
             # `value` is the reference's own search semantics (plain ADC top-k, the parity quantity); the north-star's
