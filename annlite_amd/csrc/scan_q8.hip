@@ -51,6 +51,9 @@ namespace annlite {
 #ifndef ANNLITE_Q8_WDEPTH
 #define ANNLITE_Q8_WDEPTH 16  // M = 64: landing registers (8-byte entries) of the look-up ring
 #endif
+#ifndef ANNLITE_Q8_ROWQ
+#define ANNLITE_Q8_ROWQ 1  // M = 16: the scanning waves push ROWS (any query passes), the consumer finds the queries (see q8_rows_to_entries)
+#endif
 #ifndef ANNLITE_Q8_BUILD_UNROLL
 #define ANNLITE_Q8_BUILD_UNROLL 2  // codes per thread whose table loads are in flight together in the (re)build (4 / 8: the build no
                                    // faster -- 15 -> 16 us -- and the allocator then spilled into the step loop: +12 %)
@@ -266,7 +269,7 @@ constexpr int kPopPerRing = 8;    // entries the consumer takes from one wave's 
 //   list     u64 [32][16] the 16 smallest keys of every slot, ascending; gjl u64 [32] the j-th key last published
 //   ring     u64 [16][kWaveRing]; qkey u64 [4][128], qslot u8 [4][128] insertion queues; chg u8 [32]; stamps u64 [4] (debug)
 struct Q8Lds {
-    uint32_t tab, shq, ring_ctl, gkl, step, inv, tb, ctl, clip, tau, c0, c1, list, gjl, ring, qkey, qslot, chg, stamps, seen;
+    uint32_t tab, shq, ring_ctl, gkl, step, inv, tb, ctl, clip, tau, c0, c1, list, gjl, ring, qkey, qslot, chg, stamps, seen, rowq;
     __device__ __forceinline__ explicit Q8Lds(int lut_bytes) {
         tab = lds_base_addr();
         shq = tab + (uint32_t)lut_bytes;
@@ -288,6 +291,7 @@ struct Q8Lds {
         chg = qslot + 4 * 128;
         stamps = chg + 32;
         seen = stamps + 32;  // u32: candidates this workgroup has seen (guard statistics), u32: abort flag of later items
+        rowq = seen + 16;    // u32x4 [64]: the consumer's (pass masks, row ids) of a batch, parked across q8_consume (row queue)
     }
     __device__ __forceinline__ uint32_t arrived() const { return ring_ctl; }
     __device__ __forceinline__ uint32_t blk_ctr() const { return ring_ctl + 4; }
@@ -671,6 +675,85 @@ __device__ __forceinline__ void q8_merge_tile(const ScanArgs &a, int b0, int QT,
     }
 }
 
+// ROW QUEUE (M = 16, ANNLITE_Q8_ROWQ).  A scanning wave's step with a candidate used to enumerate its (lane, query) pairs in
+// scalar code -- ~200 dynamic instructions per hit lane, 0.65 us per such step, during which the wave issues no look-ups:
+// 31 of the 211 us of the step loop at a 1.25M-row shard, where a quarter of the wave-steps have a candidate.  Now it pushes
+// only the ROW ids of its hit lanes (one ballot, lane-parallel stores) and the CONSUMER finds the queries: a popped row's
+// byte sums against all 32 queries are recomputed from the table in LDS -- the scanning waves' own 32 look-ups, for up to
+// 64 rows at once, one per lane -- and filtered with the bounds of NOW (tighter than at push time).  What comes out are the
+// entries (slot << 32 | row) q8_consume has always taken.
+// The row is rotated to the CONSUMER lane's skew (lane l reads sub-space (l + t) mod 16 at byte t: conflict-free look-ups).
+template <bool SKEWED>
+__device__ __forceinline__ void q8_row_pass_mask(const uint8_t *codes, uint32_t rid, bool act, int lane, uint32_t lds0, uint32_t shq_ad,
+                                                 uint32_t &mask) {
+    constexpr int M = 16, CW = 4, NQ = 2, RB = M * 16, KSTRIDE = NQ * RB, DEPTH = ANNLITE_Q8_DEPTH, TOT = NQ * M;
+    typedef const ANNLITE_LDS u32x4 *lds_entry_ptr;
+    uint32_t cc[CW];
+    {
+        const u32x4 v = *(const u32x4 __attribute__((address_space(1))) *)(uintptr_t)(codes + (int64_t)(act ? rid : 0u) * M);
+        cc[0] = v.x, cc[1] = v.y, cc[2] = v.z, cc[3] = v.w;
+    }
+    const int s = lane % M;
+    const int rot = SKEWED ? ((s - (int)(rid % M)) & (M - 1)) : s;  // stored byte j = code of sub-space (j + rid) mod M resp. j
+    bool abit[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) abit[i] = (((rot >> 2) >> i) & 1) != 0;
+    rotate_row<CW>(cc, abit, (uint32_t)(rot & 3));
+    uint32_t addr[M];
+    static_for<0, CW>([&](auto W) {
+        constexpr int w = decltype(W)::value;
+        uint32_t o0, o1, o2, o3;
+        byte_shl4(cc[w], (uint32_t)ilog2_c(KSTRIDE), o0, o1, o2, o3);
+        addr[4 * w + 0] = lds0 + (uint32_t)(((s + 4 * w + 0) % M) * 16) + o0;
+        addr[4 * w + 1] = lds0 + (uint32_t)(((s + 4 * w + 1) % M) * 16) + o1;
+        addr[4 * w + 2] = lds0 + (uint32_t)(((s + 4 * w + 2) % M) * 16) + o2;
+        addr[4 * w + 3] = lds0 + (uint32_t)(((s + 4 * w + 3) % M) * 16) + o3;
+    });
+    u32x4 acc[NQ];
+    u32x4 v[DEPTH];
+    static_for<0, DEPTH>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        v[i] = *(lds_entry_ptr)(uintptr_t)(addr[i % M] + (uint32_t)((i / M) * RB));
+    });
+    static_for<0, TOT>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        asm volatile("" ::: "memory");
+        if constexpr (i % M == 0) acc[i / M] = v[i % DEPTH];
+        else acc[i / M] += v[i % DEPTH];
+        if constexpr (i + DEPTH < TOT) {
+            constexpr int j = i + DEPTH;
+            v[i % DEPTH] = *(lds_entry_ptr)(uintptr_t)(addr[j % M] + (uint32_t)((j / M) * RB));
+        }
+    });
+    // bit q of the mask: query slot q passes -- S <= T of NOW (the scanning waves' filter; slot = 4 * dword + byte)
+    mask = 0u;
+#pragma unroll
+    for (int h = 0; h < NQ; ++h) {
+        const u32x4 t = *(volatile ANNLITE_LDS u32x4 *)(uintptr_t)(shq_ad + 16u * (uint32_t)h);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t sm = acc[h][w];
+            const uint32_t hb = ((t[w] - (sm & 0x7f7f7f7fu)) & ~sm & 0x80808080u) >> 7;  // bit 8 j <- byte j passes
+            // gather the four byte flags into bits 0..3: 0x01010101-spaced bits times 0x00204081 puts them at bits 21..24
+            const uint32_t nib = ((hb * 0x00204081u) >> 21) & 0xfu;
+            mask |= nib << (uint32_t)(16 * h + 4 * w);
+        }
+    }
+    if (!act) mask = 0u;
+}
+
+// Both popped rows of a lane; OUT OF LINE: inlined into the consumer branch its ~110 live registers made the allocator spill
+// three of the scanning branch's loop-invariant LDS bases into the step loop (scripts/check_q8_isa.sh).  Low word: row 0's mask.
+template <bool SKEWED>
+__device__ __attribute__((noinline)) unsigned long long q8_rows_pass_masks(const uint8_t *codes, uint32_t rid0, uint32_t rid1,
+                                                                           uint32_t act_bits, uint32_t lds0, uint32_t shq_ad) {
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    uint32_t m0, m1;
+    q8_row_pass_mask<SKEWED>(codes, rid0, (act_bits & 1u) != 0u, lane, lds0, shq_ad, m0);
+    q8_row_pass_mask<SKEWED>(codes, rid1, (act_bits & 2u) != 0u, lane, lds0, shq_ad, m1);
+    return (unsigned long long)m0 | ((unsigned long long)m1 << 32);
+}
+
 // work item -> (query tile, row slice).  item % 8 == the XCD the block lands on (speed only).  With >= 8 query tiles an
 // XCD owns the tiles congruent to it, for ALL row slices: the fp32 tables the exact sums gather from (16 KB per query,
 // 512 KB per tile) stay in that XCD's 4 MB L2 -- with the slice-per-XCD map of the u16 kernels (item_map) every XCD saw
@@ -727,6 +810,7 @@ template <int M, int NW, bool SKEWED, int NQ, int CB>
 __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const ScanArgs a) {
     constexpr bool WIDE = Q8Cfg<M>::WIDE;
     constexpr bool M8 = Q8Cfg<M>::M8, C16 = CB == 2;
+    constexpr bool ROWQ = ANNLITE_Q8_ROWQ != 0 && M == 16 && NQ == 2 && CB == 1;  // (row queue: see q8_row_pass_mask)
     constexpr int QT = q8_qt<M, NQ>(), CW = M * CB / 4, EB = 16, RB = M * EB, KSTRIDE = NQ * RB;
     static_assert(CB == 1 || (CB == 2 && M8), "uint16 codes: the M = 8 shapes");
     static_assert(NQ == 2 || (NQ == 1 && M8 && C16), "one entry group: the M = 8 / uint16 shape above Ks = 512");
@@ -911,6 +995,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     give_up();
             };
             unsigned long long pend_o = ~0ull, pend_j = ~0ull;  // bounds not yet published to the other workgroups (lane = slot)
+            bool rowq_more = false;  // (row queue) rows of the last pop still have queries to hand to q8_consume: parked in lds.rowq
             unsigned long long t_busy = 0;
             uint32_t n_batches = 0;
             int epoch = 0, epoch_step = a.q8_epoch0;  // the current epoch ends after step `epoch_step` (the last: after step n_steps - 1)
@@ -936,11 +1021,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                         if (lane < NS) ldsv_st<uint32_t>(lds.heads() + 4u * (uint32_t)lane, head_v);
                         continue;
                     }
-                    if (any) {
+                    if (any || (ROWQ && rowq_more)) {
                         const unsigned long long t0 = a.dbg ? __builtin_readcyclecounter() : 0ull;
                         __builtin_amdgcn_s_setprio(3);  // (serial code on a SIMD shared with three or four scanning waves)
                         unsigned long long e[2];
                         bool act[2];
+                        if (!(ROWQ && rowq_more)) {
                         // HEAVY load -- some wave has more than kPopPerRing entries waiting (a block full of near rows; the candidate
                         // generator of the re-rank stage, whose lists take 16 keys per slice) -- is taken 128 at a time whatever
                         // rings it sits in: ring r contributes take_r = min(avail_r, what is left of the 128) entries, slot s (two
@@ -989,6 +1075,31 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                         }
                         n_seen += (uint32_t)(__popcll(__ballot(act[0])) + __popcll(__ballot(act[1])));
                         if (lane < NS) ldsv_st<uint32_t>(lds.heads() + 4u * (uint32_t)lane, head_v);  // the wave may reuse the entries
+                        }
+                        if constexpr (ROWQ) {
+                            // the popped entries are ROWS: which of the 32 queries pass them NOW?  (out of line.)  Then ROUNDS of
+                            // (slot, row) entries, one per popped row and round -- a row passes for one query as a rule: one round.
+                            // Masks and row ids are parked in LDS and every round is one pass of this loop (a loop of rounds around
+                            // the inlined q8_consume cost the scanning branch a loop-invariant register: a scratch reload per step)
+                            const uint32_t park = lds.rowq + 16u * (uint32_t)lane;
+                            if (!rowq_more) {
+                                const uint32_t rid0 = (uint32_t)e[0], rid1 = (uint32_t)e[1];
+                                const unsigned long long pmm = q8_rows_pass_masks<SKEWED>((const uint8_t *)a.codes, rid0, rid1,
+                                                                                          (act[0] ? 1u : 0u) | (act[1] ? 2u : 0u), lds.tab, lds.shq);
+                                ldsv_st<u32x4>(park, (u32x4){(uint32_t)pmm, (uint32_t)(pmm >> 32), rid0, rid1});
+                            }
+                            const u32x4 pk = ldsv<u32x4>(park);
+                            uint32_t pmr[2] = {pk.x, pk.y};
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                act[u] = pmr[u] != 0u;
+                                const uint32_t q = act[u] ? (uint32_t)__builtin_ctz(pmr[u]) : 0u;
+                                pmr[u] &= pmr[u] - 1u;
+                                e[u] = ((unsigned long long)q << 32) | (u ? pk.w : pk.z);
+                            }
+                            ldsv_st<u32x2>(park, (u32x2){pmr[0], pmr[1]});
+                            rowq_more = __ballot((pmr[0] | pmr[1]) != 0u) != 0;
+                        }
                         q8_consume<M, SKEWED, QT, CB>(fc, lds, e, act, lane, n_kept, n_offered, pend_o, pend_j);
                         __builtin_amdgcn_s_setprio(0);
                         ++n_batches;
@@ -1055,8 +1166,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             const uint32_t lds0 = lds.tab;
             uint32_t mbase[(WIDE || M8) ? 1 : M];
             if constexpr (!WIDE && !M8) {
+                // (computed from an opaque copy of s: the compiler hoisted these 16 lane constants above the consumer / scanning
+                // branch, where the consumer's register needs then decided which of them were spilled -- and reloaded in every step)
+                int s_here = s;
+                asm volatile("" : "+v"(s_here));
 #pragma unroll
-                for (int t = 0; t < M; ++t) mbase[t] = lds0 + (uint32_t)(((s + t) % M) * EB);
+                for (int t = 0; t < M; ++t) mbase[t] = lds0 + (uint32_t)(((s_here + t) % M) * EB);
             }
             // M8 (M = 8; uint16 codes, or uint8 ones up to Ks = 256): a code row of the table is 256 bytes = [2 entry groups][8 sub-spaces][16 B], the address of
             // look-up t is (code << 8) | column byte -- ONE v_perm_b32 of the code dword with a lane constant (kx / ky: byte t of
@@ -1351,6 +1466,28 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                         anyv &= 0x80808080u;
                     }
                     unsigned long long rem = __ballot(anyv != 0) & vmask;
+                    if constexpr (ROWQ) {
+                        if (rem && !(a.dbg_skip & 4)) {
+                            // push the ROW ids of the hit lanes (the consumer finds the queries: q8_row_pass_mask) -- one ring
+                            // reservation, lane-parallel stores
+                            ++n_slow;
+                            const uint32_t n = (uint32_t)__popcll(rem);
+                            uint32_t tl = rs & 0xffffu, hd = rs >> 16;
+                            while (((tl + n - hd) & 0xffffu) > (uint32_t)kWaveRing) {  // the consumer is behind
+                                hd = ldsv<uint32_t>(lds.heads() + 4u * (uint32_t)wave) & 0xffffu;
+                                if (((tl + n - hd) & 0xffffu) <= (uint32_t)kWaveRing) break;
+                                __builtin_amdgcn_s_sleep(8);
+                            }
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(rem >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rem, 0u));
+                            if (__builtin_amdgcn_inverse_ballot_w64(rem))  // (the hit lanes: exec <- rem)
+                                ldsv_st<uint32_t>(lds.ring + 8u * ((uint32_t)wave * kWaveRing + ((tl + rank) & (kWaveRing - 1))),
+                                                  row0 + (uint32_t)lane);  // (the low word of the entry; the consumer reads nothing else of it)
+                            tl = (tl + n) & 0xffffu;
+                            if (lane == 0) ldsv_st<uint32_t>(lds.tails() + 4u * (uint32_t)wave, tl);
+                            rs = tl | (hd << 16);
+                            n_push += n;
+                        }
+                    } else
                     if (rem && !(a.dbg_skip & 4)) {
                         ++n_slow;
                         // The step's candidates -- (lane, query) pairs with S <= T -- are few (one or two lanes of a step that has
@@ -1388,6 +1525,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                             rem &= rem - 1ull;
                             const uint32_t rid = row0 + (uint32_t)L;
                             const uint32_t fL = M8 ? ((uint32_t)L >> 4) & 1u : 0u;  // that lane's sums[0..3] are of entry group fL
+                            if constexpr (ANNLITE_Q8_EXP == 5) {  // (timing experiment: ONE entry per hit row, no enumeration -- results wrong)
+                                if (lane == n) {
+                                    e_hi = (uint32_t)L & 31u;
+                                    e_lo = rid;
+                                }
+                                ++n;
+                                continue;
+                            }
                             static_for<0, NF>([&](auto I) {
                                 constexpr int i = decltype(I)::value;
                                 const uint32_t ss = (uint32_t)__builtin_amdgcn_readlane((int)sums[i], L);
@@ -1498,7 +1643,7 @@ using namespace annlite;
 template <int M, int NW, bool SKEWED, int NQ, int CB>
 static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
     constexpr int QT = 32;  // (the control block is laid out for 32 slots whatever the kernel uses)
-    const size_t need = (size_t)(M == 64 ? (a.Ks + 1) * 512 : a.Ks * NQ * M * 16) + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32 + 32 + 16;
+    const size_t need = (size_t)(M == 64 ? (a.Ks + 1) * 512 : a.Ks * NQ * M * 16) + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32 + 32 + 16 + 1024;
     auto fn = adc_scan_q8_kernel<M, NW, SKEWED, NQ, CB>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);

@@ -9,8 +9,9 @@ for sk in Lb1E Lb0E; do
   a=$(grep -n "^_ZN7annlite18adc_scan_q8_kernelILi16ELi16E${sk}Li2ELi1EEEvNS_8ScanArgsE:" /tmp/q8_check.s | cut -d: -f1)
   b=$(grep -n "amdhsa_kernel _ZN7annlite18adc_scan_q8_kernelILi16ELi16E${sk}Li2ELi1E" /tmp/q8_check.s | cut -d: -f1)
   sed -n "${a},${b}p" /tmp/q8_check.s > /tmp/q8_check_k.s
-  lo=$(grep -n "ds_read_b128 .* offset:256" /tmp/q8_check_k.s | head -1 | cut -d: -f1)
-  hi=$(grep -n "ds_read_b128 .* offset:256" /tmp/q8_check_k.s | tail -1 | cut -d: -f1)
+  # (the step loop's look-ups are the FIRST 16 of these in the kernel; the consumer's row queue has its own, out of line)
+  lo=$(grep -n "ds_read_b128 .* offset:256" /tmp/q8_check_k.s | sed -n 1p | cut -d: -f1)
+  hi=$(grep -n "ds_read_b128 .* offset:256" /tmp/q8_check_k.s | sed -n 16p | cut -d: -f1)
   lo=$((lo - 160)); hi=$((hi + 90))
   n_s=$(sed -n "${lo},${hi}p" /tmp/q8_check_k.s | grep -c "scratch_" || true)
   n_f=$(grep -c "flat_" /tmp/q8_check_k.s || true)
