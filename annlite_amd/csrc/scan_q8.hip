@@ -51,6 +51,9 @@ namespace annlite {
 #ifndef ANNLITE_Q8_WDEPTH
 #define ANNLITE_Q8_WDEPTH 16  // M = 64: landing registers (8-byte entries) of the look-up ring
 #endif
+#ifndef ANNLITE_Q8_THW_MASK
+#define ANNLITE_Q8_THW_MASK 1  // the scanning waves pick up the workgroup's bounds every (mask + 1)-th step
+#endif
 #ifndef ANNLITE_Q8_ROWQ
 #define ANNLITE_Q8_ROWQ 1  // M = 16: the scanning waves push ROWS (any query passes), the consumer finds the queries (see q8_rows_to_entries)
 #endif
@@ -291,7 +294,7 @@ struct Q8Lds {
         chg = qslot + 4 * 128;
         stamps = chg + 32;
         seen = stamps + 32;  // u32: candidates this workgroup has seen (guard statistics), u32: abort flag of later items
-        rowq = seen + 16;    // u32x4 [64]: the consumer's (pass masks, row ids) of a batch, parked across q8_consume (row queue)
+        rowq = seen + 16;    // [64 lanes][48 B]: the consumer's (pass masks, row ids) u32x4 + the two popped rows' 16 code bytes (row queue)
     }
     __device__ __forceinline__ uint32_t arrived() const { return ring_ctl; }
     __device__ __forceinline__ uint32_t blk_ctr() const { return ring_ctl + 4; }
@@ -376,7 +379,7 @@ __device__ __forceinline__ void q8_publish_global(const FlushCtx &c, const Q8Lds
     pend_j = ~0ull;
 }
 
-template <int M, bool SKEWED, int QT, int CB>
+template <int M, bool SKEWED, int QT, int CB, bool ROWS_IN_LDS = false>
 __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, const unsigned long long (&e)[2], bool (&act)[2],
                                            int lane, uint32_t &n_kept, uint32_t &n_offered, unsigned long long &pend_o,
                                            unsigned long long &pend_j) {
@@ -432,9 +435,14 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
         uint32_t cp[2][CW];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const uint32_t *p = (const uint32_t *)(c.codes + (int64_t)(act[u] ? (uint32_t)e[u] : 0u) * (CW * 4));
+            if constexpr (ROWS_IN_LDS) {  // (row queue: the stage that found the queries parked the rows' stored bytes -- lane, u)
+                const u32x4 v = ldsv<u32x4>(o.rowq + 48u * (uint32_t)lane + 16u + 16u * (uint32_t)u);
+                cp[u][0] = v.x, cp[u][1] = v.y, cp[u][2] = v.z, cp[u][3] = v.w;
+            } else {
+                const uint32_t *p = (const uint32_t *)(c.codes + (int64_t)(act[u] ? (uint32_t)e[u] : 0u) * (CW * 4));
 #pragma unroll
-            for (int i = 0; i < CW; ++i) cp[u][i] = p[i];
+                for (int i = 0; i < CW; ++i) cp[u][i] = p[i];
+            }
         }
         float vals[2][M];
 #pragma unroll
@@ -685,13 +693,14 @@ __device__ __forceinline__ void q8_merge_tile(const ScanArgs &a, int b0, int QT,
 // The row is rotated to the CONSUMER lane's skew (lane l reads sub-space (l + t) mod 16 at byte t: conflict-free look-ups).
 template <bool SKEWED>
 __device__ __forceinline__ void q8_row_pass_mask(const uint8_t *codes, uint32_t rid, bool act, int lane, uint32_t lds0, uint32_t shq_ad,
-                                                 uint32_t &mask) {
+                                                 uint32_t row_park, uint32_t &mask) {
     constexpr int M = 16, CW = 4, NQ = 2, RB = M * 16, KSTRIDE = NQ * RB, DEPTH = ANNLITE_Q8_DEPTH, TOT = NQ * M;
     typedef const ANNLITE_LDS u32x4 *lds_entry_ptr;
     uint32_t cc[CW];
     {
         const u32x4 v = *(const u32x4 __attribute__((address_space(1))) *)(uintptr_t)(codes + (int64_t)(act ? rid : 0u) * M);
         cc[0] = v.x, cc[1] = v.y, cc[2] = v.z, cc[3] = v.w;
+        ldsv_st<u32x4>(row_park, v);  // (the stored form: q8_consume's exact sums take it from here instead of a second global round trip)
     }
     const int s = lane % M;
     const int rot = SKEWED ? ((s - (int)(rid % M)) & (M - 1)) : s;  // stored byte j = code of sub-space (j + rid) mod M resp. j
@@ -746,11 +755,13 @@ __device__ __forceinline__ void q8_row_pass_mask(const uint8_t *codes, uint32_t 
 // three of the scanning branch's loop-invariant LDS bases into the step loop (scripts/check_q8_isa.sh).  Low word: row 0's mask.
 template <bool SKEWED>
 __device__ __attribute__((noinline)) unsigned long long q8_rows_pass_masks(const uint8_t *codes, uint32_t rid0, uint32_t rid1,
-                                                                           uint32_t act_bits, uint32_t lds0, uint32_t shq_ad) {
+                                                                           uint32_t act_bits, uint32_t lds0, uint32_t shq_ad,
+                                                                           uint32_t rowq_ad) {
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t park = rowq_ad + 48u * (uint32_t)lane;
     uint32_t m0, m1;
-    q8_row_pass_mask<SKEWED>(codes, rid0, (act_bits & 1u) != 0u, lane, lds0, shq_ad, m0);
-    q8_row_pass_mask<SKEWED>(codes, rid1, (act_bits & 2u) != 0u, lane, lds0, shq_ad, m1);
+    q8_row_pass_mask<SKEWED>(codes, rid0, (act_bits & 1u) != 0u, lane, lds0, shq_ad, park + 16u, m0);
+    q8_row_pass_mask<SKEWED>(codes, rid1, (act_bits & 2u) != 0u, lane, lds0, shq_ad, park + 32u, m1);
     return (unsigned long long)m0 | ((unsigned long long)m1 << 32);
 }
 
@@ -1081,11 +1092,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                             // (slot, row) entries, one per popped row and round -- a row passes for one query as a rule: one round.
                             // Masks and row ids are parked in LDS and every round is one pass of this loop (a loop of rounds around
                             // the inlined q8_consume cost the scanning branch a loop-invariant register: a scratch reload per step)
-                            const uint32_t park = lds.rowq + 16u * (uint32_t)lane;
+                            const uint32_t park = lds.rowq + 48u * (uint32_t)lane;
                             if (!rowq_more) {
                                 const uint32_t rid0 = (uint32_t)e[0], rid1 = (uint32_t)e[1];
                                 const unsigned long long pmm = q8_rows_pass_masks<SKEWED>((const uint8_t *)a.codes, rid0, rid1,
-                                                                                          (act[0] ? 1u : 0u) | (act[1] ? 2u : 0u), lds.tab, lds.shq);
+                                                                                          (act[0] ? 1u : 0u) | (act[1] ? 2u : 0u), lds.tab, lds.shq, lds.rowq);
                                 ldsv_st<u32x4>(park, (u32x4){(uint32_t)pmm, (uint32_t)(pmm >> 32), rid0, rid1});
                             }
                             const u32x4 pk = ldsv<u32x4>(park);
@@ -1100,7 +1111,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                             ldsv_st<u32x2>(park, (u32x2){pmr[0], pmr[1]});
                             rowq_more = __ballot((pmr[0] | pmr[1]) != 0u) != 0;
                         }
-                        q8_consume<M, SKEWED, QT, CB>(fc, lds, e, act, lane, n_kept, n_offered, pend_o, pend_j);
+                        q8_consume<M, SKEWED, QT, CB, ROWQ>(fc, lds, e, act, lane, n_kept, n_offered, pend_o, pend_j);
                         __builtin_amdgcn_s_setprio(0);
                         ++n_batches;
                         if (a.dbg) t_busy += __builtin_readcyclecounter() - t0;
@@ -1561,7 +1572,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                         }
                     }
                     // pick up the workgroup's bounds every 2nd step
-                    if (it_no & 1) {
+                    if ((it_no & ANNLITE_Q8_THW_MASK) == ANNLITE_Q8_THW_MASK) {
                         asm volatile("" ::: "memory");
                         load_thw(thw);
                     }
@@ -1643,7 +1654,7 @@ using namespace annlite;
 template <int M, int NW, bool SKEWED, int NQ, int CB>
 static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
     constexpr int QT = 32;  // (the control block is laid out for 32 slots whatever the kernel uses)
-    const size_t need = (size_t)(M == 64 ? (a.Ks + 1) * 512 : a.Ks * NQ * M * 16) + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32 + 32 + 16 + 1024;
+    const size_t need = (size_t)(M == 64 ? (a.Ks + 1) * 512 : a.Ks * NQ * M * 16) + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32 + 32 + 16 + 3072;
     auto fn = adc_scan_q8_kernel<M, NW, SKEWED, NQ, CB>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
