@@ -817,11 +817,12 @@ __device__ __attribute__((noinline)) void q8_finish_item(q8_kernarg_ptr ka, int 
     }
 }
 
-template <int M, int NW, bool SKEWED, int NQ, int CB>
+template <int M, int NW, bool SKEWED, int NQ, int CB, bool RQ>
 __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const ScanArgs a) {
     constexpr bool WIDE = Q8Cfg<M>::WIDE;
     constexpr bool M8 = Q8Cfg<M>::M8, C16 = CB == 2;
-    constexpr bool ROWQ = ANNLITE_Q8_ROWQ != 0 && M == 16 && NQ == 2 && CB == 1;  // (row queue: see q8_row_pass_mask)
+    constexpr bool ROWQ = RQ && ANNLITE_Q8_ROWQ != 0;  // (row queue: see q8_row_pass_mask)
+    static_assert(!RQ || (M == 16 && NQ == 2 && CB == 1), "the row queue is the M = 16 kernel's");
     constexpr int QT = q8_qt<M, NQ>(), CW = M * CB / 4, EB = 16, RB = M * EB, KSTRIDE = NQ * RB;
     static_assert(CB == 1 || (CB == 2 && M8), "uint16 codes: the M = 8 shapes");
     static_assert(NQ == 2 || (NQ == 1 && M8 && C16), "one entry group: the M = 8 / uint16 shape above Ks = 512");
@@ -1651,11 +1652,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
 
 using namespace annlite;
 
-template <int M, int NW, bool SKEWED, int NQ, int CB>
+template <int M, int NW, bool SKEWED, int NQ, int CB, bool RQ = false>
 static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
     constexpr int QT = 32;  // (the control block is laid out for 32 slots whatever the kernel uses)
     const size_t need = (size_t)(M == 64 ? (a.Ks + 1) * 512 : a.Ks * NQ * M * 16) + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32 + 32 + 16 + 3072;
-    auto fn = adc_scan_q8_kernel<M, NW, SKEWED, NQ, CB>;
+    auto fn = adc_scan_q8_kernel<M, NW, SKEWED, NQ, CB, RQ>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
     return launch_status("adc_scan_q8_kernel");
@@ -1663,7 +1664,12 @@ static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
 
 int annlite::launch_q8_scan(int id, bool sk, const ScanArgs &a, int grid, hipStream_t st) {
     switch (id) {
-        case 1650: return sk ? launch_q8<16, 16, true, 2, 1>(a, grid, st) : launch_q8<16, 16, false, 2, 1>(a, grid, st);
+        case 1650:
+            // shared bounds (the plain search): the row queue.  Unshared slices (the candidate generator of the re-rank stage: every
+            // slice keeps 16 keys, the consumer is the bottleneck) keep the enumeration in the scanning waves -- with the row queue the
+            // re-rank leg ran at 513 k q/s instead of 554 k
+            if (a.gkey) return sk ? launch_q8<16, 16, true, 2, 1, true>(a, grid, st) : launch_q8<16, 16, false, 2, 1, true>(a, grid, st);
+            return sk ? launch_q8<16, 16, true, 2, 1>(a, grid, st) : launch_q8<16, 16, false, 2, 1>(a, grid, st);
         case 6450: return sk ? launch_q8<64, 16, true, 2, 1>(a, grid, st) : launch_q8<64, 16, false, 2, 1>(a, grid, st);
         case 850:  // M = 8, uint16 codes (PLAIN rows): two entry groups (Ks <= 512)
         case 851:  // ... one (Ks <= 1024)

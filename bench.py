@@ -512,7 +512,7 @@ def main():
             # `value` is the reference's own search semantics (plain ADC top-k, the parity quantity); the north-star's
             # ">= 90 % recall@10" figure is the re-rank leg below
             'rerank': None if recall_rr is None else {'recall_at_10': recall_rr, 'value': rr_qps, 'unit': 'queries/s',
-                                                       'candidates_per_query': 'n_slices*64 per shard',
+                                                       'candidates_per_query': 'n_slices * rerank_k per shard (rerank_k = %d: the byte-table kernel\'s 16-key lists)' % (args.rerank_k or 16),
                                                        'answers': 'north_star recall target (>= 0.90 recall@10)'},
             'roofline': roof,
             'cpu_baseline': cpu,
