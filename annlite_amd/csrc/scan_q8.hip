@@ -1430,8 +1430,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 for (; b_cur < end_blk; ++it_no) {
                     const uint32_t row0 = s_begin + b_cur * 64u;  // (< s_end: b_cur < n_blocks)
                     pend = draw();
-                    uint32_t rot1[C16 ? CW : 1];  // (uint16 codes: first rotation stage straight from the landing registers -- no copy)
-                    if constexpr (C16) {
+                    // PLAIN 16-byte rows (M = 16 / uint8, M = 8 / uint16): first rotation stage straight from the landing registers -- no copy
+                    constexpr bool ROT4 = !SKEWED && !WIDE && CW == 4;
+                    uint32_t rot1[ROT4 ? CW : 1];
+                    if constexpr (ROT4) {
 #pragma unroll
                         for (int i = 0; i < CW; ++i)
                             asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(rot1[i]) : "v"(cnext[i]), "v"(cnext[(i + 1) % CW]), "s"(rmask0));
@@ -1447,7 +1449,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     }
                     if constexpr (!SKEWED) {
                         if constexpr (WIDE) skew64_encode(ccur, lane & 31);  // PLAIN row -> this lane's wrap-coded SKEWED row
-                        else if constexpr (C16) {
+                        else if constexpr (ROT4) {
                             // rotate_row with the two stage conditions as LANE MASKS in SGPR pairs (as `bool`s the allocator kept
                             // them as 0/1 VGPRs and re-compared before every select: 14 v_cmp + 15 s_nop per step)
                             uint32_t n[CW];
