@@ -51,6 +51,9 @@ namespace annlite {
 #ifndef ANNLITE_Q8_WDEPTH
 #define ANNLITE_Q8_WDEPTH 16  // M = 64: landing registers (8-byte entries) of the look-up ring
 #endif
+#ifndef ANNLITE_Q8_STAGE_DEPTH
+#define ANNLITE_Q8_STAGE_DEPTH 8  // look-ups in flight per lane and row in the consumer's row-queue stage (out of line: own registers; 16: no change)
+#endif
 #ifndef ANNLITE_Q8_THW_MASK
 #define ANNLITE_Q8_THW_MASK 1  // the scanning waves pick up the workgroup's bounds every (mask + 1)-th step
 #endif
@@ -694,7 +697,7 @@ __device__ __forceinline__ void q8_merge_tile(const ScanArgs &a, int b0, int QT,
 template <bool SKEWED>
 __device__ __forceinline__ void q8_row_pass_mask(const uint8_t *codes, uint32_t rid, bool act, int lane, uint32_t lds0, uint32_t shq_ad,
                                                  uint32_t row_park, uint32_t &mask) {
-    constexpr int M = 16, CW = 4, NQ = 2, RB = M * 16, KSTRIDE = NQ * RB, DEPTH = ANNLITE_Q8_DEPTH, TOT = NQ * M;
+    constexpr int M = 16, CW = 4, NQ = 2, RB = M * 16, KSTRIDE = NQ * RB, DEPTH = ANNLITE_Q8_STAGE_DEPTH, TOT = NQ * M;
     typedef const ANNLITE_LDS u32x4 *lds_entry_ptr;
     uint32_t cc[CW];
     {
