@@ -22,7 +22,8 @@
 // Clipping (min with QMAX) and a T clamped to 127 keep the bound valid for ANY step.
 // The waves DRAW their 64-row blocks from a counter in LDS (the SIMD's arbiter favours its oldest wave and one wave alone
 // issues at a third of the rate four reach together: a static deal left the last waves to run an epoch out alone).
-// Candidates are handled by a CONSUMER wave: NW - 1 waves scan and only push (S, query, row) into a ring in LDS; the last
+// Candidates are handled by a CONSUMER wave: NW - 1 waves scan and only push (S, query, row) -- the M = 16 kernel under shared
+// bounds: just the ROW, the consumer finds the queries (q8_row_pass_mask) -- into a ring in LDS; the last
 // wave of the workgroup pops them in batches of up to 128, drops those whose S no longer passes, computes the exact sums,
 // updates the lists -- it is their only writer: no locks -- and publishes the bounds (to the other workgroups one batch
 // later, behind the next batch's gathers); it imports the sibling slices' bound: the k-th smallest of their j smallest
@@ -274,6 +275,7 @@ constexpr int kPopPerRing = 8;    // entries the consumer takes from one wave's 
 //   tau      u64 [32]  the k-th key the consumer last published; c0, c1 f64 [32]: T = floor(thr * c1 + c0) + 1 (q8_bound)
 //   list     u64 [32][16] the 16 smallest keys of every slot, ascending; gjl u64 [32] the j-th key last published
 //   ring     u64 [16][kWaveRing]; qkey u64 [4][128], qslot u8 [4][128] insertion queues; chg u8 [32]; stamps u64 [4] (debug)
+//   seen     u32 x 2 (guard statistics); rowq [64 lanes][48 B]: the row queue's parked masks / row ids / code bytes
 struct Q8Lds {
     uint32_t tab, shq, ring_ctl, gkl, step, inv, tb, ctl, clip, tau, c0, c1, list, gjl, ring, qkey, qslot, chg, stamps, seen, rowq;
     __device__ __forceinline__ explicit Q8Lds(int lut_bytes) {
