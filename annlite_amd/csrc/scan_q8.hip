@@ -1170,7 +1170,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
         } else {
             // ------------------------------------------------------------------------------- scanning waves
             constexpr int NF = WIDE ? 4 : 4 * NQ;  // filter words per row: 4 dwords of byte sums per entry group (16 queries) / 4 dwords of u16 sums (WIDE: 8)
-            const int s = lane % (WIDE ? 32 : M);
+            // The lane constants of this branch (skew, look-up columns, rotation masks) are computed from OPAQUE copies of the lane
+            // number: the compiler otherwise hoists them above the consumer / scanning branch, where the consumer's register needs
+            // decide which of them are spilled -- and reloaded from scratch in every step (scripts/check_q8_isa_all.sh)
+            int lane_pin = lane;
+            asm volatile("" : "+v"(lane_pin));
+            const int s = lane_pin % (WIDE ? 32 : M);
             const int rot_bytes = CB * s;  // PLAIN rows are rotated in registers: element (s + t) mod M to position t
             const uint32_t bsh = (uint32_t)(rot_bytes & 3);
             bool abit[8];
@@ -1183,12 +1188,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             const uint32_t lds0 = lds.tab;
             uint32_t mbase[(WIDE || M8) ? 1 : M];
             if constexpr (!WIDE && !M8) {
-                // (computed from an opaque copy of s: the compiler hoisted these 16 lane constants above the consumer / scanning
-                // branch, where the consumer's register needs then decided which of them were spilled -- and reloaded in every step)
-                int s_here = s;
-                asm volatile("" : "+v"(s_here));
 #pragma unroll
-                for (int t = 0; t < M; ++t) mbase[t] = lds0 + (uint32_t)(((s_here + t) % M) * EB);
+                for (int t = 0; t < M; ++t) mbase[t] = lds0 + (uint32_t)(((s + t) % M) * EB);
             }
             // M8 (M = 8; uint16 codes, or uint8 ones up to Ks = 256): a code row of the table is 256 bytes = [2 entry groups][8 sub-spaces][16 B], the address of
             // look-up t is (code << 8) | column byte -- ONE v_perm_b32 of the code dword with a lane constant (kx / ky: byte t of
@@ -1197,7 +1198,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             // l and l ^ 24 resp. l ^ 8 ... : they differ in lane bit 4): the lanes with bit 4 set read the entry groups in the
             // OTHER order -- 16 distinct slots per lane group, conflict-free.  Their sums[0..3] then belong to queries 16..31:
             // they load the filter words swapped (load_thw) and the candidate path un-swaps the slot.
-            const uint32_t f16 = (M8 && NQ == 2) ? ((uint32_t)lane >> 4) & 1u : 0u;
+            const uint32_t f16 = (M8 && NQ == 2) ? ((uint32_t)lane_pin >> 4) & 1u : 0u;
             uint32_t kx[2] = {0u, 0u}, ky[2] = {0u, 0u};
             if constexpr (M8) {
 #pragma unroll
@@ -1218,7 +1219,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             }
             // WIDE: lane constant of the look-up addresses (the M = 64 u16 kernel's scheme): byte 0 = (lane % 32) * 8 (the column),
             // byte 2 = 0x01 (second half table); the table starts at LDS address 0 (all LDS is dynamic)
-            const uint32_t lane_k = 0x00010000u | (uint32_t)((lane & 31) * 8);
+            const uint32_t lane_k = 0x00010000u | (uint32_t)((lane_pin & 31) * 8);
             if constexpr (WIDE) {
                 if (lds0 != 0u || a.Ks != 256) __builtin_trap();
             }
