@@ -1,0 +1,50 @@
+"""The byte-table kernel's step loop sits at the 128-VGPR limit; a spill there is a scratch reload in EVERY step, each one also
+waiting for the prefetched code row (it happened three times this round, every time as a
+5-12 % slow-down with all tests green).  This test disassembles scan_q8.hip (hipcc cross-compiles gfx950 without a GPU) and
+fails when a scratch or flat operation shows up in the step loop of a default instantiation.  scripts/check_q8_isa_all.sh is the
+same check by hand."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'annlite_amd', 'csrc')
+HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
+def test_no_scratch_in_the_step_loops():
+    with tempfile.TemporaryDirectory() as tmp:
+        asm = os.path.join(tmp, 'scan_q8.s')
+        cmd = [HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-mllvm',
+               '-amdgpu-atomic-optimizer-strategy=None', '-S', '--cuda-device-only', 'scan_q8.hip', '-o', asm]
+        subprocess.run(cmd, cwd=CSRC, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+        lines = open(asm).read().splitlines()
+    starts = [(i, m.group(1)) for i, ln in enumerate(lines)
+              for m in [re.match(r'^(_ZN7annlite18adc_scan_q8_kernel\w+):', ln)] if m]
+    assert len(starts) >= 8, 'the instantiations of adc_scan_q8_kernel were not found in the assembly'
+    checked = 0
+    for i0, sym in starts:
+        i1 = next(j for j in range(i0, len(lines)) if lines[j].lstrip().startswith('.amdhsa_kernel ' + sym))
+        body = lines[i0:i1]
+        reads = [j for j, ln in enumerate(body) if re.search(r'\bds_read_b(128|64)\b', ln)]
+        # the step loop = the densest 100-line window of LDS look-ups
+        best = max(set(j // 100 for j in reads), key=lambda c: sum(1 for j in reads if j // 100 == c))
+        lo, hi = max(0, best * 100 - 150), best * 100 + 250
+        window = body[lo:hi]
+        n_scratch = sum('scratch_' in ln for ln in window)
+        n_flat = sum(re.search(r'\bflat_', ln) is not None for ln in body)
+        shape = sym.replace('_ZN7annlite18adc_scan_q8_kernelI', '').replace('EEvNS_8ScanArgsE', '')
+        assert n_flat == 0, (shape, 'flat instructions: an LDS access lost its address space')
+        # the defaults: SKEWED rows (Lb1E after the wave count) for uint8 codes, PLAIN for the uint16 shapes; PLAIN M = 64 rotates
+        # 64-byte rows in registers and is allowed its one reload
+        if shape.startswith('Li64ELi16ELb0E'):
+            assert n_scratch <= 4, (shape, n_scratch)
+        else:
+            assert n_scratch == 0, (shape, n_scratch, 'scratch operations in the step loop')
+        checked += 1
+    assert checked == len(starts)
