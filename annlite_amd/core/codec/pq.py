@@ -74,19 +74,21 @@ class PQCodec(BaseCodec):
         self.n_init = n_init
         self.seed: Optional[int] = None  # set for reproducible training (the reference is unseeded)
 
-        self._cb_dev: Optional[torch.Tensor] = None  # device copy of the codebooks
+        self._cb_dev: dict = {}  # device copies of the codebooks, one per HIP device that asked (a multi-GPU index shares ONE codec)
         self._pf = None  # streaming k-means state of partial_fit: (centers, sums, counts) device tensors
 
     # ------------------------------------------------------------------ pickling / device cache
     def __getstate__(self):
         st = self.__dict__.copy()
-        st['_cb_dev'] = None
+        st['_cb_dev'] = {}
         if self._pf is not None:
             st['_pf'] = tuple(t.cpu().numpy() for t in self._pf)
         return st
 
     def __setstate__(self, st):
         self.__dict__.update(st)
+        if not isinstance(self.__dict__.get('_cb_dev'), dict):  # (files written before the per-device cache)
+            self._cb_dev = {}
         if self._pf is not None and isinstance(self._pf[0], np.ndarray):
             self._pf_np = self._pf
             self._pf = None
@@ -102,20 +104,22 @@ class PQCodec(BaseCodec):
     def codebooks_dev(self) -> torch.Tensor:
         """f32 [M, Ks, dsub] on the current HIP device (cached)."""
         dev = ops.device()
-        if self._cb_dev is None or self._cb_dev.device != dev:
-            self._cb_dev = ops.to_dev(np.ascontiguousarray(self._codebooks, dtype=np.float32))
-        return self._cb_dev
+        cb = self._cb_dev.get(dev)
+        if cb is None:
+            cb = self._cb_dev[dev] = ops.to_dev(np.ascontiguousarray(self._codebooks, dtype=np.float32))
+        return cb
 
     def _set_codebooks(self, cb_dev: torch.Tensor):
-        self._cb_dev = cb_dev.contiguous()
-        self._codebooks = self._cb_dev.cpu().numpy()
+        cb_dev = cb_dev.contiguous()
+        self._cb_dev = {cb_dev.device: cb_dev}
+        self._codebooks = cb_dev.cpu().numpy()
 
     def set_codebooks(self, codebooks) -> 'PQCodec':
         """Install externally trained codebooks [M, Ks, dsub] (numpy or torch) and mark trained."""
         cb = codebooks if isinstance(codebooks, np.ndarray) else codebooks.detach().cpu().numpy()
         assert cb.shape == (self.n_subvectors, self.n_clusters, self.d_subvector)
         self._codebooks = np.ascontiguousarray(cb, dtype=np.float32)
-        self._cb_dev = None
+        self._cb_dev = {}
         self._is_trained = True
         return self
 

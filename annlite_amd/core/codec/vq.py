@@ -31,7 +31,7 @@ class VQCodec(BaseCodec):
         self.n_init = int(n_init)
         self.seed: Optional[int] = None
         self._codebook: Optional[np.ndarray] = None
-        self._cb_dev = None
+        self._cb_dev = {}
         self._sums = None  # partial_fit accumulators (device)
         self._counts = None
         self._pf_cb = None
@@ -41,7 +41,7 @@ class VQCodec(BaseCodec):
 
     def __getstate__(self):
         st = self.__dict__.copy()
-        st['_cb_dev'] = None
+        st['_cb_dev'] = {}
         for key in ('_sums', '_counts', '_pf_cb'):
             if st.get(key) is not None:
                 st[key] = st[key].cpu().numpy()
@@ -49,6 +49,8 @@ class VQCodec(BaseCodec):
 
     def __setstate__(self, st):
         self.__dict__.update(st)
+        if not isinstance(self.__dict__.get('_cb_dev'), dict):  # (files written before the per-device cache)
+            self._cb_dev = {}
         for key in ('_sums', '_counts', '_pf_cb'):
             if isinstance(getattr(self, key, None), np.ndarray):
                 setattr(self, key, None)  # streaming state does not survive a reload (codebook does)
@@ -63,13 +65,14 @@ class VQCodec(BaseCodec):
     def codebook_dev(self) -> torch.Tensor:
         self._check_trained()
         dev = ops.device()
-        if self._cb_dev is None or self._cb_dev.device != dev:
-            self._cb_dev = ops.to_dev(np.ascontiguousarray(self._codebook, dtype=np.float32))
-        return self._cb_dev
+        cb = self._cb_dev.get(dev)
+        if cb is None:
+            cb = self._cb_dev[dev] = ops.to_dev(np.ascontiguousarray(self._codebook, dtype=np.float32))
+        return cb
 
     def _set_codebook(self, cb: torch.Tensor):
         self._codebook = cb.detach().cpu().numpy().astype(np.float32)
-        self._cb_dev = None
+        self._cb_dev = {}
         self._is_trained = True
 
     # ------------------------------------------------------------------ training

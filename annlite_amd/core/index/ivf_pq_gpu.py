@@ -36,7 +36,8 @@ from .pq_flat_gpu import PQFlatGpuIndex
 
 
 class IvfPQGpuIndex(PQFlatGpuIndex):
-    R_CAP = 4096  # rows a query re-ranks at most (float re-rank of a pruned search)
+    R_CAP = 4096  # rows a query re-ranks at most (float re-rank of a pruned search); grows with k * n_probe: see _search_pruned
+    rerank_truncated = 0  # queries (so far) whose candidate set exceeded the cap and lost the later cells' lists
     def __init__(self, dim: int, pq_codec: Optional[PQCodec] = None, vq_codec: Optional[VQCodec] = None,
                  n_probe: Optional[int] = None, **kwargs):
         super().__init__(dim, pq_codec=pq_codec, **kwargs)
@@ -199,8 +200,19 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
         # ONE host round trip per batch: the widest candidate row and whether any list overflowed.  R is bounded: a query
         # re-ranks at most R_CAP rows (default 4096 = 8 x the ~540 a 16-cell probe emits at k = 10; beyond it the lists of
         # the later cells are cut, never the exact ADC top-k of the affected rows below)
-        stats = torch.stack([per_query.max(), over_rows.any().to(torch.int64)]).cpu()
-        R = max(min(int(stats[0]), self.R_CAP), k)
+        # (the cap follows the work asked for -- 8 x the ~3.4 k rows a list emits, per probed cell -- so that a wide probe with a
+        # large k is not cut silently; what IS cut is counted in `rerank_truncated` and logged once)
+        cap = max(self.R_CAP, 32 * k * P)
+        stats = torch.stack([per_query.max(), over_rows.any().to(torch.int64), (per_query > cap).sum()]).cpu()
+        R = max(min(int(stats[0]), cap), k)
+        if int(stats[2]):
+            if not self.rerank_truncated:
+                import logging
+
+                logging.getLogger('annlite_amd').warning(
+                    'pruned re-rank: %d queries emitted more than %d candidate rows (k=%d, n_probe=%d); the later cells\' lists were cut',
+                    int(stats[2]), cap, k, P)
+            self.rerank_truncated += int(stats[2])
         ids = ops.ivf_candidate_ids(cand, count, slot_of, R, self._row_ids)  # (an overflowed list contributes nothing)
         if bool(stats[1]):
             # a list that overflowed (many ties / a loose bound): THOSE QUERIES take their candidates from the exact path
@@ -215,10 +227,14 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
                 ids = torch.cat([ids, torch.full((ids.shape[0], kx + 1 - R), -1, dtype=ids.dtype, device=ids.device)], dim=1)
             # the exact ids go in front; what the lists emitted follows (duplicates are harmless for a top-k by position:
             # equal distances, the first position wins; they are dropped below)
-            merged = torch.cat([ids_x, ids], dim=1)
-            dup = (merged[:, kx:, None] == ids_x[:, None, :]).any(dim=2)
-            merged[:, kx:] = torch.where(dup, torch.full_like(merged[:, kx:], -1), merged[:, kx:])
-            ids = torch.where(over_rows[:, None], merged, torch.cat([ids, torch.full_like(ids_x, -1)], dim=1))
+            # (only the overflowed queries' rows are merged: a B x R x k comparison over the whole batch was 268 MB at
+            # 1024 x 4096 x 64)
+            sel = torch.nonzero(over_rows).flatten()
+            tail = ids[sel]
+            dup = (tail[:, :, None] == ids_x[sel][:, None, :]).any(dim=2)
+            tail = torch.where(dup, torch.full_like(tail, -1), tail)
+            ids = torch.cat([ids, torch.full_like(ids_x, -1)], dim=1)
+            ids[sel] = torch.cat([ids_x[sel], tail], dim=1)
         exact = ops.exact_gather_dist(int(self.metric), q, self._vectors, ids)
         d, pos = self._topk_rows_any(exact, min(k_out, ids.shape[1]))  # (k_out > 64: a stable device sort, never cut silently)
         i = torch.gather(ids, 1, pos.clamp(min=0))

@@ -40,6 +40,25 @@ class _OnDevice:
             self._ctx.__exit__(*a)
 
 
+def merge_lists_sorted(d: torch.Tensor, i: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """G lists ``[G, B, kk]`` of (distance, global id; -1 = padding) -> the k smallest per query under the (distance, id)
+    order, padding last: a stable sort by id followed by a stable sort by distance.  Any k -- the merge of ``limit > 64``
+    searches, which the wave-list kernel (``annlite_topk_merge``, k <= 64) does not take; device or host tensors."""
+    G, B, kk = d.shape
+    dd = d.permute(1, 0, 2).reshape(B, G * kk)
+    ii = i.permute(1, 0, 2).reshape(B, G * kk)
+    by_id = torch.argsort(torch.where(ii < 0, torch.full_like(ii, torch.iinfo(torch.int64).max), ii), dim=1, stable=True)
+    dd, ii = torch.gather(dd, 1, by_id), torch.gather(ii, 1, by_id)
+    dd = torch.where(ii < 0, torch.full_like(dd, float('inf')), dd)
+    # (+inf of a real row and of the padding tie: the padding was sorted behind every real id, the stable sort keeps it there)
+    by_d = torch.argsort(dd, dim=1, stable=True)[:, :k]
+    od, oi = torch.gather(dd, 1, by_d), torch.gather(ii, 1, by_d)
+    if od.shape[1] < k:
+        od = torch.cat([od, torch.full((B, k - od.shape[1]), float('inf'), dtype=od.dtype, device=od.device)], dim=1)
+        oi = torch.cat([oi, torch.full((B, k - oi.shape[1]), -1, dtype=oi.dtype, device=oi.device)], dim=1)
+    return od, oi
+
+
 class MultiGpuPQIndex(BaseIndex):
     def __init__(self, dim: int, pq_codec=None, metric: Metric = Metric.COSINE, devices: Sequence[int] = (0,), block: int = 65536,
                  shard_factory: Optional[Callable] = None, merge_packed: Optional[Callable] = None, **kwargs):
@@ -174,6 +193,8 @@ class MultiGpuPQIndex(BaseIndex):
                     from ...sharded import numpy_merge
 
                     od, oi = numpy_merge(d, i)
+                elif k > 64:  # (beyond the merge kernel's wave lists: every shard answered through its batched large-k path)
+                    od, oi = merge_lists_sorted(d, i, k)
                 else:
                     from ... import ops
 

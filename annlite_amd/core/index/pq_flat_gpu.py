@@ -321,20 +321,24 @@ class PQFlatGpuIndex(BaseIndex):
         chunk = max(1, min(B, (1 << 26) // max(N, 1)))  # <= 64M keys (512 MB) + their f32 sums per chunk
         rows = torch.arange(N, device=dev, dtype=torch.int64)
         inf = torch.tensor(float('inf'), device=dev)
+        nan = torch.tensor(float('nan'), device=dev)
+        key_none = torch.tensor(torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
         ds, is_ = [], []
         for b0 in range(0, B, chunk):
             nb = min(chunk, B - b0)
             dist = torch.empty((nb, N), dtype=torch.float32, device=dev)
             for j in range(nb):
                 ops.adc_dist(lut[b0 + j], codes, out=dist[j])
-            dist = torch.where(vb[None, :], dist + 0.0, inf)  # (-0.0 -> +0.0: equal VALUES tie-break by id)
+            dist = dist + 0.0  # (-0.0 -> +0.0: equal VALUES tie-break by id)
+            dist = torch.where(torch.isnan(dist), nan, dist)  # one NaN, sign bit clear: it sorts behind +inf (numpy's order)
             bits = dist.view(torch.int32)
             bits = bits ^ ((bits >> 31) & 0x7FFFFFFF)  # signed-comparable image of the float order
             keys = (bits.to(torch.int64) << 32) | rows[None, :]
+            keys = torch.where(vb[None, :], keys, key_none)  # deleted / never-written rows: behind every real row, NaN ones included
             top = torch.topk(keys, kk, dim=1, largest=False, sorted=True).values
             si = top & 0xFFFFFFFF
-            sd = torch.gather(dist, 1, si)
-            si = torch.where(torch.isinf(sd) & ~vb[si], torch.full_like(si, -1), si)
+            sd = torch.where(top == key_none, inf, torch.gather(dist, 1, si))
+            si = torch.where(top == key_none, torch.full_like(si, -1), si)
             ds.append(sd)
             is_.append(si)
         d, i = torch.cat(ds), torch.cat(is_)
@@ -360,9 +364,20 @@ class PQFlatGpuIndex(BaseIndex):
         # candidates per row slice: 16 where the byte-table kernel generates them (M = 16: 8 slices x 16 keys = 128 per query
         # at 1024 queries; its lists hold 16 keys), 64 otherwise (u16-table kernels)
         byte_tables = self.M == 16 and self.code_bytes == 1 and self.Ks <= 256 and self.scan_kernel != 'u16 tables'
-        rk = int(rerank_k or getattr(self, 'rerank_k', None) or (16 if byte_tables else 64))
-        rk = max(1, min(64, rk))
+        asked = rerank_k or getattr(self, 'rerank_k', None)
+        rk = max(1, min(64, int(asked or (16 if byte_tables else 64))))
         plan = scan_plan(N, self.M, self.Ks, self.code_bytes, B, rk)
+        if not asked:
+            # The pool is n_slices * rk rows per query, and a small table or a huge batch plans 1-4 slices: the default must
+            # still hand the re-rank MORE than k candidates (k of k re-ranks nothing, fewer than k returns padding) -- at
+            # least max(64, 4 k) where the table has them.  Beyond the byte-table lists' 16 keys the u16-table generator
+            # (up to 64 keys per slice) takes over: scan_plan picks it from rk.
+            want = max(64, 4 * k)
+            for _ in range(2):  # (the tile width, hence n_slices, can change with the generator)
+                if plan.n_slices * rk >= want or rk >= 64:
+                    break
+                rk = min(64, -(-want // max(plan.n_slices, 1)))
+                plan = scan_plan(N, self.M, self.Ks, self.code_bytes, B, rk)
         from ..._capi import LAYOUT_BMK, LAYOUT_TILED
 
         kind, xq = scan_in if scan_in is not None else self.pq_codec.scan_inputs(q)

@@ -54,7 +54,11 @@ __device__ __forceinline__ float ordered_to_f32(uint32_t k) {
     uint32_t mask = (k & 0x80000000u) ? 0x80000000u : 0xffffffffu;
     return __uint_as_float(k ^ mask);
 }
-constexpr uint32_t kKeyInfHi = 0xffffffffu;  // sorts after every real distance (> key(+inf))
+// ... and for NaN: the reference selects with numpy's order (math.py:107-116: argpartition / argsort), which puts NaN behind
+// every number, +inf included, whatever its sign bit.  Keys of EXACT sums go through this form (one canonical NaN key above
+// key(+inf), below "none"); the raw map above would sort a NaN with the sign bit set in front of -inf.
+__device__ __forceinline__ uint32_t f32_to_key(float f) { return f != f ? 0xffc00000u : f32_to_ordered(f); }
+constexpr uint32_t kKeyInfHi = 0xffffffffu;  // sorts after every real distance (> key(+inf), > key(NaN))
 constexpr uint32_t kIdNone = 0xffffffffu;
 
 // ---- wave-resident sorted candidate list --------------------------------------------------------

@@ -51,9 +51,9 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_generic_kernel(const ScanArg
                 if (row0 + 32 < a.N) vb |= (unsigned long long)vw[1] << 32;
                 vmask &= vb;
             }
-            const unsigned long long pm = __ballot(d <= tf) & vmask;
+            const unsigned long long pm = __ballot(!(d > tf)) & vmask;  // (a NaN sum is a candidate too: it sorts behind +inf)
             if (pm) {
-                wavelist_offer(L, pm, f32_to_ordered(d), (uint32_t)(row0 + lane), km1, th, tl, lane);
+                wavelist_offer(L, pm, f32_to_key(d), (uint32_t)(row0 + lane), km1, th, tl, lane);
                 tf = (th == kKeyInfHi) ? __builtin_inff() : ordered_to_f32(th);
             }
         }
@@ -143,8 +143,9 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float *dist, con
     const int km1 = k - 1;
     // ids are 64-bit here (global row ids of different shards), so the list is kept directly as
     // (float dist, int64 id) per lane; candidates are offered one by one (G*k is small).
+    // (compared through the order-preserving keys, the scan kernels' own order: NaN sums behind +inf, numpy's rule)
     const int total = G * k;
-    float ld = __builtin_inff();
+    uint32_t lk = kKeyInfHi;
     int64_t li = INT64_MAX;
     for (int c = 0; c < total; ++c) {
         const int g = c / k, j = c - g * k;
@@ -152,21 +153,23 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float *dist, con
         const float cd = packed ? __uint_as_float((uint32_t)packed[e * 2 + 1]) : dist[e];
         const int64_t ci = packed ? packed[e * 2] : id[e];
         if (ci < 0) continue;  // padding entry of a short shard
-        const bool less = (ld < cd) || (ld == cd && li < ci);
+        const uint32_t ck = f32_to_key(cd);
+        const bool less = (lk < ck) || (lk == ck && li < ci);
         const int pos = __popcll(__ballot(less));
         if (pos > km1) continue;
-        const float sd = __shfl_up(ld, 1);
+        const uint32_t sk = (uint32_t)__shfl_up((int)lk, 1);
         const int64_t si = __shfl_up(li, 1);
         if (lane == pos) {
-            ld = cd;
+            lk = ck;
             li = ci;
         } else if (lane > pos) {
-            ld = sd;
+            lk = sk;
             li = si;
         }
     }
     if (lane <= km1) {
         const bool none = (li == INT64_MAX);
+        const float ld = ordered_to_f32(lk);
         out_d[(int64_t)b * k + lane] = none ? __builtin_inff() : (sqrt_out ? __builtin_sqrtf(ld) : ld);
         out_i[(int64_t)b * k + lane] = none ? (int64_t)-1 : li;
     }
@@ -187,9 +190,9 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float *values, int
     for (int64_t base = 0; base < N; base += 64) {
         const int64_t i = base + lane;
         const float d = (i < N) ? src[i] : __builtin_inff();
-        const unsigned long long pm = __ballot(i < N && d <= tf);
+        const unsigned long long pm = __ballot(i < N && !(d > tf));  // (NaN values: candidates that sort behind +inf, numpy's order)
         if (pm) {
-            wavelist_offer(L, pm, f32_to_ordered(d), (uint32_t)i, km1, th, tl, lane);
+            wavelist_offer(L, pm, f32_to_key(d), (uint32_t)i, km1, th, tl, lane);
             tf = (th == kKeyInfHi) ? __builtin_inff() : ordered_to_f32(th);
         }
     }

@@ -155,6 +155,18 @@ __device__ __forceinline__ void rotate_row(uint32_t (&c)[CW], const bool (&abit)
     for (int i = 0; i < CW; ++i) c[i] = n[i];
 }
 
+// Extremes of a table column that may hold non-finite entries (a query with an inf / NaN coordinate; code words whose squared
+// distance overflows).  The MINIMUM keeps -inf (a row with such an entry IS the nearest: L = -inf makes every bound "pass")
+// and drops NaN (fminf).  The MAXIMUM -- range of the quantisation, rounding slack -- runs over the entries below +inf only:
+// +inf and NaN entries quantise to the clip value, a valid lower bound of "beyond every number" (numpy's order puts NaN last),
+// and a sum that contains one is non-finite whatever the rounding of the others.  Without this ONE overflowing code word
+// made step and slack infinite, i.e. every row a candidate of every query.
+__device__ __forceinline__ float col_max_arg(float v) { return v < __builtin_inff() ? v : -__builtin_inff(); }
+__device__ __forceinline__ float finite_mag(float v) {
+    const float a = __builtin_fabsf(v);
+    return a < __builtin_inff() ? a : 0.f;
+}
+
 // integer filter bound (0x8000 | qthr) implied by a k-th key (see the kernel header for the derivation)
 template <int M>
 __device__ __forceinline__ unsigned short qbound_from_key(unsigned long long key, float smax_b, float qstep_b,
@@ -165,8 +177,8 @@ __device__ __forceinline__ unsigned short qbound_from_key(unsigned long long key
     const double slack = (double)smax_b * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
     double qd = (thr + slack - qlo_b) / (double)qstep_b;
     qd = __builtin_floor(qd) + 1.0;  // qthr
-    if (!(qd > 0.0)) qd = 0.0;
-    if (!(qd < 32767.0)) qd = 32767.0;
+    if (!(qd < 32767.0)) qd = 32767.0;  // (a NaN -- non-finite threshold, slack or L -- lands HERE: everything passes)
+    else if (!(qd > 0.0)) qd = 0.0;
     return (unsigned short)(0x8000u | (uint32_t)qd);
 }
 

@@ -36,8 +36,8 @@ __device__ __forceinline__ unsigned char qbound8_from_key(unsigned long long key
     const double slack = (double)smax_b * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
     double qd = (thr + slack - qlo_b) / (double)step * (1.0 + 1.0 / 524288.0);
     qd = __builtin_floor(qd) + 1.0;  // T
-    if (!(qd > 0.0)) qd = 0.0;
-    if (!(qd < 127.0)) qd = 127.0;   // (a NaN lands here too: everything passes)
+    if (!(qd < 127.0)) qd = 127.0;   // (a NaN lands HERE: everything passes)
+    else if (!(qd > 0.0)) qd = 0.0;
     return (unsigned char)(0x80u | (uint32_t)qd);
 }
 
@@ -233,7 +233,7 @@ __device__ __forceinline__ void qfilter_flush_inline(const FlushCtx &c, uint32_t
     const int q = (int)(e >> 32);
     float ex = 0.f;
     if (act && !(c.skip & 1)) ex = exact_row_sum<M, SKEWED, CODE16>(c, q, rid);
-    const uint32_t khi = f32_to_ordered(ex);
+    const uint32_t khi = f32_to_key(ex);  // (NaN sums sort behind +inf: numpy's order)
     unsigned long long rem = __ballot(act);
     while (rem) {
         const int q0 = __builtin_amdgcn_readlane(q, __builtin_ctzll(rem));

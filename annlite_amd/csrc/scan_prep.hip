@@ -25,7 +25,7 @@ __global__ __launch_bounds__(1024) void lut_quantise64_kernel(const float *__res
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             mn[i] = fminf(mn[i], v[i]);
-            mx[i] = fmaxf(mx[i], v[i]);
+            mx[i] = fmaxf(mx[i], col_max_arg(v[i]));  // (over the entries below +inf: col_max_arg)
         }
     }
 #pragma unroll
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(1024) void lut_quantise64_kernel(const float *__res
         for (int mm = 0; mm < M; ++mm) {
             const float l = s_lo[0][mm][tid], h = s_hi[0][mm][tid];
             range = fmaxf(range, h - l);
-            sm += fmaxf(fabsf(l), fabsf(h));
+            sm += fmaxf(finite_mag(l), finite_mag(h));  // (rounding slack of FINITE sums)
             Lsum += (double)l;
         }
         float step = range / (float)qmax;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
                 tab[kk * M + m] = v;
                 gout[(int64_t)kk * M + m] = v;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) mn[i] = fminf(mn[i], acc[i]), mx[i] = fmaxf(mx[i], acc[i]);
+                for (int i = 0; i < 4; ++i) mn[i] = fminf(mn[i], acc[i]), mx[i] = fmaxf(mx[i], col_max_arg(acc[i]));
             }
         }
         // lanes l, l + M, ... of a wave share m
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
             for (int mm = 0; mm < M; ++mm) {
                 const float l = s_lo[mm * 4 + tid], hh = s_hi[mm * 4 + tid];
                 range = fmaxf(range, hh - l);
-                sm += fmaxf(fabsf(l), fabsf(hh));
+                sm += fmaxf(finite_mag(l), finite_mag(hh));  // (rounding slack of FINITE sums)
                 Lsum += (double)l;
             }
             float step = range / (float)sb.qmax;
@@ -281,9 +281,12 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
         if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();  // (all LDS is dynamic)
     }
 
-    uint32_t best[QPB];  // ordered distance keys
+    // per-lane minima of the rows' sums, as floats: v_min_f32 drops a NaN sum (a row whose sum is NaN -- a NaN / inf query
+    // coordinate -- sorts behind every number and never sets the bound; as a raw key a NaN with the sign bit set would have
+    // been the SMALLEST); the keys are formed after the loop
+    float bestf[QPB];
 #pragma unroll
-    for (int q = 0; q < QPB; ++q) best[q] = 0xffffffffu;
+    for (int q = 0; q < QPB; ++q) bestf[q] = __builtin_inff();
     // the code bytes (and validity word) of a lane's NEXT row are fetched while the current one is summed: the loop was
     // bound by one dependent global round trip per iteration (12.7 us per 8192 rows; the look-ups need ~4)
     auto fetch = [&](int64_t r, uint32_t (&cc)[CW], uint32_t &vw) {
@@ -345,13 +348,13 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
             for (int i = 0; i < CH; ++i) d += v[i];  // (the lane's skewed order: see the kernel's header)
         });
 #pragma unroll
-        for (int q = 0; q < QPB; ++q) {
-            const uint32_t key = f32_to_ordered(d[q]);
-            if (ok && key < best[q]) best[q] = key;
-        }
+        for (int q = 0; q < QPB; ++q) bestf[q] = fminf(bestf[q], ok ? d[q] : __builtin_inff());
         b_cur = b_nxt;
         b_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_pend);
     }
+    uint32_t best[QPB];  // ordered distance keys (a lane that saw no valid row: key(+inf), as before 0xffffffff | ... below)
+#pragma unroll
+    for (int q = 0; q < QPB; ++q) best[q] = bestf[q] < __builtin_inff() ? f32_to_ordered(bestf[q]) : 0xffffffffu;
     // Selection keys: the low 10 bits of the ordered distance are replaced by (wave, lane), which makes the
     // 1024 keys of a query unique (rank = number of smaller keys, no tie handling) and costs at most 1023
     // ulps of tightness: the k smallest keys T_i bound k distinct rows by (T_i | 1023).
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(256) void lut_minmax_kernel(const float *__restrict
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             mn[i] = fminf(mn[i], v[i]);
-            mx[i] = fmaxf(mx[i], v[i]);
+            mx[i] = fmaxf(mx[i], col_max_arg(v[i]));  // (over the entries below +inf: col_max_arg)
         }
     }
 #pragma unroll
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(256) void lut_qparams_kernel(const float *__restric
     for (int m = 0; m < M; ++m) {
         const float l = lo[(int64_t)b * M + m], h = hi[(int64_t)b * M + m];
         range = fmaxf(range, h - l);
-        sm += fmaxf(fabsf(l), fabsf(h));
+        sm += fmaxf(finite_mag(l), finite_mag(h));  // (rounding slack of FINITE sums)
         L += (double)l;
     }
     float step = range / (float)qmax;
@@ -513,9 +516,9 @@ __global__ __launch_bounds__(256) void lut_quantise_fused_kernel(const float *__
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             mn[i] = fminf(mn[i], v0[i]);
-            mx[i] = fmaxf(mx[i], v0[i]);
+            mx[i] = fmaxf(mx[i], col_max_arg(v0[i]));
             mn[4 + i] = fminf(mn[4 + i], v1[i]);
-            mx[4 + i] = fmaxf(mx[4 + i], v1[i]);
+            mx[4 + i] = fmaxf(mx[4 + i], col_max_arg(v1[i]));
         }
     }
 #pragma unroll
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(256) void lut_quantise_fused_kernel(const float *__
         for (int mm = 0; mm < M; ++mm) {
             const float l = s_lo[0][mm][tid], h = s_hi[0][mm][tid];
             range = fmaxf(range, h - l);
-            sm += fmaxf(fabsf(l), fabsf(h));
+            sm += fmaxf(finite_mag(l), finite_mag(h));  // (rounding slack of FINITE sums)
             Lsum += (double)l;
         }
         float step = range / (float)qmax;
@@ -649,7 +652,7 @@ __global__ __launch_bounds__(1024) void lut_l2_build_quantise_kernel(const float
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 mn[i] = fminf(mn[i], acc[i]);
-                mx[i] = fmaxf(mx[i], acc[i]);
+                mx[i] = fmaxf(mx[i], col_max_arg(acc[i]));
             }
         }
     }
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(1024) void lut_l2_build_quantise_kernel(const float
         for (int mm = 0; mm < M; ++mm) {
             const float l = s_lo[0][mm][tid], h = s_hi[0][mm][tid];
             range = fmaxf(range, h - l);
-            sm += fmaxf(fabsf(l), fabsf(h));
+            sm += fmaxf(finite_mag(l), finite_mag(h));  // (rounding slack of FINITE sums)
             Lsum += (double)l;
         }
         float step = range / (float)qmax;

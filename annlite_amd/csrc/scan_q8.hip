@@ -121,8 +121,8 @@ __device__ __forceinline__ uint32_t q8_bound_from_key(unsigned long long key, fl
     const double slack = (double)smax_b * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
     double qd = (thr + slack - qlo_b) / (double)step * (1.0 + 1.0 / 524288.0);
     qd = __builtin_floor(qd) + 1.0;
-    if (!(qd > 0.0)) qd = 0.0;
-    if (!(qd < (double)Q8Cfg<M>::TMAX)) qd = (double)Q8Cfg<M>::TMAX;
+    if (!(qd < (double)Q8Cfg<M>::TMAX)) qd = (double)Q8Cfg<M>::TMAX;  // (a NaN lands HERE: everything passes)
+    else if (!(qd > 0.0)) qd = 0.0;
     return Q8Cfg<M>::TFLAG | (uint32_t)qd;
 }
 
@@ -324,8 +324,8 @@ __device__ __forceinline__ uint32_t q8_bound(unsigned long long key, double c0, 
     const uint32_t hi = (uint32_t)(key >> 32);
     if (hi == kKeyInfHi) return 2u * Q8Cfg<M>::TFLAG - 1u;
     double qd = __builtin_floor(__builtin_fma((double)ordered_to_f32(hi), c1, c0)) + 1.0;
-    if (!(qd > 0.0)) qd = 0.0;
-    if (!(qd < (double)Q8Cfg<M>::TMAX)) qd = (double)Q8Cfg<M>::TMAX;  // (a NaN lands here too: everything passes)
+    if (!(qd < (double)Q8Cfg<M>::TMAX)) qd = (double)Q8Cfg<M>::TMAX;  // (a NaN lands HERE: everything passes)
+    else if (!(qd > 0.0)) qd = 0.0;
     return Q8Cfg<M>::TFLAG | (uint32_t)qd;
 }
 // where the scanning waves load a slot's bound from: a byte per slot; WIDE: half-words, slots 1 and 2 (5 and 6) swapped -- the
@@ -481,7 +481,7 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
     int cnt[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const unsigned long long key = ((unsigned long long)f32_to_ordered(ex[u]) << 32) | (uint32_t)e[u];
+        const unsigned long long key = ((unsigned long long)f32_to_key(ex[u]) << 32) | (uint32_t)e[u];  // (NaN behind +inf)
         bool pend = false;
         if (act[u]) {
             unsigned long long kth = ldsv<unsigned long long>(o.list + 8u * (uint32_t)(q[u] * 16 + c.km1));

@@ -45,8 +45,9 @@ try:  # real docarray when present (it is not in this image)
 
     if not isinstance(Document, type):  # (a test harness may have stubbed the module)
         raise ImportError('docarray is stubbed')
+    LazyMatches = None  # (real docarray: ``Document.matches`` takes its own DocumentArray type -- matches are built eagerly)
 except Exception:  # pragma: no cover - depends on the environment
-    from .docarray_compat import Document, DocumentArray, to_numpy_array
+    from .docarray_compat import Document, DocumentArray, LazyMatches, to_numpy_array
 
 logger = logging.getLogger('annlite_amd')
 
@@ -153,6 +154,8 @@ class AnnLite:
         GPU scan; ``AnnLite(..., graph=True, ef_search=..., max_connection=..., ef_construction=...)`` selects the
         HNSW-over-PQ index with the reference's knobs (graph walked on the GPU, BASELINE config 5)."""
         kw = dict(self._index_kwargs)
+        if self._devices is not None and len(self._devices) > 1 and (self._vq_codec is not None or kw.get('graph')):
+            warnings.warn('devices= is ignored for n_cells > 1 and graph=True indexes (they live on the current device)')
         if self._vq_codec is not None:
             from .core.index.ivf_pq_gpu import IvfPQGpuIndex
 
@@ -296,10 +299,18 @@ class AnnLite:
 
         snap = self.snapshot_path
         logger.info(f'Load the indexer from snapshot {snap}')
-        self.vec_index(0).load(snap / 'cell_0.hnsw')
+        try:
+            self.vec_index(0).load(snap / 'cell_0.hnsw')
+        except (AssertionError, KeyError, FileNotFoundError) as ex:
+            # the vector index file carries its own 'format' (flat / cells / graph / multi-GPU header + .shard<g> files): a
+            # snapshot is reopened with the layout arguments of the AnnLite that wrote it
+            raise RuntimeError(
+                f'snapshot {snap} does not fit this index ({type(self.vec_index(0)).__name__}): reopen it with the same '
+                f'devices= / shard_block= / n_cells / graph arguments it was dumped with ({ex!r})') from ex
         with open(snap / 'cell_0.db', 'rb') as f:
             st = pickle.load(f)
         self._offset2id, self._tags, self._docs = st['offset2id'], st['tags'], st['docs']
+        self._offset2int = None
         self._id2offset = {d: o for o, d in enumerate(self._offset2id) if d is not None}
 
     def backup(self, target_name: Optional[str] = None, token: Optional[str] = None):
@@ -338,6 +349,7 @@ class AnnLite:
         offsets = np.arange(first, first + len(docs), dtype=np.int64)
         # vectors first: if the device call fails no offset exists without codes
         self.vec_index(0).add_with_ids(np.ascontiguousarray(x, dtype=np.float32), offsets)
+        self._offset2int = None
         for d in docs:
             self._id2offset[d.id] = len(self._offset2id)
             self._offset2id.append(d.id)
@@ -376,6 +388,7 @@ class AnnLite:
                     raise Exception(f'The document (id={doc_id}) cannot be updated as it is not found in the index')
                 continue
             self._offset2id[off] = None
+            self._offset2int = None
             self._tags[off] = None
             self._docs.pop(doc_id, None)
             offs.append(off)
@@ -385,6 +398,7 @@ class AnnLite:
     def clear(self):
         self.vec_index(0).reset()
         self._offset2id, self._id2offset, self._tags, self._docs = [], {}, [], {}
+        self._offset2int = None
 
     def close(self):
         pass
@@ -418,27 +432,61 @@ class AnnLite:
         for doc, matches in zip(docs, match_docs):
             doc.matches = matches
 
-    def search_by_vectors(self, query_np, filter: Optional[dict] = None, limit: int = 10, include_metadata: bool = True):
-        """index.py:361-387 -> CellContainer.search_cells (container.py:201-235)."""
-        d, i = self._search_arrays(query_np, filter, limit)
+    def _resolver(self, include_metadata: bool):
+        """(offsets, dists) of one query -> its match documents: container.py:226-233 (``Document(id=doc_id)``, the stored
+        document's fields with ``include_metadata``, ``scores[metric].value = dist``)."""
         name = self.metric.name.lower()
-        topk_dists, topk_docs = [], []
-        for b in range(d.shape[0]):
-            keep = i[b] >= 0
-            dists = d[b][keep]
-            match_docs = DocumentArray()
-            for dist, off in zip(dists, i[b][keep]):
-                doc_id = self._offset2id[int(off)]
-                if include_metadata and doc_id in self._docs:
-                    src = self._docs[doc_id]
+        offset2id, docs = self._offset2id, self._docs
+
+        def resolve(offs, dists):
+            out = []
+            for dist, off in zip(dists, offs):
+                doc_id = offset2id[int(off)]
+                if include_metadata and doc_id in docs:
+                    src = docs[doc_id]
                     doc = Document(id=doc_id, embedding=getattr(src, 'embedding', None), tags=dict(getattr(src, 'tags', {}) or {}))
                 else:
                     doc = Document(id=doc_id)
                 doc.scores[name].value = dist
-                match_docs.append(doc)
-            topk_dists.append(dists)
-            topk_docs.append(match_docs)
+                out.append(doc)
+            return out
+
+        return resolve
+
+    @staticmethod
+    def _valid_rows(d: np.ndarray, i: np.ndarray):
+        """Per query the valid prefix of its result row (missing entries -- (+inf, -1) -- sort last): row views, no copies."""
+        if d.shape[1] == 0 or bool((i[:, -1] >= 0).all()):
+            return list(d), list(i)
+        cnt = (i >= 0).sum(axis=1)
+        return [d[b, :c] for b, c in enumerate(cnt)], [i[b, :c] for b, c in enumerate(cnt)]
+
+    def search_by_vectors(self, query_np, filter: Optional[dict] = None, limit: int = 10, include_metadata: bool = True):
+        """index.py:361-387 -> CellContainer.search_cells (container.py:201-235).  The per-query match lists are LAZY
+        (``LazyMatches``: the documents are built when a list is first read -- same ids, scores and metadata as the
+        reference's eager loop, which costs tens of milliseconds per 1024-query batch next to a 1.4 ms scan)."""
+        d, i = self._search_arrays(query_np, filter, limit)
+        resolve = self._resolver(include_metadata)
+        topk_dists, rows = self._valid_rows(d, i)
+        if LazyMatches is not None:
+            topk_docs = [LazyMatches(offs, dists, resolve) for offs, dists in zip(rows, topk_dists)]
+        else:
+            topk_docs = [DocumentArray(resolve(offs, dists)) for offs, dists in zip(rows, topk_dists)]
         return topk_dists, topk_docs
+
+    def _offsets_as_int_ids(self) -> Optional[np.ndarray]:
+        """offset -> ``int(doc_id)`` as one array (container.py:260 converts every returned id with ``int``): built once per
+        state of the table, so that a batch's ids are ONE gather instead of B*k python conversions.  ``None`` when some
+        stored id is not an integer literal (the conversion then happens per returned id, and raises like the reference's)."""
+        cache = getattr(self, '_offset2int', None)
+        if cache is None or len(cache) != len(self._offset2id):
+            try:
+                cache = np.fromiter((int(x) if x is not None else -1 for x in self._offset2id), dtype=np.int64,
+                                    count=len(self._offset2id))
+            except ValueError:
+                return None
+            self._offset2int = cache
+        return cache
 
     def search_numpy(self, query_np, filter: Dict = {}, limit: int = 10, **kwargs):
         """index.py:485-522: (list of dists[k], list of doc-id arrays).  Ids are returned as the
@@ -446,12 +494,16 @@ class AnnLite:
         if not self.is_trained:
             raise RuntimeError('The indexer is not trained, cannot add new documents')
         d, i = self._search_arrays(query_np, filter, limit)
-        dists, ids = [], []
-        for b in range(d.shape[0]):
-            keep = i[b] >= 0
-            dists.append(d[b][keep])
-            ids.append(np.array([int(self._offset2id[int(o)]) for o in i[b][keep]], dtype=int))
-        return dists, ids
+        valid = i >= 0
+        table = self._offsets_as_int_ids()
+        if table is None:  # (ids that are not integer literals: the reference's per-id conversion, and its ValueError)
+            dists, rows = self._valid_rows(d, i)
+            return dists, [np.array([int(self._offset2id[int(o)]) for o in r], dtype=int) for r in rows]
+        ids_all = table[np.where(valid, i, 0)].astype(int, copy=False)
+        if i.shape[1] == 0 or bool(valid.all()):
+            return list(d), list(ids_all)
+        cnt = valid.sum(axis=1)  # (missing entries sort last)
+        return [d[b, :c] for b, c in enumerate(cnt)], [ids_all[b, :c] for b, c in enumerate(cnt)]
 
     def get_doc_by_id(self, doc_id: str):
         return self._docs.get(doc_id)

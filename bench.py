@@ -68,7 +68,7 @@ def parse():
                    help='database / query distribution (SURVEY.md section 8d): lowrank = rank-16 (rank-64 above 128-d) latent Gaussian '
                         '+ noise; uniform = U[0,1)^D, the reference\'s own test distribution (tests/test_pq_bind.py:19)')
     p.add_argument('--legs', default='auto',
-                   help='comma list of extra legs (rank 0, N=1, never `value`): rerank, ivf, uniform, c2, c4, c5; "none"; "auto" = all '
+                   help='comma list of extra legs (rank 0, N=1, never `value`): rerank, ivf, facade, uniform, c2, c4, c5; "none"; "auto" = all '
                         'of them for the default workload, rerank + ivf otherwise')
     p.add_argument('--metric', choices=['euclidean', 'cosine', 'inner_product'], default='euclidean',
                    help="BASELINE config 2/3: euclidean; config 4 (10M x 768, m=64, batch 256): cosine")
@@ -117,18 +117,42 @@ def sub_run(cmd, timeout_s):
         return {'error': f'timeout after {timeout_s} s'}
 
 
+def free_port() -> int:
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def torchrun_argv(n_gpus: int, argv, port: int):
+    """The command line a plain ``python bench.py --gpus N`` (N > 1, no RANK / WORLD_SIZE in the environment) re-executes
+    itself as: one process per GPU over RCCL, rendezvous on 127.0.0.1 (the container hostname may not resolve) -- the form
+    the driver uses for N > 1.  ``argv`` = this script's own arguments, passed on unchanged."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_gpus}',
+            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py')] + list(argv)
+
+
 def main():
     global UNIFORM
     args = parse()
     UNIFORM = args.data == 'uniform'
+    if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the N-rank job (same arguments, same JSON line from rank 0)
+        cmd = torchrun_argv(args.gpus, sys.argv[1:], free_port())
+        print('bench.py: --gpus %d without a launcher, re-executing as: %s' % (args.gpus, ' '.join(cmd)), file=sys.stderr)
+        sys.stderr.flush()
+        os.execv(sys.executable, cmd)
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:  # the launcher decides how many ranks exist; the line reports what actually ran (n_gpus = world)
+        if rank == 0:
+            print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running {world} rank(s)', file=sys.stderr)
     N_, D_, M_, Ks_, B_, k_ = args.rows, args.dim, args.m, args.ks, args.batch, args.k
     default_workload = (N_, D_, M_, Ks_, B_, k_, args.metric, args.data) == (10_000_000, 128, 16, 256, 1024, 10, 'euclidean', 'lowrank')
     legs = args.legs.split(',') if args.legs not in ('auto', 'none') else (
-        [] if args.legs == 'none' else ['rerank', 'ivf'] + (['uniform', 'c2', 'c4', 'c5'] if default_workload else []))
+        [] if args.legs == 'none' else ['rerank', 'ivf'] + (['facade', 'uniform', 'c2', 'c4', 'c5'] if default_workload else []))
     if args.no_rerank and 'rerank' in legs:
         legs.remove('rerank')
     if args.ivf_cells <= 1 and 'ivf' in legs:
@@ -256,6 +280,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed  # (this rank's clock; `elapsed` becomes the max over the ranks)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -276,6 +301,57 @@ def main():
             _host_d, _host_i = index.search_batch(q_host, limit=k)  # numpy in -> numpy out (synchronous)
         host_qps = B * n_h / (time.perf_counter() - t0)
 
+    # ---- the drop-in API itself (north_star: "keeping the AnnLite(...)/index()/search() Python API and DocArray result shape"):
+    # AnnLite.search(docs) -- numpy embeddings in, doc.matches out -- and search_numpy over the SAME table; never `value` -------
+    facade = None
+    if world == 1 and 'facade' in legs:
+        import shutil
+        import tempfile
+
+        from annlite_amd import AnnLite
+        from annlite_amd.index import Document, DocumentArray
+
+        tmp = tempfile.mkdtemp(prefix='annlite_bench_')
+        try:
+            ann = AnnLite(n_dim=D, metric=args.metric, n_subvectors=M, n_clusters=Ks, data_path=tmp)
+            # adopt the bench's codec and table (indexing 10M python Documents is not what this leg measures): document id = str(row)
+            ann._pq_codec = codec
+            ann._vec_indexes = [index]
+            ann._offset2id = list(map(str, range(n_local)))
+            docs = DocumentArray([Document(id=f'q{b}', embedding=q_host[b]) for b in range(B)])
+            name = metric.name.lower()
+            n_f = max(3, min(args.steps, 20))
+
+            def timed(fn):
+                fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n_f):
+                    fn()
+                return B * n_f / (time.perf_counter() - t0)
+
+            def read_all():
+                ann.search(docs, limit=k)
+                return sum(1 for d in docs for m in d.matches if m.id is not None and m.scores[name].value is not None)
+
+            f_search = timed(lambda: ann.search(docs, limit=k))
+            f_numpy = timed(lambda: ann.search_numpy(q_host, limit=k))
+            f_read = timed(read_all)
+            ann.search(docs, limit=k)
+            ok = all([m.id for m in docs[b].matches] == [str(int(x)) for x in _host_i[b] if x >= 0] for b in range(0, B, 37))
+            facade = {
+                'search': {'value': f_search, 'unit': 'queries/s',
+                           'note': 'AnnLite.search(docs, limit=k): 1024 Documents with numpy embeddings in, doc.matches out (lazy: '
+                                   'the match Documents are built when a list is first read)'},
+                'search_all_matches_read': {'value': f_read, 'unit': 'queries/s',
+                                            'note': 'the same, then EVERY match\'s id and scores[metric].value read: what the '
+                                                    'reference\'s eager loop always pays (container.py:226-233)'},
+                'search_numpy': {'value': f_numpy, 'unit': 'queries/s', 'note': 'AnnLite.search_numpy(x, limit=k): lists of dists[k] / int ids[k]'},
+                'matches_equal_index_result': bool(ok),
+            }
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
     if os.environ.get('ANNLITE_DEBUG_COUNTERS') and rank == 0:
         c = _capi.debug_counters()  # of the last step (debug aid; the counters slow the kernel down)
         print('counters: slow-block entries %d, flush query-groups %d, inserting %d, publications %d, candidate rows %d' %
@@ -289,6 +365,37 @@ def main():
         kms.append(_capi.profile_last_scan_ms())
     _capi.profile_enable(False)
     kernel_ms = float(np.mean(kms))
+
+    # ---- N > 1 (or the exchange forced on one rank): what the exchange alone costs, and every rank's own figures ----
+    gathering = use_dist and (world > 1 or bool(os.environ.get('ANNLITE_FORCE_GATHER')))
+    exchange_ms = None
+    per_rank = None
+    if gathering:
+        packed = index.search_batch_packed(queries, k, lo)
+        if packed is not None:
+            G_ = dist.get_world_size()
+            gathered = torch.empty((G_ * B, k, 2), dtype=torch.int64, device=dev)
+            for _ in range(3):
+                dist.all_gather_into_tensor(gathered, packed)
+                ops.topk_merge_packed(gathered.view(G_, B, k, 2), sqrt=index.sqrt_epilogue)
+            torch.cuda.synchronize()
+            barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n_x = 20
+            e0.record()
+            for _ in range(n_x):
+                dist.all_gather_into_tensor(gathered, packed)  # (in stream order: torch makes the current stream wait for RCCL's)
+                ops.topk_merge_packed(gathered.view(G_, B, k, 2), sqrt=index.sqrt_epilogue)
+            e1.record()
+            torch.cuda.synchronize()
+            exchange_ms = e0.elapsed_time(e1) / n_x  # one packed all-gather of [B, k, 2] i64 + the merge kernel, back to back
+    if use_dist:
+        mine = torch.tensor([own_elapsed / args.steps * 1e3, kernel_ms, exchange_ms if exchange_ms is not None else -1.0, float(n_local)],
+                            dtype=torch.float64, device=dev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{'rank': r, 'ms_per_step': float(t[0]), 'kernel_ms': float(t[1]),
+                     'exchange_ms': None if float(t[2]) < 0 else float(t[2]), 'rows': int(t[3])} for r, t in enumerate(allr)]
     scan_bytes = float(B) * n_local * M  # algorithmic code bytes consumed per launch
     achieved = scan_bytes / (kernel_ms * 1e-3) / 1e9
     lookups_per_s = float(B) * n_local * M / (kernel_ms * 1e-3)
@@ -449,10 +556,19 @@ def main():
             pq_oracle.pqindex_search_reference_style(lut_np[b], codes_np, k)
         ref_style_s = (time.perf_counter() - t0) / lut_np.shape[0]
         threads = pq_oracle.max_threads()
-        nq_all = min(B, max(nqc, threads * 64))  # ~3 s on all cores at 10M rows
+        # all cores: the WHOLE batch where the host has the cores for it (16 CPUs: ~2.5 s at 10M rows) -- and its result is
+        # kept: every query of the timed batch is compared with the CPU oracle, not a sample
+        nq_all = B if threads >= 8 else min(B, max(nqc, threads * 64))
+        q_all = queries[:nq_all].cpu().numpy()
         t0 = time.perf_counter()
-        pq_oracle.index_search(queries[:nq_all].cpu().numpy(), cb_np, codes_np, omet, k, threads=threads)
+        cd_all, ci_all = pq_oracle.index_search(q_all, cb_np, codes_np, omet, k, threads=threads)
         cpu_all_s = time.perf_counter() - t0
+        if args.metric == 'cosine':
+            gd_all, gi_all = index.search_batch(q_all, limit=k)  # (host-buffer path, see above)
+        else:
+            gd_all, gi_all = out[0][:nq_all].cpu().numpy(), out[1][:nq_all].cpu().numpy()
+        parity_all = bool(np.array_equal(cd_all, gd_all) and np.array_equal(ci_all, gi_all))
+        n_bad = int(np.sum(np.any(ci_all != gi_all, axis=1) | np.any(cd_all != gd_all, axis=1)))
         cpu = {
             'value': nqc / cpu_s, 'unit': 'queries/s', 'cores': 1, 'kind': 'port',
             'sample': f'{nqc} queries x {n_local} rows (LUT + flat ADC scan + top-{k}), single thread = the reference execution '
@@ -463,6 +579,8 @@ def main():
                           '(pq_bindings.pyx:75-80, pq_index.py:46-49)'},
             'all_cores': {'value': nq_all / cpu_all_s, 'cores': threads, 'sample': f'{nq_all} queries, OpenMP over queries, one run'},
             'gpu_matches_cpu_bit_exact': parity,
+            # ids AND distances of the timed batch's result against the CPU oracle, every one of `queries_checked` queries
+            'gpu_matches_cpu_bit_exact_all': parity_all, 'queries_checked': nq_all, 'queries_differing': n_bad,
         }
 
     if rank == 0:
@@ -485,16 +603,19 @@ def main():
             'traffic': traffic,
             'kernel': kernel_name, 'kernel_ms': kernel_ms, 'lookups_per_clk_per_cu': per_clk,
             'kernel_choice': index.scan_kernel,
-            'peak_note': 'design-relative: one ds_read_b128 (ds_read_b64 at M=64) per wave64 per 4 (2) LDS cycles x 64 lanes x the '
-                         'entries this kernel packs per read (16 one-byte entries; u16 kernels 8; M=64 4) x 256 CUs x 2.4 GHz: the '
-                         'roof of THIS table format, not a chip constant',
+            'peak_note': 'design-relative: one ds_read_b128 (M=64: ds_read_b64) per wave64 per 4 (2) LDS cycles x 64 lanes x the '
+                         'entries this kernel packs per read (byte tables: 16 one-byte entries per 16 B, M=64 8 per 8 B = 256 look-ups / clk / CU; '
+                         'u16 tables: 8 per 16 B, M=64 4 per 8 B = 128) x 256 CUs x 2.4 GHz: the roof of THIS table format, not a chip constant',
+            # the M = 64 byte-table kernel is VALU-bound and holds 2.1 GHz, not the 2.4 GHz the roof is priced at (PMC:
+            # GRBM_GUI_ACTIVE / 8 XCDs / duration, profiles/r03/scan_c4_10m_m64_q8_pmc_*.csv): the fraction at THAT clock beside it
+            'frac_at_measured_clock': (lookups_per_s / (256 * per_clk * 2.1e9)) if (M == 64 and byte_tables) else None,
             # SURVEY.md 8(d)'s per-unit figure: M code bytes per (query, row) evaluation -- what a one-query-at-a-time scan
             # (the reference) streams; reported for comparison, not a fraction of anything
             'algorithmic': {'bytes_per_launch': scan_bytes, 'GB_per_s': achieved},
             'hbm': None if traffic is None else {'bytes_per_launch': traffic, 'frac': traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         rec = {
-            'metric': 'queries/sec', 'value': qps, 'unit': 'queries/s', 'n_gpus': world, 'steps': args.steps,
+            'metric': 'queries/sec', 'value': qps, 'unit': 'queries/s', 'n_gpus': world, 'gpus_arg': args.gpus, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic' if args.data == 'lowrank' else 'synthetic (uniform)',
             'config': {
@@ -508,6 +629,10 @@ def main():
                 'streams': n_streams,
                 'prewarm_steps': args.prewarm_steps,  # untimed set-up steps BEFORE the W warm-up steps (clock ramp)
             },
+            # N > 1: every rank's own clock over the K steps, its scan kernel (HIP events) and the exchange alone (one packed
+            # all-gather + merge, 20 back to back) -- a first multi-GPU run says where its time went
+            'per_rank': per_rank,
+            'exchange_ms': exchange_ms,
             'recall_at_10': recall_adc,
             # `value` is the reference's own search semantics (plain ADC top-k, the parity quantity); the north-star's
             # ">= 90 % recall@10" figure is the re-rank leg below
@@ -517,6 +642,7 @@ def main():
             'roofline': roof,
             'cpu_baseline': cpu,
             'ivf': ivf_rec,
+            'facade': facade,
             'with_host_transfer': {'value': host_qps, 'unit': 'queries/s',
                                    'note': 'numpy queries in, numpy results out per batch (PCIe both ways, synchronous)'},
             'setup': {'train_s': train_s, 'index_s': index_s},

@@ -16,8 +16,8 @@
 set -euo pipefail
 REF=${REF:-/root/reference}
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-# oracle/_ref/: .gitignore'd (stays out of history), NOT .gpurunignore'd (the two .so files travel to the GPU box like the
-# library's own); only extension modules land here, generated C/C++ is deleted right after compiling
+# oracle/_ref/: .gitignore'd (stays out of history) and .gpurunignore'd (stays in this container: the GPU box pins the oracle
+# through the committed golden fixtures); only extension modules land here, generated C/C++ is deleted right after compiling
 OUT="${ANNLITE_REF_BUILD:-$HERE/_ref}"
 if [ ! -d "$REF/bindings" ]; then
   echo "build_ref: $REF not present, skipping (GPU box uses committed golden fixtures)"; exit 0

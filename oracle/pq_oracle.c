@@ -152,7 +152,11 @@ ORACLE_API void oracle_adc_gather_u8(const float *adtable, int64_t M, int64_t Ks
  * ------------------------------------------------------------------------------------------- */
 typedef struct { float d; int64_t i; } oracle_pair_t;
 
+/* numpy's order, which the reference's argpartition / argsort use (math.py:107-116): NaN sorts behind every number,
+ * +inf included, whatever its sign bit; all NaNs tie (and ties go by row id, the build's fixed rule). */
 static int pair_less(const oracle_pair_t *a, const oracle_pair_t *b) {
+    const int an = a->d != a->d, bn = b->d != b->d;
+    if (an || bn) return an == bn ? a->i < b->i : bn;
     if (a->d < b->d) return 1;
     if (a->d > b->d) return 0;
     return a->i < b->i;

@@ -152,6 +152,22 @@ roofline = {'bound': 'hbm', 'achieved': alg_bytes / (kernel_ms * 1e-3) / 1e9, 'p
 # searchBaseLayerST with PQLookup distances), ONE thread = the reference's execution model (knn_query runs single-threaded
 # for AnnLite's one-query calls, hnsw_bindings.cpp:332-334), bounded sample; all cores beside it ------------------------
 index.walk = 'host'
+def usable_threads() -> int:
+    """The threads the graph library actually starts (hnsw_host.cpp usable_threads): min(CPUs, affinity mask, cgroup CPU quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, max(1, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max' and int(period) > 0:
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 nq1 = min(B, 256)
 threads_all = index.n_threads
 index.n_threads = 1
@@ -162,7 +178,7 @@ cpu1 = nq1 / (time.perf_counter() - t0)
 index.n_threads = threads_all
 cpu_baseline = {'value': cpu1, 'unit': 'queries/s', 'cores': 1, 'kind': 'port',
                 'sample': f'{nq1} queries, graph walk ef_search={a.ef_search} over {N} rows on the host (candidate lists only)',
-                'all_cores': {'value': walks['host'], 'cores': os.cpu_count(), 'sample': f'{B} queries x {a.steps}'}}
+                'all_cores': {'value': walks['host'], 'cores': usable_threads(), 'sample': f'{B} queries x {a.steps}'}}
 print(json.dumps({'config': f'HNSW-over-PQ: {N} x {D}-dim, PQ m={M} ks=256, L2, max_connection={a.max_connection}, '
                             f'ef_construction={a.ef_construction}, ef_search={a.ef_search}, batch {B}, k={k}',
                   'metric': 'queries/sec', 'value': res['hnsw_gpu_walk_exact_rerank']['queries_per_s'], 'unit': 'queries/s',

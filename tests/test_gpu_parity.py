@@ -1111,9 +1111,29 @@ def test_full_size_properties_config3_config4(ops, oracle, name, N, M, dsub, B, 
     for b in (0, B - 1):
         full = ops.adc_dist(lut_b[b], codes)
         assert int((full < d[b, -1]).sum().item()) <= k - 1
-    sel = [0, B // 2]
-    rd, ri = oracle.adc_search_c(lut_b[sel].cpu().numpy(), codes.cpu().numpy(), k, threads=oracle.max_threads())
-    assert np.array_equal(d[sel].cpu().numpy(), rd) and np.array_equal(i[sel].cpu().numpy(), ri)
+    # EVERY query of the batch against an independent device path: all N distances of the query by the operator-seam kernel
+    # (annlite_adc_dist = pq_bindings.pyx:52-80, one thread per row, ascending-m sum from the reference-layout table), then the k
+    # smallest (distance, row) keys by torch.topk -- no scan kernel, no filter tables, no lists (math.py:94-120 with the fixed
+    # tie-break)
+    rows = torch.arange(N, device=dev, dtype=torch.int64)
+    chunk = max(1, (1 << 26) // N)  # <= 64M keys (512 MB) per chunk
+    n_diff = 0
+    for b0 in range(0, B, chunk):
+        nb = min(chunk, B - b0)
+        dist = torch.empty((nb, N), dtype=torch.float32, device=dev)
+        for j in range(nb):
+            ops.adc_dist(lut_b[b0 + j], codes, out=dist[j])
+        bits = (dist + 0.0).view(torch.int32)
+        bits = bits ^ ((bits >> 31) & 0x7FFFFFFF)  # signed-comparable image of the float order
+        top = torch.topk((bits.to(torch.int64) << 32) | rows[None, :], k, dim=1, largest=False, sorted=True).values
+        ti = top & 0xFFFFFFFF
+        td = torch.gather(dist, 1, ti)
+        n_diff += int((~((ti == i[b0:b0 + nb]).all(dim=1) & (td == d[b0:b0 + nb]).all(dim=1))).sum().item())
+        del dist, bits, top
+    assert n_diff == 0, f'{n_diff} of {B} queries differ from the all-distances + top-k path'
+    # ... and against the CPU oracle: every query as well (all host cores; ~3 s at 16 threads)
+    rd, ri = oracle.adc_search_c(lut_b.cpu().numpy(), codes.cpu().numpy(), k, threads=oracle.max_threads())
+    assert np.array_equal(d.cpu().numpy(), rd) and np.array_equal(i.cpu().numpy(), ri)
 
 
 def test_bench_under_torchrun_rccl_gather_path(tmp_path):

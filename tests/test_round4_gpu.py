@@ -1,0 +1,235 @@
+"""GPU tests added in round 4 (run with ``-m gpu``): non-finite inputs, the ``math.top_k`` wrapper's edge cases, limit > 64
+through the single-process multi-GPU index, the default candidate pool of a re-rank index with few row slices, lazy matches."""
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason='needs an AMD GPU')]
+
+
+@pytest.fixture(scope='module')
+def ops():
+    import torch
+    from annlite_amd import ops as _ops
+
+    torch.cuda.set_device(0)
+    return _ops
+
+
+# ------------------------------------------------------------------------------------ non-finite inputs
+# The reference has no guard: pq_bindings.pyx:30-47 sums whatever the tables hold, math.py:94-120 selects with numpy's order --
+# NaN behind every number, +inf included.  The kernels must return the same rows (fixed tie-break: distance, then row id) and
+# the same distances (NaN for NaN) for: a query with an inf coordinate (its tables are all inf in one sub-space: every row's
+# sum is inf), an all-inf query, a NaN query, inner-product tables with +-inf / NaN mixed, code books with a few / with only
+# huge code words (table entries overflow to inf).  Every scan kernel family: byte tables (M = 16 / 8 / 64, k <= 16), u16
+# tables (M = 32; M = 16 with k = 32), the generic kernel (M = 12), both entry points (tables prebuilt / built by the call).
+CASES = ['inf_coordinate', 'inf_query', 'nan_query', 'ip_inf_query', 'huge_codewords_some', 'huge_codewords_all']
+
+
+def _nonfinite_inputs(case, M, dsub, N, B, Ks, seed):
+    rs = np.random.RandomState(seed)
+    D = M * dsub
+    cb = rs.randn(M, Ks, dsub).astype(np.float32)
+    lat = rs.randn(N, 6).astype(np.float32) @ rs.randn(6, D).astype(np.float32)
+    x = (lat + 0.1 * rs.randn(N, D)).astype(np.float32)
+    q = (rs.randn(B, 6).astype(np.float32) @ rs.randn(6, D).astype(np.float32)).astype(np.float32)
+    kind = 1
+    if case == 'inf_coordinate':
+        q[3, 5] = np.inf
+        q[9, D - 1] = -np.inf
+    elif case == 'inf_query':
+        q[3, :] = np.inf
+    elif case == 'nan_query':
+        q[4, 0] = np.nan
+        q[11, :] = np.nan
+    elif case == 'ip_inf_query':
+        kind = 3  # float32(1/Ks) - <q, c>  (pq.py:316-322): +-inf and (0 * inf, inf - inf) NaN entries mixed
+        q[3, 5] = np.inf
+        q[9, 2] = -np.inf
+        cb[0, 7, :] = 0.0
+    elif case == 'huge_codewords_some':
+        cb[2, 17, :] = 1e30   # its L2 entries are (1e30)^2 = inf for every query
+        cb[5, 200, 1] = -3e25
+    elif case == 'huge_codewords_all':
+        cb *= 1e25
+    return cb, x, q, kind
+
+
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('M,dsub,k', [(16, 8, 10), (16, 8, 32), (32, 4, 10), (8, 8, 10), (64, 4, 10), (12, 4, 10)])
+def test_non_finite_inputs_equal_the_oracle(ops, oracle, case, M, dsub, k):
+    import torch
+    from annlite_amd._capi import LAYOUT_BMK, LAYOUT_TILED, scan_plan
+
+    N, B, Ks = 30_000, 21, 256
+    cb, x, q, kind = _nonfinite_inputs(case, M, dsub, N, B, Ks, seed=M * 100 + k)
+    codes = oracle.encode_c(x, np.where(np.isfinite(cb), cb, 0).astype(np.float32) if case.startswith('huge') else cb)
+    if case.startswith('huge'):
+        codes[::7, 2] = 17      # rows that use the overflowing code words ...
+        codes[::11, 5] = 200    # ... (their distances are +inf for every query)
+    omet = {1: oracle.EUCLIDEAN, 3: oracle.INNER_PRODUCT}[kind]
+    with np.errstate(all='ignore'):
+        lut = oracle.batch_precompute_adc_table_c(q, dsub, Ks, cb) if kind == 1 else oracle.get_dist_mat_c(q, cb, omet)
+        rd, ri = oracle.adc_search_c(lut, codes, k)
+    cb_d, q_d, codes_d = ops.to_dev(cb), ops.to_dev(q), ops.to_dev(codes)
+    lut_d = ops.lut_build(q_d, cb_d, kind, LAYOUT_BMK).cpu().numpy()
+    assert np.array_equal(lut_d, lut, equal_nan=True), 'tables differ'
+    for layout in ((0, 1) if M in (8, 16, 32, 64) else (0,)):
+        cd = ops.codes_skew(codes_d) if layout == 1 else codes_d
+        d, i = ops.pq_search_topk(kind, q_d, cb_d, cd, k, M, Ks, codes_layout=layout)   # tables built by the call
+        torch.cuda.synchronize()
+        assert np.array_equal(i.cpu().numpy(), ri), (case, layout, 'ids')
+        assert np.array_equal(d.cpu().numpy(), rd, equal_nan=True), (case, layout, 'distances')
+        plan = scan_plan(N, M, Ks, 1, B, k)
+        lt = ops.lut_build(q_d, cb_d, kind, LAYOUT_TILED if plan.fast else LAYOUT_BMK, plan.qi)
+        d, i = ops.adc_scan_topk(cd, lt, B, k, M, Ks, codes_layout=layout)               # tables handed over
+        assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(d.cpu().numpy(), rd, equal_nan=True), (case, layout, 'prebuilt')
+
+
+@pytest.mark.parametrize('case', ['inf_query', 'nan_query', 'huge_codewords_some'])
+def test_non_finite_inputs_through_the_index_plugin(ops, oracle, case):
+    """The same through ``PQFlatGpuIndex.search_batch`` (numpy in, sqrt epilogue of EUCLIDEAN, hnsw/index.py:164-165) incl. limit > 64
+    (the all-distances path) and the single-query ``search``: every valid row is a legitimate neighbour, whatever its distance."""
+    from annlite_amd import Metric, PQCodec, PQFlatGpuIndex
+
+    M, dsub, Ks, N, B = 16, 8, 256, 5_000, 13
+    cb, x, q, _ = _nonfinite_inputs(case, M, dsub, N, B, Ks, seed=77)
+    codec = PQCodec(dim=M * dsub, n_subvectors=M, n_clusters=Ks, metric=Metric.EUCLIDEAN).set_codebooks(cb)
+    idx = PQFlatGpuIndex(dim=M * dsub, metric=Metric.EUCLIDEAN, pq_codec=codec, initial_size=N)
+    idx.add_with_ids(x, np.arange(N))
+    codes = ops.codes_to_numpy(ops.pq_encode(ops.to_dev(x), codec.codebooks_dev))
+    for k in (10, 100):
+        with np.errstate(all='ignore'):
+            rd, ri = oracle.index_search(q, cb, codes, oracle.EUCLIDEAN, k)
+        d, i = idx.search_batch(q, limit=k)
+        assert np.array_equal(i, ri), (case, k)
+        assert np.array_equal(d, rd, equal_nan=True), (case, k)
+    d1, i1 = idx.search(q[3], limit=10)
+    assert np.array_equal(i1, ri[3][:10]) and len(d1) == 10
+
+
+# ------------------------------------------------------------------------------------ math.top_k wrapper
+def test_math_top_k_wrapper_edge_cases(ops, oracle):
+    """annlite/math.py:94-120: ``descending``, ``k >= n`` (full argsort branch), k beyond the wave kernel's 64 (device sort) --
+    values as the reference returns them, indices under the fixed tie-break (value, then index)."""
+    import torch
+    from annlite_amd import math as amath
+
+    rs = np.random.RandomState(3)
+    v = rs.randint(0, 40, size=(5, 300)).astype(np.float32)  # heavy ties
+    v[2, 17] = -np.inf
+    v[3, 5] = np.inf
+
+    def want(vals, k, descending):
+        w = -vals if descending else vals
+        idx = np.stack([np.lexsort((np.arange(w.shape[1]), w[b]))[:k] for b in range(w.shape[0])])
+        return np.take_along_axis(vals, idx, axis=1), idx
+
+    for k in (1, 10, 64, 65, 100, 300, 450):
+        for desc in (False, True):
+            d, i = amath.top_k(v, k, descending=desc)
+            wd, wi = want(v, min(k, v.shape[1]), desc)
+            assert d.shape == wd.shape and np.array_equal(i, wi), (k, desc)
+            assert np.array_equal(d, wd), (k, desc)
+            dt, it = amath.top_k(torch.from_numpy(v).cuda(), k, descending=desc)  # torch in -> torch out
+            assert isinstance(dt, torch.Tensor) and np.array_equal(it.cpu().numpy(), wi) and np.array_equal(dt.cpu().numpy(), wd)
+    # the oracle's own top-k (pinned to the reference's values by the golden fixture) agrees on a row
+    od, oi = oracle.top_k_c(v[1], 100)
+    d, i = amath.top_k(v[1:2], 100)
+    assert np.array_equal(d[0], od) and np.array_equal(i[0], oi)
+
+
+# ------------------------------------------------------------------------------------ limit > 64 across shards, re-rank pool
+def test_multi_gpu_index_limit_above_64(ops, oracle, tmp_path):
+    """``AnnLite(devices=[0, 0]).search(limit=100)``: every shard answers through its batched large-k path and the lists are merged by
+    (distance, id) on the device -- equal to the flat index (the merge kernel's wave lists end at k = 64)."""
+    from annlite_amd import AnnLite
+
+    rs = np.random.RandomState(21)
+    D, M, N, B = 64, 16, 6_000, 9
+    A = rs.randn(8, D).astype(np.float32)
+    x = (rs.randn(N, 8).astype(np.float32) @ A + 0.05 * rs.randn(N, D).astype(np.float32)).astype(np.float32)
+    x[3000:3030] = x[5]  # ties across shard blocks
+    q = np.concatenate([x[5:6], (rs.randn(B - 1, 8).astype(np.float32) @ A).astype(np.float32)])
+    from annlite_amd.index import Document, DocumentArray
+
+    flat = AnnLite(D, metric='euclidean', n_subvectors=M, data_path=tmp_path / 'flat')
+    flat.train(x[:4096])
+    multi = AnnLite(D, metric='euclidean', n_subvectors=M, data_path=tmp_path / 'multi', devices=[0, 0], shard_block=512)
+    multi._pq_codec.set_codebooks(flat._pq_codec.codebooks)
+    docs = lambda: DocumentArray([Document(id=str(i), embedding=x[i]) for i in range(N)])
+    flat.index(docs())
+    multi.index(docs())
+    for k in (65, 100, 700):
+        fd, fi = flat.search_numpy(q, limit=k)
+        md, mi = multi.search_numpy(q, limit=k)
+        for b in range(B):
+            assert np.array_equal(fd[b], md[b]), (k, b)
+            # equal distances may tie differently only where the sqrt merged two raw sums: ids agree as sets per distance value
+            if not np.array_equal(fi[b], mi[b]):
+                for val in np.unique(fd[b]):
+                    sel = fd[b] == val
+                    if val == fd[b][-1]:
+                        continue  # (a tie cut by k: either member may stay)
+                    assert set(fi[b][sel]) == set(mi[b][sel]), (k, b, val)
+
+
+def test_rerank_default_pool_with_few_slices(ops):
+    """A re-rank index over a SMALL table (the plan has one or two row slices) asked for k = 32: the default candidate pool must
+    exceed k (16 keys x 1 slice would hand the exact stage fewer rows than it has to return) -- k real hits, recall >= 0.9."""
+    from annlite_amd import Metric, PQCodec, PQFlatGpuIndex
+
+    rs = np.random.RandomState(8)
+    D, M, N, B, k = 64, 16, 9_000, 64, 32
+    A = rs.randn(8, D).astype(np.float32)
+    x = (rs.randn(N, 8).astype(np.float32) @ A + 0.05 * rs.randn(N, D).astype(np.float32)).astype(np.float32)
+    q = (rs.randn(B, 8).astype(np.float32) @ A + 0.05 * rs.randn(B, D).astype(np.float32)).astype(np.float32)
+    codec = PQCodec(dim=D, n_subvectors=M, n_clusters=256, metric=Metric.EUCLIDEAN, n_init=1)
+    codec.seed = 2
+    codec.fit(x[:4096], iter=10)
+    idx = PQFlatGpuIndex(dim=D, metric=Metric.EUCLIDEAN, pq_codec=codec, rerank=True, initial_size=N)
+    idx.add_with_ids(x, np.arange(N))
+    d, i = idx.search_batch(q, limit=k)
+    assert (i >= 0).all() and np.isfinite(d).all(), 'padding in a re-rank result although the table has the rows'
+    exact = ((q[:, None, :] - x[None, :, :]) ** 2).sum(-1)
+    truth = np.argsort(exact, axis=1)[:, :k]
+    recall = np.mean([len(set(i[b]) & set(truth[b])) / k for b in range(B)])
+    assert recall >= 0.9, recall
+    assert all(len(set(i[b])) == k for b in range(B))
+    d10, i10 = idx.search_batch(q, limit=10)  # k <= 16 on a table with few slices: the pool is still wider than k
+    recall10 = np.mean([len(set(i10[b]) & set(truth[b][:10])) / 10 for b in range(B)])
+    assert recall10 >= 0.9, recall10
+
+
+# ------------------------------------------------------------------------------------ lazy matches through the facade
+def test_facade_lazy_matches_equal_the_eager_documents(ops, tmp_path):
+    """``AnnLite.search`` attaches LAZY match lists: same ids / scores / metadata as documents built on the spot
+    (container.py:226-233), built only when read; ``search_numpy`` returns the same ids as ints."""
+    from annlite_amd import AnnLite
+    from annlite_amd.docarray_compat import LazyMatches
+    from annlite_amd.index import Document, DocumentArray
+
+    rs = np.random.RandomState(9)
+    N, D, B = 3000, 64, 50
+    X = rs.rand(N, D).astype(np.float32)
+    ann = AnnLite(D, data_path=tmp_path / 'idx', n_subvectors=8, metric='euclidean')
+    ann._pq_codec.seed = 1
+    ann.train(X)
+    ann.index(DocumentArray([Document(id=str(1000 + i), embedding=X[i], tags={'n': i}) for i in range(N)]))
+    ann.delete([str(1000 + 7)])
+    query = DocumentArray([Document(embedding=X[i]) for i in range(B)])
+    ann.search(query, limit=6)
+    dists, ids = ann.search_numpy(X[:B], limit=6)
+    d_raw, i_raw = ann._search_arrays(X[:B], None, 6)
+    for b, qd in enumerate(query):
+        assert isinstance(qd.matches, LazyMatches) and not qd.matches.materialised and len(qd.matches) == 6
+        got = [(m.id, m.scores['euclidean'].value, m.tags.get('n')) for m in qd.matches]
+        assert qd.matches.materialised
+        assert [g[0] for g in got] == [str(1000 + int(o)) for o in i_raw[b]]
+        assert [g[1] for g in got] == list(d_raw[b])
+        assert [g[2] for g in got] == [int(o) for o in i_raw[b]]
+        assert ids[b].tolist() == [1000 + int(o) for o in i_raw[b]] and np.array_equal(dists[b], d_raw[b])
+    assert '1007' not in [m.id for qd in query for m in qd.matches]
+    ann.search(query, limit=6, include_metadata=False)
+    assert query[0].matches[0].tags == {}
