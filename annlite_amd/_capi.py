@@ -69,6 +69,7 @@ SYMBOLS = (
     'annlite_debug_counters',
     'annlite_debug_timeline',
     'annlite_debug_items',
+    'annlite_debug_prep_timeline',
 )
 
 
@@ -153,6 +154,7 @@ def lib() -> ctypes.CDLL:
     L.annlite_debug_counters.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     L.annlite_debug_timeline.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     L.annlite_debug_items.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
+    L.annlite_debug_prep_timeline.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     L.annlite_graph_search_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     for name in SYMBOLS:
         fn = getattr(L, name)  # AttributeError here == the .so does not export a declared symbol
@@ -282,6 +284,16 @@ def debug_timeline():
     t0 = (1 << 62) - v[0]
     return {'items': v[7], 'span_us': (v[1] - t0) / 100.0, 'avg_start_us': (v[2] / n - t0) / 100.0,
             'build_us': v[3] / n / 100.0, 'scan_us': v[4] / n / 100.0, 'wait_us': v[5] / n / 100.0, 'merge_us': v[6] / n / 100.0}
+
+
+def debug_prep_timeline():
+    """Phase durations (microseconds) of the preparation launch's first and last workgroup (``annlite_debug_prep_timeline``):
+    [(build, seed rows, selection [+ byte tables]), ...] and the start of the last workgroup relative to the first."""
+    out = (ctypes.c_uint64 * 8)()
+    check(lib().annlite_debug_prep_timeline(out), 'debug_prep_timeline')
+    v = [int(x) for x in out]
+    ph = lambda o: {'build_us': (v[o + 1] - v[o]) / 100.0, 'seed_us': (v[o + 2] - v[o + 1]) / 100.0, 'select_us': (v[o + 3] - v[o + 2]) / 100.0}
+    return {'first': ph(0), 'last': ph(4), 'last_start_after_first_us': (v[4] - v[0]) / 100.0, 'span_us': (max(v[3], v[7]) - v[0]) / 100.0}
 
 
 def debug_items():

@@ -336,9 +336,10 @@ class PQFlatGpuIndex(BaseIndex):
             keys = (bits.to(torch.int64) << 32) | rows[None, :]
             keys = torch.where(vb[None, :], keys, key_none)  # deleted / never-written rows: behind every real row, NaN ones included
             top = torch.topk(keys, kk, dim=1, largest=False, sorted=True).values
-            si = top & 0xFFFFFFFF
-            sd = torch.where(top == key_none, inf, torch.gather(dist, 1, si))
-            si = torch.where(top == key_none, torch.full_like(si, -1), si)
+            none = top == key_none
+            si = torch.where(none, torch.zeros_like(top), top & 0xFFFFFFFF)
+            sd = torch.where(none, inf, torch.gather(dist, 1, si))
+            si = torch.where(none, torch.full_like(si, -1), si)
             ds.append(sd)
             is_.append(si)
         d, i = torch.cat(ds), torch.cat(is_)

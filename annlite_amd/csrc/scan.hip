@@ -465,6 +465,7 @@ extern "C" int annlite_scan_plan_tiles(int64_t N, int64_t M, int64_t Ks, int cod
 }
 
 static unsigned long long *g_dbg = nullptr;  // debug only (ANNLITE_DEBUG_COUNTERS): leaked device buffer: 16 counters + 4096 per-item records of 8
+static unsigned long long *g_dbg_prep = nullptr;  // ... and the preparation launch's 8 phase stamps (annlite_debug_prep_timeline)
 static thread_local int g_prof_on = 0;
 static thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 static thread_local int g_ev_valid = 0;
@@ -558,6 +559,10 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
     a.dbg_skip = getenv("ANNLITE_DEBUG_SKIP") ? atoi(getenv("ANNLITE_DEBUG_SKIP")) : 0;
     if (getenv("ANNLITE_DEBUG_COUNTERS") && !(gopt && gopt->gate)) {  // (the gated pass leaves the first launch's counters alone)
         if (!g_dbg) ANNLITE_HIP_TRY(hipMalloc((void **)&g_dbg, 128 + 4096 * 64));
+        if (!g_dbg_prep) {
+            ANNLITE_HIP_TRY(hipMalloc((void **)&g_dbg_prep, 64));
+            ANNLITE_HIP_TRY(hipMemset(g_dbg_prep, 0, 64));
+        }
         ANNLITE_HIP_TRY(hipMemsetAsync(g_dbg, 0, 128, st));
         a.dbg = g_dbg;
         if (atoi(getenv("ANNLITE_DEBUG_COUNTERS")) == 2) a.dbg_skip |= 8;  // phase stamps only (annlite_debug_timeline): the
@@ -709,9 +714,20 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             const bool one_prep = c.mode == 5 && build && S > 0 && M == 16 && build->D <= 256 && ((build->D / M) % 4) == 0 &&
                                   !getenv("ANNLITE_NO_FUSED_SEED");
             if (one_prep) {
+                // ... and the scan work items' FIRST byte tables, once per query tile instead of once per (tile, slice) work item
+                // (ANNLITE_NO_PREBUILT_TABLES: the workgroups convert the fp32 tables themselves, as before round 4 -- A/B switch)
+                unsigned long long *gseed0 = nullptr;
+                uint8_t *btab = nullptr;
+                if (!getenv("ANNLITE_NO_PREBUILT_TABLES")) {
+                    gseed0 = (unsigned long long *)carve(bpad * 8);
+                    btab = (uint8_t *)carve((int64_t)a.n_tiles * Ks * 2 * M * 16);  // (inside the region the u16 plan uses for q16)
+                }
                 rc = launch_seed_build(codes_layout == ANNLITE_CODES_SKEWED, codes_dev, S, valid_bits_dev, *build, const_cast<float *>(lut_dev),
-                                       B, Ks, k, qstep, qlo, smax, qlom, gk, workspace_dev, fill_bytes, (size_t)(((bpad * 8 + 255) / 256) * 256), st);
+                                       B, Ks, k, qstep, qlo, smax, qlom, gk, workspace_dev, fill_bytes, (size_t)(((bpad * 8 + 255) / 256) * 256), st,
+                                       gseed0, btab, a.q8_target, a.dbg ? g_dbg_prep : nullptr);
                 if (rc != ANNLITE_OK) return rc;
+                a.gseed0 = gseed0;
+                a.btab = btab;
             } else {
                 const unsigned int *gate = (gopt && c.mode != 5) ? gopt->gate : nullptr;
                 rc = launch_lut_quantise(M, Ks, Bq, ((Bq + 15) / 16) * 16, (tm && build) ? nullptr : lut_dev, build, q16, qstep,
@@ -782,6 +798,17 @@ extern "C" int annlite_debug_timeline(uint64_t *out8) {
     }
     ANNLITE_HIP_TRY(hipDeviceSynchronize());
     ANNLITE_HIP_TRY(hipMemcpy(out8, g_dbg + 8, 64, hipMemcpyDeviceToHost));
+    return ANNLITE_OK;
+}
+
+extern "C" int annlite_debug_prep_timeline(uint64_t *out8) {
+    ANNLITE_REQUIRE(out8 != nullptr, "out8 is NULL");
+    if (!g_dbg_prep) {
+        set_error("no stamps recorded (set ANNLITE_DEBUG_COUNTERS before a search through annlite_pq_search_topk)");
+        return ANNLITE_ERR_INVALID;
+    }
+    ANNLITE_HIP_TRY(hipDeviceSynchronize());
+    ANNLITE_HIP_TRY(hipMemcpy(out8, g_dbg_prep, 64, hipMemcpyDeviceToHost));
     return ANNLITE_OK;
 }
 

@@ -72,6 +72,10 @@ struct ScanArgs {
     const unsigned int *gate;           // u16 kernels: run only if *gate == 0 (NULL: always)
     unsigned int *host_stats;           // host-mapped, optional: the last workgroup writes [1] gave up, [2..3] candidates, [4] B,
     uint32_t stats_seq;                 // [5] N (low 32 bits), then [0] = stats_seq
+    // byte tables PREBUILT by the preparation launch (seed_bound_kernel<..., BUILD>; M = 16): the 8 workgroups of a query tile
+    // copy their first table (128 KB, L2) instead of each converting the tile's 512 KB of fp32 tables
+    const unsigned long long *gseed0;   // [ceil32(B)] the seed keys as the preparation launch left them (gkey moves on: atomic min)
+    const uint8_t *btab;                // [n_tiles][Ks * 2 * 16 * 16 B] LDS images, quantised for gseed0; NULL: the workgroups build
 };
 
 // work item -> (query tile, row slice).  item % 8 == blockIdx % 8 == the XCD the block lands on (speed
@@ -243,6 +247,73 @@ constexpr int kGk2Keys = ANNLITE_GK2_KEYS;
 // measured 5 % on the config-4 shape -- 0.95 against 0.90 ms per launch)
 __host__ __device__ constexpr int gk2_cell_keys(int64_t M) { return M == 64 ? 1 : kGk2Keys; }
 
+// ---- byte-table kernel (scan_q8.hip): shape constants and slot parameters, shared with the preparation launch (scan_prep.hip) ----
+// Q8Cfg: entries are clipped at QMAX; a slot without a bound yet ("open": nothing seeded it) clips at QOPEN so that its T
+// passes every row.  M <= 32: the byte sums ARE the filter sums (M * QMAX <= 240: a byte sum never carries), bounds are bytes
+// (0x80 | T, T <= 127), 32 queries per workgroup.  M = 64 (WIDE): 8 queries per 8-byte entry, the byte sums of 16 look-ups
+// (16 * 15 = 240) are widened into u16 sums four times per row, bounds are half-words (0x8000 | T), 8 queries per workgroup.
+template <int M>
+struct Q8Cfg {
+    static constexpr bool WIDE = M == 64;
+    static constexpr bool M8 = M == 8;  // M = 8: table [Ks][NQ entry groups][8 sub-spaces][16 B], permute addressing (see the kernel)
+    static constexpr int QMAX = WIDE ? 15 : 240 / M, QOPEN = WIDE ? 7 : 112 / M;
+    static constexpr uint32_t TMAX = WIDE ? 32767u : 127u, TFLAG = TMAX + 1u;
+};
+// NQ = entry groups of 16 queries per workgroup (the second shape parameter): 2 everywhere but M = 8 with 512 < Ks <= 1024,
+// where only one group's table fits the LDS (WIDE: 8 queries whatever NQ says)
+template <int M, int NQ>
+constexpr int q8_qt() { return Q8Cfg<M>::WIDE ? 8 : 16 * NQ; }
+template <int M, int NQ>
+__device__ __forceinline__ int q8_table_bytes(int Ks) {
+    return Q8Cfg<M>::WIDE ? (Ks + 1) * 512 : Ks * NQ * M * 16;  // WIDE: two half tables of 32 sub-spaces, [Ks + 1][32][8 B] each
+}
+
+// filter bound (TFLAG | T) implied by a k-th key for a table quantised with `step`:
+// T = floor((thr + slack32 - L) / step * (1 + 2^-19)) + 1, clamped to TMAX (a NaN lands there too: everything passes)
+template <int M>
+__device__ __forceinline__ uint32_t q8_bound_from_key(unsigned long long key, float smax_b, float step, double qlo_b) {
+    const uint32_t hi = (uint32_t)(key >> 32);
+    if (hi == kKeyInfHi) return 2u * Q8Cfg<M>::TFLAG - 1u;
+    const double thr = (double)ordered_to_f32(hi);
+    const double slack = (double)smax_b * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
+    double qd = (thr + slack - qlo_b) / (double)step * (1.0 + 1.0 / 524288.0);
+    qd = __builtin_floor(qd) + 1.0;
+    if (!(qd < (double)Q8Cfg<M>::TMAX)) qd = (double)Q8Cfg<M>::TMAX;  // (a NaN lands HERE: everything passes)
+    else if (!(qd > 0.0)) qd = 0.0;
+    return Q8Cfg<M>::TFLAG | (uint32_t)qd;
+}
+
+template <int M>
+__device__ __forceinline__ void q8_slot_params(bool real, unsigned long long key, float range, float smax_b, double L, int target,
+                                               float &step, float &inv, float &clip, uint32_t &tbits) {
+    clip = (float)Q8Cfg<M>::QOPEN;
+    if (!real) {  // pad slot: all-zero table, never passes (TMAX - 0 has the flag bit clear)
+        step = 1.f;
+        inv = 0.f;
+        tbits = Q8Cfg<M>::TMAX;
+        return;
+    }
+    float open_step = range / (float)Q8Cfg<M>::QOPEN;  // no bound yet: the whole range, everything passes (S <= M * QOPEN <= TMAX)
+    if (!(open_step > 1e-30f) || !(open_step < 1e30f)) open_step = 1.f;
+    step = open_step;
+    const uint32_t hi = (uint32_t)(key >> 32);
+    if (hi != kKeyInfHi) {
+        const double thr = (double)ordered_to_f32(hi);
+        const double slack = (double)smax_b * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
+        const double R = thr + slack - L;
+        if (R > 0.0 && R < 1e30) {
+            float s = (float)(R / (double)(target - 1));  // T = target right after a (re)build
+            const float smin = open_step * (1.f / 65536.f);
+            if (!(s >= smin)) s = smin;  // (a larger step only lowers T)
+            step = s;
+            clip = (float)Q8Cfg<M>::QMAX;  // T <= target now and it only falls
+        }
+    }
+    inv = 1.0f / step;
+    tbits = q8_bound_from_key<M>(key, smax_b, step, L);
+}
+
+
 // ---- launchers of the scan kernels, one translation unit per kernel family -----------------------
 // (scan_q8.hip: byte filter tables; scan_qfilter.hip: u16 filter tables, tile mode; scan_prep.hip: table build /
 // quantisation parameters / seed bound)
@@ -264,8 +335,12 @@ int launch_seed_bound(int64_t M, bool skewed, const void *codes_dev, int code_by
                       const unsigned int *gate = nullptr);
 
 // byte-table plan: table build + quantisation parameters + workspace reset + seed bound in one launch (scan_prep.hip)
+// gseed0 / btab (optional, both or none): the seed keys kept aside and the byte tables of every query tile quantised for them
+// with `target` (ScanArgs::q8_target); dbg (optional): 8 phase stamps of the first and the last workgroup
 int launch_seed_build(bool skewed, const void *codes_dev, int64_t S, const uint32_t *valid_bits_dev, const LutBuild &build,
                       float *lut_out, int64_t B, int64_t Ks, int64_t k, float *qstep, double *qlo, float *smax, float *qlom,
-                      unsigned long long *gkey, void *fill, size_t fill_bytes, size_t gkey_bytes, hipStream_t st);
+                      unsigned long long *gkey, void *fill, size_t fill_bytes, size_t gkey_bytes, hipStream_t st,
+                      unsigned long long *gseed0 = nullptr, uint8_t *btab = nullptr, int target = 0,
+                      unsigned long long *dbg = nullptr);
 
 }  // namespace annlite

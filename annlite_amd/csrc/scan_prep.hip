@@ -120,7 +120,18 @@ struct SeedBuild {
     int64_t fill_vec16, skip_lo, skip_hi;
     int32_t D, qmax;
     const unsigned int *gate;  // (any launch) run only if *gate == 0: the u16-table pass behind a byte-table launch that may give up
+    // BUILD, optional: the byte tables of the scan kernel's work items, built HERE once per query (the workgroup holds its 4
+    // queries' fp32 tables in LDS and knows their seed bound) instead of by each of the tile's 8 scan workgroups from L2
+    unsigned long long *gseed0;  // [..] the seed key of every query, kept aside (gkey itself is lowered by the scan)
+    uint8_t *btab;               // [n_tiles][Ks][2][16][16 B]: this workgroup writes its queries' dword of every entry
+    int32_t target;              // T of a freshly built table (ScanArgs::q8_target)
+    unsigned long long *dbg;     // optional: wall-clock stamps (100 MHz) of workgroup 0 [0..3] and the last one [4..7]:
+                                 // start, tables built, rows scanned, end
 };
+// LDS behind the fp32 tables: [0, 16 KB) the selection's candidates u32 [QPB][16 waves * k] (BUILD: first the queries, the
+// per-wave column minima / maxima), [16 KB, 20 KB) the waves' 64 lane minima, then the block counter and what the BUILD
+// variant keeps until its end (column minima, parameters, seed keys)
+constexpr int kSeedWkeyOff = 16384, kSeedCtrOff = 20480, kSeedKeepOff = 20544, kSeedLdsExtra = 24576;
 // QPB queries per workgroup: 4 (one fp32 TILED group) where their rows fit the LDS, 2 for M = 64
 // CODE16: uint16 codes (PLAIN tables)
 template <int M, bool SKEWED, int QPB, bool CODE16 = false, bool BUILD = false>
@@ -134,6 +145,13 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
     static_assert(!(CODE16 && SKEWED), "uint16 code tables are PLAIN");
     static_assert(!BUILD || (QPB == 4 && !CODE16 && M <= 16), "the fused build serves the byte-table plan");
     if (sb.gate && __hip_atomic_load(sb.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    auto stamp = [&](int i) {
+        if constexpr (BUILD) {
+            if (sb.dbg && threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
+                sb.dbg[(blockIdx.x == 0 ? 0 : 4) + i] = wall_clock64();
+        }
+    };
+    stamp(0);
     // blockIdx.y = row slice (per-slice bounds of the candidate generator: rows [y * seed_stride, + S), bound ->
     // gkey[y * gkey_stride + b]; seed_stride is a multiple of 64, so the lanes keep their skew residues); one slice: the first S rows
     {
@@ -169,7 +187,7 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
         float *s_q = (float *)cand;                                  // [4][D]
         float *s_lo = (float *)((unsigned char *)cand + 4096);       // [16 waves][M][4]
         float *s_hi = s_lo + kSeedWaves * M * 4;
-        float *s_par = s_hi + kSeedWaves * M * 4 + 4;                // [4] smax (behind the block counter)
+        float *s_par = (float *)((unsigned char *)cand + kSeedKeepOff);  // [4] smax, [4] step; then L f64 [4], seed keys u64 [4], lo f32 [M][4]
         const int D = sb.D, dsub = D / M;
         for (int i = tid; i < 4 * D; i += kSeedWaves * 64) {
             const int b = g4 * 4 + i / D;
@@ -225,6 +243,7 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
             s_lo[mm * 4 + i] = l;
             s_hi[mm * 4 + i] = hh;
             sb.qlom[(int64_t)(g4 * 4 + i) * M + mm] = l;
+            s_par[24 + mm * 4 + i] = l;  // (kept: the byte tables are quantised after the selection has reused s_lo)
         }
         __syncthreads();
         if (tid < 4) {
@@ -243,12 +262,16 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
             sb.qlo[b] = Lsum;
             sb.smax[b] = sm;
             s_par[tid] = sm;
+            s_par[4 + tid] = step;
+            ((double *)(s_par + 8))[tid] = Lsum;
+            ((unsigned long long *)(s_par + 16))[tid] = ~0ull;
             gkey[b] = ~0ull;  // (the fill leaves the bounds to this kernel; the selection below overwrites it)
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) smax_built[i] = s_par[i];
         __syncthreads();  // (cand is reused by the selection)
+        stamp(1);
     } else {
         const f32x4 *src = (const f32x4 *)lut + (int64_t)g4 * Ks * M;
         for (int i = tid; i < Ks * M; i += kSeedWaves * 64) {
@@ -259,7 +282,7 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
     }
     // the waves draw their blocks of 64 rows from this counter (see adc_scan_q8_kernel: a static deal leaves the waves the
     // SIMD's arbiter does not favour to finish alone, at a third of the issue rate)
-    uint32_t *blk_ctr = (uint32_t *)((unsigned char *)cand + 12288);  // (cand / minima use the first 8 KB of their 16)
+    uint32_t *blk_ctr = (uint32_t *)((unsigned char *)cand + kSeedCtrOff);
     if (tid == 0) *blk_ctr = 0;
     __syncthreads();
     // forward skew rotation of PLAIN rows (row % M == lane % M: the rows of a wave start at a multiple of 64); SKEWED
@@ -355,19 +378,19 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
     uint32_t best[QPB];  // ordered distance keys (a lane that saw no valid row: key(+inf), as before 0xffffffff | ... below)
 #pragma unroll
     for (int q = 0; q < QPB; ++q) best[q] = bestf[q] < __builtin_inff() ? f32_to_ordered(bestf[q]) : 0xffffffffu;
+    stamp(2);
     // Selection keys: the low 10 bits of the ordered distance are replaced by (wave, lane), which makes the
     // 1024 keys of a query unique (rank = number of smaller keys, no tie handling) and costs at most 1023
     // ulps of tightness: the k smallest keys T_i bound k distinct rows by (T_i | 1023).
+    // All QPB queries go through the two ranking passes TOGETHER: a wave ranks its 64 lane minima query after query (its own
+    // LDS traffic is in order: no barrier), ONE barrier, then thread t ranks candidate t % nc of query t / nc.  (One query
+    // at a time -- two barriers and a 160-step serial ranking loop each -- was ~5 us of the launch.)
     const int nc = kSeedWaves * k;  // candidates per query
-    uint32_t *cand32 = (uint32_t *)cand;                                  // [kSeedWaves][k]
-    uint32_t *wkeys = (uint32_t *)cand + kSeedWaves * 64 + wave * 64;     // this wave's 64 lane minima
-#pragma unroll 1
-    for (int q = 0; q < QPB; ++q) {
-        uint32_t mine = best[0];
+    uint32_t *cand32 = (uint32_t *)cand;                                                        // [QPB][kSeedWaves * k]
+    uint32_t *wkeys = (uint32_t *)((unsigned char *)cand + kSeedWkeyOff) + wave * 64;          // this wave's 64 lane minima
 #pragma unroll
-        for (int qq = 1; qq < QPB; ++qq)
-            if (q == qq) mine = best[qq];
-        mine = (mine & ~1023u) | (uint32_t)(wave << 6) | (uint32_t)lane;
+    for (int q = 0; q < QPB; ++q) {
+        const uint32_t mine = (best[q] & ~1023u) | (uint32_t)(wave << 6) | (uint32_t)lane;
         // rank among the wave's 64: all lanes read the 64 keys back with wave-uniform addresses (broadcast)
         wkeys[lane] = mine;
         int rank = 0;
@@ -376,31 +399,82 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
             const u32x4 o = *(const u32x4 *)(wkeys + j);
             rank += (o.x < mine) + (o.y < mine) + (o.z < mine) + (o.w < mine);
         }
-        if (rank < k) cand32[wave * k + rank] = mine;
-        __syncthreads();
-        // the k-th smallest of the 16*k candidates, same way: thread t ranks candidate t
-        for (int t = tid; t < nc; t += kSeedWaves * 64) {
-            const uint32_t me = cand32[t];
-            int rk = 0;
+        if (rank < k) cand32[q * nc + wave * k + rank] = mine;
+        asm volatile("" ::: "memory");  // (the next query's keys go into the same 64 slots: after these reads)
+    }
+    __syncthreads();
+    // the k-th smallest of every query's 16*k candidates, same way
+    for (int t = tid; t < QPB * nc; t += kSeedWaves * 64) {
+        const int q = t / nc;
+        const uint32_t *cq = cand32 + q * nc;
+        const uint32_t me = cq[t - q * nc];
+        int rk = 0;
 #pragma unroll 8
-            for (int j = 0; j < nc; ++j) rk += cand32[j] < me;
-            const int b = g4 * 4 + h * QPB + q;
-            // the bound admits every row at or below (me | 1023), whatever its id; +1 in the distance field
-            // because the seed rows are in nobody's list: the scan must still ACCEPT the rows that set it
-            if (rk == k - 1 && b < B && (me | 1023u) != 0xffffffffu) {
-                // + the rounding margin between this sum order and the reference's, rounded up
-                float sm_b;
-                if constexpr (BUILD) sm_b = q == 0 ? smax_built[0] : q == 1 ? smax_built[1] : q == 2 ? smax_built[2] : smax_built[3];
-                else sm_b = smax[b];
-                const float slack = sm_b * (float)(2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
-                float thr = ordered_to_f32(me | 1023u);
-                thr = thr + slack;
-                const uint32_t key = f32_to_ordered(thr) + 1u;
-                gkey[b] = ((unsigned long long)key + 1ull) << 32;
+        for (int j = 0; j < nc; ++j) rk += cq[j] < me;
+        const int b = g4 * 4 + h * QPB + q;
+        // the bound admits every row at or below (me | 1023), whatever its id; +1 in the distance field
+        // because the seed rows are in nobody's list: the scan must still ACCEPT the rows that set it
+        if (rk == k - 1 && b < B && (me | 1023u) != 0xffffffffu) {
+            // + the rounding margin between this sum order and the reference's, rounded up
+            float sm_b;
+            if constexpr (BUILD) sm_b = q == 0 ? smax_built[0] : q == 1 ? smax_built[1] : q == 2 ? smax_built[2] : smax_built[3];
+            else sm_b = smax[b];
+            const float slack = sm_b * (float)(2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
+            float thr = ordered_to_f32(me | 1023u);
+            thr = thr + slack;
+            const uint32_t key = f32_to_ordered(thr) + 1u;
+            const unsigned long long bound = ((unsigned long long)key + 1ull) << 32;
+            gkey[b] = bound;
+            if constexpr (BUILD) ((unsigned long long *)((float *)((unsigned char *)cand + kSeedKeepOff) + 16))[q] = bound;
+        }
+    }
+    if constexpr (BUILD) {
+        if (sb.btab) {
+            // ---- the scan kernel's byte tables for these 4 queries, quantised for their seed bound: exactly what the scan
+            // workgroups would build (q8_slot_params from the seed key, q8_build_table's conversion) -- built ONCE here, from
+            // the fp32 tables still in LDS, instead of by the 8 workgroups of the tile from L2.  Query b = g4 * 4 + i sits in
+            // tile b / 32, entry group (b % 32) / 16, byte b % 16 of an entry: this workgroup owns dword (b % 16) / 4. ----------
+            __syncthreads();  // (the seed keys are in; the selection's LDS is dead)
+            float *par = (float *)((unsigned char *)cand + kSeedKeepOff);
+            float *s_inv = (float *)cand, *s_clip = s_inv + 4;
+            if (tid < 4) {
+                const int b = g4 * 4 + tid;
+                const bool real = b < B;
+                const unsigned long long key0 = ((const unsigned long long *)(par + 16))[tid];
+                float step, inv, clip;
+                uint32_t tb;
+                q8_slot_params<M>(real, key0, real ? par[4 + tid] * (float)(32767 / M) : 0.f, real ? par[tid] : 0.f,
+                                  real ? ((const double *)(par + 8))[tid] : 0.0, sb.target, step, inv, clip, tb);
+                s_inv[tid] = real ? inv : 0.f;
+                s_clip[tid] = clip;
+                sb.gseed0[b] = key0;
+            }
+            __syncthreads();
+            constexpr int KPT = kSeedWaves * 64 / M, NSW = 256 / KPT;
+            const int m = tid % M, kr = tid / M;
+            const int q0 = (g4 * 4) & 31;
+            uint32_t *bt = (uint32_t *)(sb.btab + (int64_t)((g4 * 4) >> 5) * ((int64_t)Ks * 2 * M * 16)) + (q0 >> 4) * (M * 4) + ((q0 & 15) >> 2);
+            float lo_r[4], inv_r[4], clip_r[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lo_r[i] = par[24 + m * 4 + i], inv_r[i] = s_inv[i], clip_r[i] = s_clip[i];
+#pragma unroll
+            for (int sw = 0; sw < NSW; ++sw) {
+                const int kk = kr + sw * KPT;
+                if (kk < Ks) {
+                    const fq v = tab[kk * M + m];
+                    uint32_t pk = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = __builtin_fmaf(v[e] - lo_r[e], inv_r[e], -0.5f);
+                        t = __builtin_fminf(t, clip_r[e]);
+                        pk = __builtin_amdgcn_cvt_pk_u8_f32(t, e, pk);  // saturates below 0 (q8_build_table's conversion)
+                    }
+                    bt[((int64_t)kk * 2 * M + m) * 4] = pk;
+                }
             }
         }
-        __syncthreads();
     }
+    stamp(3);
 }
 
 // ---- quantisation of the fp32 TILED table [Bpad/4][Ks][M][4] -------------------------------------
@@ -768,7 +842,7 @@ int annlite::launch_seed_bound(int64_t M, bool skw, const void *codes_dev, int c
 #define ANNLITE_SEED(MM, QPB_)                                                                                    \
     {                                                                                                             \
         auto fn = skw ? seed_bound_kernel<MM, true, QPB_> : seed_bound_kernel<MM, false, QPB_>;                   \
-        const size_t lds = (size_t)Ks * MM * 4 * QPB_ + (size_t)2 * kSeedWaves * 64 * 8; /* cand + minima */         \
+        const size_t lds = (size_t)Ks * MM * 4 * QPB_ + (size_t)kSeedLdsExtra; /* cand + minima + counter */         \
         ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(fn, dim3((unsigned)(((B + 3) / 4) * (4 / QPB_)), ny), dim3(kSeedWaves * 64), lds, st,  \
                            (const uint8_t *)codes_dev, S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, smax, gk,    \
@@ -778,7 +852,7 @@ int annlite::launch_seed_bound(int64_t M, bool skw, const void *codes_dev, int c
 #define ANNLITE_SEED16(MM)                                                                                         \
     {                                                                                                             \
         auto fn = seed_bound_kernel<MM, false, 4, true>;                                                          \
-        const size_t lds = (size_t)Ks * MM * 16 + (size_t)2 * kSeedWaves * 64 * 8;                                 \
+        const size_t lds = (size_t)Ks * MM * 16 + (size_t)kSeedLdsExtra;                                          \
         ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(fn, dim3((unsigned)((B + 3) / 4), ny), dim3(kSeedWaves * 64), lds, st, (const uint8_t *)codes_dev, \
                            S, valid_bits_dev, lut_dev, (int)B, (int)Ks, (int)k, smax, gk, seed_stride, N, gstride, nob); \
@@ -798,7 +872,8 @@ int annlite::launch_seed_bound(int64_t M, bool skw, const void *codes_dev, int c
 // seed bound from the first S rows.
 int annlite::launch_seed_build(bool skw, const void *codes_dev, int64_t S, const uint32_t *valid_bits_dev, const LutBuild &build,
                                float *lut_out, int64_t B, int64_t Ks, int64_t k, float *qstep, double *qlo, float *smax, float *qlom,
-                               unsigned long long *gk, void *fill, size_t fill_bytes, size_t gk_bytes, hipStream_t st) {
+                               unsigned long long *gk, void *fill, size_t fill_bytes, size_t gk_bytes, hipStream_t st,
+                               unsigned long long *gseed0, uint8_t *btab, int target, unsigned long long *dbg) {
     constexpr int M = 16;
     SeedBuild sb;
     sb.queries = build.queries;
@@ -815,8 +890,12 @@ int annlite::launch_seed_build(bool skw, const void *codes_dev, int64_t S, const
     sb.D = (int32_t)build.D;
     sb.qmax = 32767 / M;
     sb.gate = nullptr;
+    sb.gseed0 = (gseed0 && btab) ? gseed0 : nullptr;
+    sb.btab = (gseed0 && btab) ? btab : nullptr;
+    sb.target = target;
+    sb.dbg = dbg;
     auto fn = skw ? seed_bound_kernel<M, true, 4, false, true> : seed_bound_kernel<M, false, 4, false, true>;
-    const size_t lds = (size_t)Ks * M * 16 + (size_t)2 * kSeedWaves * 64 * 8;
+    const size_t lds = (size_t)Ks * M * 16 + (size_t)kSeedLdsExtra;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned n_g4 = (unsigned)(((B + 15) / 16) * 4);
     hipLaunchKernelGGL(fn, dim3(n_g4, 1), dim3(kSeedWaves * 64), lds, st, (const uint8_t *)codes_dev, S, valid_bits_dev,

@@ -91,71 +91,8 @@ __device__ __forceinline__ uint32_t lds_base_addr() {
     return (uint32_t)(uintptr_t)(ANNLITE_LDS unsigned char *)g_smem;
 }
 
-// Q8Cfg: entries are clipped at QMAX; a slot without a bound yet ("open": nothing seeded it) clips at QOPEN so that its T
-// passes every row.  M <= 32: the byte sums ARE the filter sums (M * QMAX <= 240: a byte sum never carries), bounds are bytes
-// (0x80 | T, T <= 127), 32 queries per workgroup.  M = 64 (WIDE): 8 queries per 8-byte entry, the byte sums of 16 look-ups
-// (16 * 15 = 240) are widened into u16 sums four times per row, bounds are half-words (0x8000 | T), 8 queries per workgroup.
-template <int M>
-struct Q8Cfg {
-    static constexpr bool WIDE = M == 64;
-    static constexpr bool M8 = M == 8;  // M = 8: table [Ks][NQ entry groups][8 sub-spaces][16 B], permute addressing (see the kernel)
-    static constexpr int QMAX = WIDE ? 15 : 240 / M, QOPEN = WIDE ? 7 : 112 / M;
-    static constexpr uint32_t TMAX = WIDE ? 32767u : 127u, TFLAG = TMAX + 1u;
-};
-// NQ = entry groups of 16 queries per workgroup (the second shape parameter): 2 everywhere but M = 8 with 512 < Ks <= 1024,
-// where only one group's table fits the LDS (WIDE: 8 queries whatever NQ says)
-template <int M, int NQ>
-constexpr int q8_qt() { return Q8Cfg<M>::WIDE ? 8 : 16 * NQ; }
-template <int M, int NQ>
-__device__ __forceinline__ int q8_table_bytes(int Ks) {
-    return Q8Cfg<M>::WIDE ? (Ks + 1) * 512 : Ks * NQ * M * 16;  // WIDE: two half tables of 32 sub-spaces, [Ks + 1][32][8 B] each
-}
-
-// filter bound (TFLAG | T) implied by a k-th key for a table quantised with `step`:
-// T = floor((thr + slack32 - L) / step * (1 + 2^-19)) + 1, clamped to TMAX (a NaN lands there too: everything passes)
-template <int M>
-__device__ __forceinline__ uint32_t q8_bound_from_key(unsigned long long key, float smax_b, float step, double qlo_b) {
-    const uint32_t hi = (uint32_t)(key >> 32);
-    if (hi == kKeyInfHi) return 2u * Q8Cfg<M>::TFLAG - 1u;
-    const double thr = (double)ordered_to_f32(hi);
-    const double slack = (double)smax_b * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
-    double qd = (thr + slack - qlo_b) / (double)step * (1.0 + 1.0 / 524288.0);
-    qd = __builtin_floor(qd) + 1.0;
-    if (!(qd < (double)Q8Cfg<M>::TMAX)) qd = (double)Q8Cfg<M>::TMAX;  // (a NaN lands HERE: everything passes)
-    else if (!(qd > 0.0)) qd = 0.0;
-    return Q8Cfg<M>::TFLAG | (uint32_t)qd;
-}
-
-template <int M>
-__device__ __forceinline__ void q8_slot_params(bool real, unsigned long long key, float range, float smax_b, double L, int target,
-                                               float &step, float &inv, float &clip, uint32_t &tbits) {
-    clip = (float)Q8Cfg<M>::QOPEN;
-    if (!real) {  // pad slot: all-zero table, never passes (TMAX - 0 has the flag bit clear)
-        step = 1.f;
-        inv = 0.f;
-        tbits = Q8Cfg<M>::TMAX;
-        return;
-    }
-    float open_step = range / (float)Q8Cfg<M>::QOPEN;  // no bound yet: the whole range, everything passes (S <= M * QOPEN <= TMAX)
-    if (!(open_step > 1e-30f) || !(open_step < 1e30f)) open_step = 1.f;
-    step = open_step;
-    const uint32_t hi = (uint32_t)(key >> 32);
-    if (hi != kKeyInfHi) {
-        const double thr = (double)ordered_to_f32(hi);
-        const double slack = (double)smax_b * (2.0 * M * 5.9604644775390625e-08 * (1.0 + 1.0 / 1024.0));
-        const double R = thr + slack - L;
-        if (R > 0.0 && R < 1e30) {
-            float s = (float)(R / (double)(target - 1));  // T = target right after a (re)build
-            const float smin = open_step * (1.f / 65536.f);
-            if (!(s >= smin)) s = smin;  // (a larger step only lowers T)
-            step = s;
-            clip = (float)Q8Cfg<M>::QMAX;  // T <= target now and it only falls
-        }
-    }
-    inv = 1.0f / step;
-    tbits = q8_bound_from_key<M>(key, smax_b, step, L);
-}
-
+// (Q8Cfg, q8_qt, q8_table_bytes, q8_bound_from_key, q8_slot_params: scan_common.h -- the preparation launch computes the same
+// parameters when it prebuilds the byte tables)
 // The workgroup's byte table from the fp32 TILED tables of its 32 queries: thread (m, h) = (tid % M, (tid / M) % 2)
 // keeps the minima and 1/step of its 16 queries in registers and walks the codes.  RNE(t - 0.5) <= floor(t): the
 // conversion's rounding mode does not matter for the bound.
@@ -172,7 +109,32 @@ struct Q8Build {  // what a (re)build needs, gathered from the kernarg segment i
     const double *qlo;
     const unsigned long long *gkey;  // first bounds: the shared array, or this slice's row of the per-slice seeds, or NULL
     int32_t Ks, B, k, target;
+    const unsigned long long *gseed0;  // prebuilt first tables (ScanArgs::btab): the seed keys they were quantised for
+    const uint8_t *btab;
 };
+
+// First table of a work item where the preparation launch has prebuilt it (ScanArgs::btab): the tile's LDS image, 16-byte
+// loads from L2, instead of converting the tile's fp32 tables (4x the bytes, and the conversion).  Entry groups of 4 queries
+// beyond the batch (a ragged last tile: nobody wrote their dword) are zeroed -- the all-zero table of a pad slot.
+template <int M, int NW, int NQ>
+__device__ __forceinline__ void q8_copy_table(const Q8Build &a, int tile, uint32_t tab_ad, int tid) {
+    constexpr int NT = NW * 64;
+    const int n16 = a.Ks * NQ * M;  // 16-byte entries
+    const int n_g4 = ((a.B + 15) / 16) * 4;
+    const u32x4 *src = (const u32x4 *)(a.btab + (int64_t)tile * ((int64_t)n16 * 16));
+#pragma unroll 4
+    for (int i = tid; i < n16; i += NT) {
+        u32x4 v = src[i];
+        const int g4 = tile * (4 * NQ) + ((i / M) % NQ) * 4;
+        if (g4 + 3 >= n_g4) {
+            if (g4 + 0 >= n_g4) v.x = 0u;
+            if (g4 + 1 >= n_g4) v.y = 0u;
+            if (g4 + 2 >= n_g4) v.z = 0u;
+            v.w = 0u;
+        }
+        *(ANNLITE_LDS u32x4 *)(uintptr_t)(tab_ad + 16u * (uint32_t)i) = v;
+    }
+}
 
 template <int M, int NW, int NQ>
 __device__ __forceinline__ void q8_build_table(const Q8Build &a, int tile, uint32_t tab_ad, uint32_t inv_ad, uint32_t clip_ad,
@@ -554,17 +516,22 @@ __device__ __attribute__((noinline)) void q8_rebuild(q8_kernarg_ptr ka, int tile
     // shared between the slices -- in this slice's row of the per-slice seeds ([n_slices][n_tiles * 32])
     const Q8Build a = {ka->lut, ka->qlom, ka->qstep, ka->smax, ka->qlo,
                        ka->gkey ? ka->gkey : (ka->gseed ? ka->gseed + (int64_t)slice * (ka->n_tiles * QT) : nullptr),
-                       ka->Ks, ka->B, ka->k, ka->q8_target};
+                       ka->Ks, ka->B, ka->k, ka->q8_target, ka->gseed0, ka->btab};
+    const bool prebuilt = first && a.btab != nullptr && M == 16 && NQ == 2;
     const int tid = threadIdx.x;
     const Q8Lds o(q8_table_bytes<M, NQ>(a.Ks));
     if (tid < 32) {  // (the control block has 32 slots whatever QT is: the consumer's lanes 0 .. 31 look at all of them)
         const uint32_t t8 = 8u * (uint32_t)tid, t4 = 4u * (uint32_t)tid;
         const int b = tile * QT + tid;
         const bool real = tid < QT && b < a.B;
-        unsigned long long key = ~0ull;
+        unsigned long long key = ~0ull, key_now = ~0ull;
         if (first) {
             if (a.gkey && real) key = __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ldsv_st<unsigned long long>(o.gkl + t8, key);
+            key_now = key;
+            // (prebuilt table: quantised for the SEED key -- the shared bound may have moved on since; it only tightens T below)
+            if (prebuilt && real) key = a.gseed0[b];
+            if (key < key_now) key_now = key;
+            ldsv_st<unsigned long long>(o.gkl + t8, key_now);
             ldsv_st<unsigned long long>(o.gjl + t8, ~0ull);
             ldsv_st<unsigned long long>(o.tau + t8, ~0ull);
             ldsv_st<unsigned char>(o.chg + (uint32_t)tid, 0);
@@ -587,13 +554,19 @@ __device__ __attribute__((noinline)) void q8_rebuild(q8_kernarg_ptr ka, int tile
             ldsv_st<double>(o.c0 + t8, (slack - (real ? a.qlo[b] : 0.0)) * c1);
         }
         if (tid < QT) {
-            q8_st_bound<M>(o, tid, tb);
+            uint32_t tnow = tb;  // the bound to filter with: the table's own T, or what a tighter shared bound gives under its step
+            if (prebuilt && real && key_now < key) {
+                const uint32_t t2 = q8_bound_from_key<M>(key_now, a.smax[b], step, a.qlo[b]);
+                tnow = t2 < tb ? t2 : tb;
+            }
+            q8_st_bound<M>(o, tid, tnow);
             if constexpr (Q8Cfg<M>::WIDE) ldsv_st<unsigned short>(o.tb + 2u * (uint32_t)tid, (unsigned short)tb);
             else ldsv_st<unsigned char>(o.tb + (uint32_t)tid, (unsigned char)tb);
         }
     }
     __syncthreads();
     if constexpr (Q8Cfg<M>::WIDE) q8_build_table_wide<NW>(a, tile, o.tab, o.inv, o.clip, tid);
+    else if (prebuilt) q8_copy_table<M, NW, NQ>(a, tile, o.tab, tid);
     else q8_build_table<M, NW, NQ>(a, tile, o.tab, o.inv, o.clip, tid);
     __syncthreads();
 }

@@ -72,7 +72,7 @@ def parse():
                         'of them for the default workload, rerank + ivf otherwise')
     p.add_argument('--metric', choices=['euclidean', 'cosine', 'inner_product'], default='euclidean',
                    help="BASELINE config 2/3: euclidean; config 4 (10M x 768, m=64, batch 256): cosine")
-    p.add_argument('--streams', type=int, choices=[0, 1, 2], default=0,
+    p.add_argument('--streams', type=int, choices=list(range(0, 9)), default=0,
                    help='streams the timed batches alternate on (0 = auto: 2 when the exchange runs, else 1 -- so that the kernel '
                         'durations rocprofv3 reports for this command are not inflated by overlap; 2 on one GPU: the next '
                         'batch\'s table build and seed fill the CUs the previous scan\'s tail leaves idle, -1.4 %% / -4 %% per '
@@ -249,7 +249,7 @@ def main():
         return sharded.search_batch(queries, limit=k)
 
     n_streams = args.streams or (2 if (world > 1 or os.environ.get('ANNLITE_FORCE_GATHER')) else 1)
-    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)] if n_streams == 2 else [torch.cuda.current_stream(dev)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams >= 2 else [torch.cuda.current_stream(dev)]
     for st in streams:
         st.wait_stream(torch.cuda.current_stream(dev))
     # clocks: a GPU that has idled through index construction and host-side set-up takes milliseconds of work to reach its

@@ -255,6 +255,9 @@ ANNLITE_API int annlite_debug_timeline(uint64_t *out8);
 /* ... and per work item (up to 4096 records of 8 uint64): query tile, row slice, the stamps start / table built / step loop
  * left / last barrier passed / end, block index. */
 ANNLITE_API int annlite_debug_items(uint64_t *out, int64_t max_items, int64_t *n_items);
+/* ... and of the byte-table plan's preparation launch (tables + parameters + reset + seed bound [+ byte tables], one launch):
+ * stamps of its first workgroup [0..3] and its last one [4..7]: start, tables built, seed rows scanned, end. */
+ANNLITE_API int annlite_debug_prep_timeline(uint64_t *out8);
 
 /* Convert between the PLAIN and the SKEWED code-table layout (uint8 codes).
  * forward (inverse=0): table_out[id][j] = codes_in[i][(j + id) mod M]   -- scatter rows i -> id

@@ -85,6 +85,11 @@ if os.environ.get('ANNLITE_DEBUG_COUNTERS') and plan.qt == 32:
     print('byte-table kernel: wave-steps with candidates %d, pushed %d, exact sums %d, queued for a list %d, table rebuilds %d, consumer batches %d; '
           'per workgroup: consumer inside batches %.1f us, wave 0 at epoch ends %.1f us' % (c[0], c[1], c[2], c[3], c[5], c[6], c[4] / nwg / 2400., c[7] / nwg / 2400.))
     print('byte-table kernel timeline (us; per-work-item averages but the span):', _capi.debug_timeline())
+    if a.fused:
+        try:
+            print('preparation launch (us; first / last workgroup):', _capi.debug_prep_timeline())
+        except Exception as ex:  # (a plan without the fused preparation launch)
+            print('preparation launch: no stamps (%s)' % ex)
     it = _capi.debug_items()
     if len(it):
         t0 = it[:, 2].min()
