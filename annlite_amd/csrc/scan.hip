@@ -605,7 +605,13 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
     if (plan.fast) {
         FastCfg c;
         fast_cfg(M, Ks, code_bytes, k, &c, tm != nullptr);
-        if (c.mode == 5 && a.n_tiles >= 8) a.n_items = 8 * ((a.n_tiles + 7) / 8) * a.n_slices;  // q8_item_map
+        // M = 64 (64-byte rows: 640 MB at 10M rows): tile-per-XCD makes every XCD stream the whole table (FETCH_SIZE 6.2 GB per
+        // launch, 36 % of the HBM peak, L2 hit rate 71 %) and its candidates are few -- slice-per-XCD instead: an XCD streams its
+        // row slices once for all the query tiles that walk them together.  ANNLITE_Q8_MAP=0/1 overrides (A/B).
+        a.q8_map_slices = (M == 64) ? 1 : 0;
+        if (const char *e = getenv("ANNLITE_Q8_MAP")) a.q8_map_slices = atoi(e) ? 1 : 0;
+        if (a.n_slices < 8) a.q8_map_slices = 0;
+        if (c.mode == 5 && a.n_tiles >= 8 && !a.q8_map_slices) a.n_items = 8 * ((a.n_tiles + 7) / 8) * a.n_slices;  // q8_item_map
         // epochs end after steps 15, 255, 4095 (x 15 blocks of 64 rows) and a slot asks for a new table when its T has halved:
         // 10M rows x 1024 queries 1.497 ms per launch with {3, 15, 63, ...} / T 64 / rebuild at 7/8, 1.445 with this, 1.441 with no
         // epoch at all (1.25M rows: 0.284 / 0.261 / 0.254) -- on the bench's data a barrier of all 16 waves costs more than a
@@ -614,7 +620,9 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         a.q8_epoch_mul = 16;
         a.q8_ring_limit = 384;
         a.q8_import_mask = 3;
-        a.q8_target = M == 64 ? 384 : 96;  // (M = 64: u16 sums of 64 entries clipped at 15 -- simulated: 6x the u16 tables' candidates)
+        // (M = 64: u16 sums of 64 entries clipped at 15.  10M x 768-d, 256 queries, ms per launch at T = 256 / 384 / 512 / 768: 2.09 / 2.04 /
+        // 2.03 / 3.54 -- a finer table clips more entries of a row near the bound: at 768 the filter leaks)
+        a.q8_target = M == 64 ? 512 : 96;
         a.q8_rebuild_8ths = 4;
         if (const char *e = getenv("ANNLITE_Q8_REBUILD")) {
             const int t = atoi(e);
@@ -760,6 +768,11 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             a.q16 = q16;
             a.qlom = qlom;
         }
+        // early merger (scan_q8.hip: q8_early_merge): every work item must have its own resident workgroup
+        a.q8_early_merge = (c.mode == 5 && a.tile_done && a.n_slices >= 2 && a.n_slices <= 31 && a.n_items <= grid &&
+                            !getenv("ANNLITE_NO_EARLY_MERGE")) ? 1 : 0;
+        a.q8_merge_patience = 20000u;
+        if (const char *e = getenv("ANNLITE_EARLY_MERGE_PATIENCE")) a.q8_merge_patience = (uint32_t)atoll(e);
         const bool bracket = !(gopt && gopt->gate);  // (measurement hooks: the launch that does the work, not the gated pass)
         if (bracket) prof_begin(st);
         rc = c.mode == 5 ? launch_q8_scan(c.id, sk, a, grid, st) : launch_qfilter_scan(c.id, sk, a, grid, st);

@@ -76,6 +76,12 @@ struct ScanArgs {
     // copy their first table (128 KB, L2) instead of each converting the tile's 512 KB of fp32 tables
     const unsigned long long *gseed0;   // [ceil32(B)] the seed keys as the preparation launch left them (gkey moves on: atomic min)
     const uint8_t *btab;                // [n_tiles][Ks * 2 * 16 * 16 B] LDS images, quantised for gseed0; NULL: the workgroups build
+    int32_t q8_early_merge;             // byte-table kernel: the FIRST workgroup of a tile to finish merges the others' lists as they
+                                        // arrive (tile_done is then a bitmask of the slices still out); 0: the last one merges all
+    uint32_t q8_merge_patience;         // ... and leaves (the last slice to arrive then merges all) after this many 100 MHz ticks
+                                        // without an arrival (20000 = 200 us; ANNLITE_EARLY_MERGE_PATIENCE: tests force the path)
+    int32_t q8_map_slices;              // byte-table kernel: work items mapped slice-per-XCD (item_map) instead of tile-per-XCD
+                                        // (q8_item_map): an XCD streams ITS row slices once for all query tiles
 };
 
 // work item -> (query tile, row slice).  item % 8 == blockIdx % 8 == the XCD the block lands on (speed

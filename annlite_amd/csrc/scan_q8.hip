@@ -44,7 +44,7 @@
 
 #ifndef ANNLITE_Q8_EXP
 #define ANNLITE_Q8_EXP 0  // (timing experiments, results wrong: 1 = look-ups without the adds, 2 = adds without the look-ups,
-                          // 3 = code rows computed instead of loaded, 4 = M = 64 rows read as interleaved 16-byte pieces)
+                          // 3 = code rows computed instead of loaded; 5 = one entry per hit row, no enumeration)
 #endif
 
 namespace annlite {
@@ -750,12 +750,123 @@ __device__ __attribute__((noinline)) unsigned long long q8_rows_pass_masks(const
 // the fabric: ~190 ns per candidate, the consumer wave's whole budget.  The code rows are then read by every XCD
 // (8 x the table per launch, 1.3 GB at 10M rows: a fraction of a ms of HBM / Infinity Cache bandwidth).
 __device__ __forceinline__ bool q8_item_map(const ScanArgs &a, int item, int &tile, int &slice) {
-    if (a.n_tiles < 8) return item_map(a, item, tile, slice);
+    if (a.n_tiles < 8 || a.q8_map_slices) return item_map(a, item, tile, slice);
     const int xcd = item & 7, j = item >> 3;
     const int tpx = (a.n_tiles + 7) >> 3;
     slice = j / tpx;
     tile = xcd + 8 * (j - slice * tpx);
     return tile < a.n_tiles && slice < a.n_slices;
+}
+
+// EARLY MERGER.  With one work item per CU the launch ends when the slowest tile has merged: its last workgroup to arrive used
+// to merge all n_slices lists of the tile's queries then -- ~13 us (device-scope loads of n_slices * k keys per query, rank
+// counting) on the critical path of EVERY launch, while the tile's first workgroup had left 20-40 us earlier.  Now the FIRST
+// workgroup to finish stays: its own lists (LDS) are the running result, it polls the tile's arrival mask and folds the lists
+// of the slices that have come in since (up to 64 / k slices per pass, one key per lane, the same rank counting) -- when the
+// last slice arrives one short pass is left.  Only where every work item has its own workgroup (n_items <= grid) and
+// n_slices <= 31 (one mask word + the flag below).  A waiting merger holds its CU, and the workgroups it waits for may not be
+// resident yet (other launches on other streams): if EVERY resident workgroup were such a merger nothing would move.  So a
+// merger that has seen no arrival for ScanArgs::q8_merge_patience ticks (200 us) LEAVES: it clears bit 31 of the mask ("no merger") and the
+// workgroup that then clears the last slice bit merges everything from global memory, as before (q8_merge_tile).  The two
+// atomics serialise: exactly one of them finishes the tile.
+constexpr uint32_t kEarlyMergerBit = 0x80000000u;
+template <int NW>
+__device__ __forceinline__ void q8_early_merge(const ScanArgs &a, const Q8Lds &lds, int tile, int slice, int QT, int wave, int lane) {
+    const int tid = threadIdx.x, k = a.k, km1 = k - 1, b0 = tile * QT;
+    int nq = a.B - b0;
+    if (nq > QT) nq = QT;
+    const uint32_t low = (1u << a.n_slices) - 1u;
+    uint32_t merged = 1u << slice;
+    unsigned long long t_last = wall_clock64();
+    const int per_pass = 64 / k;
+    const uint32_t my_scratch = lds.ring + (uint32_t)wave * 128u;  // u64 [16]
+    auto rd64 = [&](unsigned long long v, int l) -> unsigned long long {
+        return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) |
+               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    };
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) ldsv_st<uint32_t>(lds.ctl + 4, __hip_atomic_load(a.tile_done + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __syncthreads();
+        const uint32_t mask = ldsv<uint32_t>(lds.ctl + 4);  // bit s set: slice s is still out
+        const uint32_t arrived = ~mask & low & ~merged;
+        if (!arrived) {
+            if ((~mask & low) == low) break;  // every slice is in and merged
+            if (wall_clock64() - t_last >= (unsigned long long)a.q8_merge_patience) {
+                // nothing has arrived for a long time: leave, unless everything turns out to be in (then finish here)
+                __syncthreads();
+                if (tid == 0)
+                    ldsv_st<uint32_t>(lds.ctl + 4, __hip_atomic_fetch_and(a.tile_done + tile, ~kEarlyMergerBit, __ATOMIC_RELAXED,
+                                                                          __HIP_MEMORY_SCOPE_AGENT));
+                __syncthreads();
+                if ((ldsv<uint32_t>(lds.ctl + 4) & low) != 0u) return;  // the last slice to arrive merges the tile (q8_finish_item)
+                t_last = wall_clock64();
+                continue;
+            }
+            __builtin_amdgcn_s_sleep(32);
+            continue;
+        }
+        t_last = wall_clock64();
+        // this pass: the per_pass lowest arrived slices, slice j of the pass in lanes [j k, (j + 1) k)
+        int my_sl = -1;
+        uint32_t take = 0u, rest = arrived;
+        for (int j = 0; j < per_pass && rest; ++j) {
+            const int s = __builtin_ctz(rest);
+            rest &= rest - 1u;
+            take |= 1u << s;
+            if (lane >= j * k && lane < (j + 1) * k) my_sl = s;
+        }
+        unsigned long long key[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = wave + NW * u;
+            key[u] = ~0ull;
+            if (q < nq && my_sl >= 0)
+                key[u] = __hip_atomic_load(a.partial + ((int64_t)(b0 + q) * a.n_slices + my_sl) * k + (lane % k), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll 1
+        for (int u = 0; u < 2; ++u) {
+            const int q = wave + NW * u;
+            if (q >= nq) continue;
+            const uint32_t lst = lds.list + 8u * (uint32_t)(q * 16);
+            unsigned long long best = lane < k ? ldsv<unsigned long long>(lst + 8u * (uint32_t)lane) : ~0ull;
+            unsigned long long ky = key[u];
+            if (!(ky < rd64(best, km1))) ky = ~0ull;
+            unsigned long long m = __ballot(ky != ~0ull);
+            if (!m) continue;
+            int r_c = 0, r_b = lane;  // ranks in the union of my new key / my list entry
+            while (m) {
+                const int L = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const unsigned long long ck = rd64(ky, L);
+                r_c += ck < ky ? 1 : 0;
+                r_b += ck < best ? 1 : 0;
+            }
+#pragma unroll 1
+            for (int j = 0; j < k; ++j) r_c += rd64(best, j) < ky ? 1 : 0;
+            if (lane < k && r_b < k) ldsv_st<unsigned long long>(my_scratch + 8u * (uint32_t)r_b, best);
+            if (ky != ~0ull && r_c < k) ldsv_st<unsigned long long>(my_scratch + 8u * (uint32_t)r_c, ky);
+            if (lane < k) ldsv_st<unsigned long long>(lst + 8u * (uint32_t)lane, ldsv<unsigned long long>(my_scratch + 8u * (uint32_t)lane));
+        }
+        merged |= take;
+    }
+    for (int q = wave; q < nq; q += NW) {
+        if (lane > km1) continue;
+        const unsigned long long best = ldsv<unsigned long long>(lds.list + 8u * (uint32_t)(q * 16 + lane));
+        const int b = b0 + q;
+        const uint32_t hi = (uint32_t)(best >> 32), lo = (uint32_t)best;
+        const bool none = (hi == kKeyInfHi && lo == kIdNone);
+        const float d = none ? __builtin_inff() : ordered_to_f32(hi);
+        const int64_t id = none ? (int64_t)-1 : a.row_base + (int64_t)lo;
+        if (a.out_packed) {
+            a.out_packed[((int64_t)b * a.k + lane) * 2 + 0] = id;
+            a.out_packed[((int64_t)b * a.k + lane) * 2 + 1] = (int64_t)__float_as_uint(d);
+        } else {
+            a.out_d[(int64_t)b * a.k + lane] = a.sqrt_out ? __builtin_sqrtf(d) : d;
+            a.out_i[(int64_t)b * a.k + lane] = id;
+        }
+    }
 }
 
 // End of a work item: the lists ARE the workgroup's result for this (tile, slice) -- the final epoch_sync was the barrier:
@@ -781,15 +892,25 @@ __device__ __attribute__((noinline)) void q8_finish_item(q8_kernarg_ptr ka, int 
         // the last of the tile's n_slices workgroups to arrive merges them
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have completed
         __syncthreads();
+        const bool early = ka->q8_early_merge != 0;
         if (tid == 0) {
-            const unsigned int old = __hip_atomic_fetch_add(tile_done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ldsv_st<uint32_t>(lds.ctl + 4, (old + 1u == (unsigned int)(n_slices - 1)) ? 1u : 0u);
+            if (early) {
+                // tile_done: a mask of the slices still out + bit 31 "the early merger is there" (all-ones from the fill).  The FIRST
+                // to arrive becomes the early merger (1); after it has left, the one that clears the last slice bit merges all (2)
+                const unsigned int old = __hip_atomic_fetch_and(tile_done + tile, ~(1u << slice), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int low = (1u << n_slices) - 1u;
+                ldsv_st<uint32_t>(lds.ctl + 4, old == 0xffffffffu ? 1u : (!(old & kEarlyMergerBit) && (old & low) == (1u << slice)) ? 2u : 0u);
+            } else {      // ... a counter from -1: the LAST to arrive merges
+                const unsigned int old = __hip_atomic_fetch_add(tile_done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ldsv_st<uint32_t>(lds.ctl + 4, (old + 1u == (unsigned int)(n_slices - 1)) ? 1u : 0u);
+            }
         }
         __syncthreads();
         if (ldsv<uint32_t>(lds.ctl + 4)) {
             ScanArgs a;  // (cold path: the merging workgroup reads the block once)
             __builtin_memcpy(&a, (const void *)ka, sizeof(ScanArgs));
-            q8_merge_tile<NW>(a, tile * QT, QT, km1, wave, lane, lds.ring);
+            if (early && ldsv<uint32_t>(lds.ctl + 4) == 1u) q8_early_merge<NW>(a, lds, tile, slice, QT, wave, lane);
+            else q8_merge_tile<NW>(a, tile * QT, QT, km1, wave, lane, lds.ring);
         }
         __syncthreads();
     }
@@ -1232,12 +1353,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 } else {
 #pragma unroll
                     for (int i = 0; i < CW / 4; ++i) {
-                        if constexpr (ANNLITE_Q8_EXP == 4) {  // (timing experiment: the 16-byte pieces of 64 rows interleaved -- coalesced, wrong rows)
-                            const gptr_t pb = (gptr_t)codes_v + (int64_t)(row & ~63u) * CW + (row & 63u) * 4 + i * 256;
-                            const u32x4 v = *(const u32x4 __attribute__((address_space(1))) *)pb;
-                            c[4 * i + 0] = v.x, c[4 * i + 1] = v.y, c[4 * i + 2] = v.z, c[4 * i + 3] = v.w;
-                            continue;
-                        }
                         const u32x4 v = *(const u32x4 __attribute__((address_space(1))) *)(p + 4 * i);
                         c[4 * i + 0] = v.x;
                         c[4 * i + 1] = v.y;

@@ -233,3 +233,43 @@ def test_facade_lazy_matches_equal_the_eager_documents(ops, tmp_path):
     assert '1007' not in [m.id for qd in query for m in qd.matches]
     ann.search(query, limit=6, include_metadata=False)
     assert query[0].matches[0].tags == {}
+
+
+# ------------------------------------------------------------------------------------ early merger of a tile's row slices
+@pytest.mark.parametrize('patience', [None, '0', '3'])
+@pytest.mark.parametrize('M,dsub,k', [(16, 8, 10), (16, 8, 16), (64, 4, 10), (8, 8, 3)])
+def test_early_merger_and_its_give_up_path(ops, oracle, monkeypatch, patience, M, dsub, k):
+    """The first workgroup of a query tile to finish folds the other slices' lists as they arrive (scan_q8.hip: q8_early_merge);
+    with no patience (ANNLITE_EARLY_MERGE_PATIENCE=0 / 3 ticks) it leaves at once and the last slice to arrive merges the tile
+    from global memory -- both roads, and the switch that turns the early merger off, return the oracle's bits; heavy ties across
+    slices, deleted rows, a ragged batch."""
+    import torch
+    from annlite_amd._capi import LUT_L2
+
+    rs = np.random.RandomState(M + k)
+    N, B, Ks, D = 400_000, 70, 256, M * dsub
+    cb = rs.randn(M, Ks, dsub).astype(np.float32)
+    base = rs.randint(0, Ks, size=(500, M)).astype(np.uint8)
+    codes = base[rs.randint(0, 500, N)]  # 500 distinct code rows: every distance ties ~800 times, across all slices
+    valid = np.ones(((N + 31) // 32 + 2) * 32, dtype=bool)
+    valid[N:] = False
+    valid[rs.choice(N, 50_000, replace=False)] = False
+    q = rs.randn(B, D).astype(np.float32)
+    lut = oracle.batch_precompute_adc_table_c(q, dsub, Ks, cb)
+    live = np.nonzero(valid[:N])[0]
+    rd, ri = oracle.adc_search_c(lut, codes[live], k, threads=oracle.max_threads())
+    ri = live[ri]
+    bits = ops.to_dev(np.packbits(valid.reshape(-1, 32), axis=1, bitorder='little').view(np.int32).reshape(-1))  # bit n of word n / 32
+    cb_d, q_d, codes_d = ops.to_dev(cb), ops.to_dev(q), ops.to_dev(codes)
+    envs = [{}] if patience is None else [{'ANNLITE_EARLY_MERGE_PATIENCE': patience}]
+    envs.append({'ANNLITE_NO_EARLY_MERGE': '1'})
+    for env in envs:
+        for key in ('ANNLITE_EARLY_MERGE_PATIENCE', 'ANNLITE_NO_EARLY_MERGE'):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        for layout in (0, 1):
+            cd = ops.codes_skew(codes_d) if layout == 1 else codes_d
+            for rep in range(3):
+                d, i = ops.pq_search_topk(LUT_L2, q_d, cb_d, cd, k, M, Ks, codes_layout=layout, valid_bits=bits)
+                assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(d.cpu().numpy(), rd), (env, layout, rep)
