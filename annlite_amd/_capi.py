@@ -18,6 +18,8 @@ LIB_PATH = os.environ.get('ANNLITE_HIP_LIB') or os.path.join(_HERE, LIB_NAME)
 
 ANNLITE_OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE = 1, 2, 3, 4
+NOT_APPLICABLE = 5  # (not an error: annlite_pq_search_split has no effect for this shape / state)
+PHASE_PREPARE, PHASE_SCAN, SEED_KEYS = 1, 2, 16
 
 LUT_L2, LUT_IP, LUT_IPDIST = 1, 2, 3
 LAYOUT_BMK, LAYOUT_TILED = 0, 1
@@ -46,6 +48,8 @@ SYMBOLS = (
     'annlite_pq_search_workspace_bytes',
     'annlite_pq_search_topk',
     'annlite_pq_search_topk_ex',
+    'annlite_pq_search_split',
+    'annlite_pq_search_seed_union',
     'annlite_adc_scan_candidates',
     'annlite_topk_merge',
     'annlite_topk_merge_packed',
@@ -125,6 +129,8 @@ def lib() -> ctypes.CDLL:
     L.annlite_pq_search_topk.argtypes = [i32, vp, i64, i64, vp, vp, i32, i32, i64, i64, i64, vp, i64, i64, vp, vp, vp, i32,
                                          vp, sz, vp]
     L.annlite_pq_search_topk_ex.argtypes = L.annlite_pq_search_topk.argtypes + [vp]
+    L.annlite_pq_search_split.argtypes = [i32, i64] + L.annlite_pq_search_topk_ex.argtypes + [vp]
+    L.annlite_pq_search_seed_union.argtypes = [vp, i64, i64, i64, i64, i32, i64, i64, vp, sz, vp]
     L.annlite_scan_state_create.argtypes = [ctypes.POINTER(vp)]
     L.annlite_scan_state_destroy.argtypes = [vp]
     L.annlite_scan_state_reset.argtypes = [vp]

@@ -36,6 +36,14 @@ from ..codec.pq import PQCodec
 from .base import BaseIndex
 
 
+class SplitBatch:
+    """A batch between the two halves of the split search (``PQFlatGpuIndex.split_prepare``; protocol: sharded.py)."""
+
+    def __init__(self, keys, n_queries, device, union, scan, plain, keep=None):
+        self.keys, self.n_queries, self.device = keys, n_queries, device
+        self.union, self.scan, self.plain, self._keep = union, scan, plain, keep
+
+
 class PQFlatGpuIndex(BaseIndex):
     def __init__(
         self,
@@ -293,6 +301,42 @@ class PQFlatGpuIndex(BaseIndex):
         return ops.pq_search_topk(
             kind, xq, self.pq_codec.codebooks_dev, self._codes, k, self.M, self.Ks, valid_bits=self._valid,
             row_base=row_base, n_rows=N, codes_layout=self._layout(), workspace=self._ws, packed=True, state=self.scan_state)
+
+    def split_supported(self, x, limit: int) -> bool:
+        """STATIC part of the split search's conditions -- the same on every rank of a row-sharded search (configuration, batch
+        shape, input kind), so that all ranks agree on whether the seed collective takes place at all."""
+        k = int(limit)
+        dsub = self.dim // self.M if self.M else 0
+        return (isinstance(x, torch.Tensor) and x.ndim == 2 and x.shape[0] > 0 and not (self.rerank and self._vectors is not None) and
+                1 <= k <= 16 and self.M == 16 and self.code_bytes == 1 and self.Ks <= 256 and self.dim <= 256 and dsub % 4 == 0 and
+                self.metric == Metric.EUCLIDEAN and not self.pq_codec.normalize_input)
+
+    def split_prepare(self, x, limit: int, row_base: int, seed_rows: int, workspace) -> Optional['SplitBatch']:
+        """First half of ``search_batch_packed`` for a rank of a row-sharded search WITH a seed exchange (sharded.py runs the
+        protocol): the preparation launch, seeding from this rank's first ``seed_rows`` rows only, into ``workspace`` (None: the index's own,
+        per-stream scratch).  Returns the batch's handle -- ``keys`` i64 [B, 16] (this
+        rank's contribution to the seed all-gather) or ``keys is None`` when the split does not apply to THIS rank NOW (fewer
+        than 4096 rows, the library has not settled on the byte-table kernel yet: nothing was launched, ``plain()`` is the
+        search) -- or ``None`` when ``split_supported`` says no (the same answer on every rank: no collective at all)."""
+        from ..._capi import PHASE_PREPARE, PHASE_SCAN
+
+        if not self.split_supported(x, limit):
+            return None
+        k = int(limit)
+        q = self._pre(x)
+        B = q.shape[0]
+        kind, xq = self._scan_inputs(x, q)
+        args = dict(valid_bits=self._valid, row_base=row_base, n_rows=self._n_rows, codes_layout=self._layout())
+        workspace = workspace if workspace is not None else self._ws
+        call = lambda phase, **kw: ops.pq_search_split(phase, kind, xq, self.pq_codec.codebooks_dev, self._codes, k, self.M, self.Ks,
+                                                       self.scan_state, workspace, **args, **kw)
+        keys = call(PHASE_PREPARE, seed_rows=seed_rows) if self._n_rows >= 4096 else None
+
+        def union(all_keys):
+            ops.pq_search_seed_union(all_keys.contiguous(), self._codes, B, k, self.M, self.Ks, workspace, n_rows=self._n_rows)
+
+        return SplitBatch(keys=keys, n_queries=B, device=q.device, union=union, scan=lambda: call(PHASE_SCAN),
+                          plain=lambda: self.search_batch_packed(x, limit, row_base), keep=(q, xq))
 
     @property
     def sqrt_epilogue(self) -> bool:

@@ -175,6 +175,45 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float *dist, con
     }
 }
 
+// Seed exchange of the row-sharded search (annlite_pq_search_split): all_keys [G][B][kSeedKeys] = every rank's bounds of its
+// seed's k smallest rows.  One wave per query: the k-th smallest of the G * k keys (ties by position: equal keys of two ranks
+// are two rows) has k distinct rows of the global table at or below it; the prepared batch's bound becomes min(own, that).
+__global__ __launch_bounds__(256) void seed_union_kernel(const unsigned long long *__restrict__ all_keys, int G, int B, int k,
+                                                        unsigned long long *__restrict__ gkey) {
+    __shared__ unsigned long long s_keys[4][8 * kSeedKeys];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + w;
+    if (b >= B) return;
+    const int n = G * kSeedKeys;  // (G <= 8: at most 128 slots, two per lane)
+    unsigned long long mine[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int idx = lane + 64 * u;
+        mine[u] = ~0ull;
+        if (idx < n && (idx % kSeedKeys) < k) mine[u] = all_keys[((int64_t)(idx / kSeedKeys) * B + b) * kSeedKeys + (idx % kSeedKeys)];
+        if (idx < 8 * kSeedKeys) s_keys[w][idx] = mine[u];
+    }
+    // (a wave's own LDS traffic is in order: no barrier)
+    unsigned long long found = ~0ull;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int idx = lane + 64 * u;
+        if (idx >= n || mine[u] == ~0ull) continue;
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const unsigned long long o = s_keys[w][j];
+            rank += (o < mine[u] || (o == mine[u] && j < idx)) ? 1 : 0;
+        }
+        if (rank == k - 1) found = mine[u];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long p = __shfl_xor(found, o);
+        found = p < found ? p : found;
+    }
+    if (lane == 0 && found < gkey[b]) gkey[b] = found;
+}
+
 // Row-wise top-k of a dense matrix (annlite/math.py:94-120 with the fixed tie-break); wave per row.
 __global__ __launch_bounds__(256) void topk_rows_kernel(const float *values, int B, int64_t N, int k,
                                                        int64_t id_base, float *out_d, int64_t *out_i) {
@@ -513,11 +552,18 @@ struct GuardOpt {
     unsigned int *guard_out;      // out: the byte-table launch's guard block (the gate of the launch behind it)
 };
 
+// annlite_pq_search_split: the byte-table plan in two halves with the ranks' seed exchange in between
+struct SplitOpt {
+    int phase;                      // ANNLITE_PHASE_PREPARE: everything up to and including the preparation launch; _SCAN: the rest
+    int64_t seed_rows;              // rows of this rank's seed (<= 0: the default)
+    unsigned long long *seed_keys;  // PREPARE: [B][kSeedKeys] out
+};
+
 static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M, int64_t Ks,
                         const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B, int64_t k,
                         void *workspace_dev, size_t workspace_bytes, hipStream_t st, annlite_scan_plan *plan_out,
                         bool share_across_slices, const LutBuild *build = nullptr, ScanOut *outp = nullptr,
-                        const TileMode *tm = nullptr, GuardOpt *gopt = nullptr) {
+                        const TileMode *tm = nullptr, GuardOpt *gopt = nullptr, const SplitOpt *split = nullptr) {
     annlite_scan_plan plan;
     int rc = plan_query_impl(N, M, Ks, code_bytes, B, k, tm ? 1 : 0, &plan);
     if (rc != ANNLITE_OK) return rc;
@@ -592,6 +638,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         FastCfg c1;
         fused_fill = N > 0 && plan.fast && fast_cfg(M, Ks, code_bytes, k, &c1, tm != nullptr) && c1.qf() && M != 64;  // lut_quantise_fused_kernel
         // (own kernel: one launch like any other of the plan, no second mechanism on the stream)
+        if (split && !fused_fill) return ANNLITE_NOT_APPLICABLE;  // (the split search is the fused preparation launch's)
         if (!fused_fill) {
             const int64_t n16 = (int64_t)((fill + 15) / 16);
             hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (u32x4 *)workspace_dev, n16);
@@ -715,13 +762,21 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 if (c.mode == 5 && M != 64)  // (M = 64: two queries per seed workgroup, 63 us per 8192 rows)
                     S = N / 32 < 8192 ? 8192 : N / 32 > 32768 ? 32768 : ((N / 32 + 1023) / 1024) * 1024;
                 if (const char *e = getenv("ANNLITE_SEED_ROWS")) S = atoll(e);
+                if (split && split->seed_rows > 0) S = split->seed_rows;  // (a rank of a row-sharded search: its share of the seed rows)
                 if (S > N) S = N;
                 if (S < 0) S = 0;  // (ANNLITE_SEED_ROWS=0: the scan starts without a bound)
             }
             // byte-table plan behind annlite_pq_search_topk: tables, parameters, reset and seed bound in ONE launch
             const bool one_prep = c.mode == 5 && build && S > 0 && M == 16 && build->D <= 256 && ((build->D / M) % 4) == 0 &&
                                   !getenv("ANNLITE_NO_FUSED_SEED");
-            if (one_prep) {
+            if (split && !one_prep) return ANNLITE_NOT_APPLICABLE;  // (nothing has been launched)
+            if (one_prep && split && split->phase == ANNLITE_PHASE_SCAN) {
+                // the batch was prepared by the PREPARE half on this workspace: the same carving, no launch
+                if (!getenv("ANNLITE_NO_PREBUILT_TABLES")) {
+                    a.gseed0 = (unsigned long long *)carve(bpad * 8);
+                    a.btab = (uint8_t *)carve((int64_t)a.n_tiles * Ks * 2 * M * 16);
+                }
+            } else if (one_prep) {
                 // ... and the scan work items' FIRST byte tables, once per query tile instead of once per (tile, slice) work item
                 // (ANNLITE_NO_PREBUILT_TABLES: the workgroups convert the fp32 tables themselves, as before round 4 -- A/B switch)
                 unsigned long long *gseed0 = nullptr;
@@ -732,10 +787,11 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 }
                 rc = launch_seed_build(codes_layout == ANNLITE_CODES_SKEWED, codes_dev, S, valid_bits_dev, *build, const_cast<float *>(lut_dev),
                                        B, Ks, k, qstep, qlo, smax, qlom, gk, workspace_dev, fill_bytes, (size_t)(((bpad * 8 + 255) / 256) * 256), st,
-                                       gseed0, btab, a.q8_target, a.dbg ? g_dbg_prep : nullptr);
+                                       gseed0, btab, a.q8_target, a.dbg ? g_dbg_prep : nullptr, split ? split->seed_keys : nullptr);
                 if (rc != ANNLITE_OK) return rc;
                 a.gseed0 = gseed0;
                 a.btab = btab;
+                if (split && split->phase == ANNLITE_PHASE_PREPARE) return ANNLITE_OK;  // (the scan follows the seed exchange)
             } else {
                 const unsigned int *gate = (gopt && c.mode != 5) ? gopt->gate : nullptr;
                 rc = launch_lut_quantise(M, Ks, Bq, ((Bq + 15) / 16) * 16, (tm && build) ? nullptr : lut_dev, build, q16, qstep,
@@ -1164,6 +1220,79 @@ extern "C" int annlite_pq_search_topk(int lut_kind, const float *queries_dev, in
     return pq_search_impl(lut_kind, queries_dev, B, D, codebooks_dev, codes_dev, code_bytes, codes_layout, N, M, Ks,
                           valid_bits_dev, k, row_base, out_dist_dev, out_id_dev, out_packed_dev, flags, workspace_dev,
                           workspace_bytes, stream, nullptr);
+}
+
+// ---- the search in two halves with the ranks' seed exchange in between (annlite_hip.h: annlite_pq_search_split) ----------------
+static bool split_shape_ok(int lut_kind, int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t D, int64_t k) {
+    return lut_kind == ANNLITE_LUT_L2 && M == 16 && code_bytes == 1 && Ks <= 256 && k >= 1 && k <= 16 && B >= 1 && N >= 4096 &&
+           D <= 256 && D % M == 0 && ((D / M) % 4) == 0 && !getenv("ANNLITE_NO_FUSED_SEED") && !getenv("ANNLITE_NO_FUSED_LUT") &&
+           !getenv("ANNLITE_NO_INKERNEL_MERGE") && env_variant() < 0;
+}
+
+extern "C" int annlite_pq_search_split(int phase, int64_t seed_rows, int lut_kind, const float *queries_dev, int64_t B, int64_t D,
+                                       const float *codebooks_dev, const void *codes_dev, int code_bytes, int codes_layout,
+                                       int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev, int64_t k,
+                                       int64_t row_base, float *out_dist_dev, int64_t *out_id_dev, int64_t *out_packed_dev,
+                                       int flags, void *workspace_dev, size_t workspace_bytes, void *stream,
+                                       annlite_scan_state *state, uint64_t *seed_keys_dev) {
+    ANNLITE_REQUIRE(phase == ANNLITE_PHASE_PREPARE || phase == ANNLITE_PHASE_SCAN, "phase must be ANNLITE_PHASE_PREPARE or _SCAN");
+    ANNLITE_REQUIRE(state != nullptr, "the split search needs the table's annlite_scan_state");
+    if (!split_shape_ok(lut_kind, N, M, Ks, code_bytes, B, D, k)) return ANNLITE_NOT_APPLICABLE;
+    if (phase == ANNLITE_PHASE_PREPARE) {
+        ANNLITE_REQUIRE(seed_keys_dev != nullptr, "seed_keys_dev is NULL");
+        // only once the library has settled on the byte-table kernel for this table (no guarded second pass to split)
+        if (search_policy(state, N, M, Ks, code_bytes, B, k, false) != kModeByteStats) return ANNLITE_NOT_APPLICABLE;
+    } else {
+        ANNLITE_REQUIRE(out_packed_dev || (out_dist_dev && out_id_dev), "null output pointer");
+    }
+    VariantScope vs(50);
+    annlite_scan_plan plan;
+    int rc = plan_query_impl(N, M, Ks, code_bytes, B, k, 0, &plan);
+    if (rc != ANNLITE_OK) return rc;
+    const size_t scan_ws = r256z((size_t)plan.workspace_bytes);
+    const size_t need = scan_ws + r256z((size_t)plan.lut_floats * 4);
+    if (workspace_bytes < need) {
+        set_error("workspace %zu B < required %zu B (annlite_pq_search_workspace_bytes)", workspace_bytes, need);
+        return ANNLITE_ERR_WORKSPACE;
+    }
+    ANNLITE_REQUIRE(queries_dev && codebooks_dev && workspace_dev && codes_dev, "null device pointer");
+    float *lut = (float *)((char *)workspace_dev + scan_ws);
+    const LutBuild lb = {queries_dev, codebooks_dev, D};
+    const int sqrt_out = (flags & ANNLITE_FLAG_SQRT) && !out_packed_dev ? 1 : 0;
+    ScanOut so = {out_dist_dev, out_id_dev, out_packed_dev, row_base, sqrt_out, false};
+    if (phase == ANNLITE_PHASE_PREPARE) so.packed = (int64_t *)seed_keys_dev;  // (any non-NULL output: the prepare half writes none)
+    GuardOpt g = {};
+    g.abort_enabled = 0;
+    g.host_stats = state->dev;
+    if (phase == ANNLITE_PHASE_SCAN) g.seq = ++state->seq ? state->seq : ++state->seq;
+    const SplitOpt sp = {phase, seed_rows, (unsigned long long *)seed_keys_dev};
+    annlite_scan_plan p1;
+    rc = scan_partial(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut, B, k, workspace_dev, scan_ws,
+                      (hipStream_t)stream, &p1, true, &lb, &so, nullptr, &g, &sp);
+    if (rc != ANNLITE_OK) return rc;
+    if (phase == ANNLITE_PHASE_SCAN) ANNLITE_REQUIRE(so.merged, "the byte-table launch did not merge in-kernel");
+    return ANNLITE_OK;
+}
+
+extern "C" int annlite_pq_search_seed_union(const uint64_t *all_keys_dev, int64_t G, int64_t N, int64_t M, int64_t Ks,
+                                            int code_bytes, int64_t B, int64_t k, void *workspace_dev, size_t workspace_bytes,
+                                            void *stream) {
+    ANNLITE_REQUIRE(all_keys_dev && workspace_dev, "null device pointer");
+    ANNLITE_REQUIRE(G >= 1 && G <= 8, "G=%lld outside [1, 8] (one node)", (long long)G);
+    ANNLITE_REQUIRE(k >= 1 && k <= kSeedKeys && B >= 1, "bad B=%lld k=%lld", (long long)B, (long long)k);
+    VariantScope vs(50);
+    annlite_scan_plan plan;
+    int rc = plan_query_impl(N, M, Ks, code_bytes, B, k, 0, &plan);
+    if (rc != ANNLITE_OK) return rc;
+    ANNLITE_REQUIRE(plan.fast && plan.qt == 32, "no byte-table plan for this shape");
+    // the shared bounds sit right behind the per-(query, slice) lists (scan_partial's carving)
+    const int64_t n_tiles = (B + plan.qt - 1) / plan.qt;
+    const size_t off = r256z((size_t)n_tiles * plan.qt * plan.n_slices * k * 8);
+    ANNLITE_REQUIRE(off + (size_t)pad_queries(B, plan.qt) * 8 <= workspace_bytes, "workspace too small");
+    unsigned long long *gk = (unsigned long long *)((char *)workspace_dev + off);
+    hipLaunchKernelGGL(seed_union_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned long long *)all_keys_dev, (int)G, (int)B, (int)k, gk);
+    return launch_status("seed_union_kernel");
 }
 
 extern "C" int annlite_pq_search_tiles_workspace_bytes(int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t V,

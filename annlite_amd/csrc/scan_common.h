@@ -347,6 +347,8 @@ int launch_seed_build(bool skewed, const void *codes_dev, int64_t S, const uint3
                       float *lut_out, int64_t B, int64_t Ks, int64_t k, float *qstep, double *qlo, float *smax, float *qlom,
                       unsigned long long *gkey, void *fill, size_t fill_bytes, size_t gkey_bytes, hipStream_t st,
                       unsigned long long *gseed0 = nullptr, uint8_t *btab = nullptr, int target = 0,
-                      unsigned long long *dbg = nullptr);
+                      unsigned long long *dbg = nullptr, unsigned long long *seedk = nullptr);
+// seedk (optional): [B][kSeedKeys] the bounds implied by the seed's k smallest rows (annlite_pq_search_split)
+constexpr int kSeedKeys = 16;
 
 }  // namespace annlite

@@ -125,6 +125,8 @@ struct SeedBuild {
     unsigned long long *gseed0;  // [..] the seed key of every query, kept aside (gkey itself is lowered by the scan)
     uint8_t *btab;               // [n_tiles][Ks][2][16][16 B]: this workgroup writes its queries' dword of every entry
     int32_t target;              // T of a freshly built table (ScanArgs::q8_target)
+    unsigned long long *seedk;   // optional [B][kSeedKeys]: the bounds implied by the seed's k smallest rows, ascending -- what
+                                 // the OTHER ranks of a row-sharded search may prune with (annlite_pq_search_split)
     unsigned long long *dbg;     // optional: wall-clock stamps (100 MHz) of workgroup 0 [0..3] and the last one [4..7]:
                                  // start, tables built, rows scanned, end
 };
@@ -266,6 +268,8 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
             ((double *)(s_par + 8))[tid] = Lsum;
             ((unsigned long long *)(s_par + 16))[tid] = ~0ull;
             gkey[b] = ~0ull;  // (the fill leaves the bounds to this kernel; the selection below overwrites it)
+            if (sb.seedk)
+                for (int j = 0; j < kSeedKeys; ++j) sb.seedk[(int64_t)b * kSeedKeys + j] = ~0ull;
         }
         __syncthreads();
 #pragma unroll
@@ -412,9 +416,11 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
 #pragma unroll 8
         for (int j = 0; j < nc; ++j) rk += cq[j] < me;
         const int b = g4 * 4 + h * QPB + q;
+        bool publish = false;
+        if constexpr (BUILD) publish = sb.seedk != nullptr && rk < k;  // (the k smallest, for the peers' union)
         // the bound admits every row at or below (me | 1023), whatever its id; +1 in the distance field
         // because the seed rows are in nobody's list: the scan must still ACCEPT the rows that set it
-        if (rk == k - 1 && b < B && (me | 1023u) != 0xffffffffu) {
+        if ((rk == k - 1 || publish) && b < B && (me | 1023u) != 0xffffffffu) {
             // + the rounding margin between this sum order and the reference's, rounded up
             float sm_b;
             if constexpr (BUILD) sm_b = q == 0 ? smax_built[0] : q == 1 ? smax_built[1] : q == 2 ? smax_built[2] : smax_built[3];
@@ -424,8 +430,13 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
             thr = thr + slack;
             const uint32_t key = f32_to_ordered(thr) + 1u;
             const unsigned long long bound = ((unsigned long long)key + 1ull) << 32;
-            gkey[b] = bound;
-            if constexpr (BUILD) ((unsigned long long *)((float *)((unsigned char *)cand + kSeedKeepOff) + 16))[q] = bound;
+            if constexpr (BUILD) {
+                if (publish) sb.seedk[(int64_t)b * kSeedKeys + rk] = bound;
+            }
+            if (rk == k - 1) {
+                gkey[b] = bound;
+                if constexpr (BUILD) ((unsigned long long *)((float *)((unsigned char *)cand + kSeedKeepOff) + 16))[q] = bound;
+            }
         }
     }
     if constexpr (BUILD) {
@@ -873,7 +884,8 @@ int annlite::launch_seed_bound(int64_t M, bool skw, const void *codes_dev, int c
 int annlite::launch_seed_build(bool skw, const void *codes_dev, int64_t S, const uint32_t *valid_bits_dev, const LutBuild &build,
                                float *lut_out, int64_t B, int64_t Ks, int64_t k, float *qstep, double *qlo, float *smax, float *qlom,
                                unsigned long long *gk, void *fill, size_t fill_bytes, size_t gk_bytes, hipStream_t st,
-                               unsigned long long *gseed0, uint8_t *btab, int target, unsigned long long *dbg) {
+                               unsigned long long *gseed0, uint8_t *btab, int target, unsigned long long *dbg,
+                               unsigned long long *seedk) {
     constexpr int M = 16;
     SeedBuild sb;
     sb.queries = build.queries;
@@ -894,6 +906,7 @@ int annlite::launch_seed_build(bool skw, const void *codes_dev, int64_t S, const
     sb.btab = (gseed0 && btab) ? btab : nullptr;
     sb.target = target;
     sb.dbg = dbg;
+    sb.seedk = seedk;
     auto fn = skw ? seed_bound_kernel<M, true, 4, false, true> : seed_bound_kernel<M, false, 4, false, true>;
     const size_t lds = (size_t)Ks * M * 16 + (size_t)kSeedLdsExtra;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

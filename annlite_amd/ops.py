@@ -202,6 +202,51 @@ def pq_search_topk(lut_kind: int, queries: torch.Tensor, codebooks: torch.Tensor
     return op if packed else (od, oi)
 
 
+def pq_search_split(phase: int, lut_kind: int, queries: torch.Tensor, codebooks: torch.Tensor, codes: torch.Tensor, k: int, M: int,
+                    Ks: int, state, workspace: ScanWorkspace, valid_bits: Optional[torch.Tensor] = None, row_base: int = 0,
+                    n_rows: Optional[int] = None, codes_layout: int = CODES_PLAIN, seed_rows: int = 0,
+                    seed_keys: Optional[torch.Tensor] = None):
+    """One half of the row-sharded search with a seed exchange (``annlite_pq_search_split``).
+    ``PHASE_PREPARE`` -> the rank's seed keys i64 [B, SEED_KEYS], or None when the split does not apply to this batch (nothing
+    was launched: make the plain call); ``PHASE_SCAN`` -> the packed result i64 [B, k, 2] of the prepared batch (same
+    arguments, same workspace object, same stream)."""
+    from ._capi import NOT_APPLICABLE, PHASE_PREPARE, SEED_KEYS
+
+    N = codes.shape[0] if n_rows is None else n_rows
+    B, D = queries.shape
+    cb = code_bytes_of(codes)
+    need = ctypes.c_int64(0)
+    check(lib().annlite_pq_search_workspace_bytes(N, M, Ks, cb, B, k, ctypes.byref(need)), 'pq_search_workspace_bytes')
+    dev = codes.device
+    ws = workspace.get(int(need.value), dev)
+    op = None
+    if phase == PHASE_PREPARE:
+        seed_keys = torch.empty((B, SEED_KEYS), dtype=torch.int64, device=dev) if seed_keys is None else seed_keys
+    else:
+        op = torch.empty((B, k, 2), dtype=torch.int64, device=dev)
+    rc = lib().annlite_pq_search_split(phase, int(seed_rows), lut_kind, queries.data_ptr(), B, D, codebooks.data_ptr(), codes.data_ptr(),
+                                       cb, codes_layout, N, M, Ks, _ptr(valid_bits), k, row_base, None, None, _ptr(op), 0,
+                                       ws.data_ptr(), ws.numel(), stream_ptr(), state.ptr, _ptr(seed_keys))
+    if rc == NOT_APPLICABLE:
+        return None
+    check(rc, 'pq_search_split')
+    return seed_keys if phase == PHASE_PREPARE else op
+
+
+def pq_search_seed_union(all_keys: torch.Tensor, codes: torch.Tensor, B: int, k: int, M: int, Ks: int, workspace: ScanWorkspace,
+                         n_rows: Optional[int] = None) -> None:
+    """``all_keys`` i64 [G, B, SEED_KEYS] (the all-gathered seed keys of the G ranks): tighten the prepared batch's bounds to the
+    k-th smallest of every query's G * k keys (``annlite_pq_search_seed_union``; between the two halves of ``pq_search_split``)."""
+    N = codes.shape[0] if n_rows is None else n_rows
+    cb = code_bytes_of(codes)
+    need = ctypes.c_int64(0)
+    check(lib().annlite_pq_search_workspace_bytes(N, M, Ks, cb, B, k, ctypes.byref(need)), 'pq_search_workspace_bytes')
+    ws = workspace.get(int(need.value), codes.device)
+    assert all_keys.dtype == torch.int64 and all_keys.is_contiguous() and all_keys.shape[1] == B
+    check(lib().annlite_pq_search_seed_union(all_keys.data_ptr(), all_keys.shape[0], N, M, Ks, cb, B, k, ws.data_ptr(), ws.numel(),
+                                             stream_ptr()), 'pq_search_seed_union')
+
+
 def ivf_select_cells(kind: int, queries: torch.Tensor, centroids: torch.Tensor, n_probe: int) -> torch.Tensor:
     """The ``n_probe`` nearest cells of every query, i32 [B, P] ascending in (distance, cell)
     (``AnnLite._cell_selection``, annlite/index.py:458-466).  kind 0: squared L2, 1: negative inner product."""

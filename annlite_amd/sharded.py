@@ -47,6 +47,9 @@ def gather_and_merge(local_d: torch.Tensor, local_i: torch.Tensor, merge_fn: Cal
     return merge_fn(all_d.view(G, B, k), all_i.view(G, B, k))
 
 
+SEED_KEYS = 16  # keys per query in the ranks' seed exchange (annlite_hip.h: ANNLITE_SEED_KEYS)
+
+
 class ShardedSearcher:
     """``scan_fn(queries, k) -> (dist [B,k], global ids [B,k])`` over the local shard, then the
     gather + ``merge_fn([G,B,k], [G,B,k]) -> ([B,k], [B,k])``."""
@@ -66,10 +69,22 @@ class ShardedPQIndex:
     the global table; ``search_batch`` returns global row ids on every rank."""
 
     def __init__(self, index, row_base: int, group: Optional[dist.ProcessGroup] = None,
-                 merge: Optional[Callable] = None, merge_packed: Optional[Callable] = None):
+                 merge: Optional[Callable] = None, merge_packed: Optional[Callable] = None, seed_exchange: bool = False,
+                 n_total: Optional[int] = None):
         self.index = index
         self.row_base = int(row_base)
         self.group = group
+        # SEED EXCHANGE (opt-in): every rank repeats the per-batch work for all B queries, and the largest part
+        # of it is the seed bound -- the exact k-th distance of the table's first ~32768 rows.  With the exchange a rank seeds from
+        # 1/G of those rows, the ranks all-gather the bounds of their seeds' k smallest rows ([B, 16] keys, 128 KB at 1024
+        # queries: one more small collective per batch, on its OWN process group so that it never queues behind a result
+        # all-gather that waits for a scan) and every rank starts its scan with the k-th smallest of the union.  OFF by default:
+        # measured on one MI355X (one rank, 7 emulated peers: bench.py --seed-exchange --emulate-seed-peers 8) the collective's
+        # cross-stream hops between the preparation launch and the scan cost more than the smaller seed saves (DESIGN.md section 8).
+        self.seed_exchange = bool(seed_exchange)
+        self.n_total = n_total  # rows of the whole table (default: this shard's rows x world size)
+        self._seed_group = None
+        self._peer_keys = None  # (measurement aid, bench.py --emulate-seed-peers: precomputed key sets standing in for peers)
         if merge is None or merge_packed is None:  # the product: the merge kernels (tests inject numpy restatements)
             from . import ops
 
@@ -92,8 +107,12 @@ class ShardedPQIndex:
         measured ~15 us of idle time per batch on one MI355X, twice per batch)."""
         gather = dist.is_available() and dist.is_initialized() and (
             dist.get_world_size(self.group) > 1 or bool(os.environ.get('ANNLITE_FORCE_GATHER')))
-        packed = self.index.search_batch_packed(queries, limit, self.row_base) if gather and isinstance(
-            queries, torch.Tensor) else None
+        packed = None
+        if gather and isinstance(queries, torch.Tensor):
+            if self.seed_exchange and hasattr(self.index, 'split_prepare'):
+                packed = self._split_search(queries, limit)
+            if packed is None:
+                packed = self.index.search_batch_packed(queries, limit, self.row_base)
         if packed is None:
             return PendingSearch(self, value=ShardedSearcher(self._scan, self._merge, self.group).search(queries, limit))
         # ONE collective per batch: (global id, raw ADC sum) pairs, 16 B each; merged on the raw sums (the
@@ -104,10 +123,16 @@ class ShardedPQIndex:
             gathered = torch.empty((G * B, k, 2), dtype=torch.int64)
             dist.all_gather_into_tensor(gathered, packed.contiguous(), group=self.group)
             return PendingSearch(self, value=self._merge_packed(gathered.view(G, B, k, 2), sqrt=self.index.sqrt_epilogue))
+        return self._exchange_result(packed, None)
+
+    def _exchange_result(self, packed: torch.Tensor, scanned) -> 'PendingSearch':
+        G = dist.get_world_size(self.group)
+        B, k, _ = packed.shape
         if self._xstream is None:
             self._xstream = torch.cuda.Stream(device=packed.device)
-        scanned = torch.cuda.Event()
-        scanned.record(torch.cuda.current_stream(packed.device))
+        if scanned is None:  # (the scan ran on the caller's stream)
+            scanned = torch.cuda.Event()
+            scanned.record(torch.cuda.current_stream(packed.device))
         with torch.cuda.stream(self._xstream):
             self._xstream.wait_event(scanned)
             packed.record_stream(self._xstream)
@@ -118,6 +143,50 @@ class ShardedPQIndex:
             done = torch.cuda.Event()
             done.record(self._xstream)
         return PendingSearch(self, value=value, done=done, keep=(packed, gathered))
+
+    # ------------------------------------------------------------------ seed exchange
+    def seed_rows(self) -> int:
+        """Rows of this rank's seed: the single-GPU rule (N / 32 clamped to [8192, 32768]) applied to the WHOLE table, dealt out
+        over the ranks (not below 4096: the seed costs ~0.7 us per 1024 rows, the bound's rank is what the scan pays for)."""
+        G = dist.get_world_size(self.group) + (0 if self._peer_keys is None else int(self._peer_keys.shape[0]))
+        n_total = self.n_total or getattr(self.index, '_n_rows', 0) * G
+        whole = min(32768, max(8192, -(-(n_total // 32) // 1024) * 1024))
+        return max(4096, -(-(whole // G) // 1024) * 1024)
+
+    def _split_search(self, queries: torch.Tensor, limit: int) -> Optional[torch.Tensor]:
+        """This rank's packed result through the search in two halves (index.split_prepare), everything in the calling stream's
+        order.  The per-batch protocol -- identical on every rank whatever its private state:
+            batch = index.split_prepare(...)     None: the split is not for this configuration (every rank says so: no collective)
+            all_keys = exchange(batch.keys or "no bound" keys)      ALWAYS: the ranks' collectives stay aligned although
+                                                 `keys is None` (table too small, kernel choice not settled) is a per-rank fact
+            batch.union(all_keys); batch.scan()  -- or batch.plain(), the ordinary search, where keys is None
+        (Measured on one MI355X, DESIGN.md section 8: the collective between the two halves costs two cross-stream hops of
+        15-40 us each on this runtime; a caller that alternates batches between two streams hides part of them.  A deeper
+        pipeline -- preparation side, scans and result exchange on streams of their own, one call apart -- was built and measured
+        SLOWER: HIP streams share a few in-order hardware queues, and a preparation launch needs every CU a scan holds.)"""
+        batch = self.index.split_prepare(queries, limit, self.row_base, self.seed_rows(), None)
+        if batch is None:
+            return None
+        keys = batch.keys if batch.keys is not None else torch.full((batch.n_queries, SEED_KEYS), -1, dtype=torch.int64,
+                                                                    device=queries.device)
+        all_keys = self._exchange_seeds(keys)
+        if batch.keys is None:
+            return batch.plain()
+        batch.union(all_keys)
+        return batch.scan()
+
+    def _exchange_seeds(self, keys: torch.Tensor) -> torch.Tensor:
+        """ONE all-gather of the ranks' seed keys [B, 16] -> [G, B, 16], in the calling (preparation) stream's order."""
+        G = dist.get_world_size(self.group)
+        if self._seed_group is None:  # (first batch, every rank: new_group is itself collective)
+            ranks = dist.get_process_group_ranks(self.group) if self.group is not None else None
+            self._seed_group = dist.new_group(ranks=ranks)
+        out = torch.empty((G * keys.shape[0], keys.shape[1]), dtype=keys.dtype, device=keys.device)
+        dist.all_gather_into_tensor(out, keys.contiguous(), group=self._seed_group)
+        out = out.view(G, keys.shape[0], keys.shape[1])
+        if self._peer_keys is not None:
+            out = torch.cat([out, self._peer_keys.to(out.device)], dim=0)
+        return out
 
 
 class PendingSearch:

@@ -84,6 +84,14 @@ def parse():
     p.add_argument('--ivf-cells', type=int, default=256,
                    help='extra leg (N=1, never `value`): pruned search over this many cells; 0 = skip')
     p.add_argument('--ivf-probe', type=int, default=16)
+    p.add_argument('--seed-exchange', action='store_true',
+                   help='N > 1 (opt-in): every rank seeds from 1 / N of the single-GPU seed rows and the ranks all-gather their seeds\' '
+                        'k smallest bounds before the scan (sharded.py: measured slower than the plain search on this runtime)')
+    p.add_argument('--emulate-seed-peers', type=int, default=0,
+                   help='ONE rank with the exchange forced (ANNLITE_FORCE_GATHER=1 under torchrun): stand-ins for P - 1 peers in the '
+                        'seed exchange -- key sets precomputed, untimed, from P - 1 other row ranges of THIS shard (valid bounds for it) '
+                        '-- so that a single GPU runs a rank of a P-rank job at that job\'s cost: seed from 1 / P of the rows, the '
+                        'collective, the union over P key sets, a scan that starts from a P-rank bound')
     return p.parse_args()
 
 
@@ -227,7 +235,7 @@ def main():
         index.add_with_ids(xs, torch.arange(a - lo, b - lo, device=dev, dtype=torch.int64))
     torch.cuda.synchronize()
     index_s = time.time() - t0
-    sharded = ShardedPQIndex(index, row_base=lo)
+    sharded = ShardedPQIndex(index, row_base=lo, seed_exchange=args.seed_exchange, n_total=N)
 
     gq = torch.Generator(device=dev)
     gq.manual_seed(4321)
@@ -259,6 +267,32 @@ def main():
     for _ in range(args.prewarm_steps):
         step()
     torch.cuda.synchronize()
+    n_emulated = 0
+    if args.emulate_seed_peers > 1 and world == 1 and use_dist and os.environ.get('ANNLITE_FORCE_GATHER') and args.seed_exchange:
+        # (after the set-up steps: the table's kernel state has settled by now, PREPARE applies)
+        from annlite_amd._capi import PHASE_PREPARE
+
+        P = args.emulate_seed_peers
+        s_rows = max(4096, -(-(min(32768, max(8192, -(-(N * P // 32) // 1024) * 1024)) // P) // 1024) * 1024)
+        kind, xq = index._scan_inputs(queries, index._pre(queries))
+        peers = []
+        for j in range(1, P):
+            # (row ranges in the first half of the shard: a view must keep more than half the table's rows, or the table's kernel
+            # state takes it for another table and measures again)
+            off = (j * (n_local // (2 * P))) // 64 * 64
+            pk = ops.pq_search_split(PHASE_PREPARE, kind, xq, codec.codebooks_dev, index._codes[off:], k, M, Ks, index.scan_state,
+                                     index._ws, valid_bits=index._valid[off // 32:], n_rows=n_local - off,
+                                     codes_layout=index._layout(), seed_rows=s_rows)
+            if pk is not None:
+                peers.append(pk.clone())
+        if len(peers) == P - 1:
+            sharded._peer_keys = torch.stack(peers).contiguous()
+            sharded.n_total = N * P  # (this shard stands for 1 / P of a P-times larger table)
+            n_emulated = P
+        torch.cuda.synchronize()
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
     for w_i in range(max(args.warmup, len(streams))):  # (every stream warms its own scratch buffer up)
         with torch.cuda.stream(streams[w_i % len(streams)]):
             step()
@@ -277,6 +311,7 @@ def main():
             out = pending.result(wait=False)  # read only after the closing synchronisation
         pending = nxt
     out = pending.result(wait=False)
+    host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3  # host time per step to ENQUEUE the K steps (no device wait in it)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -583,6 +618,7 @@ def main():
             'gpu_matches_cpu_bit_exact_all': parity_all, 'queries_checked': nq_all, 'queries_differing': n_bad,
         }
 
+    gathering_cfg = use_dist and (world > 1 or bool(os.environ.get('ANNLITE_FORCE_GATHER')))
     if rank == 0:
         # The scan does not stream its algorithmic bytes from HBM (every code row is shared by the 16 / 32 queries of a
         # tile and stays in L2): its roof is the LDS look-up rate.  One ds_read_b128 (4 LDS cycles per wave64) serves
@@ -628,11 +664,17 @@ def main():
                 # independent batches alternate between this many HIP streams (each batch's kernels in order on its own)
                 'streams': n_streams,
                 'prewarm_steps': args.prewarm_steps,  # untimed set-up steps BEFORE the W warm-up steps (clock ramp)
+                # N > 1: every rank seeds from 1 / N of the single-GPU seed rows and the ranks all-gather their seeds' k smallest
+                # bounds before the scan (sharded.py); seed_peers_emulated: --emulate-seed-peers (one rank standing for P)
+                'seed_exchange': bool(gathering_cfg and sharded.seed_exchange and index.split_supported(queries, k)),
+                'seed_rows': sharded.seed_rows() if gathering_cfg else None,
+                'seed_peers_emulated': n_emulated,
             },
             # N > 1: every rank's own clock over the K steps, its scan kernel (HIP events) and the exchange alone (one packed
             # all-gather + merge, 20 back to back) -- a first multi-GPU run says where its time went
             'per_rank': per_rank,
             'exchange_ms': exchange_ms,
+            'host_enqueue_ms_per_step': host_enqueue_ms,  # (close to ms_per_step: the host, not the GPU, paces the loop)
             'recall_at_10': recall_adc,
             # `value` is the reference's own search semantics (plain ADC top-k, the parity quantity); the north-star's
             # ">= 90 % recall@10" figure is the re-rank leg below

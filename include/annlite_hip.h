@@ -48,6 +48,8 @@ extern "C" {
 #define ANNLITE_ERR_UNSUPPORTED 2 /* valid request this build has no kernel for                    */
 #define ANNLITE_ERR_HIP 3         /* HIP runtime error (no device, launch failure ...)             */
 #define ANNLITE_ERR_WORKSPACE 4   /* workspace too small: call the matching *_workspace_bytes()    */
+#define ANNLITE_NOT_APPLICABLE 5  /* not an error: the request has no effect for this shape / state; nothing was launched
+                                     (annlite_pq_search_split: make the plain call instead)                              */
 
 /* metric ids == annlite/enums.py:25-28 (Metric.EUCLIDEAN / INNER_PRODUCT / COSINE) */
 #define ANNLITE_METRIC_EUCLIDEAN 1
@@ -208,6 +210,33 @@ ANNLITE_API int annlite_pq_search_topk_ex(int lut_kind, const float *queries_dev
                               int64_t row_base, float *out_dist_dev, int64_t *out_id_dev, int64_t *out_packed_dev,
                               int flags, void *workspace_dev, size_t workspace_bytes, void *stream,
                               struct annlite_scan_state *state);
+
+/* The row-sharded search of one process per GPU, with a SEED EXCHANGE between the ranks: the search above
+ * in two halves, so that a rank can seed from 1/G of the rows a single GPU would and still start its scan with the bound of
+ * all G ranks' seed rows together.  (Every rank repeats the per-batch work for all B queries; the seed bound -- the exact
+ * k-th distance of the first rows -- is the largest part of it: 22 of 39 us at 32768 rows x 1024 queries.)
+ *   phase ANNLITE_PHASE_PREPARE  tables, parameters, reset, the seed bound from this rank's first `seed_rows` rows (<= 0: the
+ *       single-GPU default) and -- the rank's contribution to one all-gather -- seed_keys_dev [B][ANNLITE_SEED_KEYS] u64: the
+ *       bounds implied by the seed's k smallest rows, ascending (all-ones where it has fewer).  Outputs untouched.
+ *   annlite_pq_search_seed_union  all_keys_dev [G][B][ANNLITE_SEED_KEYS] (the all-gathered keys): the k-th smallest of a
+ *       query's G * k keys has k distinct rows of the GLOBAL table at or below it -- the prepared batch's bound becomes
+ *       min(own, that).
+ *   phase ANNLITE_PHASE_SCAN     the scan of the prepared batch (same arguments, same workspace, same stream order).
+ * PREPARE returns ANNLITE_NOT_APPLICABLE -- nothing launched, make the plain call -- unless the batch runs the byte-table
+ * plan with the fused preparation launch (M = 16, uint8 codes, L2 tables, k <= 16, D <= 256, N >= 4096) and `state` has
+ * settled on the byte-table kernel.  Results are those of the plain call, bit for bit (a bound only prunes). */
+#define ANNLITE_PHASE_PREPARE 1
+#define ANNLITE_PHASE_SCAN 2
+#define ANNLITE_SEED_KEYS 16
+ANNLITE_API int annlite_pq_search_split(int phase, int64_t seed_rows, int lut_kind, const float *queries_dev, int64_t B, int64_t D,
+                            const float *codebooks_dev, const void *codes_dev, int code_bytes, int codes_layout,
+                            int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev, int64_t k,
+                            int64_t row_base, float *out_dist_dev, int64_t *out_id_dev, int64_t *out_packed_dev,
+                            int flags, void *workspace_dev, size_t workspace_bytes, void *stream,
+                            struct annlite_scan_state *state, uint64_t *seed_keys_dev);
+ANNLITE_API int annlite_pq_search_seed_union(const uint64_t *all_keys_dev, int64_t G, int64_t N, int64_t M, int64_t Ks,
+                                 int code_bytes, int64_t B, int64_t k, void *workspace_dev, size_t workspace_bytes,
+                                 void *stream);
 
 /* Same scan, but return the UNMERGED per-slice lists: plan.n_slices * k candidates per query
  * ([B][n_slices*k], unordered across slices, (+inf,-1) where a slice had fewer rows).  The set is a

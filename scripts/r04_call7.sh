@@ -1,0 +1,30 @@
+#!/usr/bin/env bash
+# round 4, GPU call 7: split search tests; the shard with the exchange forced: no seed exchange / seed exchange (1 rank) / 8 emulated
+# peers, one and two caller streams; kernel timeline of the emulated 8-rank pipeline
+set -u
+cd "$(dirname "$0")/.."; OUT=gpurun_out/r04c7; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_round4_gpu.py -m gpu -q --maxfail=10 -p no:cacheprovider -k "split_search or seed_exchange" > $OUT/pytest_new.txt 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_new.txt
+tail -25 $OUT/pytest_new.txt
+A="--rows 1250000 --legs none --cpu-queries 4 --cpu-repeats 1 --recall-queries 0 --no-rerank --steps 200 --warmup 20"
+T="python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1"
+export ANNLITE_FORCE_GATHER=1
+p=29550
+for s in 2 1; do
+  for v in "--no-seed-exchange" "" "--emulate-seed-peers 8"; do
+    p=$((p+1)); n=$(echo "s${s}_$v" | tr -d ' -')
+    timeout 300 $T --master-port $p bench.py --gpus 1 $A --streams $s $v > $OUT/shard_$n.json 2>$OUT/err_$n.txt
+  done
+done
+p=$((p+1)); timeout 300 $T --master-port $p bench.py --gpus 1 $A --streams 2 --no-seed-exchange > $OUT/shard_s2_noseedexchange_again.json 2>/dev/null
+p=$((p+1)); timeout 300 $T --master-port $p bench.py --gpus 1 $A --streams 2 --emulate-seed-peers 8 > $OUT/shard_s2_emulateseedpeers8_again.json 2>/dev/null
+bash scripts/gpu_timeline.sh seedx 40 -- $T --master-port 29570 bench.py --gpus 1 --rows 1250000 --legs none --cpu-queries 0 --recall-queries 0 --no-rerank --steps 12 --warmup 4 --prewarm-steps 8 --streams 1 --emulate-seed-peers 8 > $OUT/timeline_seedx.txt 2>&1
+unset ANNLITE_FORCE_GATHER
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r04c7/*.json')):
+    try:
+        d=json.loads([l for l in open(f) if l.startswith('{')][-1]); r=d['roofline']; c=d['config']
+        print('%-44s ms/step %.4f kernel_ms %.4f exch %.4f seedx %s rows %s emul %s streams %s parity %s' % (f.split('/')[-1], d['ms_per_step'], r['kernel_ms'], d.get('exchange_ms') or 0, c.get('seed_exchange'), c.get('seed_rows'), c.get('seed_peers_emulated'), c.get('streams'), (d.get('cpu_baseline') or {}).get('gpu_matches_cpu_bit_exact_all')))
+    except Exception as e: print(f, 'ERR', e)
+PY
+tail -42 $OUT/timeline_seedx.txt

@@ -273,3 +273,92 @@ def test_early_merger_and_its_give_up_path(ops, oracle, monkeypatch, patience, M
             for rep in range(3):
                 d, i = ops.pq_search_topk(LUT_L2, q_d, cb_d, cd, k, M, Ks, codes_layout=layout, valid_bits=bits)
                 assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(d.cpu().numpy(), rd), (env, layout, rep)
+
+
+# ------------------------------------------------------------------------------------ the search in two halves with a seed exchange
+def test_split_search_with_seed_union_equals_the_plain_search(ops, oracle):
+    """annlite_pq_search_split (PREPARE -> annlite_pq_search_seed_union -> SCAN): a rank that seeds from few rows and tightens
+    its bound with the union of "peer" key sets (here: the seeds of other row ranges of the same table -- valid bounds for it)
+    returns the plain search's bits; NOT_APPLICABLE before the table's state has settled and for shapes without the fused
+    preparation launch (nothing launched: the plain call follows)."""
+    import torch
+    from annlite_amd import _capi
+    from annlite_amd._capi import LUT_L2, PHASE_PREPARE, PHASE_SCAN, SEED_KEYS
+
+    rs = np.random.RandomState(5)
+    N, M, dsub, Ks, B, k = 600_000, 16, 8, 256, 70, 10
+    D = M * dsub
+    cb = rs.randn(M, Ks, dsub).astype(np.float32)
+    A = rs.randn(8, D).astype(np.float32)
+    cb_d = ops.to_dev(cb)
+    codes_d = torch.empty((N, M), dtype=torch.uint8, device='cuda')
+    for c0 in range(0, N, 100_000):
+        x = (rs.randn(100_000, 8).astype(np.float32) @ A + 0.05 * rs.randn(100_000, D).astype(np.float32)).astype(np.float32)
+        codes_d[c0:c0 + 100_000] = ops.pq_encode(ops.to_dev(x), cb_d)
+    q = (rs.randn(B, 8).astype(np.float32) @ A + 0.05 * rs.randn(B, D).astype(np.float32)).astype(np.float32)
+    q_d = ops.to_dev(q)
+    codes = codes_d.cpu().numpy()
+    lut = oracle.batch_precompute_adc_table_c(q, dsub, Ks, cb)
+    rd, ri = oracle.adc_search_c(lut, codes, k, threads=oracle.max_threads())
+    for layout in (1, 0):
+        cd = ops.codes_skew(codes_d) if layout else codes_d
+        ws, state = ops.ScanWorkspace(), _capi.ScanState()
+        call = lambda phase, **kw: ops.pq_search_split(phase, LUT_L2, q_d, cb_d, cd, k, M, Ks, state, ws, codes_layout=layout, **kw)
+        assert call(PHASE_PREPARE, seed_rows=4096) is None  # the state has not seen a launch yet: not applicable
+        keys = None
+        for _ in range(12):  # a few plain calls settle the kernel choice (read without synchronising: give it launches)
+            d, i = ops.pq_search_topk(LUT_L2, q_d, cb_d, cd, k, M, Ks, codes_layout=layout, workspace=ws, state=state)
+            torch.cuda.synchronize()
+            assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(d.cpu().numpy(), rd)
+            keys = call(PHASE_PREPARE, seed_rows=4096)
+            if keys is not None:
+                break
+        assert keys is not None and keys.shape == (B, SEED_KEYS), 'the state never settled on the byte-table kernel'
+        torch.cuda.synchronize()
+        kh = keys.cpu().numpy().view(np.uint64)
+        assert (np.diff(kh[:, :k].astype(np.float64), axis=1) >= 0).all() and (kh[:, k:] == np.uint64(2 ** 64 - 1)).all()
+        # "peers": the seeds of three other row ranges (each a PREPARE on a view of the table), then this rank's own
+        peers = []
+        for off in (64_000, 128_000, 256_000):  # (views of more than half the table: the state's size watch stays quiet)
+            sub = cd[off:]
+            pk = ops.pq_search_split(PHASE_PREPARE, LUT_L2, q_d, cb_d, sub, k, M, Ks, state, ws, codes_layout=layout, seed_rows=4096)
+            assert pk is not None
+            peers.append(pk.clone())
+        own = call(PHASE_PREPARE, seed_rows=4096)
+        allk = torch.stack([own] + peers).contiguous()
+        ops.pq_search_seed_union(allk, cd, B, k, M, Ks, ws)
+        packed = call(PHASE_SCAN)
+        torch.cuda.synchronize()
+        p = packed.cpu().numpy()
+        assert np.array_equal(p[..., 0], ri), layout
+        assert np.array_equal((p[..., 1] & 0xFFFFFFFF).astype(np.uint32).view(np.float32), rd), layout
+        # the union bound is at least as tight as the own one: k-th smallest of 4 k keys <= own k-th
+        uk = np.sort(allk.cpu().numpy().view(np.uint64).transpose(1, 0, 2).reshape(B, -1), axis=1)[:, k - 1]
+        assert (uk <= kh[:, k - 1]).all()
+    # a shape without the fused preparation launch: not applicable, whatever the state
+    cb32 = ops.to_dev(rs.randn(32, Ks, 4).astype(np.float32))
+    c32 = torch.randint(0, Ks, (50_000, 32), dtype=torch.uint8, device='cuda')
+    q32 = ops.to_dev(rs.randn(5, 128).astype(np.float32))
+    assert ops.pq_search_split(PHASE_PREPARE, LUT_L2, q32, cb32, c32, k, 32, Ks, _capi.ScanState(), ops.ScanWorkspace()) is None
+
+
+def test_bench_seed_exchange_under_torchrun_one_rank(tmp_path):
+    """bench.py as one rank under torchrun with the exchange forced and 8 emulated seed peers: the seed collective + union + scan
+    pipeline on two streams, results = the CPU oracle for every query of the batch."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = dict(os.environ, ANNLITE_FORCE_GATHER='1', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29537', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--rows', '400000', '--steps', '12',
+           '--warmup', '2', '--recall-queries', '0', '--cpu-queries', '2', '--no-rerank', '--legs', 'none', '--seed-exchange',
+           '--emulate-seed-peers', '8']
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert rec['config']['seed_exchange'] is True and rec['config']['seed_peers_emulated'] == 8 and rec['config']['seed_rows'] == 4096
+    assert rec['per_rank'][0]['exchange_ms'] is not None and rec['exchange_ms'] > 0

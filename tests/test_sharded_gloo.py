@@ -95,3 +95,118 @@ def test_sharded_search_world2_gloo(oracle):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the row-sharded search WITH the seed exchange (ShardedPQIndex._split_search / _exchange_seeds): two ranks, the
+# product's collectives (a second process group for the seeds, the result all-gather on the first), the kernels restated in numpy
+def _split_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import pq_oracle
+    from annlite_amd.sharded import SEED_KEYS, ShardedPQIndex, numpy_merge, numpy_merge_packed, shard_range
+
+    rs = np.random.RandomState(1)
+    N, M, Ks, B, k = 40_000, 16, 256, 9, 10
+    codes = rs.randint(0, Ks, size=(N, M)).astype(np.uint8)
+    codes[19_990:20_010] = codes[7]  # ties across the shard boundary
+    lo, hi = shard_range(N, world, rank)
+    NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+    def key_of(d):  # monotone u64 image of a non-negative f32 distance, as a bound: (bits + 2) << 32 (the kernels' form)
+        return (d.astype(np.float32).view(np.uint32).astype(np.uint64) + np.uint64(2)) << np.uint64(32)
+
+    class FakeShard:
+        sqrt_epilogue = True
+        _n_rows = hi - lo
+
+        def __init__(self):
+            self.batch = 0
+            self.log = []
+
+        def _dist(self, lut):
+            return np.stack([pq_oracle.dist_pqcodes_to_codebooks_c(lut[b], codes[lo:hi]) for b in range(lut.shape[0])])
+
+        def _packed(self, lut, bound=None):
+            d = self._dist(lut)
+            out = np.empty((lut.shape[0], k, 2), dtype=np.int64)
+            for b in range(lut.shape[0]):
+                dd = d[b]
+                order = np.lexsort((np.arange(dd.shape[0]), dd))
+                if bound is not None:  # the scan under a bound: rows above it never reach the lists
+                    order = order[key_of(dd[order]) <= bound[b]]
+                order = order[:k]
+                ids = np.full(k, -1, np.int64)
+                ds = np.full(k, np.inf, np.float32)
+                ids[:len(order)], ds[:len(order)] = order + lo, dd[order]
+                out[b, :, 0], out[b, :, 1] = ids, ds.view(np.uint32).astype(np.int64)
+            return torch.from_numpy(out)
+
+        def search_batch_packed(self, lut_t, kk, row_base):
+            return self._packed(lut_t.numpy())
+
+        def split_prepare(self, lut_t, kk, row_base, seed_rows, workspace):
+            lut = lut_t.numpy()
+            self.batch += 1
+            settled = not (rank == 1 and self.batch <= 2)  # rank 1's kernel choice settles two batches later than rank 0's
+            keys = None
+            if settled:
+                d = self._dist(lut)[:, :seed_rows]
+                kk_ = np.full((lut.shape[0], SEED_KEYS), NONE, dtype=np.uint64)
+                kk_[:, :k] = key_of(np.sort(d, axis=1)[:, :k])
+                keys = torch.from_numpy(kk_.view(np.int64))
+            shard = self
+
+            class Batch:
+                n_queries = lut.shape[0]
+                device = torch.device('cpu')
+
+                def union(self, all_keys):
+                    u = all_keys.numpy().view(np.uint64)  # [G, B, 16]
+                    G = u.shape[0]
+                    flat = np.sort(u.transpose(1, 0, 2).reshape(lut.shape[0], G * SEED_KEYS), axis=1)
+                    self.bound = flat[:, k - 1]
+                    shard.log.append((G, int((u[:, 0, 0] != NONE).sum())))
+
+                def scan(self):
+                    return shard._packed(lut, self.bound)
+
+                def plain(self):
+                    return shard._packed(lut)
+
+            bt = Batch()
+            bt.keys = keys
+            return bt
+
+    ok = True
+    sh = ShardedPQIndex(FakeShard(), row_base=lo, merge=numpy_merge, merge_packed=numpy_merge_packed, n_total=N, seed_exchange=True)
+    ok = ok and sh.seed_rows() == 4096  # (N / 32 clamped to 8192, over two ranks, not below 4096)
+    for step in range(5):  # several batches: the seed collective and the result collective alternate, on their own groups
+        lut = rs.rand(B, M, Ks).astype(np.float32)
+        pd, pi = sh.search_batch_async(torch.from_numpy(lut), limit=k).result()
+        rd, ri = pq_oracle.adc_search_c(lut, codes, k)
+        ok = ok and bool(np.array_equal(pd.numpy(), np.sqrt(rd)) and np.array_equal(pi.numpy(), ri))
+    # rank 1 sat out two exchanges (contributing "no bound"), rank 0 none; from batch 3 on both ranks' keys are in the union
+    log = sh.index.log
+    ok = ok and sh._seed_group is not None and len(log) == (5 if rank == 0 else 3)
+    ok = ok and all(g == 2 for g, _ in log) and [n for _, n in log][-3:] == [2, 2, 2]
+    if rank == 0:
+        ok = ok and [n for _, n in log][:2] == [1, 1]
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_sharded_search_with_seed_exchange_world2_gloo(oracle):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
