@@ -172,7 +172,9 @@ def main():
     sub = {}
     if rank == 0 and world == 1:
         me = os.path.join(ROOT, 'bench.py')
-        common = ['--legs', 'none', '--gpus', '1']
+        # (consecutive batches of a leg alternate between two streams, as the multi-GPU runs do: the next batch's table build /
+        # seed overlaps the tail of the previous scan; the leg's own config says so)
+        common = ['--legs', 'none', '--gpus', '1', '--streams', '2']
         if 'c2' in legs:  # config 2: 1M x 128, m=16, L2, batch 1024
             sub['c2'] = sub_run([me, '--rows', '1000000', '--steps', '40', '--warmup', '10'] + common, 240)
         if 'c4' in legs:  # config 4: 10M x 768, m=64, cosine, batch 256
@@ -183,7 +185,7 @@ def main():
             sub['c5'] = sub_run([os.path.join(ROOT, 'scripts', 'bench_hnsw.py'), '--rows', '5000000', '--steps', '5'], 600)
         if 'uniform' in legs:  # U[0,1)^D: unstructured codes -- the kernel the library picks for them
             sub['uniform'] = sub_run([me, '--data', 'uniform', '--steps', '10', '--warmup', '3', '--cpu-queries', '0',
-                                      '--recall-queries', '32'] + common, 300)
+                                      '--recall-queries', '32', '--legs', 'none', '--gpus', '1'], 300)
 
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -336,63 +338,15 @@ def main():
             _host_d, _host_i = index.search_batch(q_host, limit=k)  # numpy in -> numpy out (synchronous)
         host_qps = B * n_h / (time.perf_counter() - t0)
 
-    # ---- the drop-in API itself (north_star: "keeping the AnnLite(...)/index()/search() Python API and DocArray result shape"):
-    # AnnLite.search(docs) -- numpy embeddings in, doc.matches out -- and search_numpy over the SAME table; never `value` -------
-    facade = None
-    if world == 1 and 'facade' in legs:
-        import shutil
-        import tempfile
-
-        from annlite_amd import AnnLite
-        from annlite_amd.index import Document, DocumentArray
-
-        tmp = tempfile.mkdtemp(prefix='annlite_bench_')
-        try:
-            ann = AnnLite(n_dim=D, metric=args.metric, n_subvectors=M, n_clusters=Ks, data_path=tmp)
-            # adopt the bench's codec and table (indexing 10M python Documents is not what this leg measures): document id = str(row)
-            ann._pq_codec = codec
-            ann._vec_indexes = [index]
-            ann._offset2id = list(map(str, range(n_local)))
-            docs = DocumentArray([Document(id=f'q{b}', embedding=q_host[b]) for b in range(B)])
-            name = metric.name.lower()
-            n_f = max(3, min(args.steps, 20))
-
-            def timed(fn):
-                fn()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(n_f):
-                    fn()
-                return B * n_f / (time.perf_counter() - t0)
-
-            def read_all():
-                ann.search(docs, limit=k)
-                return sum(1 for d in docs for m in d.matches if m.id is not None and m.scores[name].value is not None)
-
-            f_search = timed(lambda: ann.search(docs, limit=k))
-            f_numpy = timed(lambda: ann.search_numpy(q_host, limit=k))
-            f_read = timed(read_all)
-            ann.search(docs, limit=k)
-            ok = all([m.id for m in docs[b].matches] == [str(int(x)) for x in _host_i[b] if x >= 0] for b in range(0, B, 37))
-            facade = {
-                'search': {'value': f_search, 'unit': 'queries/s',
-                           'note': 'AnnLite.search(docs, limit=k): 1024 Documents with numpy embeddings in, doc.matches out (lazy: '
-                                   'the match Documents are built when a list is first read)'},
-                'search_all_matches_read': {'value': f_read, 'unit': 'queries/s',
-                                            'note': 'the same, then EVERY match\'s id and scores[metric].value read: what the '
-                                                    'reference\'s eager loop always pays (container.py:226-233)'},
-                'search_numpy': {'value': f_numpy, 'unit': 'queries/s', 'note': 'AnnLite.search_numpy(x, limit=k): lists of dists[k] / int ids[k]'},
-                'matches_equal_index_result': bool(ok),
-            }
-        finally:
-            shutil.rmtree(tmp, ignore_errors=True)
-
     if os.environ.get('ANNLITE_DEBUG_COUNTERS') and rank == 0:
         c = _capi.debug_counters()  # of the last step (debug aid; the counters slow the kernel down)
         print('counters: slow-block entries %d, flush query-groups %d, inserting %d, publications %d, candidate rows %d' %
               (c[0], c[1], c[2], c[3], c[4]), file=sys.stderr)
 
     # ---- roofline leg: HIP events around the dominant kernel, live, over the same steps ------------
+    for _ in range(min(args.prewarm_steps, 32)):  # (the host-transfer leg above left the GPU waiting on the host: sustained clock first)
+        step()
+    torch.cuda.synchronize()
     _capi.profile_enable(True)
     kms = []
     for _ in range(max(3, min(args.steps, 10))):
@@ -555,6 +509,57 @@ def main():
                                  'recall_at_10': float(np.mean([len(set(got_iv[b]) & set(truth[b])) / k for b in range(nq)]))}
         del ivf
 
+    # ---- the drop-in API itself (north_star: "keeping the AnnLite(...)/index()/search() Python API and DocArray result shape"):
+    # AnnLite.search(docs) -- numpy embeddings in, doc.matches out -- and search_numpy over the SAME table; never `value` -------
+    facade = None
+    if world == 1 and 'facade' in legs:
+        import shutil
+        import tempfile
+
+        from annlite_amd import AnnLite
+        from annlite_amd.index import Document, DocumentArray
+
+        tmp = tempfile.mkdtemp(prefix='annlite_bench_')
+        try:
+            ann = AnnLite(n_dim=D, metric=args.metric, n_subvectors=M, n_clusters=Ks, data_path=tmp)
+            # adopt the bench's codec and table (indexing 10M python Documents is not what this leg measures): document id = str(row)
+            ann._pq_codec = codec
+            ann._vec_indexes = [index]
+            ann._offset2id = list(map(str, range(n_local)))
+            docs = DocumentArray([Document(id=f'q{b}', embedding=q_host[b]) for b in range(B)])
+            name = metric.name.lower()
+            n_f = max(3, min(args.steps, 20))
+
+            def timed(fn):
+                fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n_f):
+                    fn()
+                return B * n_f / (time.perf_counter() - t0)
+
+            def read_all():
+                ann.search(docs, limit=k)
+                return sum(1 for d in docs for m in d.matches if m.id is not None and m.scores[name].value is not None)
+
+            f_search = timed(lambda: ann.search(docs, limit=k))
+            f_numpy = timed(lambda: ann.search_numpy(q_host, limit=k))
+            f_read = timed(read_all)
+            ann.search(docs, limit=k)
+            ok = all([m.id for m in docs[b].matches] == [str(int(x)) for x in _host_i[b] if x >= 0] for b in range(0, B, 37))
+            facade = {
+                'search': {'value': f_search, 'unit': 'queries/s',
+                           'note': 'AnnLite.search(docs, limit=k): 1024 Documents with numpy embeddings in, doc.matches out (lazy: '
+                                   'the match Documents are built when a list is first read)'},
+                'search_all_matches_read': {'value': f_read, 'unit': 'queries/s',
+                                            'note': 'the same, then EVERY match\'s id and scores[metric].value read: what the '
+                                                    'reference\'s eager loop always pays (container.py:226-233)'},
+                'search_numpy': {'value': f_numpy, 'unit': 'queries/s', 'note': 'AnnLite.search_numpy(x, limit=k): lists of dists[k] / int ids[k]'},
+                'matches_equal_index_result': bool(ok),
+            }
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
     # ---- CPU baseline: the oracle (C port of the reference loops) on a bounded sample, rank 0, N=1 --
     cpu = None
     if rank == 0 and world == 1 and args.cpu_queries > 0:
@@ -696,7 +701,8 @@ def main():
                 rec[name] = {kk: r[kk] for kk in ('config', 'value', 'unit', 'recall_at_10', 'build_s', 'graph_walk_queries_per_s',
                                                  'roofline', 'cpu_baseline', 'hnsw_gpu_walk_adc', 'exhaustive_exact_rerank') if kk in r}
             else:
-                rec[name] = {'config': r['config']['workload'], 'value': r['value'], 'unit': r['unit'], 'ms_per_step': r['ms_per_step'],
+                rec[name] = {'config': r['config']['workload'], 'streams': r['config'].get('streams'), 'value': r['value'], 'unit': r['unit'],
+                             'ms_per_step': r['ms_per_step'],
                              'recall_at_10': r.get('recall_at_10'), 'roofline': r['roofline'], 'cpu_baseline': r['cpu_baseline']}
         print(json.dumps(rec))
     if use_dist:
