@@ -61,5 +61,14 @@ for f in sorted(glob.glob('gpurun_out/r04p/bench_shard_*.json')):
     except Exception as e: print(f, 'ERR', e)
 PY
   ;;
-esac; done
-find $OUT -name "*.db" -delete 2>/dev/null; true
+esac; find gpurun_out -name '*.db' -delete 2>/dev/null; find gpurun_out -name '*kernel_trace.csv' -delete 2>/dev/null; done
+# what travels back is capped at 64 MiB: keep the summaries, the kernel stats and the scan kernels' counter rows only
+prune() {
+  find gpurun_out -name "*.db" -delete 2>/dev/null
+  find gpurun_out -name "*kernel_trace.csv" -delete 2>/dev/null
+  find gpurun_out -name "*agent_info.csv" -delete 2>/dev/null
+  for f in $(find gpurun_out -name '*counter_collection.csv'); do (head -1 $f; grep annlite $f) > $f.tmp; mv $f.tmp $f; done
+  true
+}
+prune
+du -sh gpurun_out
