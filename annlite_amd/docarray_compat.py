@@ -26,15 +26,72 @@ class NamedScore:
 
 
 class Document:
+    """id / embedding / tags / text / scores / matches.  ``scores`` (a ``defaultdict(NamedScore)``) and ``matches`` (a
+    ``DocumentArray``) are created when first touched: a search result is ten thousand ``Document(id)`` objects per 1024-query
+    batch (annlite/container.py:226-233), most of which are only ever asked for their id and one score."""
+    __slots__ = ('id', 'embedding', 'tags', 'text', '_scores', '_matches', '_score1', '__dict__')
+
     def __init__(self, id: Optional[str] = None, embedding=None, tags: Optional[dict] = None, text: str = '', **kwargs):
         self.id = id if id is not None else uuid.uuid4().hex
         self.embedding = embedding
         self.tags = dict(tags) if tags else {}
         self.text = text
-        self.scores = defaultdict(NamedScore)
-        self.matches = DocumentArray()
+        self._scores = None
+        self._matches = None
+        self._score1 = None
         for k, v in kwargs.items():
             setattr(self, k, v)
+
+    @classmethod
+    def match(cls, id, score_name: str, value, embedding=None, tags=None) -> 'Document':
+        """A search match: ``Document(id)`` with ``scores[score_name].value = value`` (the score object itself is made when
+        ``scores`` is first read)."""
+        d = cls.__new__(cls)
+        d.id, d.embedding, d.tags, d.text = id, embedding, (dict(tags) if tags else {}), ''
+        d._scores, d._matches, d._score1 = None, None, (score_name, value)
+        return d
+
+    @property
+    def scores(self):
+        sc = self._scores
+        if sc is None:
+            sc = self._scores = defaultdict(NamedScore)
+            if self._score1 is not None:
+                sc[self._score1[0]].value = self._score1[1]
+                self._score1 = None
+        return sc
+
+    @scores.setter
+    def scores(self, value):
+        self._scores, self._score1 = value, None
+
+    @property
+    def matches(self):
+        if self._matches is None:
+            self._matches = DocumentArray()
+        return self._matches
+
+    @matches.setter
+    def matches(self, value):
+        self._matches = value
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st.update(id=self.id, embedding=self.embedding, tags=self.tags, text=self.text, scores=dict(self.scores),
+                  matches=list(self.matches) if self._matches is not None else [])
+        return st
+
+    def __setstate__(self, st):
+        sc = st.pop('scores', {})
+        ms = st.pop('matches', [])
+        self.id, self.embedding, self.tags, self.text = st.pop('id'), st.pop('embedding', None), st.pop('tags', {}), st.pop('text', '')
+        self._scores, self._matches, self._score1 = None, None, None
+        for k, v in st.items():
+            setattr(self, k, v)
+        for k, v in sc.items():
+            self.scores[k] = v
+        if ms:
+            self._matches = DocumentArray(ms)
 
     def __repr__(self):
         return f'<Document id={self.id!r}>'

@@ -438,16 +438,20 @@ class AnnLite:
         name = self.metric.name.lower()
         offset2id, docs = self._offset2id, self._docs
 
+        fast = getattr(Document, 'match', None)  # (the in-repo stand-in: the score object is made when first read)
+
         def resolve(offs, dists):
             out = []
-            for dist, off in zip(dists, offs):
-                doc_id = offset2id[int(off)]
-                if include_metadata and doc_id in docs:
-                    src = docs[doc_id]
-                    doc = Document(id=doc_id, embedding=getattr(src, 'embedding', None), tags=dict(getattr(src, 'tags', {}) or {}))
+            for dist, off in zip(dists, offs.tolist() if hasattr(offs, 'tolist') else offs):
+                doc_id = offset2id[off]
+                src = docs.get(doc_id) if include_metadata else None
+                if fast is not None:
+                    doc = fast(doc_id, name, dist) if src is None else fast(doc_id, name, dist, getattr(src, 'embedding', None),
+                                                                            getattr(src, 'tags', None))
                 else:
-                    doc = Document(id=doc_id)
-                doc.scores[name].value = dist
+                    doc = Document(id=doc_id) if src is None else Document(id=doc_id, embedding=getattr(src, 'embedding', None),
+                                                                           tags=dict(getattr(src, 'tags', {}) or {}))
+                    doc.scores[name].value = dist
                 out.append(doc)
             return out
 
