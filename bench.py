@@ -73,10 +73,11 @@ def parse():
     p.add_argument('--metric', choices=['euclidean', 'cosine', 'inner_product'], default='euclidean',
                    help="BASELINE config 2/3: euclidean; config 4 (10M x 768, m=64, batch 256): cosine")
     p.add_argument('--streams', type=int, choices=list(range(0, 9)), default=0,
-                   help='streams the timed batches alternate on (0 = auto: 2 when the exchange runs, else 1 -- so that the kernel '
-                        'durations rocprofv3 reports for this command are not inflated by overlap; 2 on one GPU: the next '
-                        'batch\'s table build and seed fill the CUs the previous scan\'s tail leaves idle, -1.4 %% / -4 %% per '
-                        'batch at 10M / 1.25M rows)')
+                   help='HIP streams the timed, independent batches alternate on (0 = auto: 2 when the exchange runs, else 1).  On two '
+                        'streams the next batch\'s preparation launch fills the CUs the previous scan\'s tail leaves idle (-1.8 %% per batch '
+                        'at 10M rows, -7 %% at 1.25M) -- but a scan launched while the previous one still holds the CUs is TIMED from its '
+                        'launch: rocprofv3 then reports 1.77 ms per scan kernel where HIP events around a lone launch say 1.34 '
+                        '(profiles/r04/bench_10m_n1_two_streams_rocprof_kernel_stats.txt), so the default single-GPU line stays on one stream')
     p.add_argument('--prewarm-steps', type=int, default=64, help='untimed steps of set-up before the W warm-up steps (clock ramp); 0 = none')
     p.add_argument('--layout', choices=['skewed', 'plain'], default='skewed')
     p.add_argument('--rerank-k', type=int, default=0, help='ADC candidates per row slice of the exact re-rank leg (0 = the index default, 64)')
@@ -172,8 +173,7 @@ def main():
     sub = {}
     if rank == 0 and world == 1:
         me = os.path.join(ROOT, 'bench.py')
-        # (consecutive batches of a leg alternate between two streams, as the multi-GPU runs do: the next batch's table build /
-        # seed overlaps the tail of the previous scan; the leg's own config says so)
+        # (the legs' batches alternate between two streams, as the multi-GPU runs do; each leg's own config says so)
         common = ['--legs', 'none', '--gpus', '1', '--streams', '2']
         if 'c2' in legs:  # config 2: 1M x 128, m=16, L2, batch 1024
             sub['c2'] = sub_run([me, '--rows', '1000000', '--steps', '40', '--warmup', '10'] + common, 240)
@@ -185,7 +185,7 @@ def main():
             sub['c5'] = sub_run([os.path.join(ROOT, 'scripts', 'bench_hnsw.py'), '--rows', '5000000', '--steps', '5'], 600)
         if 'uniform' in legs:  # U[0,1)^D: unstructured codes -- the kernel the library picks for them
             sub['uniform'] = sub_run([me, '--data', 'uniform', '--steps', '10', '--warmup', '3', '--cpu-queries', '0',
-                                      '--recall-queries', '32', '--legs', 'none', '--gpus', '1'], 300)
+                                      '--recall-queries', '32'] + common, 300)
 
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
