@@ -6,8 +6,8 @@ row id) per batch, then every rank merges the ``G`` lists with the same (distanc
 The reference has no collective of any kind; its only multi-worker mode is Jina ``shards=N`` with
 ``polling ALL`` and a gateway-side merge (tests/executor/test_executor.py:326-350), whose per-cell
 analogue inside one process is the hstack + argsort merge of annlite/container.py:130-138.  The
-exchange is 12 B * B * k per rank (120 KB at B=1024, k=10): latency-bound, so a single
-``all_gather_into_tensor`` per tensor is used and nothing is bucketed.
+exchange is 16 B * B * k per rank (160 KB at B=1024, k=10): latency-bound, so ONE
+``all_gather_into_tensor`` per batch is used and nothing is bucketed.
 
 The scan and the merge are injected callables so that the partition / gather logic can be covered
 by world_size-2 ``gloo`` tests on CPU (tests/test_sharded_gloo.py) with the oracle standing in for
@@ -39,12 +39,14 @@ def gather_and_merge(local_d: torch.Tensor, local_i: torch.Tensor, merge_fn: Cal
         return local_d, local_i  # (the env switch lets a 1-GPU box exercise the RCCL + merge path)
     G = dist.get_world_size(group)
     B, k = local_d.shape
-    # concatenation form ([G*B, k]): accepted by both RCCL and gloo; viewed as [G, B, k] for the merge
-    all_d = torch.empty((G * B, k), dtype=local_d.dtype, device=local_d.device)
-    all_i = torch.empty((G * B, k), dtype=local_i.dtype, device=local_i.device)
-    dist.all_gather_into_tensor(all_d, local_d.contiguous(), group=group)
-    dist.all_gather_into_tensor(all_i, local_i.contiguous(), group=group)
-    return merge_fn(all_d.view(G, B, k), all_i.view(G, B, k))
+    # ONE collective here too (the general path: re-rank, limit > 64): (id, bits of the f32 distance) pairs in one int64 buffer,
+    # concatenation form ([G*B, k, 2]: accepted by both RCCL and gloo), unpacked into [G, B, k] for the merge
+    both = torch.stack([local_i.to(torch.int64), local_d.to(torch.float32).contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF], dim=2)
+    gathered = torch.empty((G * B, k, 2), dtype=torch.int64, device=local_d.device)
+    dist.all_gather_into_tensor(gathered, both.contiguous(), group=group)
+    all_i = gathered[..., 0].contiguous().view(G, B, k)
+    all_d = gathered[..., 1].to(torch.int32).view(torch.float32).view(G, B, k)
+    return merge_fn(all_d.contiguous(), all_i)
 
 
 SEED_KEYS = 16  # keys per query in the ranks' seed exchange (annlite_hip.h: ANNLITE_SEED_KEYS)

@@ -142,8 +142,14 @@ for _ in range(max(3, a.steps)):
 kernel_ms = float(np.mean(kms))
 lpn = links.shape[1] - 1
 alg_bytes = n_expand * 4.0 * (lpn + 1) + n_eval * float(M) + B * seeds.numel() * float(M)
+# measured HBM traffic of the walk launch: the committed rocprofv3 PMC pass (FETCH_SIZE x 2 + WRITE_SIZE, profiles/traffic.json)
+try:
+    _tt = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'traffic.json')))
+    traffic = _tt.get(f'graph_beam_search_kernel:{N}x{M}x{B}', {}).get('hbm_bytes_per_launch')
+except Exception:
+    traffic = None
 roofline = {'bound': 'hbm', 'achieved': alg_bytes / (kernel_ms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
-            'frac': alg_bytes / (kernel_ms * 1e-3) / 1e9 / 8000.0, 'traffic': None,
+            'frac': alg_bytes / (kernel_ms * 1e-3) / 1e9 / 8000.0, 'traffic': traffic,
             'kernel': 'graph_beam_search_kernel', 'kernel_ms': kernel_ms,
             'algorithmic_bytes_per_launch': alg_bytes, 'expansions_per_query': n_expand / B, 'rows_evaluated_per_query': n_eval / B,
             'note': 'every evaluated row is a random 16-byte read (one 64-byte sector): the walk is latency-bound by design'}
