@@ -146,6 +146,7 @@ class AnnLite:
         self._id2offset: Dict[str, int] = {}
         self._tags: List[Optional[dict]] = []
         self._docs: Dict[str, object] = {}
+        self._tomb: Dict[int, tuple] = {}  # offset -> (doc id, document) of deleted rows: what pending lazy match lists still name
         if self.is_trained and self.snapshot_path is not None:  # index.py:194-195: restore what `dump()` left
             self._rebuild_index_from_local()
 
@@ -309,7 +310,7 @@ class AnnLite:
                 f'devices= / shard_block= / n_cells / graph arguments it was dumped with ({ex!r})') from ex
         with open(snap / 'cell_0.db', 'rb') as f:
             st = pickle.load(f)
-        self._offset2id, self._tags, self._docs = st['offset2id'], st['tags'], st['docs']
+        self._offset2id, self._tags, self._docs, self._tomb = st['offset2id'], st['tags'], st['docs'], {}
         self._offset2int = None
         self._id2offset = {d: o for o, d in enumerate(self._offset2id) if d is not None}
 
@@ -390,14 +391,14 @@ class AnnLite:
             self._offset2id[off] = None
             self._offset2int = None
             self._tags[off] = None
-            self._docs.pop(doc_id, None)
+            self._tomb[off] = (doc_id, self._docs.pop(doc_id, None))
             offs.append(off)
         if offs:
             self.vec_index(0).delete(offs)
 
     def clear(self):
         self.vec_index(0).reset()
-        self._offset2id, self._id2offset, self._tags, self._docs = [], {}, [], {}
+        self._offset2id, self._id2offset, self._tags, self._docs, self._tomb = [], {}, [], {}, {}
         self._offset2int = None
 
     def close(self):
@@ -436,15 +437,20 @@ class AnnLite:
         """(offsets, dists) of one query -> its match documents: container.py:226-233 (``Document(id=doc_id)``, the stored
         document's fields with ``include_metadata``, ``scores[metric].value = dist``)."""
         name = self.metric.name.lower()
-        offset2id, docs = self._offset2id, self._docs
-
+        # (what a LAZY list resolves against later: offsets are never reused and `clear()` / a reload rebind these containers, so
+        # the only mutation that can reach a pending list is `delete()` -- which leaves the row's id and document in `_tomb`)
+        offset2id, docs, tomb = self._offset2id, self._docs, self._tomb
         fast = getattr(Document, 'match', None)  # (the in-repo stand-in: the score object is made when first read)
 
         def resolve(offs, dists):
             out = []
             for dist, off in zip(dists, offs.tolist() if hasattr(offs, 'tolist') else offs):
                 doc_id = offset2id[off]
-                src = docs.get(doc_id) if include_metadata else None
+                if doc_id is None:  # deleted since the search: the match still is what it was when the search ran
+                    doc_id, src = tomb.get(off, (None, None))
+                    src = src if include_metadata else None
+                else:
+                    src = docs.get(doc_id) if include_metadata else None
                 if fast is not None:
                     doc = fast(doc_id, name, dist) if src is None else fast(doc_id, name, dist, getattr(src, 'embedding', None),
                                                                             getattr(src, 'tags', None))

@@ -205,7 +205,13 @@ def test_annlite_facade_over_two_fake_devices(world, tmp_path):
     for b, doc in enumerate(qd):
         assert [m.id for m in doc.matches] == [str(i) for i in ri[b]]
         assert np.allclose([m.scores['euclidean'].value for m in doc.matches], np.sqrt(rd[b]), rtol=0, atol=0)
+    # lazy match lists resolve what they named WHEN THE SEARCH RAN, also after a delete (container.py:226-233 builds them eagerly)
+    qd2 = DocumentArray([Document(id=f'p{i}', embedding=q[i]) for i in range(len(q))])
+    ann.search(qd2, limit=10)
+    assert not getattr(qd2[0].matches, 'materialised', False) and len(qd2[0].matches) == 10
     ann.delete([str(i) for i in (int(ri[0][0]), int(ri[1][0]))])
+    assert [m.id for m in qd2[0].matches] == [str(i) for i in ri[0]] and qd2[0].matches[0].tags == {'price': int(ri[0][0]) % 7}
+    assert [m.id for m in qd2[1].matches] == [str(i) for i in ri[1]]
     keep = np.ones(N, bool)
     keep[[int(ri[0][0]), int(ri[1][0])]] = False
     rows = np.nonzero(keep)[0]
