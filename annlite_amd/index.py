@@ -27,6 +27,7 @@ import hashlib
 import logging
 import sqlite3
 import warnings
+import weakref
 from pathlib import Path
 from typing import Dict, List, Optional, Union
 
@@ -147,6 +148,7 @@ class AnnLite:
         self._tags: List[Optional[dict]] = []
         self._docs: Dict[str, object] = {}
         self._tomb: Dict[int, tuple] = {}  # offset -> (doc id, document) of deleted rows: what pending lazy match lists still name
+        self._live_resolvers = weakref.WeakSet()  # resolvers of match lists not yet read: tombstones are kept only while one is alive
         if self.is_trained and self.snapshot_path is not None:  # index.py:194-195: restore what `dump()` left
             self._rebuild_index_from_local()
 
@@ -382,6 +384,11 @@ class AnnLite:
         # ids or documents (the reference takes either, index.py:389-414; a DocumentArray may itself be a list subclass)
         ids = [d if isinstance(d, str) else d.id for d in docs]
         offs = []
+        # tombstones exist for match lists handed out and not read yet; once none is left (read, or dropped by the caller) nothing
+        # can ask for a deleted row again -- a later search never returns it -- and the map is emptied instead of growing for ever
+        pending = len(self._live_resolvers) > 0
+        if not pending and self._tomb:
+            self._tomb.clear()
         for doc_id in ids:
             off = self._id2offset.pop(doc_id, None)
             if off is None:
@@ -391,7 +398,9 @@ class AnnLite:
             self._offset2id[off] = None
             self._offset2int = None
             self._tags[off] = None
-            self._tomb[off] = (doc_id, self._docs.pop(doc_id, None))
+            doc = self._docs.pop(doc_id, None)
+            if pending:
+                self._tomb[off] = (doc_id, doc)
             offs.append(off)
         if offs:
             self.vec_index(0).delete(offs)
@@ -461,6 +470,7 @@ class AnnLite:
                 out.append(doc)
             return out
 
+        self._live_resolvers.add(resolve)
         return resolve
 
     @staticmethod

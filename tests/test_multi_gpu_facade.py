@@ -212,6 +212,14 @@ def test_annlite_facade_over_two_fake_devices(world, tmp_path):
     ann.delete([str(i) for i in (int(ri[0][0]), int(ri[1][0]))])
     assert [m.id for m in qd2[0].matches] == [str(i) for i in ri[0]] and qd2[0].matches[0].tags == {'price': int(ri[0][0]) % 7}
     assert [m.id for m in qd2[1].matches] == [str(i) for i in ri[1]]
+    # ... and the tombstones live only as long as a handed-out list has not been read: the other queries' lists are still pending
+    assert set(ann._tomb) == {int(ri[0][0]), int(ri[1][0])} and len(ann._live_resolvers) == 1
+    for doc in qd2:
+        doc.matches[0]
+    del doc
+    assert len(ann._live_resolvers) == 0
+    ann.delete([])
+    assert ann._tomb == {}
     keep = np.ones(N, bool)
     keep[[int(ri[0][0]), int(ri[1][0])]] = False
     rows = np.nonzero(keep)[0]
