@@ -182,3 +182,60 @@ def test_oracle_topk_sorts_nan_last_like_numpy(oracle):
         assert np.array_equal(in_, i) and np.array_equal(dn, d, equal_nan=True)
     d, i = oracle.top_k_c(np.full((50,), np.nan, np.float32), 5)
     assert i.tolist() == [0, 1, 2, 3, 4] and np.isnan(d).all()
+
+
+# ------------------------------------------------------------------ seed exchange: what every rank must agree on without talking
+def test_split_search_conditions_are_static_configuration():
+    """``split_supported`` decides whether the ranks of a row-sharded search run the seed collective at all: it may depend on the
+    configuration, the batch's shape and the input kind only -- never on how many rows THIS rank holds (a short last shard
+    answers ``keys is None`` inside the protocol instead, sharded.py ``_split_search``)."""
+    import torch
+
+    from annlite_amd import Metric, PQCodec
+    from annlite_amd.core.index.pq_flat_gpu import PQFlatGpuIndex
+
+    def index(dim=128, m=16, metric=Metric.EUCLIDEAN, rerank=False, ks=256):
+        return PQFlatGpuIndex(dim=dim, pq_codec=PQCodec(dim=dim, n_subvectors=m, n_clusters=ks, metric=metric), metric=metric,
+                              rerank=rerank)
+
+    x = torch.zeros((4, 128))
+    a, b = index(), index()
+    b._n_rows = 10  # (no storage touched: the answer must not look at it)
+    assert a.split_supported(x, 10) and b.split_supported(x, 10) and a.split_supported(x, 16) and a.split_supported(x, 1)
+    assert not a.split_supported(x, 17) and not a.split_supported(x, 0)
+    assert not a.split_supported(x.numpy(), 10) and not a.split_supported(x[:0], 10) and not a.split_supported(x[0], 10)
+    assert not index(m=32).split_supported(x, 10) and not index(m=8).split_supported(x, 10)
+    assert not index(metric=Metric.COSINE).split_supported(x, 10) and not index(metric=Metric.INNER_PRODUCT).split_supported(x, 10)
+    assert not index(dim=512, m=16).split_supported(torch.zeros((4, 512)), 10)  # (dim > 256: the preparation launch's LDS)
+    assert not index(dim=96, m=16).split_supported(torch.zeros((4, 96)), 10)  # (6-dim sub-vectors: not a multiple of 4)
+    assert index(dim=64, m=16).split_supported(torch.zeros((4, 64)), 10)
+
+
+def test_seed_rows_deal_the_single_gpu_seed_over_the_ranks():
+    """``ShardedPQIndex.seed_rows``: the single-GPU rule (N / 32 clamped to [8192, 32768], scan.hip plan) on the WHOLE table, divided
+    by the ranks (emulated peers count), in multiples of 1024 and not below 4096."""
+    import torch
+    import torch.distributed as dist
+
+    from annlite_amd.sharded import SEED_KEYS, ShardedPQIndex
+
+    class Shard:
+        _n_rows = 1_250_000
+        sqrt_epilogue = True
+
+    port = _bench_module().free_port()
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+    try:
+        ident = lambda *a, **k: None  # noqa: E731  (merges are not called)
+        s = ShardedPQIndex(Shard(), row_base=0, merge=ident, merge_packed=ident, seed_exchange=True)
+        assert s.seed_rows() == 32768  # one rank, 1.25M rows: the single-GPU seed
+        s._peer_keys = torch.zeros((7, 4, SEED_KEYS), dtype=torch.int64)
+        assert s.seed_rows() == 4096  # 8 ranks x 1.25M = 10M rows: 32768 / 8
+        s._peer_keys = torch.zeros((1, 4, SEED_KEYS), dtype=torch.int64)
+        assert s.seed_rows() == 16384
+        s.n_total = 200_000  # a small table: 8192 rows in all, never below 4096 per rank
+        assert s.seed_rows() == 4096
+        s._peer_keys, s.n_total = None, 400_000
+        assert s.seed_rows() == 13312  # ceil(12500 / 1024) * 1024
+    finally:
+        dist.destroy_process_group()
