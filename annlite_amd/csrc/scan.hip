@@ -380,7 +380,12 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
             if (v == 32) { *c = {16, 4, 2, 8, 2, 1, 1632, 4}; return true; }   // u16 tables, 8 waves
             *c = {16, 4, 2, 16, 4, 1, 1631, 4};                               // u16 tables, 16 queries / WG, 16 waves (variant 31)
             return true;
-        case 32: *c = {32, 4, 1, 12, 3, 1, 3230, 4}; return true;  // u16 tables, 8 queries / WG
+        case 32:
+            // default: byte tables (scan_q8.hip, 3250: one entry group, 16 queries / WG, 15 scanning waves + 1 consumer -- 10M rows x 1024
+            // queries 2.79 ms against the u16 tables' 7.41); k > 16, tile mode and variant 31: u16 tables, 8 queries / WG
+            if ((v == 0 || v == 50) && !tiles && k <= 16) { *c = {32, 4, 1, 16, 4, 1, 3250, 5}; return true; }
+            *c = {32, 4, 1, 12, 3, 1, 3230, 4};
+            return true;
         case 64:
             // default: byte tables (scan_q8.hip, WIDE: 8 queries per 8-byte entry, u16 sums), 15 scanning waves + 1 consumer;
             // k > 16, tile mode and variant 31: the u16-table kernel (4 queries per entry, 12 waves)
@@ -950,8 +955,8 @@ enum SearchMode { kModePlain, kModeGuarded, kModeByteStats, kModeU16, kModeU16Pr
 
 static SearchMode search_policy(annlite_scan_state *s, int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t k,
                                 bool tiles) {
-    // the shapes with both a byte-table and a u16-table kernel: M = 16 / u8 codes, M = 8 / u16 codes up to Ks = 512
-    const bool both = ((M == 16 || M == 8) && code_bytes == 1 && Ks <= 256) || (M == 8 && code_bytes == 2 && Ks <= 1024);
+    // the shapes with both a byte-table and a u16-table kernel: M = 8 / 16 / 32 with u8 codes, M = 8 / u16 codes up to Ks = 1024
+    const bool both = ((M == 16 || M == 8 || M == 32) && code_bytes == 1 && Ks <= 256) || (M == 8 && code_bytes == 2 && Ks <= 1024);
     if (tiles || !both || k > 16 || N <= 0 || B <= 0) return kModePlain;
     if (g_variant_scope >= 0 || env_variant() >= 0) return kModePlain;        // (an explicit variant: A/B measurements)
     if (getenv("ANNLITE_NO_INKERNEL_MERGE")) return kModePlain;                // (debug switch: no guarded pass)

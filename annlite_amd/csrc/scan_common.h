@@ -262,6 +262,10 @@ template <int M>
 struct Q8Cfg {
     static constexpr bool WIDE = M == 64;
     static constexpr bool M8 = M == 8;  // M = 8: table [Ks][NQ entry groups][8 sub-spaces][16 B], permute addressing (see the kernel)
+    // M = 32: ONE entry group (16 queries per workgroup: 32 sub-spaces x 16 B x 256 codes fill the LDS), two half tables of 16
+    // sub-spaces, [256][16][16 B] each, the second 64 KB behind the first: look-up address = (half << 16) | (code << 8) | column,
+    // ONE v_perm_b32 of the code dword with a lane constant (see the kernel)
+    static constexpr bool M32 = M == 32;
     static constexpr int QMAX = WIDE ? 15 : 240 / M, QOPEN = WIDE ? 7 : 112 / M;
     static constexpr uint32_t TMAX = WIDE ? 32767u : 127u, TFLAG = TMAX + 1u;
 };
@@ -271,6 +275,7 @@ template <int M, int NQ>
 constexpr int q8_qt() { return Q8Cfg<M>::WIDE ? 8 : 16 * NQ; }
 template <int M, int NQ>
 __device__ __forceinline__ int q8_table_bytes(int Ks) {
+    if (Q8Cfg<M>::M32) return 131072;  // two half tables [256][16][16 B] whatever Ks (<= 256) is: the halves' distance is an address bit
     return Q8Cfg<M>::WIDE ? (Ks + 1) * 512 : Ks * NQ * M * 16;  // WIDE: two half tables of 32 sub-spaces, [Ks + 1][32][8 B] each
 }
 

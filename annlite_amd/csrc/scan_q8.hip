@@ -40,6 +40,9 @@
 //         read in lane-dependent order (conflict-free), PLAIN rows rotated in registers;
 //   851   M = 8, uint16 codes, Ks <= 1024, NQ = 1: 16 queries per workgroup (2-way bank conflicts, inherent).
 //   852   M = 8, uint8 codes (Ks <= 256), NQ = 2: the 850 shape with a 64 KB table; SKEWED rows need no rotation.
+//   3250  M = 32, uint8 codes, NQ = 1: 16 queries per workgroup (32 sub-spaces x 16 B x 256 codes = 128 KB), entries clipped at
+//         7 (32 x 7 = 224: a byte sum never carries), two half tables [256][16][16 B] 64 KB apart, one v_perm_b32 per address
+//         ((half << 16) | (code << 8) | column), candidates as (S, slot, row) entries like the M = 8 shapes.
 #include "scan_lists.h"
 
 #ifndef ANNLITE_Q8_EXP
@@ -173,7 +176,11 @@ __device__ __forceinline__ void q8_build_table(const Q8Build &a, int tile, uint3
             }
             w[i] = pk;
         }
-        *(ANNLITE_LDS u32x4 *)(uintptr_t)(tab_ad + (uint32_t)((k * NQ + h) * RB + m * 16)) = (u32x4){w[0], w[1], w[2], w[3]};
+        uint32_t ad;
+        if constexpr (Q8Cfg<M>::M32)  // two half tables of 16 sub-spaces, 64 KB apart: (half << 16) | (code << 8) | column
+            ad = tab_ad + ((uint32_t)(m >> 4) << 16) + ((uint32_t)k << 8) + (uint32_t)(m & 15) * 16u;
+        else ad = tab_ad + (uint32_t)((k * NQ + h) * RB + m * 16);
+        *(ANNLITE_LDS u32x4 *)(uintptr_t)ad = (u32x4){w[0], w[1], w[2], w[3]};
     }
 }
 
@@ -364,8 +371,8 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
     n_kept += (uint32_t)(__popcll(__ballot(act[0])) + __popcll(__ballot(act[1])));
     // exact ascending-m fp32 sums of both rows (exact_row_sum's arithmetic; the loads of the two rows interleaved)
     float ex[2] = {0.f, 0.f};
-    if constexpr (Q8Cfg<M>::WIDE) {
-        // M = 64: one row at a time, its 64 table entries in four rounds of 16 gathers (the sum stays the ascending-m chain)
+    if constexpr (Q8Cfg<M>::WIDE || Q8Cfg<M>::M32) {
+        // M = 64 / 32: one row at a time, its M table entries in rounds of 16 gathers (the sum stays the ascending-m chain)
         if (!(c.skip & 1)) {
 #pragma unroll 1
             for (int u = 0; u < 2; ++u) {
@@ -375,11 +382,18 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
                 const uint32_t *p = (const uint32_t *)(c.codes + (int64_t)rid * M);
 #pragma unroll
                 for (int i = 0; i < CW; ++i) cp[i] = p[i];
-                if constexpr (SKEWED) skew64_decode(cp, (int)(rid % 32));  // two skewed halves, wrap-coded
+                if constexpr (SKEWED && Q8Cfg<M>::WIDE) skew64_decode(cp, (int)(rid % 32));  // two skewed halves, wrap-coded
+                else if constexpr (SKEWED) {  // stored byte j of row n is the code of sub-space (j + n) mod M: rotate back
+                    const int sinv = (M - (int)(rid % M)) % M;
+                    bool abit_inv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) abit_inv[i] = (((sinv >> 2) >> i) & 1) != 0;
+                    rotate_row<CW>(cp, abit_inv, (uint32_t)(sinv & 3));
+                }
                 const int b = c.b0 + (act[u] ? q[u] : 0);
                 const float *lq = c.lut + ((int64_t)(b >> 2) * c.Ks) * (M * 4) + (b & 3);
                 float sum = 0.f;
-                static_for<0, 4>([&](auto C) {
+                static_for<0, M / 16>([&](auto C) {
                     constexpr int m0 = decltype(C)::value * 16;
                     float vals[16];
 #pragma unroll
@@ -919,12 +933,14 @@ __device__ __attribute__((noinline)) void q8_finish_item(q8_kernarg_ptr ka, int 
 template <int M, int NW, bool SKEWED, int NQ, int CB, bool RQ>
 __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const ScanArgs a) {
     constexpr bool WIDE = Q8Cfg<M>::WIDE;
-    constexpr bool M8 = Q8Cfg<M>::M8, C16 = CB == 2;
+    constexpr bool M8 = Q8Cfg<M>::M8, M32 = Q8Cfg<M>::M32, C16 = CB == 2;
     constexpr bool ROWQ = RQ && ANNLITE_Q8_ROWQ != 0;  // (row queue: see q8_row_pass_mask)
     static_assert(!RQ || (M == 16 && NQ == 2 && CB == 1), "the row queue is the M = 16 kernel's");
     constexpr int QT = q8_qt<M, NQ>(), CW = M * CB / 4, EB = 16, RB = M * EB, KSTRIDE = NQ * RB;
     static_assert(CB == 1 || (CB == 2 && M8), "uint16 codes: the M = 8 shapes");
-    static_assert(NQ == 2 || (NQ == 1 && M8 && C16), "one entry group: the M = 8 / uint16 shape above Ks = 512");
+    static_assert(NQ == 2 || (NQ == 1 && M8 && C16) || (NQ == 1 && M32 && !C16),
+                  "one entry group: the M = 8 / uint16 shape above Ks = 512, and M = 32");
+    static_assert(!M32 || NQ == 1, "M = 32: 16 queries per workgroup");
     constexpr int NS = NW - 1;  // scanning waves; wave NS is the consumer
     static_assert(M % 8 == 0 && (M <= 32 || WIDE) && (KSTRIDE & (KSTRIDE - 1)) == 0 && !(C16 && SKEWED), "unsupported shape");
 
@@ -1280,8 +1296,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             typedef const ANNLITE_LDS u32x4 *lds_entry_ptr;
             typedef const ANNLITE_LDS u32x2 *lds_entry8_ptr;
             const uint32_t lds0 = lds.tab;
-            uint32_t mbase[(WIDE || M8) ? 1 : M];
-            if constexpr (!WIDE && !M8) {
+            uint32_t mbase[(WIDE || M8 || M32) ? 1 : M];
+            if constexpr (!WIDE && !M8 && !M32) {
 #pragma unroll
                 for (int t = 0; t < M; ++t) mbase[t] = lds0 + (uint32_t)(((s + t) % M) * EB);
             }
@@ -1311,6 +1327,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
 #pragma unroll
                 for (int t = 0; t < M; ++t) mcol[t] = lds0 + (uint32_t)(((s + t) % M) * EB);
             }
+            // M32: the table is two half tables of 16 sub-spaces, [256][16][16 B] each, 64 KB apart, at LDS address 0: the address of
+            // look-up t is (half << 16) | (code << 8) | column -- ONE v_perm_b32 of the code dword with a lane constant: k32[t / 2]
+            // holds (column, half) of look-ups t = 2 j and 2 j + 1 in its bytes (0, 1) and (2, 3).  A ds_read_b128 lane group (16
+            // consecutive lanes) reads 16 consecutive sub-spaces mod 32: 16 distinct columns, conflict-free whatever the codes
+            uint32_t k32[M32 ? 16 : 1];
+            if constexpr (M32) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t s0 = (uint32_t)((s + 2 * j) % 32), s1 = (uint32_t)((s + 2 * j + 1) % 32);
+                    k32[j] = ((s0 & 15u) << 4) | ((s0 >> 4) << 8) | ((s1 & 15u) << 20) | ((s1 >> 4) << 24);
+                }
+                if (lds0 != 0u || a.Ks > 256) __builtin_trap();
+            }
             // WIDE: lane constant of the look-up addresses (the M = 64 u16 kernel's scheme): byte 0 = (lane % 32) * 8 (the column),
             // byte 2 = 0x01 (second half table); the table starts at LDS address 0 (all LDS is dynamic)
             const uint32_t lane_k = 0x00010000u | (uint32_t)((lane_pin & 31) * 8);
@@ -1336,7 +1365,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 return v;
             };
             uint32_t ccur[CW], cnext[CW];
-            uint32_t addr[(WIDE || M8) ? 1 : M];
+            uint32_t addr[(WIDE || M8 || M32) ? 1 : M];
             auto load_row = [&](uint32_t row, uint32_t (&c)[CW]) {
                 if constexpr (ANNLITE_Q8_EXP == 3) {  // (timing experiment: no code rows from memory)
 #pragma unroll
@@ -1362,7 +1391,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 }
             };
             auto make_addr = [&](const uint32_t (&cc)[CW]) {
-                if constexpr (!WIDE && !M8)
+                if constexpr (!WIDE && !M8 && !M32)
                     static_for<0, CW>([&](auto W) {
                         constexpr int w = decltype(W)::value;
                         uint32_t o0, o1, o2, o3;
@@ -1457,6 +1486,28 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     });
 #pragma unroll
                     for (int h = 0; h < NQ; ++h) sums[4 * h + 0] = acc[h].x, sums[4 * h + 1] = acc[h].y, sums[4 * h + 2] = acc[h].z, sums[4 * h + 3] = acc[h].w;
+                } else if constexpr (M32) {
+                    // 32 look-ups (one entry group: the byte sums of 32 entries clipped at 7 never carry) through a ring of DEPTH
+                    // landing registers, one v_perm_b32 per address
+                    constexpr int DEPTH = ANNLITE_Q8_DEPTH;
+                    u32x4 acc;
+                    u32x4 v[DEPTH];
+                    auto fetch = [&](u32x4 &dst, auto I) {
+                        constexpr int t = decltype(I)::value, b = t % 2;
+                        // byte 0 <- the column (k32 byte 2 b), byte 1 <- code byte t % 4, byte 2 <- the half (k32 byte 2 b + 1), byte 3 <- 0
+                        constexpr uint32_t sel = 0x0c000000u | ((uint32_t)(2 * b + 1) << 16) | ((uint32_t)(4 + t % 4) << 8) | (uint32_t)(2 * b);
+                        const uint32_t ad = __builtin_amdgcn_perm(cc[t / 4], k32[t / 2], sel);
+                        dst = *(lds_entry_ptr)(uintptr_t)ad;
+                    };
+                    static_for<0, DEPTH>([&](auto I) { fetch(v[decltype(I)::value], I); });
+                    static_for<0, M>([&](auto I) {
+                        constexpr int i = decltype(I)::value;
+                        asm volatile("" ::: "memory");
+                        if constexpr (i == 0) acc = v[0];
+                        else acc += v[i % DEPTH];
+                        if constexpr (i + DEPTH < M) fetch(v[i % DEPTH], std::integral_constant<int, i + DEPTH>{});
+                    });
+                    sums[0] = acc.x, sums[1] = acc.y, sums[2] = acc.z, sums[3] = acc.w;
                 } else {
                     constexpr int DEPTH = ANNLITE_Q8_DEPTH, TOT = NQ * M;
                     u32x4 acc[NQ];
@@ -1751,7 +1802,7 @@ using namespace annlite;
 template <int M, int NW, bool SKEWED, int NQ, int CB, bool RQ = false>
 static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
     constexpr int QT = 32;  // (the control block is laid out for 32 slots whatever the kernel uses)
-    const size_t need = (size_t)(M == 64 ? (a.Ks + 1) * 512 : a.Ks * NQ * M * 16) + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32 + 32 + 16 + 3072;
+    const size_t need = (size_t)(M == 64 ? (a.Ks + 1) * 512 : M == 32 ? 131072 : a.Ks * NQ * M * 16) + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32 + 32 + 16 + 3072;
     auto fn = adc_scan_q8_kernel<M, NW, SKEWED, NQ, CB, RQ>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
@@ -1767,6 +1818,8 @@ int annlite::launch_q8_scan(int id, bool sk, const ScanArgs &a, int grid, hipStr
             if (a.gkey) return sk ? launch_q8<16, 16, true, 2, 1, true>(a, grid, st) : launch_q8<16, 16, false, 2, 1, true>(a, grid, st);
             return sk ? launch_q8<16, 16, true, 2, 1>(a, grid, st) : launch_q8<16, 16, false, 2, 1>(a, grid, st);
         case 6450: return sk ? launch_q8<64, 16, true, 2, 1>(a, grid, st) : launch_q8<64, 16, false, 2, 1>(a, grid, st);
+        case 3250:  // M = 32: one entry group, 16 queries per workgroup, two half tables of 16 sub-spaces
+            return sk ? launch_q8<32, 16, true, 1, 1>(a, grid, st) : launch_q8<32, 16, false, 1, 1>(a, grid, st);
         case 850:  // M = 8, uint16 codes (PLAIN rows): two entry groups (Ks <= 512)
         case 851:  // ... one (Ks <= 1024)
             if (sk) { set_error("uint16 codes: PLAIN rows only"); return ANNLITE_ERR_UNSUPPORTED; }

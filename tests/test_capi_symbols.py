@@ -45,6 +45,10 @@ def test_scan_plan_arithmetic_no_gpu():
     assert (p.fast, p.qi, p.qt) == (1, 4, 16)
     p = _capi.scan_plan(1000, 8, 768, 2, 5, 40)  # ... k > 16: u16 tables, 8 queries per workgroup
     assert (p.fast, p.qi, p.qt) == (1, 4, 8)
+    p = _capi.scan_plan(1000, 32, 256, 1, 5, 10)  # M = 32, k <= 16 -> byte tables of one entry group, 16 queries per workgroup
+    assert (p.fast, p.qi, p.qt, p.waves) == (1, 4, 16, 16) and p.lut_floats == 16 * 32 * 256
+    p = _capi.scan_plan(1000, 32, 256, 1, 5, 17)  # ... k > 16: u16 tables, 8 queries per workgroup, 12 waves
+    assert (p.fast, p.qi, p.qt, p.waves) == (1, 4, 8, 12)
     p = _capi.scan_plan(1000, 16, 768, 2, 5, 10)  # uint16 codes that do not -> generic kernel
     assert p.fast == 0 and p.qt == 1
     import pytest
