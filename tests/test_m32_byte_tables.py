@@ -245,3 +245,80 @@ def test_candidate_lists_with_slice_bounds(ops, oracle, layout):
         rd, ri = oracle.adc_search_c(lut, codes[a:b][keep], k)
         assert np.array_equal(cd[:, sl * k:(sl + 1) * k], rd), sl
         assert np.array_equal(ci[:, sl * k:(sl + 1) * k], keep[ri] + a), sl
+
+
+@pytest.mark.parametrize('tune', [('1,2,192,0', '64', '7'), ('100000,2,384,3', '96', '4')])
+def test_epochs_and_rebuilds(ops, oracle, tune, monkeypatch):
+    """an epoch end every other step with the tables rebuilt as soon as a bound moves (the default schedule is sparse: small
+    tables never reach its first epoch end), and a schedule without any epoch: the oracle's bits either way"""
+    from annlite_amd import Metric, PQCodec, _capi
+
+    rs = np.random.RandomState(21)
+    N, D, B, k = 200_000, 128, 48, 10
+    A = rs.randn(16, D).astype(np.float32)
+    x = (rs.randn(N, 16).astype(np.float32) @ A + 0.05 * rs.randn(N, D).astype(np.float32)).astype(np.float32)
+    q = (rs.randn(B, 16).astype(np.float32) @ A + 0.05 * rs.randn(B, D).astype(np.float32)).astype(np.float32)
+    codec = PQCodec(dim=D, n_subvectors=M, n_clusters=256, metric=Metric.EUCLIDEAN, n_init=1)
+    codec.seed = 4
+    codec.fit(x[:8192], iter=5)
+    codes = oracle.encode_c(x, codec.codebooks)
+    lut = oracle.get_dist_mat_c(q, codec.codebooks, oracle.EUCLIDEAN)
+    rd, ri = oracle.adc_search_c(lut, codes, k)
+    monkeypatch.setenv('ANNLITE_Q8_TUNE', tune[0])
+    monkeypatch.setenv('ANNLITE_Q8_TARGET', tune[1])
+    monkeypatch.setenv('ANNLITE_Q8_REBUILD', tune[2])
+    monkeypatch.setenv('ANNLITE_SEED_ROWS', '4096')  # (a loose first bound: the tables have something to follow)
+    for layout in (0, 1):
+        d, i = _scan(ops, codes, lut, k, layout)
+        assert np.array_equal(d, rd) and np.array_equal(i, ri)
+        if tune[0].startswith('1,2'):
+            assert _capi.debug_counters()[5] > 0  # tables were rebuilt
+
+
+def test_give_up_path_and_kernel_choice_on_uniform_codes(ops, oracle, monkeypatch):
+    """Independent uniform codes (the byte filter leaks on them).  Without the variant switch the library's first launch is the
+    GUARDED byte-table kernel with the gated u16-table pass queued behind it; forced to give up at once (a budget of 8 candidates per
+    workgroup) the gated pass must deliver the same bits; a per-table state then settles on the u16 kernel.  Every path returns what
+    the u16 kernel forced through the environment returns, and the oracle's bits on a sample."""
+    import torch
+    from annlite_amd import _capi
+    from annlite_amd._capi import LUT_L2
+
+    torch.manual_seed(6)
+    N, Ks, B, k, D = 1_000_000, 256, 200, 10, 128
+    codes = torch.randint(0, 256, (N, M), dtype=torch.uint8, device='cuda')
+    cb = torch.randn((M, Ks, D // M), device='cuda')
+    q = torch.randn((B, D), device='cuda')
+    sk = ops.codes_skew(codes)
+    ws = ops.ScanWorkspace()
+
+    def run(state=None):
+        return ops.pq_search_topk(LUT_L2, q, cb, sk, k, M, Ks, codes_layout=1, workspace=ws, state=state)
+
+    monkeypatch.setenv('ANNLITE_SCAN_VARIANT', '31')
+    d31, i31 = run()
+    monkeypatch.setenv('ANNLITE_SCAN_VARIANT', '50')
+    d50, i50 = run()
+    assert torch.equal(d50, d31) and torch.equal(i50, i31)
+    monkeypatch.delenv('ANNLITE_SCAN_VARIANT')
+    d0, i0 = run()  # stateless: guarded
+    assert torch.equal(d0, d31) and torch.equal(i0, i31)
+    monkeypatch.setenv('ANNLITE_GUARD_BASE', '8')
+    dg, ig = run()
+    assert torch.equal(dg, d31) and torch.equal(ig, i31)
+    st = _capi.ScanState()
+    for _ in range(3):
+        dg, ig = run(st)
+        torch.cuda.synchronize()
+        assert torch.equal(dg, d31) and torch.equal(ig, i31)
+    assert st.info()[0] == 2, st.info()
+    monkeypatch.delenv('ANNLITE_GUARD_BASE')
+    st2 = _capi.ScanState()
+    for _ in range(6):
+        ds, is_ = run(st2)
+        torch.cuda.synchronize()
+        assert torch.equal(ds, d31) and torch.equal(is_, i31)
+    assert st2.info()[0] in (1, 2), st2.info()
+    lut = ops.lut_build(q[:4], cb, LUT_L2).cpu().numpy()
+    rd, ri = oracle.adc_search_c(lut, codes.cpu().numpy(), k)
+    assert np.array_equal(d0[:4].cpu().numpy(), rd) and np.array_equal(i0[:4].cpu().numpy(), ri)
