@@ -22,8 +22,8 @@ algorithmic code bytes per second and the measured HBM traffic are reported besi
 section 7) and `cpu_baseline` (the C oracle, single thread = the reference's execution model,
 bounded sample).  Extra legs (rank 0, N=1, never `value`): `rerank` (recall target), `ivf`, and --
 with the default workload only -- `c2`, `c4`, `c5` (the other BASELINE configurations, each a
-sub-run with its own `roofline` and `cpu_baseline`) and `uniform` (the reference's own test
-distribution); `--legs` selects them.
+sub-run with its own `roofline` and `cpu_baseline`), `m32` (the default workload at m = 32) and `uniform` (the reference's
+own test distribution); `--legs` selects them.
 
 Set-up before the W warm-up steps includes `--prewarm-steps` (64) untimed steps: a GPU that idled through index
 construction needs milliseconds of work to reach its sustained clock -- at a 0.27 ms step (one rank's shard of 8) W = 2 /
@@ -68,7 +68,7 @@ def parse():
                    help='database / query distribution (SURVEY.md section 8d): lowrank = rank-16 (rank-64 above 128-d) latent Gaussian '
                         '+ noise; uniform = U[0,1)^D, the reference\'s own test distribution (tests/test_pq_bind.py:19)')
     p.add_argument('--legs', default='auto',
-                   help='comma list of extra legs (rank 0, N=1, never `value`): rerank, ivf, facade, uniform, c2, c4, c5; "none"; "auto" = all '
+                   help='comma list of extra legs (rank 0, N=1, never `value`): rerank, ivf, facade, uniform, c2, c4, c5, m32; "none"; "auto" = all '
                         'of them for the default workload, rerank + ivf otherwise')
     p.add_argument('--metric', choices=['euclidean', 'cosine', 'inner_product'], default='euclidean',
                    help="BASELINE config 2/3: euclidean; config 4 (10M x 768, m=64, batch 256): cosine")
@@ -161,7 +161,7 @@ def main():
     N_, D_, M_, Ks_, B_, k_ = args.rows, args.dim, args.m, args.ks, args.batch, args.k
     default_workload = (N_, D_, M_, Ks_, B_, k_, args.metric, args.data) == (10_000_000, 128, 16, 256, 1024, 10, 'euclidean', 'lowrank')
     legs = args.legs.split(',') if args.legs not in ('auto', 'none') else (
-        [] if args.legs == 'none' else ['rerank', 'ivf'] + (['facade', 'uniform', 'c2', 'c4', 'c5'] if default_workload else []))
+        [] if args.legs == 'none' else ['rerank', 'ivf'] + (['facade', 'uniform', 'c2', 'c4', 'c5', 'm32'] if default_workload else []))
     if args.no_rerank and 'rerank' in legs:
         legs.remove('rerank')
     if args.ivf_cells <= 1 and 'ivf' in legs:
@@ -183,6 +183,8 @@ def main():
                                  '--recall-queries', '32'] + common, 400)
         if 'c5' in legs:  # config 5: HNSW-over-PQ, 5M x 128, ef_search 128, GPU walk + exact re-rank
             sub['c5'] = sub_run([os.path.join(ROOT, 'scripts', 'bench_hnsw.py'), '--rows', '5000000', '--steps', '5'], 600)
+        if 'm32' in legs:  # the default workload at m = 32 (the reference's own table-test shape): byte tables of one entry group
+            sub['m32'] = sub_run([me, '--m', '32', '--steps', '20', '--warmup', '5', '--cpu-queries', '0', '--recall-queries', '32'] + common, 300)
         if 'uniform' in legs:  # U[0,1)^D: unstructured codes -- the kernel the library picks for them
             sub['uniform'] = sub_run([me, '--data', 'uniform', '--steps', '10', '--warmup', '3', '--cpu-queries', '0',
                                       '--recall-queries', '32'] + common, 300)
@@ -631,7 +633,8 @@ def main():
         # 64 x 4.  256 CUs at 2.4 GHz (MI355X_MICROARCH.md: 256 B / clk / CU).
         plan_k = _capi.scan_plan(n_local, M, Ks, index.code_bytes, B, k)
         # (which M = 16 kernel served the table is the library's choice, from what its launches measured: index.scan_kernel)
-        byte_tables = (plan_k.qt == 32 or (M == 64 and plan_k.qt == 8) or (M == 8 and index.code_bytes == 2 and plan_k.qt == 16)) and \
+        byte_tables = (plan_k.qt == 32 or (M == 64 and plan_k.qt == 8) or (M == 8 and index.code_bytes == 2 and plan_k.qt == 16) or
+                       (M == 32 and plan_k.qt == 16)) and \
             index.scan_kernel != 'u16 tables' and \
             os.environ.get('ANNLITE_SCAN_VARIANT', '0') in ('0', '50')
         per_clk = 256 if byte_tables else 128
