@@ -252,7 +252,7 @@ ANNLITE_API int annlite_adc_scan_candidates(const void *codes_dev, int code_byte
  * launch stream; annlite_profile_last_scan_ms() waits for the last one and returns its duration. */
 ANNLITE_API int annlite_profile_enable(int on);
 ANNLITE_API int annlite_profile_last_scan_ms(float *ms);
-/* Kernel choice (M = 16 with uint8 codes, M = 8 with uint16 codes up to Ks = 512; k <= 16): byte filter tables (the default)
+/* Kernel choice (M = 8 / 16 / 32 with uint8 codes, M = 8 with uint16 codes up to Ks = 1024; k <= 16): byte filter tables (the default)
  * or u16 filter tables -- made INSIDE the library, per call, never by a process-wide switch.  Without a state every
  * byte-table launch is guarded: it gives up when a workgroup has seen more than 1024 + (rows it has drawn) / 16 candidates
  * (a byte filter that leaks) and a gated u16-table pass queued behind it redoes the scan (~10 us per batch of gated
