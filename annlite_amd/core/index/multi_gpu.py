@@ -47,11 +47,18 @@ def merge_lists_sorted(d: torch.Tensor, i: torch.Tensor, k: int) -> Tuple[torch.
     G, B, kk = d.shape
     dd = d.permute(1, 0, 2).reshape(B, G * kk)
     ii = i.permute(1, 0, 2).reshape(B, G * kk)
-    by_id = torch.argsort(torch.where(ii < 0, torch.full_like(ii, torch.iinfo(torch.int64).max), ii), dim=1, stable=True)
-    dd, ii = torch.gather(dd, 1, by_id), torch.gather(ii, 1, by_id)
-    dd = torch.where(ii < 0, torch.full_like(dd, float('inf')), dd)
-    # (+inf of a real row and of the padding tie: the padding was sorted behind every real id, the stable sort keeps it there)
-    by_d = torch.argsort(dd, dim=1, stable=True)[:, :k]
+    pad = ii < 0
+    by_id = torch.argsort(torch.where(pad, torch.full_like(ii, torch.iinfo(torch.int64).max), ii), dim=1, stable=True)
+    dd, ii, pad = torch.gather(dd, 1, by_id), torch.gather(ii, 1, by_id), torch.gather(pad, 1, by_id)
+    dd = torch.where(pad, torch.full_like(dd, float('inf')), dd)
+    # The library's order everywhere else (f32_to_key, annlite_topk_merge): numbers ascending, +inf, then a real row's NaN,
+    # and only then "none".  torch sorts NaN behind +inf too -- i.e. behind the PADDING's +inf: a real row with a NaN distance
+    # would be cut in favour of padding.  So: stable sort by the distance with NaN read as +inf (ties keep the id order, the
+    # padding stays behind every real id), then a stable sort by class (number or +inf / NaN / padding).
+    nan = torch.isnan(dd) & ~pad
+    by_d = torch.argsort(torch.where(nan, torch.full_like(dd, float('inf')), dd), dim=1, stable=True)
+    cls = torch.gather(nan.to(torch.int8) + 2 * pad.to(torch.int8), 1, by_d)
+    by_d = torch.gather(by_d, 1, torch.argsort(cls, dim=1, stable=True))[:, :k]
     od, oi = torch.gather(dd, 1, by_d), torch.gather(ii, 1, by_d)
     if od.shape[1] < k:
         od = torch.cat([od, torch.full((B, k - od.shape[1]), float('inf'), dtype=od.dtype, device=od.device)], dim=1)

@@ -240,7 +240,8 @@ constexpr int kPopPerRing = 8;    // entries the consumer takes from one wave's 
 //            from, +16 tails [16] (entries wave w has pushed, mod 2^16: written by wave w only), +80 heads [16] (entries of wave
 //            w's ring consumed: written by the consumer only)
 //   gkl      u64 [32]  best bound known for the slot (own k-th key or imported)
-//   step / inv / clip f32 [32], tb u8 [32] (T the table was built for), ctl u32 (+0 rebuild flag, +4 merge flag)
+//   step / inv / clip f32 [32], tb u8 [32] (T the table was built for), ctl u32 (+0 rebuild flag, +4 merge flag / arrival mask,
+//            +8 the early merger's "patience is over" verdict)
 //   tau      u64 [32]  the k-th key the consumer last published; c0, c1 f64 [32]: T = floor(thr * c1 + c0) + 1 (q8_bound)
 //   list     u64 [32][16] the 16 smallest keys of every slot, ascending; gjl u64 [32] the j-th key last published
 //   ring     u64 [16][kWaveRing]; qkey u64 [4][128], qslot u8 [4][128] insertion queues; chg u8 [32]; stamps u64 [4] (debug)
@@ -798,15 +799,24 @@ __device__ __forceinline__ void q8_early_merge(const ScanArgs &a, const Q8Lds &l
         return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) |
                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
     };
+    // Every decision of the loop is WORKGROUP-uniform: thread 0 polls the mask, reads the clock and leaves both the mask and its
+    // verdict ("patience is over") in LDS; all waves branch on those words after the barrier.  (Each wave comparing its own
+    // clock reading let waves straddle the threshold: some left while others went on merging -- only for their own queries.)
     for (;;) {
         __syncthreads();
-        if (tid == 0) ldsv_st<uint32_t>(lds.ctl + 4, __hip_atomic_load(a.tile_done + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (tid == 0) {
+            const uint32_t m = __hip_atomic_load(a.tile_done + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool nothing_new = (~m & low & ~merged) == 0u && (~m & low) != low;
+            ldsv_st<uint32_t>(lds.ctl + 4, m);
+            ldsv_st<uint32_t>(lds.ctl + 8, (nothing_new && wall_clock64() - t_last >= (unsigned long long)a.q8_merge_patience) ? 1u : 0u);
+        }
         __syncthreads();
         const uint32_t mask = ldsv<uint32_t>(lds.ctl + 4);  // bit s set: slice s is still out
+        const bool timed_out = ldsv<uint32_t>(lds.ctl + 8) != 0u;
         const uint32_t arrived = ~mask & low & ~merged;
         if (!arrived) {
             if ((~mask & low) == low) break;  // every slice is in and merged
-            if (wall_clock64() - t_last >= (unsigned long long)a.q8_merge_patience) {
+            if (timed_out) {
                 // nothing has arrived for a long time: leave, unless everything turns out to be in (then finish here)
                 __syncthreads();
                 if (tid == 0)

@@ -142,6 +142,11 @@ class LazyMatches(DocumentArray):
     scan.  Here a query's matches hold the row of (offset, distance) arrays the GPU returned and a resolver; the
     ``Document`` objects -- same ``.id``, ``.scores[metric].value``, metadata -- are built when the list is first read
     (indexing, iteration, ``in``, comparison, mutation); ``len()`` answers without building anything.
+
+    Known limit of a ``list`` subclass with deferred storage: CPython routines that read a list's item array directly
+    (``[] + m``, ``lst[a:b] = m``, ``np.array(m)`` -- the ``PySequence_Fast`` users) bypass the overrides and see an empty list
+    until the first python-level access; call ``list(m)`` (or touch ``m[0]``) first.  ``AnnLite.search`` with the real docarray
+    never builds these (eager matches, as the reference).
     """
 
     def __init__(self, offsets, dists, resolve):
@@ -151,9 +156,13 @@ class LazyMatches(DocumentArray):
     def _ensure(self):
         p = self.__dict__.get('_pending')
         if p is not None:
-            self._pending = None
             offsets, dists, resolve = p
-            list.extend(self, resolve(offsets, dists))
+            docs = resolve(offsets, dists)
+            # storage first, the flag afterwards: a second reader that still sees `_pending` resolves again and finds the flag
+            # cleared below -- it never sees an empty list that claims to be materialised
+            if self.__dict__.get('_pending') is p:
+                list.extend(self, docs)
+                self._pending = None
         return self
 
     @property

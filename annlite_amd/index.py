@@ -449,7 +449,9 @@ class AnnLite:
         # (what a LAZY list resolves against later: offsets are never reused and `clear()` / a reload rebind these containers, so
         # the only mutation that can reach a pending list is `delete()` -- which leaves the row's id and document in `_tomb`)
         offset2id, docs, tomb = self._offset2id, self._docs, self._tomb
-        fast = getattr(Document, 'match', None)  # (the in-repo stand-in: the score object is made when first read)
+        # the in-repo stand-in's factory (the score object is made when first read).  Gated on the stand-in itself: the real
+        # docarray < 0.30 also has a ``Document.match`` -- its nearest-neighbour matcher, a different function altogether
+        fast = Document.match if LazyMatches is not None else None
 
         def resolve(offs, dists):
             out = []

@@ -41,11 +41,14 @@ def gather_and_merge(local_d: torch.Tensor, local_i: torch.Tensor, merge_fn: Cal
     B, k = local_d.shape
     # ONE collective here too (the general path: re-rank, limit > 64): (id, bits of the f32 distance) pairs in one int64 buffer,
     # concatenation form ([G*B, k, 2]: accepted by both RCCL and gloo), unpacked into [G, B, k] for the merge
-    both = torch.stack([local_i.to(torch.int64), local_d.to(torch.float32).contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF], dim=2)
+    # (the distance's own bits: f32 in the low word, f64 as the whole int64 -- a float64 caller gets float64 back)
+    f64 = local_d.dtype == torch.float64
+    bits = local_d.contiguous().view(torch.int64) if f64 else local_d.to(torch.float32).contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    both = torch.stack([local_i.to(torch.int64), bits], dim=2)
     gathered = torch.empty((G * B, k, 2), dtype=torch.int64, device=local_d.device)
     dist.all_gather_into_tensor(gathered, both.contiguous(), group=group)
     all_i = gathered[..., 0].contiguous().view(G, B, k)
-    all_d = gathered[..., 1].to(torch.int32).view(torch.float32).view(G, B, k)
+    all_d = (gathered[..., 1].contiguous().view(torch.float64) if f64 else gathered[..., 1].to(torch.int32).view(torch.float32)).view(G, B, k)
     return merge_fn(all_d.contiguous(), all_i)
 
 
@@ -72,7 +75,7 @@ class ShardedPQIndex:
 
     def __init__(self, index, row_base: int, group: Optional[dist.ProcessGroup] = None,
                  merge: Optional[Callable] = None, merge_packed: Optional[Callable] = None, seed_exchange: bool = False,
-                 n_total: Optional[int] = None):
+                 n_total: Optional[int] = None, seed_group: Optional[dist.ProcessGroup] = None):
         self.index = index
         self.row_base = int(row_base)
         self.group = group
@@ -85,7 +88,14 @@ class ShardedPQIndex:
         # cross-stream hops between the preparation launch and the scan cost more than the smaller seed saves.
         self.seed_exchange = bool(seed_exchange)
         self.n_total = n_total  # rows of the whole table (default: this shard's rows x world size)
-        self._seed_group = None
+        # The seed exchange's own process group.  ``dist.new_group`` is collective over the WHOLE default group (members and
+        # non-members alike), so it is made HERE -- construction with ``seed_exchange=True`` is collective over the world, as
+        # torch.distributed requires -- never on the first batch's critical path.  A caller whose ``group`` is a strict
+        # sub-group creates the seed group itself (every process of the world calling ``new_group``) and passes it in.
+        self._seed_group = seed_group
+        if self.seed_exchange and self._seed_group is None and dist.is_available() and dist.is_initialized():
+            ranks = dist.get_process_group_ranks(group) if group is not None else None
+            self._seed_group = dist.new_group(ranks=ranks)
         self._peer_keys = None  # (measurement aid, bench.py --emulate-seed-peers: precomputed key sets standing in for peers)
         if merge is None or merge_packed is None:  # the product: the merge kernels (tests inject numpy restatements)
             from . import ops
@@ -180,9 +190,9 @@ class ShardedPQIndex:
     def _exchange_seeds(self, keys: torch.Tensor) -> torch.Tensor:
         """ONE all-gather of the ranks' seed keys [B, 16] -> [G, B, 16], in the calling (preparation) stream's order."""
         G = dist.get_world_size(self.group)
-        if self._seed_group is None:  # (first batch, every rank: new_group is itself collective)
-            ranks = dist.get_process_group_ranks(self.group) if self.group is not None else None
-            self._seed_group = dist.new_group(ranks=ranks)
+        if self._seed_group is None:
+            raise RuntimeError('seed exchange without its process group: construct ShardedPQIndex(seed_exchange=True) after '
+                               'init_process_group (collective over the world), or pass seed_group=')
         out = torch.empty((G * keys.shape[0], keys.shape[1]), dtype=keys.dtype, device=keys.device)
         dist.all_gather_into_tensor(out, keys.contiguous(), group=self._seed_group)
         out = out.view(G, keys.shape[0], keys.shape[1])

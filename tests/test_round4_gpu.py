@@ -236,13 +236,15 @@ def test_facade_lazy_matches_equal_the_eager_documents(ops, tmp_path):
 
 
 # ------------------------------------------------------------------------------------ early merger of a tile's row slices
-@pytest.mark.parametrize('patience', [None, '0', '3'])
+@pytest.mark.parametrize('patience', [None, '0', '3', '300', '2000'])
 @pytest.mark.parametrize('M,dsub,k', [(16, 8, 10), (16, 8, 16), (64, 4, 10), (8, 8, 3)])
 def test_early_merger_and_its_give_up_path(ops, oracle, monkeypatch, patience, M, dsub, k):
     """The first workgroup of a query tile to finish folds the other slices' lists as they arrive (scan_q8.hip: q8_early_merge);
     with no patience (ANNLITE_EARLY_MERGE_PATIENCE=0 / 3 ticks) it leaves at once and the last slice to arrive merges the tile
     from global memory -- both roads, and the switch that turns the early merger off, return the oracle's bits; heavy ties across
-    slices, deleted rows, a ragged batch."""
+    slices, deleted rows, a ragged batch.  Patience of 3 / 20 us (300 / 2000 ticks of the 100 MHz clock) runs out WHILE slices keep
+    arriving: the leave decision is taken by one thread for the whole workgroup (round 5; per-wave clock readings could
+    split the workgroup at the threshold)."""
     import torch
     from annlite_amd._capi import LUT_L2
 
