@@ -70,6 +70,8 @@ SYMBOLS = (
     'annlite_codes_skew',
     'annlite_profile_enable',
     'annlite_profile_last_scan_ms',
+    'annlite_profile_last_scan_clock_mhz',
+    'annlite_kernel_rev',
     'annlite_debug_counters',
     'annlite_debug_timeline',
     'annlite_debug_items',
@@ -157,6 +159,8 @@ def lib() -> ctypes.CDLL:
                                       vp, i32, vp]
     L.annlite_profile_enable.argtypes = [i32]
     L.annlite_profile_last_scan_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]
+    L.annlite_profile_last_scan_clock_mhz.argtypes = [ctypes.POINTER(ctypes.c_float)]
+    L.annlite_kernel_rev.argtypes = [ctypes.c_char_p]
     L.annlite_debug_counters.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     L.annlite_debug_timeline.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     L.annlite_debug_items.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
@@ -271,6 +275,19 @@ def profile_last_scan_ms() -> float:
     ms = ctypes.c_float(0.0)
     check(lib().annlite_profile_last_scan_ms(ctypes.byref(ms)), 'profile_last_scan_ms')
     return float(ms.value)
+
+
+def kernel_rev(kernel: str) -> int:
+    """Revision of the kernel's memory behaviour (0: unknown name) -- what profiles/traffic.json entries are tagged with."""
+    return int(lib().annlite_kernel_rev(kernel.encode()))
+
+
+def profile_last_scan_clock_mhz():
+    """Shader clock (MHz) the last profiled byte-table scan held, or None (another kernel served the launch)."""
+    mhz = ctypes.c_float(0.0)
+    if lib().annlite_profile_last_scan_clock_mhz(ctypes.byref(mhz)) != 0:
+        return None
+    return float(mhz.value)
 
 
 def graph_search_stats():

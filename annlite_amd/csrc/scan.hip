@@ -513,6 +513,7 @@ static unsigned long long *g_dbg_prep = nullptr;  // ... and the preparation lau
 static thread_local int g_prof_on = 0;
 static thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 static thread_local int g_ev_valid = 0;
+static unsigned long long *g_clk = nullptr;  // (annlite_profile_enable) the byte-table kernel's cycle / wall-clock stamps, 4 x u64, leaked
 
 static void prof_begin(hipStream_t st) {
     if (!g_prof_on) return;
@@ -833,6 +834,13 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         a.q8_early_merge = (c.mode == 5 && a.tile_done && a.n_slices >= 2 && a.n_slices <= 31 && a.n_items <= grid &&
                             !getenv("ANNLITE_NO_EARLY_MERGE")) ? 1 : 0;
         a.q8_merge_patience = 20000u;
+        if (g_prof_on && c.mode == 5 && !(gopt && gopt->gate)) {
+            if (!g_clk) {
+                ANNLITE_HIP_TRY(hipMalloc((void **)&g_clk, 32));
+                ANNLITE_HIP_TRY(hipMemset(g_clk, 0, 32));
+            }
+            a.clk = g_clk;
+        }
         if (const char *e = getenv("ANNLITE_EARLY_MERGE_PATIENCE")) a.q8_merge_patience = (uint32_t)atoll(e);
         const bool bracket = !(gopt && gopt->gate);  // (measurement hooks: the launch that does the work, not the gated pass)
         if (bracket) prof_begin(st);
@@ -916,6 +924,42 @@ extern "C" int annlite_profile_last_scan_ms(float *ms) {
     }
     ANNLITE_HIP_TRY(hipEventSynchronize(g_ev1));
     ANNLITE_HIP_TRY(hipEventElapsedTime(ms, g_ev0, g_ev1));
+    return ANNLITE_OK;
+}
+
+// Revision of a kernel's memory behaviour (work-item map, table formats, what is read how often): bumped BY HAND with such a
+// change.  profiles/traffic.json records it with every PMC pass; bench.py refuses a pass taken on another revision.
+extern "C" int annlite_kernel_rev(const char *kernel) {
+    ANNLITE_REQUIRE(kernel != nullptr, "kernel is NULL");
+    static const struct { const char *name; int rev; } revs[] = {
+        {"adc_scan_q8_kernel", 4},        // 4: round 4 (prebuilt byte tables, early merger, M = 64 slice-per-XCD)
+        {"adc_scan_qfilter_kernel", 1},
+        {"adc_scan_qfilter64_kernel", 1},
+        {"adc_scan_generic_kernel", 1},
+        {"graph_beam_search_kernel", 1},
+    };
+    for (const auto &r : revs)
+        if (strcmp(r.name, kernel) == 0) return r.rev;
+    return 0;  // unknown kernel: no revision (never matches a recorded one)
+}
+
+// The shader clock the last profiled byte-table scan actually held: workgroup 0's s_memtime delta (shader cycles on gfx950) over
+// its 100 MHz wall-clock delta.  The roofline prices a launch at the nominal 2.4 GHz; a power- or thermally-limited box holds
+// less, and a reader of one bench line cannot otherwise tell a slow box from a slow kernel.
+extern "C" int annlite_profile_last_scan_clock_mhz(float *mhz) {
+    ANNLITE_REQUIRE(mhz != nullptr, "mhz is NULL");
+    if (!g_ev_valid || !g_clk) {
+        set_error("no byte-table scan has been recorded (call annlite_profile_enable(1) first)");
+        return ANNLITE_ERR_INVALID;
+    }
+    ANNLITE_HIP_TRY(hipEventSynchronize(g_ev1));
+    unsigned long long h[4];
+    ANNLITE_HIP_TRY(hipMemcpy(h, g_clk, 32, hipMemcpyDeviceToHost));
+    if (h[3] <= h[1] || h[2] <= h[0]) {
+        set_error("the last scan left no clock stamps (not a byte-table launch)");
+        return ANNLITE_ERR_INVALID;
+    }
+    *mhz = (float)((double)(h[2] - h[0]) / (double)(h[3] - h[1]) * 100.0);
     return ANNLITE_OK;
 }
 

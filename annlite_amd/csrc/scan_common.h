@@ -82,6 +82,8 @@ struct ScanArgs {
                                         // without an arrival (20000 = 200 us; ANNLITE_EARLY_MERGE_PATIENCE: tests force the path)
     int32_t q8_map_slices;              // byte-table kernel: work items mapped slice-per-XCD (item_map) instead of tile-per-XCD
                                         // (q8_item_map): an XCD streams ITS row slices once for all query tiles
+    unsigned long long *clk;            // optional (annlite_profile_enable): workgroup 0 leaves [0] shader cycles (s_memtime) and [1] 100 MHz
+                                        // ticks at its start, [2] / [3] at its end -- the clock the kernel actually held
 };
 
 // work item -> (query tile, row slice).  item % 8 == blockIdx % 8 == the XCD the block lands on (speed

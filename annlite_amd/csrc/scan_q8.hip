@@ -964,6 +964,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
     const q8_kernarg_ptr ka = q8_kernarg();
 
     if (a.guard && tid == 0) ldsv_st<uint32_t>(lds.seen, 0u);
+    // (measurement hook, read from the kernarg segment: see q8_kernarg; not in the M = 8 shapes -- there the two scalar
+    // reads moved the allocator's choices and a scratch reload appeared in the 851 shape's step loop)
+    if constexpr (!M8) {
+        if (blockIdx.x == 0 && tid == 0) {
+            unsigned long long *clk = ka->clk;
+            if (clk) clk[0] = __builtin_readcyclecounter(), clk[1] = wall_clock64();
+        }
+    }
     for (int it = 0;; ++it) {
         const int item = blockIdx.x + it * gridDim.x;
         if (item >= a.n_items) break;
@@ -1780,6 +1788,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 r[6] = t_end;
                 r[7] = (unsigned long long)blockIdx.x;
             }
+        }
+    }
+    if constexpr (!M8) {
+        if (blockIdx.x == 0 && tid == 0) {
+            unsigned long long *clk = ka->clk;
+            if (clk) clk[2] = __builtin_readcyclecounter(), clk[3] = wall_clock64();
         }
     }
     // ---- guard statistics: candidates seen by the whole launch, written to the caller's host-mapped block by the last

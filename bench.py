@@ -58,6 +58,9 @@ def parse():
     p.add_argument('--ks', type=int, default=256)
     p.add_argument('--batch', type=int, default=1024)
     p.add_argument('--k', type=int, default=10)
+    p.add_argument('--query-batches', type=int, default=4,
+                   help='DISTINCT query batches the warm-up and the timed steps rotate through (step i searches batch i mod this); every '
+                        'one of them is checked against the CPU oracle and enters `result_sha256`')
     p.add_argument('--train-rows', type=int, default=20480)
     p.add_argument('--train-iters', type=int, default=20)
     p.add_argument('--recall-queries', type=int, default=128, help='queries used for recall@10 (0 = skip)')
@@ -68,7 +71,7 @@ def parse():
                    help='database / query distribution (SURVEY.md section 8d): lowrank = rank-16 (rank-64 above 128-d) latent Gaussian '
                         '+ noise; uniform = U[0,1)^D, the reference\'s own test distribution (tests/test_pq_bind.py:19)')
     p.add_argument('--legs', default='auto',
-                   help='comma list of extra legs (rank 0, N=1, never `value`): rerank, ivf, facade, uniform, c2, c4, c5, m32; "none"; "auto" = all '
+                   help='comma list of extra legs (rank 0, N=1, never `value`): rerank, ivf, facade, uniform, c2, c4, c5, m32, k50; "none"; "auto" = all '
                         'of them for the default workload, rerank + ivf otherwise')
     p.add_argument('--metric', choices=['euclidean', 'cosine', 'inner_product'], default='euclidean',
                    help="BASELINE config 2/3: euclidean; config 4 (10M x 768, m=64, batch 256): cosine")
@@ -161,7 +164,7 @@ def main():
     N_, D_, M_, Ks_, B_, k_ = args.rows, args.dim, args.m, args.ks, args.batch, args.k
     default_workload = (N_, D_, M_, Ks_, B_, k_, args.metric, args.data) == (10_000_000, 128, 16, 256, 1024, 10, 'euclidean', 'lowrank')
     legs = args.legs.split(',') if args.legs not in ('auto', 'none') else (
-        [] if args.legs == 'none' else ['rerank', 'ivf'] + (['facade', 'uniform', 'c2', 'c4', 'c5', 'm32'] if default_workload else []))
+        [] if args.legs == 'none' else ['rerank', 'ivf'] + (['facade', 'uniform', 'c2', 'c4', 'c5', 'm32', 'k50'] if default_workload else []))
     if args.no_rerank and 'rerank' in legs:
         legs.remove('rerank')
     if args.ivf_cells <= 1 and 'ivf' in legs:
@@ -174,7 +177,7 @@ def main():
     if rank == 0 and world == 1:
         me = os.path.join(ROOT, 'bench.py')
         # (the legs' batches alternate between two streams, as the multi-GPU runs do; each leg's own config says so)
-        common = ['--legs', 'none', '--gpus', '1', '--streams', '2']
+        common = ['--legs', 'none', '--gpus', '1', '--streams', '2', '--query-batches', '2']
         if 'c2' in legs:  # config 2: 1M x 128, m=16, L2, batch 1024
             sub['c2'] = sub_run([me, '--rows', '1000000', '--steps', '40', '--warmup', '10'] + common, 240)
         if 'c4' in legs:  # config 4: 10M x 768, m=64, cosine, batch 256
@@ -184,9 +187,13 @@ def main():
         if 'c5' in legs:  # config 5: HNSW-over-PQ, 5M x 128, ef_search 128, GPU walk + exact re-rank
             sub['c5'] = sub_run([os.path.join(ROOT, 'scripts', 'bench_hnsw.py'), '--rows', '5000000', '--steps', '5'], 600)
         if 'm32' in legs:  # the default workload at m = 32 (the reference's own table-test shape): byte tables of one entry group
-            sub['m32'] = sub_run([me, '--m', '32', '--steps', '20', '--warmup', '5', '--cpu-queries', '0', '--recall-queries', '32'] + common, 300)
+            sub['m32'] = sub_run([me, '--m', '32', '--steps', '20', '--warmup', '5', '--cpu-queries', '16', '--cpu-repeats', '3',
+                                  '--recall-queries', '32'] + common, 300)
+        if 'k50' in legs:  # the default workload at k = 50 (the reference's own PQ test asks for topk = 50: tests/test_pq_index.py:83-135)
+            sub['k50'] = sub_run([me, '--k', '50', '--steps', '20', '--warmup', '5', '--cpu-queries', '16', '--cpu-repeats', '3',
+                                  '--recall-queries', '32'] + common, 300)
         if 'uniform' in legs:  # U[0,1)^D: unstructured codes -- the kernel the library picks for them
-            sub['uniform'] = sub_run([me, '--data', 'uniform', '--steps', '10', '--warmup', '3', '--cpu-queries', '0',
+            sub['uniform'] = sub_run([me, '--data', 'uniform', '--steps', '10', '--warmup', '3', '--cpu-queries', '16', '--cpu-repeats', '3',
                                       '--recall-queries', '32'] + common, 300)
 
     torch.cuda.set_device(local_rank)
@@ -241,14 +248,21 @@ def main():
     index_s = time.time() - t0
     sharded = ShardedPQIndex(index, row_base=lo, seed_exchange=args.seed_exchange, n_total=N)
 
-    gq = torch.Generator(device=dev)
-    gq.manual_seed(4321)
-    if UNIFORM:
-        queries = torch.rand((B, D), generator=gq, device=dev)
-    else:
-        zq = torch.randn((B, r_lat), generator=gq, device=dev)
-        eq = torch.randn((B, D), generator=gq, device=dev)
-        queries = (zq @ A + 0.05 * eq).contiguous()
+    # NB distinct query batches (same on every rank): the steps rotate through them, so that nothing the library keeps per
+    # table (annlite_scan_state: its kernel choice rests on statistics of the batches it has seen) or per stream is tuned to
+    # ONE batch; batch 0 is round 1-4's batch (seed 4321)
+    NB = max(1, args.query_batches)
+    q_sets = []
+    for j in range(NB):
+        gq = torch.Generator(device=dev)
+        gq.manual_seed(4321 + 7919 * j)
+        if UNIFORM:
+            q_sets.append(torch.rand((B, D), generator=gq, device=dev))
+        else:
+            zq = torch.randn((B, r_lat), generator=gq, device=dev)
+            eq = torch.randn((B, D), generator=gq, device=dev)
+            q_sets.append((zq @ A + 0.05 * eq).contiguous())
+    queries = q_sets[0]
 
     def barrier():
         if world > 1:
@@ -257,8 +271,11 @@ def main():
     # the product path is plain ADC (no re-rank): that is the reference's PQ search semantics
     index.rerank = False
 
+    step_no = [0]
+
     def step():
-        return sharded.search_batch(queries, limit=k)
+        step_no[0] += 1
+        return sharded.search_batch(q_sets[step_no[0] % NB], limit=k)
 
     n_streams = args.streams or (2 if (world > 1 or os.environ.get('ANNLITE_FORCE_GATHER')) else 1)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams >= 2 else [torch.cuda.current_stream(dev)]
@@ -308,13 +325,14 @@ def main():
     # Consecutive batches alternate between two streams: each batch's kernels are in order on their own stream,
     # and the next batch's table build / seed / first workgroups fill the CUs the previous scan's tail leaves idle
     pending = None
+    outs = [None] * NB  # the LAST result of every distinct batch (read only after the closing synchronisation)
     for s_i in range(args.steps):
         with torch.cuda.stream(streams[s_i % len(streams)]):
-            nxt = sharded.search_batch_async(queries, limit=k)
+            nxt = sharded.search_batch_async(q_sets[s_i % NB], limit=k)
         if pending is not None:
-            out = pending.result(wait=False)  # read only after the closing synchronisation
+            outs[(s_i - 1) % NB] = pending.result(wait=False)
         pending = nxt
-    out = pending.result(wait=False)
+    outs[(args.steps - 1) % NB] = pending.result(wait=False)
     host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3  # host time per step to ENQUEUE the K steps (no device wait in it)
     torch.cuda.synchronize()
     barrier()
@@ -326,6 +344,38 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     qps = B * args.steps / elapsed
+    for j in range(NB):  # (fewer timed steps than batches: the rest untimed, so that every batch has a result to check)
+        if outs[j] is None:
+            outs[j] = sharded.search_batch(q_sets[j], limit=k)
+    torch.cuda.synchronize()
+    out = outs[0]
+
+    # ---- what was computed, as checksums a reader can compare ACROSS runs: the merged result of every distinct batch (ids +
+    # distance bits; identical on every rank and for every N -- a SCALE line must print the N = 1 line's digest), and an
+    # ADDITIVE checksum of each rank's shard of the code table (the ranks' sums add up to the N = 1 figure mod 2^64) ----------
+    import hashlib
+
+    h_all = hashlib.sha256()
+    sha_batches = []
+    for j in range(NB):
+        blob = outs[j][1].to(torch.int64).cpu().numpy().tobytes() + outs[j][0].to(torch.float32).cpu().numpy().view(np.uint32).tobytes()
+        h_all.update(blob)
+        sha_batches.append(hashlib.sha256(blob).hexdigest()[:16])
+    result_sha256 = h_all.hexdigest()
+
+    def shard_checksum():
+        total = 0
+        plain = index._plain_codes(n_local)
+        wcol = (torch.arange(M * index.code_bytes, device=dev, dtype=torch.int64) * 2 + 1)[None, :]
+        for a0 in range(0, n_local, 1 << 20):
+            a1 = min(n_local, a0 + (1 << 20))
+            rows8 = plain[a0:a1].contiguous().view(torch.uint8).view(a1 - a0, -1).to(torch.int64)
+            gid = torch.arange(lo + a0, lo + a1, device=dev, dtype=torch.int64)
+            wrow = ((gid * 2654435761 + 12345) & 0x7fffffff) | 1
+            total = (total + int(((rows8 * wcol).sum(1) * wrow).sum().item())) & 0xFFFFFFFFFFFFFFFF
+        return total
+
+    my_checksum = shard_checksum()
 
     # ---- second figure: the same steps with the host buffers the AnnLite API hands over --
     # numpy queries in (H2D), numpy results out (D2H); never `value`
@@ -350,12 +400,14 @@ def main():
         step()
     torch.cuda.synchronize()
     _capi.profile_enable(True)
-    kms = []
+    kms, clks = [], []
     for _ in range(max(3, min(args.steps, 10))):
         step()
         kms.append(_capi.profile_last_scan_ms())
+        clks.append(_capi.profile_last_scan_clock_mhz())  # (byte-table kernel: the shader clock that launch held; else None)
     _capi.profile_enable(False)
     kernel_ms = float(np.mean(kms))
+    clock_mhz = float(np.mean([c for c in clks if c])) if any(clks) else None
 
     # ---- N > 1 (or the exchange forced on one rank): what the exchange alone costs, and every rank's own figures ----
     gathering = use_dist and (world > 1 or bool(os.environ.get('ANNLITE_FORCE_GATHER')))
@@ -381,12 +433,18 @@ def main():
             torch.cuda.synchronize()
             exchange_ms = e0.elapsed_time(e1) / n_x  # one packed all-gather of [B, k, 2] i64 + the merge kernel, back to back
     if use_dist:
-        mine = torch.tensor([own_elapsed / args.steps * 1e3, kernel_ms, exchange_ms if exchange_ms is not None else -1.0, float(n_local)],
+        mine = torch.tensor([own_elapsed / args.steps * 1e3, kernel_ms, exchange_ms if exchange_ms is not None else -1.0, float(n_local),
+                             float(my_checksum >> 32), float(my_checksum & 0xFFFFFFFF), float(int(result_sha256[:8], 16)),
+                             clock_mhz if clock_mhz else -1.0],
                             dtype=torch.float64, device=dev)
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [{'rank': r, 'ms_per_step': float(t[0]), 'kernel_ms': float(t[1]),
-                     'exchange_ms': None if float(t[2]) < 0 else float(t[2]), 'rows': int(t[3])} for r, t in enumerate(allr)]
+                     'exchange_ms': None if float(t[2]) < 0 else float(t[2]), 'rows': int(t[3]),
+                     'shard_codes_checksum': '%016x' % ((int(t[4]) << 32) | int(t[5])),
+                     # (every rank holds the merged result: the first 32 bits of ITS digest -- all equal, or a rank merged differently)
+                     'result_sha256_head': '%08x' % int(t[6]),
+                     'shader_clock_mhz': None if float(t[7]) < 0 else float(t[7])} for r, t in enumerate(allr)]
     scan_bytes = float(B) * n_local * M  # algorithmic code bytes consumed per launch
     achieved = scan_bytes / (kernel_ms * 1e-3) / 1e9
     lookups_per_s = float(B) * n_local * M / (kernel_ms * 1e-3)
@@ -601,16 +659,24 @@ def main():
         # all cores: the WHOLE batch where the host has the cores for it (16 CPUs: ~2.5 s at 10M rows) -- and its result is
         # kept: every query of the timed batch is compared with the CPU oracle, not a sample
         nq_all = B if threads >= 8 else min(B, max(nqc, threads * 64))
-        q_all = queries[:nq_all].cpu().numpy()
-        t0 = time.perf_counter()
-        cd_all, ci_all = pq_oracle.index_search(q_all, cb_np, codes_np, omet, k, threads=threads)
-        cpu_all_s = time.perf_counter() - t0
-        if args.metric == 'cosine':
-            gd_all, gi_all = index.search_batch(q_all, limit=k)  # (host-buffer path, see above)
-        else:
-            gd_all, gi_all = out[0][:nq_all].cpu().numpy(), out[1][:nq_all].cpu().numpy()
-        parity_all = bool(np.array_equal(cd_all, gd_all) and np.array_equal(ci_all, gi_all))
-        n_bad = int(np.sum(np.any(ci_all != gi_all, axis=1) | np.any(cd_all != gd_all, axis=1)))
+        cpu_all_s = 0.0
+        n_bad = 0
+        bad_batches = []
+        for j in range(NB):  # EVERY distinct batch of the timed loop, not only batch 0
+            q_all = q_sets[j][:nq_all].cpu().numpy()
+            t0 = time.perf_counter()
+            cd_all, ci_all = pq_oracle.index_search(q_all, cb_np, codes_np, omet, k, threads=threads)
+            cpu_all_s += time.perf_counter() - t0
+            if args.metric == 'cosine':
+                gd_all, gi_all = index.search_batch(q_all, limit=k)  # (host-buffer path, see above)
+            else:
+                gd_all, gi_all = outs[j][0][:nq_all].cpu().numpy(), outs[j][1][:nq_all].cpu().numpy()
+            nb_j = int(np.sum(np.any(ci_all != gi_all, axis=1) | np.any(cd_all != gd_all, axis=1)))
+            n_bad += nb_j
+            if nb_j:
+                bad_batches.append(j)
+        parity_all = n_bad == 0
+        nq_all_total = nq_all * NB
         cpu = {
             'value': nqc / cpu_s, 'unit': 'queries/s', 'cores': 1, 'kind': 'port',
             'sample': f'{nqc} queries x {n_local} rows (LUT + flat ADC scan + top-{k}), single thread = the reference execution '
@@ -619,10 +685,12 @@ def main():
                 'value': 1.0 / ref_style_s, 'unit': 'queries/s', 'cores': 1,
                 'sample': f'{lut_np.shape[0]} queries: ADC kernel -> Python list of N floats -> np.expand_dims -> argpartition top-k '
                           '(pq_bindings.pyx:75-80, pq_index.py:46-49)'},
-            'all_cores': {'value': nq_all / cpu_all_s, 'cores': threads, 'sample': f'{nq_all} queries, OpenMP over queries, one run'},
+            'all_cores': {'value': nq_all_total / cpu_all_s, 'cores': threads,
+                          'sample': f'{NB} batches x {nq_all} queries, OpenMP over queries, one run each'},
             'gpu_matches_cpu_bit_exact': parity,
             # ids AND distances of the timed batch's result against the CPU oracle, every one of `queries_checked` queries
-            'gpu_matches_cpu_bit_exact_all': parity_all, 'queries_checked': nq_all, 'queries_differing': n_bad,
+            'gpu_matches_cpu_bit_exact_all': parity_all, 'queries_checked': nq_all_total, 'queries_differing': n_bad,
+            'batches_checked': NB, 'batches_differing': bad_batches,
         }
 
     gathering_cfg = use_dist and (world > 1 or bool(os.environ.get('ANNLITE_FORCE_GATHER')))
@@ -641,18 +709,35 @@ def main():
         lds_peak = 256 * per_clk * 2.4e9
         kernel_name = ('adc_scan_generic_kernel' if not plan_k.fast else 'adc_scan_q8_kernel' if byte_tables else
                        'adc_scan_qfilter64_kernel' if M == 64 else 'adc_scan_qfilter_kernel')
-        traffic = traffic_table.get(f'{kernel_name}:{n_local}x{M}x{B}', {}).get('hbm_bytes_per_launch')
+        # measured HBM traffic: a committed PMC pass of the same kernel / shape (bench.py cannot run rocprof on itself).  An entry
+        # measured on ANOTHER revision of the kernel (the library's ANNLITE_KERNEL_REV for it has moved on since) is refused, loudly
+        t_key = f'{kernel_name}:{n_local}x{M}x{B}' + ('' if k <= 16 else f':k{k}')
+        t_ent = traffic_table.get(t_key, {})
+        traffic = t_ent.get('hbm_bytes_per_launch')
+        traffic_note = None if traffic is not None else f'no PMC pass kept for {t_key}'
+        lib_rev = _capi.kernel_rev(kernel_name)
+        if traffic is not None and t_ent.get('kernel_rev') != lib_rev:
+            traffic_note = (f'STALE: profiles/traffic.json[{t_key}] was measured on kernel revision {t_ent.get("kernel_rev")}, '
+                            f'the library is at revision {lib_rev}: re-run the PMC passes (scripts/r05_profiles.sh)')
+            print('bench.py: ' + traffic_note, file=sys.stderr)
+            traffic = None
+        # shapes with both a byte-table and a u16-table kernel (scan.hip: search_policy) have a choice to report
+        has_choice = k <= 16 and index.code_bytes in (1, 2) and ((M in (8, 16, 32) and index.code_bytes == 1 and Ks <= 256) or
+                                                                 (M == 8 and index.code_bytes == 2 and Ks <= 1024))
         roof = {
             'bound': 'lds', 'achieved': lookups_per_s, 'peak': lds_peak, 'unit': 'look-ups/s', 'frac': lookups_per_s / lds_peak,
-            'traffic': traffic,
+            'traffic': traffic, 'traffic_note': traffic_note, 'kernel_rev': lib_rev,
             'kernel': kernel_name, 'kernel_ms': kernel_ms, 'lookups_per_clk_per_cu': per_clk,
-            'kernel_choice': index.scan_kernel,
+            'kernel_choice': index.scan_kernel if has_choice else 'fixed',
             'peak_note': 'design-relative: one ds_read_b128 (M=64: ds_read_b64) per wave64 per 4 (2) LDS cycles x 64 lanes x the '
                          'entries this kernel packs per read (byte tables: 16 one-byte entries per 16 B, M=64 8 per 8 B = 256 look-ups / clk / CU; '
                          'u16 tables: 8 per 16 B, M=64 4 per 8 B = 128) x 256 CUs x 2.4 GHz: the roof of THIS table format, not a chip constant',
             # the M = 64 byte-table kernel is VALU-bound and holds 2.1 GHz, not the 2.4 GHz the roof is priced at (PMC:
             # GRBM_GUI_ACTIVE / 8 XCDs / duration, profiles/r03/scan_c4_10m_m64_q8_pmc_*.csv): the fraction at THAT clock beside it
-            'frac_at_measured_clock': (lookups_per_s / (256 * per_clk * 2.1e9)) if (M == 64 and byte_tables) else None,
+            # round 5: the clock is MEASURED in the run (workgroup 0's s_memtime over its 100 MHz wall clock, mean over the profiled
+            # launches) for every byte-table shape -- a slow box shows here, not as a slow kernel
+            'shader_clock_mhz': clock_mhz,
+            'frac_at_measured_clock': (lookups_per_s / (256 * per_clk * clock_mhz * 1e6)) if clock_mhz else None,
             # SURVEY.md 8(d)'s per-unit figure: M code bytes per (query, row) evaluation -- what a one-query-at-a-time scan
             # (the reference) streams; reported for comparison, not a fraction of anything
             'algorithmic': {'bytes_per_launch': scan_bytes, 'GB_per_s': achieved},
@@ -671,6 +756,7 @@ def main():
                 'backend': (dist.get_backend() + ' (RCCL)') if use_dist else None,
                 # independent batches alternate between this many HIP streams (each batch's kernels in order on its own)
                 'streams': n_streams,
+                'query_batches': NB,  # distinct batches the timed steps rotate through
                 'prewarm_steps': args.prewarm_steps,  # untimed set-up steps BEFORE the W warm-up steps (clock ramp)
                 # N > 1: every rank seeds from 1 / N of the single-GPU seed rows and the ranks all-gather their seeds' k smallest
                 # bounds before the scan (sharded.py); seed_peers_emulated: --emulate-seed-peers (one rank standing for P)
@@ -681,6 +767,12 @@ def main():
             # N > 1: every rank's own clock over the K steps, its scan kernel (HIP events) and the exchange alone (one packed
             # all-gather + merge, 20 back to back) -- a first multi-GPU run says where its time went
             'per_rank': per_rank,
+            # digest of (ids, distance bits) of the LAST result of each of the `query_batches` distinct batches, in order: the same
+            # for every N (the merged result is the single-GPU result) -- compare a SCALE line with the N = 1 line
+            'result_sha256': result_sha256, 'result_sha256_per_batch': sha_batches,
+            # additive checksum of the rank's shard of the code table (sum over ranks mod 2^64 == the N = 1 value)
+            'shard_codes_checksum_sum': '%016x' % (sum(int(r['shard_codes_checksum'], 16) for r in per_rank) & 0xFFFFFFFFFFFFFFFF)
+            if per_rank else '%016x' % my_checksum,
             'exchange_ms': exchange_ms,
             'host_enqueue_ms_per_step': host_enqueue_ms,  # (close to ms_per_step: the host, not the GPU, paces the loop)
             'recall_at_10': recall_adc,
@@ -705,6 +797,7 @@ def main():
                                                  'roofline', 'cpu_baseline', 'hnsw_gpu_walk_adc', 'exhaustive_exact_rerank') if kk in r}
             else:
                 rec[name] = {'config': r['config']['workload'], 'streams': r['config'].get('streams'), 'value': r['value'], 'unit': r['unit'],
+                             'result_sha256': r.get('result_sha256'),
                              'ms_per_step': r['ms_per_step'],
                              'recall_at_10': r.get('recall_at_10'), 'roofline': r['roofline'], 'cpu_baseline': r['cpu_baseline']}
         print(json.dumps(rec))

@@ -252,6 +252,12 @@ ANNLITE_API int annlite_adc_scan_candidates(const void *codes_dev, int code_byte
  * launch stream; annlite_profile_last_scan_ms() waits for the last one and returns its duration. */
 ANNLITE_API int annlite_profile_enable(int on);
 ANNLITE_API int annlite_profile_last_scan_ms(float *ms);
+/* ... and, for the byte-table kernel, the shader clock that launch actually held (MHz): workgroup 0's s_memtime delta over
+ * its 100 MHz wall-clock delta.  ANNLITE_ERR_INVALID when the last profiled scan was not a byte-table launch. */
+ANNLITE_API int annlite_profile_last_scan_clock_mhz(float *mhz);
+/* Revision (> 0) of a kernel's memory behaviour, by kernel name ("adc_scan_q8_kernel", ...); 0 = unknown name.  Recorded with every
+ * kept PMC pass (profiles/traffic.json): bench.py's roofline.traffic refuses a pass taken on another revision. */
+ANNLITE_API int annlite_kernel_rev(const char *kernel);
 /* Kernel choice (M = 8 / 16 / 32 with uint8 codes, M = 8 with uint16 codes up to Ks = 1024; k <= 16): byte filter tables (the default)
  * or u16 filter tables -- made INSIDE the library, per call, never by a process-wide switch.  Without a state every
  * byte-table launch is guarded: it gives up when a workgroup has seen more than 1024 + (rows it has drawn) / 16 candidates

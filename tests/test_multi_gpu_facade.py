@@ -176,6 +176,47 @@ def test_a_shard_with_fewer_rows_than_k(world):
     assert (i[:, 4:] == -1).all() and np.isinf(d[:, 4:]).all() and (i[:, :4] >= 0).all()
 
 
+@pytest.mark.parametrize('G', [4, 8])
+def test_four_and_eight_fake_devices_uneven_empty_and_short_shards(world, G):
+    """Round 5: the single-process index over G = 4 / 8 devices (what ``AnnLite(devices=[0..7])`` builds on the 8-GPU node) --
+    a table that does not divide into the block-cyclic deal, shards EMPTY (fewer blocks than devices), every shard shorter than
+    k, k beyond the merge kernel's 64 (merge_lists_sorted); deletes that empty a whole shard."""
+    o, codec, *_ = world
+    codec = _codec_with_books(world)
+    rs = np.random.RandomState(10 + G)
+    B = 6
+    q = rs.randn(B, 32).astype(np.float32)
+    lut = o.get_dist_mat_c(q, codec.codebooks, o.EUCLIDEAN)
+    for N in (64 * (2 * G + 1) + 7, 64 * 2 + 3, G + 1, 5):  # uneven / empty shards beyond the third / a few rows in shard 0 only
+        x = rs.randn(N, 32).astype(np.float32)
+        if N > 70:
+            x[60:70] = x[1]  # ties across the first block boundary
+        idx = _make(world, block=64, G=G)
+        idx.add_with_ids(x, np.arange(N))
+        assert idx.size == N
+        codes = o.encode_c(x, codec.codebooks)
+        for k in (10, 1, 70):
+            rd, ri = o.adc_search_c(lut, codes, min(k, 64)) if k <= 64 else (None, None)
+            if k > 64:  # beyond the oracle's lists: full sort by (distance, id)
+                dd = np.stack([o.dist_pqcodes_to_codebooks_c(lut[b], codes) for b in range(B)])
+                order = np.stack([np.lexsort((np.arange(N), dd[b]))[:k] for b in range(B)])
+                ri = np.full((B, k), -1, np.int64)
+                rd = np.full((B, k), np.inf, np.float32)
+                ri[:, :order.shape[1]] = order
+                rd[:, :order.shape[1]] = np.take_along_axis(dd, order, axis=1)
+            d, i = idx.search_batch(q, limit=k)
+            assert np.array_equal(i, ri) and np.array_equal(d, np.sqrt(rd)), (G, N, k)
+        if N > 64 * 2:  # empty the whole second block (= all of shard 1's rows when the table has at most G blocks)
+            gone = np.arange(64, 128)
+            idx.delete(gone)
+            keep = np.ones(N, bool)
+            keep[gone] = False
+            rows = np.nonzero(keep)[0]
+            rd, ri = o.adc_search_c(lut, codes[rows], 10)
+            d, i = idx.search_batch(q, limit=10)
+            assert np.array_equal(i, np.where(ri >= 0, rows[np.clip(ri, 0, len(rows) - 1)], -1)) and np.array_equal(d, np.sqrt(rd)), (G, N)
+
+
 def test_annlite_facade_over_two_fake_devices(world, tmp_path):
     """``AnnLite(..., devices=[0, 1])``: index() / search() / delete() / a filter through the reference's one-object API
     (annlite/index.py:274-359), the code table dealt over two (fake) devices -- results equal one flat oracle scan."""

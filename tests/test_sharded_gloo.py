@@ -210,3 +210,140 @@ def test_sharded_search_with_seed_exchange_world2_gloo(oracle):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 5: world sizes 4 and 8 (what the 8-GPU node will run), through BOTH exchanges -- ShardedSearcher's general gather and
+# ShardedPQIndex's packed one -- on tables that do not divide by the rank count, leave a rank EMPTY, leave every rank shorter
+# than k, and (seed exchange) leave ranks shorter than their share of the seed rows
+def _wide_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import pq_oracle
+    from annlite_amd.core.index.multi_gpu import merge_lists_sorted
+    from annlite_amd.sharded import SEED_KEYS, ShardedPQIndex, ShardedSearcher, numpy_merge, numpy_merge_packed, shard_range
+
+    rs = np.random.RandomState(3)  # same data on every rank
+    M, Ks, B = 16, 256, 7
+    full = rs.randint(0, Ks, size=(5003, M)).astype(np.uint8)
+    full[600:660] = full[600]    # ties across the first shard boundaries of both world sizes (626 / 1251)
+    full[1240:1260] = full[600]
+    lut = rs.rand(B, M, Ks).astype(np.float32)
+    lut_t = torch.from_numpy(lut)
+    ok = True
+    why = []
+
+    class FakeShard:
+        sqrt_epilogue = True
+
+        def __init__(self, rows, base):
+            self.rows, self.base = rows, base
+
+        def search_batch_packed(self, queries_lut, kk, row_base):
+            d, i = pq_oracle.adc_search_c(queries_lut.numpy(), self.rows, kk, id_base=row_base)
+            out = np.empty(d.shape + (2,), dtype=np.int64)
+            out[..., 0], out[..., 1] = i, d.view(np.uint32).astype(np.int64)
+            return torch.from_numpy(out)
+
+    # N: not divisible by G / one row per rank and EMPTY ranks (N < G at world 8) / every rank shorter than k / empty table
+    for N in (5003, 5, 13, 2 * world + 1, 0):
+        rows_all = full[:N]
+        lo, hi = shard_range(N, world, rank)
+        for k in (10, 1, 33):
+            rd, ri = pq_oracle.adc_search_c(lut, rows_all, k)
+
+            def scan(queries_lut, kk):
+                d, i = pq_oracle.adc_search_c(queries_lut, rows_all[lo:hi], kk, id_base=lo)
+                return torch.from_numpy(d), torch.from_numpy(i)
+
+            d, i = ShardedSearcher(scan, numpy_merge).search(lut, k)
+            good = np.array_equal(d.numpy(), rd) and np.array_equal(i.numpy(), ri)
+            # ... the same gather with the product's any-k merge (MultiGpuPQIndex / limit > 64: merge_lists_sorted)
+            d2, i2 = ShardedSearcher(scan, lambda ad, ai: merge_lists_sorted(ad, ai, k)).search(lut, k)
+            good = good and np.array_equal(d2.numpy(), rd) and np.array_equal(i2.numpy(), ri)
+            sh = ShardedPQIndex(FakeShard(rows_all[lo:hi], lo), row_base=lo, merge=numpy_merge, merge_packed=numpy_merge_packed)
+            pd, pi = sh.search_batch_async(lut_t, limit=k).result()
+            good = good and np.array_equal(pd.numpy(), np.sqrt(rd)) and np.array_equal(pi.numpy(), ri)
+            if not good:
+                ok = False
+                why.append(('gather', N, k))
+
+    # ---- the seed exchange at this world size: ranks whose shard is shorter than seed_rows() (and, at the small table, empty
+    # ranks) contribute the keys they have; the k-th smallest of the union bounds every rank's scan
+    NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
+    k = 10
+
+    def key_of(d):
+        return (d.astype(np.float32).view(np.uint32).astype(np.uint64) + np.uint64(2)) << np.uint64(32)
+
+    for N in (5003, world + 3):  # 5003 / G < 4096 seed rows: every rank is shorter than its seed; world + 3: ranks of 2, 1 and 0 rows
+        rows_all = full[:N]
+        lo, hi = shard_range(N, world, rank)
+
+        class SplitShard(FakeShard):
+            _n_rows = hi - lo
+
+            def split_prepare(self, lut_tt, kk, row_base, seed_rows, workspace):
+                lq = lut_tt.numpy()
+                mine = self.rows[:seed_rows]  # (shorter than seed_rows: all the rank has)
+                dd = np.stack([pq_oracle.dist_pqcodes_to_codebooks_c(lq[b], mine) for b in range(lq.shape[0])]) if len(mine) else \
+                    np.zeros((lq.shape[0], 0), np.float32)
+                kk_ = np.full((lq.shape[0], SEED_KEYS), NONE, dtype=np.uint64)
+                n = min(k, dd.shape[1])
+                if n:
+                    kk_[:, :n] = key_of(np.sort(dd, axis=1)[:, :n])
+                shard = self
+
+                class Batch:
+                    n_queries = lq.shape[0]
+                    keys = torch.from_numpy(kk_.view(np.int64))
+
+                    def union(self, all_keys):
+                        u = all_keys.numpy().view(np.uint64)
+                        flat = np.sort(u.transpose(1, 0, 2).reshape(lq.shape[0], -1), axis=1)
+                        self.bound = flat[:, k - 1]  # (NONE when the whole table has fewer than k rows: no bound)
+
+                    def scan(self):
+                        d, i = pq_oracle.adc_search_c(lq, shard.rows, k, id_base=shard.base)
+                        keep = key_of(d) <= self.bound[:, None]  # rows above the bound never reach the lists
+                        i = np.where(keep, i, -1)
+                        d = np.where(keep, d, np.inf).astype(np.float32)
+                        out = np.empty(d.shape + (2,), dtype=np.int64)
+                        out[..., 0], out[..., 1] = i, d.view(np.uint32).astype(np.int64)
+                        return torch.from_numpy(out)
+
+                    def plain(self):
+                        return shard.search_batch_packed(lut_tt, k, shard.base)
+
+                return Batch()
+
+        sh = ShardedPQIndex(SplitShard(rows_all[lo:hi], lo), row_base=lo, merge=numpy_merge, merge_packed=numpy_merge_packed,
+                            n_total=max(N, 1), seed_exchange=True)
+        for _ in range(2):
+            pd, pi = sh.search_batch_async(lut_t, limit=k).result()
+            rd, ri = pq_oracle.adc_search_c(lut, rows_all, k)
+            if not (np.array_equal(pd.numpy(), np.sqrt(rd)) and np.array_equal(pi.numpy(), ri)):
+                ok = False
+                why.append(('seed', N))
+    q.put((rank, ok, why))
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize('world', [4, 8])
+def test_sharded_search_world4_world8_gloo(oracle, world):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wide_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True, []) for r in range(world)], res
