@@ -39,6 +39,8 @@ CASES = {
     't_m32_d128': (32, 4, 256, 1024, 5, 104),      # tests/test_pq_bind.py shape
     'ks512_m8_d64': (8, 8, 512, 1000, 5, 105),     # tests/test_pq_index.py:80 (uint16 codes)
     'ks768_m8_d64': (8, 8, 768, 1000, 5, 106),     # tests/test_pq_index.py:80, the third n_clusters (round 3: 16-query byte tables)
+    'ex_m64_d128': (64, 2, 256, 512, 4, 107),      # examples/pq_benchmark.py:44 `for n_subvectors in [64, 128]` at D = 128: dsub = 2 ...
+    'ex_m128_d128': (128, 1, 256, 512, 4, 108),    # ... and dsub = 1 (round 5)
 }
 K = 10
 

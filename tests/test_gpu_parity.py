@@ -159,10 +159,14 @@ def _scan(ops, codes, lut_bmk, k, layout=0, valid=None, row_base=0):
 @pytest.mark.parametrize('name', [n for n in golden_names()])
 @pytest.mark.parametrize('layout', [0, 1])
 def test_scan_topk_vs_fixture(ops, oracle, name, layout):
+    from annlite_amd._capi import scan_plan
+
     g = load_golden(name)
     if g['codes'].dtype != np.uint8 and layout == 1:
         pytest.skip('SKEWED layout is uint8-only')
     k = g['K']
+    if layout == 1 and not scan_plan(g['N'], g['M'], g['Ks'], 1, g['B'], k).fast:
+        pytest.skip('SKEWED needs the fast plan')  # (M = 128: the generic kernel)
     d, i, plan = _scan(ops, g['codes'], g['lut_l2_batch'], k, layout)
     if g['codes'].dtype == np.uint8:
         rd, ri = oracle.adc_search_c(g['lut_l2_batch'], g['codes'], k)
@@ -185,6 +189,9 @@ SHAPES = [
     (8, 256, 3000, 17, 10), (8, 200, 999, 5, 3), (32, 256, 2500, 6, 10), (64, 256, 1500, 5, 10), (64, 100, 700, 2, 7),
     (16, 256, 40000, 24, 50), (4, 256, 1000, 5, 10), (3, 17, 500, 4, 10), (12, 256, 800, 3, 10),
     (64, 256, 70000, 9, 10), (64, 256, 8200, 4, 64), (8, 256, 50000, 33, 10), (32, 256, 30000, 17, 16),
+    # round 5: the reference example's own shapes -- examples/pq_benchmark.py:44 loops n_subvectors in [64, 128] at D = 128
+    # (dsub 2 and 1): M = 128 has no fast kernel (the generic one), M = 64 at k = 50 the u16 tables
+    (128, 256, 3000, 9, 10), (128, 256, 40000, 5, 50), (128, 256, 129, 3, 1), (64, 256, 20000, 6, 50),
 ]
 
 
@@ -205,6 +212,42 @@ def test_scan_topk_random_shapes(ops, oracle, M, Ks, N, B, k, layout):
     ri = np.where(ri == -1, -1, ri)
     assert np.array_equal(d, rd)
     assert np.array_equal(i, ri)
+
+
+@pytest.mark.parametrize('M,dsub', [(64, 2), (128, 1)])
+@pytest.mark.parametrize('metric', ['euclidean', 'cosine', 'inner_product'])
+def test_example_shapes_queries_in_neighbours_out(ops, oracle, M, dsub, metric):
+    """examples/pq_benchmark.py:44 (`for n_subvectors in [64, 128]` at D = 128): sub-vectors of 2 floats and of ONE float,
+    queries in -> neighbours out through annlite_pq_search_topk (no fused preparation launch for them: dsub % 4 != 0) and through
+    the index plug-in, all three metrics, against the oracle's restatement of the reference pipeline."""
+    from annlite_amd import Metric, PQCodec
+    from annlite_amd._capi import LUT_IPDIST, LUT_L2
+    from annlite_amd.core.index.pq_flat_gpu import PQFlatGpuIndex
+
+    rs = np.random.RandomState(M + len(metric))
+    N, B, k, Ks = 30_000, 19, 10, 256
+    D = M * dsub
+    A = rs.randn(12, D).astype(np.float32)
+    x = (rs.randn(N, 12).astype(np.float32) @ A + 0.05 * rs.randn(N, D).astype(np.float32)).astype(np.float32)
+    q = (rs.randn(B, 12).astype(np.float32) @ A + 0.05 * rs.randn(B, D).astype(np.float32)).astype(np.float32)
+    xn = oracle.l2_normalize(x) if metric == 'cosine' else x  # (what the index stores codes of: hnsw/index.py:28-29)
+    cb = np.stack([xn[rs.choice(N, Ks, replace=False), m * dsub:(m + 1) * dsub] for m in range(M)]).astype(np.float32)
+    omet = {'euclidean': oracle.EUCLIDEAN, 'cosine': oracle.COSINE, 'inner_product': oracle.INNER_PRODUCT}[metric]
+    met = {'euclidean': Metric.EUCLIDEAN, 'cosine': Metric.COSINE, 'inner_product': Metric.INNER_PRODUCT}[metric]
+    codes = oracle.encode_c(xn, cb)
+    rd, ri = oracle.index_search(q, cb, codes, omet, k)
+    # the C entry point (tables from the queries inside the call)
+    qn = oracle.l2_normalize(oracle.l2_normalize(q)) if metric == 'cosine' else q  # (index.py:28-29 + pq.py:309-310: normalised twice)
+    kind = LUT_L2 if metric == 'euclidean' else LUT_IPDIST
+    d, i = ops.pq_search_topk(kind, ops.to_dev(np.ascontiguousarray(qn, np.float32)), ops.to_dev(cb), ops.to_dev(codes), k, M, Ks,
+                              sqrt=(metric == 'euclidean'))
+    assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(d.cpu().numpy(), rd)
+    # the index plug-in (encode on the GPU, numpy in -> numpy out)
+    codec = PQCodec(dim=D, n_subvectors=M, n_clusters=Ks, metric=met).set_codebooks(cb)
+    idx = PQFlatGpuIndex(dim=D, metric=met, pq_codec=codec, initial_size=N)
+    idx.add_with_ids(x, np.arange(N))
+    d2, i2 = idx.search_batch(q, limit=k)
+    assert np.array_equal(np.asarray(i2), ri) and np.array_equal(np.asarray(d2), rd)
 
 
 @pytest.mark.parametrize('M', [16, 8, 32, 64])
