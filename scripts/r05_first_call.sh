@@ -11,10 +11,19 @@ for rows in 10000000 1250000; do
   timeout 120 python bench.py $A --streams 2 > $OUT/bench_shard_${rows}_s2.json 2>/dev/null
   ANNLITE_FORCE_GATHER=1 timeout 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 $A --streams 2 > $OUT/bench_shard_${rows}_forced_gather.json 2>/dev/null
 done
+# slice-per-XCD map for M = 16 (what M = 64 got in round 4): A/B on this box, 10M and 1.25M rows, one stream
+for rows in 10000000 1250000; do
+  for map in 0 1; do
+    ANNLITE_Q8_MAP=$map timeout 120 python bench.py --rows $rows --legs none --cpu-queries 0 --recall-queries 0 --no-rerank --steps 100 --warmup 20 > $OUT/bench_map${map}_${rows}.json 2>/dev/null
+  done
+done
 P="--rows 10000000 --data lowrank --fused --valid --iters 8"
 ANNLITE_SCAN_VARIANT=50 timeout 60 python scripts/prof_scan.py $P --m 32 --dsub 4 --k 10 2>&1 | grep -v "^/opt" | head -2 > $OUT/scan_10m_m32_q8.txt
 ANNLITE_SCAN_VARIANT=31 timeout 60 python scripts/prof_scan.py $P --m 32 --dsub 4 --k 10 2>&1 | grep -v "^/opt" | head -2 > $OUT/scan_10m_m32_u16.txt
 timeout 60 python scripts/prof_scan.py $P --k 50 2>&1 | grep -v "^/opt" | head -2 > $OUT/scan_10m_k50_u16.txt
+# what 16 row slices cost the byte-table kernel at k = 16 (two work items per workgroup): the shape a 16-key-list k = 50 plan would run
+timeout 60 python scripts/prof_scan.py $P --k 16 2>&1 | grep -v "^/opt" | head -2 > $OUT/scan_10m_k16_q8_8slices.txt
+ANNLITE_SCAN_SLICES=16 timeout 60 python scripts/prof_scan.py $P --k 16 2>&1 | grep -v "^/opt" | head -2 > $OUT/scan_10m_k16_q8_16slices.txt
 python - <<'PY'
 import json, glob
 for f in sorted(glob.glob('gpurun_out/r05first/bench_*.json')):
