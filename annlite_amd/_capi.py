@@ -43,6 +43,10 @@ SYMBOLS = (
     'annlite_adc_gather',
     'annlite_graph_search',
     'annlite_graph_search_stats',
+    'annlite_graph_search_stats_ex',
+    'annlite_graph_record_bytes',
+    'annlite_graph_pack',
+    'annlite_graph_search_packed',
     'annlite_adc_scan_topk',
     'annlite_adc_scan_topk_packed',
     'annlite_pq_search_workspace_bytes',
@@ -124,6 +128,9 @@ def lib() -> ctypes.CDLL:
     L.annlite_adc_dist.argtypes = [vp, i64, i64, vp, i32, i64, vp, vp]
     L.annlite_adc_gather.argtypes = [vp, i64, i64, i64, vp, i32, i64, vp, i64, vp, vp]
     L.annlite_graph_search.argtypes = [vp, i32, vp, i64, vp, i64, i64, i64, vp, vp, i64, i32, vp, vp, vp]
+    L.annlite_graph_search_packed.argtypes = [vp, i32, vp, i64, vp, i64, i64, i64, vp, vp, i64, i32, vp, vp, vp]
+    L.annlite_graph_pack.argtypes = [vp, i32, vp, i64, i64, vp, vp]
+    L.annlite_graph_record_bytes.argtypes = [i32, i64, ctypes.POINTER(ctypes.c_int64)]
     L.annlite_adc_scan_topk.argtypes = [vp, i32, i32, i64, i64, i64, vp, vp, i64, i64, i64, vp, vp, vp, sz, vp]
     L.annlite_adc_scan_candidates.argtypes = L.annlite_adc_scan_topk.argtypes
     L.annlite_adc_scan_topk_packed.argtypes = [vp, i32, i32, i64, i64, i64, vp, vp, i64, i64, i64, vp, vp, sz, vp]
@@ -166,6 +173,7 @@ def lib() -> ctypes.CDLL:
     L.annlite_debug_items.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
     L.annlite_debug_prep_timeline.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     L.annlite_graph_search_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    L.annlite_graph_search_stats_ex.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     for name in SYMBOLS:
         fn = getattr(L, name)  # AttributeError here == the .so does not export a declared symbol
         if name == 'annlite_ivf_max_tiles':
@@ -295,6 +303,13 @@ def graph_search_stats():
     out = (ctypes.c_uint64 * 2)()
     check(lib().annlite_graph_search_stats(out), 'graph_search_stats')
     return int(out[0]), int(out[1])
+
+
+def graph_search_stats_ex():
+    """(expansions, rows evaluated, prefetched records used) of the last GPU graph walk (ANNLITE_DEBUG_COUNTERS=1)."""
+    out = (ctypes.c_uint64 * 4)()
+    check(lib().annlite_graph_search_stats_ex(out), 'graph_search_stats_ex')
+    return int(out[0]), int(out[1]), int(out[2])
 
 
 def debug_timeline():

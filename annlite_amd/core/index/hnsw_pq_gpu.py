@@ -32,7 +32,7 @@ from .pq_flat_gpu import PQFlatGpuIndex
 class HnswPQGpuIndex(PQFlatGpuIndex):
     def __init__(self, dim: int, pq_codec=None, metric: Metric = Metric.COSINE, ef_construction: int = 200,
                  ef_search: int = 50, max_connection: int = 16, n_threads: int = 0, seed: int = 100,
-                 walk: str = 'gpu', **kwargs):
+                 walk: str = 'gpu', packed_graph: bool = True, **kwargs):
         super().__init__(dim, pq_codec=pq_codec, metric=metric, **kwargs)
         self.ef_construction = int(ef_construction)  # hnsw/index.py:66-69
         self.ef_search = int(ef_search)
@@ -41,6 +41,11 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
         self.seed = int(seed)
         assert walk in ('gpu', 'host')
         self.walk = walk  # where the graph is walked at query time: GPU kernel (default) or the host library
+        # GPU walk over packed node records (neighbours' code rows inline: 656 B per node at M = 16, max_connection 16) -- the
+        # default; False = the plain lists + code table (the parity tests compare the two)
+        self.packed_graph = bool(packed_graph)
+        self._packed = None
+        self._packed_key = None
         self._graph = None
         self._gpu_graph = None  # (key, links i32 [N, L+1], seeds i32 [S]) exported for the GPU walk
         self._mutations = 0     # bumped by every add / delete / reset / load: the key of the two device-side caches
@@ -103,6 +108,8 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
         self._gpu_graph = None
         self._plain_cache = None
         self._plain_cache_key = None
+        self._packed = None
+        self._packed_key = None
         if self._graph is not None:
             gc.lib().annlite_hnsw_free(self._graph)
             self._graph = None
@@ -124,6 +131,14 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
                                torch.from_numpy(seeds[:ns.value].astype(np.int32)).to(dev))
         return self._gpu_graph[1], self._gpu_graph[2]
 
+    def _packed_records(self, links: torch.Tensor, plain: torch.Tensor) -> torch.Tensor:
+        """The packed node records of the current graph (cached; rebuilt with the export after inserts / deletes)."""
+        key = (self._n_rows, self._mutations)
+        if getattr(self, '_packed_key', None) != key:
+            self._packed = ops.graph_pack(links, plain, n_rows=self._n_rows)
+            self._packed_key = key
+        return self._packed
+
     def _gpu_walk_ok(self) -> bool:
         return self.walk == 'gpu' and self.M in (8, 16, 32) and self.Ks <= 256
 
@@ -138,8 +153,13 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
             self._ensure_graph()
             links, seeds = self._export_graph()
             lut = ops.lut_build(xg, self.pq_codec.codebooks_dev, LUT_L2, LAYOUT_BMK)
-            return ops.graph_search(links, seeds, self._plain_table(self._n_rows), lut, ef, valid_bits=self._valid,
-                                    n_rows=self._n_rows)
+            plain = self._plain_table(self._n_rows)
+            if self.packed_graph and links.shape[1] - 1 <= 64:
+                # packed node records (round 5): the neighbours' code rows sit behind every node's link list -- one contiguous
+                # read per expansion, the next record prefetched; the candidate lists are the plain walk's, bit for bit
+                return ops.graph_search_packed(self._packed_records(links, plain), links.shape[1] - 1, seeds, plain, lut, ef,
+                                               valid_bits=self._valid, n_rows=self._n_rows)
+            return ops.graph_search(links, seeds, plain, lut, ef, valid_bits=self._valid, n_rows=self._n_rows)
         x_np = np.ascontiguousarray(xg.cpu().numpy(), dtype=np.float32)
         B = x_np.shape[0]
         ids = np.empty((B, ef), dtype=np.int64)

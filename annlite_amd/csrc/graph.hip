@@ -13,6 +13,16 @@
 // sectors) and evaluate hnswlib::PQLookup from LDS -- fp32 adds in ascending sub-space order, the same
 // bits as the flat scan (space_pq.h:15-37) -- and the survivors are inserted into the sorted list.
 // The walk ends when the list holds no unexpanded node (hnswalg.h searchBaseLayerST's stop rule).
+//
+// PACKED layout (round 5, annlite_graph_pack / annlite_graph_search_packed).  With the plain layout an expansion is TWO dependent
+// random round trips -- the node's link list, then the 16-byte code rows of its unseen neighbours, each of which costs a
+// 128-byte line: 385 MB of HBM traffic per 5M-row launch against 62 MB algorithmic, L2 hit rate 12 % -- and one wave per SIMD
+// hides none of it.  A packed node record holds the neighbours' CODE ROWS behind its link list,
+//     [L x M code bytes of neighbour 0 .. L-1][L x u32 link ids][u32 count][pad to 16 B]      (656 B at L = 32, M = 16)
+// so an expansion is ONE contiguous read (lane j: neighbour j's 16 code bytes + its id), and the record of the best
+// still-unexpanded node is PREFETCHED into registers while the current node's neighbours are evaluated: if the next pick is
+// that node -- it is, once the walk has reached its plateau -- no round trip is exposed at all.  The order of the walk and
+// the arithmetic are unchanged: candidate lists are bit-equal to the plain kernel's (tests/test_graph_packed.py).
 #include "scan_common.h"
 
 namespace annlite {
@@ -66,8 +76,9 @@ __device__ __forceinline__ void beam_insert(BeamList<E> &L, uint32_t chi, uint32
     }
 }
 
-template <int M, int E>
+template <int M, int E, bool PACKED>
 __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *__restrict__ links, int links_per_node,
+                                                               const uint8_t *__restrict__ packed, int64_t rec_stride,
                                                                const uint32_t *__restrict__ seeds, int n_seeds,
                                                                const uint8_t *__restrict__ codes, int64_t N,
                                                                const uint32_t *__restrict__ valid,
@@ -76,7 +87,7 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
                                                                float *__restrict__ out_dist,
                                                                unsigned long long *__restrict__ stats) {
     constexpr int CW = M / 4;
-    unsigned int n_expand = 0, n_eval = 0;  // (ANNLITE_DEBUG_COUNTERS: link lists read, rows evaluated)
+    unsigned int n_expand = 0, n_eval = 0, n_hit = 0;  // (ANNLITE_DEBUG_COUNTERS: link lists read, rows evaluated, prefetched records used)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -106,15 +117,21 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
         }
         return true;
     };
-    auto pq_lookup = [&](uint32_t node) -> float {  // hnswlib::PQLookup: ascending-m fp32 adds
+    auto load_row = [&](uint32_t node, uint32_t (&c)[CW]) {
         const uint32_t *p = (const uint32_t *)(codes + (int64_t)node * M);
-        uint32_t c[CW];
 #pragma unroll
         for (int i = 0; i < CW; ++i) c[i] = p[i];
+    };
+    auto pq_sum = [&](const uint32_t (&c)[CW]) -> float {  // hnswlib::PQLookup: ascending-m fp32 adds
         float d = 0.f;
 #pragma unroll
         for (int m = 0; m < M; ++m) d += s_lut[m * Ks + ((c[m / 4] >> (8 * (m % 4))) & 0xffu)];
         return d;
+    };
+    auto pq_lookup = [&](uint32_t node) -> float {
+        uint32_t c[CW];
+        load_row(node, c);
+        return pq_sum(c);
     };
     auto is_valid = [&](uint32_t node) -> bool { return !valid || ((valid[node >> 5] >> (node & 31)) & 1u); };
 
@@ -157,20 +174,33 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
     // ---- seeds: the top of the hierarchy, scanned flat -------------------------------------------------
     // (seeds are distinct: no visited check while scanning them; only the ones that made the list are recorded --
     // recording all of them would fill the hash table before the walk starts)
-    for (int s0 = 0; s0 < n_seeds; s0 += 64) {
-        const bool have = s0 + lane < n_seeds;
-        const uint32_t node = have ? seeds[s0 + lane] : 0u;
-        const bool mine = have && (int64_t)node < N;
-        const float d = mine ? pq_lookup(node) : 0.f;
-        n_eval += (unsigned int)__popcll(__ballot(mine));
-        offer(mine, node, d);
+    // (the round's code rows are requested one round ahead, its seed ids two: the rounds' two dependent round trips overlap
+    // the previous rounds' insertions; the ORDER of the offers is unchanged)
+    {
+        auto seed_at = [&](int s0) -> uint32_t { return s0 + lane < n_seeds ? seeds[s0 + lane] : 0xffffffffu; };
+        uint32_t node_cur = seed_at(0), node_nxt = seed_at(64);
+        uint32_t c_cur[CW];
+        load_row(((int64_t)node_cur < N) ? node_cur : 0u, c_cur);
+        for (int s0 = 0; s0 < n_seeds; s0 += 64) {
+            const uint32_t node = node_cur;
+            const bool mine = s0 + lane < n_seeds && (int64_t)node < N;
+            uint32_t c[CW];
+#pragma unroll
+            for (int i = 0; i < CW; ++i) c[i] = c_cur[i];
+            node_cur = node_nxt;
+            if (s0 + 64 < n_seeds) load_row(((int64_t)node_cur < N) ? node_cur : 0u, c_cur);
+            node_nxt = seed_at(s0 + 128);
+            const float d = mine ? pq_sum(c) : 0.f;
+            n_eval += (unsigned int)__popcll(__ballot(mine));
+            offer(mine, node, d);
+        }
     }
 #pragma unroll
     for (int e = 0; e < E; ++e)
         if (L.lo[e] != kIdNone) visit(L.lo[e]);
 
     // ---- walk ------------------------------------------------------------------------------------------
-    for (;;) {
+    auto pick_next = [&](uint32_t &node, bool mark) -> bool {  // best unexpanded entry of the list (wave-uniform)
         int pick = -1;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -179,27 +209,86 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
                 if (m) pick = e * 64 + __builtin_ctzll(m);
             }
         }
-        if (pick < 0) break;
-        uint32_t node = 0;
+        if (pick < 0) return false;
+        node = 0;
 #pragma unroll
         for (int e = 0; e < E; ++e)
             if (pick / 64 == e) {
                 node = __builtin_amdgcn_readlane(L.lo[e], pick % 64);
-                if (lane == pick % 64) L.exp[e] = true;
+                if (mark && lane == pick % 64) L.exp[e] = true;
             }
-        const uint32_t *ll = links + (int64_t)node * (links_per_node + 1);
-        const uint32_t cnt = ll[0];
-        ++n_expand;
-        bool mine = false;
-        uint32_t nb = 0;
-        float d = 0.f;
-        for (uint32_t base = 0; base < cnt; base += 64) {  // (links_per_node <= 64 in practice: one round)
-            mine = base + lane < cnt;
-            nb = mine ? ll[1 + base + lane] : 0u;
+        return true;
+    };
+    if constexpr (PACKED) {
+        // record of a node: lane j < L holds neighbour j's code row and id; the count is a wave-uniform load
+        const int Lc = links_per_node;  // (<= 64: one lane per neighbour)
+        // (slots beyond the node's count hold the id 0xffffffff, which fails the `nb < N` test like any id beyond the table:
+        // the walk never reads the count -- a wave-uniform, i.e. SCALAR load would share its counter with the LDS traffic of
+        // visit() and stall it for a full memory round trip whenever a prefetch is in flight)
+        auto load_rec = [&](uint32_t node, uint32_t (&c)[CW], uint32_t &nb) {
+            const uint8_t *r = packed + (int64_t)node * rec_stride;
+            const int j = lane < Lc ? lane : 0;
+            const uint32_t *pc = (const uint32_t *)(r + (int64_t)j * M);
+#pragma unroll
+            for (int i = 0; i < CW; ++i) c[i] = pc[i];
+            nb = ((const uint32_t *)(r + (int64_t)Lc * M))[j];
+        };
+        uint32_t pf_c[CW], pf_nb = 0, pf_node = kEmpty;  // the prefetched record (pf_node == kEmpty: none)
+#pragma unroll
+        for (int i = 0; i < CW; ++i) pf_c[i] = 0;
+        for (;;) {
+            uint32_t node = 0;
+            if (!pick_next(node, true)) break;
+            uint32_t c[CW], nb;
+            if (pf_node == node) {
+                ++n_hit;
+#pragma unroll
+                for (int i = 0; i < CW; ++i) c[i] = pf_c[i];
+                nb = pf_nb;
+            } else {
+                load_rec(node, c, nb);
+            }
+            // The current record must have ARRIVED before the prefetch below is issued: the memory counter is in order and the
+            // compiler, merging the paths with and without a prefetch, otherwise waits for everything outstanding -- the
+            // prefetch included -- at the first use of the current record.  (An empty asm that reads the registers.)
+            asm volatile("" : "+v"(nb));
+#pragma unroll
+            for (int i = 0; i < CW; ++i) asm volatile("" : "+v"(c[i]));
+            // request the record of the best node that is unexpanded NOW: the next pick unless one of this node's neighbours
+            // turns out better
+            pf_node = kEmpty;
+            {
+                uint32_t nxt = 0;
+                if (pick_next(nxt, false)) {
+                    pf_node = nxt;
+                    load_rec(nxt, pf_c, pf_nb);
+                }
+            }
+            ++n_expand;
+            bool mine = lane < Lc;
             mine = mine && (int64_t)nb < N && visit(nb);
             n_eval += (unsigned int)__popcll(__ballot(mine));
-            d = mine ? pq_lookup(nb) : 0.f;
+            const float d = mine ? pq_sum(c) : 0.f;
             offer(mine, nb, d);
+        }
+    } else {
+        for (;;) {
+            uint32_t node = 0;
+            if (!pick_next(node, true)) break;
+            const uint32_t *ll = links + (int64_t)node * (links_per_node + 1);
+            const uint32_t cnt = ll[0];
+            ++n_expand;
+            bool mine = false;
+            uint32_t nb = 0;
+            float d = 0.f;
+            for (uint32_t base = 0; base < cnt; base += 64) {  // (links_per_node <= 64 in practice: one round)
+                mine = base + lane < cnt;
+                nb = mine ? ll[1 + base + lane] : 0u;
+                mine = mine && (int64_t)nb < N && visit(nb);
+                n_eval += (unsigned int)__popcll(__ballot(mine));
+                d = mine ? pq_lookup(nb) : 0.f;
+                offer(mine, nb, d);
+            }
         }
     }
 
@@ -217,6 +306,7 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
     if (stats && lane == 0) {
         atomicAdd(stats + 0, (unsigned long long)n_expand);
         atomicAdd(stats + 1, (unsigned long long)n_eval);
+        atomicAdd(stats + 2, (unsigned long long)n_hit);
     }
 }
 
@@ -224,23 +314,50 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
 
 using namespace annlite;
 
-template <int M, int E>
-static int launch_beam(const uint32_t *links, int lpn, const uint32_t *seeds, int n_seeds, const uint8_t *codes, int64_t N,
-                       const uint32_t *valid, const float *lut, int64_t B, int64_t Ks, int ef, int hash_bits,
+// Packed node records for graph_beam_search_kernel<.., PACKED>: [L x M code bytes][L x u32 ids][u32 count][pad to 16 B].
+// One thread per (node, neighbour slot): copies the neighbour's code row (slots beyond the count / ids beyond N: zeros).
+__global__ __launch_bounds__(256) void graph_pack_kernel(const uint32_t *__restrict__ links, int L, const uint8_t *__restrict__ codes,
+                                                        int64_t N, int M, uint8_t *__restrict__ out, int64_t stride) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * L) return;
+    const int64_t node = t / L;
+    const int j = (int)(t - node * L);
+    const uint32_t *ll = links + node * (L + 1);
+    const uint32_t cnt = ll[0];
+    const uint32_t nb = (uint32_t)j < cnt ? ll[1 + j] : kEmpty;  // (an unused slot: an id no table holds)
+    const bool ok = (uint32_t)j < cnt && (int64_t)nb < N;
+    uint8_t *r = out + node * stride;
+    uint32_t *dst = (uint32_t *)(r + (int64_t)j * M);
+    const uint32_t *src = (const uint32_t *)(codes + (int64_t)(ok ? nb : 0u) * M);
+    for (int i = 0; i < M / 4; ++i) dst[i] = ok ? src[i] : 0u;
+    uint32_t *hdr = (uint32_t *)(r + (int64_t)L * M);
+    hdr[j] = nb;
+    if (j == 0) {
+        hdr[L] = cnt;
+        for (int64_t b = (int64_t)L * M + 4 * L + 4; b + 4 <= stride; b += 4) *(uint32_t *)(r + b) = 0u;
+    }
+}
+
+static int64_t graph_record_stride(int64_t L, int64_t M) { return ((L * M + 4 * L + 4 + 15) / 16) * 16; }
+
+template <int M, int E, bool PACKED>
+static int launch_beam(const uint32_t *links, int lpn, const uint8_t *packed, const uint32_t *seeds, int n_seeds, const uint8_t *codes,
+                       int64_t N, const uint32_t *valid, const float *lut, int64_t B, int64_t Ks, int ef, int hash_bits,
                        int64_t *out_ids, float *out_dist, unsigned long long *stats, hipStream_t st) {
     const size_t per_wave = (size_t)M * Ks * 4 + ((size_t)4 << hash_bits);
     int wpb = (int)((size_t)160 * 1024 / per_wave);
     if (wpb > 4) wpb = 4;
     ANNLITE_REQUIRE(wpb >= 1, "M * Ks tables do not fit the LDS");
     const size_t lds = wpb * per_wave;
-    auto fn = graph_beam_search_kernel<M, E>;
+    auto fn = graph_beam_search_kernel<M, E, PACKED>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(fn, dim3((unsigned)((B + wpb - 1) / wpb)), dim3(wpb * 64), lds, st, links, lpn, seeds, n_seeds, codes, N,
-                       valid, lut, (int)B, (int)Ks, ef, hash_bits, out_ids, out_dist, stats);
+    hipLaunchKernelGGL(fn, dim3((unsigned)((B + wpb - 1) / wpb)), dim3(wpb * 64), lds, st, links, lpn, packed,
+                       graph_record_stride(lpn, M), seeds, n_seeds, codes, N, valid, lut, (int)B, (int)Ks, ef, hash_bits, out_ids,
+                       out_dist, stats);
     return launch_status("graph_beam_search_kernel");
 }
 
-static unsigned long long *g_graph_stats = nullptr;  // debug only (ANNLITE_DEBUG_COUNTERS): leaked 16-byte device buffer
+static unsigned long long *g_graph_stats = nullptr;  // debug only (ANNLITE_DEBUG_COUNTERS): leaked 32-byte device buffer
 
 extern "C" int annlite_graph_search_stats(uint64_t *out2) {
     ANNLITE_REQUIRE(out2 != nullptr, "out2 is NULL");
@@ -253,16 +370,16 @@ extern "C" int annlite_graph_search_stats(uint64_t *out2) {
     return ANNLITE_OK;
 }
 
-extern "C" int annlite_graph_search(const uint32_t *links_dev, int links_per_node, const uint32_t *seeds_dev, int64_t n_seeds,
-                                    const void *codes_dev, int64_t N, int64_t M, int64_t Ks,
-                                    const uint32_t *valid_bits_dev, const float *lut_bmk_dev, int64_t B, int ef,
-                                    int64_t *out_ids_dev, float *out_dist_dev, void *stream) {
+static int graph_search_impl(const uint32_t *links_dev, const uint8_t *packed_dev, int links_per_node, const uint32_t *seeds_dev,
+                             int64_t n_seeds, const void *codes_dev, int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev,
+                             const float *lut_bmk_dev, int64_t B, int ef, int64_t *out_ids_dev, float *out_dist_dev, void *stream) {
     ANNLITE_REQUIRE(B >= 0 && N >= 0 && ef >= 1 && ef <= 256, "bad B=%lld N=%lld ef=%d (ef <= 256)", (long long)B,
                     (long long)N, ef);
     ANNLITE_REQUIRE(Ks >= 1 && Ks <= 256 && (M == 8 || M == 16 || M == 32), "graph search supports M in {8,16,32}, Ks <= 256");
     ANNLITE_REQUIRE(links_per_node >= 1 && n_seeds >= 1 && N < (1ll << 32) - 1, "bad graph");
+    ANNLITE_REQUIRE(!packed_dev || links_per_node <= 64, "packed records hold at most 64 neighbours (links_per_node = %d)", links_per_node);
     if (B == 0) return ANNLITE_OK;
-    ANNLITE_REQUIRE(links_dev && seeds_dev && codes_dev && lut_bmk_dev && out_ids_dev && out_dist_dev, "null device pointer");
+    ANNLITE_REQUIRE((links_dev || packed_dev) && seeds_dev && codes_dev && lut_bmk_dev && out_ids_dev && out_dist_dev, "null device pointer");
     hipStream_t st = (hipStream_t)stream;
     // 4096 entries up to ef = 128 (a walk records 2-3k nodes: 5M rows, ef 128 gave the same recall as 8192 entries at
     // 1.5x the speed -- 5 instead of 3 waves per CU), 8192 beyond; a full table only costs re-evaluations (see visit)
@@ -271,19 +388,69 @@ extern "C" int annlite_graph_search(const uint32_t *links_dev, int links_per_nod
     const uint8_t *codes = (const uint8_t *)codes_dev;
     unsigned long long *stats = nullptr;
     if (getenv("ANNLITE_DEBUG_COUNTERS")) {
-        if (!g_graph_stats) ANNLITE_HIP_TRY(hipMalloc((void **)&g_graph_stats, 16));
-        ANNLITE_HIP_TRY(hipMemsetAsync(g_graph_stats, 0, 16, st));
+        if (!g_graph_stats) ANNLITE_HIP_TRY(hipMalloc((void **)&g_graph_stats, 32));
+        ANNLITE_HIP_TRY(hipMemsetAsync(g_graph_stats, 0, 32, st));
         stats = g_graph_stats;
     }
-#define ANNLITE_BEAM(MM)                                                                                                \
-    (ef <= 64 ? launch_beam<MM, 1>(links_dev, links_per_node, seeds_dev, (int)n_seeds, codes, N, valid_bits_dev, lut_bmk_dev, \
-                                   B, Ks, ef, hash_bits, out_ids_dev, out_dist_dev, stats, st)                        \
-     : ef <= 128 ? launch_beam<MM, 2>(links_dev, links_per_node, seeds_dev, (int)n_seeds, codes, N, valid_bits_dev,     \
-                                      lut_bmk_dev, B, Ks, ef, hash_bits, out_ids_dev, out_dist_dev, stats, st)        \
-                 : launch_beam<MM, 4>(links_dev, links_per_node, seeds_dev, (int)n_seeds, codes, N, valid_bits_dev,     \
-                                      lut_bmk_dev, B, Ks, ef, hash_bits, out_ids_dev, out_dist_dev, stats, st))
-    if (M == 8) return ANNLITE_BEAM(8);
-    if (M == 16) return ANNLITE_BEAM(16);
-    return ANNLITE_BEAM(32);
+#define ANNLITE_BEAM_ARGS links_dev, links_per_node, packed_dev, seeds_dev, (int)n_seeds, codes, N, valid_bits_dev, lut_bmk_dev, B, Ks, ef, \
+                          hash_bits, out_ids_dev, out_dist_dev, stats, st
+#define ANNLITE_BEAM(MM, PK) \
+    (ef <= 64 ? launch_beam<MM, 1, PK>(ANNLITE_BEAM_ARGS) : ef <= 128 ? launch_beam<MM, 2, PK>(ANNLITE_BEAM_ARGS) : launch_beam<MM, 4, PK>(ANNLITE_BEAM_ARGS))
+    if (packed_dev) {
+        if (M == 8) return ANNLITE_BEAM(8, true);
+        if (M == 16) return ANNLITE_BEAM(16, true);
+        return ANNLITE_BEAM(32, true);
+    }
+    if (M == 8) return ANNLITE_BEAM(8, false);
+    if (M == 16) return ANNLITE_BEAM(16, false);
+    return ANNLITE_BEAM(32, false);
 #undef ANNLITE_BEAM
+#undef ANNLITE_BEAM_ARGS
+}
+
+extern "C" int annlite_graph_search_stats_ex(uint64_t *out4) {  // [0] expansions, [1] rows evaluated, [2] prefetched records used, [3] 0
+    ANNLITE_REQUIRE(out4 != nullptr, "out4 is NULL");
+    if (!g_graph_stats) {
+        set_error("no counters recorded (set ANNLITE_DEBUG_COUNTERS=1 before the walk)");
+        return ANNLITE_ERR_INVALID;
+    }
+    ANNLITE_HIP_TRY(hipDeviceSynchronize());
+    ANNLITE_HIP_TRY(hipMemcpy(out4, g_graph_stats, 32, hipMemcpyDeviceToHost));
+    return ANNLITE_OK;
+}
+
+extern "C" int annlite_graph_search(const uint32_t *links_dev, int links_per_node, const uint32_t *seeds_dev, int64_t n_seeds,
+                                    const void *codes_dev, int64_t N, int64_t M, int64_t Ks,
+                                    const uint32_t *valid_bits_dev, const float *lut_bmk_dev, int64_t B, int ef,
+                                    int64_t *out_ids_dev, float *out_dist_dev, void *stream) {
+    return graph_search_impl(links_dev, nullptr, links_per_node, seeds_dev, n_seeds, codes_dev, N, M, Ks, valid_bits_dev, lut_bmk_dev,
+                             B, ef, out_ids_dev, out_dist_dev, stream);
+}
+
+extern "C" int annlite_graph_record_bytes(int links_per_node, int64_t M, int64_t *bytes) {
+    ANNLITE_REQUIRE(bytes != nullptr && links_per_node >= 1 && links_per_node <= 64 && (M == 8 || M == 16 || M == 32),
+                    "packed records: links_per_node in [1, 64], M in {8,16,32}");
+    *bytes = graph_record_stride(links_per_node, M);
+    return ANNLITE_OK;
+}
+
+extern "C" int annlite_graph_pack(const uint32_t *links_dev, int links_per_node, const void *codes_dev, int64_t N, int64_t M,
+                                  void *packed_dev, void *stream) {
+    ANNLITE_REQUIRE(N >= 0 && links_per_node >= 1 && links_per_node <= 64 && (M == 8 || M == 16 || M == 32),
+                    "packed records: links_per_node in [1, 64], M in {8,16,32}");
+    if (N == 0) return ANNLITE_OK;
+    ANNLITE_REQUIRE(links_dev && codes_dev && packed_dev, "null device pointer");
+    const int64_t total = N * links_per_node;
+    hipLaunchKernelGGL(graph_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, links_dev,
+                       links_per_node, (const uint8_t *)codes_dev, N, (int)M, (uint8_t *)packed_dev, graph_record_stride(links_per_node, M));
+    return launch_status("graph_pack_kernel");
+}
+
+extern "C" int annlite_graph_search_packed(const void *packed_dev, int links_per_node, const uint32_t *seeds_dev, int64_t n_seeds,
+                                           const void *codes_dev, int64_t N, int64_t M, int64_t Ks,
+                                           const uint32_t *valid_bits_dev, const float *lut_bmk_dev, int64_t B, int ef,
+                                           int64_t *out_ids_dev, float *out_dist_dev, void *stream) {
+    ANNLITE_REQUIRE(packed_dev != nullptr || B == 0, "packed_dev is NULL");
+    return graph_search_impl(nullptr, (const uint8_t *)packed_dev, links_per_node, seeds_dev, n_seeds, codes_dev, N, M, Ks,
+                             valid_bits_dev, lut_bmk_dev, B, ef, out_ids_dev, out_dist_dev, stream);
 }

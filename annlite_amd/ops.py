@@ -119,6 +119,35 @@ def graph_search(links: torch.Tensor, seeds: torch.Tensor, codes: torch.Tensor, 
     return out_i, out_d
 
 
+def graph_pack(links: torch.Tensor, codes: torch.Tensor, n_rows: Optional[int] = None) -> torch.Tensor:
+    """Packed node records (``annlite_graph_pack``): u8 [N, record_bytes] = every node's neighbours' code rows + its link
+    list, from the exported lists ``links`` i32 [N, L+1] and the PLAIN ``codes`` u8 [N, M]."""
+    import ctypes
+
+    N = codes.shape[0] if n_rows is None else n_rows
+    L, M = links.shape[1] - 1, codes.shape[1]
+    nb = ctypes.c_int64(0)
+    check(lib().annlite_graph_record_bytes(L, M, ctypes.byref(nb)), 'graph_record_bytes')
+    out = torch.empty((max(N, 1), int(nb.value)), dtype=torch.uint8, device=codes.device)
+    check(lib().annlite_graph_pack(links.data_ptr(), L, codes.data_ptr(), N, M, out.data_ptr(), stream_ptr()), 'graph_pack')
+    return out
+
+
+def graph_search_packed(packed: torch.Tensor, links_per_node: int, seeds: torch.Tensor, codes: torch.Tensor, lut_bmk: torch.Tensor,
+                        ef: int, valid_bits: Optional[torch.Tensor] = None, n_rows: Optional[int] = None
+                        ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``graph_search`` over packed node records (``annlite_graph_search_packed``): one contiguous read per expansion, the
+    next record prefetched; candidate lists bit-equal to ``graph_search``'s."""
+    B, M, Ks = lut_bmk.shape
+    N = codes.shape[0] if n_rows is None else n_rows
+    out_i = torch.empty((B, ef), dtype=torch.int64, device=codes.device)
+    out_d = torch.empty((B, ef), dtype=torch.float32, device=codes.device)
+    check(lib().annlite_graph_search_packed(packed.data_ptr(), int(links_per_node), seeds.data_ptr(), seeds.numel(), codes.data_ptr(),
+                                            N, M, Ks, _ptr(valid_bits), lut_bmk.data_ptr(), B, int(ef), out_i.data_ptr(),
+                                            out_d.data_ptr(), stream_ptr()), 'graph_search_packed')
+    return out_i, out_d
+
+
 class ScanWorkspace:
     """Re-usable device scratch for the scan (avoids an allocation per search call).  One buffer PER STREAM:
     batches issued on different streams run concurrently (the next batch's kernels fill the CUs the previous

@@ -711,7 +711,7 @@ def main():
                        'adc_scan_qfilter64_kernel' if M == 64 else 'adc_scan_qfilter_kernel')
         # measured HBM traffic: a committed PMC pass of the same kernel / shape (bench.py cannot run rocprof on itself).  An entry
         # measured on ANOTHER revision of the kernel (the library's ANNLITE_KERNEL_REV for it has moved on since) is refused, loudly
-        t_key = f'{kernel_name}:{n_local}x{M}x{B}' + ('' if k <= 16 else f':k{k}')
+        t_key = f'{kernel_name}:{n_local}x{M}x{B}' + ('' if k <= 16 else f':k{k}') + ('' if args.data == 'lowrank' else f':{args.data}')
         t_ent = traffic_table.get(t_key, {})
         traffic = t_ent.get('hbm_bytes_per_launch')
         traffic_note = None if traffic is not None else f'no PMC pass kept for {t_key}'

@@ -150,10 +150,26 @@ ANNLITE_API int annlite_graph_search(const uint32_t *links_dev, int links_per_no
                          int64_t n_seeds, const void *codes_dev, int64_t N, int64_t M, int64_t Ks,
                          const uint32_t *valid_bits_dev, const float *lut_bmk_dev, int64_t B, int ef,
                          int64_t *out_ids_dev, float *out_dist_dev, void *stream);
+/* The same walk over PACKED node records (round 5): a record holds the node's neighbours' CODE ROWS behind its link list --
+ * [L x M code bytes][L x u32 ids][u32 count][pad to 16 B], annlite_graph_record_bytes() per node (656 B at L = 32, M = 16) --
+ * so one expansion is ONE contiguous read instead of the link list followed by L random 16-byte rows (a 128-byte line
+ * each), and the record of the next node is prefetched while the current one's neighbours are evaluated.  Same walk order,
+ * same hnswlib::PQLookup arithmetic (space_pq.h:15-37, hnswalg.h:243-329): candidate lists bit-equal to annlite_graph_search's.
+ * annlite_graph_pack builds the records from the exported lists and the PLAIN code table (rebuild after inserts; deletes
+ * need none: deleted rows keep routing the walk, as in hnswlib).  links_per_node <= 64; codes_dev is still read for the seeds. */
+ANNLITE_API int annlite_graph_record_bytes(int links_per_node, int64_t M, int64_t *bytes);
+ANNLITE_API int annlite_graph_pack(const uint32_t *links_dev, int links_per_node, const void *codes_dev, int64_t N, int64_t M,
+                       void *packed_dev, void *stream);
+ANNLITE_API int annlite_graph_search_packed(const void *packed_dev, int links_per_node, const uint32_t *seeds_dev,
+                         int64_t n_seeds, const void *codes_dev, int64_t N, int64_t M, int64_t Ks,
+                         const uint32_t *valid_bits_dev, const float *lut_bmk_dev, int64_t B, int ef,
+                         int64_t *out_ids_dev, float *out_dist_dev, void *stream);
 /* Debug aid: with ANNLITE_DEBUG_COUNTERS=1 the walk counts [0] expansions (link lists read) and [1] rows evaluated
  * (PQLookup sums) over the batch; this copies the two counters of the last walk to the host (the roofline of
  * scripts/bench_hnsw.py: algorithmic bytes = expansions * 4 (links_per_node + 1) + evaluations * M). */
 ANNLITE_API int annlite_graph_search_stats(uint64_t *out2);
+/* ... and [2] the expansions whose record had been prefetched (packed walk), [3] reserved. */
+ANNLITE_API int annlite_graph_search_stats_ex(uint64_t *out4);
 
 /* ------------------------------------------------------------------------------------------------
  * Batched flat ADC scan + top-k: the hot path.

@@ -127,32 +127,70 @@ _, xg = codec.scan_inputs(qd)
 links, seeds = index._export_graph()
 lut = ops.lut_build(xg, codec.codebooks_dev, LUT_L2, LAYOUT_BMK)
 plain = index._plain_table(index._n_rows)
-os.environ['ANNLITE_DEBUG_COUNTERS'] = '1'
-ops.graph_search(links, seeds, plain, lut, a.ef_search, valid_bits=index._valid, n_rows=index._n_rows)
-n_expand, n_eval = _capi.graph_search_stats()
-del os.environ['ANNLITE_DEBUG_COUNTERS']
-kms = []
-for _ in range(max(3, a.steps)):
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    ops.graph_search(links, seeds, plain, lut, a.ef_search, valid_bits=index._valid, n_rows=index._n_rows)
-    e1.record()
-    e1.synchronize()
-    kms.append(e0.elapsed_time(e1))
-kernel_ms = float(np.mean(kms))
 lpn = links.shape[1] - 1
+packed = index._packed_records(links, plain) if index.packed_graph and lpn <= 64 else None
+
+
+def walk_once(use_packed):
+    if use_packed:
+        return ops.graph_search_packed(packed, lpn, seeds, plain, lut, a.ef_search, valid_bits=index._valid, n_rows=index._n_rows)
+    return ops.graph_search(links, seeds, plain, lut, a.ef_search, valid_bits=index._valid, n_rows=index._n_rows)
+
+
+def walk_ms(use_packed):
+    for _ in range(2):
+        walk_once(use_packed)
+    torch.cuda.synchronize()
+    out = []
+    for _ in range(max(3, a.steps)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        walk_once(use_packed)
+        e1.record()
+        e1.synchronize()
+        out.append(e0.elapsed_time(e1))
+    return float(np.mean(out))
+
+
+os.environ['ANNLITE_DEBUG_COUNTERS'] = '1'
+walk_once(packed is not None)
+n_expand, n_eval, n_hit = _capi.graph_search_stats_ex()
+del os.environ['ANNLITE_DEBUG_COUNTERS']
+kernel_ms = walk_ms(packed is not None)
+plain_ms = walk_ms(False) if packed is not None else kernel_ms
+same = None
+if packed is not None:  # the two layouts walk the same graph in the same order: bit-equal candidate lists
+    (i1, d1), (i2, d2) = walk_once(True), walk_once(False)
+    same = bool(torch.equal(i1, i2) and torch.equal(d1.view(torch.int32), d2.view(torch.int32)))
+rec_bytes = int(packed.shape[1]) if packed is not None else None
+# algorithmic bytes: what the WALK needs -- one link list per expansion + M code bytes per evaluated row (+ the seed rows);
+# the packed layout reads a whole record per expansion by design (`bytes_read_by_design`)
 alg_bytes = n_expand * 4.0 * (lpn + 1) + n_eval * float(M) + B * seeds.numel() * float(M)
-# measured HBM traffic of the walk launch: the committed rocprofv3 PMC pass (FETCH_SIZE x 2 + WRITE_SIZE, profiles/traffic.json)
+design_bytes = (n_expand * float(rec_bytes) + B * seeds.numel() * float(M)) if packed is not None else alg_bytes
+# measured HBM traffic of the walk launch: the committed rocprofv3 PMC pass (FETCH_SIZE x 2 + WRITE_SIZE, profiles/traffic.json),
+# refused when it was taken on another revision of the kernel
+traffic = None
+traffic_note = None
 try:
     _tt = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'traffic.json')))
-    traffic = _tt.get(f'graph_beam_search_kernel:{N}x{M}x{B}', {}).get('hbm_bytes_per_launch')
-except Exception:
-    traffic = None
+    ent = _tt.get(f'graph_beam_search_kernel:{N}x{M}x{B}', {})
+    traffic = ent.get('hbm_bytes_per_launch')
+    rev = _capi.kernel_rev('graph_beam_search_kernel')
+    if traffic is not None and ent.get('kernel_rev') != rev:
+        traffic_note = f'STALE: measured on kernel revision {ent.get("kernel_rev")}, the library is at {rev}'
+        print('bench_hnsw.py: profiles/traffic.json ' + traffic_note, file=sys.stderr)
+        traffic = None
+except Exception as ex:  # noqa: BLE001
+    traffic_note = str(ex)
 roofline = {'bound': 'hbm', 'achieved': alg_bytes / (kernel_ms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
-            'frac': alg_bytes / (kernel_ms * 1e-3) / 1e9 / 8000.0, 'traffic': traffic,
-            'kernel': 'graph_beam_search_kernel', 'kernel_ms': kernel_ms,
-            'algorithmic_bytes_per_launch': alg_bytes, 'expansions_per_query': n_expand / B, 'rows_evaluated_per_query': n_eval / B,
-            'note': 'every evaluated row is a random 16-byte read (one 64-byte sector): the walk is latency-bound by design'}
+            'frac': alg_bytes / (kernel_ms * 1e-3) / 1e9 / 8000.0, 'traffic': traffic, 'traffic_note': traffic_note,
+            'kernel': 'graph_beam_search_kernel', 'kernel_rev': _capi.kernel_rev('graph_beam_search_kernel'), 'kernel_ms': kernel_ms,
+            'layout': 'packed node records (neighbours\' code rows inline, next record prefetched)' if packed is not None else 'plain',
+            'plain_layout_kernel_ms': plain_ms, 'packed_equals_plain_bit_exact': same, 'record_bytes': rec_bytes,
+            'prefetched_records_used': (n_hit / max(n_expand, 1)),
+            'algorithmic_bytes_per_launch': alg_bytes, 'bytes_read_by_design': design_bytes,
+            'expansions_per_query': n_expand / B, 'rows_evaluated_per_query': n_eval / B,
+            'note': 'a pointer chase, latency-bound by design: one wave per query, one dependent record read per expansion'}
 
 # ---- CPU baseline: the same graph walked on the host by libannlite_graph.so (C++ restatement of hnswlib's searchKnn /
 # searchBaseLayerST with PQLookup distances), ONE thread = the reference's execution model (knn_query runs single-threaded

@@ -33,6 +33,7 @@ p.add_argument('--ef-search', type=int, default=128)
 p.add_argument('--ef-construction', type=int, default=200)
 p.add_argument('--max-connection', type=int, default=16)
 p.add_argument('--iters', type=int, default=4)
+p.add_argument('--layout', choices=['packed', 'plain'], default='packed', help='node records with the neighbours\' code rows inline (round 5) / link lists + code table')
 a = p.parse_args()
 assert (a.build is None) != (a.walk is None), 'exactly one of --build / --walk'
 dev = torch.device('cuda', 0)
@@ -88,19 +89,31 @@ _, xg = codec.scan_inputs(qd)
 links, seeds = index._export_graph()
 lut = ops.lut_build(xg, codec.codebooks_dev, LUT_L2, LAYOUT_BMK)
 plain = index._plain_table(index._n_rows)
+lpn = links.shape[1] - 1
+packed = index._packed_records(links, plain) if a.layout == 'packed' else None
+
+
+def walk():
+    if packed is not None:
+        return ops.graph_search_packed(packed, lpn, seeds, plain, lut, a.ef_search, valid_bits=index._valid, n_rows=index._n_rows)
+    return ops.graph_search(links, seeds, plain, lut, a.ef_search, valid_bits=index._valid, n_rows=index._n_rows)
+
+
 os.environ['ANNLITE_DEBUG_COUNTERS'] = '1'
-ops.graph_search(links, seeds, plain, lut, a.ef_search, valid_bits=index._valid, n_rows=index._n_rows)
-n_expand, n_eval = _capi.graph_search_stats()
+walk()
+n_expand, n_eval, n_hit = _capi.graph_search_stats_ex()
 del os.environ['ANNLITE_DEBUG_COUNTERS']
 kms = []
 for _ in range(a.iters):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    ops.graph_search(links, seeds, plain, lut, a.ef_search, valid_bits=index._valid, n_rows=index._n_rows)
+    walk()
     e1.record()
     e1.synchronize()
     kms.append(e0.elapsed_time(e1))
 lpn = links.shape[1] - 1
 alg = n_expand * 4.0 * (lpn + 1) + n_eval * float(M) + B * seeds.numel() * float(M)
 print(f'graph walk: {index._n_rows} rows, batch {B}, ef_search {a.ef_search}: kernel ms {np.round(kms, 3).tolist()}; '
-      f'expansions/query {n_expand / B:.1f}, rows evaluated/query {n_eval / B:.1f}, algorithmic bytes/launch {alg:.4g}', flush=True)
+      f'expansions/query {n_expand / B:.1f}, rows evaluated/query {n_eval / B:.1f}, algorithmic bytes/launch {alg:.4g}; layout {a.layout}'
+      + (f', record {packed.shape[1]} B, bytes read by design {n_expand * float(packed.shape[1]) + B * seeds.numel() * float(M):.4g}, '
+         f'prefetched records used {n_hit / max(n_expand, 1):.3f}' if packed is not None else ''), flush=True)
