@@ -76,7 +76,13 @@ __device__ __forceinline__ void beam_insert(BeamList<E> &L, uint32_t chi, uint32
     }
 }
 
-template <int M, int E, bool PACKED>
+// BATCH (round 5): the neighbours of an expansion that beat the list's worst entry are MERGED into the sorted list in one pass --
+// every list entry counts the candidates below it, every candidate the entries and candidates below it, all move to their
+// final positions through a per-wave LDS scratch -- instead of one full-wave shift per candidate (~110 instructions each, the
+// largest single item of the walk: one wave per SIMD executes them back to back).  The result is the same sorted list --
+// the top of (old list + candidates) -- so the walk is unchanged; BATCH = false keeps the one-at-a-time insertion (the
+// comparison path of tests/test_graph_packed.py).
+template <int M, int E, bool PACKED, bool BATCH>
 __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *__restrict__ links, int links_per_node,
                                                                const uint8_t *__restrict__ packed, int64_t rec_stride,
                                                                const uint32_t *__restrict__ seeds, int n_seeds,
@@ -94,9 +100,10 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
     const int b = blockIdx.x * (blockDim.x >> 6) + wave;  // 1..4 waves per workgroup, as many as the LDS holds
     if (b >= B) return;  // (whole waves leave; no block-wide barrier below)
     const uint32_t hash_n = 1u << hash_bits;
-    const size_t per_wave = (size_t)M * Ks * 4 + (size_t)hash_n * 4;  // (same formula as launch_beam)
+    const size_t per_wave = (size_t)M * Ks * 4 + (size_t)hash_n * 4 + (BATCH ? (size_t)E * 64 * 12 : 0);  // (same formula as launch_beam)
     float *s_lut = (float *)(smem + wave * per_wave);
     uint32_t *s_hash = (uint32_t *)(smem + wave * per_wave + (size_t)M * Ks * 4);
+    uint32_t *s_mrg = s_hash + hash_n;  // BATCH: the merge's scratch, u32 [3][64 E]: keys hi, ids, expanded flags
     {
         const f32x4 *src = (const f32x4 *)(lut_bmk + (int64_t)b * M * Ks);
         for (int i = lane; i < M * Ks / 4; i += 64) ((f32x4 *)s_lut)[i] = src[i];
@@ -159,15 +166,77 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
         worst(whi, wlo);
         const uint32_t khi = f32_to_ordered(d);
         unsigned long long pm = __ballot(mine && key_less(khi, node, whi, wlo));
-        while (pm) {
-            const int src = __builtin_ctzll(pm);
-            pm &= pm - 1;
-            const uint32_t chi = __builtin_amdgcn_readlane(khi, src), clo = __builtin_amdgcn_readlane(node, src);
-            worst(whi, wlo);
-            bool dup = false;
+        if constexpr (!BATCH) {
+            while (pm) {
+                const int src = __builtin_ctzll(pm);
+                pm &= pm - 1;
+                const uint32_t chi = __builtin_amdgcn_readlane(khi, src), clo = __builtin_amdgcn_readlane(node, src);
+                worst(whi, wlo);
+                bool dup = false;
 #pragma unroll
-            for (int e = 0; e < E; ++e) dup = dup || __ballot(L.lo[e] == clo && L.hi[e] == chi) != 0ull;
-            if (!dup && key_less(chi, clo, whi, wlo)) beam_insert<E>(L, chi, clo, lane);
+                for (int e = 0; e < E; ++e) dup = dup || __ballot(L.lo[e] == clo && L.hi[e] == chi) != 0ull;
+                if (!dup && key_less(chi, clo, whi, wlo)) beam_insert<E>(L, chi, clo, lane);
+            }
+        } else {
+            if (!pm) return;
+            // One pass over the candidates (wave-uniform: their keys are broadcast): a list entry counts the candidates below
+            // it, a candidate lane the list entries and the other candidates below its key.  A candidate that is already in the
+            // list, or equals an earlier candidate (both only when the visited table is full: see visit), is dropped --
+            // what the one-at-a-time insertion's duplicate check does.
+            int shift[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) shift[e] = 0;
+            int mypos = 0;
+            bool in = ((pm >> lane) & 1ull) != 0;
+            unsigned long long rem = pm;
+            while (rem) {
+                const int src = __builtin_ctzll(rem);
+                rem &= rem - 1;
+                const uint32_t chi = __builtin_amdgcn_readlane(khi, src), clo = __builtin_amdgcn_readlane(node, src);
+                bool dup = false;
+#pragma unroll
+                for (int e = 0; e < E; ++e) dup = dup || __ballot(L.lo[e] == clo && L.hi[e] == chi) != 0ull;
+                if (dup) {
+                    if (lane == src) in = false;
+                    continue;
+                }
+                const unsigned long long same = __ballot(in && lane > src && khi == chi && node == clo) & rem;
+                if (same) {
+                    if ((same >> lane) & 1ull) in = false;
+                    rem &= ~same;
+                }
+                int below = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const bool lt = key_less(L.hi[e], L.lo[e], chi, clo);  // entry < candidate (never equal: see above)
+                    below += __popcll(__ballot(lt));
+                    shift[e] += lt ? 0 : 1;
+                }
+                if (lane == src) mypos += below;
+                else if (in && key_less(chi, clo, khi, node)) mypos += 1;
+            }
+            // every element of (list + kept candidates) now knows its rank in the union: the first 64 E go back into the list
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int np = e * 64 + lane + shift[e];
+                if (np < 64 * E) {
+                    s_mrg[np] = L.hi[e];
+                    s_mrg[64 * E + np] = L.lo[e];
+                    s_mrg[128 * E + np] = L.exp[e] ? 1u : 0u;
+                }
+            }
+            if (in && mypos < 64 * E) {
+                s_mrg[mypos] = khi;
+                s_mrg[64 * E + mypos] = node;
+                s_mrg[128 * E + mypos] = 0u;
+            }
+            // (one wave: its LDS writes are visible to its own later reads in program order)
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                L.hi[e] = s_mrg[e * 64 + lane];
+                L.lo[e] = s_mrg[64 * E + e * 64 + lane];
+                L.exp[e] = s_mrg[128 * E + e * 64 + lane] != 0u;
+            }
         }
     };
 
@@ -200,23 +269,31 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
         if (L.lo[e] != kIdNone) visit(L.lo[e]);
 
     // ---- walk ------------------------------------------------------------------------------------------
-    auto pick_next = [&](uint32_t &node, bool mark) -> bool {  // best unexpanded entry of the list (wave-uniform)
-        int pick = -1;
+    // the best unexpanded entry of the list (marked expanded) and -- `second` -- the next best one, unmarked: the prefetch target
+    auto pick_next = [&](uint32_t &node, uint32_t &second) -> bool {
+        int p0 = -1, p1 = -1;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            if (pick < 0) {
-                const unsigned long long m = __ballot(!L.exp[e] && (e * 64 + lane) < cap);
-                if (m) pick = e * 64 + __builtin_ctzll(m);
+            if (p1 < 0) {
+                unsigned long long m = __ballot(!L.exp[e] && (e * 64 + lane) < cap);
+                if (m && p0 < 0) {
+                    p0 = e * 64 + __builtin_ctzll(m);
+                    m &= m - 1;
+                }
+                if (m && p0 >= 0) p1 = e * 64 + __builtin_ctzll(m);
             }
         }
-        if (pick < 0) return false;
+        if (p0 < 0) return false;
         node = 0;
+        second = kEmpty;
 #pragma unroll
-        for (int e = 0; e < E; ++e)
-            if (pick / 64 == e) {
-                node = __builtin_amdgcn_readlane(L.lo[e], pick % 64);
-                if (mark && lane == pick % 64) L.exp[e] = true;
+        for (int e = 0; e < E; ++e) {
+            if (p0 / 64 == e) {
+                node = __builtin_amdgcn_readlane(L.lo[e], p0 % 64);
+                if (lane == p0 % 64) L.exp[e] = true;
             }
+            if (p1 >= 0 && p1 / 64 == e) second = __builtin_amdgcn_readlane(L.lo[e], p1 % 64);
+        }
         return true;
     };
     if constexpr (PACKED) {
@@ -237,8 +314,8 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
 #pragma unroll
         for (int i = 0; i < CW; ++i) pf_c[i] = 0;
         for (;;) {
-            uint32_t node = 0;
-            if (!pick_next(node, true)) break;
+            uint32_t node = 0, second = kEmpty;
+            if (!pick_next(node, second)) break;
             uint32_t c[CW], nb;
             if (pf_node == node) {
                 ++n_hit;
@@ -256,14 +333,8 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
             for (int i = 0; i < CW; ++i) asm volatile("" : "+v"(c[i]));
             // request the record of the best node that is unexpanded NOW: the next pick unless one of this node's neighbours
             // turns out better
-            pf_node = kEmpty;
-            {
-                uint32_t nxt = 0;
-                if (pick_next(nxt, false)) {
-                    pf_node = nxt;
-                    load_rec(nxt, pf_c, pf_nb);
-                }
-            }
+            pf_node = second;
+            if (second != kEmpty) load_rec(second, pf_c, pf_nb);
             ++n_expand;
             bool mine = lane < Lc;
             mine = mine && (int64_t)nb < N && visit(nb);
@@ -273,8 +344,8 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
         }
     } else {
         for (;;) {
-            uint32_t node = 0;
-            if (!pick_next(node, true)) break;
+            uint32_t node = 0, second = kEmpty;
+            if (!pick_next(node, second)) break;
             const uint32_t *ll = links + (int64_t)node * (links_per_node + 1);
             const uint32_t cnt = ll[0];
             ++n_expand;
@@ -340,16 +411,16 @@ __global__ __launch_bounds__(256) void graph_pack_kernel(const uint32_t *__restr
 
 static int64_t graph_record_stride(int64_t L, int64_t M) { return ((L * M + 4 * L + 4 + 15) / 16) * 16; }
 
-template <int M, int E, bool PACKED>
+template <int M, int E, bool PACKED, bool BATCH>
 static int launch_beam(const uint32_t *links, int lpn, const uint8_t *packed, const uint32_t *seeds, int n_seeds, const uint8_t *codes,
                        int64_t N, const uint32_t *valid, const float *lut, int64_t B, int64_t Ks, int ef, int hash_bits,
                        int64_t *out_ids, float *out_dist, unsigned long long *stats, hipStream_t st) {
-    const size_t per_wave = (size_t)M * Ks * 4 + ((size_t)4 << hash_bits);
+    const size_t per_wave = (size_t)M * Ks * 4 + ((size_t)4 << hash_bits) + (BATCH ? (size_t)E * 64 * 12 : 0);
     int wpb = (int)((size_t)160 * 1024 / per_wave);
     if (wpb > 4) wpb = 4;
     ANNLITE_REQUIRE(wpb >= 1, "M * Ks tables do not fit the LDS");
     const size_t lds = wpb * per_wave;
-    auto fn = graph_beam_search_kernel<M, E, PACKED>;
+    auto fn = graph_beam_search_kernel<M, E, PACKED, BATCH>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(fn, dim3((unsigned)((B + wpb - 1) / wpb)), dim3(wpb * 64), lds, st, links, lpn, packed,
                        graph_record_stride(lpn, M), seeds, n_seeds, codes, N, valid, lut, (int)B, (int)Ks, ef, hash_bits, out_ids,
@@ -394,16 +465,23 @@ static int graph_search_impl(const uint32_t *links_dev, const uint8_t *packed_de
     }
 #define ANNLITE_BEAM_ARGS links_dev, links_per_node, packed_dev, seeds_dev, (int)n_seeds, codes, N, valid_bits_dev, lut_bmk_dev, B, Ks, ef, \
                           hash_bits, out_ids_dev, out_dist_dev, stats, st
-#define ANNLITE_BEAM(MM, PK) \
-    (ef <= 64 ? launch_beam<MM, 1, PK>(ANNLITE_BEAM_ARGS) : ef <= 128 ? launch_beam<MM, 2, PK>(ANNLITE_BEAM_ARGS) : launch_beam<MM, 4, PK>(ANNLITE_BEAM_ARGS))
+#define ANNLITE_BEAM(MM, PK, BT) \
+    (ef <= 64 ? launch_beam<MM, 1, PK, BT>(ANNLITE_BEAM_ARGS) : ef <= 128 ? launch_beam<MM, 2, PK, BT>(ANNLITE_BEAM_ARGS) : launch_beam<MM, 4, PK, BT>(ANNLITE_BEAM_ARGS))
     if (packed_dev) {
-        if (M == 8) return ANNLITE_BEAM(8, true);
-        if (M == 16) return ANNLITE_BEAM(16, true);
-        return ANNLITE_BEAM(32, true);
+        if (M == 8) return ANNLITE_BEAM(8, true, true);
+        if (M == 16) return ANNLITE_BEAM(16, true, true);
+        return ANNLITE_BEAM(32, true, true);
     }
-    if (M == 8) return ANNLITE_BEAM(8, false);
-    if (M == 16) return ANNLITE_BEAM(16, false);
-    return ANNLITE_BEAM(32, false);
+    // ANNLITE_GRAPH_SEQ_INSERT=1 (plain layout): the one-at-a-time list insertion of rounds 2-4 -- the parity tests walk with
+    // both and compare
+    if (getenv("ANNLITE_GRAPH_SEQ_INSERT")) {
+        if (M == 8) return ANNLITE_BEAM(8, false, false);
+        if (M == 16) return ANNLITE_BEAM(16, false, false);
+        return ANNLITE_BEAM(32, false, false);
+    }
+    if (M == 8) return ANNLITE_BEAM(8, false, true);
+    if (M == 16) return ANNLITE_BEAM(16, false, true);
+    return ANNLITE_BEAM(32, false, true);
 #undef ANNLITE_BEAM
 #undef ANNLITE_BEAM_ARGS
 }

@@ -10,6 +10,15 @@ from conftest import has_gpu
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason='needs a GPU')]
 
 
+@pytest.fixture(scope='module')
+def ops():
+    import torch
+    from annlite_amd import ops as _ops
+
+    torch.cuda.set_device(0)
+    return _ops
+
+
 def _random_graph(rs, N, L, full_frac=0.6):
     """links i32 [N, L+1]: a random regular-ish graph (what the walk needs is a graph, not a good one) with ragged counts,
     a few empty lists, ids beyond the table (never followed) and duplicate neighbours"""
@@ -25,8 +34,9 @@ def _random_graph(rs, N, L, full_frac=0.6):
     return links.view(np.int32)
 
 
-@pytest.mark.parametrize('M,L,ef', [(16, 32, 128), (16, 32, 64), (16, 32, 200), (8, 32, 128), (32, 24, 100), (16, 64, 128), (16, 5, 10)])
-def test_packed_walk_bit_equal_to_plain_walk(ops, oracle, M, L, ef):
+@pytest.mark.parametrize('M,L,ef', [(16, 32, 128), (16, 32, 64), (16, 32, 200), (8, 32, 128), (32, 24, 100), (16, 64, 128), (16, 5, 10),
+                                    (16, 32, 33)])
+def test_packed_walk_bit_equal_to_plain_walk(ops, oracle, monkeypatch, M, L, ef):
     import torch
 
     rs = np.random.RandomState(M * 100 + L + ef)
@@ -56,9 +66,15 @@ def test_packed_walk_bit_equal_to_plain_walk(ops, oracle, M, L, ef):
     for vbits in (None, vb):
         pi, pd = ops.graph_search(links_d, seeds_d, codes_d, lut_d, ef, valid_bits=vbits)
         qi, qd = ops.graph_search_packed(packed, L, seeds_d, codes_d, lut_d, ef, valid_bits=vbits)
+        # ... and the plain walk with the one-at-a-time list insertion of rounds 2-4 (the merge insertion builds the same list)
+        monkeypatch.setenv('ANNLITE_GRAPH_SEQ_INSERT', '1')
+        si, sd = ops.graph_search(links_d, seeds_d, codes_d, lut_d, ef, valid_bits=vbits)
+        monkeypatch.delenv('ANNLITE_GRAPH_SEQ_INSERT')
         torch.cuda.synchronize()
         assert np.array_equal(pi.cpu().numpy(), qi.cpu().numpy())
         assert np.array_equal(pd.cpu().numpy().view(np.uint32), qd.cpu().numpy().view(np.uint32))
+        assert np.array_equal(si.cpu().numpy(), qi.cpu().numpy())
+        assert np.array_equal(sd.cpu().numpy().view(np.uint32), qd.cpu().numpy().view(np.uint32))
         ids = qi.cpu().numpy()
         # and the distances are the oracle's PQLookup of those rows
         dd = qd.cpu().numpy()
@@ -67,6 +83,40 @@ def test_packed_walk_bit_equal_to_plain_walk(ops, oracle, M, L, ef):
             assert np.array_equal(dd[b][ok], oracle.adc_gather_c(lut[b], codes, ids[b][ok]))
             if vbits is not None:
                 assert valid[ids[b][ok]].all()
+
+
+def test_a_full_visited_table_changes_nothing_but_the_speed(ops, oracle, monkeypatch):
+    """ANNLITE_GRAPH_HASH_BITS=6: 64 visited slots -- the table is full after the first expansions, nodes are re-evaluated and the
+    list's duplicate check keeps them out (one-at-a-time insertion: per candidate; merge insertion: against the list and against
+    the earlier candidates of the same expansion).  All three walks still agree, and equal the walk with a large table."""
+    import torch
+
+    rs = np.random.RandomState(77)
+    N, B, Ks, M, L, ef = 20_000, 33, 256, 16, 32, 96
+    links = _random_graph(rs, N, L)
+    codes = rs.randint(0, Ks, size=(N, M)).astype(np.uint8)
+    lut = rs.rand(B, M, Ks).astype(np.float32)
+    seeds = rs.choice(N, 300, replace=False).astype(np.int32)
+    links_d, codes_d, lut_d, seeds_d = ops.to_dev(links), ops.to_dev(codes), ops.to_dev(lut), ops.to_dev(seeds)
+    packed = ops.graph_pack(links_d, codes_d)
+    ref_i, ref_d = ops.graph_search(links_d, seeds_d, codes_d, lut_d, ef)
+    torch.cuda.synchronize()
+    monkeypatch.setenv('ANNLITE_GRAPH_HASH_BITS', '6')
+    pi, pd = ops.graph_search(links_d, seeds_d, codes_d, lut_d, ef)
+    qi, qd = ops.graph_search_packed(packed, L, seeds_d, codes_d, lut_d, ef)
+    monkeypatch.setenv('ANNLITE_GRAPH_SEQ_INSERT', '1')
+    si, sd = ops.graph_search(links_d, seeds_d, codes_d, lut_d, ef)
+    torch.cuda.synchronize()
+    for ai, ad in ((pi, pd), (qi, qd)):
+        assert np.array_equal(ai.cpu().numpy(), si.cpu().numpy())
+        assert np.array_equal(ad.cpu().numpy().view(np.uint32), sd.cpu().numpy().view(np.uint32))
+    ids = si.cpu().numpy()
+    for b in range(B):  # no node twice in a list
+        real = ids[b][ids[b] >= 0]
+        assert len(np.unique(real)) == len(real)
+    # a table that never fills records every node once: the same walk unless the full table's re-evaluations changed the order
+    # of ties -- they cannot: a re-evaluated node has the same key
+    assert np.array_equal(ref_i.cpu().numpy(), ids) and np.array_equal(ref_d.cpu().numpy().view(np.uint32), sd.cpu().numpy().view(np.uint32))
 
 
 def test_index_uses_packed_records_and_rebuilds_them_after_inserts(ops, oracle):
