@@ -307,8 +307,9 @@ def graph_search_stats():
 
 def graph_search_stats_ex():
     """(expansions, rows evaluated, prefetched records used) of the last GPU graph walk (ANNLITE_DEBUG_COUNTERS=1)."""
-    out = (ctypes.c_uint64 * 4)()
+    out = (ctypes.c_uint64 * 8)()
     check(lib().annlite_graph_search_stats_ex(out), 'graph_search_stats_ex')
+    graph_search_stats_ex.cycles = {'seed': int(out[3]), 'record': int(out[4]), 'visited': int(out[5]), 'sums': int(out[6]), 'merge': int(out[7])}
     return int(out[0]), int(out[1]), int(out[2])
 
 

@@ -94,6 +94,8 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
                                                                unsigned long long *__restrict__ stats) {
     constexpr int CW = M / 4;
     unsigned int n_expand = 0, n_eval = 0, n_hit = 0;  // (ANNLITE_DEBUG_COUNTERS: link lists read, rows evaluated, prefetched records used)
+    unsigned long long t_seed = 0, t_rec = 0, t_visit = 0, t_sum = 0, t_offer = 0;  // ... and shader cycles by phase (packed walk)
+    auto now = [&]() -> unsigned long long { return stats ? __builtin_readcyclecounter() : 0ull; };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -114,13 +116,23 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
     // true if the node was not seen before (it is recorded now).  A (nearly) full table cannot record any more: the
     // node is then reported as new every time -- evaluated again, never lost -- and `offer` keeps it out of the list
     // if it is already there, so a walk that outgrows the table only gets slower, not worse.
+    // BUCKETS of four entries (round 5): one 16-byte read shows a bucket, the node is looked for in it and, if there is room,
+    // claimed with ONE compare-and-swap.  (One entry per probe: at the end of a 5M-row walk the 4096-entry table holds ~2600
+    // nodes and the slowest of an expansion's 32 lanes needed a dozen dependent LDS round trips.)
     auto visit = [&](uint32_t node) -> bool {
-        uint32_t h = (node * 2654435761u) >> (32 - hash_bits);
-        for (uint32_t probe = 0; probe < 64; ++probe) {
-            const uint32_t old = atomicCAS(s_hash + h, kEmpty, node);
-            if (old == kEmpty) return true;
-            if (old == node) return false;
-            h = (h + 1) & (hash_n - 1);
+        const uint32_t n_buckets = hash_n >> 2;
+        uint32_t bk = ((node * 2654435761u) >> (32 - hash_bits)) >> 2;
+        for (uint32_t probe = 0; probe < 16; ++probe) {
+            const u32x4 v = *(volatile u32x4 *)(s_hash + 4u * bk);
+            if (v.x == node || v.y == node || v.z == node || v.w == node) return false;
+            const int slot = v.x == kEmpty ? 0 : v.y == kEmpty ? 1 : v.z == kEmpty ? 2 : v.w == kEmpty ? 3 : -1;
+            if (slot >= 0) {
+                const uint32_t old = atomicCAS(s_hash + 4u * bk + (uint32_t)slot, kEmpty, node);
+                if (old == kEmpty) return true;
+                if (old == node) return false;
+                continue;  // (another lane of this expansion took the slot: look at the bucket again)
+            }
+            bk = (bk + 1) & (n_buckets - 1);
         }
         return true;
     };
@@ -246,6 +258,7 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
     // (the round's code rows are requested one round ahead, its seed ids two: the rounds' two dependent round trips overlap
     // the previous rounds' insertions; the ORDER of the offers is unchanged)
     {
+        const unsigned long long t_s0 = now();
         auto seed_at = [&](int s0) -> uint32_t { return s0 + lane < n_seeds ? seeds[s0 + lane] : 0xffffffffu; };
         uint32_t node_cur = seed_at(0), node_nxt = seed_at(64);
         uint32_t c_cur[CW];
@@ -263,6 +276,7 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
             n_eval += (unsigned int)__popcll(__ballot(mine));
             offer(mine, node, d);
         }
+        t_seed = now() - t_s0;
     }
 #pragma unroll
     for (int e = 0; e < E; ++e)
@@ -315,6 +329,7 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
         for (int i = 0; i < CW; ++i) pf_c[i] = 0;
         for (;;) {
             uint32_t node = 0, second = kEmpty;
+            const unsigned long long t0 = now();
             if (!pick_next(node, second)) break;
             uint32_t c[CW], nb;
             if (pf_node == node) {
@@ -336,11 +351,19 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
             pf_node = second;
             if (second != kEmpty) load_rec(second, pf_c, pf_nb);
             ++n_expand;
+            const unsigned long long t1 = now();
             bool mine = lane < Lc;
             mine = mine && (int64_t)nb < N && visit(nb);
             n_eval += (unsigned int)__popcll(__ballot(mine));
-            const float d = mine ? pq_sum(c) : 0.f;
+            const unsigned long long t2 = now();
+            float d = mine ? pq_sum(c) : 0.f;
+            if (stats) asm volatile("" : "+v"(d));
+            const unsigned long long t3 = now();
             offer(mine, nb, d);
+            if (stats) {
+                const unsigned long long t4 = now();
+                t_rec += t1 - t0, t_visit += t2 - t1, t_sum += t3 - t2, t_offer += t4 - t3;
+            }
         }
     } else {
         for (;;) {
@@ -378,6 +401,7 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
         atomicAdd(stats + 0, (unsigned long long)n_expand);
         atomicAdd(stats + 1, (unsigned long long)n_eval);
         atomicAdd(stats + 2, (unsigned long long)n_hit);
+        atomicAdd(stats + 3, t_seed), atomicAdd(stats + 4, t_rec), atomicAdd(stats + 5, t_visit), atomicAdd(stats + 6, t_sum), atomicAdd(stats + 7, t_offer);
     }
 }
 
@@ -428,7 +452,7 @@ static int launch_beam(const uint32_t *links, int lpn, const uint8_t *packed, co
     return launch_status("graph_beam_search_kernel");
 }
 
-static unsigned long long *g_graph_stats = nullptr;  // debug only (ANNLITE_DEBUG_COUNTERS): leaked 32-byte device buffer
+static unsigned long long *g_graph_stats = nullptr;  // debug only (ANNLITE_DEBUG_COUNTERS): leaked 64-byte device buffer
 
 extern "C" int annlite_graph_search_stats(uint64_t *out2) {
     ANNLITE_REQUIRE(out2 != nullptr, "out2 is NULL");
@@ -459,8 +483,8 @@ static int graph_search_impl(const uint32_t *links_dev, const uint8_t *packed_de
     const uint8_t *codes = (const uint8_t *)codes_dev;
     unsigned long long *stats = nullptr;
     if (getenv("ANNLITE_DEBUG_COUNTERS")) {
-        if (!g_graph_stats) ANNLITE_HIP_TRY(hipMalloc((void **)&g_graph_stats, 32));
-        ANNLITE_HIP_TRY(hipMemsetAsync(g_graph_stats, 0, 32, st));
+        if (!g_graph_stats) ANNLITE_HIP_TRY(hipMalloc((void **)&g_graph_stats, 64));
+        ANNLITE_HIP_TRY(hipMemsetAsync(g_graph_stats, 0, 64, st));
         stats = g_graph_stats;
     }
 #define ANNLITE_BEAM_ARGS links_dev, links_per_node, packed_dev, seeds_dev, (int)n_seeds, codes, N, valid_bits_dev, lut_bmk_dev, B, Ks, ef, \
@@ -486,14 +510,16 @@ static int graph_search_impl(const uint32_t *links_dev, const uint8_t *packed_de
 #undef ANNLITE_BEAM_ARGS
 }
 
-extern "C" int annlite_graph_search_stats_ex(uint64_t *out4) {  // [0] expansions, [1] rows evaluated, [2] prefetched records used, [3] 0
-    ANNLITE_REQUIRE(out4 != nullptr, "out4 is NULL");
+// [0] expansions, [1] rows evaluated, [2] prefetched records used; shader cycles summed over the queries' waves: [3] seed phase, packed
+// walk: [4] pick + wait for the record, [5] visited table, [6] PQLookup sums, [7] list merge
+extern "C" int annlite_graph_search_stats_ex(uint64_t *out4) {
+    ANNLITE_REQUIRE(out4 != nullptr, "out8 is NULL");
     if (!g_graph_stats) {
         set_error("no counters recorded (set ANNLITE_DEBUG_COUNTERS=1 before the walk)");
         return ANNLITE_ERR_INVALID;
     }
     ANNLITE_HIP_TRY(hipDeviceSynchronize());
-    ANNLITE_HIP_TRY(hipMemcpy(out4, g_graph_stats, 32, hipMemcpyDeviceToHost));
+    ANNLITE_HIP_TRY(hipMemcpy(out4, g_graph_stats, 64, hipMemcpyDeviceToHost));
     return ANNLITE_OK;
 }
 

@@ -376,6 +376,9 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
             // default: byte tables, 32 queries / WG, 15 scanning waves + 1 consumer (small k: the candidate generator of the
             // re-rank stage asks for 64 per slice and starts without a seed -- the u16 tables filter that much better)
             if ((v == 0 && !tiles && k <= 16) || (v == 50 && !tiles && k <= 16)) { *c = {16, 4, 2, 16, 4, 1, 1650, 5}; return true; }
+            // 16 < k <= 64 (round 5): the byte-table kernel with 64-key lists -- only where the library asks for it (variant 50: the
+            // shared-bound search, scan_topk_impl); the PUBLIC plan of these k stays the u16 plan (the candidate generator, tile mode)
+            if (v == 50 && !tiles && k <= 64) { *c = {16, 4, 2, 16, 4, 1, 1664, 5}; return true; }
             if (v == 30) { *c = {16, 4, 2, 12, 3, 1, 1630, 4}; return true; }  // u16 tables, 12 waves
             if (v == 32) { *c = {16, 4, 2, 8, 2, 1, 1632, 4}; return true; }   // u16 tables, 8 waves
             *c = {16, 4, 2, 16, 4, 1, 1631, 4};                               // u16 tables, 16 queries / WG, 16 waves (variant 31)
@@ -397,6 +400,9 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
         default: return false;
     }
 }
+
+// shapes the byte-table kernel serves beyond k = 16 (64-key lists, scan_q8.hip id 1664)
+static bool lk64_shape(int64_t M, int64_t Ks, int code_bytes, int64_t k) { return M == 16 && code_bytes == 1 && Ks <= 256 && k > 16 && k <= 64; }
 
 static int round_up(int64_t x, int64_t m) { return (int)(((x + m - 1) / m) * m); }
 // queries the per-query workspace arrays are sized for: whole tiles, at least the 16 the fp32 TILED table is padded to
@@ -481,6 +487,14 @@ static int plan_query_impl(int64_t N, int64_t M, int64_t Ks, int code_bytes, int
             VariantScope vs(31);
             if (plan_query_impl(N, M, Ks, code_bytes, B, k, force_ns, &p2) == ANNLITE_OK)
                 plan->workspace_bytes = ((plan->workspace_bytes + 255) / 256) * 256 + p2.workspace_bytes;
+        }
+        // ... and the other way round for 16 < k <= 64 at M = 16: the public plan is the u16 plan, the library's search runs the
+        // byte-table kernel (64-key lists) in a region of its own IN FRONT of it
+        if (c.mode == 4 && k > 16 && lk64_shape(M, Ks, code_bytes, k) && force_ns == 0 && g_variant_scope < 0 && env_variant() < 0) {
+            annlite_scan_plan p1;
+            VariantScope vs(50);
+            if (plan_query_impl(N, M, Ks, code_bytes, B, k, force_ns, &p1) == ANNLITE_OK)
+                plan->workspace_bytes = ((p1.workspace_bytes + 255) / 256) * 256 + plan->workspace_bytes;
         }
     } else {
         plan->fast = 0;
@@ -731,7 +745,8 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 a.cand_cap = (int32_t)tm->cand_cap;
                 if (outp) outp->merged = true;  // (the tile scan's result is the candidate lists)
             }
-            if (share_across_slices && outp && (outp->packed || (outp->d && outp->i))) {
+            // (64-key lists: the slices are merged by merge_partial_kernel, not in the scan)
+            if (share_across_slices && outp && (outp->packed || (outp->d && outp->i)) && !(c.mode == 5 && k > 16)) {
                 a.tile_done = tile_done;
                 a.out_d = outp->d;
                 a.out_i = outp->i;
@@ -749,6 +764,22 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             {
                 const int64_t grp = plan.n_slices < 8 ? plan.n_slices : 8;  // slices scanned concurrently
                 a.jm1 = (int)((k + grp - 1) / grp) - 1;
+                if (c.mode == 5 && k > 16) {
+                    // 64-key lists: a slice publishes the keys at four list positions, ~0.64 / 0.96 / 1.28 / 1.92 of its share k / G of
+                    // the k best rows (8 slices, k = 50: positions 4, 6, 8, 12 -- the weighted bound sits near rank 56; q8_weighted_bound)
+                    const double share = (double)k / (double)grp;
+                    const double f[4] = {0.64, 0.96, 1.28, 1.92};
+                    int prev = 0;
+                    a.q8_pos = 0;
+                    for (int i = 0; i < 4; ++i) {
+                        int p = (int)ceil(f[i] * share);
+                        if (p <= prev) p = prev + 1;
+                        if (p > 61 + i) p = 61 + i;  // (positions stay inside the 64-key list, strictly ascending)
+                        prev = p;
+                        a.q8_pos |= (uint32_t)(p - 1) << (8 * i);
+                    }
+                    a.jm1 = prev - 1;
+                }
                 a.flush_mask = 63;
                 if (const char *e = getenv("ANNLITE_FLUSH_MASK")) a.flush_mask = atoi(e);
             }
@@ -1001,7 +1032,8 @@ static SearchMode search_policy(annlite_scan_state *s, int64_t N, int64_t M, int
                                 bool tiles) {
     // the shapes with both a byte-table and a u16-table kernel: M = 8 / 16 / 32 with u8 codes, M = 8 / u16 codes up to Ks = 1024
     const bool both = ((M == 16 || M == 8 || M == 32) && code_bytes == 1 && Ks <= 256) || (M == 8 && code_bytes == 2 && Ks <= 1024);
-    if (tiles || !both || k > 16 || N <= 0 || B <= 0) return kModePlain;
+    // (k > 16: the byte-table kernel with 64-key lists exists for M = 16 / uint8 codes; it needs a table worth seeding)
+    if (tiles || !both || (k > 16 && !(lk64_shape(M, Ks, code_bytes, k) && N >= 65536)) || N <= 0 || B <= 0) return kModePlain;
     if (g_variant_scope >= 0 || env_variant() >= 0) return kModePlain;        // (an explicit variant: A/B measurements)
     if (getenv("ANNLITE_NO_INKERNEL_MERGE")) return kModePlain;                // (debug switch: no guarded pass)
     if (!s) return kModeGuarded;
@@ -1151,7 +1183,14 @@ static int scan_topk_impl(const void *codes_dev, int code_bytes, int codes_layou
             rc = scan_partial(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut_dev, B, k, workspace_dev,
                               workspace_bytes, st, &p1, true, build, &so, nullptr, &g);
             if (rc != ANNLITE_OK || B == 0) return rc;
-            ANNLITE_REQUIRE(so.merged, "the byte-table launch did not merge in-kernel");
+            if (!so.merged) {  // 16 < k <= 64: the 64-key lists of the slices, merged here (a launch that gave up leaves garbage: the
+                               // gated pass below overwrites it)
+                ANNLITE_REQUIRE(k > 16, "the byte-table launch did not merge in-kernel");
+                hipLaunchKernelGGL(merge_partial_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, (const unsigned long long *)workspace_dev,
+                                   (int)B, p1.n_slices, (int)k, row_base, out_dist_dev, out_id_dev, out_packed_dev, sqrt_out);
+                rc = launch_status("merge_partial_kernel");
+                if (rc != ANNLITE_OK) return rc;
+            }
             used = ((size_t)p1.workspace_bytes + 255) / 256 * 256;
         }
         if (mode == kModeGuarded && g.guard_out) {

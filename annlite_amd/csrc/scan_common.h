@@ -82,6 +82,8 @@ struct ScanArgs {
                                         // without an arrival (20000 = 200 us; ANNLITE_EARLY_MERGE_PATIENCE: tests force the path)
     int32_t q8_map_slices;              // byte-table kernel: work items mapped slice-per-XCD (item_map) instead of tile-per-XCD
                                         // (q8_item_map): an XCD streams ITS row slices once for all query tiles
+    uint32_t q8_pos;                    // byte-table kernel, 16 < k <= 64 (64-key lists): the list positions p0 < p1 < p2 < p3 (one per byte) whose
+                                        // keys a slice publishes -- cell i = "this slice holds p_i + 1 rows at or below this key"; G (p3 + 1) >= k
     unsigned long long *clk;            // optional (annlite_profile_enable): workgroup 0 leaves [0] shader cycles (s_memtime) and [1] 100 MHz
                                         // ticks at its start, [2] / [3] at its end -- the clock the kernel actually held
 };

@@ -25,6 +25,9 @@ struct FlushCtx {
     // byte-entry kernel (scan_q8.hip): the filter bounds are bytes (0x80 | T) at shq_off + q and the quantisation step of a
     // slot is chosen by the workgroup itself (f32 [QT] in LDS at step_off); 0 = the u16 kernels (qstep[] in global memory)
     uint32_t step_off;
+    // byte-table kernel with 64-key lists (16 < k <= 64): the four list positions (one per byte, ascending) whose keys a slice
+    // publishes to its sibling slices (ScanArgs::q8_pos)
+    uint32_t pos;
 };
 
 // byte filter bound (0x80 | T) implied by a k-th key for a table quantised with `step` (scan_q8.hip has the derivation)

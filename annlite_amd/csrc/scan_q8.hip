@@ -248,7 +248,9 @@ constexpr int kPopPerRing = 8;    // entries the consumer takes from one wave's 
 //   seen     u32 x 2 (guard statistics); rowq [64 lanes][48 B]: the row queue's parked masks / row ids / code bytes
 struct Q8Lds {
     uint32_t tab, shq, ring_ctl, gkl, step, inv, tb, ctl, clip, tau, c0, c1, list, gjl, ring, qkey, qslot, chg, stamps, seen, rowq;
-    __device__ __forceinline__ explicit Q8Lds(int lut_bytes) {
+    // lk: keys per slot list -- 16 (k <= 16, four insertions at a time), or 64 (16 < k <= 64: one 64-lane list per slot, 16 KB;
+    // its ring entries are the row queue's bare 4-byte row ids, which is what makes the 160 KB hold it)
+    __device__ __forceinline__ explicit Q8Lds(int lut_bytes, int lk = 16) {
         tab = lds_base_addr();
         shq = tab + (uint32_t)lut_bytes;
         ring_ctl = shq + 32;
@@ -262,9 +264,9 @@ struct Q8Lds {
         c0 = shq + 1152;
         c1 = shq + 1408;
         list = shq + 1664;
-        gjl = list + 32 * 128;
+        gjl = list + 32u * (uint32_t)lk * 8u;
         ring = gjl + 32 * 8;
-        qkey = ring + kRingSize * 8;
+        qkey = ring + kRingSize * (lk == 64 ? 4 : 8);
         qslot = qkey + 4 * 128 * 8;
         chg = qslot + 4 * 128;
         stamps = chg + 32;
@@ -331,7 +333,7 @@ __device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t x) {
 // The global publication of a batch's bounds (the other row slices' workgroups import them) is DEFERRED to the next batch,
 // behind the issue of its table gathers: the device-scope atomics take microseconds and the wave's memory counter is in
 // order -- issued right away they sat in front of the next batch's gathers.
-template <int QT>
+template <int QT, int LK = 16>
 __device__ __forceinline__ void q8_publish_global(const FlushCtx &c, const Q8Lds &o, int lane, unsigned long long &pend_o,
                                                   unsigned long long &pend_j) {
     if (lane < QT) {  // (slots beyond QT never change; their cells do not exist)
@@ -339,6 +341,16 @@ __device__ __forceinline__ void q8_publish_global(const FlushCtx &c, const Q8Lds
         if (pend_o != ~0ull && c.gkey) __hip_atomic_fetch_min(c.gkey + b, pend_o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (pend_j != ~0ull && c.gk2) {
             unsigned long long *cell = c.gk2 + ((int64_t)b * c.n_slices + c.slice) * kGk2Keys;
+            if constexpr (LK == 64) {
+                // 16 < k <= 64: the keys at four list positions p_0 < p_1 < p_2 < p_3 (FlushCtx::pos) as they are NOW: cell i says
+                // "this slice holds pos_i + 1 rows at or below this key" -- true of any later version too (keys only fall), so a
+                // reader may mix versions (import_bounds: the weighted count)
+                const uint32_t lst = o.list + (uint32_t)lane * (64u * 8u);
+#pragma unroll
+                for (int i = 0; i < kGk2Keys; ++i)
+                    __hip_atomic_store(cell + i, ldsv<unsigned long long>(lst + 8u * (uint32_t)((c.pos >> (8 * i)) & 0xff)), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            } else
             if (c.jm1 < 2) {
                 // this slice's j smallest keys as they are NOW (keys only fall; a reader may see a mix of two versions:
                 // each key belongs to a row of this slice, and it drops a duplicate)
@@ -354,7 +366,7 @@ __device__ __forceinline__ void q8_publish_global(const FlushCtx &c, const Q8Lds
     pend_j = ~0ull;
 }
 
-template <int M, bool SKEWED, int QT, int CB, bool ROWS_IN_LDS = false>
+template <int M, bool SKEWED, int QT, int CB, bool ROWS_IN_LDS = false, int LK = 16>
 __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, const unsigned long long (&e)[2], bool (&act)[2],
                                            int lane, uint32_t &n_kept, uint32_t &n_offered, unsigned long long &pend_o,
                                            unsigned long long &pend_j) {
@@ -404,7 +416,7 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
                         vals[j] = lq[((int64_t)code * M + m) * 4];
                     }
                     if constexpr (m0 == 0) {
-                        if (u == 0) q8_publish_global<QT>(c, o, lane, pend_o, pend_j);  // (the previous batch's, behind these gathers)
+                        if (u == 0) q8_publish_global<QT, LK>(c, o, lane, pend_o, pend_j);  // (the previous batch's, behind these gathers)
                     }
 #pragma unroll
                     for (int j = 0; j < 16; ++j) sum += vals[j];
@@ -445,7 +457,7 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
                 vals[u][m] = lq[((int64_t)code * M + m) * 4];
             }
         }
-        q8_publish_global<QT>(c, o, lane, pend_o, pend_j);  // (the previous batch's, behind this batch's gathers)
+        q8_publish_global<QT, LK>(c, o, lane, pend_o, pend_j);  // (the previous batch's, behind this batch's gathers)
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -461,7 +473,7 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
         const unsigned long long key = ((unsigned long long)f32_to_key(ex[u]) << 32) | (uint32_t)e[u];  // (NaN behind +inf)
         bool pend = false;
         if (act[u]) {
-            unsigned long long kth = ldsv<unsigned long long>(o.list + 8u * (uint32_t)(q[u] * 16 + c.km1));
+            unsigned long long kth = ldsv<unsigned long long>(o.list + 8u * (uint32_t)(q[u] * LK + c.km1));
             const unsigned long long gk = ldsv<unsigned long long>(o.gkl + 8u * (uint32_t)q[u]);
             if (gk < kth) kth = gk;
             pend = key < kth;
@@ -483,6 +495,27 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
     int rounds = cnt[0] > cnt[1] ? cnt[0] : cnt[1];
     rounds = rounds > cnt[2] ? rounds : cnt[2];
     rounds = rounds > cnt[3] ? rounds : cnt[3];
+    if constexpr (LK == 64) {
+        // 64-key lists: lane = list position, ONE insertion per wave operation -- the keys in front of the candidate are a prefix
+        // (the list is ascending), every lane behind it hands its key one position up THROUGH the LDS (no cross-lane traffic:
+        // the wave's LDS operations execute in order, all reads of the old list precede the writes)
+#pragma unroll 1
+        for (int rr = 0; rr < 4; ++rr) {
+            const int n_rr = rr == 0 ? cnt[0] : rr == 1 ? cnt[1] : rr == 2 ? cnt[2] : cnt[3];
+#pragma unroll 1
+            for (int t = 0; t < n_rr; ++t) {
+                const unsigned long long ckey = ldsv<unsigned long long>(o.qkey + 8u * (uint32_t)(rr * 128 + t));
+                const int cq = ldsv<unsigned char>(o.qslot + (uint32_t)(rr * 128 + t)) & 31;
+                const uint32_t ent_ad = o.list + 8u * (uint32_t)(cq * 64 + lane);
+                const unsigned long long ent = ldsv<unsigned long long>(ent_ad);
+                const int pos = __popcll(__ballot(ent < ckey));
+                if (pos <= c.km1) {  // (an earlier insertion of this batch may have pushed the k-th key below the candidate)
+                    if (lane >= pos && lane < 63) ldsv_st<unsigned long long>(ent_ad + 8u, ent);
+                    if (lane == pos) ldsv_st<unsigned long long>(ent_ad, ckey);
+                }
+            }
+        }
+    } else {
 #pragma unroll 1
     for (int t = 0; t < rounds; ++t) {
         const bool valid = t < mycnt;
@@ -495,12 +528,13 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
         const unsigned long long sh = ((unsigned long long)dpp_row_shr1((uint32_t)(ent >> 32)) << 32) | dpp_row_shr1((uint32_t)ent);
         if (valid && li >= pos) ldsv_st<unsigned long long>(ent_ad, li == pos ? ckey : sh);
     }
+    }
     const uint32_t changed = (uint32_t)__ballot(lane < 32 && ldsv<unsigned char>(o.chg + (uint32_t)(lane & 31)) != 0);
     if (lane < 32) ldsv_st<unsigned char>(o.chg + (uint32_t)lane, 0);
     // publish the bounds of the slots that changed: lane = slot
     if (lane < 32 && ((changed >> lane) & 1u)) {
-        const unsigned long long okey = ldsv<unsigned long long>(o.list + 8u * (uint32_t)(lane * 16 + c.km1));
-        const unsigned long long jkey = ldsv<unsigned long long>(o.list + 8u * (uint32_t)(lane * 16 + c.jm1));
+        const unsigned long long okey = ldsv<unsigned long long>(o.list + 8u * (uint32_t)(lane * LK + c.km1));
+        const unsigned long long jkey = ldsv<unsigned long long>(o.list + 8u * (uint32_t)(lane * LK + (LK == 64 ? 0 : c.jm1)));
         const uint32_t tau_ad = o.tau + 8u * (uint32_t)lane, gkl_ad = o.gkl + 8u * (uint32_t)lane;
         if (okey < ldsv<unsigned long long>(tau_ad)) {
             ldsv_st<unsigned long long>(tau_ad, okey);
@@ -511,6 +545,9 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
                 if (nb < q8_ld_bound<M>(o, lane)) q8_st_bound<M>(o, lane, nb);
             }
         }
+        if constexpr (LK == 64) {
+            if (c.gk2) pend_j = jkey;  // (the list changed: its keys at the four published positions go out with the next batch)
+        } else
         if (c.gk2 && jkey != ~0ull) {  // the slice's j smallest keys changed: the sibling slices compute their bound from them
             const uint32_t gjl_ad = o.gjl + 8u * (uint32_t)lane;
             if (jkey < ldsv<unsigned long long>(gjl_ad)) {
@@ -524,7 +561,7 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
 // (Re)build of a workgroup's table: slot parameters (one thread per slot) from the best bound known for the query, then
 // the byte table.  Out of line on purpose: it runs a dozen times per work item, and inlined into the step loop its 40
 // live registers made the compiler spill the loop-invariant LDS base registers of the look-ups into the hot path.
-template <int M, int NW, int NQ>
+template <int M, int NW, int NQ, int LK = 16>
 __device__ __attribute__((noinline)) void q8_rebuild(q8_kernarg_ptr ka, int tile, int first, int slice) {
     constexpr int QT = q8_qt<M, NQ>();
     // first bounds of the item's queries: what the seed launch left in the shared array, or -- candidate generator, nothing
@@ -534,7 +571,7 @@ __device__ __attribute__((noinline)) void q8_rebuild(q8_kernarg_ptr ka, int tile
                        ka->Ks, ka->B, ka->k, ka->q8_target, ka->gseed0, ka->btab};
     const bool prebuilt = first && a.btab != nullptr && M == 16 && NQ == 2;
     const int tid = threadIdx.x;
-    const Q8Lds o(q8_table_bytes<M, NQ>(a.Ks));
+    const Q8Lds o(q8_table_bytes<M, NQ>(a.Ks), LK);
     if (tid < 32) {  // (the control block has 32 slots whatever QT is: the consumer's lanes 0 .. 31 look at all of them)
         const uint32_t t8 = 8u * (uint32_t)tid, t4 = 4u * (uint32_t)tid;
         const int b = tile * QT + tid;
@@ -758,6 +795,60 @@ __device__ __attribute__((noinline)) unsigned long long q8_rows_pass_masks(const
     return (unsigned long long)m0 | ((unsigned long long)m1 << 32);
 }
 
+// 16 < k <= 64 (64-key lists): the bound the sibling slices' published keys imply for query b.  A slice publishes the keys at four
+// list positions p0 < p1 < p2 < p3 (ScanArgs::q8_pos): cell i says "this slice holds p_i + 1 rows at or below this key".  For a
+// threshold t the slices of a group of 8 therefore hold at least
+//     count(t) = sum over their cells <= t of w_i,   w_i = p_i - p_(i-1)   (p_(-1) = -1)
+// rows at or below t: the cells of a slice are ascending, so the increments of its cells <= t add up to p_i + 1 of the largest
+// of them (a reader that mixes two versions of a slice's cells only undercounts: every cell's own claim holds whatever the
+// others say, keys only fall).  The smallest published key with count >= k has k rows of the table at or below it (+ 1: that row
+// itself must still be accepted).  With 8 slices and positions (4, 6, 8, 12) the bound sits near global rank 56 for k = 50 -- the
+// MAX of the slices' 7th keys (the rule for j > 2 below) near rank 89, and the candidates are in proportion (rank^1.6).
+// Lane = (slot, half): a lane holds the 4 x 4 cells of four slices and ranks them against all 32 of the group.  Out of line: ~60
+// live registers that must not reach the scanning branch's allocation.
+__device__ __attribute__((noinline)) unsigned long long q8_weighted_bound(const unsigned long long *gk2, int b, int n_slices, int k,
+                                                                          uint32_t pos, bool real) {
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int part = lane >> 5;
+    int w[4];
+    w[0] = (int)(pos & 0xffu) + 1;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) w[i] = (int)((pos >> (8 * i)) & 0xffu) - (int)((pos >> (8 * (i - 1))) & 0xffu);
+    unsigned long long best = ~0ull;
+#pragma unroll 1
+    for (int g0 = 0; g0 < n_slices; g0 += 8) {
+        unsigned long long kk[16];
+#pragma unroll
+        for (int sl4 = 0; sl4 < 4; ++sl4) {
+            const int sl = g0 + part * 4 + sl4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                kk[4 * sl4 + i] = ~0ull;
+                if (real && sl < n_slices)
+                    kk[4 * sl4 + i] = __hip_atomic_load(gk2 + ((int64_t)b * n_slices + sl) * kGk2Keys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        int cnt[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cnt[i] = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const unsigned long long oj = __shfl_xor(kk[j], 32);  // the other half's cell j
+            const int wj = w[j & 3];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cnt[i] += (kk[j] <= kk[i] ? wj : 0) + (oj <= kk[i] ? wj : 0);
+        }
+        unsigned long long found = ~0ull;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (cnt[i] >= k && kk[i] < found) found = kk[i];  // (an empty cell, ~0, is never below `found`)
+        const unsigned long long o = __shfl_xor(found, 32);
+        found = o < found ? o : found;
+        if (found != ~0ull && found + 1ull < best) best = found + 1ull;
+    }
+    return best;
+}
+
 // work item -> (query tile, row slice).  item % 8 == the XCD the block lands on (speed only).  With >= 8 query tiles an
 // XCD owns the tiles congruent to it, for ALL row slices: the fp32 tables the exact sums gather from (16 KB per query,
 // 512 KB per tile) stay in that XCD's 4 MB L2 -- with the slice-per-XCD map of the u16 kernels (item_map) every XCD saw
@@ -896,22 +987,23 @@ __device__ __forceinline__ void q8_early_merge(const ScanArgs &a, const Q8Lds &l
 // End of a work item: the lists ARE the workgroup's result for this (tile, slice) -- the final epoch_sync was the barrier:
 // every candidate is in --; the last of the tile's workgroups to arrive merges the slices.  Out of line, arguments from the
 // kernarg segment (see q8_kernarg).
-template <int M, int NW, int NQ>
+template <int M, int NW, int NQ, int LK = 16>
 __device__ __attribute__((noinline)) void q8_finish_item(q8_kernarg_ptr ka, int tile, int slice) {
     constexpr int QT = q8_qt<M, NQ>();
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int km1 = ka->k - 1, B = ka->B, n_slices = ka->n_slices, k = ka->k;
-    const Q8Lds lds(q8_table_bytes<M, NQ>(ka->Ks));
+    const Q8Lds lds(q8_table_bytes<M, NQ>(ka->Ks), LK);
     unsigned long long *partial = ka->partial;
     for (int q = wave; q < QT; q += NW) {
         const int b = tile * QT + q;
         // device-scope stores: the merging workgroup may sit on another XCD (own L2)
         if (b < B && lane <= km1)
             __hip_atomic_store(partial + ((int64_t)b * n_slices + slice) * k + lane,
-                               ldsv<unsigned long long>(lds.list + 8u * (uint32_t)(q * 16 + lane)), __ATOMIC_RELAXED,
+                               ldsv<unsigned long long>(lds.list + 8u * (uint32_t)(q * LK + lane)), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
     }
     unsigned int *tile_done = ka->tile_done;
+    if constexpr (LK == 16)  // (64-key lists: the slices are merged by merge_partial_kernel -- the in-kernel merges hold 16 keys per lane row)
     if (tile_done) {
         // the last of the tile's n_slices workgroups to arrive merges them
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have completed
@@ -940,8 +1032,10 @@ __device__ __attribute__((noinline)) void q8_finish_item(q8_kernarg_ptr ka, int 
     }
 }
 
-template <int M, int NW, bool SKEWED, int NQ, int CB, bool RQ>
+template <int M, int NW, bool SKEWED, int NQ, int CB, bool RQ, int LK = 16>
 __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const ScanArgs a) {
+    static_assert(LK == 16 || (LK == 64 && RQ), "64-key lists: the shared-bound M = 16 kernel with the row queue (4-byte ring entries)");
+    constexpr uint32_t RE = LK == 64 ? 4u : 8u;  // bytes of a ring entry
     constexpr bool WIDE = Q8Cfg<M>::WIDE;
     constexpr bool M8 = Q8Cfg<M>::M8, M32 = Q8Cfg<M>::M32, C16 = CB == 2;
     constexpr bool ROWQ = RQ && ANNLITE_Q8_ROWQ != 0;  // (row queue: see q8_row_pass_mask)
@@ -960,7 +1054,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
     const int km1 = a.k - 1;
 
     const int lut_bytes = q8_table_bytes<M, NQ>(a.Ks);
-    const Q8Lds lds(lut_bytes);
+    const Q8Lds lds(lut_bytes, LK);
     const q8_kernarg_ptr ka = q8_kernarg();
 
     if (a.guard && tid == 0) ldsv_st<uint32_t>(lds.seen, 0u);
@@ -1013,11 +1107,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             }
             __syncthreads();
             if (ldsv<uint32_t>(lds.ctl)) {
-                q8_rebuild<M, NW, NQ>(ka, tile, 0, slice);
+                q8_rebuild<M, NW, NQ, LK>(ka, tile, 0, slice);
                 if (a.dbg && tid == 0) atomicAdd(a.dbg + 5, 1ull);
             }
         };
-        for (int idx = tid; idx < 32 * 16; idx += NW * 64) ldsv_st<unsigned long long>(lds.list + 8u * (uint32_t)idx, ~0ull);  // (all 32 slots)
+        for (int idx = tid; idx < 32 * LK; idx += NW * 64) ldsv_st<unsigned long long>(lds.list + 8u * (uint32_t)idx, ~0ull);  // (all 32 slots)
         if (tid < 16) {
             ldsv_st<uint32_t>(lds.tails() + 4u * (uint32_t)tid, 0);
             ldsv_st<uint32_t>(lds.heads() + 4u * (uint32_t)tid, 0);
@@ -1026,7 +1120,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             ldsv_st<uint32_t>(lds.arrived(), 0);
             ldsv_st<uint32_t>(lds.blk_ctr(), 0);  // the block counter the scanning waves draw from
         }
-        q8_rebuild<M, NW, NQ>(ka, tile, 1, slice);  // (its barriers cover the initialisation above)
+        q8_rebuild<M, NW, NQ, LK>(ka, tile, 1, slice);  // (its barriers cover the initialisation above)
         stamp(1);
 
         // epochs end after steps q8_epoch0, q8_epoch0 * mul + (mul - 1), ... and after the last step
@@ -1034,7 +1128,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             // ------------------------------------------------------------------------------- consumer wave
             const FlushCtx fc = {(const uint8_t *)a.codes, a.lut, a.smax, a.qstep, a.qlo, a.gkey, a.gk2, nullptr,
                                  a.Ks, tile * QT, a.n_slices, slice, km1, a.jm1, a.dbg_skip,
-                                 0u, 0u, 0u, 0u, 0u, 0u};
+                                 0u, 0u, 0u, 0u, 0u, 0u, a.q8_pos};
             // what the other workgroups of these queries (the other row slices) have proven: the best k-th key any of
             // them published and, per group of 8 concurrently scanned slices, the k-th smallest of the keys they published
             // (below; +1: that row itself must still be accepted)
@@ -1047,6 +1141,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 const bool real = q < QT && b < a.B;
                 unsigned long long bound = ~0ull;
                 if (real) bound = __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if constexpr (LK == 64) {
+                    if (a.gk2 && a.n_slices > 1) {
+                        const unsigned long long wb = q8_weighted_bound(a.gk2, b, a.n_slices, a.k, a.q8_pos, real);
+                        if (wb < bound) bound = wb;
+                    }
+                } else
                 if (a.gk2 && a.jm1 < 2) {
                     // The G <= 8 concurrently scanned slices publish their j = ceil(k / G) <= 2 smallest keys: G j >= k keys
                     // of distinct rows, so the k-th smallest of them has k rows at or below it (+1: that row itself must
@@ -1202,7 +1302,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                                     const uint32_t sl = (uint32_t)lane + 64u * (uint32_t)u;
                                     if (sl >= ex_r && sl < ex_r + tk_r) {
                                         act[u] = true;
-                                        e[u] = ldsv<unsigned long long>(lds.ring + 8u * ((uint32_t)r * kWaveRing + ((hd_r + sl - ex_r) & (kWaveRing - 1))));
+                                        const uint32_t ad = lds.ring + RE * ((uint32_t)r * kWaveRing + ((hd_r + sl - ex_r) & (kWaveRing - 1)));
+                                        e[u] = RE == 4u ? (unsigned long long)ldsv<uint32_t>(ad) : ldsv<unsigned long long>(ad);
                                     }
                                 }
                                 if (has_ring && my_ring == r) my_take = tk_r;
@@ -1214,7 +1315,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                                 const uint32_t i = (uint32_t)(my_i + 4 * u);
                                 act[u] = i < avail;
                                 e[u] = 0ull;
-                                if (act[u]) e[u] = ldsv<unsigned long long>(lds.ring + 8u * ((uint32_t)my_ring * kWaveRing + ((head_v + i) & (kWaveRing - 1))));
+                                if (act[u]) {
+                                    const uint32_t ad = lds.ring + RE * ((uint32_t)my_ring * kWaveRing + ((head_v + i) & (kWaveRing - 1)));
+                                    e[u] = RE == 4u ? (unsigned long long)ldsv<uint32_t>(ad) : ldsv<unsigned long long>(ad);
+                                }
                             }
                             head_v = (head_v + avail) & 0xffffu;  // (avail <= kPopPerRing everywhere)
                         }
@@ -1245,7 +1349,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                             ldsv_st<u32x2>(park, (u32x2){pmr[0], pmr[1]});
                             rowq_more = __ballot((pmr[0] | pmr[1]) != 0u) != 0;
                         }
-                        q8_consume<M, SKEWED, QT, CB, ROWQ>(fc, lds, e, act, lane, n_kept, n_offered, pend_o, pend_j);
+                        q8_consume<M, SKEWED, QT, CB, ROWQ, LK>(fc, lds, e, act, lane, n_kept, n_offered, pend_o, pend_j);
                         __builtin_amdgcn_s_setprio(0);
                         ++n_batches;
                         if (a.dbg) t_busy += __builtin_readcyclecounter() - t0;
@@ -1270,14 +1374,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     }
                     __builtin_amdgcn_s_sleep(4);
                 }
-                q8_publish_global<QT>(fc, lds, lane, pend_o, pend_j);
+                q8_publish_global<QT, LK>(fc, lds, lane, pend_o, pend_j);
                 epoch_sync(final);
                 if (final) break;
                 if (ldsv<uint32_t>(lds.ctl)) {
                     // the table was rebuilt: the integer sums of the waiting candidates are in the OLD table's steps --
                     // clear them, so that the stale-candidate check lets them through to the exact sum (every scanning wave has
                     // arrived: its pushes are complete)
-                    if (has_ring) {
+                    if (has_ring && RE == 8u) {  // (row ids carry no sum)
                         const uint32_t tail_v = ldsv<uint32_t>(lds.tails() + 4u * (uint32_t)my_ring);
                         for (uint32_t i = (uint32_t)my_i; i < ((tail_v - head_v) & 0xffffu); i += 4u) {
                             const uint32_t ad = lds.ring + 8u * ((uint32_t)my_ring * kWaveRing + ((head_v + i) & (kWaveRing - 1)));
@@ -1657,7 +1761,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                             }
                             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(rem >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rem, 0u));
                             if (__builtin_amdgcn_inverse_ballot_w64(rem))  // (the hit lanes: exec <- rem)
-                                ldsv_st<uint32_t>(lds.ring + 8u * ((uint32_t)wave * kWaveRing + ((tl + rank) & (kWaveRing - 1))),
+                                ldsv_st<uint32_t>(lds.ring + RE * ((uint32_t)wave * kWaveRing + ((tl + rank) & (kWaveRing - 1))),
                                                   row0 + (uint32_t)lane);  // (the low word of the entry; the consumer reads nothing else of it)
                             tl = (tl + n) & 0xffffu;
                             if (lane == 0) ldsv_st<uint32_t>(lds.tails() + 4u * (uint32_t)wave, tl);
@@ -1761,7 +1865,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             }
         }
 
-        q8_finish_item<M, NW, NQ>(ka, tile, slice);
+        q8_finish_item<M, NW, NQ, LK>(ka, tile, slice);
         if (a.dbg && tid == 0) {
             // [8] 2^62 - earliest start, [9] latest end, sums over the work items: [10] start, [11] init + first table build,
             // [12] thread 0's step loop, [13] its wait at the last barrier (the consumer's backlog, the slower waves),
@@ -1823,11 +1927,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
 
 using namespace annlite;
 
-template <int M, int NW, bool SKEWED, int NQ, int CB, bool RQ = false>
+template <int M, int NW, bool SKEWED, int NQ, int CB, bool RQ = false, int LK = 16>
 static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
     constexpr int QT = 32;  // (the control block is laid out for 32 slots whatever the kernel uses)
-    const size_t need = (size_t)(M == 64 ? (a.Ks + 1) * 512 : M == 32 ? 131072 : a.Ks * NQ * M * 16) + 1664 + (size_t)QT * 128 + QT * 8 + (size_t)kRingSize * 8 + 4 * 128 * 9 + 32 + 32 + 16 + 3072;
-    auto fn = adc_scan_q8_kernel<M, NW, SKEWED, NQ, CB, RQ>;
+    const size_t need = (size_t)(M == 64 ? (a.Ks + 1) * 512 : M == 32 ? 131072 : a.Ks * NQ * M * 16) + 1664 + (size_t)QT * LK * 8 + QT * 8 +
+                        (size_t)kRingSize * (LK == 64 ? 4 : 8) + 4 * 128 * 9 + 32 + 32 + 16 + 3072;
+    ANNLITE_REQUIRE(need <= 160 * 1024, "byte-table kernel: %zu B of LDS", need);
+    auto fn = adc_scan_q8_kernel<M, NW, SKEWED, NQ, CB, RQ, LK>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
     return launch_status("adc_scan_q8_kernel");
@@ -1841,6 +1947,9 @@ int annlite::launch_q8_scan(int id, bool sk, const ScanArgs &a, int grid, hipStr
             // re-rank leg ran at 513 k q/s instead of 554 k
             if (a.gkey) return sk ? launch_q8<16, 16, true, 2, 1, true>(a, grid, st) : launch_q8<16, 16, false, 2, 1, true>(a, grid, st);
             return sk ? launch_q8<16, 16, true, 2, 1>(a, grid, st) : launch_q8<16, 16, false, 2, 1>(a, grid, st);
+        case 1664:  // M = 16, 16 < k <= 64: 64-key lists (one insertion per wave operation), the slices merged by merge_partial_kernel
+            if (!a.gkey || a.tile_done) { set_error("the 64-key-list kernel serves the shared-bound search without an in-kernel merge"); return ANNLITE_ERR_UNSUPPORTED; }
+            return sk ? launch_q8<16, 16, true, 2, 1, true, 64>(a, grid, st) : launch_q8<16, 16, false, 2, 1, true, 64>(a, grid, st);
         case 6450: return sk ? launch_q8<64, 16, true, 2, 1>(a, grid, st) : launch_q8<64, 16, false, 2, 1>(a, grid, st);
         case 3250:  // M = 32: one entry group, 16 queries per workgroup, two half tables of 16 sub-spaces
             return sk ? launch_q8<32, 16, true, 1, 1>(a, grid, st) : launch_q8<32, 16, false, 1, 1>(a, grid, st);

@@ -701,8 +701,10 @@ def main():
         # 64 x 4.  256 CUs at 2.4 GHz (MI355X_MICROARCH.md: 256 B / clk / CU).
         plan_k = _capi.scan_plan(n_local, M, Ks, index.code_bytes, B, k)
         # (which M = 16 kernel served the table is the library's choice, from what its launches measured: index.scan_kernel)
+        # (16 < k <= 64 at M = 16: the public plan is the u16 plan, the library's search runs the byte-table kernel with 64-key lists)
+        lk64 = M == 16 and index.code_bytes == 1 and Ks <= 256 and 16 < k <= 64 and n_local >= 65536
         byte_tables = (plan_k.qt == 32 or (M == 64 and plan_k.qt == 8) or (M == 8 and index.code_bytes == 2 and plan_k.qt == 16) or
-                       (M == 32 and plan_k.qt == 16)) and \
+                       (M == 32 and plan_k.qt == 16) or lk64) and \
             index.scan_kernel != 'u16 tables' and \
             os.environ.get('ANNLITE_SCAN_VARIANT', '0') in ('0', '50')
         per_clk = 256 if byte_tables else 128
@@ -722,7 +724,7 @@ def main():
             print('bench.py: ' + traffic_note, file=sys.stderr)
             traffic = None
         # shapes with both a byte-table and a u16-table kernel (scan.hip: search_policy) have a choice to report
-        has_choice = k <= 16 and index.code_bytes in (1, 2) and ((M in (8, 16, 32) and index.code_bytes == 1 and Ks <= 256) or
+        has_choice = (k <= 16 or lk64) and index.code_bytes in (1, 2) and ((M in (8, 16, 32) and index.code_bytes == 1 and Ks <= 256) or
                                                                  (M == 8 and index.code_bytes == 2 and Ks <= 1024))
         roof = {
             'bound': 'lds', 'achieved': lookups_per_s, 'peak': lds_peak, 'unit': 'look-ups/s', 'frac': lookups_per_s / lds_peak,

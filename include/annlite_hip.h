@@ -168,8 +168,9 @@ ANNLITE_API int annlite_graph_search_packed(const void *packed_dev, int links_pe
  * (PQLookup sums) over the batch; this copies the two counters of the last walk to the host (the roofline of
  * scripts/bench_hnsw.py: algorithmic bytes = expansions * 4 (links_per_node + 1) + evaluations * M). */
 ANNLITE_API int annlite_graph_search_stats(uint64_t *out2);
-/* ... and [2] the expansions whose record had been prefetched (packed walk), [3] reserved. */
-ANNLITE_API int annlite_graph_search_stats_ex(uint64_t *out4);
+/* ... EIGHT counters: [2] the expansions whose record had been prefetched (packed walk); shader cycles summed over the queries'
+ * waves: [3] seed phase, [4] pick + wait for the record, [5] visited table, [6] PQLookup sums, [7] list merge. */
+ANNLITE_API int annlite_graph_search_stats_ex(uint64_t *out8);
 
 /* ------------------------------------------------------------------------------------------------
  * Batched flat ADC scan + top-k: the hot path.

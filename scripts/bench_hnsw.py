@@ -155,6 +155,7 @@ def walk_ms(use_packed):
 os.environ['ANNLITE_DEBUG_COUNTERS'] = '1'
 walk_once(packed is not None)
 n_expand, n_eval, n_hit = _capi.graph_search_stats_ex()
+phase_cycles = dict(_capi.graph_search_stats_ex.cycles)
 del os.environ['ANNLITE_DEBUG_COUNTERS']
 kernel_ms = walk_ms(packed is not None)
 plain_ms = walk_ms(False) if packed is not None else kernel_ms
@@ -188,6 +189,8 @@ roofline = {'bound': 'hbm', 'achieved': alg_bytes / (kernel_ms * 1e-3) / 1e9, 'p
             'layout': 'packed node records (neighbours\' code rows inline, next record prefetched)' if packed is not None else 'plain',
             'plain_layout_kernel_ms': plain_ms, 'packed_equals_plain_bit_exact': same, 'record_bytes': rec_bytes,
             'prefetched_records_used': (n_hit / max(n_expand, 1)),
+            # shader cycles per query by phase of the walk (ANNLITE_DEBUG_COUNTERS run: the stamps themselves cost a few per cent)
+            'cycles_per_query_by_phase': {kk: vv / B for kk, vv in phase_cycles.items()},
             'algorithmic_bytes_per_launch': alg_bytes, 'bytes_read_by_design': design_bytes,
             'expansions_per_query': n_expand / B, 'rows_evaluated_per_query': n_eval / B,
             'note': 'a pointer chase, latency-bound by design: one wave per query, one dependent record read per expansion'}

@@ -73,6 +73,16 @@ for it in range(a.iters):
         d, i = ops.adc_scan_topk(codes, lut, B, k, M, Ks, codes_layout=a.layout, workspace=ws, valid_bits=valid)
     ms.append(_capi.profile_last_scan_ms())
 torch.cuda.synchronize()
+if a.fused and not os.environ.get('ANNLITE_DEBUG_COUNTERS'):  # the whole call (preparation launch, scan, merge), back to back
+    import time
+    _capi.profile_enable(False)
+    n_w = 20
+    t0 = time.perf_counter()
+    for _ in range(n_w):
+        ops.pq_search_topk(LUT_L2, q, cb, codes, k, M, Ks, codes_layout=a.layout, workspace=ws, valid_bits=valid, state=state)
+    torch.cuda.synchronize()
+    print('whole call, %d back to back: %.4f ms per batch' % (n_w, (time.perf_counter() - t0) / n_w * 1e3))
+    _capi.profile_enable(True)
 look = B * N * M
 med = float(np.median(ms[len(ms) // 2:]))  # (the first iterations include module load and the clock ramp)
 print('kernel choice:', _capi.ScanState.KERNELS[state.info()[0]], state.info())
