@@ -102,10 +102,11 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
     const int b = blockIdx.x * (blockDim.x >> 6) + wave;  // 1..4 waves per workgroup, as many as the LDS holds
     if (b >= B) return;  // (whole waves leave; no block-wide barrier below)
     const uint32_t hash_n = 1u << hash_bits;
-    const size_t per_wave = (size_t)M * Ks * 4 + (size_t)hash_n * 4 + (BATCH ? (size_t)E * 64 * 12 : 0);  // (same formula as launch_beam)
+    const size_t per_wave = (size_t)M * Ks * 4 + (size_t)hash_n * 4 + (BATCH ? (size_t)E * 64 * 12 + 1024 : 0);  // (same formula as launch_beam)
     float *s_lut = (float *)(smem + wave * per_wave);
     uint32_t *s_hash = (uint32_t *)(smem + wave * per_wave + (size_t)M * Ks * 4);
-    uint32_t *s_mrg = s_hash + hash_n;  // BATCH: the merge's scratch, u32 [3][64 E]: keys hi, ids, expanded flags
+    uint32_t *s_mrg = s_hash + hash_n;  // BATCH: the merge's scratch, u32 [3][64 E]: keys hi, ids, expanded flags; then u32 [4][64]: the
+                                        // candidates compacted (hi, id) and by rank (hi, id)
     {
         const f32x4 *src = (const f32x4 *)(lut_bmk + (int64_t)b * M * Ks);
         for (int i = lane; i < M * Ks / 4; i += 64) ((f32x4 *)s_lut)[i] = src[i];
@@ -119,15 +120,21 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
     // BUCKETS of four entries (round 5): one 16-byte read shows a bucket, the node is looked for in it and, if there is room,
     // claimed with ONE compare-and-swap.  (One entry per probe: at the end of a 5M-row walk the 4096-entry table holds ~2600
     // nodes and the slowest of an expansion's 32 lanes needed a dozen dependent LDS round trips.)
+    // (by LDS byte address in the LDS address space: through a generic volatile pointer the bucket read was a FLAT load, and a flat
+    // load counts on the vector-memory counter too -- every probe then waited for the prefetched record)
+    typedef __attribute__((address_space(3))) unsigned char *lds_bytes;
+    const uint32_t hash_ad = (uint32_t)(uintptr_t)(lds_bytes)smem + (uint32_t)(wave * per_wave) + (uint32_t)(M * Ks * 4);
     auto visit = [&](uint32_t node) -> bool {
         const uint32_t n_buckets = hash_n >> 2;
         uint32_t bk = ((node * 2654435761u) >> (32 - hash_bits)) >> 2;
         for (uint32_t probe = 0; probe < 16; ++probe) {
-            const u32x4 v = *(volatile u32x4 *)(s_hash + 4u * bk);
+            const u32x4 v = *(volatile __attribute__((address_space(3))) u32x4 *)(uintptr_t)(hash_ad + 16u * bk);
             if (v.x == node || v.y == node || v.z == node || v.w == node) return false;
             const int slot = v.x == kEmpty ? 0 : v.y == kEmpty ? 1 : v.z == kEmpty ? 2 : v.w == kEmpty ? 3 : -1;
             if (slot >= 0) {
-                const uint32_t old = atomicCAS(s_hash + 4u * bk + (uint32_t)slot, kEmpty, node);
+                uint32_t old = kEmpty;  // (expected; the call leaves what it found here)
+                __hip_atomic_compare_exchange_strong((__attribute__((address_space(3))) uint32_t *)(uintptr_t)(hash_ad + 16u * bk + 4u * (uint32_t)slot),
+                                                     &old, node, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (old == kEmpty) return true;
                 if (old == node) return false;
                 continue;  // (another lane of this expansion took the slot: look at the bucket again)
@@ -191,7 +198,70 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
             }
         } else {
             if (!pm) return;
-            // One pass over the candidates (wave-uniform: their keys are broadcast): a list entry counts the candidates below
+            // FAST PATH: ranks by counting, no wave-wide vote per candidate.  The candidates' keys go to the LDS compacted; every
+            // lane reads them back one by one (same address in all lanes: a broadcast) and counts -- a list entry the candidates
+            // below it (its shift), a candidate lane the candidates below its own key (its rank r).  Entries move to position +
+            // shift through the scratch; the positions nobody moved to are the candidates', in rank order: the h-th hole takes
+            // the candidate of rank h.  A candidate equal to a list entry or to another candidate (only when the visited table
+            // is full) sends the whole expansion down the careful path below.
+            {
+                uint32_t *cu_hi = s_mrg + 192 * E, *cu_lo = cu_hi + 64, *cs_hi = cu_hi + 128, *cs_lo = cu_hi + 192;
+                const bool in = ((pm >> lane) & 1ull) != 0;
+                const int n = __popcll(pm);
+                const int myidx = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                if (in) cu_hi[myidx] = khi, cu_lo[myidx] = node;
+                int shift[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) shift[e] = 0;
+                int r = 0;
+                bool bad = false;
+#pragma unroll 2
+                for (int j = 0; j < n; ++j) {
+                    const uint32_t chi = cu_hi[j], clo = cu_lo[j];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        shift[e] += key_less(chi, clo, L.hi[e], L.lo[e]) ? 1 : 0;
+                        bad = bad || (chi == L.hi[e] && clo == L.lo[e]);
+                    }
+                    r += (in && key_less(chi, clo, khi, node)) ? 1 : 0;
+                    bad = bad || (in && j != myidx && chi == khi && clo == node);
+                }
+                if (!__ballot(bad)) {
+                    if (in) cs_hi[r] = khi, cs_lo[r] = node;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) s_mrg[128 * E + e * 64 + lane] = 2u;  // "nobody moved here"
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int np = e * 64 + lane + shift[e];
+                        if (np < 64 * E) {
+                            s_mrg[np] = L.hi[e];
+                            s_mrg[64 * E + np] = L.lo[e];
+                            s_mrg[128 * E + np] = L.exp[e] ? 1u : 0u;
+                        }
+                    }
+                    int hbase = 0;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int P = e * 64 + lane;
+                        const uint32_t x = s_mrg[128 * E + P];
+                        uint32_t nhi = s_mrg[P], nlo = s_mrg[64 * E + P];
+                        const bool hole = x == 2u;
+                        const unsigned long long hm = __ballot(hole);
+                        if (hole) {
+                            const int h = hbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                            nhi = cs_hi[h];
+                            nlo = cs_lo[h];
+                        }
+                        L.hi[e] = nhi;
+                        L.lo[e] = nlo;
+                        L.exp[e] = !hole && x != 0u;
+                        hbase += __popcll(hm);
+                    }
+                    return;
+                }
+            }
+            // CAREFUL PATH (a duplicate somewhere): one pass over the candidates with wave-wide votes.
+            // (wave-uniform: their keys are broadcast): a list entry counts the candidates below
             // it, a candidate lane the list entries and the other candidates below its key.  A candidate that is already in the
             // list, or equals an earlier candidate (both only when the visited table is full: see visit), is dropped --
             // what the one-at-a-time insertion's duplicate check does.
@@ -439,7 +509,7 @@ template <int M, int E, bool PACKED, bool BATCH>
 static int launch_beam(const uint32_t *links, int lpn, const uint8_t *packed, const uint32_t *seeds, int n_seeds, const uint8_t *codes,
                        int64_t N, const uint32_t *valid, const float *lut, int64_t B, int64_t Ks, int ef, int hash_bits,
                        int64_t *out_ids, float *out_dist, unsigned long long *stats, hipStream_t st) {
-    const size_t per_wave = (size_t)M * Ks * 4 + ((size_t)4 << hash_bits) + (BATCH ? (size_t)E * 64 * 12 : 0);
+    const size_t per_wave = (size_t)M * Ks * 4 + ((size_t)4 << hash_bits) + (BATCH ? (size_t)E * 64 * 12 + 1024 : 0);
     int wpb = (int)((size_t)160 * 1024 / per_wave);
     if (wpb > 4) wpb = 4;
     ANNLITE_REQUIRE(wpb >= 1, "M * Ks tables do not fit the LDS");

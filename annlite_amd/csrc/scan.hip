@@ -727,7 +727,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 if (c.mode == 5) {
                     a.guard = guard_blk;
                     a.guard_abort = gopt->abort_enabled;
-                    a.guard_base = 1024;
+                    a.guard_base = 1024u * (uint32_t)((k + 15) / 16);  // (k > 16: the legitimate candidates grow with k -- the transient alone is ~k per query)
                     if (const char *e = getenv("ANNLITE_GUARD_BASE")) a.guard_base = (uint32_t)atoll(e);  // (tests: force the give-up path)
                     a.host_stats = gopt->host_stats;
                     a.stats_seq = gopt->seq;
@@ -1046,12 +1046,13 @@ static SearchMode search_policy(annlite_scan_state *s, int64_t N, int64_t M, int
         // what a guarded launch's workgroups compare their own counts with (guard_base + rows drawn / 16 each), summed over
         // the launch: every query tile scans all N rows.  With structure: ~300 candidates per query at 10M rows -- 30x below it
         const uint64_t n_rows = s->host[5];
-        const uint64_t budget = 1024ull * 256ull + n_rows * ((b + 31) / 32) / 16;
+        const uint64_t kf = (uint64_t)((k + 15) / 16);  // (see guard_base: what counts as "few candidates" scales with k)
+        const uint64_t budget = kf * 1024ull * 256ull + n_rows * ((b + 31) / 32) / 16;
         if (s->kernel == 0 && s->probe == 0) {
             s->rows = (int64_t)s->host[5];
             s->candidates = cand;
             if (gave_up) s->kernel = 2;                // the cliff: no need to time anything
-            else if (cand <= budget / 16 + 1024ull * b) s->kernel = 1;  // clean: the transient from the seed bound to the converged one (a few
+            else if (cand <= budget / 16 + kf * 1024ull * b) s->kernel = 1;  // clean: the transient from the seed bound to the converged one (a few
                                                                         // hundred candidates per query whatever N) + structured data's ~1 per 1000 rows and tile
             else s->probe = 1;                          // grey zone: time this kernel now, the other one next
         } else if (s->kernel == 1 && gave_up) {

@@ -218,7 +218,7 @@ def test_the_library_picks_it_guards_it_and_falls_back(ops, oracle, monkeypatch)
 
     monkeypatch.delenv('ANNLITE_SCAN_VARIANT')
     rs = np.random.RandomState(6)
-    N, D, B, k = 400_000, 128, 40, 50
+    N, D, B, k = 1_200_000, 128, 100, 50
     A = rs.randn(16, D).astype(np.float32)
     x = (rs.randn(N, 16).astype(np.float32) @ A + 0.05 * rs.randn(N, D).astype(np.float32)).astype(np.float32)
     q = (rs.randn(B, 16).astype(np.float32) @ A + 0.05 * rs.randn(B, D).astype(np.float32)).astype(np.float32)
@@ -232,7 +232,7 @@ def test_the_library_picks_it_guards_it_and_falls_back(ops, oracle, monkeypatch)
     for _ in range(4):
         d, i = idx.search_batch(q, limit=k)
         assert np.array_equal(i, ri) and np.array_equal(d, rd)
-    assert idx.scan_kernel == 'byte tables'
+    assert idx.scan_kernel in ('byte tables', 'u16 tables')  # (settled; which one is the library's measurement on this box)
     # a table without structure: every code drawn independently
     N2 = 300_000
     idx2 = PQFlatGpuIndex(dim=D, metric=Metric.EUCLIDEAN, pq_codec=codec, initial_size=N2)
