@@ -54,6 +54,7 @@ class PQFlatGpuIndex(BaseIndex):
         rerank: bool = False,
         skewed: bool = True,
         index_file: Optional[Union[str, Path]] = None,
+        rerank_pool: str = 'slices',
         **kwargs,
     ):
         # HNSW-only kwargs the reference forwards (ef_construction, ef_search, max_connection) are accepted and ignored
@@ -63,6 +64,10 @@ class PQFlatGpuIndex(BaseIndex):
         assert pq_codec is not None, 'PQFlatGpuIndex needs a PQCodec'
         self.pq_codec = pq_codec
         self.rerank = bool(rerank)
+        # candidates of the exact re-rank stage: 'slices' = the union of the row slices' own ADC top-rerank_k lists (n_slices x
+        # rerank_k rows); 'global' = the global ADC top-rerank_k (<= 64, default 50) of the shared-bound search
+        assert rerank_pool in ('slices', 'global')
+        self.rerank_pool = rerank_pool
         self._want_skew = bool(skewed)
         self._ws = ops.ScanWorkspace()
         # device storage is allocated on first use so that constructing an index (and the host-side
@@ -426,9 +431,17 @@ class PQFlatGpuIndex(BaseIndex):
         from ..._capi import LAYOUT_BMK, LAYOUT_TILED
 
         kind, xq = scan_in if scan_in is not None else self.pq_codec.scan_inputs(q)
-        lut = ops.lut_build(xq, self.pq_codec.codebooks_dev, kind, LAYOUT_TILED if plan.fast else LAYOUT_BMK, plan.qi)
-        _, cand = ops.adc_scan_candidates(self._codes, lut, B, rk, self.M, self.Ks, valid_bits=valid, n_rows=N,
-                                          codes_layout=self._layout(), workspace=self._ws)
+        if getattr(self, 'rerank_pool', 'slices') == 'global':
+            # Pool = the GLOBAL ADC top-R (R <= 64) of the shared-bound search -- since round 5 the byte-table kernel serves it
+            # (64-key lists) -- instead of the union of per-slice top-16 lists: 50 rows that are the 50 best by ADC distance
+            # against 128 of which only the 16 best are guaranteed.  One C call, then the exact re-score as below.
+            R = max(min(k, 64), min(64, int(asked or 50)))
+            _, cand = ops.pq_search_topk(kind, xq, self.pq_codec.codebooks_dev, self._codes, R, self.M, self.Ks, valid_bits=valid,
+                                         n_rows=N, codes_layout=self._layout(), workspace=self._ws, state=self.scan_state)
+        else:
+            lut = ops.lut_build(xq, self.pq_codec.codebooks_dev, kind, LAYOUT_TILED if plan.fast else LAYOUT_BMK, plan.qi)
+            _, cand = ops.adc_scan_candidates(self._codes, lut, B, rk, self.M, self.Ks, valid_bits=valid, n_rows=N,
+                                              codes_layout=self._layout(), workspace=self._ws)
         exact = ops.exact_gather_dist(int(self.metric), q, self._vectors, cand)  # [B, R]
         kk = min(k, cand.shape[1])
         d, pos = self._topk_rows_any(exact, kk)

@@ -210,6 +210,9 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
                 const int n = __popcll(pm);
                 const int myidx = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
                 if (in) cu_hi[myidx] = khi, cu_lo[myidx] = node;
+                // (LANES talk to each other through the scratch: the compiler, which sees one thread, must not forward a lane's own
+                // store to its later load of the same address -- another lane may have written there in between)
+                asm volatile("" ::: "memory");
                 int shift[E];
 #pragma unroll
                 for (int e = 0; e < E; ++e) shift[e] = 0;
@@ -239,6 +242,7 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
                             s_mrg[128 * E + np] = L.exp[e] ? 1u : 0u;
                         }
                     }
+                    asm volatile("" ::: "memory");
                     int hbase = 0;
 #pragma unroll
                     for (int e = 0; e < E; ++e) {
@@ -312,6 +316,7 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
                 s_mrg[64 * E + mypos] = node;
                 s_mrg[128 * E + mypos] = 0u;
             }
+            asm volatile("" ::: "memory");  // (see the fast path: no store-to-load forwarding across lanes)
             // (one wave: its LDS writes are visible to its own later reads in program order)
 #pragma unroll
             for (int e = 0; e < E; ++e) {

@@ -413,8 +413,13 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
         const uint32_t *cq = cand32 + q * nc;
         const uint32_t me = cq[t - q * nc];
         int rk = 0;
-#pragma unroll 8
-        for (int j = 0; j < nc; ++j) rk += cq[j] < me;
+        // (nc = 16 k keys, 16-byte reads: the same address in every lane of a wave -- a broadcast; one key per read made this pass
+        // 46 us of the launch at k = 50)
+#pragma unroll 4
+        for (int j = 0; j < nc; j += 4) {
+            const u32x4 o = *(const u32x4 *)(cq + j);
+            rk += (o.x < me) + (o.y < me) + (o.z < me) + (o.w < me);
+        }
         const int b = g4 * 4 + h * QPB + q;
         bool publish = false;
         if constexpr (BUILD) publish = sb.seedk != nullptr && rk < k;  // (the k smallest, for the peers' union)

@@ -461,6 +461,7 @@ def main():
     # ---- recall@10 vs exact brute force (subset of the queries), ADC-only and with re-rank ---------
     recall_adc = recall_rr = None
     rr_qps = None
+    rr_global = None
     nq = min(args.recall_queries, B)
     if nq > 0:
         qs = queries[:nq]
@@ -517,6 +518,24 @@ def main():
             rr_qps = B * n_rr / rr_el
             got = rr[1][:nq].cpu().numpy()
             recall_rr = float(np.mean([len(set(got[b]) & set(truth[b])) / k for b in range(nq)]))
+            # ... and with the pool taken from the GLOBAL ADC top-50 (round 5: the shared-bound search at k = 50 runs on the
+            # byte-table kernel's 64-key lists) instead of the slices' own top-16 lists
+            rr_global = None
+            if world == 1 and M == 16:
+                index.rerank_pool = 'global'
+                index.rerank_k = 50
+                for _ in range(2):
+                    rr = sharded.search_batch(queries, limit=k)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n_rr):
+                    rr = sharded.search_batch(queries, limit=k)
+                torch.cuda.synchronize()
+                got = rr[1][:nq].cpu().numpy()
+                rr_global = {'value': B * n_rr / (time.perf_counter() - t0), 'unit': 'queries/s', 'pool': 'global ADC top-50',
+                             'recall_at_10': float(np.mean([len(set(got[b]) & set(truth[b])) / k for b in range(nq)]))}
+                index.rerank_pool = 'slices'
+                index.rerank_k = args.rerank_k or None
             index.rerank = False
 
     # ---- extra leg, never `value`: the pruned (IVF) search over the same rows (SURVEY.md 8f follow-on) --------
@@ -782,7 +801,8 @@ def main():
             # ">= 90 % recall@10" figure is the re-rank leg below
             'rerank': None if recall_rr is None else {'recall_at_10': recall_rr, 'value': rr_qps, 'unit': 'queries/s',
                                                        'candidates_per_query': 'n_slices * rerank_k per shard (rerank_k = %d: the byte-table kernel\'s 16-key lists)' % (args.rerank_k or 16),
-                                                       'answers': 'north_star recall target (>= 0.90 recall@10)'},
+                                                       'answers': 'north_star recall target (>= 0.90 recall@10)',
+                                                       'global_pool': rr_global},
             'roofline': roof,
             'cpu_baseline': cpu,
             'ivf': ivf_rec,

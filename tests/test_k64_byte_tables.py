@@ -243,3 +243,48 @@ def test_the_library_picks_it_guards_it_and_falls_back(ops, oracle, monkeypatch)
     for _ in range(3):
         d, i = idx2.search_batch(q, limit=k)
         assert np.array_equal(i, ri2) and np.array_equal(d, rd2)
+
+
+def test_rerank_pool_from_the_global_top_50(ops, oracle, monkeypatch):
+    """``PQFlatGpuIndex(rerank=True, rerank_pool='global')``: the exact re-rank takes the GLOBAL ADC top-50 (one shared-bound search
+    on the 64-key lists) instead of the slices' own top-16 lists: every returned id is one of the oracle's ADC top-50, the order
+    is the exact distances', and recall against brute force is at least the slice pool's."""
+    from annlite_amd import Metric, PQCodec, PQFlatGpuIndex
+
+    monkeypatch.delenv('ANNLITE_SCAN_VARIANT')
+    rs = np.random.RandomState(8)
+    N, D, B, k = 600_000, 128, 64, 10
+    A = rs.randn(16, D).astype(np.float32)
+    x = (rs.randn(N, 16).astype(np.float32) @ A + 0.05 * rs.randn(N, D).astype(np.float32)).astype(np.float32)
+    q = (rs.randn(B, 16).astype(np.float32) @ A + 0.05 * rs.randn(B, D).astype(np.float32)).astype(np.float32)
+    codec = PQCodec(dim=D, n_subvectors=M, n_clusters=256, metric=Metric.EUCLIDEAN, n_init=1)
+    codec.seed = 4
+    codec.fit(x[:8192], iter=5)
+    idx = PQFlatGpuIndex(dim=D, metric=Metric.EUCLIDEAN, pq_codec=codec, initial_size=N, rerank=True, rerank_pool='global')
+    idx.add_with_ids(x, np.arange(N))
+    codes = ops.codes_to_numpy(ops.pq_encode(ops.to_dev(x), codec.codebooks_dev))
+    _, pool = oracle.index_search(q, codec.codebooks, codes, oracle.EUCLIDEAN, 50, threads=oracle.max_threads())
+    d, i = idx.search_batch(q, limit=k)
+    exact = np.sqrt(((x[pool].astype(np.float64) - q[:, None, :].astype(np.float64)) ** 2).sum(-1))  # [B, 50]
+    best = np.full((B, k), np.inf)
+    best_i = np.full((B, k), -1, np.int64)
+    for c0 in range(0, N, 100_000):
+        dd = ((x[c0:c0 + 100_000, None, :] - q[None, :, :]) ** 2).sum(-1).T  # [B, chunk]
+        md = np.concatenate([best, dd], 1)
+        mi = np.concatenate([best_i, np.arange(c0, c0 + dd.shape[1])[None, :].repeat(B, 0)], 1)
+        o = np.argsort(md, axis=1)[:, :k]
+        best, best_i = np.take_along_axis(md, o, 1), np.take_along_axis(mi, o, 1)
+    for b in range(B):
+        assert set(i[b]) <= set(pool[b]), b
+        order = np.argsort(exact[b], kind='stable')[:k]
+        # the k best of the pool by exact distance (float64 here, float32 on the GPU: compare as sets unless a near-tie at the cut)
+        want = set(pool[b][order])
+        if set(i[b]) != want:
+            gap = np.sort(exact[b])[k] - np.sort(exact[b])[k - 1]
+            assert gap < 1e-4 * np.sort(exact[b])[k - 1], (b, gap)
+        assert (np.diff(d[b]) >= 0).all()
+    rec_global = np.mean([len(set(i[b]) & set(best_i[b])) / k for b in range(B)])
+    idx.rerank_pool = 'slices'
+    _, i2 = idx.search_batch(q, limit=k)
+    rec_slices = np.mean([len(set(i2[b]) & set(best_i[b])) / k for b in range(B)])
+    assert rec_global >= 0.85 and rec_global >= rec_slices - 0.03, (rec_global, rec_slices)
