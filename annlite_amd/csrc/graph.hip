@@ -122,6 +122,8 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
     // nodes and the slowest of an expansion's 32 lanes needed a dozen dependent LDS round trips.)
     // (by LDS byte address in the LDS address space: through a generic volatile pointer the bucket read was a FLAT load, and a flat
     // load counts on the vector-memory counter too -- every probe then waited for the prefetched record)
+    bool tbl_ovf = false;   // this lane has met a full stretch of the visited table
+    bool tbl_full = false;  // ... some lane of the wave has (wave-uniform, sticky)
     typedef __attribute__((address_space(3))) unsigned char *lds_bytes;
     const uint32_t hash_ad = (uint32_t)(uintptr_t)(lds_bytes)smem + (uint32_t)(wave * per_wave) + (uint32_t)(M * Ks * 4);
     auto visit = [&](uint32_t node) -> bool {
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
             }
             bk = (bk + 1) & (n_buckets - 1);
         }
+        tbl_ovf = true;  // (no room within 16 buckets: from now on a node can be evaluated twice -- the merge checks for duplicates)
         return true;
     };
     auto load_row = [&](uint32_t node, uint32_t (&c)[CW]) {
@@ -218,16 +221,28 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
                 for (int e = 0; e < E; ++e) shift[e] = 0;
                 int r = 0;
                 bool bad = false;
+                // (duplicates exist only once the visited table has overflowed: until then the equality tests are left out)
+                if (!tbl_full && __ballot(tbl_ovf)) tbl_full = true;
+                if (tbl_full) {
 #pragma unroll 2
-                for (int j = 0; j < n; ++j) {
-                    const uint32_t chi = cu_hi[j], clo = cu_lo[j];
+                    for (int j = 0; j < n; ++j) {
+                        const uint32_t chi = cu_hi[j], clo = cu_lo[j];
 #pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        shift[e] += key_less(chi, clo, L.hi[e], L.lo[e]) ? 1 : 0;
-                        bad = bad || (chi == L.hi[e] && clo == L.lo[e]);
+                        for (int e = 0; e < E; ++e) {
+                            shift[e] += key_less(chi, clo, L.hi[e], L.lo[e]) ? 1 : 0;
+                            bad = bad || (chi == L.hi[e] && clo == L.lo[e]);
+                        }
+                        r += (in && key_less(chi, clo, khi, node)) ? 1 : 0;
+                        bad = bad || (in && j != myidx && chi == khi && clo == node);
                     }
-                    r += (in && key_less(chi, clo, khi, node)) ? 1 : 0;
-                    bad = bad || (in && j != myidx && chi == khi && clo == node);
+                } else {
+#pragma unroll 2
+                    for (int j = 0; j < n; ++j) {
+                        const uint32_t chi = cu_hi[j], clo = cu_lo[j];
+#pragma unroll
+                        for (int e = 0; e < E; ++e) shift[e] += key_less(chi, clo, L.hi[e], L.lo[e]) ? 1 : 0;
+                        r += (in && key_less(chi, clo, khi, node)) ? 1 : 0;
+                    }
                 }
                 if (!__ballot(bad)) {
                     if (in) cs_hi[r] = khi, cs_lo[r] = node;
