@@ -248,7 +248,7 @@ def test_the_library_picks_it_guards_it_and_falls_back(ops, oracle, monkeypatch)
 def test_rerank_pool_from_the_global_top_50(ops, oracle, monkeypatch):
     """``PQFlatGpuIndex(rerank=True, rerank_pool='global')``: the exact re-rank takes the GLOBAL ADC top-50 (one shared-bound search
     on the 64-key lists) instead of the slices' own top-16 lists: every returned id is one of the oracle's ADC top-50, the order
-    is the exact distances', and recall against brute force is at least the slice pool's."""
+    is the exact distances', and recall against brute force is that of a 50-row pool."""
     from annlite_amd import Metric, PQCodec, PQFlatGpuIndex
 
     monkeypatch.delenv('ANNLITE_SCAN_VARIANT')
@@ -287,4 +287,6 @@ def test_rerank_pool_from_the_global_top_50(ops, oracle, monkeypatch):
     idx.rerank_pool = 'slices'
     _, i2 = idx.search_batch(q, limit=k)
     rec_slices = np.mean([len(set(i2[b]) & set(best_i[b])) / k for b in range(B)])
-    assert rec_global >= 0.85 and rec_global >= rec_slices - 0.03, (rec_global, rec_slices)
+    # (this small table plans 128 row slices for its two query tiles: the slice pool is 2048 rows and finds everything -- at the
+    # bench's 10M x 1024 it is 8 x 16 = 128 rows, see the `rerank.global_pool` leg)
+    assert rec_global >= 0.85 and rec_slices >= rec_global - 0.02, (rec_global, rec_slices)
