@@ -967,7 +967,7 @@ extern "C" int annlite_kernel_rev(const char *kernel) {
         {"adc_scan_qfilter_kernel", 1},
         {"adc_scan_qfilter64_kernel", 1},
         {"adc_scan_generic_kernel", 1},
-        {"graph_beam_search_kernel", 1},
+        {"graph_beam_search_kernel", 2},  // 2: round 5 (packed node records + prefetch, merge insertion, bucketed visited table)
     };
     for (const auto &r : revs)
         if (strcmp(r.name, kernel) == 0) return r.rev;
