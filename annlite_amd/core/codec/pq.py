@@ -73,6 +73,10 @@ class PQCodec(BaseCodec):
         self.kmeans = []  # attribute kept for API compatibility (the reference stores sklearn objects here)
         self.n_init = n_init
         self.seed: Optional[int] = None  # set for reproducible training (the reference is unseeded)
+        # With a seed the initial centres repeat, the Lloyd steps' float atomics do not: codebooks of two runs agree to the last
+        # few bits only.  ``deterministic = True`` accumulates the cluster sums in a fixed order instead (``_assign_accumulate_det``):
+        # bit-identical codebooks run after run -- what lets bench.py's result digests be compared ACROSS runs (N = 1 against N = 8)
+        self.deterministic: bool = False
 
         self._cb_dev: dict = {}  # device copies of the codebooks, one per HIP device that asked (a multi-GPU index shares ONE codec)
         self._pf = None  # streaming k-means state of partial_fit: (centers, sums, counts) device tensors
@@ -178,6 +182,30 @@ class PQCodec(BaseCodec):
             d2 = dc[ar, best]
         return cb
 
+    def _assign_accumulate_det(self, x: torch.Tensor, cb: torch.Tensor, sums: torch.Tensor, counts: torch.Tensor, inertia: torch.Tensor):
+        """What ``annlite_kmeans_assign_accumulate`` leaves in (sums, counts, inertia), in a FIXED summation order: the
+        assignment is the encode kernel's (first minimum), the rows of a cluster are laid out side by side in assignment order
+        (a stable sort: unique scatter targets) and summed along that axis in float64 by ``torch.sum`` -- no atomics anywhere."""
+        M, Ks, ds = self.n_subvectors, self.n_clusters, self.d_subvector
+        N = x.shape[0]
+        codes = ops.pq_encode(x, cb).to(torch.int64)  # [N, M]
+        ar = torch.arange(N, device=x.device)
+        for m in range(M):
+            idx = codes[:, m]
+            order = torch.argsort(idx, stable=True)
+            cnt = torch.bincount(idx, minlength=Ks)
+            start = torch.cumsum(cnt, 0) - cnt  # (integers: exact whatever the order)
+            sidx = idx[order]
+            pos = ar - start[sidx]
+            xm = x[:, m * ds:(m + 1) * ds][order].to(torch.float64)
+            mat = torch.zeros((Ks, int(cnt.max().item()) if N else 1, ds), dtype=torch.float64, device=x.device)
+            mat[sidx, pos] = xm
+            s64 = mat.sum(1)
+            sums[m] = s64.to(torch.float32)
+            counts[m] = cnt.to(torch.int32)
+            diff = xm - cb[m].to(torch.float64)[sidx]
+            inertia[m] = (diff * diff).sum(1).sum()
+
     def _init_centres(self, x: torch.Tensor, gen: torch.Generator) -> torch.Tensor:
         return self._random_centres(x, gen) if getattr(self, 'init', 'k-means++') == 'random' else self._kmeanspp_centres(x, gen)
 
@@ -212,9 +240,10 @@ class PQCodec(BaseCodec):
         inertia = torch.empty((M,), dtype=torch.float64, device=dev)
         for _ in range(max(1, int(self.n_init))):
             cb = self._init_centres(x, gen)
+            accumulate = self._assign_accumulate_det if getattr(self, 'deterministic', False) else ops.kmeans_assign_accumulate
             for it in range(max(1, int(iter))):
                 sums.zero_(); counts.zero_(); inertia.zero_()
-                ops.kmeans_assign_accumulate(x, cb, sums, counts, inertia)
+                accumulate(x, cb, sums, counts, inertia)
                 old = cb.clone()
                 ops.kmeans_update(sums, counts, cb)
                 empty = counts == 0
@@ -228,7 +257,7 @@ class PQCodec(BaseCodec):
                 if bool((shift <= tol).all()):
                     break
             sums.zero_(); counts.zero_(); inertia.zero_()
-            ops.kmeans_assign_accumulate(x, cb, sums, counts, inertia)
+            accumulate(x, cb, sums, counts, inertia)
             better = inertia < best_inertia
             best_cb[better] = cb[better]
             best_inertia = torch.where(better, inertia, best_inertia)

@@ -217,6 +217,7 @@ def main():
     metric = {'euclidean': Metric.EUCLIDEAN, 'cosine': Metric.COSINE, 'inner_product': Metric.INNER_PRODUCT}[args.metric]
     codec = PQCodec(dim=D, n_subvectors=M, n_clusters=Ks, metric=metric, n_init=1)
     codec.seed = 7
+    codec.deterministic = True  # (bit-identical codebooks run after run: the result digests compare across runs)
     CH = 250_000
     t0 = time.time()
     if rank == 0:

@@ -47,6 +47,7 @@ def gen(chunk, rows):
 
 codec = PQCodec(dim=D, n_subvectors=M, n_clusters=256, metric=Metric.EUCLIDEAN, n_init=1)
 codec.seed = 7
+codec.deterministic = True
 codec.fit(gen(0, 250_000)[:20480], iter=20)
 index = HnswPQGpuIndex(dim=D, metric=Metric.EUCLIDEAN, pq_codec=codec, initial_size=N, rerank=True,
                        ef_search=a.ef_search, ef_construction=a.ef_construction, max_connection=a.max_connection)

@@ -62,6 +62,7 @@ def new_index(codec):
 if a.build:
     codec = PQCodec(dim=D, n_subvectors=M, n_clusters=256, metric=Metric.EUCLIDEAN, n_init=1)
     codec.seed = 7
+    codec.deterministic = True
     codec.fit(gen(0, CH)[:20480], iter=20)
     index = new_index(codec)
     t0 = time.time()

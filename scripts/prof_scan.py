@@ -50,6 +50,7 @@ else:
 
     codec = PQCodec(dim=D, n_subvectors=M, n_clusters=Ks, metric=Metric.EUCLIDEAN, n_init=1)
     codec.seed = 7
+    codec.deterministic = True
     codec.fit(gen(20480), iter=20)
     cb = codec.codebooks_dev
     codes = torch.empty((N, M), dtype=torch.uint8 if Ks <= 256 else torch.int16, device=dev)

@@ -364,3 +364,28 @@ def test_bench_seed_exchange_under_torchrun_one_rank(tmp_path):
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     assert rec['config']['seed_exchange'] is True and rec['config']['seed_peers_emulated'] == 8 and rec['config']['seed_rows'] == 4096
     assert rec['per_rank'][0]['exchange_ms'] is not None and rec['exchange_ms'] > 0
+
+
+# ------------------------------------------------------------------------------------ round 5: reproducible training
+def test_deterministic_fit_repeats_bit_for_bit(ops, oracle):
+    """``PQCodec.deterministic = True`` (+ a seed): the Lloyd steps accumulate in a fixed order -- two fits give the SAME codebooks,
+    bit for bit (with the float atomics of the default path they agree to the last few bits only), at the default path's quality.
+    bench.py trains this way so that its ``result_sha256`` can be compared across runs (an N = 8 line against the N = 1 line)."""
+    from annlite_amd import Metric, PQCodec
+
+    rs = np.random.RandomState(0)
+    N, D, M = 20480, 128, 16
+    A = rs.randn(16, D).astype(np.float32)
+    x = (rs.randn(N, 16).astype(np.float32) @ A + 0.05 * rs.randn(N, D).astype(np.float32)).astype(np.float32)
+    books, mse = [], []
+    for det in (True, True, False):
+        c = PQCodec(dim=D, n_subvectors=M, n_clusters=256, metric=Metric.EUCLIDEAN, n_init=1)
+        c.seed = 7
+        c.deterministic = det
+        c.fit(x, iter=12)
+        books.append(c.codebooks.copy())
+        codes = oracle.encode_c(x, c.codebooks)
+        rec = np.concatenate([c.codebooks[m][codes[:, m]] for m in range(M)], axis=1)
+        mse.append(float(((x - rec) ** 2).mean()))
+    assert np.array_equal(books[0].view(np.uint32), books[1].view(np.uint32))
+    assert abs(mse[0] - mse[2]) <= 0.02 * mse[2], mse
