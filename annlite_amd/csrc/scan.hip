@@ -871,6 +871,8 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 ANNLITE_HIP_TRY(hipMemset(g_clk, 0, 32));
             }
             a.clk = g_clk;
+        } else if (g_prof_on && g_clk && !(gopt && gopt->gate)) {
+            ANNLITE_HIP_TRY(hipMemsetAsync(g_clk, 0, 32, st));  // (another kernel serves this launch: no stale stamps)
         }
         if (const char *e = getenv("ANNLITE_EARLY_MERGE_PATIENCE")) a.q8_merge_patience = (uint32_t)atoll(e);
         const bool bracket = !(gopt && gopt->gate);  // (measurement hooks: the launch that does the work, not the gated pass)

@@ -389,3 +389,45 @@ def test_deterministic_fit_repeats_bit_for_bit(ops, oracle):
         mse.append(float(((x - rec) ** 2).mean()))
     assert np.array_equal(books[0].view(np.uint32), books[1].view(np.uint32))
     assert abs(mse[0] - mse[2]) <= 0.02 * mse[2], mse
+
+
+def test_measured_shader_clock_and_kernel_revisions(ops, oracle):
+    """bench.py's evidence hooks: the byte-table kernel leaves its own cycle / wall-clock stamps when profiling is on -- a plausible
+    MI355X shader clock --, another kernel's launch says "none"; ``annlite_kernel_rev`` knows the kernels profiles/traffic.json
+    records and every recorded entry names a revision."""
+    import json
+    import os
+
+    import torch
+    from annlite_amd import _capi
+    from annlite_amd._capi import LUT_L2
+    from conftest import ROOT
+
+    rs = np.random.RandomState(3)
+    N, M, dsub, Ks, B, k = 300_000, 16, 8, 256, 64, 10
+    cb = rs.randn(M, Ks, dsub).astype(np.float32)
+    base = rs.randint(0, Ks, size=(2000, M)).astype(np.uint8)
+    codes = base[rs.randint(0, 2000, N)]
+    q = rs.randn(B, M * dsub).astype(np.float32)
+    cb_d, q_d, codes_d = ops.to_dev(cb), ops.to_dev(q), ops.to_dev(codes)
+    _capi.profile_enable(True)
+    try:
+        os.environ['ANNLITE_SCAN_VARIANT'] = '50'
+        ops.pq_search_topk(LUT_L2, q_d, cb_d, codes_d, k, M, Ks)
+        torch.cuda.synchronize()
+        ms, mhz = _capi.profile_last_scan_ms(), _capi.profile_last_scan_clock_mhz()
+        assert ms > 0 and mhz is not None and 800.0 < mhz < 2600.0, (ms, mhz)
+        os.environ['ANNLITE_SCAN_VARIANT'] = '31'  # the u16-table kernel: no stamps of its own
+        ops.pq_search_topk(LUT_L2, q_d, cb_d, codes_d, k, M, Ks)
+        torch.cuda.synchronize()
+        assert _capi.profile_last_scan_ms() > 0 and _capi.profile_last_scan_clock_mhz() is None
+    finally:
+        os.environ.pop('ANNLITE_SCAN_VARIANT', None)
+        _capi.profile_enable(False)
+    for name in ('adc_scan_q8_kernel', 'adc_scan_qfilter_kernel', 'adc_scan_qfilter64_kernel', 'graph_beam_search_kernel'):
+        assert _capi.kernel_rev(name) >= 1
+    assert _capi.kernel_rev('no_such_kernel') == 0
+    table = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+    for key, ent in table.items():
+        if isinstance(ent, dict):
+            assert isinstance(ent.get('kernel_rev'), int) and ent['hbm_bytes_per_launch'] > 0, key
