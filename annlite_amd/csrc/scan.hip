@@ -768,7 +768,12 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                     // 64-key lists: a slice publishes the keys at four list positions, ~0.64 / 0.96 / 1.28 / 1.92 of its share k / G of
                     // the k best rows (8 slices, k = 50: positions 4, 6, 8, 12 -- the weighted bound sits near rank 56; q8_weighted_bound)
                     const double share = (double)k / (double)grp;
-                    const double f[4] = {0.64, 0.96, 1.28, 1.92};
+                    double f[4] = {0.64, 0.96, 1.28, 1.92};
+                    if (const char *e = getenv("ANNLITE_Q8_POS")) {  // "f0,f1,f2,f3" (measurements)
+                        double g[4];
+                        if (sscanf(e, "%lf,%lf,%lf,%lf", &g[0], &g[1], &g[2], &g[3]) == 4 && g[0] > 0 && g[0] < g[1] && g[1] < g[2] && g[2] < g[3] && g[3] >= 1.0)
+                            for (int i = 0; i < 4; ++i) f[i] = g[i];
+                    }
                     int prev = 0;
                     a.q8_pos = 0;
                     for (int i = 0; i < 4; ++i) {
