@@ -687,6 +687,9 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         a.q8_epoch_mul = 16;
         a.q8_ring_limit = 384;
         a.q8_import_mask = 3;
+        // (64-key lists: an import ranks 32 published keys per slot -- every 8th batch instead of every 4th: 1.79 against 1.87 ms at
+        // k = 50, 10M rows; every 2nd 1.89, every 16th 1.84 -- profiles/r05/k50_knobs.txt)
+        if (c.mode == 5 && k > 16) a.q8_import_mask = 7;
         // (M = 64: u16 sums of 64 entries clipped at 15.  10M x 768-d, 256 queries, ms per launch at T = 256 / 384 / 512 / 768: 2.09 / 2.04 /
         // 2.03 / 3.54 -- a finer table clips more entries of a row near the bound: at 768 the filter leaks)
         a.q8_target = M == 64 ? 512 : 96;

@@ -407,16 +407,40 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
         asm volatile("" ::: "memory");  // (the next query's keys go into the same 64 slots: after these reads)
     }
     __syncthreads();
-    // the k-th smallest of every query's 16*k candidates, same way
-    for (int t = tid; t < QPB * nc; t += kSeedWaves * 64) {
-        const int q = t / nc;
-        const uint32_t *cq = cand32 + q * nc;
-        const uint32_t me = cq[t - q * nc];
-        int rk = 0;
-        // (nc = 16 k keys, 16-byte reads: the same address in every lane of a wave -- a broadcast; one key per read made this pass
-        // 46 us of the launch at k = 50)
+    // k > 16 (the byte-table kernel's 64-key lists, round 5): ranking all 16 k candidates against each other is 16 k x 16 k
+    // comparisons per query -- 48 us of the launch at k = 50, VALU-bound.  One level in between: the candidates of FOUR waves (4 k,
+    // contiguous) are ranked among themselves and their k smallest go on (the k smallest of all are among them): 4 x (4 k)^2 +
+    // (4 k)^2 comparisons instead of (16 k)^2.  (The waves' key slots behind the candidates are free after the barrier.)
+    const uint32_t *sel = cand32;
+    int nsel = nc;
+    if (k > 16) {
+        uint32_t *st2 = (uint32_t *)((unsigned char *)cand + kSeedWkeyOff);  // [QPB][4 groups][k]
+        const int n4 = 4 * k;
+        for (int t = tid; t < QPB * nc; t += kSeedWaves * 64) {
+            const int q = t / nc, idx = t - q * nc, g = idx / n4;
+            const uint32_t *cg = cand32 + q * nc + g * n4;
+            const uint32_t me = cand32[t];
+            int rk = 0;
 #pragma unroll 4
-        for (int j = 0; j < nc; j += 4) {
+            for (int j = 0; j < n4; j += 4) {
+                const u32x4 o = *(const u32x4 *)(cg + j);
+                rk += (o.x < me) + (o.y < me) + (o.z < me) + (o.w < me);
+            }
+            if (rk < k) st2[(q * 4 + g) * k + rk] = me;
+        }
+        __syncthreads();
+        sel = st2;
+        nsel = n4;
+    }
+    // the k-th smallest of every query's candidates (16 k of them, or the 4 k that came through the level above), same way
+    for (int t = tid; t < QPB * nsel; t += kSeedWaves * 64) {
+        const int q = t / nsel;
+        const uint32_t *cq = sel + q * nsel;
+        const uint32_t me = cq[t - q * nsel];
+        int rk = 0;
+        // (16-byte reads: the same address in every lane of a wave -- a broadcast)
+#pragma unroll 4
+        for (int j = 0; j < nsel; j += 4) {
             const u32x4 o = *(const u32x4 *)(cq + j);
             rk += (o.x < me) + (o.y < me) + (o.z < me) + (o.w < me);
         }
