@@ -570,6 +570,8 @@ static int graph_search_impl(const uint32_t *links_dev, const uint8_t *packed_de
     // 1.5x the speed -- 5 instead of 3 waves per CU), 8192 beyond; a full table only costs re-evaluations (see visit)
     int hash_bits = ef <= 128 ? 12 : 13;
     if (const char *e = getenv("ANNLITE_GRAPH_HASH_BITS")) hash_bits = atoi(e);
+    if (hash_bits < 4) hash_bits = 4;    // (buckets of four entries, 16-byte initialisation)
+    if (hash_bits > 15) hash_bits = 15;  // (128 KB: what is left of the LDS beside the smallest table)
     const uint8_t *codes = (const uint8_t *)codes_dev;
     unsigned long long *stats = nullptr;
     if (getenv("ANNLITE_DEBUG_COUNTERS")) {
