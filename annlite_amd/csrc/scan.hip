@@ -411,8 +411,13 @@ static int64_t pad_queries(int64_t B, int qt) {
     return ((B + p - 1) / p) * p;
 }
 
+// m32_bytes: the byte-table plan of M = 32 (64 tiles of 16 queries at 1024 queries): at >= 8M rows 8 slices instead of the 4 one
+// work item per CU gives -- two work items per workgroup -- so that the slice-per-XCD map applies (an XCD streams an eighth of the
+// 32-byte rows for all tiles instead of the whole table for its own: -2 % at 10M rows, profiles/r05/m32_8_slices_xcd_map_ab.txt)
+static bool m32_wants_8_slices(int64_t N, int n_tiles) { return N >= 8000000 && n_tiles >= 32 && n_tiles <= 128; }
+
 static void plan_slices(int64_t N, int n_tiles, int waves, int n_cu, bool xcd8, int *n_slices, int64_t *slice_rows,
-                        int64_t B = 0) {
+                        int64_t B = 0, bool m32_bytes = false) {
     // at least one slice per XCD; more when few query tiles exist, as long as every wave keeps
     // >= 8 steps of 64 rows
     const int64_t min_rows = (int64_t)waves * 64 * (xcd8 ? 16 : 8);
@@ -428,6 +433,7 @@ static void plan_slices(int64_t N, int n_tiles, int waves, int n_cu, bool xcd8, 
     int64_t ns = want;
     if (xcd8) ns = want <= 1 ? 1 : want <= 2 ? 2 : want <= 4 ? 4 : ((want + 7) / 8) * 8;
     if (ns < 1) ns = 1;
+    if (xcd8 && m32_bytes && ns == 4 && m32_wants_8_slices(N, n_tiles)) ns = 8;
     if (xcd8) {
         if (const char *e = getenv("ANNLITE_SCAN_SLICES")) {
             const int64_t v = atoll(e);
@@ -470,7 +476,7 @@ static int plan_query_impl(int64_t N, int64_t M, int64_t Ks, int code_bytes, int
         const int n_tiles = (int)((B + plan->qt - 1) / plan->qt);
         int ns;
         int64_t sr;
-        plan_slices(N > 0 ? N : 1, n_tiles > 0 ? n_tiles : 1, c.NW, n_cu, true, &ns, &sr, B);
+        plan_slices(N > 0 ? N : 1, n_tiles > 0 ? n_tiles : 1, c.NW, n_cu, true, &ns, &sr, B, c.mode == 5 && M == 32 && force_ns == 0);
         if (force_ns > 0) ns = force_ns;
         plan->n_slices = ns;
         plan->lut_floats = ((B + 15) / 16) * 16 * M * Ks;  // padded to 16 queries
@@ -637,7 +643,9 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
     {
         int ns;
         int64_t sr;
-        plan_slices(N > 0 ? N : 1, a.n_tiles, plan.waves, n_cu, plan.fast != 0, &ns, &sr, B);
+        FastCfg cs;
+        const bool m32_bytes = plan.fast && !tm && M == 32 && fast_cfg(M, Ks, code_bytes, k, &cs, false) && cs.mode == 5;
+        plan_slices(N > 0 ? N : 1, a.n_tiles, plan.waves, n_cu, plan.fast != 0, &ns, &sr, B, m32_bytes);
         a.slice_rows = tm ? ((N + 63) / 64) * 64 : sr;
     }
     // slots of slices that hold no rows stay "none"
@@ -675,7 +683,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         // M = 64 (64-byte rows: 640 MB at 10M rows): tile-per-XCD makes every XCD stream the whole table (FETCH_SIZE 6.2 GB per
         // launch, 36 % of the HBM peak, L2 hit rate 71 %) and its candidates are few -- slice-per-XCD instead: an XCD streams its
         // row slices once for all the query tiles that walk them together.  ANNLITE_Q8_MAP=0/1 overrides (A/B).
-        a.q8_map_slices = (M == 64) ? 1 : 0;
+        a.q8_map_slices = (M == 64 || (M == 32 && c.mode == 5 && a.n_slices == 8 && m32_wants_8_slices(N, a.n_tiles))) ? 1 : 0;
         if (const char *e = getenv("ANNLITE_Q8_MAP")) a.q8_map_slices = atoi(e) ? 1 : 0;
         if (a.n_slices < 8) a.q8_map_slices = 0;
         if (c.mode == 5 && a.n_tiles >= 8 && !a.q8_map_slices) a.n_items = 8 * ((a.n_tiles + 7) / 8) * a.n_slices;  // q8_item_map
