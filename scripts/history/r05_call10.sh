@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Round 5, GPU call 10: knobs of the k = 50 scan (import frequency, published positions, slices) and of the graph walk (visited-table size), one box.
 set -u
-cd "$(dirname "$0")/.."; OUT=gpurun_out/r05c10; mkdir -p $OUT
+cd "$(dirname "$0")/../.."; OUT=gpurun_out/r05c10; mkdir -p $OUT
 P="--rows 10000000 --data lowrank --fused --valid --iters 8 --k 50"
 run() { tag=$1; shift; env "$@" ANNLITE_SCAN_VARIANT=50 timeout 90 python scripts/prof_scan.py $P 2>&1 | grep -v "^/opt" | head -3 | tr '\n' ' ' > $OUT/k50_$tag.txt; echo "k50 $tag: $(cut -c1-200 $OUT/k50_$tag.txt)"; }
 run base X=1

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Round 5, GPU call 11: two-level seed selection for k > 16 + import every 8th batch: tests, k = 50 / 64 / 20 timings, preparation timeline.
 set -u
-cd "$(dirname "$0")/.."; OUT=gpurun_out/r05c11; mkdir -p $OUT
+cd "$(dirname "$0")/../.."; OUT=gpurun_out/r05c11; mkdir -p $OUT
 timeout 600 python -m pytest tests/test_k64_byte_tables.py tests/test_round4_gpu.py -x -q -m gpu > $OUT/pytest_k64_r4.txt 2>&1; echo "k64 + round4 rc=$?"; tail -3 $OUT/pytest_k64_r4.txt
 timeout 400 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "random_shapes or ties or topk" > $OUT/pytest_parity_k.txt 2>&1; echo "parity rc=$?"; tail -3 $OUT/pytest_parity_k.txt
 P="--rows 10000000 --data lowrank --fused --valid --iters 8"

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Round 5, GPU call 19: M = 32 byte-table plan with 8 slices + slice-per-XCD map at >= 8M rows: tests, the m32 leg's own command (parity of every query), timing.
 set -u
-cd "$(dirname "$0")/.."; OUT=gpurun_out/r05c19; rm -rf gpurun_out/*; mkdir -p $OUT
+cd "$(dirname "$0")/../.."; OUT=gpurun_out/r05c19; rm -rf gpurun_out/*; mkdir -p $OUT
 timeout 400 python -m pytest tests/test_m32_byte_tables.py tests/test_m32_addressing.py -x -q > $OUT/pytest_m32.txt 2>&1; echo "m32 tests rc=$?"; tail -3 $OUT/pytest_m32.txt
 timeout 300 python bench.py --m 32 --legs none --steps 20 --warmup 5 --cpu-queries 16 --cpu-repeats 3 --recall-queries 32 --streams 2 --query-batches 2 > $OUT/bench_m32_leg.json 2>/dev/null; echo "bench rc=$?"
 python - <<'PY'

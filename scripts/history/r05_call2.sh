@@ -2,7 +2,7 @@
 # Round 5, GPU call 2: the packed graph walk (tests + config 5 at 5M rows, packed against plain on one box), the new parity cases
 # (example shapes, early-merger patience) -- each step under its own timeout.
 set -u
-cd "$(dirname "$0")/.."; OUT=gpurun_out/r05c2; mkdir -p $OUT
+cd "$(dirname "$0")/../.."; OUT=gpurun_out/r05c2; mkdir -p $OUT
 timeout 300 python -m pytest tests/test_graph_packed.py -x -q > $OUT/pytest_graph_packed.txt 2>&1; echo "graph_packed rc=$?"; tail -3 $OUT/pytest_graph_packed.txt
 timeout 400 python -m pytest tests/test_gpu_parity.py tests/test_round4_gpu.py -x -q -m gpu -k "example_shapes or random_shapes or vs_fixture or fixture or early_merger or config5 or hnsw" > $OUT/pytest_new_cases.txt 2>&1; echo "new cases rc=$?"; tail -3 $OUT/pytest_new_cases.txt
 timeout 600 python scripts/bench_hnsw.py --rows 5000000 --steps 5 > $OUT/bench_hnsw_5m.json 2>$OUT/bench_hnsw_5m.err; echo "bench_hnsw rc=$?"

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Round 5, GPU call 23: where the M = 32 rule (8 slices + slice-per-XCD) stops paying: 5M and 2.5M rows, interleaved on one box
 set -u
-cd "$(dirname "$0")/.."; rm -rf gpurun_out/*; mkdir -p gpurun_out/r05c23
+cd "$(dirname "$0")/../.."; rm -rf gpurun_out/*; mkdir -p gpurun_out/r05c23
 for rows in 5000000 2500000; do
   P="--rows $rows --m 32 --dsub 4 --data lowrank --fused --valid --iters 12"
   for rep in 1 2; do

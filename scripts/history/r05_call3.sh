@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Round 5, GPU call 3: the graph walk with merge insertion (tests: packed / plain / one-at-a-time agree) and config 5 at 5M rows.
 set -u
-cd "$(dirname "$0")/.."; OUT=gpurun_out/r05c3; mkdir -p $OUT
+cd "$(dirname "$0")/../.."; OUT=gpurun_out/r05c3; mkdir -p $OUT
 timeout 400 python -m pytest tests/test_graph_packed.py -x -q > $OUT/pytest_graph_packed.txt 2>&1; echo "graph_packed rc=$?"; tail -3 $OUT/pytest_graph_packed.txt
 timeout 400 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "config5 or hnsw or graph" > $OUT/pytest_graph_cases.txt 2>&1; echo "graph cases rc=$?"; tail -3 $OUT/pytest_graph_cases.txt
 timeout 600 python scripts/bench_hnsw.py --rows 5000000 --steps 5 > $OUT/bench_hnsw_5m.json 2>$OUT/bench_hnsw_5m.err; echo "bench_hnsw rc=$?"

@@ -2,7 +2,7 @@
 # Round 5, GPU call 4: 16 < k <= 64 on the byte-table kernel (64-key lists): tests, k = 50 at 10M rows against the u16 tables;
 # the graph walk with the bucketed visited table + phase cycles.
 set -u
-cd "$(dirname "$0")/.."; OUT=gpurun_out/r05c4; mkdir -p $OUT
+cd "$(dirname "$0")/../.."; OUT=gpurun_out/r05c4; mkdir -p $OUT
 timeout 600 python -m pytest tests/test_k64_byte_tables.py -x -q > $OUT/pytest_k64.txt 2>&1; echo "k64 rc=$?"; tail -5 $OUT/pytest_k64.txt
 P="--rows 10000000 --data lowrank --fused --valid --iters 8"
 ANNLITE_SCAN_VARIANT=50 timeout 90 python scripts/prof_scan.py $P --k 50 2>&1 | grep -v "^/opt" | head -3 > $OUT/scan_10m_k50_q8lk64.txt

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Round 5, GPU call 5: graph walk with the rank-count merge + LDS-addressed visited table; k64 tests with the scaled guard.
 set -u
-cd "$(dirname "$0")/.."; OUT=gpurun_out/r05c5; mkdir -p $OUT
+cd "$(dirname "$0")/../.."; OUT=gpurun_out/r05c5; mkdir -p $OUT
 timeout 300 python -m pytest tests/test_graph_packed.py -x -q > $OUT/pytest_graph_packed.txt 2>&1; echo "graph_packed rc=$?"; tail -3 $OUT/pytest_graph_packed.txt
 timeout 600 python -m pytest tests/test_k64_byte_tables.py -x -q > $OUT/pytest_k64.txt 2>&1; echo "k64 rc=$?"; tail -3 $OUT/pytest_k64.txt
 timeout 400 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "config5 or hnsw or graph" > $OUT/pytest_graph_cases.txt 2>&1; echo "graph cases rc=$?"; tail -3 $OUT/pytest_graph_cases.txt

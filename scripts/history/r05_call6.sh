@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Round 5, GPU call 6: the whole GPU suite on the current tree; k = 50 whole-call time (vectorised seed selection); config 5.
 set -u
-cd "$(dirname "$0")/.."; OUT=gpurun_out/r05c6; mkdir -p $OUT
+cd "$(dirname "$0")/../.."; OUT=gpurun_out/r05c6; mkdir -p $OUT
 timeout 600 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.txt 2>&1; echo "suite rc=$?"; tail -4 $OUT/pytest_gpu.txt
 P="--rows 10000000 --data lowrank --fused --valid --iters 8"
 timeout 90 python scripts/prof_scan.py $P --k 50 2>&1 | grep -v "^/opt" | head -3 > $OUT/scan_10m_k50_library_choice.txt

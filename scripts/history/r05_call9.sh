@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Round 5, GPU call 9: deterministic training -- the result digest of the same workload must repeat across processes, streams and the forced exchange.
 set -u
-cd "$(dirname "$0")/.."; OUT=gpurun_out/r05c9; mkdir -p $OUT
+cd "$(dirname "$0")/../.."; OUT=gpurun_out/r05c9; mkdir -p $OUT
 timeout 200 python -m pytest tests/test_round4_gpu.py -x -q -m gpu -k "deterministic_fit" > $OUT/pytest_det.txt 2>&1; echo "det rc=$?"; tail -3 $OUT/pytest_det.txt
 A="--rows 1250000 --legs none --cpu-queries 16 --recall-queries 0 --no-rerank --steps 40 --warmup 8"
 timeout 200 python bench.py $A --streams 1 > $OUT/digest_run1_s1.json 2>/dev/null
