@@ -814,6 +814,14 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 // 8k / 16k / 32k / 64k seed rows, 10M rows 1.852 / 1.838 / 1.831 / 1.857
                 if (c.mode == 5 && M != 64)  // (M = 64: two queries per seed workgroup, 63 us per 8192 rows)
                     S = N / 32 < 8192 ? 8192 : N / 32 > 32768 ? 32768 : ((N / 32 + 1023) / 1024) * 1024;
+                // 64-key lists (16 < k <= 64): the seed bound's rank in the table is k N / S -- the 32768 rows were tuned at k = 10; at
+                // k = 50 they leave the first epochs consumer-bound (wave 0 waits 190 us at the epoch ends of a 10M-row launch, 40 us
+                // with 131072 rows).  10M rows x 1024 queries, whole call at 32k / 64k / 128k / 256k seed rows: 1.836 / 1.764 / 1.71 /
+                // 1.697 ms (profiles/r05/k50_seed_rows.txt): S x ceil(k / 16), at most a sixteenth of the table
+                if (c.mode == 5 && k > 16) {
+                    const int64_t s2 = S * ((k + 15) / 16), cap = N / 16 > S ? N / 16 : S;
+                    S = ((s2 < cap ? s2 : cap) + 1023) / 1024 * 1024;
+                }
                 if (const char *e = getenv("ANNLITE_SEED_ROWS")) S = atoll(e);
                 if (split && split->seed_rows > 0) S = split->seed_rows;  // (a rank of a row-sharded search: its share of the seed rows)
                 if (S > N) S = N;
