@@ -827,6 +827,13 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 if (S > N) S = N;
                 if (S < 0) S = 0;  // (ANNLITE_SEED_ROWS=0: the scan starts without a bound)
             }
+            // the S seed rows are 64-row blocks spread evenly over the table (ANNLITE_SEED_CONTIGUOUS=1: its first S rows -- A/B switch)
+            const int64_t seed_extent = getenv("ANNLITE_SEED_CONTIGUOUS") ? S : N;
+            // with a first bound from rows spread over the whole table the early epoch end only costs its barrier (ms per batch with the
+            // first end after step 15 / 255 / never: 1.25M rows 0.2387 / 0.2339 / 0.2338, 1M rows 0.2157 / 0.2099 / 0.2099, 10M rows 1.352 /
+            // 1.347 / 1.342 -- profiles/r05/epoch_schedule_sweep.txt): the first end moves to step 255; the early one stays where the
+            // scan starts without such a bound
+            if (c.mode == 5 && S >= 8192 && seed_extent > S && !getenv("ANNLITE_Q8_TUNE")) a.q8_epoch0 = 255;
             // byte-table plan behind annlite_pq_search_topk: tables, parameters, reset and seed bound in ONE launch
             const bool one_prep = c.mode == 5 && build && S > 0 && M == 16 && build->D <= 256 && ((build->D / M) % 4) == 0 &&
                                   !getenv("ANNLITE_NO_FUSED_SEED");
@@ -846,7 +853,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                     gseed0 = (unsigned long long *)carve(bpad * 8);
                     btab = (uint8_t *)carve((int64_t)a.n_tiles * Ks * 2 * M * 16);  // (inside the region the u16 plan uses for q16)
                 }
-                rc = launch_seed_build(codes_layout == ANNLITE_CODES_SKEWED, codes_dev, S, valid_bits_dev, *build, const_cast<float *>(lut_dev),
+                rc = launch_seed_build(codes_layout == ANNLITE_CODES_SKEWED, codes_dev, S, seed_extent, valid_bits_dev, *build, const_cast<float *>(lut_dev),
                                        B, Ks, k, qstep, qlo, smax, qlom, gk, workspace_dev, fill_bytes, (size_t)(((bpad * 8 + 255) / 256) * 256), st,
                                        gseed0, btab, a.q8_target, a.dbg ? g_dbg_prep : nullptr, split ? split->seed_keys : nullptr);
                 if (rc != ANNLITE_OK) return rc;
@@ -860,7 +867,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 if (rc != ANNLITE_OK) return rc;
                 if (S > 0) {
                     rc = launch_seed_bound(M, codes_layout == ANNLITE_CODES_SKEWED, codes_dev, code_bytes, S, valid_bits_dev, lut_dev,
-                                           B, Ks, k, smax, gk, st, 0, 1, 0, 0, gate);
+                                           B, Ks, k, smax, gk, st, seed_extent, 1, 0, 0, gate);
                     if (rc != ANNLITE_OK) return rc;
                 }
             }

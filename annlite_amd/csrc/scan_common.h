@@ -352,7 +352,7 @@ int launch_seed_bound(int64_t M, bool skewed, const void *codes_dev, int code_by
 // byte-table plan: table build + quantisation parameters + workspace reset + seed bound in one launch (scan_prep.hip)
 // gseed0 / btab (optional, both or none): the seed keys kept aside and the byte tables of every query tile quantised for them
 // with `target` (ScanArgs::q8_target); dbg (optional): 8 phase stamps of the first and the last workgroup
-int launch_seed_build(bool skewed, const void *codes_dev, int64_t S, const uint32_t *valid_bits_dev, const LutBuild &build,
+int launch_seed_build(bool skewed, const void *codes_dev, int64_t S, int64_t N, const uint32_t *valid_bits_dev, const LutBuild &build,
                       float *lut_out, int64_t B, int64_t Ks, int64_t k, float *qstep, double *qlo, float *smax, float *qlom,
                       unsigned long long *gkey, void *fill, size_t fill_bytes, size_t gkey_bytes, hipStream_t st,
                       unsigned long long *gseed0 = nullptr, uint8_t *btab = nullptr, int target = 0,

@@ -125,6 +125,7 @@ struct SeedBuild {
     unsigned long long *gseed0;  // [..] the seed key of every query, kept aside (gkey itself is lowered by the scan)
     uint8_t *btab;               // [n_tiles][Ks][2][16][16 B]: this workgroup writes its queries' dword of every entry
     int32_t target;              // T of a freshly built table (ScanArgs::q8_target)
+    int32_t chunk_log;           // (any launch) the seed rows come in runs of 2^chunk_log blocks of 64 rows (seed_chunk_log())
     unsigned long long *seedk;   // optional [B][kSeedKeys]: the bounds implied by the seed's k smallest rows, ascending -- what
                                  // the OTHER ranks of a row-sharded search may prune with (annlite_pq_search_split)
     unsigned long long *dbg;     // optional: wall-clock stamps (100 MHz) of workgroup 0 [0..3] and the last one [4..7]:
@@ -154,11 +155,19 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
         }
     };
     stamp(0);
-    // blockIdx.y = row slice (per-slice bounds of the candidate generator: rows [y * seed_stride, + S), bound ->
-    // gkey[y * gkey_stride + b]; seed_stride is a multiple of 64, so the lanes keep their skew residues); one slice: the first S rows
+    // blockIdx.y = row slice (per-slice bounds of the candidate generator: S rows of [y * seed_stride, + seed_stride), bound ->
+    // gkey[y * gkey_stride + b]; seed_stride is a multiple of 64, so the lanes keep their skew residues); one slice: S rows of
+    // the table.  The S rows are ceil(S / 64) blocks of 64 rows in runs of 2^chunk_log blocks spread EVENLY over the extent (block j =
+    // rows [(j >> chunk_log) * run_step + (j mod 2^chunk_log) * 64, + 64)): a table filled in cluster order has an
+    // unrepresentative head, and a bound from it alone leaves the byte tables coarse for the whole scan (1.25M rows ordered along
+    // one latent direction: 0.645 ms per 1024-query batch seeded from the head, 0.330 from spread rows; 10M rows 3.11 / 1.44 --
+    // profiles/r05/seed_rows_spread.txt).  Any subset of the valid rows gives a correct bound.
+    int64_t ext;
     {
         const int64_t base = (int64_t)blockIdx.y * seed_stride;
-        if (base + S > N) S = N - base;
+        ext = N - base;
+        if (seed_stride > 0 && seed_stride < ext) ext = seed_stride;
+        if (S > ext) S = ext;
         if (S <= 0) return;
         codes += base * M * (CODE16 ? 2 : 1);
         if (valid) valid += base >> 5;
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
     // the code bytes (and validity word) of a lane's NEXT row are fetched while the current one is summed: the loop was
     // bound by one dependent global round trip per iteration (12.7 us per 8192 rows; the look-ups need ~4)
     auto fetch = [&](int64_t r, uint32_t (&cc)[CW], uint32_t &vw) {
-        const int64_t rr = r < S ? r : S - 1;
+        const int64_t rr = r < ext ? r : ext - 1;
         const uint32_t *p = (const uint32_t *)(codes + rr * M * (CODE16 ? 2 : 1));
 #pragma unroll
         for (int i = 0; i < CW; ++i) cc[i] = p[i];
@@ -330,18 +339,23 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
         return v;
     };
     const uint32_t n_blocks = (uint32_t)((S + 63) >> 6);
+    const int clog = sb.chunk_log;
+    const uint32_t cmask = (1u << clog) - 1u;
+    int64_t run_step = ((ext >> 6) / ((n_blocks + cmask) >> clog)) << 6;  // rows between the starts of two runs of seed blocks
+    if (run_step < ((int64_t)64 << clog)) run_step = (int64_t)64 << clog;
+    auto block_row = [&](uint32_t b) -> int64_t { return (int64_t)(b >> clog) * run_step + (int64_t)((b & cmask) << 6); };
     uint32_t b_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)draw_block());
     uint32_t b_pend = draw_block();
-    fetch((int64_t)b_cur * 64 + lane, cn, vn);
+    fetch(block_row(b_cur) + lane, cn, vn);
     uint32_t b_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_pend);
     while (b_cur < n_blocks) {
-        const int64_t r = (int64_t)b_cur * 64 + lane;
+        const int64_t r = block_row(b_cur) + lane;
         b_pend = draw_block();
-        bool ok = r < S && ((vn >> (r & 31)) & 1u);
+        bool ok = r < ext && ((vn >> (r & 31)) & 1u);
         uint32_t c[CW];
 #pragma unroll
         for (int i = 0; i < CW; ++i) c[i] = cn[i];
-        fetch((int64_t)b_nxt * 64 + lane, cn, vn);
+        fetch(block_row(b_nxt) + lane, cn, vn);
         if constexpr (M == 64) {
             if constexpr (SKEWED) {
 #pragma unroll
@@ -870,12 +884,21 @@ int annlite::launch_lut_quantise(int64_t M, int64_t Ks, int64_t B, int64_t bpad,
     return launch_status("lut_quantise_fused_kernel");
 }
 
+// runs of 8 blocks (512 rows: 8 KB of 16-byte code rows) keep the seed launch's scattered reads to a page per run
+// (ANNLITE_SEED_CHUNK_LOG=0..6: measurements)
+static int seed_chunk_log() {
+    const char *e = getenv("ANNLITE_SEED_CHUNK_LOG");
+    const int t = e ? atoi(e) : 3;
+    return t < 0 ? 0 : t > 6 ? 6 : t;
+}
+
 int annlite::launch_seed_bound(int64_t M, bool skw, const void *codes_dev, int code_bytes, int64_t S, const uint32_t *valid_bits_dev,
                                const float *lut_dev, int64_t B, int64_t Ks, int64_t k, const float *smax,
                                unsigned long long *gk, hipStream_t st, int64_t N, int n_seed_slices, int64_t seed_stride,
                                int64_t gkey_stride, const unsigned int *gate) {
     SeedBuild nob = {};
     nob.gate = gate;
+    nob.chunk_log = seed_chunk_log();
     const unsigned ny = (unsigned)(n_seed_slices > 0 ? n_seed_slices : 1);
     const int gstride = (int)gkey_stride;
     if (N <= 0) N = S;
@@ -909,8 +932,8 @@ int annlite::launch_seed_bound(int64_t M, bool skw, const void *codes_dev, int c
 
 // The byte-table plan's whole preparation in ONE launch (M = 16, L2 tables, sub-vectors of a multiple of 4 floats, D <= 256):
 // tables of every group of 4 queries built into LDS + global memory, quantisation parameters, reset of the lists / bounds,
-// seed bound from the first S rows.
-int annlite::launch_seed_build(bool skw, const void *codes_dev, int64_t S, const uint32_t *valid_bits_dev, const LutBuild &build,
+// seed bound from S rows spread over the table's N (N <= 0: its first S).
+int annlite::launch_seed_build(bool skw, const void *codes_dev, int64_t S, int64_t N, const uint32_t *valid_bits_dev, const LutBuild &build,
                                float *lut_out, int64_t B, int64_t Ks, int64_t k, float *qstep, double *qlo, float *smax, float *qlom,
                                unsigned long long *gk, void *fill, size_t fill_bytes, size_t gk_bytes, hipStream_t st,
                                unsigned long long *gseed0, uint8_t *btab, int target, unsigned long long *dbg,
@@ -934,6 +957,7 @@ int annlite::launch_seed_build(bool skw, const void *codes_dev, int64_t S, const
     sb.gseed0 = (gseed0 && btab) ? gseed0 : nullptr;
     sb.btab = (gseed0 && btab) ? btab : nullptr;
     sb.target = target;
+    sb.chunk_log = seed_chunk_log();
     sb.dbg = dbg;
     sb.seedk = seedk;
     auto fn = skw ? seed_bound_kernel<M, true, 4, false, true> : seed_bound_kernel<M, false, 4, false, true>;
@@ -941,6 +965,6 @@ int annlite::launch_seed_build(bool skw, const void *codes_dev, int64_t S, const
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned n_g4 = (unsigned)(((B + 15) / 16) * 4);
     hipLaunchKernelGGL(fn, dim3(n_g4, 1), dim3(kSeedWaves * 64), lds, st, (const uint8_t *)codes_dev, S, valid_bits_dev,
-                       (const float *)nullptr, (int)B, (int)Ks, (int)k, (const float *)nullptr, gk, (int64_t)0, S, 0, sb);
+                       (const float *)nullptr, (int)B, (int)Ks, (int)k, (const float *)nullptr, gk, (int64_t)0, N > S ? N : S, 0, sb);
     return launch_status("seed_bound_kernel (fused table build)");
 }

@@ -13,8 +13,9 @@
 //     T = q8_target (96) when the table is built, entries above QMAX steps are clipped -- such a row is far outside;
 //   * the threshold tightens over a scan, so the workgroup builds its table ITSELF from the fp32 TILED table (L2) with the
 //     bound it starts from (seed kernel / other slices) and rebuilds it at an epoch end when the bounds of a quarter of its
-//     queries have halved their T (epochs end after blocks 15 * 16, 15 * 256, ...: a barrier of all waves costs more than
-//     a finer table saves, the sparse schedule is the guard against a seed bound that is far off);
+//     queries have halved their T (epochs end after steps q8_epoch0 = 255, 4095, ... -- 15, 255, ... where the scan starts
+//     without a seed bound from rows spread over the table: a barrier of all waves costs more than a finer table saves,
+//     the sparse schedule is the guard against a first bound that is far off);
 //   * filter: ((0x80 | T) - (S & 0x7f)) & ~S keeps bit 7 of a byte iff S <= T (T <= 127: no borrow crosses a byte).
 // Bound: Q <= (v - lo) / step * (1 + 2^-22) (fp32 subtract, multiply by 1/step, round down), hence
 //     d_real - L >= S * step * (1 - 2^-22);  a row can be in the top-k only if d_fp32 <= thr, i.e.

@@ -28,6 +28,9 @@ p.add_argument('--valid', action='store_true', help='pass an all-ones validity b
 p.add_argument('--fused', action='store_true', help='annlite_pq_search_topk (tables built inside)')
 p.add_argument('--data', choices=['random', 'lowrank'], default='random',
                help="random: uniform codes + gaussian codebooks; lowrank: the bench's data (rank-16 latent + noise, trained codec)")
+p.add_argument('--order', choices=['iid', 'sorted'], default='iid',
+               help='lowrank data: sorted = the table is filled in order of the first latent coordinate (an insertion order that makes '
+                    'the head of the table unrepresentative: the seed rows of the first bound must not be its first rows)')
 a = p.parse_args()
 torch.cuda.set_device(0)
 dev = torch.device('cuda', 0)
@@ -57,6 +60,15 @@ else:
     for c0 in range(0, N, 500_000):
         n = min(500_000, N - c0)
         codes[c0:c0 + n] = ops.pq_encode(gen(n), cb)
+    if a.order == 'sorted':  # (rows ordered by their projection on the first latent direction)
+        key = torch.empty((N,), device=dev)
+        cbf = cb.reshape(M, Ks, -1)
+        u = (A[0] / A[0].norm()).reshape(M, -1)
+        proj = torch.einsum('mkd,md->mk', cbf, u)  # contribution of every codeword to the projection
+        for c0 in range(0, N, 500_000):
+            cc = codes[c0:c0 + 500_000].long()
+            key[c0:c0 + cc.shape[0]] = proj.gather(1, cc.t()).sum(0)
+        codes = codes[torch.argsort(key)].contiguous()
     q = gen(B)
     if a.layout == 1:
         codes = ops.codes_skew(codes)

@@ -901,8 +901,10 @@ def test_library_picks_the_scan_kernel(ops, oracle, monkeypatch):
     assert ms_state <= 1.3 * ms_u16, (ms_state, ms_u16, st.info())
     assert torch.equal(ds, d31) and torch.equal(is_, i31)
     # the give-up path itself, forced: a budget of 8 candidates per workgroup trips at once -- the gated u16 pass must deliver
-    # the same bits, and a state must settle on the u16 kernel
+    # the same bits, and a state must settle on the u16 kernel.  (With the early epoch end: the scanning waves stop at step 15
+    # while the consumer counts the transient's candidates -- without it the rows drawn raise the budget as fast as this table leaks.)
     monkeypatch.setenv('ANNLITE_GUARD_BASE', '8')
+    monkeypatch.setenv('ANNLITE_Q8_TUNE', '15,16,384,3')
     dg, ig = run()
     assert torch.equal(dg, d31) and torch.equal(ig, i31)
     st3 = _capi.ScanState()
@@ -912,6 +914,7 @@ def test_library_picks_the_scan_kernel(ops, oracle, monkeypatch):
         assert torch.equal(dg, d31) and torch.equal(ig, i31)
     assert st3.info()[0] == 2, st3.info()
     monkeypatch.delenv('ANNLITE_GUARD_BASE')
+    monkeypatch.delenv('ANNLITE_Q8_TUNE')
     import os
     os.makedirs('gpurun_out', exist_ok=True)
     with open('gpurun_out/kernel_choice_2m_uniform_codes.txt', 'w') as f:
