@@ -180,3 +180,32 @@ def test_update_and_delete_of_unknown_documents(tmp_path):
         ann.delete(ghosts, raise_errors_on_not_found=True)
     ann.delete(ghosts)  # silently ignored
     ann.delete(['nope'])
+
+
+def test_seed_rows_are_spread_over_the_table():
+    """scan_prep.hip: seed_bound_kernel draws ceil(S / 64) blocks of 64 rows in runs of 2^c blocks, the runs spread evenly over the
+    extent (block_row).  The mapping restated: every block starts inside the extent on a multiple of 64 (the lanes keep their skew
+    residues), no two blocks overlap, the last run starts in the last 1/n_runs of the table (its tail is sampled), and S >= extent
+    degenerates to the contiguous scan."""
+    def block_rows(S, ext, c):
+        S = min(S, ext)
+        n_blocks = (S + 63) >> 6
+        mask = (1 << c) - 1
+        run_step = ((ext >> 6) // ((n_blocks + mask) >> c)) << 6
+        run_step = max(run_step, 64 << c)
+        return [(b >> c) * run_step + ((b & mask) << 6) for b in range(n_blocks)], run_step
+
+    for ext in (4_100, 65_600, 1_250_000, 10_000_000, 9_999_937):
+        for S in (100, 8192, 32768, 131072, ext, ext + 5):
+            for c in (0, 3, 6):
+                rows, step = block_rows(S, ext, c)
+                assert all(r % 64 == 0 for r in rows)
+                assert len(set(rows)) == len(rows)
+                srt = sorted(rows)
+                assert all(b - a >= 64 for a, b in zip(srt, srt[1:]))
+                inside = [r for r in rows if r < ext]
+                assert len(inside) >= len(rows) - (1 << c), (ext, S, c)  # (only a last partial run may stick out: its lanes are masked)
+                if min(S, ext) * 2 <= ext and len(rows) >= (2 << c):
+                    assert max(inside) >= ext - 2 * step - 64 * len(rows), (ext, S, c)  # (the run step is rounded down to blocks)
+                if S >= ext:
+                    assert rows == list(range(0, ((ext + 63) >> 6) << 6, 64))
