@@ -687,6 +687,18 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         if (const char *e = getenv("ANNLITE_Q8_MAP")) a.q8_map_slices = atoi(e) ? 1 : 0;
         if (a.n_slices < 8) a.q8_map_slices = 0;
         if (c.mode == 5 && a.n_tiles >= 8 && !a.q8_map_slices) a.n_items = 8 * ((a.n_tiles + 7) / 8) * a.n_slices;  // q8_item_map
+        // Interleaved row slices (ANNLITE_Q8_ILV=1..8, default off): slice s takes the runs of 2^ILV blocks of 64 rows number s, s + n_slices, ...
+        // instead of one contiguous range -- built for tables in cluster order, where a query tile's neighbourhoods sit in ONE range and
+        // that work item handles most of the tile's candidates (1.25M rows sorted along one latent direction: step loops of 175 ... 321 us
+        // within one launch).  Measured (profiles/r05/interleaved_slices_ab.txt): such a table 1.456 -> 1.419 ms per batch at 10M rows but
+        // 0.326 -> 0.337 at 1.25M (every slice now inserts the hot region's rows into its own list); the bench's tables -0.3 % (noise).  Exact
+        // either way (332 GPU tests with it on); not adopted.  Never for the candidate generator of the re-rank stage: its per-slice seed
+        // bounds are bounds of the slice's OWN contiguous rows.
+        a.q8_ilv_log = 0;
+        if (const char *e = getenv("ANNLITE_Q8_ILV")) {
+            const int t = atoi(e);
+            if (c.mode == 5 && share_across_slices && !tm && a.n_slices >= 2 && t >= 0 && t <= 8) a.q8_ilv_log = t;
+        }
         // epochs end after steps 15, 255, 4095 (x 15 blocks of 64 rows) and a slot asks for a new table when its T has halved:
         // 10M rows x 1024 queries 1.497 ms per launch with {3, 15, 63, ...} / T 64 / rebuild at 7/8, 1.445 with this, 1.441 with no
         // epoch at all (1.25M rows: 0.284 / 0.261 / 0.254) -- on the bench's data a barrier of all 16 waves costs more than a

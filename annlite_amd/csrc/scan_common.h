@@ -84,6 +84,10 @@ struct ScanArgs {
                                         // (q8_item_map): an XCD streams ITS row slices once for all query tiles
     uint32_t q8_pos;                    // byte-table kernel, 16 < k <= 64 (64-key lists): the list positions p0 < p1 < p2 < p3 (one per byte) whose
                                         // keys a slice publishes -- cell i = "this slice holds p_i + 1 rows at or below this key"; G (p3 + 1) >= k
+    int32_t q8_ilv_log;                 // byte-table kernel, shared bounds: > 0: the row slices are INTERLEAVED -- slice s owns the runs of 2^q8_ilv_log
+                                        // blocks of 64 rows number s, s + n_slices, s + 2 n_slices, ... of the table instead of one contiguous
+                                        // range (a table in cluster order has its queries' neighbourhoods in ONE range: that work item ran 1.5x the
+                                        // others); 0: contiguous ranges of slice_rows rows
     unsigned long long *clk;            // optional (annlite_profile_enable): workgroup 0 leaves [0] shader cycles (s_memtime) and [1] 100 MHz
                                         // ticks at its start, [2] / [3] at its end -- the clock the kernel actually held
 };

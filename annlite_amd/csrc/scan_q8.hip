@@ -1081,8 +1081,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
         const int64_t slice_begin = (int64_t)slice * a.slice_rows;
         int64_t slice_end = slice_begin + a.slice_rows;
         if (slice_end > a.N) slice_end = a.N;
-        const int64_t stride = (int64_t)NS * 64;
-        const int n_steps = slice_end > slice_begin ? (int)((slice_end - slice_begin + stride - 1) / stride) : 0;
+        // blocks of 64 rows of this work item: its contiguous range, or (q8_ilv_log > 0) the runs of G = 2^q8_ilv_log blocks number
+        // slice, slice + n_slices, ... of the table's ceil(N / 64) blocks
+        uint32_t item_blocks;
+        if (a.q8_ilv_log > 0) {
+            const uint32_t G = 1u << a.q8_ilv_log, per = (uint32_t)a.n_slices << a.q8_ilv_log;
+            const uint32_t nb = (uint32_t)((a.N + 63) >> 6), rounds = nb / per, rest = nb - rounds * per;
+            const uint32_t mine = rest > (uint32_t)slice * G ? rest - (uint32_t)slice * G : 0u;
+            item_blocks = rounds * G + (mine < G ? mine : G);
+        } else item_blocks = slice_end > slice_begin ? (uint32_t)((slice_end - slice_begin + 63) >> 6) : 0u;
+        const int n_steps = (int)((item_blocks + (uint32_t)NS - 1u) / (uint32_t)NS);
 
         __syncthreads();  // every wave is done with the previous item
         // ANNLITE_DEBUG_COUNTERS: phase stamps of thread 0 (100 MHz wall clock; kept in LDS: four live 64-bit values pushed the
@@ -1476,8 +1484,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             unsigned long long codes_v = (unsigned long long)(uintptr_t)a.codes, valid_v = (unsigned long long)(uintptr_t)a.valid;
             if constexpr (WIDE) asm volatile("" : "+v"(codes_v), "+v"(valid_v));
             // rows are < 2^32 per call (plan): 32-bit row arithmetic keeps the loop control in SGPRs
-            const uint32_t s_begin = (uint32_t)slice_begin, s_end = (uint32_t)slice_end, n_rows = (uint32_t)a.N;
-            const uint32_t n_blocks = (s_end - s_begin + 63u) >> 6;
+            const uint32_t n_rows = (uint32_t)a.N;
+            const uint32_t n_blocks = item_blocks;
+            // block b of the work item starts at row blk_off + ((b >> blk_log) * blk_per + (b & blk_msk)) * 64: contiguous range
+            // (blk_log = 26: b >> 26 = 0 for every table the plan admits) or interleaved runs (ScanArgs::q8_ilv_log); scalar arithmetic
+            const bool ilv = a.q8_ilv_log > 0;
+            const uint32_t blk_log = ilv ? (uint32_t)a.q8_ilv_log : 26u, blk_msk = (1u << blk_log) - 1u;
+            const uint32_t blk_per = ilv ? (uint32_t)a.n_slices << blk_log : 0u;
+            const uint32_t blk_off = ilv ? ((uint32_t)slice << blk_log) << 6 : (uint32_t)slice_begin;
+            const uint32_t s_end = ilv ? n_rows : (uint32_t)slice_end;  // (the rows behind the item's last block)
+            auto blk_row = [&](uint32_t b) -> uint32_t { return blk_off + (((b >> blk_log) * blk_per + (b & blk_msk)) << 6); };
             // The waves DRAW their blocks of 64 rows from a counter in LDS.  (The SIMD's arbiter favours its oldest wave, and
             // one wave alone issues at about a third of the rate four reach together -- scripts/ubench/valu_cost.hip,
             // step_loop.hip.  With the rows dealt out statically the favoured waves finished their share of an epoch early
@@ -1682,8 +1698,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             // load it had just issued: s_waitcnt vmcnt(0) every step.)
             uint32_t b_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)draw());
             uint32_t pend = draw();
-            load_row(s_begin + b_cur * 64u + lane, cnext);
-            vnext = load_valid(s_begin + b_cur * 64u + lane);
+            load_row(blk_row(b_cur) + lane, cnext);
+            vnext = load_valid(blk_row(b_cur) + lane);
             uint32_t b_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend);
             // The blocks are cut into epochs that end after block 15 * 16, 15 * 256, ... (q8_epoch0, q8_epoch_mul) and after the last one (the
             // epochs' barriers meet).  The step loop of an epoch contains no call and no barrier: the loop-invariant
@@ -1696,7 +1712,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 const bool final = epoch_step >= n_steps - 1;
                 const uint32_t end_blk = final ? n_blocks : (uint32_t)NS * (uint32_t)(epoch_step + 1);
                 for (; b_cur < end_blk; ++it_no) {
-                    const uint32_t row0 = s_begin + b_cur * 64u;  // (< s_end: b_cur < n_blocks)
+                    const uint32_t row0 = blk_row(b_cur);  // (< s_end: b_cur < n_blocks)
                     pend = draw();
                     // PLAIN 16-byte rows (M = 16 / uint8, M = 8 / uint16): first rotation stage straight from the landing registers -- no copy
                     constexpr bool ROT4 = !SKEWED && !WIDE && CW == 4;
@@ -1711,7 +1727,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     }
                     vcur = vnext;
                     {
-                        const uint32_t row1 = s_begin + b_nxt * 64u + lane;  // (past the slice at its end: clamped, unused)
+                        const uint32_t row1 = blk_row(b_nxt) + lane;  // (past the slice at its end: clamped, unused)
                         load_row(row1, cnext);
                         vnext = load_valid(row1);
                     }

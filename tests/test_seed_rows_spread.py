@@ -1,7 +1,8 @@
 """The first bound of a scan comes from S seed rows spread over the whole table in runs of 64-row blocks (scan_prep.hip:
 seed_bound_kernel; round 5) instead of from its first S rows.  Any subset of the valid rows gives a correct bound, so the results
 must not move: a table filled in cluster order (the case the spread is for), a deleted head, ragged sizes, both code layouts,
-k on the 16-key and the 64-key lists, every run length, more seed rows than the table has -- bit-exact against the CPU oracle
+k on the 16-key and the 64-key lists, every run length, more seed rows than the table has, and the opt-in interleaved row slices
+of the scan itself -- bit-exact against the CPU oracle
 (reference: annlite/core/codec/pq.py:316-322 tables, pq_bindings.pyx:30-47 sums, math.py:94-120 selection)."""
 import numpy as np
 import pytest
@@ -33,7 +34,10 @@ def _sorted_table(N, M, dsub, Ks, seed):
 
 
 ENVS = [{}, {'ANNLITE_SEED_CONTIGUOUS': '1'}, {'ANNLITE_SEED_CHUNK_LOG': '0'}, {'ANNLITE_SEED_CHUNK_LOG': '6'},
-        {'ANNLITE_SEED_ROWS': '100'}, {'ANNLITE_SEED_ROWS': '100000000'}, {'ANNLITE_SEED_ROWS': '0'}]
+        {'ANNLITE_SEED_ROWS': '100'}, {'ANNLITE_SEED_ROWS': '100000000'}, {'ANNLITE_SEED_ROWS': '0'},
+        # interleaved row slices (scan.hip at ANNLITE_Q8_ILV; opt-in): runs of 2 / 16 / 256 blocks, 8 and 24 slices
+        {'ANNLITE_Q8_ILV': '1'}, {'ANNLITE_Q8_ILV': '4'}, {'ANNLITE_Q8_ILV': '8', 'ANNLITE_SCAN_SLICES': '8'},
+        {'ANNLITE_Q8_ILV': '2', 'ANNLITE_SCAN_SLICES': '24'}]
 
 
 @pytest.mark.parametrize('N,k', [(300_001, 10), (300_001, 50), (65_600, 16), (4_100, 10)])
@@ -58,7 +62,7 @@ def test_spread_seed_rows_keep_the_results(ops, oracle, monkeypatch, N, k):
     bits = ops.to_dev(np.packbits(valid.reshape(-1, 32), axis=1, bitorder='little').view(np.int32).reshape(-1))
     cb_d, q_d, codes_d = ops.to_dev(cb), ops.to_dev(q), ops.to_dev(codes)
     for env in ENVS:
-        for key in ('ANNLITE_SEED_CONTIGUOUS', 'ANNLITE_SEED_CHUNK_LOG', 'ANNLITE_SEED_ROWS'):
+        for key in ('ANNLITE_SEED_CONTIGUOUS', 'ANNLITE_SEED_CHUNK_LOG', 'ANNLITE_SEED_ROWS', 'ANNLITE_Q8_ILV', 'ANNLITE_SCAN_SLICES'):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
             monkeypatch.setenv(key, val)
