@@ -712,7 +712,11 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         if (c.mode == 5 && k > 16) a.q8_import_mask = 7;
         // (M = 64: u16 sums of 64 entries clipped at 15.  10M x 768-d, 256 queries, ms per launch at T = 256 / 384 / 512 / 768: 2.09 / 2.04 /
         // 2.03 / 3.54 -- a finer table clips more entries of a row near the bound: at 768 the filter leaks)
-        a.q8_target = M == 64 ? 512 : 96;
+        // (M = 16, k <= 16: 88 -- at 1.25M rows, where the consumer wave is 75-85 % busy, T = 80 / 88 take 0.2367 / 0.2368 ms per batch against
+        // 0.2412 at 96 and 0.2548 / 0.2759 at 112 / 127: an entry is clipped at 15 steps, so a coarser step clips fewer entries of the rows near
+        // the bound; 1M and 10M rows: no difference between 80, 88 and 96 -- profiles/r05/table_target_sweep.txt.  The 64-key lists stay at 96:
+        // k = 50 at T = 80 / 96 / 112 1.92 / 1.87 / 1.83 ms, profiles/r05/k50_knobs.txt)
+        a.q8_target = M == 64 ? 512 : (M == 16 && k <= 16) ? 88 : 96;
         a.q8_rebuild_8ths = 4;
         if (const char *e = getenv("ANNLITE_Q8_REBUILD")) {
             const int t = atoi(e);
