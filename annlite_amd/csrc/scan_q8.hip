@@ -10,7 +10,7 @@
 //     the SAME instruction stream as the u16 kernel (32 ds_read_b128 + ~146 VALU per 64 rows) for twice the queries;
 //   * 4-bit entries are enough because the quantisation follows the THRESHOLD, not the table's range: what decides the
 //     number of rows passing the filter is the resolution relative to R = thr - L (L = sum_m lo): step = R / (T - 1) with
-//     T = q8_target (96) when the table is built, entries above QMAX steps are clipped -- such a row is far outside;
+//     T = q8_target (88 for M = 16 with 16-key lists, else 96) when the table is built, entries above QMAX steps are clipped -- such a row is far outside;
 //   * the threshold tightens over a scan, so the workgroup builds its table ITSELF from the fp32 TILED table (L2) with the
 //     bound it starts from (seed kernel / other slices) and rebuilds it at an epoch end when the bounds of a quarter of its
 //     queries have halved their T (epochs end after steps q8_epoch0 = 255, 4095, ... -- 15, 255, ... where the scan starts
