@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Randomised parity run (GPU box): random shapes, table orders, validity patterns, k, layouts and entry points against the CPU
+oracle, bit for bit, until the time budget is spent.  The oracle is the checker (oracle/pq_oracle.py restates pq_bindings.pyx:30-47,
+149-274 and math.py:94-120 with the fixed tie-break distance, then row id).
+
+Test infrastructure (it is the oracle that checks): `tests/test_fuzz_parity.py` runs a short budget inside the GPU suite;
+
+    python tests/fuzz_parity.py --seconds 200 --seed 1
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import pq_oracle as oracle  # noqa: E402
+from annlite_amd import ops  # noqa: E402
+from annlite_amd._capi import LAYOUT_BMK, LAYOUT_TILED, scan_plan  # noqa: E402
+
+
+
+def run(seconds, seed, verbose=True):
+    """Random cases until `seconds` are spent; returns (cases, calls, mismatches, cases by M)."""
+    oracle.build()
+    torch.cuda.set_device(0)
+    rs = np.random.RandomState(seed)
+    t_end = time.time() + seconds
+    n_cases = n_calls = n_bad = 0
+    by_m = {}
+    while time.time() < t_end:
+        M = int(rs.choice([8, 16, 16, 16, 32, 64, 12]))
+        dsub = int(rs.choice([2, 4, 8]))
+        Ks = 256
+        N = int(np.exp(rs.uniform(np.log(1), np.log(600_000))))
+        B = int(np.exp(rs.uniform(np.log(1), np.log(300))))
+        B = max(1, min(B, int(1.5e9 / (N * M))))  # (the oracle's share of the time budget)
+        k = int(rs.choice([1, 3, 10, 10, 16, 17, 33, 50, 64]))
+        kind = int(rs.choice([1, 1, 3]))
+        order = rs.choice(['iid', 'sorted', 'few_distinct', 'uniform_codes'])
+        D = M * dsub
+        r = 6
+        A = rs.randn(r, D).astype(np.float32)
+        cb = (rs.randn(Ks, r).astype(np.float32) @ A).reshape(Ks, M, dsub).transpose(1, 0, 2).copy()
+        if order == 'uniform_codes':
+            codes = rs.randint(0, Ks, size=(N, M)).astype(np.uint8)
+            cb = rs.randn(M, Ks, dsub).astype(np.float32)
+        elif order == 'few_distinct':
+            base = rs.randint(0, Ks, size=(max(1, min(N, 300)), M)).astype(np.uint8)
+            codes = base[rs.randint(0, base.shape[0], N)]
+        else:
+            z = rs.randn(N, r).astype(np.float32)
+            if order == 'sorted':
+                z = z[np.argsort(z[:, 0], kind='stable')]
+            x = z @ A + 0.05 * rs.randn(N, D).astype(np.float32)
+            codes = oracle.encode_c(x, cb, threads=oracle.max_threads())
+        q = (rs.randn(B, r).astype(np.float32) @ A).astype(np.float32)
+        if rs.rand() < 0.3:
+            q += 0.7 * A[0]
+        vmode = rs.choice(['none', 'random', 'head', 'most'])
+        valid = np.ones(((N + 31) // 32 + 2) * 32, dtype=bool)
+        valid[N:] = False
+        if vmode == 'random':
+            valid[:N] &= rs.rand(N) > 0.2
+        elif vmode == 'head':
+            valid[:N // 3] = False
+        elif vmode == 'most':
+            valid[:N] &= rs.rand(N) > 0.95
+        live = np.nonzero(valid[:N])[0]
+        if live.size == 0:
+            continue
+        k = min(k, int(live.size))
+        omet = {1: oracle.EUCLIDEAN, 3: oracle.INNER_PRODUCT}[kind]
+        lut = oracle.batch_precompute_adc_table_c(q, dsub, Ks, cb) if kind == 1 else oracle.get_dist_mat_c(q, cb, omet)
+        rd, ri = oracle.adc_search_c(lut, codes[live], k, threads=oracle.max_threads())
+        ri = live[ri]
+        bits = None if vmode == 'none' else ops.to_dev(np.packbits(valid.reshape(-1, 32), axis=1, bitorder='little').view(np.int32).reshape(-1))
+        cb_d, q_d, codes_d = ops.to_dev(cb), ops.to_dev(q), ops.to_dev(codes)
+        n_cases += 1
+        by_m[M] = by_m.get(M, 0) + 1
+        for layout in ((0, 1) if M in (8, 16, 32, 64) else (0,)):
+            cd = ops.codes_skew(codes_d) if layout == 1 else codes_d
+            outs = [('fused', ops.pq_search_topk(kind, q_d, cb_d, cd, k, M, Ks, codes_layout=layout, valid_bits=bits))]
+            plan = scan_plan(N, M, Ks, 1, B, k)
+            lt = ops.lut_build(q_d, cb_d, kind, LAYOUT_TILED if plan.fast else LAYOUT_BMK, plan.qi)
+            outs.append(('prebuilt', ops.adc_scan_topk(cd, lt, B, k, M, Ks, codes_layout=layout, valid_bits=bits)))
+            for name, (d, i) in outs:
+                n_calls += 1
+                if not (np.array_equal(i.cpu().numpy(), ri) and np.array_equal(d.cpu().numpy(), rd, equal_nan=True)):
+                    n_bad += 1
+                    print('MISMATCH', dict(M=M, dsub=dsub, N=N, B=B, k=k, kind=kind, order=str(order), valid=str(vmode), layout=layout, entry=name), flush=True)
+    return n_cases, n_calls, n_bad, dict(sorted(by_m.items()))
+
+
+if __name__ == '__main__':
+    p = argparse.ArgumentParser()
+    p.add_argument('--seconds', type=float, default=200)
+    p.add_argument('--seed', type=int, default=1)
+    a = p.parse_args()
+    n_cases, n_calls, n_bad, by_m = run(a.seconds, a.seed)
+    print('fuzz_parity: seed %d, %d cases (by M: %s), %d calls compared with the oracle bit for bit, %d mismatches' % (a.seed, n_cases, by_m, n_calls, n_bad))
+    sys.exit(1 if n_bad else 0)
