@@ -232,7 +232,7 @@ ANNLITE_API int annlite_pq_search_topk_ex(int lut_kind, const float *queries_dev
  * in two halves, so that a rank can seed from 1/G of the rows a single GPU would and still start its scan with the bound of
  * all G ranks' seed rows together.  (Every rank repeats the per-batch work for all B queries; the seed bound -- the exact
  * k-th distance of S rows spread over the table -- is the largest part of it: 22 of 39 us at 32768 rows x 1024 queries.)
- *   phase ANNLITE_PHASE_PREPARE  tables, parameters, reset, the seed bound from this rank's first `seed_rows` rows (<= 0: the
+ *   phase ANNLITE_PHASE_PREPARE  tables, parameters, reset, the seed bound from `seed_rows` rows spread over this rank's table (<= 0: the
  *       single-GPU default) and -- the rank's contribution to one all-gather -- seed_keys_dev [B][ANNLITE_SEED_KEYS] u64: the
  *       bounds implied by the seed's k smallest rows, ascending (all-ones where it has fewer).  Outputs untouched.
  *   annlite_pq_search_seed_union  all_keys_dev [G][B][ANNLITE_SEED_KEYS] (the all-gathered keys): the k-th smallest of a
