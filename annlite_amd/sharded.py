@@ -45,11 +45,28 @@ def gather_and_merge(local_d: torch.Tensor, local_i: torch.Tensor, merge_fn: Cal
     f64 = local_d.dtype == torch.float64
     bits = local_d.contiguous().view(torch.int64) if f64 else local_d.to(torch.float32).contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
     both = torch.stack([local_i.to(torch.int64), bits], dim=2)
-    gathered = torch.empty((G * B, k, 2), dtype=torch.int64, device=local_d.device)
-    dist.all_gather_into_tensor(gathered, both.contiguous(), group=group)
+    gathered = _all_gather_rows(both.contiguous(), G, group)
     all_i = gathered[..., 0].contiguous().view(G, B, k)
     all_d = (gathered[..., 1].contiguous().view(torch.float64) if f64 else gathered[..., 1].to(torch.int32).view(torch.float32)).view(G, B, k)
     return merge_fn(all_d.contiguous(), all_i)
+
+
+def _through_host(t: torch.Tensor, group) -> bool:
+    """Device tensors under the gloo backend: the collective runs on host copies (gloo's support for device tensors differs per
+    collective).  That configuration exists for tests -- two ranks sharing one GPU, which RCCL refuses -- not for production."""
+    return t.is_cuda and dist.get_backend(group) == 'gloo'
+
+
+def _all_gather_rows(t: torch.Tensor, G: int, group) -> torch.Tensor:
+    """ONE ``all_gather_into_tensor`` in concatenation form: ``[n, ...] -> [G * n, ...]`` on ``t``'s device."""
+    if _through_host(t, group):
+        h = t.cpu()
+        out = torch.empty((G * h.shape[0],) + tuple(h.shape[1:]), dtype=h.dtype)
+        dist.all_gather_into_tensor(out, h, group=group)
+        return out.to(t.device)
+    out = torch.empty((G * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out
 
 
 SEED_KEYS = 16  # keys per query in the ranks' seed exchange (annlite_hip.h: ANNLITE_SEED_KEYS)
@@ -135,6 +152,9 @@ class ShardedPQIndex:
             gathered = torch.empty((G * B, k, 2), dtype=torch.int64)
             dist.all_gather_into_tensor(gathered, packed.contiguous(), group=self.group)
             return PendingSearch(self, value=self._merge_packed(gathered.view(G, B, k, 2), sqrt=self.index.sqrt_epilogue))
+        if _through_host(packed, self.group):  # (gloo with device tensors: synchronous, through the host -- tests only)
+            gathered = _all_gather_rows(packed.contiguous(), G, self.group)
+            return PendingSearch(self, value=self._merge_packed(gathered.view(G, B, k, 2), sqrt=self.index.sqrt_epilogue))
         return self._exchange_result(packed, None)
 
     def _exchange_result(self, packed: torch.Tensor, scanned) -> 'PendingSearch':
@@ -193,9 +213,7 @@ class ShardedPQIndex:
         if self._seed_group is None:
             raise RuntimeError('seed exchange without its process group: construct ShardedPQIndex(seed_exchange=True) after '
                                'init_process_group (collective over the world), or pass seed_group=')
-        out = torch.empty((G * keys.shape[0], keys.shape[1]), dtype=keys.dtype, device=keys.device)
-        dist.all_gather_into_tensor(out, keys.contiguous(), group=self._seed_group)
-        out = out.view(G, keys.shape[0], keys.shape[1])
+        out = _all_gather_rows(keys.contiguous(), G, self._seed_group).view(G, keys.shape[0], keys.shape[1])
         if self._peer_keys is not None:
             out = torch.cat([out, self._peer_keys.to(out.device)], dim=0)
         return out

@@ -91,6 +91,12 @@ def parse():
     p.add_argument('--seed-exchange', action='store_true',
                    help='N > 1 (opt-in): every rank seeds from 1 / N of the single-GPU seed rows and the ranks all-gather their seeds\' '
                         'k smallest bounds before the scan (sharded.py: measured slower than the plain search on this runtime)')
+    p.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl',
+                   help='torch.distributed backend of an N > 1 run.  nccl (= RCCL over xGMI) is the product path and what the driver '
+                        'launches.  gloo exists so that the script\'s N > 1 branches (shard ranges, broadcast of the codebooks, the packed '
+                        'exchange + merge kernel, max-over-ranks timing, per-rank records, the merged recall) can run on ONE GPU: '
+                        'RCCL refuses two ranks on one device, gloo does not care -- the ranks share cuda:(local_rank mod device count) '
+                        'and every collective goes through host memory (tests/test_bench_two_ranks.py)')
     p.add_argument('--emulate-seed-peers', type=int, default=0,
                    help='ONE rank with the exchange forced (ANNLITE_FORCE_GATHER=1 under torchrun): stand-ins for P - 1 peers in the '
                         'seed exchange -- key sets precomputed, untimed, from P - 1 other row ranges of THIS shard (valid bounds for it) '
@@ -196,12 +202,39 @@ def main():
             sub['uniform'] = sub_run([me, '--data', 'uniform', '--steps', '10', '--warmup', '3', '--cpu-queries', '16', '--cpu-repeats', '3',
                                       '--recall-queries', '32'] + common, 300)
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    gloo = args.backend == 'gloo'
+    dev_idx = local_rank % max(1, torch.cuda.device_count()) if gloo else local_rank  # (gloo: the ranks may share a device)
+    torch.cuda.set_device(dev_idx)
+    dev = torch.device('cuda', dev_idx)
     use_dist = world > 1 or 'RANK' in os.environ  # torchrun with 1 rank also initialises RCCL
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if gloo:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
+
+    # the script's own collectives (never inside the timed region's data path: that is sharded.py's packed exchange).  Under gloo
+    # they go through host memory -- gloo's support for device tensors differs per collective
+    def coll_bcast(t):
+        if not gloo:
+            dist.broadcast(t, src=0)
+            return t
+        h = t.cpu()
+        dist.broadcast(h, src=0)
+        t.copy_(h)
+        return t
+
+    def coll_max(x: float) -> float:
+        t = torch.tensor([x], dtype=torch.float64, device='cpu' if gloo else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def coll_gather(t):
+        src = t.cpu() if gloo else t
+        outl = [torch.empty_like(src) for _ in range(world)]
+        dist.all_gather(outl, src)
+        return [o.to(dev) for o in outl]
 
     from annlite_amd import Metric, PQCodec, _capi, ops
     from annlite_amd.core.index.pq_flat_gpu import PQFlatGpuIndex
@@ -227,7 +260,7 @@ def main():
     else:
         cb = torch.empty((M, Ks, D // M), dtype=torch.float32, device=dev)
     if world > 1:
-        dist.broadcast(cb, src=0)
+        coll_bcast(cb)
     codec.set_codebooks(cb)
     train_s = time.time() - t0
 
@@ -340,9 +373,7 @@ def main():
     elapsed = time.perf_counter() - t0
     own_elapsed = elapsed  # (this rank's clock; `elapsed` becomes the max over the ranks)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = coll_max(elapsed)
     ms_per_step = elapsed / args.steps * 1e3
     qps = B * args.steps / elapsed
     for j in range(NB):  # (fewer timed steps than batches: the rest untimed, so that every batch has a result to check)
@@ -414,7 +445,7 @@ def main():
     gathering = use_dist and (world > 1 or bool(os.environ.get('ANNLITE_FORCE_GATHER')))
     exchange_ms = None
     per_rank = None
-    if gathering:
+    if gathering and not gloo:  # (gloo: the exchange bounces through the host, nothing to price)
         packed = index.search_batch_packed(queries, k, lo)
         if packed is not None:
             G_ = dist.get_world_size()
@@ -438,8 +469,7 @@ def main():
                              float(my_checksum >> 32), float(my_checksum & 0xFFFFFFFF), float(int(result_sha256[:8], 16)),
                              clock_mhz if clock_mhz else -1.0],
                             dtype=torch.float64, device=dev)
-        allr = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
+        allr = coll_gather(mine) if world > 1 else [mine]
         per_rank = [{'rank': r, 'ms_per_step': float(t[0]), 'kernel_ms': float(t[1]),
                      'exchange_ms': None if float(t[2]) < 0 else float(t[2]), 'rows': int(t[3]),
                      'shard_codes_checksum': '%016x' % ((int(t[4]) << 32) | int(t[5])),
@@ -488,10 +518,7 @@ def main():
             o = torch.argsort(md, dim=1)[:, :k]
             best_d, best_i = torch.gather(md, 1, o), torch.gather(mi, 1, o)
         if world > 1:
-            gd = [torch.empty_like(best_d) for _ in range(world)]
-            gi = [torch.empty_like(best_i) for _ in range(world)]
-            dist.all_gather(gd, best_d)
-            dist.all_gather(gi, best_i)
+            gd, gi = coll_gather(best_d), coll_gather(best_i)
             md, mi = torch.cat(gd, 1), torch.cat(gi, 1)
             o = torch.argsort(md, dim=1)[:, :k]
             best_i = torch.gather(mi, 1, o)
@@ -513,9 +540,7 @@ def main():
             barrier()
             rr_el = time.perf_counter() - t0
             if world > 1:
-                t = torch.tensor([rr_el], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                rr_el = float(t.item())
+                rr_el = coll_max(rr_el)
             rr_qps = B * n_rr / rr_el
             got = rr[1][:nq].cpu().numpy()
             recall_rr = float(np.mean([len(set(got[b]) & set(truth[b])) / k for b in range(nq)]))
@@ -775,7 +800,7 @@ def main():
                 'codes_layout': args.layout,
                 # what torch.distributed itself reports (one process per GPU over RCCL); 1 / None without a process group
                 'n_ranks': dist.get_world_size() if use_dist else 1,
-                'backend': (dist.get_backend() + ' (RCCL)') if use_dist else None,
+                'backend': (dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else ' (collectives through host memory; ranks may share a device)')) if use_dist else None,
                 # independent batches alternate between this many HIP streams (each batch's kernels in order on its own)
                 'streams': n_streams,
                 'query_batches': NB,  # distinct batches the timed steps rotate through
@@ -823,6 +848,40 @@ def main():
                              'result_sha256': r.get('result_sha256'),
                              'ms_per_step': r['ms_per_step'],
                              'recall_at_10': r.get('recall_at_10'), 'roofline': r['roofline'], 'cpu_baseline': r['cpu_baseline']}
+        # LAST key of the line: every leg in a few numbers -- a reader who keeps only the tail of the line (the driver's record
+        # keeps its last kilobytes) still sees all of them: q/s, ms per batch, kernel's fraction of its roof, queries checked against
+        # the CPU oracle / differing, the first 8 hex digits of the result digest; N > 1: every rank's digest head and checksum
+        def _r(x, n):
+            return None if x is None else round(float(x), n)
+
+        def leg_summary(r):
+            if not isinstance(r, dict) or 'error' in r:
+                return {'error': (r or {}).get('error', 'missing')} if isinstance(r, dict) else None
+            rf, cb = r.get('roofline') or {}, r.get('cpu_baseline') or {}
+            o = {'qps': _r(r.get('value'), 0), 'ms': _r(r.get('ms_per_step'), 4), 'frac': _r(rf.get('frac'), 3),
+                 'chk': cb.get('queries_checked'), 'diff': cb.get('queries_differing'), 'cpu_qps': _r(cb.get('value'), 1),
+                 'sha': (r.get('result_sha256') or '')[:8] or None}
+            if r.get('recall_at_10') is not None:
+                o['recall'] = _r(r['recall_at_10'], 3)
+            return {kk: v for kk, v in o.items() if v is not None}
+
+        summ = {'main': leg_summary(rec)}
+        summ['main']['n'] = world
+        if rec.get('rerank'):
+            summ['rerank'] = {'qps': _r(rec['rerank']['value'], 0), 'recall': _r(rec['rerank']['recall_at_10'], 3)}
+        if ivf_rec:
+            summ['ivf'] = {'qps': _r(ivf_rec['value'], 0), 'agree': _r(ivf_rec['agreement_with_exhaustive_adc_top10'], 3)}
+        if facade:
+            summ['facade'] = {'search_qps': _r(facade['search']['value'], 0), 'numpy_qps': _r(facade['search_numpy']['value'], 0)}
+        for name in ('c2', 'c4', 'c5', 'm32', 'k50', 'uniform'):
+            if name in rec:
+                summ[name] = leg_summary(rec[name])
+                if name == 'c5' and isinstance(rec[name], dict) and 'build_s' in rec[name]:
+                    summ[name]['build_s'] = _r(rec[name]['build_s'], 1)
+        if per_rank and world > 1:
+            summ['ranks'] = {'sha': [r['result_sha256_head'] for r in per_rank], 'rows': [r['rows'] for r in per_rank],
+                             'ms': [_r(r['ms_per_step'], 4) for r in per_rank], 'checksum_sum': rec['shard_codes_checksum_sum']}
+        rec['summary'] = summ
         print(json.dumps(rec))
     if use_dist:
         dist.destroy_process_group()
