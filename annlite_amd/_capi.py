@@ -31,6 +31,7 @@ SYMBOLS = (
     'annlite_hip_last_error',
     'annlite_hip_device_count',
     'annlite_hip_device_arch',
+    'annlite_knobs_reload',
     'annlite_scan_plan_query',
     'annlite_scan_plan_tiles',
     'annlite_scan_state_create',
@@ -198,6 +199,13 @@ def check(rc: int, what: str = '') -> None:
     if rc == ERR_INVALID:
         raise AssertionError(msg)
     raise RuntimeError(f'annlite_hip error {rc}: {msg}')
+
+
+def knobs_reload() -> None:
+    """The library parses its ANNLITE_* switches once, when it is loaded; a process that changes them afterwards (tests, A/B
+    measurements) has them parsed again with this.  No-op before the library is loaded (it will read the environment then)."""
+    if _lib is not None:
+        check(_lib.annlite_knobs_reload(), 'knobs_reload')
 
 
 def device_count() -> int:

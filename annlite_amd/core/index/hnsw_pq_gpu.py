@@ -48,7 +48,10 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
         self._packed_key = None
         self._graph = None
         self._gpu_graph = None  # (key, links i32 [N, L+1], seeds i32 [S]) exported for the GPU walk
-        self._mutations = 0     # bumped by every add / delete / reset / load: the key of the two device-side caches
+        self._mutations = 0     # bumped by every add / delete / reset / load: the key of the exported graph (a delete changes the seeds)
+        self._structure = 0     # bumped by add / reset / load only: the key of the caches a delete leaves valid -- the PLAIN code
+                                # table and the packed node records (N x 656 B at 32 links, M = 16: 3.3 GB at 5M rows; a delete only
+                                # clears a validity bit, the records and the link lists stay as they are)
 
     # ------------------------------------------------------------------ graph handle
     def _ensure_graph(self):
@@ -81,6 +84,7 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
             return
         super().add_with_ids(x, ids)  # code table / validity / float vectors (the parent pre-processes itself)
         self._mutations += 1
+        self._structure += 1
         # the graph sees what the reference's add_items sees: the pre-processed vectors (+ their code bytes);
         # PQCodec.get_dist_mat would normalise them once more for cosine (pq.py:309-310) -- do the same
         _, xg = self.pq_codec.scan_inputs(xq)
@@ -105,6 +109,7 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
     def reset(self, capacity: Optional[int] = None):
         super().reset(capacity=capacity)
         self._mutations += 1
+        self._structure = getattr(self, '_structure', 0) + 1
         self._gpu_graph = None
         self._plain_cache = None
         self._plain_cache_key = None
@@ -132,8 +137,8 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
         return self._gpu_graph[1], self._gpu_graph[2]
 
     def _packed_records(self, links: torch.Tensor, plain: torch.Tensor) -> torch.Tensor:
-        """The packed node records of the current graph (cached; rebuilt with the export after inserts / deletes)."""
-        key = (self._n_rows, self._mutations)
+        """The packed node records of the current graph (cached; rebuilt after INSERTS -- deletes leave links and code rows alone)."""
+        key = (self._n_rows, self._structure)
         if getattr(self, '_packed_key', None) != key:
             self._packed = ops.graph_pack(links, plain, n_rows=self._n_rows)
             self._packed_key = key
@@ -159,6 +164,7 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
                 # read per expansion, the next record prefetched; the candidate lists are the plain walk's, bit for bit
                 return ops.graph_search_packed(self._packed_records(links, plain), links.shape[1] - 1, seeds, plain, lut, ef,
                                                valid_bits=self._valid, n_rows=self._n_rows)
+            self._packed, self._packed_key = None, None  # (the plain walk: the records' memory goes back)
             return ops.graph_search(links, seeds, plain, lut, ef, valid_bits=self._valid, n_rows=self._n_rows)
         x_np = np.ascontiguousarray(xg.cpu().numpy(), dtype=np.float32)
         B = x_np.shape[0]
@@ -213,7 +219,7 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
 
     def _plain_table(self, N: int) -> torch.Tensor:
         """Code rows in sub-space order for the gather kernel (cached; rebuilt after inserts)."""
-        key = (N, self._mutations)
+        key = (N, self._structure)
         if getattr(self, '_plain_cache_key', None) != key:
             self._plain_cache = self._plain_codes(N).contiguous()
             self._plain_cache_key = key
@@ -228,6 +234,7 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
     def load(self, index_file: Union[str, Path]):
         super().load(index_file)
         self._mutations = getattr(self, '_mutations', 0) + 1
+        self._structure = getattr(self, '_structure', 0) + 1
         gpath = str(index_file) + '.graph'
         if Path(gpath).exists():
             if self._graph is not None:

@@ -269,7 +269,7 @@ class PQFlatGpuIndex(BaseIndex):
             d = torch.full((B, k), float('inf'), dtype=torch.float32, device=dev)
             i = torch.full((B, k), -1, dtype=torch.int64, device=dev)
         elif self.rerank and self._vectors is not None:
-            d, i = self._search_rerank(q, k, valid, N, rerank_k, self._scan_inputs(x, q))
+            d, i = self._search_rerank(q, k, valid, N, rerank_k, self._scan_inputs(x, q), filtered=indices is not None)
         elif k <= 64:
             # table build + scan + top-k: one C call (annlite_pq_search_topk)
             kind, xq = self._scan_inputs(x, q)
@@ -409,7 +409,7 @@ class PQFlatGpuIndex(BaseIndex):
         sd, si = sd[:, :k], si[:, :k]
         return sd, torch.where(torch.isinf(sd), torch.full_like(si, -1), si)
 
-    def _search_rerank(self, q, k, valid, N, rerank_k, scan_in=None):
+    def _search_rerank(self, q, k, valid, N, rerank_k, scan_in=None, filtered=False):
         B = q.shape[0]
         # candidates per row slice: 16 where the byte-table kernel generates them (M = 16: 8 slices x 16 keys = 128 per query
         # at 1024 queries; its lists hold 16 keys), 64 otherwise (u16-table kernels)
@@ -431,13 +431,17 @@ class PQFlatGpuIndex(BaseIndex):
         from ..._capi import LAYOUT_BMK, LAYOUT_TILED
 
         kind, xq = scan_in if scan_in is not None else self.pq_codec.scan_inputs(q)
-        if getattr(self, 'rerank_pool', 'slices') == 'global':
+        # (the global pool holds at most 64 rows: a larger `limit` takes the slice pool, n_slices * rk rows -- never 64 real rows
+        # plus padding; a filtered call -- `valid` is the caller's mask, not the table's own bitmap -- keeps its candidate counts out
+        # of the table's kernel-choice state, as search_batch does)
+        if getattr(self, 'rerank_pool', 'slices') == 'global' and k <= 64:
             # Pool = the GLOBAL ADC top-R (R <= 64) of the shared-bound search -- since round 5 the byte-table kernel serves it
             # (64-key lists) -- instead of the union of per-slice top-16 lists: 50 rows that are the 50 best by ADC distance
             # against 128 of which only the 16 best are guaranteed.  One C call, then the exact re-score as below.
             R = max(min(k, 64), min(64, int(asked or 50)))
             _, cand = ops.pq_search_topk(kind, xq, self.pq_codec.codebooks_dev, self._codes, R, self.M, self.Ks, valid_bits=valid,
-                                         n_rows=N, codes_layout=self._layout(), workspace=self._ws, state=self.scan_state)
+                                         n_rows=N, codes_layout=self._layout(), workspace=self._ws,
+                                         state=None if filtered else self.scan_state)
         else:
             lut = ops.lut_build(xq, self.pq_codec.codebooks_dev, kind, LAYOUT_TILED if plan.fast else LAYOUT_BMK, plan.qi)
             _, cand = ops.adc_scan_candidates(self._codes, lut, B, rk, self.M, self.Ks, valid_bits=valid, n_rows=N,

@@ -34,6 +34,45 @@ inline int launch_status(const char *kernel) {
 
 int device_cu_count();
 
+// ---- measurement / test switches (ANNLITE_* environment variables) --------------------------------
+// Read ONCE, when the library is loaded, into this block; the search path reads the block, never the environment (a getenv per
+// launch races with a concurrent setenv, and a variable set later would silently change which kernel a production index runs).
+// A process that changes the variables afterwards -- the tests' A/B switches -- says so: annlite_knobs_reload() parses the
+// environment again and publishes a NEW block (readers hold the old or the new one, never a half-written one).
+// "unset" is -1 for the integer knobs unless said otherwise.
+struct Knobs {
+    int scan_variant;           // ANNLITE_SCAN_VARIANT
+    bool no_fast_code16;        // ANNLITE_NO_FAST_CODE16
+    int64_t scan_slices;        // ANNLITE_SCAN_SLICES (0: unset)
+    int debug_skip;             // ANNLITE_DEBUG_SKIP (0: unset)
+    int debug_counters;         // ANNLITE_DEBUG_COUNTERS (0: unset; 2 = phase stamps only)
+    int q8_map;                 // ANNLITE_Q8_MAP
+    int q8_ilv;                 // ANNLITE_Q8_ILV
+    int q8_rebuild;             // ANNLITE_Q8_REBUILD
+    int q8_target;              // ANNLITE_Q8_TARGET
+    bool q8_tune_set;           // ANNLITE_Q8_TUNE = "epoch0,mul,ring_limit,import_mask" (set: the string was given, valid or not)
+    bool q8_tune_ok;
+    int q8_tune[4];
+    int64_t guard_base;         // ANNLITE_GUARD_BASE
+    bool q8_pos_ok;             // ANNLITE_Q8_POS = "f0,f1,f2,f3"
+    double q8_pos[4];
+    int flush_mask;             // ANNLITE_FLUSH_MASK
+    bool seed_rows_set;         // ANNLITE_SEED_ROWS (0 is a value: the scan starts without a bound)
+    int64_t seed_rows;
+    bool seed_contiguous;       // ANNLITE_SEED_CONTIGUOUS
+    int seed_chunk_log;         // ANNLITE_SEED_CHUNK_LOG (clamped to [0, 6]; default 3)
+    bool no_fused_seed;         // ANNLITE_NO_FUSED_SEED
+    bool no_prebuilt_tables;    // ANNLITE_NO_PREBUILT_TABLES
+    bool no_early_merge;        // ANNLITE_NO_EARLY_MERGE
+    int64_t early_merge_patience;  // ANNLITE_EARLY_MERGE_PATIENCE
+    bool no_inkernel_merge;     // ANNLITE_NO_INKERNEL_MERGE
+    bool no_fused_lut;          // ANNLITE_NO_FUSED_LUT
+    bool no_mfma_seed;          // ANNLITE_NO_MFMA_SEED (A/B: the seed rows' exact scan instead of the MFMA candidate launch)
+    int graph_hash_bits;        // ANNLITE_GRAPH_HASH_BITS
+    bool graph_seq_insert;      // ANNLITE_GRAPH_SEQ_INSERT
+};
+const Knobs &knobs();
+
 // ---- vector types -------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

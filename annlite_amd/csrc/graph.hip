@@ -569,12 +569,12 @@ static int graph_search_impl(const uint32_t *links_dev, const uint8_t *packed_de
     // 4096 entries up to ef = 128 (a walk records 2-3k nodes: 5M rows, ef 128 gave the same recall as 8192 entries at
     // 1.5x the speed -- 5 instead of 3 waves per CU), 8192 beyond; a full table only costs re-evaluations (see visit)
     int hash_bits = ef <= 128 ? 12 : 13;
-    if (const char *e = getenv("ANNLITE_GRAPH_HASH_BITS")) hash_bits = atoi(e);
+    if (knobs().graph_hash_bits >= 0) hash_bits = knobs().graph_hash_bits;  // (ANNLITE_GRAPH_HASH_BITS: tests force a tiny table)
     if (hash_bits < 4) hash_bits = 4;    // (buckets of four entries, 16-byte initialisation)
     if (hash_bits > 15) hash_bits = 15;  // (128 KB: what is left of the LDS beside the smallest table)
     const uint8_t *codes = (const uint8_t *)codes_dev;
     unsigned long long *stats = nullptr;
-    if (getenv("ANNLITE_DEBUG_COUNTERS")) {
+    if (knobs().debug_counters) {
         if (!g_graph_stats) ANNLITE_HIP_TRY(hipMalloc((void **)&g_graph_stats, 64));
         ANNLITE_HIP_TRY(hipMemsetAsync(g_graph_stats, 0, 64, st));
         stats = g_graph_stats;
@@ -590,7 +590,7 @@ static int graph_search_impl(const uint32_t *links_dev, const uint8_t *packed_de
     }
     // ANNLITE_GRAPH_SEQ_INSERT=1 (plain layout): the one-at-a-time list insertion of rounds 2-4 -- the parity tests walk with
     // both and compare
-    if (getenv("ANNLITE_GRAPH_SEQ_INSERT")) {
+    if (knobs().graph_seq_insert) {
         if (M == 8) return ANNLITE_BEAM(8, false, false);
         if (M == 16) return ANNLITE_BEAM(16, false, false);
         return ANNLITE_BEAM(32, false, false);

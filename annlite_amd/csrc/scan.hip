@@ -8,6 +8,8 @@
 // The scan kernels live in scan_q8.hip (byte filter tables: the default for M = 16, small k), scan_qfilter.hip (u16
 // filter tables, tile mode) and scan_prep.hip (table build, quantisation parameters, seed bound); DESIGN.md section 3.  No fallback to the
 // CPU exists; shapes without a fast kernel use the generic kernel below (tables through L2).
+#include <mutex>
+
 #include "scan_common.h"
 
 namespace annlite {
@@ -325,7 +327,7 @@ struct FastCfg {
     bool qf() const { return true; }  // integer filter + exact recompute, shared bounds (every fast kernel)
 };
 
-// Kernel variants per M.  ANNLITE_SCAN_VARIANT (environment, read per call: A/B measurements) selects among the
+// Kernel variants per M.  ANNLITE_SCAN_VARIANT (environment, parsed at load -- common.h: Knobs; A/B measurements) selects among the
 // instantiations; variant 0 is the default plan for every M.  Which of the two M = 16 kernels serves a table -- byte or u16
 // filter tables -- is otherwise decided inside the library, per call (search_policy below): the entry points scope their
 // choice to the call through this thread-local (never visible to the caller, never left set).
@@ -335,10 +337,7 @@ struct VariantScope {
     explicit VariantScope(int v) : prev(g_variant_scope) { g_variant_scope = v; }
     ~VariantScope() { g_variant_scope = prev; }
 };
-static int env_variant() {
-    const char *e = getenv("ANNLITE_SCAN_VARIANT");
-    return e ? atoi(e) : -1;
-}
+static int env_variant() { return knobs().scan_variant; }  // (ANNLITE_SCAN_VARIANT as parsed at load / the last reload)
 static int scan_variant() {
     if (g_variant_scope >= 0) return g_variant_scope;
     const int e = env_variant();
@@ -351,7 +350,7 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
     if (code_bytes == 2) {
         // uint16 codes (Ks > 256; the reference's PQ tests run Ks = 512 and 768 at M = 8): the u16-table kernel with 8 queries
         // per workgroup, as many codes as fit the LDS, PLAIN layout, row slices only
-        if (tiles || getenv("ANNLITE_NO_FAST_CODE16")) return false;  // (the switch: A/B against the generic kernel)
+        if (tiles || knobs().no_fast_code16) return false;  // (the switch: A/B against the generic kernel)
         // M = 8, Ks <= 512, k <= 16: the byte-table kernel (scan_q8.hip, C16: table [Ks][2][8][16 B], 32 queries per workgroup,
         // conflict-free); ANNLITE_SCAN_VARIANT=31: the u16-table kernel (A/B)
         if (M == 8 && Ks <= 512 && k <= 16 && (scan_variant() == 0 || scan_variant() == 50)) { *c = {8, 4, 2, 16, 4, 1, 850, 5}; return true; }
@@ -435,8 +434,8 @@ static void plan_slices(int64_t N, int n_tiles, int waves, int n_cu, bool xcd8, 
     if (ns < 1) ns = 1;
     if (xcd8 && m32_bytes && ns == 4 && m32_wants_8_slices(N, n_tiles)) ns = 8;
     if (xcd8) {
-        if (const char *e = getenv("ANNLITE_SCAN_SLICES")) {
-            const int64_t v = atoll(e);
+        {
+            const int64_t v = knobs().scan_slices;  // (ANNLITE_SCAN_SLICES)
             if (v == 1 || v == 2 || v == 4 || (v >= 8 && v % 8 == 0 && v <= 4096)) ns = v;
         }
     }
@@ -533,7 +532,26 @@ static unsigned long long *g_dbg_prep = nullptr;  // ... and the preparation lau
 static thread_local int g_prof_on = 0;
 static thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 static thread_local int g_ev_valid = 0;
-static unsigned long long *g_clk = nullptr;  // (annlite_profile_enable) the byte-table kernel's cycle / wall-clock stamps, 4 x u64, leaked
+// (annlite_profile_enable) the byte-table kernel's cycle / wall-clock stamps, 4 x u64 PER DEVICE (a launch on device d writes
+// device d's buffer -- one process may drive several GPUs: MultiGpuPQIndex), allocated by annlite_profile_enable(1) on the device
+// that is current then (or by the first profiled launch on another one), leaked
+static unsigned long long *g_clk_dev[32] = {};
+static std::mutex g_clk_mutex;
+static unsigned long long *clk_buffer(bool create) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    std::lock_guard<std::mutex> lock(g_clk_mutex);
+    if (!g_clk_dev[dev] && create) {
+        unsigned long long *p = nullptr;
+        if (hipMalloc((void **)&p, 32) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, 32) != hipSuccess) {
+            (void)hipFree(p);
+            return nullptr;
+        }
+        g_clk_dev[dev] = p;
+    }
+    return g_clk_dev[dev];
+}
 
 static void prof_begin(hipStream_t st) {
     if (!g_prof_on) return;
@@ -628,8 +646,9 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
     a.qlo = nullptr;
     a.gkey = nullptr;
     a.dbg = nullptr;
-    a.dbg_skip = getenv("ANNLITE_DEBUG_SKIP") ? atoi(getenv("ANNLITE_DEBUG_SKIP")) : 0;
-    if (getenv("ANNLITE_DEBUG_COUNTERS") && !(gopt && gopt->gate)) {  // (the gated pass leaves the first launch's counters alone)
+    const Knobs &kn = knobs();  // (one block for the whole call)
+    a.dbg_skip = kn.debug_skip;
+    if (kn.debug_counters && !(gopt && gopt->gate)) {  // (the gated pass leaves the first launch's counters alone)
         if (!g_dbg) ANNLITE_HIP_TRY(hipMalloc((void **)&g_dbg, 128 + 4096 * 64));
         if (!g_dbg_prep) {
             ANNLITE_HIP_TRY(hipMalloc((void **)&g_dbg_prep, 64));
@@ -637,7 +656,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         }
         ANNLITE_HIP_TRY(hipMemsetAsync(g_dbg, 0, 128, st));
         a.dbg = g_dbg;
-        if (atoi(getenv("ANNLITE_DEBUG_COUNTERS")) == 2) a.dbg_skip |= 8;  // phase stamps only (annlite_debug_timeline): the
+        if (kn.debug_counters == 2) a.dbg_skip |= 8;  // phase stamps only (annlite_debug_timeline): the
                                                                            // per-wave event counters cost tens of microseconds
     }
     {
@@ -684,7 +703,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         // launch, 36 % of the HBM peak, L2 hit rate 71 %) and its candidates are few -- slice-per-XCD instead: an XCD streams its
         // row slices once for all the query tiles that walk them together.  ANNLITE_Q8_MAP=0/1 overrides (A/B).
         a.q8_map_slices = (M == 64 || (M == 32 && c.mode == 5 && a.n_slices == 8 && m32_wants_8_slices(N, a.n_tiles))) ? 1 : 0;
-        if (const char *e = getenv("ANNLITE_Q8_MAP")) a.q8_map_slices = atoi(e) ? 1 : 0;
+        if (kn.q8_map >= 0) a.q8_map_slices = kn.q8_map ? 1 : 0;
         if (a.n_slices < 8) a.q8_map_slices = 0;
         if (c.mode == 5 && a.n_tiles >= 8 && !a.q8_map_slices) a.n_items = 8 * ((a.n_tiles + 7) / 8) * a.n_slices;  // q8_item_map
         // Interleaved row slices (ANNLITE_Q8_ILV=1..8, default off): slice s takes the runs of 2^ILV blocks of 64 rows number s, s + n_slices, ...
@@ -695,8 +714,8 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         // either way (332 GPU tests with it on); not adopted.  Never for the candidate generator of the re-rank stage: its per-slice seed
         // bounds are bounds of the slice's OWN contiguous rows.
         a.q8_ilv_log = 0;
-        if (const char *e = getenv("ANNLITE_Q8_ILV")) {
-            const int t = atoi(e);
+        {
+            const int t = kn.q8_ilv;
             if (c.mode == 5 && share_across_slices && !tm && a.n_slices >= 2 && t >= 0 && t <= 8) a.q8_ilv_log = t;
         }
         // epochs end after steps 15, 255, 4095 (x 15 blocks of 64 rows) and a slot asks for a new table when its T has halved:
@@ -718,23 +737,13 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         // k = 50 at T = 80 / 96 / 112 1.92 / 1.87 / 1.83 ms, profiles/r05/k50_knobs.txt)
         a.q8_target = M == 64 ? 512 : (M == 16 && k <= 16) ? 88 : 96;
         a.q8_rebuild_8ths = 4;
-        if (const char *e = getenv("ANNLITE_Q8_REBUILD")) {
-            const int t = atoi(e);
-            if (t >= 0 && t <= 8) a.q8_rebuild_8ths = t;
-        }
-        if (const char *e = getenv("ANNLITE_Q8_TARGET")) {
-            const int t = atoi(e);
-            if (t >= 16 && t <= (M == 64 ? 960 : 127)) a.q8_target = t;
-        }
-        if (const char *e = getenv("ANNLITE_Q8_TUNE")) {  // "epoch0,mul,ring_limit,import_mask" (measurements)
-            int e0 = 15, mul = 16, rl = 384, im = 3;
-            // (a ring limit below 192 can deadlock: the consumer waits for entries of a producer the limit holds back)
-            if (sscanf(e, "%d,%d,%d,%d", &e0, &mul, &rl, &im) == 4 && e0 >= 0 && mul >= 2 && rl >= 192 && rl <= 448 && im >= 0) {
-                a.q8_epoch0 = e0;
-                a.q8_epoch_mul = mul;
-                a.q8_ring_limit = rl;
-                a.q8_import_mask = im;
-            }
+        if (kn.q8_rebuild >= 0 && kn.q8_rebuild <= 8) a.q8_rebuild_8ths = kn.q8_rebuild;
+        if (kn.q8_target >= 16 && kn.q8_target <= (M == 64 ? 960 : 127)) a.q8_target = kn.q8_target;
+        if (kn.q8_tune_ok) {  // ANNLITE_Q8_TUNE = "epoch0,mul,ring_limit,import_mask" (measurements; validated when parsed)
+            a.q8_epoch0 = kn.q8_tune[0];
+            a.q8_epoch_mul = kn.q8_tune[1];
+            a.q8_ring_limit = kn.q8_tune[2];
+            a.q8_import_mask = kn.q8_tune[3];
         }
         int grid = a.n_items < n_cu * c.wg_per_cu ? a.n_items : n_cu * c.wg_per_cu;
         const bool sk = codes_layout == ANNLITE_CODES_SKEWED;
@@ -755,7 +764,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                     a.guard = guard_blk;
                     a.guard_abort = gopt->abort_enabled;
                     a.guard_base = 1024u * (uint32_t)((k + 15) / 16);  // (k > 16: the legitimate candidates grow with k -- the transient alone is ~k per query)
-                    if (const char *e = getenv("ANNLITE_GUARD_BASE")) a.guard_base = (uint32_t)atoll(e);  // (tests: force the give-up path)
+                    if (kn.guard_base >= 0) a.guard_base = (uint32_t)kn.guard_base;  // (ANNLITE_GUARD_BASE, tests: force the give-up path)
                     a.host_stats = gopt->host_stats;
                     a.stats_seq = gopt->seq;
                     gopt->guard_out = guard_blk;
@@ -796,11 +805,8 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                     // the k best rows (8 slices, k = 50: positions 4, 6, 8, 12 -- the weighted bound sits near rank 56; q8_weighted_bound)
                     const double share = (double)k / (double)grp;
                     double f[4] = {0.64, 0.96, 1.28, 1.92};
-                    if (const char *e = getenv("ANNLITE_Q8_POS")) {  // "f0,f1,f2,f3" (measurements)
-                        double g[4];
-                        if (sscanf(e, "%lf,%lf,%lf,%lf", &g[0], &g[1], &g[2], &g[3]) == 4 && g[0] > 0 && g[0] < g[1] && g[1] < g[2] && g[2] < g[3] && g[3] >= 1.0)
-                            for (int i = 0; i < 4; ++i) f[i] = g[i];
-                    }
+                    if (kn.q8_pos_ok)  // ANNLITE_Q8_POS = "f0,f1,f2,f3" (measurements)
+                        for (int i = 0; i < 4; ++i) f[i] = kn.q8_pos[i];
                     int prev = 0;
                     a.q8_pos = 0;
                     for (int i = 0; i < 4; ++i) {
@@ -813,7 +819,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                     a.jm1 = prev - 1;
                 }
                 a.flush_mask = 63;
-                if (const char *e = getenv("ANNLITE_FLUSH_MASK")) a.flush_mask = atoi(e);
+                if (kn.flush_mask >= 0) a.flush_mask = kn.flush_mask;
             }
             // (the q16 table sits behind the small arrays; carve order is irrelevant to the kernels)
             // byte-table kernel: no u16 tables, the per-(query, sub-space) minima instead (same region, smaller)
@@ -838,25 +844,25 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                     const int64_t s2 = S * ((k + 15) / 16), cap = N / 16 > S ? N / 16 : S;
                     S = ((s2 < cap ? s2 : cap) + 1023) / 1024 * 1024;
                 }
-                if (const char *e = getenv("ANNLITE_SEED_ROWS")) S = atoll(e);
+                if (kn.seed_rows_set) S = kn.seed_rows;
                 if (split && split->seed_rows > 0) S = split->seed_rows;  // (a rank of a row-sharded search: its share of the seed rows)
                 if (S > N) S = N;
                 if (S < 0) S = 0;  // (ANNLITE_SEED_ROWS=0: the scan starts without a bound)
             }
             // the S seed rows are 64-row blocks spread evenly over the table (ANNLITE_SEED_CONTIGUOUS=1: its first S rows -- A/B switch)
-            const int64_t seed_extent = getenv("ANNLITE_SEED_CONTIGUOUS") ? S : N;
+            const int64_t seed_extent = kn.seed_contiguous ? S : N;
             // with a first bound from rows spread over the whole table the early epoch end only costs its barrier (ms per batch with the
             // first end after step 15 / 255 / never: 1.25M rows 0.2387 / 0.2339 / 0.2338, 1M rows 0.2157 / 0.2099 / 0.2099, 10M rows 1.352 /
             // 1.347 / 1.342 -- profiles/r05/epoch_schedule_sweep.txt): the first end moves to step 255; the early one stays where the
             // scan starts without such a bound
-            if (c.mode == 5 && S >= 8192 && seed_extent > S && !getenv("ANNLITE_Q8_TUNE")) a.q8_epoch0 = 255;
+            if (c.mode == 5 && S >= 8192 && seed_extent > S && !kn.q8_tune_set) a.q8_epoch0 = 255;
             // byte-table plan behind annlite_pq_search_topk: tables, parameters, reset and seed bound in ONE launch
             const bool one_prep = c.mode == 5 && build && S > 0 && M == 16 && build->D <= 256 && ((build->D / M) % 4) == 0 &&
-                                  !getenv("ANNLITE_NO_FUSED_SEED");
+                                  !kn.no_fused_seed;
             if (split && !one_prep) return ANNLITE_NOT_APPLICABLE;  // (nothing has been launched)
             if (one_prep && split && split->phase == ANNLITE_PHASE_SCAN) {
                 // the batch was prepared by the PREPARE half on this workspace: the same carving, no launch
-                if (!getenv("ANNLITE_NO_PREBUILT_TABLES")) {
+                if (!kn.no_prebuilt_tables) {
                     a.gseed0 = (unsigned long long *)carve(bpad * 8);
                     a.btab = (uint8_t *)carve((int64_t)a.n_tiles * Ks * 2 * M * 16);
                 }
@@ -865,7 +871,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 // (ANNLITE_NO_PREBUILT_TABLES: the workgroups convert the fp32 tables themselves, as before round 4 -- A/B switch)
                 unsigned long long *gseed0 = nullptr;
                 uint8_t *btab = nullptr;
-                if (!getenv("ANNLITE_NO_PREBUILT_TABLES")) {
+                if (!kn.no_prebuilt_tables) {
                     gseed0 = (unsigned long long *)carve(bpad * 8);
                     btab = (uint8_t *)carve((int64_t)a.n_tiles * Ks * 2 * M * 16);  // (inside the region the u16 plan uses for q16)
                 }
@@ -893,7 +899,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 // unused without sharing and reset by the fill, holds them).  Without one the slice's table would start "open"
                 // (everything passes until the first epoch end: 15k rows x 32 queries through the consumer wave).
                 int64_t S = a.slice_rows / 64 < 2048 ? 2048 : a.slice_rows / 64 > 8192 ? 8192 : ((a.slice_rows / 64 + 1023) / 1024) * 1024;
-                if (const char *e = getenv("ANNLITE_SEED_ROWS")) S = atoll(e);
+                if (kn.seed_rows_set) S = kn.seed_rows;
                 if (S > a.slice_rows) S = a.slice_rows;
                 if (S > 0) {
                     rc = launch_seed_bound(M, codes_layout == ANNLITE_CODES_SKEWED, codes_dev, code_bytes, S, valid_bits_dev, lut_dev,
@@ -910,18 +916,15 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         }
         // early merger (scan_q8.hip: q8_early_merge): every work item must have its own resident workgroup
         a.q8_early_merge = (c.mode == 5 && a.tile_done && a.n_slices >= 2 && a.n_slices <= 31 && a.n_items <= grid &&
-                            !getenv("ANNLITE_NO_EARLY_MERGE")) ? 1 : 0;
+                            !kn.no_early_merge) ? 1 : 0;
         a.q8_merge_patience = 20000u;
         if (g_prof_on && c.mode == 5 && !(gopt && gopt->gate)) {
-            if (!g_clk) {
-                ANNLITE_HIP_TRY(hipMalloc((void **)&g_clk, 32));
-                ANNLITE_HIP_TRY(hipMemset(g_clk, 0, 32));
-            }
-            a.clk = g_clk;
-        } else if (g_prof_on && g_clk && !(gopt && gopt->gate)) {
-            ANNLITE_HIP_TRY(hipMemsetAsync(g_clk, 0, 32, st));  // (another kernel serves this launch: no stale stamps)
+            a.clk = clk_buffer(true);  // (this device's)
+        } else if (g_prof_on && !(gopt && gopt->gate)) {
+            if (unsigned long long *clk = clk_buffer(false))
+                ANNLITE_HIP_TRY(hipMemsetAsync(clk, 0, 32, st));  // (another kernel serves this launch: no stale stamps)
         }
-        if (const char *e = getenv("ANNLITE_EARLY_MERGE_PATIENCE")) a.q8_merge_patience = (uint32_t)atoll(e);
+        if (kn.early_merge_patience >= 0) a.q8_merge_patience = (uint32_t)kn.early_merge_patience;
         const bool bracket = !(gopt && gopt->gate);  // (measurement hooks: the launch that does the work, not the gated pass)
         if (bracket) prof_begin(st);
         rc = c.mode == 5 ? launch_q8_scan(c.id, sk, a, grid, st) : launch_qfilter_scan(c.id, sk, a, grid, st);
@@ -993,6 +996,7 @@ extern "C" int annlite_debug_items(uint64_t *out, int64_t max_items, int64_t *n_
 extern "C" int annlite_profile_enable(int on) {
     g_prof_on = on ? 1 : 0;
     g_ev_valid = 0;
+    if (on) (void)clk_buffer(true);  // (here, not on the launch path: the allocation synchronises)
     return ANNLITE_OK;
 }
 
@@ -1028,13 +1032,14 @@ extern "C" int annlite_kernel_rev(const char *kernel) {
 // less, and a reader of one bench line cannot otherwise tell a slow box from a slow kernel.
 extern "C" int annlite_profile_last_scan_clock_mhz(float *mhz) {
     ANNLITE_REQUIRE(mhz != nullptr, "mhz is NULL");
-    if (!g_ev_valid || !g_clk) {
+    unsigned long long *clk = clk_buffer(false);  // (of the device that is current: where the profiled launch ran)
+    if (!g_ev_valid || !clk) {
         set_error("no byte-table scan has been recorded (call annlite_profile_enable(1) first)");
         return ANNLITE_ERR_INVALID;
     }
     ANNLITE_HIP_TRY(hipEventSynchronize(g_ev1));
     unsigned long long h[4];
-    ANNLITE_HIP_TRY(hipMemcpy(h, g_clk, 32, hipMemcpyDeviceToHost));
+    ANNLITE_HIP_TRY(hipMemcpy(h, clk, 32, hipMemcpyDeviceToHost));
     if (h[3] <= h[1] || h[2] <= h[0]) {
         set_error("the last scan left no clock stamps (not a byte-table launch)");
         return ANNLITE_ERR_INVALID;
@@ -1084,7 +1089,7 @@ static SearchMode search_policy(annlite_scan_state *s, int64_t N, int64_t M, int
     // (k > 16: the byte-table kernel with 64-key lists exists for M = 16 / uint8 codes; it needs a table worth seeding)
     if (tiles || !both || (k > 16 && !(lk64_shape(M, Ks, code_bytes, k) && N >= 65536)) || N <= 0 || B <= 0) return kModePlain;
     if (g_variant_scope >= 0 || env_variant() >= 0) return kModePlain;        // (an explicit variant: A/B measurements)
-    if (getenv("ANNLITE_NO_INKERNEL_MERGE")) return kModePlain;                // (debug switch: no guarded pass)
+    if (knobs().no_inkernel_merge) return kModePlain;                // (debug switch: no guarded pass)
     if (!s) return kModeGuarded;
     const uint32_t seq = __atomic_load_n(s->host, __ATOMIC_ACQUIRE);
     if (seq != s->seen_seq && seq != 0) {  // a byte-table launch has completed since the last look
@@ -1192,7 +1197,7 @@ static int scan_topk_impl(const void *codes_dev, int code_bytes, int codes_layou
     ANNLITE_REQUIRE(B == 0 || tm || out_packed_dev || (out_dist_dev && out_id_dev), "null output pointer");
     const int sqrt_out = (flags & ANNLITE_FLAG_SQRT) && !out_packed_dev ? 1 : 0;
     ScanOut so = {out_dist_dev, out_id_dev, out_packed_dev, row_base, sqrt_out, false};
-    if (getenv("ANNLITE_NO_INKERNEL_MERGE") && !tm) so.d = nullptr, so.i = nullptr, so.packed = nullptr;
+    if (knobs().no_inkernel_merge && !tm) so.d = nullptr, so.i = nullptr, so.packed = nullptr;
     const SearchMode mode = search_policy(state, N, M, Ks, code_bytes, B, k, tm != nullptr);
     if (mode != kModePlain) {
         // (workspace: the public plan's size = byte-table region + u16 region; each pass checks its own)
@@ -1326,7 +1331,7 @@ static int pq_search_impl(int lut_kind, const float *queries_dev, int64_t B, int
     float *lut = (float *)((char *)workspace_dev + scan_ws);
     FastCfg c;
     const bool fuse = N > 0 && plan.fast && fast_cfg(M, Ks, code_bytes, k, &c, tm != nullptr) && c.qf() && M != 64 && Ks <= 256 &&
-                      lut_kind == ANNLITE_LUT_L2 && ((D / M) % 4) == 0 && !getenv("ANNLITE_NO_FUSED_LUT");
+                      lut_kind == ANNLITE_LUT_L2 && ((D / M) % 4) == 0 && !knobs().no_fused_lut;
     if (!fuse) {
         rc = annlite_lut_build(lut_kind, queries_dev, B, D, codebooks_dev, M, Ks, lut,
                                plan.fast ? ANNLITE_LAYOUT_TILED : ANNLITE_LAYOUT_BMK, plan.qi, stream);
@@ -1363,8 +1368,8 @@ extern "C" int annlite_pq_search_topk(int lut_kind, const float *queries_dev, in
 // ---- the search in two halves with the ranks' seed exchange in between (annlite_hip.h: annlite_pq_search_split) ----------------
 static bool split_shape_ok(int lut_kind, int64_t N, int64_t M, int64_t Ks, int code_bytes, int64_t B, int64_t D, int64_t k) {
     return lut_kind == ANNLITE_LUT_L2 && M == 16 && code_bytes == 1 && Ks <= 256 && k >= 1 && k <= 16 && B >= 1 && N >= 4096 &&
-           D <= 256 && D % M == 0 && ((D / M) % 4) == 0 && !getenv("ANNLITE_NO_FUSED_SEED") && !getenv("ANNLITE_NO_FUSED_LUT") &&
-           !getenv("ANNLITE_NO_INKERNEL_MERGE") && env_variant() < 0;
+           D <= 256 && D % M == 0 && ((D / M) % 4) == 0 && !knobs().no_fused_seed && !knobs().no_fused_lut &&
+           !knobs().no_inkernel_merge && env_variant() < 0;
 }
 
 extern "C" int annlite_pq_search_split(int phase, int64_t seed_rows, int lut_kind, const float *queries_dev, int64_t B, int64_t D,

@@ -886,11 +886,7 @@ int annlite::launch_lut_quantise(int64_t M, int64_t Ks, int64_t B, int64_t bpad,
 
 // runs of 8 blocks (512 rows: 8 KB of 16-byte code rows) keep the seed launch's scattered reads to a page per run
 // (ANNLITE_SEED_CHUNK_LOG=0..6: measurements)
-static int seed_chunk_log() {
-    const char *e = getenv("ANNLITE_SEED_CHUNK_LOG");
-    const int t = e ? atoi(e) : 3;
-    return t < 0 ? 0 : t > 6 ? 6 : t;
-}
+static int seed_chunk_log() { return knobs().seed_chunk_log; }
 
 int annlite::launch_seed_bound(int64_t M, bool skw, const void *codes_dev, int code_bytes, int64_t S, const uint32_t *valid_bits_dev,
                                const float *lut_dev, int64_t B, int64_t Ks, int64_t k, const float *smax,

@@ -5,6 +5,7 @@ section 7 "docarray is not installable here").  They expose exactly what the hot
 ``docs[:, 'id']`` (annlite/container.py:226-233, annlite/index.py:352-359, 540).
 With docarray installed the real classes are used and this module is never imported.
 """
+import threading
 import uuid
 from collections import defaultdict
 from typing import Iterable, List, Optional
@@ -134,6 +135,11 @@ class DocumentArray(list):
         return list.__contains__(self, item)
 
 
+# (one lock for all lists: materialisation is microseconds of python per list, and a per-instance lock would cost 1024 lock objects
+# per batch on the path this class exists to keep cheap)
+_MATERIALISE_LOCK = threading.RLock()
+
+
 class LazyMatches(DocumentArray):
     """``doc.matches`` of a search result, materialised on first use.
 
@@ -154,15 +160,15 @@ class LazyMatches(DocumentArray):
         self._pending = (offsets, dists, resolve)
 
     def _ensure(self):
-        p = self.__dict__.get('_pending')
-        if p is not None:
-            offsets, dists, resolve = p
-            docs = resolve(offsets, dists)
-            # storage first, the flag afterwards: a second reader that still sees `_pending` resolves again and finds the flag
-            # cleared below -- it never sees an empty list that claims to be materialised
-            if self.__dict__.get('_pending') is p:
-                list.extend(self, docs)
-                self._pending = None
+        if self.__dict__.get('_pending') is not None:
+            # ONE thread materialises, under the lock: check -> extend -> clear is not atomic otherwise (two readers could both pass
+            # the check and both extend: every match twice).  A reader that loses the race waits here and finds `_pending` cleared.
+            with _MATERIALISE_LOCK:
+                p = self.__dict__.get('_pending')
+                if p is not None:
+                    offsets, dists, resolve = p
+                    list.extend(self, resolve(offsets, dists))  # storage first, the flag afterwards
+                    self._pending = None
         return self
 
     @property

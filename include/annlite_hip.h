@@ -19,7 +19,9 @@
  *     shared space object and is not re-entrant: include/hnswlib/space_pq.h:55-64).  What a call
  *     remembers for the next one -- which scan kernel suits a code table -- lives in an
  *     annlite_scan_state the CALLER owns (one per table), never in the process.  The thread-local
- *     items are the last-error message and the measurement hooks (annlite_profile_*).
+ *     items are the last-error message and the measurement hooks (annlite_profile_*).  The ANNLITE_* environment
+ *     variables (A/B switches of measurements and tests, listed in DESIGN.md) are parsed ONCE when the library is
+ *     loaded; nothing on the search path reads the environment (annlite_knobs_reload() below).
  *   - there is NO CPU fallback in this library: if no gfx950 device is present the launches fail
  *     with ANNLITE_ERR_HIP.
  *
@@ -78,6 +80,11 @@ ANNLITE_API const char *annlite_hip_last_error(void);
 /* number of visible HIP devices and the gfx arch name of device `dev` (e.g. "gfx950:sramecc+:xnack-") */
 ANNLITE_API int annlite_hip_device_count(int *count);
 ANNLITE_API int annlite_hip_device_arch(int dev, char *buf, size_t buf_len);
+/* The measurement / test switches (ANNLITE_SCAN_VARIANT, ANNLITE_Q8_*, ANNLITE_SEED_*, ANNLITE_NO_*, ANNLITE_GUARD_BASE, ...) are
+ * read from the environment once, at load.  A process that changes them afterwards calls this to have them parsed again: the new
+ * block is published atomically, calls already running keep the one they started with.  No reference counterpart (the reference has
+ * no such switches); a production deployment never calls it. */
+ANNLITE_API int annlite_knobs_reload(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Scan plan: how the ADC scan kernel wants its inputs for a (M, Ks, code width, k) problem.
@@ -143,7 +150,8 @@ ANNLITE_API int annlite_adc_gather(const float *lut_bmk_dev, int64_t B, int64_t 
  * include/hnswlib/hnswalg.h searchBaseLayerST) for a whole batch; edge distances are hnswlib::PQLookup
  * (space_pq.h:15-37) bit for bit.  The graph comes from libannlite_graph.so (annlite_hnsw_export).
  * links_dev u32 [N][links_per_node + 1] (count, ids) ; seeds_dev u32 [n_seeds] DISTINCT nodes (top of the
- * hierarchy, scanned flat) ; codes_dev u8 [N][M] PLAIN ; lut_bmk_dev f32 [B][M][Ks] L2 tables ; ef <= 256 ; M in {8, 16, 32}
+ * hierarchy, scanned flat -- REQUIRED distinct, as annlite_hnsw_export produces them: the seed scan inserts without a duplicate
+ * test, a node listed twice would enter the beam twice and come back twice) ; codes_dev u8 [N][M] PLAIN ; lut_bmk_dev f32 [B][M][Ks] L2 tables ; ef <= 256 ; M in {8, 16, 32}
  * out_ids_dev i64 [B][ef] ascending by distance (-1 padded, deleted rows per valid_bits dropped),
  * out_dist_dev f32 [B][ef] (+inf padded). */
 ANNLITE_API int annlite_graph_search(const uint32_t *links_dev, int links_per_node, const uint32_t *seeds_dev,

@@ -154,10 +154,12 @@ def walk_ms(use_packed):
 
 
 os.environ['ANNLITE_DEBUG_COUNTERS'] = '1'
+_capi.knobs_reload()  # (the library parses its switches at load)
 walk_once(packed is not None)
 n_expand, n_eval, n_hit = _capi.graph_search_stats_ex()
 phase_cycles = dict(_capi.graph_search_stats_ex.cycles)
 del os.environ['ANNLITE_DEBUG_COUNTERS']
+_capi.knobs_reload()
 kernel_ms = walk_ms(packed is not None)
 plain_ms = walk_ms(False) if packed is not None else kernel_ms
 same = None

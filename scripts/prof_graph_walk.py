@@ -101,9 +101,11 @@ def walk():
 
 
 os.environ['ANNLITE_DEBUG_COUNTERS'] = '1'
+_capi.knobs_reload()  # (the library parses its switches at load)
 walk()
 n_expand, n_eval, n_hit = _capi.graph_search_stats_ex()
 del os.environ['ANNLITE_DEBUG_COUNTERS']
+_capi.knobs_reload()
 kms = []
 for _ in range(a.iters):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -47,6 +47,36 @@ def golden(request):
     return load_golden(request.param)
 
 
+def reload_knobs():
+    """The library reads its ANNLITE_* switches once, at load (common.h: Knobs); a test that changes them says so."""
+    from annlite_amd import _capi
+
+    _capi.knobs_reload()
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """pytest's monkeypatch, with the library told whenever an ANNLITE_* variable changes (setenv / delenv) and once more when
+    the test's changes are undone -- the tests' A/B switches keep working although nothing on the search path reads the
+    environment any more."""
+    setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
+
+    def _setenv(name, value, prepend=None):
+        setenv(name, value, prepend)
+        if name.startswith('ANNLITE_'):
+            reload_knobs()
+
+    def _delenv(name, raising=True):
+        delenv(name, raising)
+        if name.startswith('ANNLITE_'):
+            reload_knobs()
+
+    monkeypatch.setenv, monkeypatch.delenv = _setenv, _delenv
+    yield monkeypatch
+    monkeypatch.undo()
+    reload_knobs()
+
+
 def has_gpu():
     try:
         import torch

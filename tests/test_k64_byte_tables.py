@@ -51,12 +51,14 @@ def _scan(ops, codes, lut, k, layout, valid=None, row_base=0):
         codes_d = ops.codes_skew(codes_d)
     vb = ops.to_dev(_bits(valid)) if valid is not None else None
     os.environ['ANNLITE_DEBUG_COUNTERS'] = '2'
+    _capi.knobs_reload()  # (the library parses its switches at load: tell it)
     try:
         d, i = ops.adc_scan_topk(codes_d, lut_d, B, k, M, Ks, valid_bits=vb, row_base=row_base, codes_layout=layout)
         torch.cuda.synchronize()
         items = _capi.debug_timeline()['items'] if codes.shape[0] > 0 else 1
     finally:
         del os.environ['ANNLITE_DEBUG_COUNTERS']
+        _capi.knobs_reload()
     assert items > 0, 'the byte-table kernel did not run'
     return d.cpu().numpy(), i.cpu().numpy()
 

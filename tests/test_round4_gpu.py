@@ -413,16 +413,19 @@ def test_measured_shader_clock_and_kernel_revisions(ops, oracle):
     _capi.profile_enable(True)
     try:
         os.environ['ANNLITE_SCAN_VARIANT'] = '50'
+        _capi.knobs_reload()  # (the library parses its switches at load: tell it)
         ops.pq_search_topk(LUT_L2, q_d, cb_d, codes_d, k, M, Ks)
         torch.cuda.synchronize()
         ms, mhz = _capi.profile_last_scan_ms(), _capi.profile_last_scan_clock_mhz()
         assert ms > 0 and mhz is not None and 800.0 < mhz < 2600.0, (ms, mhz)
         os.environ['ANNLITE_SCAN_VARIANT'] = '31'  # the u16-table kernel: no stamps of its own
+        _capi.knobs_reload()
         ops.pq_search_topk(LUT_L2, q_d, cb_d, codes_d, k, M, Ks)
         torch.cuda.synchronize()
         assert _capi.profile_last_scan_ms() > 0 and _capi.profile_last_scan_clock_mhz() is None
     finally:
         os.environ.pop('ANNLITE_SCAN_VARIANT', None)
+        _capi.knobs_reload()
         _capi.profile_enable(False)
     for name in ('adc_scan_q8_kernel', 'adc_scan_qfilter_kernel', 'adc_scan_qfilter64_kernel', 'graph_beam_search_kernel'):
         assert _capi.kernel_rev(name) >= 1
