@@ -81,6 +81,7 @@ SYMBOLS = (
     'annlite_debug_timeline',
     'annlite_debug_items',
     'annlite_debug_prep_timeline',
+    'annlite_debug_seed_candidates',
 )
 
 
@@ -173,6 +174,7 @@ def lib() -> ctypes.CDLL:
     L.annlite_debug_timeline.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     L.annlite_debug_items.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
     L.annlite_debug_prep_timeline.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    L.annlite_debug_seed_candidates.argtypes = [vp, i64, i64, vp, vp, i32, i64, i64, i64, vp, i64, vp, vp]
     L.annlite_graph_search_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     L.annlite_graph_search_stats_ex.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     for name in SYMBOLS:

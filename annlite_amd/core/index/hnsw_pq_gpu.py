@@ -43,7 +43,7 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
         self.walk = walk  # where the graph is walked at query time: GPU kernel (default) or the host library
         # GPU walk over packed node records (neighbours' code rows inline: 656 B per node at M = 16, max_connection 16) -- the
         # default; False = the plain lists + code table (the parity tests compare the two)
-        self.packed_graph = bool(packed_graph)
+        self.packed_graph = bool(packed_graph)  # (False: the plain walk; `release_packed()` gives the records' memory back)
         self._packed = None
         self._packed_key = None
         self._graph = None
@@ -144,6 +144,10 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
             self._packed_key = key
         return self._packed
 
+    def release_packed(self):
+        """Free the packed node records (N x 656 B at 32 links, M = 16: 3.3 GB at 5M rows); the next packed walk rebuilds them."""
+        self._packed, self._packed_key = None, None
+
     def _gpu_walk_ok(self) -> bool:
         return self.walk == 'gpu' and self.M in (8, 16, 32) and self.Ks <= 256
 
@@ -164,7 +168,6 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
                 # read per expansion, the next record prefetched; the candidate lists are the plain walk's, bit for bit
                 return ops.graph_search_packed(self._packed_records(links, plain), links.shape[1] - 1, seeds, plain, lut, ef,
                                                valid_bits=self._valid, n_rows=self._n_rows)
-            self._packed, self._packed_key = None, None  # (the plain walk: the records' memory goes back)
             return ops.graph_search(links, seeds, plain, lut, ef, valid_bits=self._valid, n_rows=self._n_rows)
         x_np = np.ascontiguousarray(xg.cpu().numpy(), dtype=np.float32)
         B = x_np.shape[0]

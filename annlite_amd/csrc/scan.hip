@@ -875,9 +875,32 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                     gseed0 = (unsigned long long *)carve(bpad * 8);
                     btab = (uint8_t *)carve((int64_t)a.n_tiles * Ks * 2 * M * 16);  // (inside the region the u16 plan uses for q16)
                 }
-                rc = launch_seed_build(codes_layout == ANNLITE_CODES_SKEWED, codes_dev, S, seed_extent, valid_bits_dev, *build, const_cast<float *>(lut_dev),
+                // Round 6: the seed rows' exact scan (S x B x M look-up-adds on the VALU: 22 of the launch's 39 us) is replaced by an MFMA
+                // launch that NOMINATES kSeedCand rows per query (seed_mfma.hip) and the exact sums of those nominees here.  Where it
+                // applies: 128-d vectors (8-float sub-vectors: one code word = one MFMA operand half), a batch worth a 128-query
+                // workgroup tile, seed rows spread over the table (S rounded UP to a multiple of 8192 <= 131072: the groups), room in the
+                // workspace.  ANNLITE_NO_MFMA_SEED: the exact scan (A/B switch).  Any k distinct valid rows bound the k-th key: results
+                // are bit-exact either way.
+                const uint32_t *cand = nullptr;
+                int64_t S_prep = S;
+                {
+                    const int64_t S_m = ((S + 8191) / 8192) * 8192;
+                    const size_t cand_bytes = (size_t)bpad * kSeedCand * 4;
+                    char *ws_end = (char *)workspace_dev + plan.workspace_bytes;
+                    char *cp = (char *)((((uintptr_t)wp + 255) / 256) * 256);
+                    if (!kn.no_mfma_seed && build->D == 128 && B >= 64 && S >= 8192 && S_m <= 131072 && S_m <= N && seed_extent == N &&
+                        code_bytes == 1 && !(split && split->seed_rows > 0) && cp + cand_bytes <= ws_end) {
+                        rc = launch_seed_mfma(codes_layout == ANNLITE_CODES_SKEWED, build->queries, B, build->codebooks, Ks, codes_dev,
+                                              valid_bits_dev, N, S_m, knobs().seed_chunk_log, (uint32_t *)cp, st);
+                        if (rc != ANNLITE_OK) return rc;
+                        cand = (const uint32_t *)cp;
+                        wp = cp + cand_bytes;
+                        S_prep = S_m;
+                    }
+                }
+                rc = launch_seed_build(codes_layout == ANNLITE_CODES_SKEWED, codes_dev, S_prep, seed_extent, valid_bits_dev, *build, const_cast<float *>(lut_dev),
                                        B, Ks, k, qstep, qlo, smax, qlom, gk, workspace_dev, fill_bytes, (size_t)(((bpad * 8 + 255) / 256) * 256), st,
-                                       gseed0, btab, a.q8_target, a.dbg ? g_dbg_prep : nullptr, split ? split->seed_keys : nullptr);
+                                       gseed0, btab, a.q8_target, a.dbg ? g_dbg_prep : nullptr, split ? split->seed_keys : nullptr, cand, kSeedCand);
                 if (rc != ANNLITE_OK) return rc;
                 a.gseed0 = gseed0;
                 a.btab = btab;
@@ -975,6 +998,17 @@ extern "C" int annlite_debug_prep_timeline(uint64_t *out8) {
     ANNLITE_HIP_TRY(hipDeviceSynchronize());
     ANNLITE_HIP_TRY(hipMemcpy(out8, g_dbg_prep, 64, hipMemcpyDeviceToHost));
     return ANNLITE_OK;
+}
+
+extern "C" int annlite_debug_seed_candidates(const float *queries_dev, int64_t B, int64_t D, const float *codebooks_dev,
+                                             const void *codes_dev, int codes_layout, int64_t N, int64_t M, int64_t Ks,
+                                             const uint32_t *valid_bits_dev, int64_t seed_rows, uint32_t *cand_dev, void *stream) {
+    ANNLITE_REQUIRE(queries_dev && codebooks_dev && codes_dev && cand_dev, "null device pointer");
+    ANNLITE_REQUIRE(codes_layout == ANNLITE_CODES_PLAIN || codes_layout == ANNLITE_CODES_SKEWED, "bad codes_layout %d", codes_layout);
+    if (M != 16 || D != 128 || Ks < 1 || Ks > 256 || B < 1 || seed_rows < 8192 || seed_rows % 8192 != 0 || seed_rows > 131072 || seed_rows > N)
+        return ANNLITE_NOT_APPLICABLE;
+    return launch_seed_mfma(codes_layout == ANNLITE_CODES_SKEWED, queries_dev, B, codebooks_dev, Ks, codes_dev, valid_bits_dev, N, seed_rows,
+                            knobs().seed_chunk_log, cand_dev, (hipStream_t)stream);
 }
 
 extern "C" int annlite_debug_items(uint64_t *out, int64_t max_items, int64_t *n_items) {

@@ -360,8 +360,15 @@ int launch_seed_build(bool skewed, const void *codes_dev, int64_t S, int64_t N, 
                       float *lut_out, int64_t B, int64_t Ks, int64_t k, float *qstep, double *qlo, float *smax, float *qlom,
                       unsigned long long *gkey, void *fill, size_t fill_bytes, size_t gkey_bytes, hipStream_t st,
                       unsigned long long *gseed0 = nullptr, uint8_t *btab = nullptr, int target = 0,
-                      unsigned long long *dbg = nullptr, unsigned long long *seedk = nullptr);
+                      unsigned long long *dbg = nullptr, unsigned long long *seedk = nullptr, const uint32_t *cand = nullptr,
+                      int n_cand = 0);
 // seedk (optional): [B][kSeedKeys] the bounds implied by the seed's k smallest rows (annlite_pq_search_split)
 constexpr int kSeedKeys = 16;
+// seed_mfma.hip (round 6): per query the best row -- by a bf16 MFMA approximation of the ADC sum -- of each of kSeedCand disjoint
+// groups of S / kSeedCand seed rows; the preparation launch takes its bound from the nominees' exact sums instead of scanning the
+// S rows itself (launch_seed_build: cand)
+constexpr int kSeedCand = 512;
+int launch_seed_mfma(bool skewed, const float *queries_dev, int64_t B, const float *cb_dev, int64_t Ks, const void *codes_dev,
+                     const uint32_t *valid_bits_dev, int64_t N, int64_t S, int chunk_log, uint32_t *cand_dev, hipStream_t st);
 
 }  // namespace annlite

@@ -130,7 +130,84 @@ struct SeedBuild {
                                  // the OTHER ranks of a row-sharded search may prune with (annlite_pq_search_split)
     unsigned long long *dbg;     // optional: wall-clock stamps (100 MHz) of workgroup 0 [0..3] and the last one [4..7]:
                                  // start, tables built, rows scanned, end
+    // BUILD, optional (round 6): the rows an MFMA launch has NOMINATED for every query (seed_mfma.hip: the best row, by a bf16
+    // approximation of the ADC sum, of each of n_cand disjoint groups of seed rows; 0xffffffff = none) -- the bound then comes from
+    // THEIR exact sums (n_cand x 4 rows per workgroup) instead of the exact sums of all S seed rows
+    const uint32_t *cand;        // [B][n_cand] table rows, distinct per query
+    int32_t n_cand;
 };
+// BUILD (round 6): the seed bound from the rows an MFMA launch has nominated (seed_mfma.hip) instead of from S seed rows this
+// kernel scans itself.  Query p of the workgroup's 4 takes ceil(n_cand / 64) wave-iterations: lane = nominee; a row's sums run in
+// the lane's skewed order like the seed rows' (the row is rotated to the lane's skew: it sits at an arbitrary table row), only
+// query p's sum is used -- the nominees of ONE query are distinct rows, two queries may nominate the same row.  Two iterations
+// per wave at 512 nominees: both row ids are requested first, then both code rows (two dependent round trips for the pair, not
+// four).  Returns the lane's minimum per query (+inf: none).  The fp32 tables [Ks][M] x 4 queries sit at LDS address 0 (PERM
+// addressing).  (inlined: as an out-of-line call it cost the kernel a scratch frame -- 156 B -- for registers saved around the call)
+template <int M, bool SKEWED>
+__device__ __forceinline__ f32x4 seed_nominee_minima(const uint8_t *codes, const uint32_t *valid, int64_t ext,
+                                                               const uint32_t *cand, int n_cand, int g4, int B) {
+    static_assert(M == 16, "the fused preparation launch");
+    constexpr int CW = M / 4, CH = 16;
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t moff[M];
+#pragma unroll
+    for (int t = 0; t < M; ++t) moff[t] = (uint32_t)((lane + t) % M) << 4;
+    f32x4 best = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+    const int CI = (n_cand + 63) >> 6, total = 4 * CI;
+    for (int it0 = wave; it0 < total; it0 += 2 * kSeedWaves) {
+        uint32_t rowv[2];
+        int pq[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int it = it0 + u * kSeedWaves;
+            pq[u] = it < total ? it / CI : -1;
+            const int p = pq[u] < 0 ? 0 : pq[u];
+            const int c = (it - p * CI) * 64 + lane;
+            const int b = g4 * 4 + p;
+            rowv[u] = 0xffffffffu;
+            if (pq[u] >= 0 && c < n_cand && b < B) rowv[u] = cand[(int64_t)b * n_cand + c];
+        }
+        uint32_t cr[2][CW], vw[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t rr = (int64_t)rowv[u] < ext ? (int64_t)rowv[u] : 0;
+            const u32x4 v = *(const u32x4 *)(codes + rr * M);
+            cr[u][0] = v.x, cr[u][1] = v.y, cr[u][2] = v.z, cr[u][3] = v.w;
+            vw[u] = valid ? valid[rr >> 5] : ~0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (pq[u] < 0) continue;  // (wave-uniform)
+            const uint32_t row = rowv[u];
+            const bool ok = (int64_t)row < ext && ((vw[u] >> (row & 31)) & 1u);
+            // the row rotated to this lane's skew: byte t <- the code of sub-space (lane + t) mod M
+            const int rot = SKEWED ? (int)((uint32_t)(lane - (int)(row % M)) & (uint32_t)(M - 1)) : lane % M;
+            bool ab[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ab[i] = (((rot >> 2) >> i) & 1) != 0;
+            rotate_row<CW>(cr[u], ab, (uint32_t)(rot & 3));
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            f32x4 v[CH];
+            static_for<0, CH>([&](auto I) {
+                constexpr int t = decltype(I)::value;
+                typedef const f32x4 __attribute__((address_space(3))) *lds_fq_ptr;
+                const uint32_t ad = __builtin_amdgcn_perm(cr[u][t / 4], moff[t], 0x0c0c0000u | ((4u + (uint32_t)(t % 4)) << 8));
+                v[t] = *(lds_fq_ptr)(uintptr_t)ad;
+            });
+#pragma unroll
+            for (int i = 0; i < CH; ++i) d += v[i];  // (the lane's skewed order, like the seed rows')
+            const float mine = pq[u] == 0 ? d[0] : pq[u] == 1 ? d[1] : pq[u] == 2 ? d[2] : d[3];
+            const float dv = ok ? mine : __builtin_inff();
+            if (pq[u] == 0) best[0] = fminf(best[0], dv);
+            else if (pq[u] == 1) best[1] = fminf(best[1], dv);
+            else if (pq[u] == 2) best[2] = fminf(best[2], dv);
+            else best[3] = fminf(best[3], dv);
+        }
+    }
+    return best;
+}
+
 // LDS behind the fp32 tables: [0, 16 KB) the selection's candidates u32 [QPB][16 waves * k] (BUILD: first the queries, the
 // per-wave column minima / maxima), [16 KB, 20 KB) the waves' 64 lane minima, then the block counter and what the BUILD
 // variant keeps until its end (column minima, parameters, seed keys)
@@ -344,10 +421,19 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
     int64_t run_step = ((ext >> 6) / ((n_blocks + cmask) >> clog)) << 6;  // rows between the starts of two runs of seed blocks
     if (run_step < ((int64_t)64 << clog)) run_step = (int64_t)64 << clog;
     auto block_row = [&](uint32_t b) -> int64_t { return (int64_t)(b >> clog) * run_step + (int64_t)((b & cmask) << 6); };
-    uint32_t b_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)draw_block());
-    uint32_t b_pend = draw_block();
-    fetch(block_row(b_cur) + lane, cn, vn);
-    uint32_t b_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_pend);
+    bool nominated = false;
+    if constexpr (BUILD) nominated = sb.cand != nullptr;
+    if constexpr (BUILD && PERM) {
+        if (nominated) {  // the bound from the exact sums of the rows an MFMA launch nominated
+            const f32x4 nb = seed_nominee_minima<M, SKEWED>(codes, valid, ext, sb.cand, sb.n_cand, g4, B);
+#pragma unroll
+            for (int q = 0; q < QPB; ++q) bestf[q] = nb[q];
+        }
+    }
+    uint32_t b_cur = nominated ? n_blocks : (uint32_t)__builtin_amdgcn_readfirstlane((int)draw_block());
+    uint32_t b_pend = nominated ? n_blocks : draw_block();
+    if (!nominated) fetch(block_row(b_cur) + lane, cn, vn);
+    uint32_t b_nxt = nominated ? n_blocks : (uint32_t)__builtin_amdgcn_readfirstlane((int)b_pend);
     while (b_cur < n_blocks) {
         const int64_t r = block_row(b_cur) + lane;
         b_pend = draw_block();
@@ -933,7 +1019,7 @@ int annlite::launch_seed_build(bool skw, const void *codes_dev, int64_t S, int64
                                float *lut_out, int64_t B, int64_t Ks, int64_t k, float *qstep, double *qlo, float *smax, float *qlom,
                                unsigned long long *gk, void *fill, size_t fill_bytes, size_t gk_bytes, hipStream_t st,
                                unsigned long long *gseed0, uint8_t *btab, int target, unsigned long long *dbg,
-                               unsigned long long *seedk) {
+                               unsigned long long *seedk, const uint32_t *cand, int n_cand) {
     constexpr int M = 16;
     SeedBuild sb;
     sb.queries = build.queries;
@@ -956,6 +1042,8 @@ int annlite::launch_seed_build(bool skw, const void *codes_dev, int64_t S, int64
     sb.chunk_log = seed_chunk_log();
     sb.dbg = dbg;
     sb.seedk = seedk;
+    sb.cand = cand;
+    sb.n_cand = cand ? n_cand : 0;
     auto fn = skw ? seed_bound_kernel<M, true, 4, false, true> : seed_bound_kernel<M, false, 4, false, true>;
     const size_t lds = (size_t)Ks * M * 16 + (size_t)kSeedLdsExtra;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

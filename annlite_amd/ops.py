@@ -231,6 +231,26 @@ def pq_search_topk(lut_kind: int, queries: torch.Tensor, codebooks: torch.Tensor
     return op if packed else (od, oi)
 
 
+def debug_seed_candidates(queries: torch.Tensor, codebooks: torch.Tensor, codes: torch.Tensor, seed_rows: int,
+                          valid_bits: Optional[torch.Tensor] = None, n_rows: Optional[int] = None,
+                          codes_layout: int = CODES_PLAIN) -> Optional[torch.Tensor]:
+    """Test hook (``annlite_debug_seed_candidates``): the rows the MFMA launch nominates for the seed bound, int64 [B, 512]
+    (-1 = none); ``None`` where the launch does not apply (not M = 16 / 128-d, seed_rows not a multiple of 8192 ...)."""
+    N = codes.shape[0] if n_rows is None else n_rows
+    B, D = queries.shape
+    M, Ks = codebooks.shape[0], codebooks.shape[1]
+    out = torch.empty((B, 512), dtype=torch.int32, device=codes.device)
+    rc = lib().annlite_debug_seed_candidates(queries.data_ptr(), B, D, codebooks.data_ptr(), codes.data_ptr(), codes_layout, N, M, Ks,
+                                             _ptr(valid_bits), int(seed_rows), out.data_ptr(), stream_ptr())
+    from ._capi import NOT_APPLICABLE
+
+    if rc == NOT_APPLICABLE:
+        return None
+    check(rc, 'debug_seed_candidates')
+    o = out.to(torch.int64)
+    return torch.where(o < 0, o + (1 << 32), o).masked_fill(out == -1, -1)
+
+
 def pq_search_split(phase: int, lut_kind: int, queries: torch.Tensor, codebooks: torch.Tensor, codes: torch.Tensor, k: int, M: int,
                     Ks: int, state, workspace: ScanWorkspace, valid_bits: Optional[torch.Tensor] = None, row_base: int = 0,
                     n_rows: Optional[int] = None, codes_layout: int = CODES_PLAIN, seed_rows: int = 0,

@@ -318,6 +318,14 @@ ANNLITE_API int annlite_debug_items(uint64_t *out, int64_t max_items, int64_t *n
 /* ... and of the byte-table plan's preparation launch (tables + parameters + reset + seed bound [+ byte tables], one launch):
  * stamps of its first workgroup [0..3] and its last one [4..7]: start, tables built, seed rows scanned, end. */
 ANNLITE_API int annlite_debug_prep_timeline(uint64_t *out8);
+/* Test hook of the seed bound's MFMA nomination launch (round 6, seed_mfma.hip; M = 16, 128-d, uint8 codes): `seed_rows` seed rows
+ * (a multiple of 8192, <= 131072, <= N) spread over the table are cut into 512 disjoint groups; cand_dev u32 [B][512] receives, per
+ * query and group, the table row with the smallest APPROXIMATE (bf16 contraction) ADC distance -- 0xffffffff where the group holds
+ * no valid row.  The search itself never returns these: it takes the k-th smallest EXACT sum of a query's nominees as its first
+ * bound (any k distinct valid rows give a valid one).  ANNLITE_NOT_APPLICABLE for other shapes.  No reference counterpart. */
+ANNLITE_API int annlite_debug_seed_candidates(const float *queries_dev, int64_t B, int64_t D, const float *codebooks_dev,
+                                  const void *codes_dev, int codes_layout, int64_t N, int64_t M, int64_t Ks,
+                                  const uint32_t *valid_bits_dev, int64_t seed_rows, uint32_t *cand_dev, void *stream);
 
 /* Convert between the PLAIN and the SKEWED code-table layout (uint8 codes).
  * forward (inverse=0): table_out[id][j] = codes_in[i][(j + id) mod M]   -- scatter rows i -> id
