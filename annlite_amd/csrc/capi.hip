@@ -91,7 +91,7 @@ static Knobs *parse_knobs() {
     k->early_merge_patience = env_i64("ANNLITE_EARLY_MERGE_PATIENCE", -1);
     k->no_inkernel_merge = getenv("ANNLITE_NO_INKERNEL_MERGE") != nullptr;
     k->no_fused_lut = getenv("ANNLITE_NO_FUSED_LUT") != nullptr;
-    k->no_mfma_seed = getenv("ANNLITE_NO_MFMA_SEED") != nullptr;
+    k->mfma_seed = getenv("ANNLITE_MFMA_SEED") != nullptr;
     k->graph_hash_bits = env_int("ANNLITE_GRAPH_HASH_BITS", -1);
     k->graph_seq_insert = getenv("ANNLITE_GRAPH_SEQ_INSERT") != nullptr;
     return k;

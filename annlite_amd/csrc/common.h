@@ -67,7 +67,8 @@ struct Knobs {
     int64_t early_merge_patience;  // ANNLITE_EARLY_MERGE_PATIENCE
     bool no_inkernel_merge;     // ANNLITE_NO_INKERNEL_MERGE
     bool no_fused_lut;          // ANNLITE_NO_FUSED_LUT
-    bool no_mfma_seed;          // ANNLITE_NO_MFMA_SEED (A/B: the seed rows' exact scan instead of the MFMA candidate launch)
+    bool mfma_seed;             // ANNLITE_MFMA_SEED (opt-in: the seed bound from MFMA-nominated rows, seed_mfma.hip -- measured slower
+                                // than the seed rows' exact scan as a whole)
     int graph_hash_bits;        // ANNLITE_GRAPH_HASH_BITS
     bool graph_seq_insert;      // ANNLITE_GRAPH_SEQ_INSERT
 };

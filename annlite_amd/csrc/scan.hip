@@ -354,10 +354,13 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
         // M = 8, Ks <= 512, k <= 16: the byte-table kernel (scan_q8.hip, C16: table [Ks][2][8][16 B], 32 queries per workgroup,
         // conflict-free); ANNLITE_SCAN_VARIANT=31: the u16-table kernel (A/B)
         if (M == 8 && Ks <= 512 && k <= 16 && (scan_variant() == 0 || scan_variant() == 50)) { *c = {8, 4, 2, 16, 4, 1, 850, 5}; return true; }
+        // (16 < k <= 64, round 6: the same kernel with 64-key lists -- only where the library asks for it, variant 50, as for M = 16)
+        if (M == 8 && Ks <= 512 && k <= 64 && scan_variant() == 50) { *c = {8, 4, 2, 16, 4, 1, 8650, 5}; return true; }
         if (M == 8 && Ks <= 512) { *c = {8, 4, 2, 16, 4, 1, 8217, 4}; return true; }   // u16 tables, 16 queries per workgroup
         // 512 < Ks <= 1024: byte tables of ONE entry group (16 queries per workgroup; 2-way bank conflicts, inherent -- still
         // half the LDS time per query of the u16 tables' 8)
         if (M == 8 && Ks <= 1024 && k <= 16 && (scan_variant() == 0 || scan_variant() == 50)) { *c = {8, 4, 1, 16, 4, 1, 851, 5}; return true; }
+        if (M == 8 && Ks <= 1024 && k <= 64 && scan_variant() == 50) { *c = {8, 4, 1, 16, 4, 1, 8651, 5}; return true; }
         if (M == 8 && Ks <= 1024) { *c = {8, 4, 1, 16, 4, 1, 8216, 4}; return true; }
         if (M == 16 && Ks <= 512) { *c = {16, 4, 1, 16, 4, 1, 16216, 4}; return true; }
         return false;
@@ -369,6 +372,7 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
             // default: byte tables (scan_q8.hip, M8 shape: table [Ks][2][8][16 B] = 64 KB, 32 queries / WG); k > 16, tile mode and
             // variant 31: u16 tables, 16 queries / WG
             if ((v == 0 || v == 50) && !tiles && k <= 16) { *c = {8, 4, 2, 16, 4, 1, 852, 5}; return true; }
+            if (v == 50 && !tiles && k <= 64) { *c = {8, 4, 2, 16, 4, 1, 864, 5}; return true; }  // 64-key lists (round 6)
             *c = {8, 4, 2, 16, 4, 1, 830, 4};
             return true;
         case 16:
@@ -386,6 +390,7 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
             // default: byte tables (scan_q8.hip, 3250: one entry group, 16 queries / WG, 15 scanning waves + 1 consumer -- 10M rows x 1024
             // queries 2.79 ms against the u16 tables' 7.41); k > 16, tile mode and variant 31: u16 tables, 8 queries / WG
             if ((v == 0 || v == 50) && !tiles && k <= 16) { *c = {32, 4, 1, 16, 4, 1, 3250, 5}; return true; }
+            if (v == 50 && !tiles && k <= 64) { *c = {32, 4, 1, 16, 4, 1, 3264, 5}; return true; }  // 64-key lists (round 6)
             *c = {32, 4, 1, 12, 3, 1, 3230, 4};
             return true;
         case 64:
@@ -400,8 +405,12 @@ static bool fast_cfg(int64_t M, int64_t Ks, int code_bytes, int64_t k, FastCfg *
     }
 }
 
-// shapes the byte-table kernel serves beyond k = 16 (64-key lists, scan_q8.hip id 1664)
-static bool lk64_shape(int64_t M, int64_t Ks, int code_bytes, int64_t k) { return M == 16 && code_bytes == 1 && Ks <= 256 && k > 16 && k <= 64; }
+// shapes the byte-table kernel serves beyond k = 16 (64-key lists, scan_q8.hip ids 1664; round 6: 864 / 3264 / 8650 / 8651)
+static bool lk64_shape(int64_t M, int64_t Ks, int code_bytes, int64_t k) {
+    if (k <= 16 || k > 64) return false;
+    if (code_bytes == 1) return (M == 16 || M == 8 || M == 32) && Ks <= 256;
+    return code_bytes == 2 && M == 8 && Ks <= 1024;
+}
 
 static int round_up(int64_t x, int64_t m) { return (int)(((x + m - 1) / m) * m); }
 // queries the per-query workspace arrays are sized for: whole tiles, at least the 16 the fp32 TILED table is padded to
@@ -875,12 +884,14 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                     gseed0 = (unsigned long long *)carve(bpad * 8);
                     btab = (uint8_t *)carve((int64_t)a.n_tiles * Ks * 2 * M * 16);  // (inside the region the u16 plan uses for q16)
                 }
-                // Round 6: the seed rows' exact scan (S x B x M look-up-adds on the VALU: 22 of the launch's 39 us) is replaced by an MFMA
-                // launch that NOMINATES kSeedCand rows per query (seed_mfma.hip) and the exact sums of those nominees here.  Where it
-                // applies: 128-d vectors (8-float sub-vectors: one code word = one MFMA operand half), a batch worth a 128-query
-                // workgroup tile, seed rows spread over the table (S rounded UP to a multiple of 8192 <= 131072: the groups), room in the
-                // workspace.  ANNLITE_NO_MFMA_SEED: the exact scan (A/B switch).  Any k distinct valid rows bound the k-th key: results
-                // are bit-exact either way.
+                // Round 6, OPT-IN (ANNLITE_MFMA_SEED): the seed rows' exact scan (S x B x M look-up-adds on the VALU: 22 of the launch's
+                // 40 us) replaced by an MFMA launch that NOMINATES kSeedCand rows per query (seed_mfma.hip) and the exact sums of those
+                // nominees here.  Where it applies: 128-d vectors (8-float sub-vectors: one code word = one MFMA operand half), a batch
+                // worth a 128-query workgroup tile, seed rows spread over the table (S rounded UP to a multiple of 8192 <= 131072: the
+                // groups), room in the workspace.  Any k distinct valid rows bound the k-th key: results are bit-exact either way.
+                // Measured (profiles/r06/mfma_seed_ab.txt): the preparation launch shrinks from 40.3 to 20.6 us, the nomination launch
+                // takes more than that back (its A operand is gathered from a bf16 codebook in LDS -- bank conflicts of random codes --
+                // behind a 6 us prologue that converts the codebooks): not the default.
                 const uint32_t *cand = nullptr;
                 int64_t S_prep = S;
                 {
@@ -888,7 +899,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                     const size_t cand_bytes = (size_t)bpad * kSeedCand * 4;
                     char *ws_end = (char *)workspace_dev + plan.workspace_bytes;
                     char *cp = (char *)((((uintptr_t)wp + 255) / 256) * 256);
-                    if (!kn.no_mfma_seed && build->D == 128 && B >= 64 && S >= 8192 && S_m <= 131072 && S_m <= N && seed_extent == N &&
+                    if (kn.mfma_seed && build->D == 128 && B >= 64 && S >= 8192 && S_m <= 131072 && S_m <= N && seed_extent == N &&
                         code_bytes == 1 && !(split && split->seed_rows > 0) && cp + cand_bytes <= ws_end) {
                         rc = launch_seed_mfma(codes_layout == ANNLITE_CODES_SKEWED, build->queries, B, build->codebooks, Ks, codes_dev,
                                               valid_bits_dev, N, S_m, knobs().seed_chunk_log, (uint32_t *)cp, st);

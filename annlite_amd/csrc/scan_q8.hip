@@ -232,6 +232,10 @@ __device__ __forceinline__ void q8_build_table_wide(const Q8Build &a, int tile, 
 }
 
 constexpr int kRingSize = 1024;   // candidate ring entries (u64 each): one private ring of kWaveRing entries per scanning wave
+// bytes of a ring entry: the M = 16 kernel with 64-key lists always runs the row queue (bare 4-byte row ids -- what lets the 160 KB
+// hold its 128 KB table, 16 KB of lists and the row queue's parking area); every other shape pushes (S << 40 | slot << 32 | row)
+template <int M, int LK>
+constexpr int q8_ring_entry_bytes() { return (LK == 64 && M == 16) ? 4 : 8; }
 constexpr int kWaveRing = 64;     // (a wave-step pushes at most 64 entries at a time)
 constexpr int kPopPerRing = 8;    // entries the consumer takes from one wave's ring per batch (8 x 15 rings <= 128 = two per lane)
 
@@ -251,7 +255,8 @@ struct Q8Lds {
     uint32_t tab, shq, ring_ctl, gkl, step, inv, tb, ctl, clip, tau, c0, c1, list, gjl, ring, qkey, qslot, chg, stamps, seen, rowq;
     // lk: keys per slot list -- 16 (k <= 16, four insertions at a time), or 64 (16 < k <= 64: one 64-lane list per slot, 16 KB;
     // its ring entries are the row queue's bare 4-byte row ids, which is what makes the 160 KB hold it)
-    __device__ __forceinline__ explicit Q8Lds(int lut_bytes, int lk = 16) {
+    // re: bytes of a ring entry (q8_ring_entry_bytes: 4 = the row queue's bare row ids, 8 = (S, slot, row))
+    __device__ __forceinline__ explicit Q8Lds(int lut_bytes, int lk = 16, int re = 8) {
         tab = lds_base_addr();
         shq = tab + (uint32_t)lut_bytes;
         ring_ctl = shq + 32;
@@ -267,7 +272,7 @@ struct Q8Lds {
         list = shq + 1664;
         gjl = list + 32u * (uint32_t)lk * 8u;
         ring = gjl + 32 * 8;
-        qkey = ring + kRingSize * (lk == 64 ? 4 : 8);
+        qkey = ring + kRingSize * (uint32_t)re;
         qslot = qkey + 4 * 128 * 8;
         chg = qslot + 4 * 128;
         stamps = chg + 32;
@@ -572,7 +577,7 @@ __device__ __attribute__((noinline)) void q8_rebuild(q8_kernarg_ptr ka, int tile
                        ka->Ks, ka->B, ka->k, ka->q8_target, ka->gseed0, ka->btab};
     const bool prebuilt = first && a.btab != nullptr && M == 16 && NQ == 2;
     const int tid = threadIdx.x;
-    const Q8Lds o(q8_table_bytes<M, NQ>(a.Ks), LK);
+    const Q8Lds o(q8_table_bytes<M, NQ>(a.Ks), LK, q8_ring_entry_bytes<M, LK>());
     if (tid < 32) {  // (the control block has 32 slots whatever QT is: the consumer's lanes 0 .. 31 look at all of them)
         const uint32_t t8 = 8u * (uint32_t)tid, t4 = 4u * (uint32_t)tid;
         const int b = tile * QT + tid;
@@ -993,7 +998,7 @@ __device__ __attribute__((noinline)) void q8_finish_item(q8_kernarg_ptr ka, int 
     constexpr int QT = q8_qt<M, NQ>();
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int km1 = ka->k - 1, B = ka->B, n_slices = ka->n_slices, k = ka->k;
-    const Q8Lds lds(q8_table_bytes<M, NQ>(ka->Ks), LK);
+    const Q8Lds lds(q8_table_bytes<M, NQ>(ka->Ks), LK, q8_ring_entry_bytes<M, LK>());
     unsigned long long *partial = ka->partial;
     for (int q = wave; q < QT; q += NW) {
         const int b = tile * QT + q;
@@ -1035,8 +1040,8 @@ __device__ __attribute__((noinline)) void q8_finish_item(q8_kernarg_ptr ka, int 
 
 template <int M, int NW, bool SKEWED, int NQ, int CB, bool RQ, int LK = 16>
 __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const ScanArgs a) {
-    static_assert(LK == 16 || (LK == 64 && RQ), "64-key lists: the shared-bound M = 16 kernel with the row queue (4-byte ring entries)");
-    constexpr uint32_t RE = LK == 64 ? 4u : 8u;  // bytes of a ring entry
+    static_assert(LK == 16 || (LK == 64 && (RQ || M != 16) && M != 64), "64-key lists: M = 16 with the row queue (4-byte ring entries), M = 8 / 32");
+    constexpr uint32_t RE = (uint32_t)q8_ring_entry_bytes<M, LK>();  // bytes of a ring entry
     constexpr bool WIDE = Q8Cfg<M>::WIDE;
     constexpr bool M8 = Q8Cfg<M>::M8, M32 = Q8Cfg<M>::M32, C16 = CB == 2;
     constexpr bool ROWQ = RQ && ANNLITE_Q8_ROWQ != 0;  // (row queue: see q8_row_pass_mask)
@@ -1055,7 +1060,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
     const int km1 = a.k - 1;
 
     const int lut_bytes = q8_table_bytes<M, NQ>(a.Ks);
-    const Q8Lds lds(lut_bytes, LK);
+    const Q8Lds lds(lut_bytes, LK, (int)RE);
     const q8_kernarg_ptr ka = q8_kernarg();
 
     if (a.guard && tid == 0) ldsv_st<uint32_t>(lds.seen, 0u);
@@ -1947,8 +1952,10 @@ using namespace annlite;
 template <int M, int NW, bool SKEWED, int NQ, int CB, bool RQ = false, int LK = 16>
 static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
     constexpr int QT = 32;  // (the control block is laid out for 32 slots whatever the kernel uses)
+    // (the row queue's parking area, 3072 B behind everything else, exists only for the kernels that run it: the 128 KB tables of
+    // M = 32 / M = 8 with uint16 codes + 16 KB of 64-key lists + the 8 KB ring fit the 160 KB without it)
     const size_t need = (size_t)(M == 64 ? (a.Ks + 1) * 512 : M == 32 ? 131072 : a.Ks * NQ * M * 16) + 1664 + (size_t)QT * LK * 8 + QT * 8 +
-                        (size_t)kRingSize * (LK == 64 ? 4 : 8) + 4 * 128 * 9 + 32 + 32 + 16 + 3072;
+                        (size_t)kRingSize * q8_ring_entry_bytes<M, LK>() + 4 * 128 * 9 + 32 + 32 + 16 + ((RQ || LK == 16) ? 3072 : 0);
     ANNLITE_REQUIRE(need <= 160 * 1024, "byte-table kernel: %zu B of LDS", need);
     auto fn = adc_scan_q8_kernel<M, NW, SKEWED, NQ, CB, RQ, LK>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
@@ -1967,6 +1974,14 @@ int annlite::launch_q8_scan(int id, bool sk, const ScanArgs &a, int grid, hipStr
         case 1664:  // M = 16, 16 < k <= 64: 64-key lists (one insertion per wave operation), the slices merged by merge_partial_kernel
             if (!a.gkey || a.tile_done) { set_error("the 64-key-list kernel serves the shared-bound search without an in-kernel merge"); return ANNLITE_ERR_UNSUPPORTED; }
             return sk ? launch_q8<16, 16, true, 2, 1, true, 64>(a, grid, st) : launch_q8<16, 16, false, 2, 1, true, 64>(a, grid, st);
+        // 16 < k <= 64 for M = 8 / 32 (round 6: the reference's own PQ test searches topk = 50 at M = 8, Ks 256 / 512 / 768,
+        // tests/test_pq_index.py:78-135): the same kernels with 64-key lists, merged by merge_partial_kernel like 1664
+        case 864: case 3264: case 8650: case 8651:
+            if (!a.gkey || a.tile_done) { set_error("the 64-key-list kernels serve the shared-bound search without an in-kernel merge"); return ANNLITE_ERR_UNSUPPORTED; }
+            if (id == 864) return sk ? launch_q8<8, 16, true, 2, 1, false, 64>(a, grid, st) : launch_q8<8, 16, false, 2, 1, false, 64>(a, grid, st);
+            if (id == 3264) return sk ? launch_q8<32, 16, true, 1, 1, false, 64>(a, grid, st) : launch_q8<32, 16, false, 1, 1, false, 64>(a, grid, st);
+            if (sk) { set_error("uint16 codes: PLAIN rows only"); return ANNLITE_ERR_UNSUPPORTED; }
+            return id == 8651 ? launch_q8<8, 16, false, 1, 2, false, 64>(a, grid, st) : launch_q8<8, 16, false, 2, 2, false, 64>(a, grid, st);
         case 6450: return sk ? launch_q8<64, 16, true, 2, 1>(a, grid, st) : launch_q8<64, 16, false, 2, 1>(a, grid, st);
         case 3250:  // M = 32: one entry group, 16 queries per workgroup, two half tables of 16 sub-spaces
             return sk ? launch_q8<32, 16, true, 1, 1>(a, grid, st) : launch_q8<32, 16, false, 1, 1>(a, grid, st);

@@ -747,7 +747,7 @@ def main():
         plan_k = _capi.scan_plan(n_local, M, Ks, index.code_bytes, B, k)
         # (which M = 16 kernel served the table is the library's choice, from what its launches measured: index.scan_kernel)
         # (16 < k <= 64 at M = 16: the public plan is the u16 plan, the library's search runs the byte-table kernel with 64-key lists)
-        lk64 = M == 16 and index.code_bytes == 1 and Ks <= 256 and 16 < k <= 64 and n_local >= 65536
+        lk64 = ((M in (8, 16, 32) and index.code_bytes == 1 and Ks <= 256) or (M == 8 and index.code_bytes == 2 and Ks <= 1024)) and 16 < k <= 64 and n_local >= 65536
         byte_tables = (plan_k.qt == 32 or (M == 64 and plan_k.qt == 8) or (M == 8 and index.code_bytes == 2 and plan_k.qt == 16) or
                        (M == 32 and plan_k.qt == 16) or lk64) and \
             index.scan_kernel != 'u16 tables' and \

@@ -4,7 +4,7 @@ nominees -- any k distinct valid rows give a valid bound, so the results must no
 
 What is checked here: (1) the nomination launch itself -- every nominee is a valid row of ITS group and (nearly) the group's best
 by the exact ascending-m fp32 sum (a wrong operand layout nominates random rows); (2) the search with the nominated seed equals the
-search with the exact seed scan (ANNLITE_NO_MFMA_SEED) and the CPU oracle, bit for bit, on both code layouts, with deleted rows,
+search with the exact seed scan (the default; ANNLITE_MFMA_SEED=1 opts in) and the CPU oracle, bit for bit, on both code layouts, with deleted rows,
 ragged batches, k on the 16- and the 64-key lists, and a table whose seed rows must be rounded up to the group grid
 (reference: annlite/core/codec/pq.py:316-322 tables, pq_bindings.pyx:30-47 sums, math.py:94-120 selection)."""
 import numpy as np
@@ -154,11 +154,11 @@ def test_search_with_nominated_seed_equals_exact_seed_and_oracle(ops, oracle, mo
     stored = ops.codes_skew(codes) if layout == 1 else codes
     kw = dict(valid_bits=vb, n_rows=N, codes_layout=layout)
     out = {}
-    for name, env in (('mfma', None), ('exact', '1')):
+    for name, env in (('mfma', '1'), ('exact', None)):
         if env:
-            monkeypatch.setenv('ANNLITE_NO_MFMA_SEED', env)
+            monkeypatch.setenv('ANNLITE_MFMA_SEED', env)
         else:
-            monkeypatch.delenv('ANNLITE_NO_MFMA_SEED', raising=False)
+            monkeypatch.delenv('ANNLITE_MFMA_SEED', raising=False)
         st = _capi.ScanState()
         for _ in range(3):  # (guarded first call, then the settled byte-table kernel)
             d, i = ops.pq_search_topk(LUT_L2, q_d, cb_d, stored, k, 16, 256, state=st, **kw)
@@ -186,11 +186,11 @@ def test_preparation_launch_is_shorter_with_nominees(ops, monkeypatch):
     q_d = ops.to_dev((rs.randn(B, 12).astype(np.float32) @ A).astype(np.float32))
     seed_us = {}
     monkeypatch.setenv('ANNLITE_DEBUG_COUNTERS', '2')
-    for name, env in (('mfma', None), ('exact', '1')):
+    for name, env in (('mfma', '1'), ('exact', None)):
         if env:
-            monkeypatch.setenv('ANNLITE_NO_MFMA_SEED', env)
+            monkeypatch.setenv('ANNLITE_MFMA_SEED', env)
         else:
-            monkeypatch.delenv('ANNLITE_NO_MFMA_SEED', raising=False)
+            monkeypatch.delenv('ANNLITE_MFMA_SEED', raising=False)
         st = _capi.ScanState()
         for _ in range(4):
             ops.pq_search_topk(LUT_L2, q_d, cb_d, codes, k, 16, 256, codes_layout=1, state=st)
