@@ -222,16 +222,34 @@ def device_arch(dev: int = 0) -> str:
     return buf.value.decode()
 
 
+_gpu_seen = False
+
+
 def require_gpu() -> None:
+    global _gpu_seen
+    if _gpu_seen:  # (torch.cuda.is_available() costs microseconds of python per call: seven calls per batch on the search path)
+        return
     import torch
 
     if not torch.cuda.is_available():
         raise RuntimeError('annlite_amd needs an AMD GPU (MI355X / gfx950); no HIP device is visible and there is no CPU fallback')
+    _gpu_seen = True
+
+
+_raw_stream = None
 
 
 def stream_ptr() -> int:
+    """hipStream_t of torch's current stream on the current device, as an integer.  torch.cuda.current_stream() builds a python Stream
+    object through three layers of device-index resolution (~3 us, five times per batch with the exchange on); the raw getter is one C
+    call."""
+    global _raw_stream
     import torch
 
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', False)
+    if _raw_stream:
+        return int(_raw_stream(torch._C._cuda_getDevice()))
     return int(torch.cuda.current_stream().cuda_stream)
 
 

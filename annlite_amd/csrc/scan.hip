@@ -78,6 +78,110 @@ __global__ __launch_bounds__(NW * 64) void adc_scan_generic_kernel(const ScanArg
 }
 
 // =================================================================================================
+// The same scan with the query's table IN LDS (round 6): shapes without a filter kernel whose fp32 table [M][Ks] fits
+// (<= 144 KB: the reference example's M = 128 / 1-float sub-vectors, examples/pq_benchmark.py:44, odd M, uint16 codes at M = 16,
+// ...).  One query per 16-wave workgroup; a lane's code row comes in 16-byte (or 4-byte) loads instead of one byte load per
+// (row, sub-space) -- the generic kernel's M global byte loads per row, every one a separate cache-line request per lane, were
+// 99 % of its time: 1M rows x 256 queries at M = 128 took 143 ms (2.3 10^11 look-ups/s).  The sum stays the reference's
+// ascending-m fp32 chain (pq_bindings.pyx:30-47); all lanes read the same sub-space's row of the table at a time, so the LDS
+// banks are hit by the codes' low bits (random: ~4-way conflicts) -- exact, simple, and ~20x the generic kernel.
+// VEC: bytes per code-row load (16 where M * sizeof(CODE_T) is a multiple of 16, else 4, else sizeof(CODE_T)).
+// =================================================================================================
+template <typename CODE_T, int NW, int VEC>
+__global__ __launch_bounds__(NW * 64) void adc_scan_lds_kernel(const ScanArgs a, int M) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) unsigned char *lds_bytes;
+    const uint32_t tab_ad = (uint32_t)(uintptr_t)(lds_bytes)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int km1 = a.k - 1;
+    const int n_items = a.n_tiles * a.n_slices;
+    const int n_tab = M * a.Ks;  // floats
+    unsigned long long *scratch = (unsigned long long *)(smem + (((size_t)n_tab * 4 + 15) / 16) * 16);  // [NW][64]
+    constexpr int CPV = VEC / (int)sizeof(CODE_T);  // codes per load
+    const int n_vec = M / CPV;                      // (M * sizeof(CODE_T) is a multiple of VEC: the launcher picks VEC)
+    int loaded = -1;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int b = item % a.n_tiles;  // QT == 1
+        const int slice = item / a.n_tiles;
+        __syncthreads();  // (every wave is done with the previous item's table and scratch)
+        if (b != loaded) {
+            const float *lut = a.lut + (int64_t)b * n_tab;
+            if ((n_tab & 3) == 0) {
+                for (int i = tid; i < n_tab / 4; i += NW * 64) ((f32x4 *)smem)[i] = ((const f32x4 *)lut)[i];
+            } else {
+                for (int i = tid; i < n_tab; i += NW * 64) ((float *)smem)[i] = lut[i];
+            }
+            loaded = b;
+        }
+        __syncthreads();
+        WaveList L;
+        L.reset();
+        uint32_t th = kKeyInfHi, tl = kIdNone;
+        float tf = __builtin_inff();
+        const int64_t slice_begin = (int64_t)slice * a.slice_rows;
+        int64_t slice_end = slice_begin + a.slice_rows;
+        if (slice_end > a.N) slice_end = a.N;
+        const unsigned char *codes = (const unsigned char *)a.codes;
+        const int64_t row_bytes = (int64_t)M * (int64_t)sizeof(CODE_T);
+        for (int64_t row0 = slice_begin + (int64_t)wave * 64; row0 < slice_end; row0 += (int64_t)NW * 64) {
+            int64_t row = row0 + lane;
+            const bool inb = row < slice_end;
+            if (!inb) row = a.N - 1;
+            const unsigned char *cr = codes + row * row_bytes;
+            float d = 0.f;
+            uint32_t base = tab_ad;  // LDS byte address of sub-space m's row of the table
+            const uint32_t ks4 = (uint32_t)a.Ks * 4u;
+            for (int v = 0; v < n_vec; ++v) {
+                uint32_t w[VEC >= 4 ? VEC / 4 : 1];
+                if constexpr (VEC == 16) {
+                    const u32x4 x = *(const u32x4 *)(cr + (int64_t)v * 16);
+                    w[0] = x.x, w[1] = x.y, w[2] = x.z, w[3] = x.w;
+                } else if constexpr (VEC == 4) {
+                    w[0] = *(const uint32_t *)(cr + (int64_t)v * 4);
+                } else {
+                    w[0] = (uint32_t)(*(const CODE_T *)(cr + (int64_t)v * (int64_t)sizeof(CODE_T)));
+                }
+#pragma unroll
+                for (int e = 0; e < CPV; ++e) {  // ascending m: the reference's sum order
+                    uint32_t code;
+                    if constexpr (sizeof(CODE_T) == 1) code = (w[e / 4] >> (8 * (e % 4))) & 0xffu;
+                    else if constexpr (sizeof(CODE_T) == 2) code = (w[e / 2] >> (16 * (e % 2))) & 0xffffu;
+                    else code = w[e];
+                    d += *(const __attribute__((address_space(3))) float *)(uintptr_t)(base + (code << 2));
+                    base += ks4;
+                }
+            }
+            unsigned long long vmask = __ballot(inb);
+            if (a.valid) {
+                const uint32_t *vw = a.valid + (row0 >> 5);
+                unsigned long long vb = (unsigned long long)vw[0];
+                if (row0 + 32 < a.N) vb |= (unsigned long long)vw[1] << 32;
+                vmask &= vb;
+            }
+            const unsigned long long pm = __ballot(!(d > tf)) & vmask;  // (a NaN sum is a candidate too: it sorts behind +inf)
+            if (pm) {
+                wavelist_offer(L, pm, f32_to_key(d), (uint32_t)(row0 + lane), km1, th, tl, lane);
+                tf = (th == kKeyInfHi) ? __builtin_inff() : ordered_to_f32(th);
+            }
+        }
+        scratch[wave * 64 + lane] = ((unsigned long long)L.hi << 32) | L.lo;
+        __syncthreads();
+        if (wave == 0) {
+            for (int w = 1; w < NW; ++w) {
+                const unsigned long long key = scratch[w * 64 + lane];
+                const uint32_t chi = (uint32_t)(key >> 32), clo = (uint32_t)key;
+                const unsigned long long pm = __ballot(lane <= km1 && key_less(chi, clo, th, tl));
+                wavelist_offer(L, pm, chi, clo, km1, th, tl, lane);
+            }
+            if (lane <= km1)
+                a.partial[((int64_t)b * a.n_slices + slice) * a.k + lane] = ((unsigned long long)L.hi << 32) | L.lo;
+        }
+    }
+}
+
+// =================================================================================================
 // Final merge: partial keys [B][NS][k] -> (dist f32, id i64) [B][k]; one wave per query.
 // =================================================================================================
 // With `out_packed` the result is written as [B][k][2] int64 (global id, distance bits) instead: ONE buffer,
@@ -412,6 +516,9 @@ static bool lk64_shape(int64_t M, int64_t Ks, int code_bytes, int64_t k) {
     return code_bytes == 2 && M == 8 && Ks <= 1024;
 }
 
+// shapes without a filter kernel whose fp32 table [M][Ks] fits the LDS beside the waves' merge scratch: adc_scan_lds_kernel
+static bool generic_table_in_lds(int64_t M, int64_t Ks) { return M * Ks * 4 <= 144 * 1024; }
+
 static int round_up(int64_t x, int64_t m) { return (int)(((x + m - 1) / m) * m); }
 // queries the per-query workspace arrays are sized for: whole tiles, at least the 16 the fp32 TILED table is padded to
 static int64_t pad_queries(int64_t B, int qt) {
@@ -514,10 +621,10 @@ static int plan_query_impl(int64_t N, int64_t M, int64_t Ks, int code_bytes, int
         plan->fast = 0;
         plan->qi = 1;
         plan->qt = 1;
-        plan->waves = 4;
+        plan->waves = generic_table_in_lds(M, Ks) ? 16 : 4;  // (adc_scan_lds_kernel: one 16-wave workgroup per query and row slice)
         int ns;
         int64_t sr;
-        plan_slices(N > 0 ? N : 1, B > 0 ? (int)B : 1, 4, n_cu, false, &ns, &sr);
+        plan_slices(N > 0 ? N : 1, B > 0 ? (int)B : 1, plan->waves, n_cu, false, &ns, &sr);
         plan->n_slices = ns;
         plan->lut_floats = B * M * Ks;
         plan->workspace_bytes = B * ns * k * 8;
@@ -873,7 +980,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 // the batch was prepared by the PREPARE half on this workspace: the same carving, no launch
                 if (!kn.no_prebuilt_tables) {
                     a.gseed0 = (unsigned long long *)carve(bpad * 8);
-                    a.btab = (uint8_t *)carve((int64_t)a.n_tiles * Ks * 2 * M * 16);
+                    a.btab = (uint8_t *)carve((int64_t)a.n_tiles * kQ8Image16);
                 }
             } else if (one_prep) {
                 // ... and the scan work items' FIRST byte tables, once per query tile instead of once per (tile, slice) work item
@@ -882,7 +989,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                 uint8_t *btab = nullptr;
                 if (!kn.no_prebuilt_tables) {
                     gseed0 = (unsigned long long *)carve(bpad * 8);
-                    btab = (uint8_t *)carve((int64_t)a.n_tiles * Ks * 2 * M * 16);  // (inside the region the u16 plan uses for q16)
+                    btab = (uint8_t *)carve((int64_t)a.n_tiles * kQ8Image16);  // (inside the region the u16 plan uses for q16)
                 }
                 // Round 6, OPT-IN (ANNLITE_MFMA_SEED): the seed rows' exact scan (S x B x M look-up-adds on the VALU: 22 of the launch's
                 // 40 us) replaced by an MFMA launch that NOMINATES kSeedCand rows per query (seed_mfma.hip) and the exact sums of those
@@ -964,6 +1071,28 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         rc = c.mode == 5 ? launch_q8_scan(c.id, sk, a, grid, st) : launch_qfilter_scan(c.id, sk, a, grid, st);
         if (bracket) prof_end(st);
         return rc;
+    }
+    if (generic_table_in_lds(M, Ks)) {
+        constexpr int NW = 16;
+        const size_t tab = (((size_t)M * Ks * 4 + 15) / 16) * 16;
+        const size_t lds_need = tab + (size_t)NW * 64 * 8;
+        const int per_cu = tab > 64 * 1024 ? 1 : 2;
+        const int grid_l = n_items < n_cu * per_cu ? n_items : n_cu * per_cu;
+        const int64_t rb = M * code_bytes;
+        const bool al16 = rb % 16 == 0 && ((uintptr_t)codes_dev % 16) == 0, al4 = rb % 4 == 0 && ((uintptr_t)codes_dev % 4) == 0;
+        prof_begin(st);
+#define ANNLITE_LDS_SCAN(T)                                                                                                       \
+    {                                                                                                                             \
+        auto fn = al16 ? adc_scan_lds_kernel<T, NW, 16> : al4 ? adc_scan_lds_kernel<T, NW, 4> : adc_scan_lds_kernel<T, NW, (int)sizeof(T)>; \
+        ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));       \
+        hipLaunchKernelGGL(fn, dim3(grid_l), dim3(NW * 64), lds_need, st, a, (int)M);                                             \
+    }
+        if (code_bytes == 1) ANNLITE_LDS_SCAN(uint8_t)
+        else if (code_bytes == 2) ANNLITE_LDS_SCAN(uint16_t)
+        else ANNLITE_LDS_SCAN(uint32_t)
+#undef ANNLITE_LDS_SCAN
+        prof_end(st);
+        return launch_status("adc_scan_lds_kernel");
     }
     const int grid = n_items < n_cu * 8 ? n_items : n_cu * 8;
     const size_t lds = 4 * 64 * 8;
@@ -1065,6 +1194,7 @@ extern "C" int annlite_kernel_rev(const char *kernel) {
         {"adc_scan_qfilter_kernel", 1},
         {"adc_scan_qfilter64_kernel", 1},
         {"adc_scan_generic_kernel", 1},
+        {"adc_scan_lds_kernel", 1},       // round 6: the generic scan with the query's fp32 table in LDS and 16-byte code-row loads
         {"graph_beam_search_kernel", 2},  // 2: round 5 (packed node records + prefetch, merge insertion, bucketed visited table)
     };
     for (const auto &r : revs)

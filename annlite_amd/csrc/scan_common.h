@@ -75,7 +75,7 @@ struct ScanArgs {
     // byte tables PREBUILT by the preparation launch (seed_bound_kernel<..., BUILD>; M = 16): the 8 workgroups of a query tile
     // copy their first table (128 KB, L2) instead of each converting the tile's 512 KB of fp32 tables
     const unsigned long long *gseed0;   // [ceil32(B)] the seed keys as the preparation launch left them (gkey moves on: atomic min)
-    const uint8_t *btab;                // [n_tiles][Ks * 2 * 16 * 16 B] LDS images, quantised for gseed0; NULL: the workgroups build
+    const uint8_t *btab;                // [n_tiles][kQ8Image16] LDS images (q8_entry16), quantised for gseed0; NULL: the workgroups build
     int32_t q8_early_merge;             // byte-table kernel: the FIRST workgroup of a tile to finish merges the others' lists as they
                                         // arrive (tile_done is then a bitmask of the slices still out); 0: the last one merges all
     uint32_t q8_merge_patience;         // ... and leaves (the last slice to arrive then merges all) after this many 100 MHz ticks
@@ -277,6 +277,18 @@ struct Q8Cfg {
     static constexpr int QMAX = WIDE ? 15 : 240 / M, QOPEN = WIDE ? 7 : 112 / M;
     static constexpr uint32_t TMAX = WIDE ? 32767u : 127u, TFLAG = TMAX + 1u;
 };
+// M = 16 (round 6): the LDS image of a tile's byte table -- TWO half tables by sub-space PARITY, 64 KB apart; a code's row of a half
+// is 256 bytes = 8 sub-spaces x 2 entry groups x 16 B, both groups of a (code, sub-space) ADJACENT.  Entry (code, m, group g):
+//     (p << 16) + (code << 8) + ((2 (m >> 1) + g + p) << 4),   p = m & 1
+// so that a look-up address is ONE v_perm_b32 of the code dword with a lane constant (byte 0: the slot, byte 2: the half) and the
+// second entry group is the first + 16 -- an immediate: one address instruction per TWO look-ups where the [Ks][2][16][16 B] layout
+// needed a byte shift (code x 512 is not a byte move) and an add per look-up address.  The odd half is shifted by ONE slot (its last
+// entry spills into the next code's row: 257 rows): the 16 lanes of a ds_read_b128 -- 16 different sub-spaces, the skew -- then hit
+// 16 different 16-byte bank groups in both reads.  scripts/ubench/step_loop.hip ADDR=3: 0.883 -> 0.923 of the look-up roof.
+constexpr int kQ8Image16 = 131072 + 256;
+__host__ __device__ constexpr uint32_t q8_entry16(uint32_t code, uint32_t m, uint32_t g) {
+    return ((m & 1u) << 16) + (code << 8) + ((2u * (m >> 1) + g + (m & 1u)) << 4);
+}
 // NQ = entry groups of 16 queries per workgroup (the second shape parameter): 2 everywhere but M = 8 with 512 < Ks <= 1024,
 // where only one group's table fits the LDS (WIDE: 8 queries whatever NQ says)
 template <int M, int NQ>
@@ -284,6 +296,7 @@ constexpr int q8_qt() { return Q8Cfg<M>::WIDE ? 8 : 16 * NQ; }
 template <int M, int NQ>
 __device__ __forceinline__ int q8_table_bytes(int Ks) {
     if (Q8Cfg<M>::M32) return 131072;  // two half tables [256][16][16 B] whatever Ks (<= 256) is: the halves' distance is an address bit
+    if (M == 16 && NQ == 2) return kQ8Image16;  // two half tables by sub-space parity (q8_entry16), whatever Ks is
     return Q8Cfg<M>::WIDE ? (Ks + 1) * 512 : Ks * NQ * M * 16;  // WIDE: two half tables of 32 sub-spaces, [Ks + 1][32][8 B] each
 }
 

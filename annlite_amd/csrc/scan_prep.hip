@@ -123,7 +123,7 @@ struct SeedBuild {
     // BUILD, optional: the byte tables of the scan kernel's work items, built HERE once per query (the workgroup holds its 4
     // queries' fp32 tables in LDS and knows their seed bound) instead of by each of the tile's 8 scan workgroups from L2
     unsigned long long *gseed0;  // [..] the seed key of every query, kept aside (gkey itself is lowered by the scan)
-    uint8_t *btab;               // [n_tiles][Ks][2][16][16 B]: this workgroup writes its queries' dword of every entry
+    uint8_t *btab;               // [n_tiles][kQ8Image16] (q8_entry16): this workgroup writes its queries' dword of every entry
     int32_t target;              // T of a freshly built table (ScanArgs::q8_target)
     int32_t chunk_log;           // (any launch) the seed rows come in runs of 2^chunk_log blocks of 64 rows (seed_chunk_log())
     unsigned long long *seedk;   // optional [B][kSeedKeys]: the bounds implied by the seed's k smallest rows, ascending -- what
@@ -593,7 +593,9 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
             constexpr int KPT = kSeedWaves * 64 / M, NSW = 256 / KPT;
             const int m = tid % M, kr = tid / M;
             const int q0 = (g4 * 4) & 31;
-            uint32_t *bt = (uint32_t *)(sb.btab + (int64_t)((g4 * 4) >> 5) * ((int64_t)Ks * 2 * M * 16)) + (q0 >> 4) * (M * 4) + ((q0 & 15) >> 2);
+            // (the tile's LDS image, q8_entry16: two half tables by sub-space parity, the two entry groups of a (code, sub-space) adjacent)
+            uint8_t *img = sb.btab + (int64_t)((g4 * 4) >> 5) * (int64_t)kQ8Image16 + 4 * ((q0 & 15) >> 2);
+            const uint32_t grp = (uint32_t)(q0 >> 4);
             float lo_r[4], inv_r[4], clip_r[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) lo_r[i] = par[24 + m * 4 + i], inv_r[i] = s_inv[i], clip_r[i] = s_clip[i];
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
                         t = __builtin_fminf(t, clip_r[e]);
                         pk = __builtin_amdgcn_cvt_pk_u8_f32(t, e, pk);  // saturates below 0 (q8_build_table's conversion)
                     }
-                    bt[((int64_t)kk * 2 * M + m) * 4] = pk;
+                    *(uint32_t *)(img + q8_entry16((uint32_t)kk, (uint32_t)m, grp)) = pk;
                 }
             }
         }

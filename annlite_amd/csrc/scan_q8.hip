@@ -123,13 +123,17 @@ struct Q8Build {  // what a (re)build needs, gathered from the kernarg segment i
 template <int M, int NW, int NQ>
 __device__ __forceinline__ void q8_copy_table(const Q8Build &a, int tile, uint32_t tab_ad, int tid) {
     constexpr int NT = NW * 64;
-    const int n16 = a.Ks * NQ * M;  // 16-byte entries
+    static_assert(M == 16 && NQ == 2, "the prebuilt image is the M = 16 kernel's (q8_entry16)");
+    // the whole image, whatever Ks is (rows >= Ks of a half are never addressed): 16-byte entry i sits in slot i % 16 of its row, and
+    // slot = 2 j + group + half (the odd half is shifted by one slot; its 257th row holds one entry, in slot 0)
+    constexpr int n16 = kQ8Image16 / 16;
     const int n_g4 = ((a.B + 15) / 16) * 4;
-    const u32x4 *src = (const u32x4 *)(a.btab + (int64_t)tile * ((int64_t)n16 * 16));
+    const u32x4 *src = (const u32x4 *)(a.btab + (int64_t)tile * (int64_t)kQ8Image16);
 #pragma unroll 4
     for (int i = tid; i < n16; i += NT) {
         u32x4 v = src[i];
-        const int g4 = tile * (4 * NQ) + ((i / M) % NQ) * 4;
+        const int half = i >= 4096 ? 1 : 0;
+        const int g4 = tile * (4 * NQ) + (((i & 15) - half) & 1) * 4;
         if (g4 + 3 >= n_g4) {
             if (g4 + 0 >= n_g4) v.x = 0u;
             if (g4 + 1 >= n_g4) v.y = 0u;
@@ -180,6 +184,7 @@ __device__ __forceinline__ void q8_build_table(const Q8Build &a, int tile, uint3
         uint32_t ad;
         if constexpr (Q8Cfg<M>::M32)  // two half tables of 16 sub-spaces, 64 KB apart: (half << 16) | (code << 8) | column
             ad = tab_ad + ((uint32_t)(m >> 4) << 16) + ((uint32_t)k << 8) + (uint32_t)(m & 15) * 16u;
+        else if constexpr (M == 16 && NQ == 2) ad = tab_ad + q8_entry16((uint32_t)k, (uint32_t)m, (uint32_t)h);  // two half tables by sub-space parity
         else ad = tab_ad + (uint32_t)((k * NQ + h) * RB + m * 16);
         *(ANNLITE_LDS u32x4 *)(uintptr_t)ad = (u32x4){w[0], w[1], w[2], w[3]};
     }
@@ -624,8 +629,10 @@ __device__ __attribute__((noinline)) void q8_rebuild(q8_kernarg_ptr ka, int tile
     }
     __syncthreads();
     if constexpr (Q8Cfg<M>::WIDE) q8_build_table_wide<NW>(a, tile, o.tab, o.inv, o.clip, tid);
-    else if (prebuilt) q8_copy_table<M, NW, NQ>(a, tile, o.tab, tid);
-    else q8_build_table<M, NW, NQ>(a, tile, o.tab, o.inv, o.clip, tid);
+    else if constexpr (M == 16 && NQ == 2) {
+        if (prebuilt) q8_copy_table<M, NW, NQ>(a, tile, o.tab, tid);
+        else q8_build_table<M, NW, NQ>(a, tile, o.tab, o.inv, o.clip, tid);
+    } else q8_build_table<M, NW, NQ>(a, tile, o.tab, o.inv, o.clip, tid);
     __syncthreads();
 }
 
@@ -730,7 +737,8 @@ __device__ __forceinline__ void q8_merge_tile(const ScanArgs &a, int b0, int QT,
 template <bool SKEWED>
 __device__ __forceinline__ void q8_row_pass_mask(const uint8_t *codes, uint32_t rid, bool act, int lane, uint32_t lds0, uint32_t shq_ad,
                                                  uint32_t row_park, uint32_t &mask) {
-    constexpr int M = 16, CW = 4, NQ = 2, RB = M * 16, KSTRIDE = NQ * RB, DEPTH = ANNLITE_Q8_STAGE_DEPTH, TOT = NQ * M;
+    // (q8_entry16: the second entry group of a look-up sits 16 bytes behind the first, a code's row is 256 bytes)
+    constexpr int M = 16, CW = 4, NQ = 2, RB = 16, DEPTH = ANNLITE_Q8_STAGE_DEPTH, TOT = NQ * M;
     typedef const ANNLITE_LDS u32x4 *lds_entry_ptr;
     uint32_t cc[CW];
     {
@@ -748,11 +756,11 @@ __device__ __forceinline__ void q8_row_pass_mask(const uint8_t *codes, uint32_t 
     static_for<0, CW>([&](auto W) {
         constexpr int w = decltype(W)::value;
         uint32_t o0, o1, o2, o3;
-        byte_shl4(cc[w], (uint32_t)ilog2_c(KSTRIDE), o0, o1, o2, o3);
-        addr[4 * w + 0] = lds0 + (uint32_t)(((s + 4 * w + 0) % M) * 16) + o0;
-        addr[4 * w + 1] = lds0 + (uint32_t)(((s + 4 * w + 1) % M) * 16) + o1;
-        addr[4 * w + 2] = lds0 + (uint32_t)(((s + 4 * w + 2) % M) * 16) + o2;
-        addr[4 * w + 3] = lds0 + (uint32_t)(((s + 4 * w + 3) % M) * 16) + o3;
+        byte_shl4(cc[w], 8u, o0, o1, o2, o3);
+        addr[4 * w + 0] = lds0 + q8_entry16(0u, (uint32_t)((s + 4 * w + 0) % M), 0u) + o0;
+        addr[4 * w + 1] = lds0 + q8_entry16(0u, (uint32_t)((s + 4 * w + 1) % M), 0u) + o1;
+        addr[4 * w + 2] = lds0 + q8_entry16(0u, (uint32_t)((s + 4 * w + 2) % M), 0u) + o2;
+        addr[4 * w + 3] = lds0 + q8_entry16(0u, (uint32_t)((s + 4 * w + 3) % M), 0u) + o3;
     });
     u32x4 acc[NQ];
     u32x4 v[DEPTH];
@@ -1432,10 +1440,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             typedef const ANNLITE_LDS u32x4 *lds_entry_ptr;
             typedef const ANNLITE_LDS u32x2 *lds_entry8_ptr;
             const uint32_t lds0 = lds.tab;
+            // M = 16 (q8_entry16, round 6): the table is two half tables by sub-space PARITY at LDS address 0; look-up t of this lane reads
+            // sub-space (s + t) mod 16: its address is ONE v_perm_b32 of the code dword with mbase[t] (byte 0: the slot of the first entry
+            // group, byte 2: the half), the second entry group sits 16 bytes behind (immediate)
+            constexpr bool P16 = M == 16 && NQ == 2 && CB == 1;
             uint32_t mbase[(WIDE || M8 || M32) ? 1 : M];
             if constexpr (!WIDE && !M8 && !M32) {
 #pragma unroll
-                for (int t = 0; t < M; ++t) mbase[t] = lds0 + (uint32_t)(((s + t) % M) * EB);
+                for (int t = 0; t < M; ++t) mbase[t] = P16 ? q8_entry16(0u, (uint32_t)((s + t) % M), 0u) : lds0 + (uint32_t)(((s + t) % M) * EB);
+                if constexpr (P16) {
+                    if (lds0 != 0u) __builtin_trap();
+                }
             }
             // M8 (M = 8; uint16 codes, or uint8 ones up to Ks = 256): a code row of the table is 256 bytes = [2 entry groups][8 sub-spaces][16 B], the address of
             // look-up t is (code << 8) | column byte -- ONE v_perm_b32 of the code dword with a lane constant (kx / ky: byte t of
@@ -1535,7 +1550,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 }
             };
             auto make_addr = [&](const uint32_t (&cc)[CW]) {
-                if constexpr (!WIDE && !M8 && !M32)
+                if constexpr (P16)
+                    static_for<0, M>([&](auto T) {
+                        constexpr int t = decltype(T)::value;
+                        // byte 0 <- mbase byte 0 (slot), byte 1 <- code byte t % 4, byte 2 <- mbase byte 2 (half), byte 3 <- 0
+                        addr[t] = __builtin_amdgcn_perm(cc[t / 4], mbase[t], 0x0c020000u | ((4u + (uint32_t)(t % 4)) << 8));
+                    });
+                else if constexpr (!WIDE && !M8 && !M32)
                     static_for<0, CW>([&](auto W) {
                         constexpr int w = decltype(W)::value;
                         uint32_t o0, o1, o2, o3;
@@ -1654,6 +1675,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     sums[0] = acc.x, sums[1] = acc.y, sums[2] = acc.z, sums[3] = acc.w;
                 } else {
                     constexpr int DEPTH = ANNLITE_Q8_DEPTH, TOT = NQ * M;
+                    constexpr int GOFF = P16 ? 16 : RB;  // distance of a look-up's second entry group
                     u32x4 acc[NQ];
                     u32x4 v[DEPTH];
                     auto fetch = [&](u32x4 &dst, uint32_t ad) {
@@ -1662,7 +1684,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     };
                     static_for<0, DEPTH>([&](auto I) {
                         constexpr int i = decltype(I)::value;
-                        fetch(v[i], addr[i % M] + (uint32_t)((i / M) * RB));
+                        fetch(v[i], addr[i % M] + (uint32_t)((i / M) * GOFF));
                     });
                     static_for<0, TOT>([&](auto I) {
                         constexpr int i = decltype(I)::value;
@@ -1676,7 +1698,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                         }
                         if constexpr (i + DEPTH < TOT) {
                             constexpr int j = i + DEPTH;
-                            fetch(v[i % DEPTH], addr[j % M] + (uint32_t)((j / M) * RB));
+                            fetch(v[i % DEPTH], addr[j % M] + (uint32_t)((j / M) * GOFF));
                         }
                     });
 #pragma unroll
@@ -1954,7 +1976,8 @@ static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
     constexpr int QT = 32;  // (the control block is laid out for 32 slots whatever the kernel uses)
     // (the row queue's parking area, 3072 B behind everything else, exists only for the kernels that run it: the 128 KB tables of
     // M = 32 / M = 8 with uint16 codes + 16 KB of 64-key lists + the 8 KB ring fit the 160 KB without it)
-    const size_t need = (size_t)(M == 64 ? (a.Ks + 1) * 512 : M == 32 ? 131072 : a.Ks * NQ * M * 16) + 1664 + (size_t)QT * LK * 8 + QT * 8 +
+    const size_t need = (size_t)(M == 64 ? (a.Ks + 1) * 512 : M == 32 ? 131072 : (M == 16 && NQ == 2) ? kQ8Image16 : a.Ks * NQ * M * 16) + 1664 +
+                        (size_t)QT * LK * 8 + QT * 8 +
                         (size_t)kRingSize * q8_ring_entry_bytes<M, LK>() + 4 * 128 * 9 + 32 + 32 + 16 + ((RQ || LK == 16) ? 3072 : 0);
     ANNLITE_REQUIRE(need <= 160 * 1024, "byte-table kernel: %zu B of LDS", need);
     auto fn = adc_scan_q8_kernel<M, NW, SKEWED, NQ, CB, RQ, LK>;

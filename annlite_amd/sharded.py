@@ -162,18 +162,26 @@ class ShardedPQIndex:
         B, k, _ = packed.shape
         if self._xstream is None:
             self._xstream = torch.cuda.Stream(device=packed.device)
-        if scanned is None:  # (the scan ran on the caller's stream)
-            scanned = torch.cuda.Event()
-            scanned.record(torch.cuda.current_stream(packed.device))
-        with torch.cuda.stream(self._xstream):
-            self._xstream.wait_event(scanned)
-            packed.record_stream(self._xstream)
+        xs = self._xstream
+        # (hand-rolled `with torch.cuda.stream(xs)`: ONE current_stream() per batch instead of the context manager's own + the
+        # event's + three inside the ops -- python-level stream look-ups were a third of the 0.10 ms a batch cost the host with the
+        # exchange on, profiles/r06/host_overhead.txt)
+        cur = torch.cuda.current_stream(packed.device)
+        if scanned is None:  # (the scan ran on the caller's stream: the side stream waits for what has been enqueued there so far)
+            xs.wait_stream(cur)
+        else:
+            xs.wait_event(scanned)
+        torch.cuda.set_stream(xs)
+        try:
+            packed.record_stream(xs)
             gathered = torch.empty((G * B, k, 2), dtype=torch.int64, device=packed.device)
             work = dist.all_gather_into_tensor(gathered, packed, group=self.group, async_op=True)
             work.wait()  # the SIDE stream waits for the collective
             value = self._merge_packed(gathered.view(G, B, k, 2), sqrt=self.index.sqrt_epilogue)
             done = torch.cuda.Event()
-            done.record(self._xstream)
+            done.record(xs)
+        finally:
+            torch.cuda.set_stream(cur)
         return PendingSearch(self, value=value, done=done, keep=(packed, gathered))
 
     # ------------------------------------------------------------------ seed exchange

@@ -754,7 +754,7 @@ def main():
             os.environ.get('ANNLITE_SCAN_VARIANT', '0') in ('0', '50')
         per_clk = 256 if byte_tables else 128
         lds_peak = 256 * per_clk * 2.4e9
-        kernel_name = ('adc_scan_generic_kernel' if not plan_k.fast else 'adc_scan_q8_kernel' if byte_tables else
+        kernel_name = (('adc_scan_lds_kernel' if M * Ks * 4 <= 144 * 1024 else 'adc_scan_generic_kernel') if not plan_k.fast else 'adc_scan_q8_kernel' if byte_tables else
                        'adc_scan_qfilter64_kernel' if M == 64 else 'adc_scan_qfilter_kernel')
         # measured HBM traffic: a committed PMC pass of the same kernel / shape (bench.py cannot run rocprof on itself).  An entry
         # measured on ANOTHER revision of the kernel (the library's ANNLITE_KERNEL_REV for it has moved on since) is refused, loudly

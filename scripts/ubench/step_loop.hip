@@ -9,6 +9,10 @@
 
 #ifndef ADDR
 #define ADDR 1  // 0: loop-invariant addresses, 1: SDWA byte shift + add per look-up address (what the kernel does), 2: SDWA word shift only (prescaled)
+                // 3 (round 6): ONE v_perm_b32 per PAIR of look-ups -- two half tables by sub-space parity, 64 KB apart, both entry groups of a
+                //    (code, sub-space) adjacent: address = (parity << 16) | (code << 8) | (slot << 4), slot = 2 (m >> 1) + group + parity (the odd
+                //    half table is shifted by one slot -- its last entry spills into the next code's row, 257 rows -- so that the 16 lanes of a
+                //    read hit 16 different slots); the second group is the first + 16 (immediate)
 #endif
 #ifndef FILTER
 #define FILTER 1  // 0: none, 1: the kernel's (and, sub, bitop3 per dword), 2: folded into the sums (and-reduce)
@@ -53,7 +57,7 @@ __device__ __forceinline__ void word_shl2(uint32_t x, uint32_t sh, uint32_t &o0,
 }
 
 __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void step_loop(unsigned long long *out, const uint32_t *codes, int steps, uint32_t sh) {
-    constexpr int M = 16, NQ = 2, RB = 256, TOT = NQ * M;
+    constexpr int M = 16, NQ = 2, RB = ADDR == 3 ? 16 : 256, TOT = NQ * M;  // (RB: distance of a look-up's second entry group)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 128 * 1024 / 4; i += NWAVES * 64) ((uint32_t *)smem)[i] = (uint32_t)i * 0x01010101u & 0x03030303u;
@@ -63,6 +67,14 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void step_loop(unsigned lo
 #pragma unroll
     for (int t = 0; t < M; ++t) mbase[t] = (uint32_t)(((s + t) % M) * 16);
     uint32_t addr[M];
+#if ADDR == 3
+    uint32_t kperm[M];  // byte 0: slot << 4 of the step's FIRST read, byte 2: the half table (sub-space parity)
+#pragma unroll
+    for (int t = 0; t < M; ++t) {
+        const uint32_t m = (uint32_t)((s + t) % M), par = m & 1u;
+        kperm[t] = ((2u * (m >> 1) + par) << 4) | (par << 16);
+    }
+#endif
     u32x4 thp[NQ];
 #pragma unroll
     for (int h = 0; h < NQ; ++h) thp[h] = (u32x4){0x80808080u | (uint32_t)lane, 0x81818181u, 0x82828282u, 0x83838383u};
@@ -103,6 +115,15 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void step_loop(unsigned lo
                 addr[4 * w + 1] = mbase[4 * w + 1] + o1;
                 addr[4 * w + 2] = mbase[4 * w + 2] + o2;
                 addr[4 * w + 3] = mbase[4 * w + 3] + o3;
+            });
+        }
+#elif ADDR == 3
+        {
+            const uint32_t cc[4] = {ccur.x, ccur.y, ccur.z, ccur.w};
+            static_for<0, M>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                // byte 0 <- kperm byte 0, byte 1 <- code byte t % 4, byte 2 <- kperm byte 2, byte 3 <- 0
+                addr[t] = __builtin_amdgcn_perm(cc[t / 4], kperm[t], 0x0c020000u | ((4u + (uint32_t)(t % 4)) << 8));
             });
         }
 #elif ADDR == 2
