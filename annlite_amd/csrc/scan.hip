@@ -1190,7 +1190,8 @@ extern "C" int annlite_profile_last_scan_ms(float *ms) {
 extern "C" int annlite_kernel_rev(const char *kernel) {
     ANNLITE_REQUIRE(kernel != nullptr, "kernel is NULL");
     static const struct { const char *name; int rev; } revs[] = {
-        {"adc_scan_q8_kernel", 4},        // 4: round 4 (prebuilt byte tables, early merger, M = 64 slice-per-XCD)
+        {"adc_scan_q8_kernel", 5},        // 4: round 4 (prebuilt byte tables, early merger, M = 64 slice-per-XCD); 5: round 6 (M = 16: the table's
+                                          // LDS image is two half tables by sub-space parity -- 128.25 KB copied per work item whatever Ks is)
         {"adc_scan_qfilter_kernel", 1},
         {"adc_scan_qfilter64_kernel", 1},
         {"adc_scan_generic_kernel", 1},

@@ -765,7 +765,7 @@ def main():
         lib_rev = _capi.kernel_rev(kernel_name)
         if traffic is not None and t_ent.get('kernel_rev') != lib_rev:
             traffic_note = (f'STALE: profiles/traffic.json[{t_key}] was measured on kernel revision {t_ent.get("kernel_rev")}, '
-                            f'the library is at revision {lib_rev}: re-run the PMC passes (scripts/r05_profiles.sh)')
+                            f'the library is at revision {lib_rev}: re-run the PMC passes (scripts/r06_profiles.sh)')
             print('bench.py: ' + traffic_note, file=sys.stderr)
             traffic = None
         # shapes with both a byte-table and a u16-table kernel (scan.hip: search_policy) have a choice to report
