@@ -853,6 +853,11 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
         // k = 50 at T = 80 / 96 / 112 1.92 / 1.87 / 1.83 ms, profiles/r05/k50_knobs.txt)
         a.q8_target = M == 64 ? 512 : (M == 16 && k <= 16) ? 88 : 96;
         a.q8_rebuild_8ths = 4;
+        // how often the scanning waves re-read the workgroup's bounds (16 bytes of LDS + the filter words' registers): every 2nd step; every
+        // 8th where a work item scans >= 500k rows -- the bounds of a long scan move rarely, a stale one only pushes a row the consumer
+        // drops.  Same box, alternating (profiles/r06/thw_mask_ab.txt): 10M rows 759.0 / 760.7 k q/s at every 2nd step, 764.2 / 763.4 at every
+        // 4th, 767.4 / 767.3 at every 8th; 1.25M rows 0.2346 / 0.2344 -> 0.2353 / 0.2347 -> 0.2357 / 0.2352 ms (the short scans keep every 2nd)
+        a.q8_thw_mask = a.slice_rows >= 500000 ? 7 : 1;
         if (kn.q8_rebuild >= 0 && kn.q8_rebuild <= 8) a.q8_rebuild_8ths = kn.q8_rebuild;
         if (kn.q8_target >= 16 && kn.q8_target <= (M == 64 ? 960 : 127)) a.q8_target = kn.q8_target;
         if (kn.q8_tune_ok) {  // ANNLITE_Q8_TUNE = "epoch0,mul,ring_limit,import_mask" (measurements; validated when parsed)

@@ -62,6 +62,7 @@ struct ScanArgs {
     // scanning waves may be ahead of the consumer wave
     int32_t q8_epoch0, q8_epoch_mul, q8_ring_limit, q8_import_mask;
     int32_t q8_target;                  // T of a slot right after its table is (re)built (<= 127)
+    int32_t q8_thw_mask;                // the scanning waves pick up the workgroup's bounds every (mask + 1)-th step (1, 3 or 7)
     int32_t q8_rebuild_8ths;            // a slot wants a new table when its T has fallen below this many eighths of that
     // Kernel choice inside the library (scan.hip: byte-table launch with a guard, u16-table launch behind a gate):
     unsigned int *guard;                // byte-table kernel: [0] 0xffffffff = run, 0 = the launch gave up (its candidate rate

@@ -1732,6 +1732,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             // epochs' barriers meet).  The step loop of an epoch contains no call and no barrier: the loop-invariant
             // registers stay put.
             uint32_t it_no = 0;
+            const uint32_t thw_mask = (uint32_t)a.q8_thw_mask;
             uint32_t rs = 0;  // (pushed entries) | (consumed entries, as last read) << 16 of this wave's ring, both mod 2^16
             uint32_t n_slow = 0, n_push = 0;
             unsigned long long t_wait = 0;
@@ -1885,8 +1886,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                             });
                         }
                     }
-                    // pick up the workgroup's bounds every 2nd step
-                    if ((it_no & ANNLITE_Q8_THW_MASK) == ANNLITE_Q8_THW_MASK) {
+                    // pick up the workgroup's bounds every 2nd step (every 8th where a work item scans >= 500k rows: ScanArgs::q8_thw_mask)
+                    if ((it_no & thw_mask) == thw_mask) {
                         asm volatile("" ::: "memory");
                         load_thw(thw);
                     }

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/../annlite_amd/csrc"
 name=$1; shift
 mkdir -p ../../build_exp/$name
 objs=""
-for f in capi scan scan_qfilter scan_q8 scan_prep graph ivf lut codec; do
+for f in capi scan scan_qfilter scan_q8 scan_prep seed_mfma graph ivf lut codec; do
   extra=""; case $f in scan_q8|scan_qfilter|scan_prep) extra="-mllvm -amdgpu-atomic-optimizer-strategy=None";; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function -ffp-contract=off $extra "$@" -c $f.hip -o ../../build_exp/$name/$f.o &
   objs="$objs ../../build_exp/$name/$f.o"

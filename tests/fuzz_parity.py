@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import pq_oracle as oracle  # noqa: E402
-from annlite_amd import ops  # noqa: E402
+from annlite_amd import _capi, ops  # noqa: E402
 from annlite_amd._capi import LAYOUT_BMK, LAYOUT_TILED, scan_plan  # noqa: E402
 
 
@@ -33,9 +33,12 @@ def run(seconds, seed, verbose=True):
     n_cases = n_calls = n_bad = 0
     by_m = {}
     while time.time() < t_end:
-        M = int(rs.choice([8, 16, 16, 16, 32, 64, 12]))
-        dsub = int(rs.choice([2, 4, 8]))
-        Ks = 256
+        M = int(rs.choice([8, 16, 16, 16, 32, 64, 12, 24, 128]))
+        dsub = int(rs.choice([2, 4, 8])) if M < 128 else int(rs.choice([1, 2]))
+        # (round 6: fewer code words than 256; uint16 codes -- the M = 8 byte-table shapes incl. their 64-key lists, M = 16 on the u16 tables,
+        # the LDS-table / generic kernels for the rest)
+        Ks = int(rs.choice([256, 256, 256, 100, 512, 700])) if M in (8, 12, 16) else int(rs.choice([256, 256, 100]))
+        cdt = np.uint8 if Ks <= 256 else np.uint16
         N = int(np.exp(rs.uniform(np.log(1), np.log(600_000))))
         B = int(np.exp(rs.uniform(np.log(1), np.log(300))))
         B = max(1, min(B, int(1.5e9 / (N * M))))  # (the oracle's share of the time budget)
@@ -47,17 +50,17 @@ def run(seconds, seed, verbose=True):
         A = rs.randn(r, D).astype(np.float32)
         cb = (rs.randn(Ks, r).astype(np.float32) @ A).reshape(Ks, M, dsub).transpose(1, 0, 2).copy()
         if order == 'uniform_codes':
-            codes = rs.randint(0, Ks, size=(N, M)).astype(np.uint8)
+            codes = rs.randint(0, Ks, size=(N, M)).astype(cdt)
             cb = rs.randn(M, Ks, dsub).astype(np.float32)
         elif order == 'few_distinct':
-            base = rs.randint(0, Ks, size=(max(1, min(N, 300)), M)).astype(np.uint8)
+            base = rs.randint(0, Ks, size=(max(1, min(N, 300)), M)).astype(cdt)
             codes = base[rs.randint(0, base.shape[0], N)]
         else:
             z = rs.randn(N, r).astype(np.float32)
             if order == 'sorted':
                 z = z[np.argsort(z[:, 0], kind='stable')]
             x = z @ A + 0.05 * rs.randn(N, D).astype(np.float32)
-            codes = oracle.encode_c(x, cb, threads=oracle.max_threads())
+            codes = oracle.encode_c(x, cb, threads=oracle.max_threads()).astype(cdt)
         q = (rs.randn(B, r).astype(np.float32) @ A).astype(np.float32)
         if rs.rand() < 0.3:
             q += 0.7 * A[0]
@@ -82,17 +85,33 @@ def run(seconds, seed, verbose=True):
         cb_d, q_d, codes_d = ops.to_dev(cb), ops.to_dev(q), ops.to_dev(codes)
         n_cases += 1
         by_m[M] = by_m.get(M, 0) + 1
-        for layout in ((0, 1) if M in (8, 16, 32, 64) else (0,)):
+        # (round 6) a third of the cases search with the table's scan state -- guarded first call, then the settled, unguarded kernel --,
+        # and the opt-in MFMA-nominated seed is switched on for half of the cases (it applies to M = 16 / 128-d / >= 64 queries)
+        mfma = rs.rand() < 0.5
+        if mfma:
+            os.environ['ANNLITE_MFMA_SEED'] = '1'
+        else:
+            os.environ.pop('ANNLITE_MFMA_SEED', None)
+        _capi.knobs_reload()
+        for layout in ((0, 1) if (M in (8, 16, 32, 64) and Ks <= 256) else (0,)):
             cd = ops.codes_skew(codes_d) if layout == 1 else codes_d
             outs = [('fused', ops.pq_search_topk(kind, q_d, cb_d, cd, k, M, Ks, codes_layout=layout, valid_bits=bits))]
-            plan = scan_plan(N, M, Ks, 1, B, k)
+            if rs.rand() < 0.34:
+                st = _capi.ScanState()
+                for rep in range(3):
+                    o3 = ops.pq_search_topk(kind, q_d, cb_d, cd, k, M, Ks, codes_layout=layout, valid_bits=bits, state=st)
+                    torch.cuda.synchronize()
+                outs.append(('fused+state', o3))
+            plan = scan_plan(N, M, Ks, codes.dtype.itemsize, B, k)
             lt = ops.lut_build(q_d, cb_d, kind, LAYOUT_TILED if plan.fast else LAYOUT_BMK, plan.qi)
             outs.append(('prebuilt', ops.adc_scan_topk(cd, lt, B, k, M, Ks, codes_layout=layout, valid_bits=bits)))
             for name, (d, i) in outs:
                 n_calls += 1
                 if not (np.array_equal(i.cpu().numpy(), ri) and np.array_equal(d.cpu().numpy(), rd, equal_nan=True)):
                     n_bad += 1
-                    print('MISMATCH', dict(M=M, dsub=dsub, N=N, B=B, k=k, kind=kind, order=str(order), valid=str(vmode), layout=layout, entry=name), flush=True)
+                    print('MISMATCH', dict(M=M, dsub=dsub, Ks=Ks, mfma=mfma, N=N, B=B, k=k, kind=kind, order=str(order), valid=str(vmode), layout=layout, entry=name), flush=True)
+    os.environ.pop('ANNLITE_MFMA_SEED', None)
+    _capi.knobs_reload()
     return n_cases, n_calls, n_bad, dict(sorted(by_m.items()))
 
 
