@@ -51,9 +51,8 @@ def _step_loop(body):
     """The lines of the step loop: the innermost-but-one loop around the densest cluster of LDS look-ups, by LLVM's own loop annotations
     (every basic block's label carries `in Loop: Header=BBx_y Depth=d` or, a few comment lines on, `This Loop Header`).  (A fixed window
     around the densest 100 lines also caught per-work-item reloads in FRONT of the loop of the shapes with 8 look-ups per step.)"""
-    reads = [j for j, ln in enumerate(body) if re.search(r'\bds_read_b(128|64)\b', ln)]
-    best = max(set(j // 100 for j in reads), key=lambda c: sum(1 for j in reads if j // 100 == c))
-    j0 = min(j for j in reads if j // 100 == best)
+    wide = bool(re.search(r'adc_scan_q8_kernelILi64E', body[0]))  # (M = 64: 8-byte entries)
+    look = re.compile(r'\bds_read_b64\b' if wide else r'\bds_read_b128\b')
     block_hdr = {}  # line of a block's first instruction -> its loop header
     cur = None
     hdr_of = [None] * len(body)
@@ -71,7 +70,13 @@ def _step_loop(body):
                     if not ahead.lstrip().startswith(';'):
                         break
         hdr_of[j] = cur
-    H = hdr_of[j0]
-    assert H is not None, 'the look-ups are not inside a loop'
+    # the loop (by header) that holds the most table look-ups: 16-byte LDS reads (M = 64: 8-byte) -- the consumer's loops read
+    # 8-byte list entries and a handful of parked rows
+    per_loop = {}
+    for j, ln in enumerate(body):
+        if hdr_of[j] is not None and look.search(ln):
+            per_loop[hdr_of[j]] = per_loop.get(hdr_of[j], 0) + 1
+    assert per_loop, 'the look-ups are not inside a loop'
+    H = max(per_loop, key=per_loop.get)
     inside = [j for j, h in enumerate(hdr_of) if h == H]
     return body[min(inside):max(inside) + 1]
