@@ -48,6 +48,11 @@ SYMBOLS = (
     'annlite_graph_record_bytes',
     'annlite_graph_pack',
     'annlite_graph_search_packed',
+    'annlite_graph_search_packed_ex',
+    'annlite_graph_build_sdc',
+    'annlite_graph_build_select',
+    'annlite_graph_build_reverse',
+    'annlite_graph_pack_nodes',
     'annlite_adc_scan_topk',
     'annlite_adc_scan_topk_packed',
     'annlite_pq_search_workspace_bytes',
@@ -131,7 +136,12 @@ def lib() -> ctypes.CDLL:
     L.annlite_adc_gather.argtypes = [vp, i64, i64, i64, vp, i32, i64, vp, i64, vp, vp]
     L.annlite_graph_search.argtypes = [vp, i32, vp, i64, vp, i64, i64, i64, vp, vp, i64, i32, vp, vp, vp]
     L.annlite_graph_search_packed.argtypes = [vp, i32, vp, i64, vp, i64, i64, i64, vp, vp, i64, i32, vp, vp, vp]
+    L.annlite_graph_search_packed_ex.argtypes = [vp, i32, vp, i64, vp, i64, i64, i64, vp, vp, i64, i32, i32, vp, vp, vp]
     L.annlite_graph_pack.argtypes = [vp, i32, vp, i64, i64, vp, vp]
+    L.annlite_graph_build_sdc.argtypes = [vp, i64, i64, i64, vp, vp]
+    L.annlite_graph_build_select.argtypes = [vp, i32, i64, i64, vp, i64, i64, vp, i32, vp, i32, vp, vp]
+    L.annlite_graph_build_reverse.argtypes = [vp, vp, i64, vp, i64, i64, vp, vp, i32, vp]
+    L.annlite_graph_pack_nodes.argtypes = [vp, i32, vp, i64, i64, vp, i64, vp, vp]
     L.annlite_graph_record_bytes.argtypes = [i32, i64, ctypes.POINTER(ctypes.c_int64)]
     L.annlite_adc_scan_topk.argtypes = [vp, i32, i32, i64, i64, i64, vp, vp, i64, i64, i64, vp, vp, vp, sz, vp]
     L.annlite_adc_scan_candidates.argtypes = L.annlite_adc_scan_topk.argtypes

@@ -32,7 +32,7 @@ from .pq_flat_gpu import PQFlatGpuIndex
 class HnswPQGpuIndex(PQFlatGpuIndex):
     def __init__(self, dim: int, pq_codec=None, metric: Metric = Metric.COSINE, ef_construction: int = 200,
                  ef_search: int = 50, max_connection: int = 16, n_threads: int = 0, seed: int = 100,
-                 walk: str = 'gpu', packed_graph: bool = True, **kwargs):
+                 walk: str = 'gpu', packed_graph: bool = True, expand_width: int = 2, **kwargs):
         super().__init__(dim, pq_codec=pq_codec, metric=metric, **kwargs)
         self.ef_construction = int(ef_construction)  # hnsw/index.py:66-69
         self.ef_search = int(ef_search)
@@ -44,6 +44,11 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
         # GPU walk over packed node records (neighbours' code rows inline: 656 B per node at M = 16, max_connection 16) -- the
         # default; False = the plain lists + code table (the parity tests compare the two)
         self.packed_graph = bool(packed_graph)  # (False: the plain walk; `release_packed()` gives the records' memory back)
+        # nodes expanded per step of the packed GPU walk (round 6): 2 = the pair walk (the two best unexpanded entries together: half
+        # as many dependent steps per query; its own expansion order, > 0.99 of the one-at-a-time walk's candidates at ef = 128);
+        # 1 = one at a time, bit-equal to the plain walk.  Lists of more than 32 links per node are walked one at a time.
+        assert expand_width in (1, 2)
+        self.expand_width = int(expand_width)
         self._packed = None
         self._packed_key = None
         self._graph = None
@@ -165,9 +170,12 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
             plain = self._plain_table(self._n_rows)
             if self.packed_graph and links.shape[1] - 1 <= 64:
                 # packed node records (round 5): the neighbours' code rows sit behind every node's link list -- one contiguous
-                # read per expansion, the next record prefetched; the candidate lists are the plain walk's, bit for bit
-                return ops.graph_search_packed(self._packed_records(links, plain), links.shape[1] - 1, seeds, plain, lut, ef,
-                                               valid_bits=self._valid, n_rows=self._n_rows)
+                # read per expansion, the next record prefetched; with expand_width = 1 the candidate lists are the plain walk's, bit
+                # for bit
+                lpn = links.shape[1] - 1
+                return ops.graph_search_packed(self._packed_records(links, plain), lpn, seeds, plain, lut, ef,
+                                               valid_bits=self._valid, n_rows=self._n_rows,
+                                               expand_width=self.expand_width if lpn <= 32 else 1)
             return ops.graph_search(links, seeds, plain, lut, ef, valid_bits=self._valid, n_rows=self._n_rows)
         x_np = np.ascontiguousarray(xg.cpu().numpy(), dtype=np.float32)
         B = x_np.shape[0]

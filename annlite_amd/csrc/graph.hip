@@ -82,7 +82,14 @@ __device__ __forceinline__ void beam_insert(BeamList<E> &L, uint32_t chi, uint32
 // largest single item of the walk: one wave per SIMD executes them back to back).  The result is the same sorted list --
 // the top of (old list + candidates) -- so the walk is unchanged; BATCH = false keeps the one-at-a-time insertion (the
 // comparison path of tests/test_graph_packed.py).
-template <int M, int E, bool PACKED, bool BATCH>
+// W (round 6, PACKED only): nodes expanded per step.  W = 2 = the PAIR walk: the two best unexpanded entries are expanded TOGETHER --
+// lanes 0..31 take one record, lanes 32..63 the other (links_per_node <= 32), one pass through the visited table, one merge of up
+// to 64 neighbours -- so a walk's chain of dependent steps is half as long (one wave per SIMD hides no latency: the launch lasts as
+// long as one query's chain).  Every entry that stays inside the ef best is expanded sooner or later in either walk; the pair walk
+// expands the runner-up before it knows the winner's neighbours, which changes the ORDER of expansions (and, rarely, expands a node
+// the one-at-a-time walk would have seen pushed out of the list first).  The list is the same kind of object -- the ef best of the
+// nodes evaluated, exact PQLookup sums -- and tests/test_graph_pair.py pins it bit for bit against a restatement of this order.
+template <int M, int E, bool PACKED, bool BATCH, int W = 1>
 __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *__restrict__ links, int links_per_node,
                                                                const uint8_t *__restrict__ packed, int64_t rec_stride,
                                                                const uint32_t *__restrict__ seeds, int n_seeds,
@@ -400,7 +407,96 @@ __global__ __launch_bounds__(256) void graph_beam_search_kernel(const uint32_t *
         }
         return true;
     };
-    if constexpr (PACKED) {
+    if constexpr (PACKED && W == 2) {
+        const int Lc = links_per_node;  // (<= 32: one HALF wave per record)
+        const int half = lane >> 5, hj = lane & 31;
+        // the record of `node` as seen by this lane's half: neighbour hj's code row and id (slots beyond the count hold 0xffffffff)
+        auto load_rec = [&](uint32_t node, uint32_t (&c)[CW], uint32_t &nb) {
+            const uint8_t *r = packed + (int64_t)node * rec_stride;
+            const int j = hj < Lc ? hj : 0;
+            const uint32_t *pc = (const uint32_t *)(r + (int64_t)j * M);
+#pragma unroll
+            for (int i = 0; i < CW; ++i) c[i] = pc[i];
+            nb = ((const uint32_t *)(r + (int64_t)Lc * M))[j];
+        };
+        // the two best unexpanded entries (marked expanded) and the two after them (the halves' prefetch targets)
+        auto pick_pair = [&](uint32_t (&nd)[4]) -> bool {
+            int p[4] = {-1, -1, -1, -1};
+            int found = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (found < 4) {
+                    unsigned long long m = __ballot(!L.exp[e] && (e * 64 + lane) < cap);
+                    while (m && found < 4) {
+                        p[found++] = e * 64 + __builtin_ctzll(m);
+                        m &= m - 1;
+                    }
+                }
+            }
+            if (found == 0) return false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) nd[i] = kEmpty;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (p[i] >= 0 && p[i] / 64 == e) nd[i] = __builtin_amdgcn_readlane(L.lo[e], p[i] % 64);
+                if ((p[0] >= 0 && p[0] / 64 == e && lane == p[0] % 64) || (p[1] >= 0 && p[1] / 64 == e && lane == p[1] % 64)) L.exp[e] = true;
+            }
+            return true;
+        };
+        uint32_t pf_c[CW], pf_nb = kEmpty, pf_node = kEmpty;  // this HALF's prefetched record (pf_node == kEmpty: none)
+#pragma unroll
+        for (int i = 0; i < CW; ++i) pf_c[i] = 0;
+        for (;;) {
+            uint32_t nd[4];
+            const unsigned long long t0 = now();
+            if (!pick_pair(nd)) break;
+            // a prefetched record stays in the half that holds it: the halves swap nodes when that keeps more of them (the
+            // candidates of a step are merged as a SET -- which half evaluated a neighbour does not matter)
+            const uint32_t pf0 = __builtin_amdgcn_readlane(pf_node, 0), pf1 = __builtin_amdgcn_readlane(pf_node, 32);
+            const bool two = nd[1] != kEmpty;
+            const int keep_straight = (pf0 == nd[0] ? 1 : 0) + (two && pf1 == nd[1] ? 1 : 0);
+            const int keep_swapped = (two && pf0 == nd[1] ? 1 : 0) + (pf1 == nd[0] ? 1 : 0);
+            const bool swapped = keep_swapped > keep_straight;
+            const uint32_t node = ((half != 0) != swapped) ? nd[1] : nd[0];
+            const bool have = node != kEmpty;
+            uint32_t c[CW], nb = kEmpty;
+#pragma unroll
+            for (int i = 0; i < CW; ++i) c[i] = 0;
+            if (have && pf_node == node) {
+#pragma unroll
+                for (int i = 0; i < CW; ++i) c[i] = pf_c[i];
+                nb = pf_nb;
+            } else if (have) {
+                load_rec(node, c, nb);
+            }
+            n_hit += (unsigned int)__popcll(__ballot(have && pf_node == node && hj == 0));
+            // (the current records must have ARRIVED before the prefetches are issued: see the one-at-a-time loop below)
+            asm volatile("" : "+v"(nb));
+#pragma unroll
+            for (int i = 0; i < CW; ++i) asm volatile("" : "+v"(c[i]));
+            // half 0 requests the best node that is unexpanded NOW, half 1 the one after it: the next pair unless this step's
+            // neighbours turn out better
+            pf_node = half ? nd[3] : nd[2];
+            if (pf_node != kEmpty) load_rec(pf_node, pf_c, pf_nb);
+            n_expand += two ? 2u : 1u;
+            const unsigned long long t1 = now();
+            // (a neighbour of BOTH nodes is probed by two lanes at once: the table's compare-and-swap lets exactly one of them through)
+            bool mine = have && hj < Lc;
+            mine = mine && (int64_t)nb < N && visit(nb);
+            n_eval += (unsigned int)__popcll(__ballot(mine));
+            const unsigned long long t2 = now();
+            float d = mine ? pq_sum(c) : 0.f;
+            if (stats) asm volatile("" : "+v"(d));
+            const unsigned long long t3 = now();
+            offer(mine, nb, d);
+            if (stats) {
+                const unsigned long long t4 = now();
+                t_rec += t1 - t0, t_visit += t2 - t1, t_sum += t3 - t2, t_offer += t4 - t3;
+            }
+        }
+    } else if constexpr (PACKED) {
         // record of a node: lane j < L holds neighbour j's code row and id; the count is a wave-uniform load
         const int Lc = links_per_node;  // (<= 64: one lane per neighbour)
         // (slots beyond the node's count hold the id 0xffffffff, which fails the `nb < N` test like any id beyond the table:
@@ -525,7 +621,7 @@ __global__ __launch_bounds__(256) void graph_pack_kernel(const uint32_t *__restr
 
 static int64_t graph_record_stride(int64_t L, int64_t M) { return ((L * M + 4 * L + 4 + 15) / 16) * 16; }
 
-template <int M, int E, bool PACKED, bool BATCH>
+template <int M, int E, bool PACKED, bool BATCH, int W = 1>
 static int launch_beam(const uint32_t *links, int lpn, const uint8_t *packed, const uint32_t *seeds, int n_seeds, const uint8_t *codes,
                        int64_t N, const uint32_t *valid, const float *lut, int64_t B, int64_t Ks, int ef, int hash_bits,
                        int64_t *out_ids, float *out_dist, unsigned long long *stats, hipStream_t st) {
@@ -534,7 +630,7 @@ static int launch_beam(const uint32_t *links, int lpn, const uint8_t *packed, co
     if (wpb > 4) wpb = 4;
     ANNLITE_REQUIRE(wpb >= 1, "M * Ks tables do not fit the LDS");
     const size_t lds = wpb * per_wave;
-    auto fn = graph_beam_search_kernel<M, E, PACKED, BATCH>;
+    auto fn = graph_beam_search_kernel<M, E, PACKED, BATCH, W>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(fn, dim3((unsigned)((B + wpb - 1) / wpb)), dim3(wpb * 64), lds, st, links, lpn, packed,
                        graph_record_stride(lpn, M), seeds, n_seeds, codes, N, valid, lut, (int)B, (int)Ks, ef, hash_bits, out_ids,
@@ -557,9 +653,12 @@ extern "C" int annlite_graph_search_stats(uint64_t *out2) {
 
 static int graph_search_impl(const uint32_t *links_dev, const uint8_t *packed_dev, int links_per_node, const uint32_t *seeds_dev,
                              int64_t n_seeds, const void *codes_dev, int64_t N, int64_t M, int64_t Ks, const uint32_t *valid_bits_dev,
-                             const float *lut_bmk_dev, int64_t B, int ef, int64_t *out_ids_dev, float *out_dist_dev, void *stream) {
+                             const float *lut_bmk_dev, int64_t B, int ef, int64_t *out_ids_dev, float *out_dist_dev, void *stream,
+                             int width = 1) {
     ANNLITE_REQUIRE(B >= 0 && N >= 0 && ef >= 1 && ef <= 256, "bad B=%lld N=%lld ef=%d (ef <= 256)", (long long)B,
                     (long long)N, ef);
+    ANNLITE_REQUIRE(width == 1 || (width == 2 && packed_dev && links_per_node <= 32),
+                    "expansion width %d: 1, or 2 over packed records of at most 32 neighbours (links_per_node = %d)", width, links_per_node);
     ANNLITE_REQUIRE(Ks >= 1 && Ks <= 256 && (M == 8 || M == 16 || M == 32), "graph search supports M in {8,16,32}, Ks <= 256");
     ANNLITE_REQUIRE(links_per_node >= 1 && n_seeds >= 1 && N < (1ll << 32) - 1, "bad graph");
     ANNLITE_REQUIRE(!packed_dev || links_per_node <= 64, "packed records hold at most 64 neighbours (links_per_node = %d)", links_per_node);
@@ -583,6 +682,14 @@ static int graph_search_impl(const uint32_t *links_dev, const uint8_t *packed_de
                           hash_bits, out_ids_dev, out_dist_dev, stats, st
 #define ANNLITE_BEAM(MM, PK, BT) \
     (ef <= 64 ? launch_beam<MM, 1, PK, BT>(ANNLITE_BEAM_ARGS) : ef <= 128 ? launch_beam<MM, 2, PK, BT>(ANNLITE_BEAM_ARGS) : launch_beam<MM, 4, PK, BT>(ANNLITE_BEAM_ARGS))
+#define ANNLITE_BEAM2(MM) \
+    (ef <= 64 ? launch_beam<MM, 1, true, true, 2>(ANNLITE_BEAM_ARGS) : ef <= 128 ? launch_beam<MM, 2, true, true, 2>(ANNLITE_BEAM_ARGS) : launch_beam<MM, 4, true, true, 2>(ANNLITE_BEAM_ARGS))
+    if (packed_dev && width == 2) {
+        if (M == 8) return ANNLITE_BEAM2(8);
+        if (M == 16) return ANNLITE_BEAM2(16);
+        return ANNLITE_BEAM2(32);
+    }
+#undef ANNLITE_BEAM2
     if (packed_dev) {
         if (M == 8) return ANNLITE_BEAM(8, true, true);
         if (M == 16) return ANNLITE_BEAM(16, true, true);
@@ -649,4 +756,13 @@ extern "C" int annlite_graph_search_packed(const void *packed_dev, int links_per
     ANNLITE_REQUIRE(packed_dev != nullptr || B == 0, "packed_dev is NULL");
     return graph_search_impl(nullptr, (const uint8_t *)packed_dev, links_per_node, seeds_dev, n_seeds, codes_dev, N, M, Ks,
                              valid_bits_dev, lut_bmk_dev, B, ef, out_ids_dev, out_dist_dev, stream);
+}
+
+extern "C" int annlite_graph_search_packed_ex(const void *packed_dev, int links_per_node, const uint32_t *seeds_dev, int64_t n_seeds,
+                                              const void *codes_dev, int64_t N, int64_t M, int64_t Ks,
+                                              const uint32_t *valid_bits_dev, const float *lut_bmk_dev, int64_t B, int ef,
+                                              int expand_width, int64_t *out_ids_dev, float *out_dist_dev, void *stream) {
+    ANNLITE_REQUIRE(packed_dev != nullptr || B == 0, "packed_dev is NULL");
+    return graph_search_impl(nullptr, (const uint8_t *)packed_dev, links_per_node, seeds_dev, n_seeds, codes_dev, N, M, Ks,
+                             valid_bits_dev, lut_bmk_dev, B, ef, out_ids_dev, out_dist_dev, stream, expand_width);
 }

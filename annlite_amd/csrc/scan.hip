@@ -1201,7 +1201,8 @@ extern "C" int annlite_kernel_rev(const char *kernel) {
         {"adc_scan_qfilter64_kernel", 1},
         {"adc_scan_generic_kernel", 1},
         {"adc_scan_lds_kernel", 1},       // round 6: the generic scan with the query's fp32 table in LDS and 16-byte code-row loads
-        {"graph_beam_search_kernel", 2},  // 2: round 5 (packed node records + prefetch, merge insertion, bucketed visited table)
+        {"graph_beam_search_kernel", 3},  // 2: round 5 (packed node records + prefetch, merge insertion, bucketed visited table); 3: round 6 (pair walk:
+                                          // two records per step, one per half wave)
     };
     for (const auto &r : revs)
         if (strcmp(r.name, kernel) == 0) return r.rev;

@@ -134,14 +134,22 @@ def graph_pack(links: torch.Tensor, codes: torch.Tensor, n_rows: Optional[int] =
 
 
 def graph_search_packed(packed: torch.Tensor, links_per_node: int, seeds: torch.Tensor, codes: torch.Tensor, lut_bmk: torch.Tensor,
-                        ef: int, valid_bits: Optional[torch.Tensor] = None, n_rows: Optional[int] = None
+                        ef: int, valid_bits: Optional[torch.Tensor] = None, n_rows: Optional[int] = None, expand_width: int = 1
                         ) -> Tuple[torch.Tensor, torch.Tensor]:
     """``graph_search`` over packed node records (``annlite_graph_search_packed``): one contiguous read per expansion, the
-    next record prefetched; candidate lists bit-equal to ``graph_search``'s."""
+    next record prefetched; candidate lists bit-equal to ``graph_search``'s.  ``expand_width=2``
+    (``annlite_graph_search_packed_ex``): the pair walk -- the two best unexpanded entries per step, half as many dependent steps;
+    its own (pinned) expansion order."""
     B, M, Ks = lut_bmk.shape
     N = codes.shape[0] if n_rows is None else n_rows
     out_i = torch.empty((B, ef), dtype=torch.int64, device=codes.device)
     out_d = torch.empty((B, ef), dtype=torch.float32, device=codes.device)
+    if int(expand_width) != 1:
+        check(lib().annlite_graph_search_packed_ex(packed.data_ptr(), int(links_per_node), seeds.data_ptr(), seeds.numel(),
+                                                   codes.data_ptr(), N, M, Ks, _ptr(valid_bits), lut_bmk.data_ptr(), B, int(ef),
+                                                   int(expand_width), out_i.data_ptr(), out_d.data_ptr(), stream_ptr()),
+              'graph_search_packed_ex')
+        return out_i, out_d
     check(lib().annlite_graph_search_packed(packed.data_ptr(), int(links_per_node), seeds.data_ptr(), seeds.numel(), codes.data_ptr(),
                                             N, M, Ks, _ptr(valid_bits), lut_bmk.data_ptr(), B, int(ef), out_i.data_ptr(),
                                             out_d.data_ptr(), stream_ptr()), 'graph_search_packed')

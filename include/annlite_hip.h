@@ -172,6 +172,40 @@ ANNLITE_API int annlite_graph_search_packed(const void *packed_dev, int links_pe
                          int64_t n_seeds, const void *codes_dev, int64_t N, int64_t M, int64_t Ks,
                          const uint32_t *valid_bits_dev, const float *lut_bmk_dev, int64_t B, int ef,
                          int64_t *out_ids_dev, float *out_dist_dev, void *stream);
+/* ... with expand_width nodes expanded per step (round 6).  1 = annlite_graph_search_packed.  2 = the PAIR walk (links_per_node <= 32):
+ * the two best unexpanded entries of the list are expanded TOGETHER -- one half wave per record, one pass through the visited table,
+ * one merge of up to 64 neighbours -- so the chain of dependent steps of a walk (what a launch of one wave per query lasts) is half as
+ * long.  The stop rule (no unexpanded entry among the ef best, hnswalg.h searchBaseLayerST) and the arithmetic are unchanged; the
+ * ORDER of the expansions is not: the runner-up is expanded before the winner's neighbours are known, so the list can differ from
+ * the one-at-a-time walk's in its last places (candidate overlap > 0.99 at ef = 128; tests/test_graph_pair.py pins the pair order
+ * bit for bit against a restatement). */
+ANNLITE_API int annlite_graph_search_packed_ex(const void *packed_dev, int links_per_node, const uint32_t *seeds_dev,
+                         int64_t n_seeds, const void *codes_dev, int64_t N, int64_t M, int64_t Ks,
+                         const uint32_t *valid_bits_dev, const float *lut_bmk_dev, int64_t B, int ef, int expand_width,
+                         int64_t *out_ids_dev, float *out_dist_dev, void *stream);
+/* ---- the level-0 graph BUILT ON THE GPU, in batches (round 6; graph_build.hip) -------------------------------------------------
+ * replaces, for a batch of points: hnswlib addPoint (include/hnswlib/hnswalg.h:1108-1235) = searchBaseLayer with ef_construction
+ * (the walk above over the graph as it is, the points' own L2 tables as queries), getNeighborsByHeuristic2 (378-429) and
+ * mutuallyConnectNewElement (431-553), in the form libannlite_graph.so gives them (hnsw_host.cpp select_neighbors / connect: the
+ * triangle tests on the SYMMETRIC code-to-code L2 table).  Only level 0 exists -- the GPU walk scans a seed sample flat and never
+ * descends upper layers.  Node id = row of the PLAIN code table.
+ *   annlite_graph_build_sdc      sdc f32 [M][Ks][Ks] <- sum_j (C[m][a][j] - C[m][b][j])^2
+ *   annlite_graph_build_select   point i of the batch = node base0 + i; cand_dev i64 [b][ef] = its candidates in ascending search
+ *                                distance (-1 = none; ef <= 256): keeps at most max_keep of them (every one if they are that few),
+ *                                writes links[base0 + i] = (count, ids) and pairs[i][0..max_keep) = (target << 32) | source
+ *                                (INT64_MAX = none)
+ *   annlite_graph_build_reverse  keys_dev i64 [P] = the pairs SORTED ascending; seg_dev i64 [S + 1] = the boundaries of the S runs
+ *                                of equal target: every target appends its sources while its list has room, else shrinks
+ *                                (list + sources) to links_per_node (<= 32) entries with the same heuristic
+ *   annlite_graph_pack_nodes     the packed records (annlite_graph_pack) of the nodes in nodes_dev i64 [n_nodes] only */
+ANNLITE_API int annlite_graph_build_sdc(const float *codebooks_dev, int64_t M, int64_t Ks, int64_t dsub, float *sdc_dev, void *stream);
+ANNLITE_API int annlite_graph_build_select(const int64_t *cand_dev, int ef, int64_t b, int64_t base0, const void *codes_dev, int64_t M,
+                         int64_t Ks, const float *sdc_dev, int max_keep, uint32_t *links_dev, int links_per_node,
+                         int64_t *pairs_dev, void *stream);
+ANNLITE_API int annlite_graph_build_reverse(const int64_t *keys_dev, const int64_t *seg_dev, int64_t n_segments, const void *codes_dev,
+                         int64_t M, int64_t Ks, const float *sdc_dev, uint32_t *links_dev, int links_per_node, void *stream);
+ANNLITE_API int annlite_graph_pack_nodes(const uint32_t *links_dev, int links_per_node, const void *codes_dev, int64_t N, int64_t M,
+                         const int64_t *nodes_dev, int64_t n_nodes, void *packed_dev, void *stream);
 /* Debug aid: with ANNLITE_DEBUG_COUNTERS=1 the walk counts [0] expansions (link lists read) and [1] rows evaluated
  * (PQLookup sums) over the batch; this copies the two counters of the last walk to the host (the roofline of
  * scripts/bench_hnsw.py: algorithmic bytes = expansions * 4 (links_per_node + 1) + evaluations * M). */

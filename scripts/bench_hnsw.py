@@ -132,21 +132,25 @@ lpn = links.shape[1] - 1
 packed = index._packed_records(links, plain) if index.packed_graph and lpn <= 64 else None
 
 
-def walk_once(use_packed):
+width = index.expand_width if (packed is not None and lpn <= 32) else 1  # nodes per step of the packed walk (2: the pair walk)
+
+
+def walk_once(use_packed, w=None):
     if use_packed:
-        return ops.graph_search_packed(packed, lpn, seeds, plain, lut, a.ef_search, valid_bits=index._valid, n_rows=index._n_rows)
+        return ops.graph_search_packed(packed, lpn, seeds, plain, lut, a.ef_search, valid_bits=index._valid, n_rows=index._n_rows,
+                                       expand_width=width if w is None else w)
     return ops.graph_search(links, seeds, plain, lut, a.ef_search, valid_bits=index._valid, n_rows=index._n_rows)
 
 
-def walk_ms(use_packed):
+def walk_ms(use_packed, w=None):
     for _ in range(2):
-        walk_once(use_packed)
+        walk_once(use_packed, w)
     torch.cuda.synchronize()
     out = []
     for _ in range(max(3, a.steps)):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        walk_once(use_packed)
+        walk_once(use_packed, w)
         e1.record()
         e1.synchronize()
         out.append(e0.elapsed_time(e1))
@@ -163,9 +167,15 @@ _capi.knobs_reload()
 kernel_ms = walk_ms(packed is not None)
 plain_ms = walk_ms(False) if packed is not None else kernel_ms
 same = None
-if packed is not None:  # the two layouts walk the same graph in the same order: bit-equal candidate lists
-    (i1, d1), (i2, d2) = walk_once(True), walk_once(False)
+one_ms = pair_overlap = None
+if packed is not None:  # the two layouts walk the same graph in the same order (one node per step): bit-equal candidate lists
+    (i1, d1), (i2, d2) = walk_once(True, 1), walk_once(False)
     same = bool(torch.equal(i1, i2) and torch.equal(d1.view(torch.int32), d2.view(torch.int32)))
+    if width == 2:  # the pair walk against the one-at-a-time walk: time, and the share of its candidates found by both
+        one_ms = walk_ms(True, 1)
+        ip, _ = walk_once(True, 2)
+        both = (ip[:, :, None] == i1[:, None, :]).any(dim=2) & (ip >= 0)
+        pair_overlap = float(both.sum().item() / max(1, int((i1 >= 0).sum().item())))
 rec_bytes = int(packed.shape[1]) if packed is not None else None
 # algorithmic bytes: what the WALK needs -- one link list per expansion + M code bytes per evaluated row (+ the seed rows);
 # the packed layout reads a whole record per expansion by design (`bytes_read_by_design`)
@@ -191,6 +201,7 @@ roofline = {'bound': 'hbm', 'achieved': alg_bytes / (kernel_ms * 1e-3) / 1e9, 'p
             'kernel': 'graph_beam_search_kernel', 'kernel_rev': _capi.kernel_rev('graph_beam_search_kernel'), 'kernel_ms': kernel_ms,
             'layout': 'packed node records (neighbours\' code rows inline, next record prefetched)' if packed is not None else 'plain',
             'plain_layout_kernel_ms': plain_ms, 'packed_equals_plain_bit_exact': same, 'record_bytes': rec_bytes,
+            'expand_width': width, 'one_at_a_time_kernel_ms': one_ms, 'pair_candidates_shared_with_one_at_a_time': pair_overlap,
             'prefetched_records_used': (n_hit / max(n_expand, 1)),
             # shader cycles per query by phase of the walk (ANNLITE_DEBUG_COUNTERS run: the stamps themselves cost a few per cent)
             'cycles_per_query_by_phase': {kk: vv / B for kk, vv in phase_cycles.items()},
