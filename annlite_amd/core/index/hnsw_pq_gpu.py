@@ -32,7 +32,7 @@ from .pq_flat_gpu import PQFlatGpuIndex
 class HnswPQGpuIndex(PQFlatGpuIndex):
     def __init__(self, dim: int, pq_codec=None, metric: Metric = Metric.COSINE, ef_construction: int = 200,
                  ef_search: int = 50, max_connection: int = 16, n_threads: int = 0, seed: int = 100,
-                 walk: str = 'gpu', packed_graph: bool = True, expand_width: int = 2, **kwargs):
+                 walk: str = 'gpu', packed_graph: bool = True, expand_width: int = 2, build: Optional[str] = None, **kwargs):
         super().__init__(dim, pq_codec=pq_codec, metric=metric, **kwargs)
         self.ef_construction = int(ef_construction)  # hnsw/index.py:66-69
         self.ef_search = int(ef_search)
@@ -49,6 +49,16 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
         # 1 = one at a time, bit-equal to the plain walk.  Lists of more than 32 links per node are walked one at a time.
         assert expand_width in (1, 2)
         self.expand_width = int(expand_width)
+        # where the graph is BUILT: 'gpu' (round 6) = graph_gpu_build.GpuLevel0Graph -- level 0 only, inserted in batches by the GPU
+        # (the searches of an insertion are the packed pair walk itself: 5M rows in 3.5 s against 60 s on 16 host cores, same
+        # recall); GPU walks only; ids must be dense in insertion order (0, 1, 2, ...: what AnnLite's offsets are,
+        # storage/table.py:251-257).  'host' = libannlite_graph.so: the full hierarchy (host walks, the reference's structure).
+        # None: 'gpu' where it applies -- walk='gpu', max_connection <= 16, M in {8, 16, 32}, uint8 codes -- else 'host'.
+        assert build in (None, 'host', 'gpu')
+        if build is None:
+            build = 'gpu' if (walk == 'gpu' and 2 <= self.max_connection <= 16 and self.M in (8, 16, 32) and self.Ks <= 256) else 'host'
+        self.build = build
+        self._gg = None         # GpuLevel0Graph
         self._packed = None
         self._packed_key = None
         self._graph = None
@@ -73,6 +83,15 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
             self._graph = ctypes.c_void_p(h)
         return self._graph
 
+    def _ensure_gpu_graph(self):
+        if self._gg is None:
+            if not self.pq_codec.is_trained:
+                raise RuntimeError('Please train the PQ before using HNSW quantization backend')  # hnsw/index.py:32-35
+            from .graph_gpu_build import GpuLevel0Graph
+
+            self._gg = GpuLevel0Graph(self.pq_codec.codebooks_dev, self.max_connection, self.ef_construction)
+        return self._gg
+
     def __del__(self):
         try:
             if getattr(self, '_graph', None) is not None:
@@ -94,6 +113,13 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
         # PQCodec.get_dist_mat would normalise them once more for cosine (pq.py:309-310) -- do the same
         _, xg = self.pq_codec.scan_inputs(xq)
         codes = ops.pq_encode(xq, self.pq_codec.codebooks_dev)
+        if self.build == 'gpu':
+            gg = self._ensure_gpu_graph()
+            if not (ids_np[0] == gg.n and (np.diff(ids_np) == 1).all()):
+                raise RuntimeError(f"build='gpu' takes ids in insertion order (next: {gg.n}, got {ids_np[:3]}...)")
+            gg.reserve(int(self.capacity))
+            gg.add(xg, codes)
+            return
         x_np = np.ascontiguousarray(xg.cpu().numpy(), dtype=np.float32)
         c_np = np.ascontiguousarray(codes.cpu().numpy(), dtype=np.uint8)
         g = self._ensure_graph()
@@ -120,6 +146,7 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
         self._plain_cache_key = None
         self._packed = None
         self._packed_key = None
+        self._gg = None
         if self._graph is not None:
             gc.lib().annlite_hnsw_free(self._graph)
             self._graph = None
@@ -127,6 +154,9 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
     # ------------------------------------------------------------------ search
     def _export_graph(self):
         """Level-0 lists + seed set of the host graph on the device (re-exported after inserts / deletes)."""
+        if self.build == 'gpu':
+            gg = self._ensure_gpu_graph()
+            return gg.links[: gg.n], gg.seeds()
         key = self._mutations  # (sizes alone collide: clear() + the same number of documents again, restore())
         if self._gpu_graph is None or self._gpu_graph[0] != key:
             n = self._n_rows
@@ -143,6 +173,8 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
 
     def _packed_records(self, links: torch.Tensor, plain: torch.Tensor) -> torch.Tensor:
         """The packed node records of the current graph (cached; rebuilt after INSERTS -- deletes leave links and code rows alone)."""
+        if self.build == 'gpu':
+            return self._gg.packed  # (kept current by every insertion batch)
         key = (self._n_rows, self._structure)
         if getattr(self, '_packed_key', None) != key:
             self._packed = ops.graph_pack(links, plain, n_rows=self._n_rows)
@@ -164,7 +196,8 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
         if self._gpu_walk_ok() and ef <= 256:
             from ..._capi import LAYOUT_BMK, LUT_L2
 
-            self._ensure_graph()
+            if self.build != 'gpu':
+                self._ensure_graph()
             links, seeds = self._export_graph()
             lut = ops.lut_build(xg, self.pq_codec.codebooks_dev, LUT_L2, LAYOUT_BMK)
             plain = self._plain_table(self._n_rows)
@@ -177,6 +210,8 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
                                                valid_bits=self._valid, n_rows=self._n_rows,
                                                expand_width=self.expand_width if lpn <= 32 else 1)
             return ops.graph_search(links, seeds, plain, lut, ef, valid_bits=self._valid, n_rows=self._n_rows)
+        if self.build == 'gpu':
+            raise RuntimeError("build='gpu' keeps level 0 only: walk='gpu' with M in {8, 16, 32}, Ks <= 256, ef <= 256")
         x_np = np.ascontiguousarray(xg.cpu().numpy(), dtype=np.float32)
         B = x_np.shape[0]
         ids = np.empty((B, ef), dtype=np.int64)
@@ -198,7 +233,7 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
         q = self._pre(x)
         B, k = q.shape[0], int(limit)
         N = self._n_rows
-        if N == 0 or B == 0 or self._graph is None:
+        if N == 0 or B == 0 or (self._graph is None and (self._gg is None or self._gg.n == 0)):
             d = torch.full((B, k), float('inf'), dtype=torch.float32, device=q.device)
             i = torch.full((B, k), -1, dtype=torch.int64, device=q.device)
         else:
@@ -239,6 +274,10 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
     # ------------------------------------------------------------------ persistence
     def dump(self, index_file: Union[str, Path]):
         super().dump(index_file)
+        if getattr(self, 'build', 'host') == 'gpu':
+            if self._gg is not None:
+                np.save(str(index_file) + '.level0.npy', np.array([self._gg.state()], dtype=object), allow_pickle=True)
+            return
         if self._graph is not None:
             gc.check(gc.lib().annlite_hnsw_save(self._graph, (str(index_file) + '.graph').encode()), 'annlite_hnsw_save')
 
@@ -246,6 +285,13 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
         super().load(index_file)
         self._mutations = getattr(self, '_mutations', 0) + 1
         self._structure = getattr(self, '_structure', 0) + 1
+        if getattr(self, 'build', 'host') == 'gpu':
+            lpath = str(index_file) + '.level0.npy'
+            self._gg = None
+            if Path(lpath).exists():
+                st = np.load(lpath, allow_pickle=True)[0]
+                self._ensure_gpu_graph().load_state(st, self._plain_codes(self._n_rows).contiguous())
+            return
         gpath = str(index_file) + '.graph'
         if Path(gpath).exists():
             if self._graph is not None:

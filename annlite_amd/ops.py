@@ -156,6 +156,48 @@ def graph_search_packed(packed: torch.Tensor, links_per_node: int, seeds: torch.
     return out_i, out_d
 
 
+def graph_record_bytes(links_per_node: int, M: int) -> int:
+    import ctypes
+
+    nb = ctypes.c_int64(0)
+    check(lib().annlite_graph_record_bytes(int(links_per_node), int(M), ctypes.byref(nb)), 'graph_record_bytes')
+    return int(nb.value)
+
+
+def graph_build_sdc(codebooks: torch.Tensor) -> torch.Tensor:
+    """Symmetric code-to-code L2 table f32 [M, Ks, Ks] of the GPU graph build (``annlite_graph_build_sdc``)."""
+    M, Ks, dsub = codebooks.shape
+    out = torch.empty((M, Ks, Ks), dtype=torch.float32, device=codebooks.device)
+    check(lib().annlite_graph_build_sdc(codebooks.data_ptr(), M, Ks, dsub, out.data_ptr(), stream_ptr()), 'graph_build_sdc')
+    return out
+
+
+def graph_build_select(cand: torch.Tensor, base0: int, codes: torch.Tensor, sdc: torch.Tensor, max_keep: int,
+                       links: torch.Tensor) -> torch.Tensor:
+    """``annlite_graph_build_select``: the lists of the batch's points (nodes ``base0 + i``) from their candidate lists ``cand``
+    i64 [b, ef]; writes ``links`` rows in place, returns the (target << 32 | source) pairs i64 [b, max_keep] (INT64_MAX = none)."""
+    b, ef = cand.shape
+    M, Ks = codes.shape[1], sdc.shape[1]
+    pairs = torch.empty((b, int(max_keep)), dtype=torch.int64, device=codes.device)
+    check(lib().annlite_graph_build_select(cand.data_ptr(), int(ef), b, int(base0), codes.data_ptr(), M, Ks, sdc.data_ptr(),
+                                           int(max_keep), links.data_ptr(), links.shape[1] - 1, pairs.data_ptr(), stream_ptr()),
+          'graph_build_select')
+    return pairs
+
+
+def graph_build_reverse(keys_sorted: torch.Tensor, seg: torch.Tensor, codes: torch.Tensor, sdc: torch.Tensor, links: torch.Tensor):
+    """``annlite_graph_build_reverse``: reverse links for the sorted pairs; ``seg`` i64 [S + 1] bounds the runs of equal target."""
+    M, Ks = codes.shape[1], sdc.shape[1]
+    check(lib().annlite_graph_build_reverse(keys_sorted.data_ptr(), seg.data_ptr(), seg.numel() - 1, codes.data_ptr(), M, Ks,
+                                            sdc.data_ptr(), links.data_ptr(), links.shape[1] - 1, stream_ptr()), 'graph_build_reverse')
+
+
+def graph_pack_nodes(links: torch.Tensor, codes: torch.Tensor, nodes: torch.Tensor, packed: torch.Tensor, n_rows: int):
+    """``annlite_graph_pack_nodes``: re-pack the records of ``nodes`` i64 [n] in place."""
+    check(lib().annlite_graph_pack_nodes(links.data_ptr(), links.shape[1] - 1, codes.data_ptr(), int(n_rows), codes.shape[1],
+                                         nodes.data_ptr(), nodes.numel(), packed.data_ptr(), stream_ptr()), 'graph_pack_nodes')
+
+
 class ScanWorkspace:
     """Re-usable device scratch for the scan (avoids an allocation per search call).  One buffer PER STREAM:
     batches issued on different streams run concurrently (the next batch's kernels fill the CUs the previous

@@ -841,8 +841,10 @@ def main():
             if 'error' in r:
                 rec[name] = r
             elif name == 'c5':
-                rec[name] = {kk: r[kk] for kk in ('config', 'value', 'unit', 'recall_at_10', 'build_s', 'graph_walk_queries_per_s',
-                                                 'roofline', 'cpu_baseline', 'hnsw_gpu_walk_adc', 'exhaustive_exact_rerank') if kk in r}
+                rec[name] = {kk: r[kk] for kk in ('config', 'value', 'unit', 'recall_at_10', 'graph_built_on', 'build_s', 'gpu_build_s',
+                                                 'host_build_s', 'graph_walk_queries_per_s', 'roofline', 'cpu_baseline',
+                                                 'hnsw_gpu_walk_adc', 'hnsw_gpu_walk_exact_rerank_on_host_built_graph',
+                                                 'exhaustive_exact_rerank') if kk in r}
             else:
                 rec[name] = {'config': r['config']['workload'], 'streams': r['config'].get('streams'), 'value': r['value'], 'unit': r['unit'],
                              'result_sha256': r.get('result_sha256'),
@@ -878,6 +880,8 @@ def main():
                 summ[name] = leg_summary(rec[name])
                 if name == 'c5' and isinstance(rec[name], dict) and 'build_s' in rec[name]:
                     summ[name]['build_s'] = _r(rec[name]['build_s'], 1)
+                    if rec[name].get('host_build_s') is not None:
+                        summ[name]['host_build_s'] = _r(rec[name]['host_build_s'], 1)
         if per_rank and world > 1:
             summ['ranks'] = {'sha': [r['result_sha256_head'] for r in per_rank], 'rows': [r['rows'] for r in per_rank],
                              'ms': [_r(r['ms_per_step'], 4) for r in per_rank], 'checksum_sum': rec['shard_codes_checksum_sum']}

@@ -27,6 +27,10 @@ p.add_argument('--ef-search', type=int, default=128)
 p.add_argument('--ef-construction', type=int, default=200)
 p.add_argument('--max-connection', type=int, default=16)
 p.add_argument('--steps', type=int, default=5)
+p.add_argument('--build', choices=['both', 'gpu', 'host'], default='both',
+               help="where the graph is built: 'gpu' = level 0 in batches on the GPU (round 6), 'host' = libannlite_graph.so; 'both' "
+                    "(default): the GPU-built graph is what is measured, the host-built one serves the host walks / the CPU baseline "
+                    "and the graph-quality comparison")
 a = p.parse_args()
 dev = torch.device('cuda', 0)
 torch.cuda.set_device(0)
@@ -49,15 +53,25 @@ codec = PQCodec(dim=D, n_subvectors=M, n_clusters=256, metric=Metric.EUCLIDEAN, 
 codec.seed = 7
 codec.deterministic = True
 codec.fit(gen(0, 250_000)[:20480], iter=20)
-index = HnswPQGpuIndex(dim=D, metric=Metric.EUCLIDEAN, pq_codec=codec, initial_size=N, rerank=True,
-                       ef_search=a.ef_search, ef_construction=a.ef_construction, max_connection=a.max_connection)
 CH = 250_000
-t0 = time.time()
-for c in range((N + CH - 1) // CH):
-    rows = min(CH, N - c * CH)
-    index.add_with_ids(gen(c, rows), torch.arange(c * CH, c * CH + rows, device=dev, dtype=torch.int64))
-torch.cuda.synchronize()
-build_s = time.time() - t0
+
+
+def build_index(where):
+    ix = HnswPQGpuIndex(dim=D, metric=Metric.EUCLIDEAN, pq_codec=codec, initial_size=N, rerank=True, ef_search=a.ef_search,
+                        ef_construction=a.ef_construction, max_connection=a.max_connection, build=where)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for c in range((N + CH - 1) // CH):
+        rows = min(CH, N - c * CH)
+        ix.add_with_ids(gen(c, rows), torch.arange(c * CH, c * CH + rows, device=dev, dtype=torch.int64))
+    torch.cuda.synchronize()
+    return ix, time.time() - t0
+
+
+index_gpu, gpu_build_s = build_index('gpu') if a.build in ('both', 'gpu') else (None, None)
+index_host, host_build_s = build_index('host') if a.build in ('both', 'host') else (None, None)
+index = index_gpu if index_gpu is not None else index_host  # what is measured
+build_s = gpu_build_s if index_gpu is not None else host_build_s
 
 gq = torch.Generator(device=dev)
 gq.manual_seed(4321)
@@ -97,21 +111,34 @@ res = {}
 for name, rerank, graph, walk in (('hnsw_gpu_walk_adc', False, True, 'gpu'), ('hnsw_gpu_walk_exact_rerank', True, True, 'gpu'),
                                   ('hnsw_host_walk_adc', False, True, 'host'), ('hnsw_host_walk_exact_rerank', True, True, 'host'),
                                   ('exhaustive_adc', False, False, None), ('exhaustive_exact_rerank', True, False, None)):
-    index.rerank = rerank
+    ix = index_host if walk == 'host' else index  # (host walks need the hierarchy: the host-built graph)
+    if ix is None:
+        continue
+    ix.rerank = rerank
     if walk:
-        index.walk = walk
-    fn = (lambda: index.search_batch(q, limit=k)) if graph else (lambda: index.search_exhaustive(q, limit=k))
+        ix.walk = walk
+    fn = (lambda: ix.search_batch(q, limit=k)) if graph else (lambda: ix.search_exhaustive(q, limit=k))
     (d, i), qps = timed(fn)
     res[name] = {'queries_per_s': qps, 'recall_at_10': recall(i)}
+if index_gpu is not None and index_host is not None:  # graph quality: the same GPU walk over the host-built graph
+    index_host.walk, index_host.rerank = 'gpu', True
+    (d, i), qps = timed(lambda: index_host.search_batch(q, limit=k))
+    res['hnsw_gpu_walk_exact_rerank_on_host_built_graph'] = {'queries_per_s': qps, 'recall_at_10': recall(i)}
+    index_host.rerank = False
+    (d, i), qps = timed(lambda: index_host.search_batch(q, limit=k))
+    res['hnsw_gpu_walk_adc_on_host_built_graph'] = {'queries_per_s': qps, 'recall_at_10': recall(i)}
 # the walks alone
 walks = {}
 for walk in ('gpu', 'host'):
-    index.walk = walk
-    index.candidates(q, a.ef_search)
+    ix = index_host if walk == 'host' else index
+    if ix is None:
+        continue
+    ix.walk = walk
+    ix.candidates(q, a.ef_search)
     torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(a.steps):
-        index.candidates(q, a.ef_search)
+        ix.candidates(q, a.ef_search)
     torch.cuda.synchronize()
     walks[walk] = B * a.steps / (time.perf_counter() - t)
 walk_qps = walks
@@ -209,10 +236,9 @@ roofline = {'bound': 'hbm', 'achieved': alg_bytes / (kernel_ms * 1e-3) / 1e9, 'p
             'expansions_per_query': n_expand / B, 'rows_evaluated_per_query': n_eval / B,
             'note': 'a pointer chase, latency-bound by design: one wave per query, one dependent record read per expansion'}
 
-# ---- CPU baseline: the same graph walked on the host by libannlite_graph.so (C++ restatement of hnswlib's searchKnn /
+# ---- CPU baseline: the host-built graph walked on the host by libannlite_graph.so (C++ restatement of hnswlib's searchKnn /
 # searchBaseLayerST with PQLookup distances), ONE thread = the reference's execution model (knn_query runs single-threaded
 # for AnnLite's one-query calls, hnsw_bindings.cpp:332-334), bounded sample; all cores beside it ------------------------
-index.walk = 'host'
 def usable_threads() -> int:
     """The threads the graph library actually starts (hnsw_host.cpp usable_threads): min(CPUs, affinity mask, cgroup CPU quota)."""
     n = os.cpu_count() or 1
@@ -229,20 +255,25 @@ def usable_threads() -> int:
     return max(1, n)
 
 
-nq1 = min(B, 256)
-threads_all = index.n_threads
-index.n_threads = 1
-index.candidates(q[:8], a.ef_search)
-t0 = time.perf_counter()
-index.candidates(q[:nq1], a.ef_search)
-cpu1 = nq1 / (time.perf_counter() - t0)
-index.n_threads = threads_all
-cpu_baseline = {'value': cpu1, 'unit': 'queries/s', 'cores': 1, 'kind': 'port',
-                'sample': f'{nq1} queries, graph walk ef_search={a.ef_search} over {N} rows on the host (candidate lists only)',
-                'all_cores': {'value': walks['host'], 'cores': usable_threads(), 'sample': f'{B} queries x {a.steps}'}}
+cpu_baseline = None
+if index_host is not None:
+    index_host.walk = 'host'
+    nq1 = min(B, 256)
+    threads_all = index_host.n_threads
+    index_host.n_threads = 1
+    index_host.candidates(q[:8], a.ef_search)
+    t0 = time.perf_counter()
+    index_host.candidates(q[:nq1], a.ef_search)
+    cpu1 = nq1 / (time.perf_counter() - t0)
+    index_host.n_threads = threads_all
+    cpu_baseline = {'value': cpu1, 'unit': 'queries/s', 'cores': 1, 'kind': 'port',
+                    'sample': f'{nq1} queries, graph walk ef_search={a.ef_search} over {N} rows on the host (candidate lists only), host-built graph',
+                    'all_cores': {'value': walks['host'], 'cores': usable_threads(), 'sample': f'{B} queries x {a.steps}'}}
 print(json.dumps({'config': f'HNSW-over-PQ: {N} x {D}-dim, PQ m={M} ks=256, L2, max_connection={a.max_connection}, '
                             f'ef_construction={a.ef_construction}, ef_search={a.ef_search}, batch {B}, k={k}',
                   'metric': 'queries/sec', 'value': res['hnsw_gpu_walk_exact_rerank']['queries_per_s'], 'unit': 'queries/s',
                   'recall_at_10': res['hnsw_gpu_walk_exact_rerank']['recall_at_10'],
-                  'build_s': build_s, 'build_rows_per_s': N / build_s, 'host_cpus_reported': os.cpu_count(), 'note': 'the graph library starts min(CPUs, affinity, cgroup quota) threads',
+                  'graph_built_on': 'gpu (level 0, batches: graph_build.hip)' if index_gpu is not None else 'host (libannlite_graph.so)',
+                  'build_s': build_s, 'build_rows_per_s': N / build_s, 'host_build_s': host_build_s, 'gpu_build_s': gpu_build_s,
+                  'host_cpus_reported': os.cpu_count(), 'note': 'the graph library starts min(CPUs, affinity, cgroup quota) threads',
                   'graph_walk_queries_per_s': walk_qps, 'roofline': roofline, 'cpu_baseline': cpu_baseline, **res}))

@@ -135,7 +135,8 @@ def test_index_uses_packed_records_and_rebuilds_them_after_inserts(ops, oracle):
     codec.seed = 3
     codec.fit(x[:8192], iter=8)
     hn = HnswPQGpuIndex(dim=D, metric=Metric.EUCLIDEAN, pq_codec=codec, initial_size=N, ef_search=100, rerank=False,
-                        expand_width=1)  # (one node per step: the walk that equals the plain walk; the pair walk: test_graph_pair.py)
+                        expand_width=1, build='host')  # (one node per step: the walk that equals the plain walk; the pair walk:
+    # test_graph_pair.py.  build='host': this test is about the records packed from the host library's exported lists)
     hn.add_with_ids(x[:20_000], np.arange(20_000))
     qd = hn._pre(q)
 

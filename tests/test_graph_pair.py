@@ -181,7 +181,7 @@ def test_pair_walk_on_a_real_graph_finds_what_the_one_at_a_time_walk_finds(ops, 
     codec = PQCodec(dim=D, n_subvectors=M, n_clusters=256, metric=Metric.EUCLIDEAN, n_init=1)
     codec.seed = 3
     codec.fit(x[:8192], iter=8)
-    hn = HnswPQGpuIndex(dim=D, metric=Metric.EUCLIDEAN, pq_codec=codec, initial_size=N, ef_search=128, rerank=False)
+    hn = HnswPQGpuIndex(dim=D, metric=Metric.EUCLIDEAN, pq_codec=codec, initial_size=N, ef_search=128, rerank=False, build='host')
     assert hn.expand_width == 2
     hn.add_with_ids(x, np.arange(N))
     qd = hn._pre(q)
