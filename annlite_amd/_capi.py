@@ -49,6 +49,7 @@ SYMBOLS = (
     'annlite_graph_pack',
     'annlite_graph_search_packed',
     'annlite_graph_search_packed_ex',
+    'annlite_rerank_topk',
     'annlite_graph_build_sdc',
     'annlite_graph_build_select',
     'annlite_graph_build_reverse',
@@ -138,6 +139,7 @@ def lib() -> ctypes.CDLL:
     L.annlite_graph_search_packed.argtypes = [vp, i32, vp, i64, vp, i64, i64, i64, vp, vp, i64, i32, vp, vp, vp]
     L.annlite_graph_search_packed_ex.argtypes = [vp, i32, vp, i64, vp, i64, i64, i64, vp, vp, i64, i32, i32, vp, vp, vp]
     L.annlite_graph_pack.argtypes = [vp, i32, vp, i64, i64, vp, vp]
+    L.annlite_rerank_topk.argtypes = [i32, vp, i64, i64, vp, i64, vp, i64, vp, i64, i32, vp, vp, vp]
     L.annlite_graph_build_sdc.argtypes = [vp, i64, i64, i64, vp, vp]
     L.annlite_graph_build_select.argtypes = [vp, i32, i64, i64, vp, i64, i64, vp, i32, vp, i32, vp, vp]
     L.annlite_graph_build_reverse.argtypes = [vp, vp, i64, vp, i64, i64, vp, vp, i32, vp]

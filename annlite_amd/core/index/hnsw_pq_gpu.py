@@ -239,6 +239,12 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
         else:
             ef = max(int(ef_search or self.ef_search), k)
             cand, _ = self.candidates(q, ef)
+            if self.rerank and self._vectors is not None and k <= 64:
+                # (round 6) exact distances of the candidates + validity screen + top-k + sqrt in ONE launch, one wave per query:
+                # the same numbers as the steps below, bit for bit (annlite_rerank_topk)
+                d, i = ops.rerank_topk(int(self.metric), q, self._vectors, cand, k, valid_bits=self._valid,
+                                       sqrt=self.metric == Metric.EUCLIDEAN)
+                return (d.cpu().numpy(), i.cpu().numpy()) if is_np else (d, i)
             # rows deleted after the walk started / never written are masked here as well
             ok = (cand >= 0) & self._valid_bool[cand.clamp(min=0)]
             cand = torch.where(ok, cand, torch.full_like(cand, -1))

@@ -203,9 +203,98 @@ __global__ __launch_bounds__(256) void exact_gather_kernel(int metric, const flo
     if (lane == 0) out[i] = (metric == ANNLITE_METRIC_EUCLIDEAN) ? s : 1.f - s;
 }
 
+// ---- exact re-rank FUSED with the top-k (round 6): one wave per query ------------------------------------------------------------
+// The candidate lists of a graph walk / of the scan's candidate mode are short (ef = 128 rows): a wave per (query, candidate)
+// (exact_gather_kernel) followed by torch's masking, annlite_topk_rows, a gather and a sqrt was eight launches of a few
+// microseconds each around 67 MB of reads -- a quarter of a config-5 batch.  Here the query's wave walks its own list: eight
+// candidates' rows in flight at a time, the SAME per-lane partial sums and butterfly as exact_gather_kernel (bit-equal distances),
+// rows screened by the validity bitmap, the k best kept in the wave-resident list under (distance, position in the list) --
+// annlite_topk_rows' order -- and written out as (distance | sqrt, candidate id).
+__global__ __launch_bounds__(256) void rerank_topk_kernel(int metric, const float *__restrict__ q, int B, int D,
+                                                         const float *__restrict__ x, int64_t N, const int64_t *__restrict__ cand, int R,
+                                                         const uint32_t *__restrict__ valid, int k, int do_sqrt,
+                                                         float *__restrict__ out_d, int64_t *__restrict__ out_i) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    constexpr int U = 8;
+    const float *qr = q + (int64_t)b * D;
+    const int64_t *cr = cand + (int64_t)b * R;
+    const int km1 = k - 1;
+    WaveList L;
+    L.reset();
+    uint32_t th = kKeyInfHi, tl = kIdNone;
+    for (int c0 = 0; c0 < R; c0 += 64) {
+        // this block's 64 candidates: lane l screens candidate c0 + l
+        const int ci = c0 + lane;
+        int64_t row = ci < R ? cr[ci] : -1;
+        if (row >= N) row = -1;
+        if (row >= 0 && valid && !((valid[row >> 5] >> (row & 31)) & 1u)) row = -1;
+        float mine = __builtin_inff();  // lane l ends up with candidate c0 + l's distance
+        const int n_here = R - c0 < 64 ? R - c0 : 64;
+        for (int u0 = 0; u0 < n_here; u0 += U) {
+            float s[U];
+            int64_t rw[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                rw[u] = __shfl(row, u0 + u);  // (wave-uniform)
+                s[u] = 0.f;
+            }
+            for (int j = lane; j < D; j += 64) {
+                const float qj = qr[j];
+                float xv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) xv[u] = rw[u] >= 0 ? x[rw[u] * D + j] : 0.f;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (metric == ANNLITE_METRIC_EUCLIDEAN) {
+                        const float d = xv[u] - qj;
+                        s[u] = __builtin_fmaf(d, d, s[u]);
+                    } else {
+                        s[u] = __builtin_fmaf(xv[u], qj, s[u]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s[u] += __shfl_xor(s[u], o);
+                const float dist = (metric == ANNLITE_METRIC_EUCLIDEAN) ? s[u] : 1.f - s[u];
+                if (lane == u0 + u) mine = dist;
+            }
+        }
+        if (row < 0) mine = __builtin_inff();
+        const float tf = (th == kKeyInfHi) ? __builtin_inff() : ordered_to_f32(th);
+        const unsigned long long pm = __ballot(ci < R && !(mine > tf));  // (NaN: behind +inf, numpy's order -- as annlite_topk_rows)
+        if (pm) wavelist_offer(L, pm, f32_to_key(mine), (uint32_t)ci, km1, th, tl, lane);
+    }
+    if (lane <= km1) {
+        const bool none = (L.hi == kKeyInfHi && L.lo == kIdNone);
+        float d = none ? __builtin_inff() : ordered_to_f32(L.hi);
+        int64_t id = (none || d == __builtin_inff()) ? (int64_t)-1 : cr[L.lo];
+        if (id >= N) id = -1;
+        if (do_sqrt) d = __builtin_sqrtf(d);
+        out_d[(int64_t)b * k + lane] = d;
+        out_i[(int64_t)b * k + lane] = id;
+    }
+}
+
 }  // namespace annlite
 
 using namespace annlite;
+
+extern "C" int annlite_rerank_topk(int metric, const float *queries_dev, int64_t B, int64_t D, const float *vectors_dev, int64_t N,
+                                   const int64_t *cand_dev, int64_t R, const uint32_t *valid_bits_dev, int64_t k, int flags,
+                                   float *out_dist_dev, int64_t *out_id_dev, void *stream) {
+    ANNLITE_REQUIRE(metric >= 1 && metric <= 3, "bad metric %d", metric);
+    ANNLITE_REQUIRE(B >= 0 && D >= 1 && N >= 0 && R >= 0 && k >= 1 && k <= 64, "bad shape (1 <= k <= 64)");
+    if (B == 0) return ANNLITE_OK;
+    ANNLITE_REQUIRE(queries_dev && out_dist_dev && out_id_dev && (R == 0 || cand_dev) && (N == 0 || vectors_dev), "null device pointer");
+    hipLaunchKernelGGL(rerank_topk_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, metric, queries_dev, (int)B,
+                       (int)D, vectors_dev, N, cand_dev, (int)R, valid_bits_dev, (int)k, (flags & ANNLITE_FLAG_SQRT) ? 1 : 0, out_dist_dev,
+                       out_id_dev);
+    return launch_status("rerank_topk_kernel");
+}
 
 extern "C" int annlite_pq_encode(const float *x_dev, int64_t N, int64_t D, const float *codebooks_dev, int64_t M,
                                  int64_t Ks, void *out_codes_dev, int code_bytes, void *stream) {

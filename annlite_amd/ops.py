@@ -546,3 +546,17 @@ def exact_gather_dist(metric: int, queries: torch.Tensor, vectors: torch.Tensor,
     check(lib().annlite_exact_gather_dist(int(metric), queries.data_ptr(), B, D, vectors.data_ptr(), N,
                                           cand.data_ptr(), R, out.data_ptr(), stream_ptr()), 'exact_gather_dist')
     return out
+
+
+def rerank_topk(metric: int, queries: torch.Tensor, vectors: torch.Tensor, cand: torch.Tensor, k: int,
+                valid_bits: Optional[torch.Tensor] = None, sqrt: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``annlite_rerank_topk``: exact distances of the candidate lists ``cand`` i64 [B, R] fused with the top-k (k <= 64):
+    ``(dist f32 [B, k], ids i64 [B, k])`` in (distance, list position) order, (+inf, -1) padded."""
+    B, D = queries.shape
+    R = cand.shape[1]
+    out_d = torch.empty((B, k), dtype=torch.float32, device=queries.device)
+    out_i = torch.empty((B, k), dtype=torch.int64, device=queries.device)
+    check(lib().annlite_rerank_topk(int(metric), queries.data_ptr(), B, D, vectors.data_ptr(), vectors.shape[0], cand.data_ptr(), R,
+                                    _ptr(valid_bits), int(k), 1 if sqrt else 0, out_d.data_ptr(), out_i.data_ptr(),
+                                    stream_ptr()), 'rerank_topk')
+    return out_d, out_i

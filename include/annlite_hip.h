@@ -424,6 +424,13 @@ ANNLITE_API int annlite_kmeans_update(const float *sums_dev, const int32_t *coun
 ANNLITE_API int annlite_exact_gather_dist(int metric, const float *queries_dev, int64_t B, int64_t D,
                               const float *vectors_dev, int64_t N, const int64_t *cand_dev, int64_t R,
                               float *out_dev, void *stream);
+/* The same distances FUSED with the top-k (round 6): out[b][0..k) = the k smallest exact distances among cand[b][0..R) in
+ * (distance, position in the list) order -- what annlite_exact_gather_dist + annlite_topk_rows + a gather of the ids give, bit for
+ * bit -- as (distance, cand id); candidates < 0, >= N or cleared in valid_bits_dev (may be NULL) are skipped, missing places hold
+ * (+inf, -1).  k <= 64.  flags: ANNLITE_FLAG_SQRT (EUCLIDEAN results, hnsw/index.py:164-165).  One wave per query. */
+ANNLITE_API int annlite_rerank_topk(int metric, const float *queries_dev, int64_t B, int64_t D, const float *vectors_dev, int64_t N,
+                        const int64_t *cand_dev, int64_t R, const uint32_t *valid_bits_dev, int64_t k, int flags,
+                        float *out_dist_dev, int64_t *out_id_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pruned (IVF) search over cells (follow-on of rank 4).
