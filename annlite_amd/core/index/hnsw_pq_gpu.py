@@ -4,14 +4,16 @@ Mirrors the reference's ``HnswIndex(pq_codec=...)`` (annlite/core/index/hnsw/ind
 differs from the exhaustive ``PQFlatGpuIndex``: a navigable graph proposes ``ef_search`` candidate rows per
 query instead of scanning every row.
 
-  * graph: ``libannlite_graph.so`` (``annlite_amd/csrc/hnsw_host.cpp``), host code like the reference's
-    hnswlib, same knobs -- ``max_connection`` (16), ``ef_construction`` (200), ``ef_search`` (50)
-    (hnsw/index.py:66-69) -- and the same form of edge distance, hnswlib::PQLookup over the stored code bytes
-    (include/hnswlib/space_pq.h:15-37), always with L2 tables (inner-product tables break the graph, see
-    hnsw_host.cpp);
+  * graph: the reference's knobs -- ``max_connection`` (16), ``ef_construction`` (200), ``ef_search`` (50) (hnsw/index.py:66-69) --
+    and the same form of edge distance, hnswlib::PQLookup over the stored code bytes (include/hnswlib/space_pq.h:15-37), always
+    with L2 tables (inner-product tables break the graph, see hnsw_host.cpp).  BUILT on the GPU in batches (round 6,
+    ``graph_gpu_build.GpuLevel0Graph``: level 0 only, the packed pair walk as the insertion search) where the GPU walk applies,
+    else -- or with ``build='host'`` -- by ``libannlite_graph.so`` (``annlite_amd/csrc/hnsw_host.cpp``: host code like the
+    reference's hnswlib, the full hierarchy); WALKED on the GPU (``graph.hip``: packed node records, two nodes per step) or, for a
+    host-built graph, by the library (``walk='host'``);
   * the candidates' distances and the final top-k come from the GPU: ``annlite_adc_gather`` (the a2 sum of
     SURVEY.md section 8a, bit-equal to the flat scan's distances) + ``annlite_topk_rows``, or, with
-    ``rerank=True``, the exact distances on the stored float vectors (``annlite_exact_gather_dist``).
+    ``rerank=True``, the exact distances on the stored float vectors fused with the top-k (``annlite_rerank_topk``).
 
 Everything else (storage, encode, validity bitmap, dump/load of the code table, metric pre/post
 processing) is inherited from ``PQFlatGpuIndex``; ``search_exhaustive`` keeps the full scan available.

@@ -235,6 +235,8 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
             tail = torch.where(dup, torch.full_like(tail, -1), tail)
             ids = torch.cat([ids, torch.full_like(ids_x, -1)], dim=1)
             ids[sel] = torch.cat([ids_x[sel], tail], dim=1)
+        if k_out <= 64:  # (round 6) exact distances + top-k + ids + sqrt in one launch (annlite_rerank_topk): the same numbers as below
+            return ops.rerank_topk(int(self.metric), q, self._vectors, ids.contiguous(), k_out, sqrt=self.metric == Metric.EUCLIDEAN)
         exact = ops.exact_gather_dist(int(self.metric), q, self._vectors, ids)
         d, pos = self._topk_rows_any(exact, min(k_out, ids.shape[1]))  # (k_out > 64: a stable device sort, never cut silently)
         i = torch.gather(ids, 1, pos.clamp(min=0))

@@ -71,7 +71,7 @@ def parse():
                    help='database / query distribution (SURVEY.md section 8d): lowrank = rank-16 (rank-64 above 128-d) latent Gaussian '
                         '+ noise; uniform = U[0,1)^D, the reference\'s own test distribution (tests/test_pq_bind.py:19)')
     p.add_argument('--legs', default='auto',
-                   help='comma list of extra legs (rank 0, N=1, never `value`): rerank, ivf, facade, uniform, c2, c4, c5, m32, k50; "none"; "auto" = all '
+                   help='comma list of extra legs (rank 0, N=1, never `value`): rerank, graph, ivf, facade, uniform, c2, c4, c5, m32, k50; "none"; "auto" = all '
                         'of them for the default workload, rerank + ivf otherwise')
     p.add_argument('--metric', choices=['euclidean', 'cosine', 'inner_product'], default='euclidean',
                    help="BASELINE config 2/3: euclidean; config 4 (10M x 768, m=64, batch 256): cosine")
@@ -170,7 +170,7 @@ def main():
     N_, D_, M_, Ks_, B_, k_ = args.rows, args.dim, args.m, args.ks, args.batch, args.k
     default_workload = (N_, D_, M_, Ks_, B_, k_, args.metric, args.data) == (10_000_000, 128, 16, 256, 1024, 10, 'euclidean', 'lowrank')
     legs = args.legs.split(',') if args.legs not in ('auto', 'none') else (
-        [] if args.legs == 'none' else ['rerank', 'ivf'] + (['facade', 'uniform', 'c2', 'c4', 'c5', 'm32', 'k50'] if default_workload else []))
+        [] if args.legs == 'none' else ['rerank', 'ivf'] + (['graph', 'facade', 'uniform', 'c2', 'c4', 'c5', 'm32', 'k50'] if default_workload else []))
     if args.no_rerank and 'rerank' in legs:
         legs.remove('rerank')
     if args.ivf_cells <= 1 and 'ivf' in legs:
@@ -564,6 +564,43 @@ def main():
                 index.rerank_k = args.rerank_k or None
             index.rerank = False
 
+    # ---- extra leg, never `value`: HNSW-over-PQ over the SAME rows (config 5's index at the headline's size): the level-0 graph built
+    # on the GPU in batches (round 6), walked by the pair walk (ef_search 128), candidates re-ranked exactly -- the north-star's
+    # recall target (>= 0.90 recall@10) answered by the graph index instead of the exhaustive scan's candidate pool -----------------
+    graph_rec = None
+    if world == 1 and 'graph' in legs and nq > 0 and M in (8, 16, 32) and Ks <= 256 and args.metric != 'inner_product':
+        try:
+            from annlite_amd import HnswPQGpuIndex
+
+            gidx = HnswPQGpuIndex(dim=D, metric=metric, pq_codec=codec, initial_size=max(N, 64), rerank=True, ef_search=128,
+                                  ef_construction=200, max_connection=16, build='gpu')
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for c in range((N + CH - 1) // CH):
+                rows = min(CH, N - c * CH)
+                gidx.add_with_ids(gen_chunk(c, rows, D, A, dev), torch.arange(c * CH, c * CH + rows, device=dev, dtype=torch.int64))
+            torch.cuda.synchronize()
+            g_build_s = time.time() - t0  # (vector generation, encode, storage and the graph)
+            for j in range(2):
+                gr = gidx.search_batch(q_sets[j % NB], limit=k)
+            torch.cuda.synchronize()
+            n_g = max(8, args.steps // 2)
+            t0 = time.perf_counter()
+            for j in range(n_g):
+                gr = gidx.search_batch(q_sets[j % NB], limit=k)
+            torch.cuda.synchronize()
+            g_el = time.perf_counter() - t0
+            gr = gidx.search_batch(queries, limit=k)
+            got = gr[1][:nq].cpu().numpy()
+            graph_rec = {'index': 'HnswPQGpuIndex(build="gpu", ef_search=128, max_connection=16, ef_construction=200, rerank=True)',
+                         'value': B * n_g / g_el, 'unit': 'queries/s', 'ms_per_step': g_el / n_g * 1e3,
+                         'recall_at_10': float(np.mean([len(set(got[b]) & set(truth[b])) / k for b in range(nq)])),
+                         'build_s': g_build_s, 'rows': N, 'answers': 'north_star recall target (>= 0.90 recall@10)'}
+            del gidx
+            torch.cuda.empty_cache()
+        except Exception as ex:  # noqa: BLE001  (a leg never takes the line down)
+            graph_rec = {'error': repr(ex)[:300]}
+
     # ---- extra leg, never `value`: the pruned (IVF) search over the same rows (SURVEY.md 8f follow-on) --------
     ivf_rec = None
     if world == 1 and 'ivf' in legs and M in (8, 16, 32, 64) and nq > 0:
@@ -829,6 +866,7 @@ def main():
                                                        'candidates_per_query': 'n_slices * rerank_k per shard (rerank_k = %d: the byte-table kernel\'s 16-key lists)' % (args.rerank_k or 16),
                                                        'answers': 'north_star recall target (>= 0.90 recall@10)',
                                                        'global_pool': rr_global},
+            'graph': graph_rec,
             'roofline': roof,
             'cpu_baseline': cpu,
             'ivf': ivf_rec,
@@ -871,6 +909,8 @@ def main():
         summ['main']['n'] = world
         if rec.get('rerank'):
             summ['rerank'] = {'qps': _r(rec['rerank']['value'], 0), 'recall': _r(rec['rerank']['recall_at_10'], 3)}
+        if graph_rec and 'error' not in graph_rec:
+            summ['graph'] = {'qps': _r(graph_rec['value'], 0), 'recall': _r(graph_rec['recall_at_10'], 3), 'build_s': _r(graph_rec['build_s'], 1)}
         if ivf_rec:
             summ['ivf'] = {'qps': _r(ivf_rec['value'], 0), 'agree': _r(ivf_rec['agreement_with_exhaustive_adc_top10'], 3)}
         if facade:

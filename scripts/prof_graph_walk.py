@@ -74,7 +74,8 @@ if a.build:
     with open(a.build + '.codec', 'wb') as f:
         pickle.dump(codec, f)
     index.dump(a.build)
-    print('dumped', {q: os.path.getsize(q) for q in (a.build, a.build + '.graph', a.build + '.codec') if os.path.exists(q)}, flush=True)
+    print('dumped', {q: os.path.getsize(q) for q in (a.build, a.build + '.graph', a.build + '.level0.npy', a.build + '.codec') if os.path.exists(q)},
+          'graph built on', index.build, flush=True)
     sys.exit(0)
 
 with open(a.walk + '.codec', 'rb') as f:
@@ -96,7 +97,8 @@ packed = index._packed_records(links, plain) if a.layout == 'packed' else None
 
 def walk():
     if packed is not None:
-        return ops.graph_search_packed(packed, lpn, seeds, plain, lut, a.ef_search, valid_bits=index._valid, n_rows=index._n_rows)
+        return ops.graph_search_packed(packed, lpn, seeds, plain, lut, a.ef_search, valid_bits=index._valid, n_rows=index._n_rows,
+                                       expand_width=index.expand_width if lpn <= 32 else 1)
     return ops.graph_search(links, seeds, plain, lut, a.ef_search, valid_bits=index._valid, n_rows=index._n_rows)
 
 
@@ -117,6 +119,7 @@ for _ in range(a.iters):
 lpn = links.shape[1] - 1
 alg = n_expand * 4.0 * (lpn + 1) + n_eval * float(M) + B * seeds.numel() * float(M)
 print(f'graph walk: {index._n_rows} rows, batch {B}, ef_search {a.ef_search}: kernel ms {np.round(kms, 3).tolist()}; '
-      f'expansions/query {n_expand / B:.1f}, rows evaluated/query {n_eval / B:.1f}, algorithmic bytes/launch {alg:.4g}; layout {a.layout}'
+      f'expansions/query {n_expand / B:.1f}, rows evaluated/query {n_eval / B:.1f}, algorithmic bytes/launch {alg:.4g}; layout {a.layout}, '
+      f'graph built on {index.build}, expand_width {index.expand_width if (packed is not None and lpn <= 32) else 1}, seeds {seeds.numel()}'
       + (f', record {packed.shape[1]} B, bytes read by design {n_expand * float(packed.shape[1]) + B * seeds.numel() * float(M):.4g}, '
          f'prefetched records used {n_hit / max(n_expand, 1):.3f}' if packed is not None else ''), flush=True)

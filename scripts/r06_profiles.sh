@@ -45,6 +45,30 @@ for f in sorted(glob.glob('gpurun_out/r06p/bench_shard_*.json')):
     except Exception as e: print(f, 'ERR', e)
 PY
   ;;
+graph)
+  # config 5's walk alone (GPU-built graph, pair walk over packed records; the plain one-at-a-time walk beside it): HBM traffic passes
+  timeout 600 python scripts/prof_graph_walk.py --build /tmp/g5m --rows 5000000 > $OUT/graph_build.log 2>&1
+  for lay in packed plain; do
+    rocprofv3 --kernel-trace --kernel-include-regex graph_beam --pmc FETCH_SIZE GRBM_GUI_ACTIVE -f csv -d $ROOT/$OUT/graph_${lay}_c -- python scripts/prof_graph_walk.py --walk /tmp/g5m --rows 5000000 --layout $lay > $OUT/graph_walk_5m_${lay}_c.log 2>&1
+    rocprofv3 --kernel-trace --kernel-include-regex graph_beam --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -f csv -d $ROOT/$OUT/graph_${lay}_d -- python scripts/prof_graph_walk.py --walk /tmp/g5m --rows 5000000 --layout $lay > $OUT/graph_walk_5m_${lay}_d.log 2>&1
+  done
+  python - <<PY > $OUT/graph_walk_5m_pmc_summary.txt
+import csv,glob,collections
+print('command: scripts/r06_profiles.sh graph (graph built + dumped by an un-profiled process; rocprofv3 --kernel-trace --kernel-include-regex graph_beam --pmc ... -- python scripts/prof_graph_walk.py --walk /tmp/g5m --rows 5000000 --layout L; two passes per layout)')
+print(open('$OUT/graph_build.log').read().strip()[-400:])
+for lay in ('packed', 'plain'):
+    acc=collections.defaultdict(list)
+    for t in 'cd':
+        print('%s pass %s: %s' % (lay, t, [l.strip() for l in open('$OUT/graph_walk_5m_%s_%s.log' % (lay, t)) if l.startswith('graph walk')][-1:]))
+        for f in glob.glob('$OUT/graph_%s_%s/**/*counter_collection.csv' % (lay, t), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if 'graph_beam' in r['Kernel_Name']: acc[r['Counter_Name']].append(float(r['Counter_Value']))
+    m={c: sum(v)/len(v) for c,v in acc.items()}
+    print('  %s: per-dispatch means over %d dispatches: %s' % (lay, len(acc.get('FETCH_SIZE', [])), {c: round(v, 1) for c, v in m.items()}))
+    if 'FETCH_SIZE' in m and 'WRITE_SIZE' in m:
+        print('  %s: HBM bytes per launch = FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 = %.4g; L2 hit rate %.1f %%' % (lay, m['FETCH_SIZE']*2048 + m['WRITE_SIZE']*1024, 100*m.get('TCC_HIT_sum',0)/max(1.0, m.get('TCC_HIT_sum',0)+m.get('TCC_MISS_sum',0))))
+PY
+  cat $OUT/graph_walk_5m_pmc_summary.txt;;
 small)
   bash scripts/gpu_profile_lut.sh > $OUT/lut_mfma_summary.txt 2>&1
   rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -f csv -d $ROOT/$OUT/enc_a -- python scripts/bench_encode.py > $OUT/encode.jsonl 2>$OUT/enc_a.log

@@ -209,3 +209,23 @@ def test_seed_rows_are_spread_over_the_table():
                     assert max(inside) >= ext - 2 * step - 64 * len(rows), (ext, S, c)  # (the run step is rounded down to blocks)
                 if S >= ext:
                     assert rows == list(range(0, ((ext + 63) >> 6) << 6, 64))
+
+
+def test_graph_index_build_side_is_resolved_without_a_gpu():
+    """HnswPQGpuIndex(build=None): the GPU builds the level-0 graph where the GPU walk applies (max_connection <= 16, M in {8, 16, 32},
+    uint8 codes, walk='gpu'); everything else keeps the host library -- decided at construction, no device touched."""
+    from annlite_amd import HnswPQGpuIndex, Metric, PQCodec
+
+    def mk(m=8, ks=256, dim=64, **kw):
+        return HnswPQGpuIndex(dim=dim, metric=Metric.EUCLIDEAN, pq_codec=PQCodec(dim=dim, n_subvectors=m, n_clusters=ks), **kw)
+
+    assert mk().build == 'gpu' and mk().expand_width == 2
+    assert mk(walk='host').build == 'host'
+    assert mk(max_connection=32).build == 'host'
+    assert mk(m=64, dim=128).build == 'host'
+    assert mk(ks=512).build == 'host'
+    assert mk(build='host').build == 'host' and mk(m=16, build='gpu').build == 'gpu'
+    with pytest.raises(AssertionError):
+        mk(build='cpu')
+    with pytest.raises(AssertionError):
+        mk(expand_width=3)
