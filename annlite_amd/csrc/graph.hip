@@ -667,7 +667,12 @@ static int graph_search_impl(const uint32_t *links_dev, const uint8_t *packed_de
     hipStream_t st = (hipStream_t)stream;
     // 4096 entries up to ef = 128 (a walk records 2-3k nodes: 5M rows, ef 128 gave the same recall as 8192 entries at
     // 1.5x the speed -- 5 instead of 3 waves per CU), 8192 beyond; a full table only costs re-evaluations (see visit)
-    int hash_bits = ef <= 128 ? 12 : 13;
+    // round 6: 4096 entries up to ef = 208 as well -- with 8192 entries beside a list of more than 128 entries only three waves fit a CU
+    // and a 1024-query batch runs in two rounds (10M rows, ef 144 / 160 / 192: 0.594 / 0.658 / 0.755 ms per batch with 8192 entries and
+    // four registers per lane, 0.387 / 0.437 / 0.544 with 4096, 0.360 / 0.405 / 0.510 with three registers per lane on top -- the table
+    // fills towards the end of such a walk and the merge tests for duplicates from then on; same lists, same recall:
+    // profiles/r06/graph_10m_ef_sweep.txt)
+    int hash_bits = ef <= 208 ? 12 : 13;  // (ef 200, the reference's ef_construction: 0.785 -> 0.568 ms per 1024 walks at 10M rows)
     if (knobs().graph_hash_bits >= 0) hash_bits = knobs().graph_hash_bits;  // (ANNLITE_GRAPH_HASH_BITS: tests force a tiny table)
     if (hash_bits < 4) hash_bits = 4;    // (buckets of four entries, 16-byte initialisation)
     if (hash_bits > 15) hash_bits = 15;  // (128 KB: what is left of the LDS beside the smallest table)
@@ -682,8 +687,10 @@ static int graph_search_impl(const uint32_t *links_dev, const uint8_t *packed_de
                           hash_bits, out_ids_dev, out_dist_dev, stats, st
 #define ANNLITE_BEAM(MM, PK, BT) \
     (ef <= 64 ? launch_beam<MM, 1, PK, BT>(ANNLITE_BEAM_ARGS) : ef <= 128 ? launch_beam<MM, 2, PK, BT>(ANNLITE_BEAM_ARGS) : launch_beam<MM, 4, PK, BT>(ANNLITE_BEAM_ARGS))
+    // (pair walk: a list of three registers per lane for 128 < ef <= 192 -- every list operation is per register)
 #define ANNLITE_BEAM2(MM) \
-    (ef <= 64 ? launch_beam<MM, 1, true, true, 2>(ANNLITE_BEAM_ARGS) : ef <= 128 ? launch_beam<MM, 2, true, true, 2>(ANNLITE_BEAM_ARGS) : launch_beam<MM, 4, true, true, 2>(ANNLITE_BEAM_ARGS))
+    (ef <= 64 ? launch_beam<MM, 1, true, true, 2>(ANNLITE_BEAM_ARGS) : ef <= 128 ? launch_beam<MM, 2, true, true, 2>(ANNLITE_BEAM_ARGS) : \
+     ef <= 192 ? launch_beam<MM, 3, true, true, 2>(ANNLITE_BEAM_ARGS) : launch_beam<MM, 4, true, true, 2>(ANNLITE_BEAM_ARGS))
     if (packed_dev && width == 2) {
         if (M == 8) return ANNLITE_BEAM2(8);
         if (M == 16) return ANNLITE_BEAM2(16);

@@ -19,6 +19,7 @@ p.add_argument('--rows', type=int, default=5_000_000)
 p.add_argument('--seeds', default='32,64,128,256,1024')
 p.add_argument('--build-seeds', type=int, default=0, help='MAX_SEEDS while building (0: the class default)')
 p.add_argument('--batch', type=int, default=0, help='GpuLevel0Graph.BATCH (0: the class default)')
+p.add_argument('--ef', default='128', help='comma list of ef_search values (each with the default visited table and, beyond 128, with 4096 entries)')
 a = p.parse_args()
 dev = torch.device('cuda', 0)
 torch.cuda.set_device(0)
@@ -91,25 +92,37 @@ for c in range((N + CH - 1) // CH):
     o = torch.argsort(md, dim=1)[:, :k]
     best_d, best_i = torch.gather(md, 1, o), torch.gather(mi, 1, o)
 truth = best_i.cpu().numpy()
+from annlite_amd import _capi  # noqa: E402
+
 for S in [int(v) for v in a.seeds.split(',')]:
     index._gg.MAX_SEEDS = S
     index._gg._seeds = None
-    qd = index._pre(q)
-    for _ in range(2):
-        index.candidates(qd, 128)
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(10):
-        index.candidates(qd, 128)
-    torch.cuda.synchronize()
-    walk_ms = (time.perf_counter() - t) / 10 * 1e3
-    d, i = index.search_batch(q, limit=k)
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(10):
-        d, i = index.search_batch(q, limit=k)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t) / 10 * 1e3
-    ids = i.cpu().numpy()
-    rec = float(np.mean([len(set(ids[b]) & set(truth[b])) / k for b in range(B)]))
-    print('seeds %4d: candidates() %.4f ms, search_batch %.4f ms = %.0f q/s, recall@10 %.4f' % (S, walk_ms, ms, B / ms * 1e3, rec), flush=True)
+    for ef in [int(v) for v in a.ef.split(',')]:
+        for hb in ([None] if ef <= 128 else [None, 12]):
+            if hb is None:
+                os.environ.pop('ANNLITE_GRAPH_HASH_BITS', None)
+            else:
+                os.environ['ANNLITE_GRAPH_HASH_BITS'] = str(hb)
+            _capi.knobs_reload()
+            index.ef_search = ef
+            qd = index._pre(q)
+            for _ in range(2):
+                index.candidates(qd, ef)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(10):
+                index.candidates(qd, ef)
+            torch.cuda.synchronize()
+            walk_ms = (time.perf_counter() - t) / 10 * 1e3
+            d, i = index.search_batch(q, limit=k)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(10):
+                d, i = index.search_batch(q, limit=k)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t) / 10 * 1e3
+            ids = i.cpu().numpy()
+            rec = float(np.mean([len(set(ids[b]) & set(truth[b])) / k for b in range(B)]))
+            print('seeds %4d ef %3d visited table %s: candidates() %.4f ms, search_batch %.4f ms = %.0f q/s, recall@10 %.4f' % (
+                S, ef, 'default' if hb is None else '2^%d' % hb, walk_ms, ms, B / ms * 1e3, rec), flush=True)
+os.environ.pop('ANNLITE_GRAPH_HASH_BITS', None)

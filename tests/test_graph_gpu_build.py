@@ -280,3 +280,40 @@ def test_gpu_build_tiny_and_one_at_a_time(ops):
     # a point's nearest stored row is itself or a row with the same code (distance ties go to the smaller id)
     same = [np.array_equal(codes[i[b, 0]], codes[b]) for b in range(n)]
     assert np.mean(same) > 0.97
+
+
+@pytest.mark.parametrize('case', ['cluster_order', 'duplicates'])
+def test_gpu_build_on_awkward_insertion_orders(ops, case):
+    """Rows inserted in CLUSTER order (sorted along one latent direction: every batch lands next to the previous one, far from most
+    of the graph -- and from most seeds) and a table where half of the rows are exact duplicates (symmetric distance 0 between
+    candidates): the GPU-built graph answers like the host-built one."""
+    from annlite_amd import HnswPQGpuIndex, Metric, PQCodec, PQFlatGpuIndex
+
+    rs = np.random.RandomState(21)
+    N, D, M, B, k = 120_000, 64, 16, 128, 10
+    A = rs.randn(8, D).astype(np.float32)
+    z = rs.randn(N, 8).astype(np.float32)
+    if case == 'cluster_order':
+        z = z[np.argsort(z[:, 0])]
+    x = (z @ A + 0.05 * rs.randn(N, D).astype(np.float32)).astype(np.float32)
+    if case == 'duplicates':
+        x[N // 2:] = x[rs.randint(0, N // 2, N - N // 2)]
+    q = (rs.randn(B, 8).astype(np.float32) @ A + 0.05 * rs.randn(B, D).astype(np.float32)).astype(np.float32)
+    codec = PQCodec(dim=D, n_subvectors=M, n_clusters=256, metric=Metric.EUCLIDEAN, n_init=1)
+    codec.seed = 3
+    codec.fit(x[rs.choice(N, 8192, replace=False)], iter=8)
+    flat = PQFlatGpuIndex(dim=D, metric=Metric.EUCLIDEAN, pq_codec=codec, initial_size=N)
+    flat.add_with_ids(x, np.arange(N))
+    fd, fi = flat.search_batch(q, limit=k)
+    got = {}
+    for where in ('gpu', 'host'):
+        hn = HnswPQGpuIndex(dim=D, metric=Metric.EUCLIDEAN, pq_codec=codec, initial_size=N, ef_search=128, rerank=False, build=where)
+        for c0 in range(0, N, 30_000):
+            hn.add_with_ids(x[c0:c0 + 30_000], np.arange(c0, min(N, c0 + 30_000)))
+        hd, hi = hn.search_batch(q, limit=k)
+        # ids may differ where distances tie (duplicates): compare the DISTANCES found with the exhaustive scan's
+        got[where] = float(np.mean(np.isclose(hd, fd, rtol=0, atol=0) | (hd <= fd)))
+        if where == 'gpu':
+            lk = hn._gg.links[:N].cpu().numpy().view(np.uint32)
+            assert lk[:, 0].max() <= 32 and lk[:, 0].min() >= 1
+    assert got['gpu'] >= 0.9 and got['gpu'] >= got['host'] - 0.03, got

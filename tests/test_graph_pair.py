@@ -40,7 +40,7 @@ def _random_graph(rs, N, L, full_frac=0.6):
 def walk_restated(oracle, links, seeds, codes, lut, ef, width, valid=None):
     """One query.  ``links`` u32 [N, L+1] (count, ids), ``lut`` f32 [M, Ks].  Returns (ids i64 [ef], dist f32 [ef])."""
     N = codes.shape[0]
-    E = 1 if ef <= 64 else 2 if ef <= 128 else 4
+    E = 1 if ef <= 64 else 2 if ef <= 128 else 3 if (ef <= 192 and width == 2) else 4  # registers per lane of the kernel's list
     slots, cap = 64 * E, min(ef, 64 * E)
     lst = []  # sorted [(distance bits as ordered key, node, expanded)]: the kernels' list of 64 E entries, `cap` of them live
     seen = set()
@@ -89,7 +89,7 @@ def walk_restated(oracle, links, seeds, codes, lut, ef, width, valid=None):
 
 
 @pytest.mark.parametrize('M,L,ef', [(16, 32, 128), (16, 32, 64), (16, 32, 200), (8, 32, 100), (32, 24, 128), (16, 5, 10), (16, 32, 33),
-                                    (16, 17, 70)])
+                                    (16, 17, 70), (16, 32, 160), (8, 32, 192), (16, 32, 129)])
 def test_pair_walk_equals_its_restatement(ops, oracle, M, L, ef):
     import torch
 
