@@ -240,7 +240,22 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
             i = torch.full((B, k), -1, dtype=torch.int64, device=q.device)
         else:
             ef = max(int(ef_search or self.ef_search), k)
-            cand, _ = self.candidates(q, ef)
+            cand, cand_d = self.candidates(q, ef)
+            if not (self.rerank and self._vectors is not None) and self.metric == Metric.EUCLIDEAN and self._gpu_walk_ok() and ef <= 256 \
+                    and k <= 64:
+                # (round 6) EUCLIDEAN, ADC ranking: the walk's own distances ARE the metric's PQLookup sums (the graph is walked with
+                # L2 tables: same table, same ascending-m fp32 chain as annlite_adc_gather, bit for bit) and its list is ascending
+                # with the deleted rows blanked (-1, +inf) -- the result is the list's first k real entries: no table build, no
+                # gather.  (cosine / inner product: the metric's tables differ from the walk's -- the gather below.)
+                kk = min(k, ef)
+                d, pos = ops.topk_rows(cand_d, kk)
+                i = torch.gather(cand, 1, pos.clamp(min=0))
+                i = torch.where((pos < 0) | torch.isinf(d), torch.full_like(i, -1), i)
+                d = torch.sqrt(d)  # hnsw/index.py:164-165
+                if kk < k:
+                    d = torch.cat([d, torch.full((B, k - kk), float('inf'), device=d.device)], dim=1)
+                    i = torch.cat([i, torch.full((B, k - kk), -1, dtype=torch.int64, device=i.device)], dim=1)
+                return (d.cpu().numpy(), i.cpu().numpy()) if is_np else (d, i)
             if self.rerank and self._vectors is not None and k <= 64:
                 # (round 6) exact distances of the candidates + validity screen + top-k + sqrt in ONE launch, one wave per query:
                 # the same numbers as the steps below, bit for bit (annlite_rerank_topk)
