@@ -72,3 +72,22 @@ def test_single_gpu_line_ends_with_the_summary(single):
     s = single['summary']
     assert list(single.keys())[-1] == 'summary' and len(json.dumps(s)) <= 1536
     assert s['main']['n'] == 1 and s['main']['sha'] == single['result_sha256'][:8] and s['main']['qps'] > 0
+
+
+def test_bench_graph_leg(tmp_path):
+    """The `graph` leg (round 6): HNSW-over-PQ over the bench's own rows -- level 0 built on the GPU, pair walk, fused exact re-rank --
+    next to the exhaustive scan's line: present, timed, recall measured against the same brute-force truth, and in the summary."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    args = ['--rows', '300000', '--steps', '6', '--warmup', '2', '--prewarm-steps', '4', '--recall-queries', '64', '--cpu-queries', '0',
+            '--legs', 'graph']
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'] + args, capture_output=True, text=True, env=env,
+                       timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    rec = _line(r.stdout)
+    g = rec['graph']
+    assert g and 'error' not in g, g
+    assert g['rows'] == 300000 and g['value'] > 0 and g['build_s'] > 0
+    assert g['recall_at_10'] >= 0.9 and g['ef_search_160']['recall_at_10'] >= g['recall_at_10'] - 0.01  # (300k rows: the 128 best by PQ distance hold the neighbours)
+    assert g['recall_at_10'] > rec['recall_at_10']  # (the plain ADC top-10 of the main line)
+    s = rec['summary']
+    assert list(rec.keys())[-1] == 'summary' and s['graph']['qps'] > 0 and len(json.dumps(s)) <= 1536
