@@ -94,6 +94,17 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
             self._gg = GpuLevel0Graph(self.pq_codec.codebooks_dev, self.max_connection, self.ef_construction)
         return self._gg
 
+    def _rebuild_gpu_graph(self):
+        N = self._n_rows
+        gg = self._ensure_gpu_graph()
+        codes = self._plain_codes(N).contiguous()
+        gg.reserve(int(self.capacity))
+        for c0 in range(0, N, 1 << 18):
+            c1 = min(N, c0 + (1 << 18))
+            x = self._vectors[c0:c1] if self._vectors is not None else ops.pq_decode(codes[c0:c1], self.pq_codec.codebooks_dev)
+            _, xg = self.pq_codec.scan_inputs(x.contiguous())
+            gg.add(xg, codes[c0:c1])
+
     def __del__(self):
         try:
             if getattr(self, '_graph', None) is not None:
@@ -298,9 +309,12 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
     def dump(self, index_file: Union[str, Path]):
         super().dump(index_file)
         if getattr(self, 'build', 'host') == 'gpu':
+            Path(str(index_file) + '.graph').unlink(missing_ok=True)  # (one graph file per dump: the other build's would be stale)
             if self._gg is not None:
-                np.save(str(index_file) + '.level0.npy', np.array([self._gg.state()], dtype=object), allow_pickle=True)
+                with open(str(index_file) + '.level0.npy', 'wb') as f:
+                    np.save(f, np.array([self._gg.state()], dtype=object), allow_pickle=True)
             return
+        Path(str(index_file) + '.level0.npy').unlink(missing_ok=True)
         if self._graph is not None:
             gc.check(gc.lib().annlite_hnsw_save(self._graph, (str(index_file) + '.graph').encode()), 'annlite_hnsw_save')
 
@@ -308,14 +322,24 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
         super().load(index_file)
         self._mutations = getattr(self, '_mutations', 0) + 1
         self._structure = getattr(self, '_structure', 0) + 1
+        lpath, gpath = str(index_file) + '.level0.npy', str(index_file) + '.graph'
         if getattr(self, 'build', 'host') == 'gpu':
-            lpath = str(index_file) + '.level0.npy'
             self._gg = None
             if Path(lpath).exists():
                 st = np.load(lpath, allow_pickle=True)[0]
-                self._ensure_gpu_graph().load_state(st, self._plain_codes(self._n_rows).contiguous())
-            return
-        gpath = str(index_file) + '.graph'
+                if int(st['n']) == self._n_rows:  # (a file left behind by an older dump of another table is not this table's graph)
+                    self._ensure_gpu_graph().load_state(st, self._plain_codes(self._n_rows).contiguous())
+                    return
+            if not Path(gpath).exists():
+                # a dump without a graph file (written by the flat index, or the graph file was lost): the level-0 graph is
+                # rebuilt from what IS stored -- the float vectors where the index keeps them, else the decoded code rows
+                # (the walk's tables are then built from reconstructions: the distances between stored rows are the same)
+                if self._n_rows:
+                    self._rebuild_gpu_graph()
+                return
+            self.build = 'host'  # the file of a host-built graph (a snapshot of an earlier build): keep serving it as it is
+        if getattr(self, 'build', 'host') == 'host' and not Path(gpath).exists() and Path(lpath).exists():
+            raise RuntimeError(f'{index_file}: the snapshot holds a GPU-built level-0 graph; open it with build="gpu" (or build=None)')
         if Path(gpath).exists():
             if self._graph is not None:
                 gc.lib().annlite_hnsw_free(self._graph)

@@ -317,3 +317,46 @@ def test_gpu_build_on_awkward_insertion_orders(ops, case):
             lk = hn._gg.links[:N].cpu().numpy().view(np.uint32)
             assert lk[:, 0].max() <= 32 and lk[:, 0].min() >= 1
     assert got['gpu'] >= 0.9 and got['gpu'] >= got['host'] - 0.03, got
+
+
+def test_snapshots_across_the_two_builds(ops, tmp_path):
+    """A snapshot of a host-built graph opened by an index whose default is the GPU build keeps being served (build switches to
+    'host'); a dump without any graph file is rebuilt from the stored rows; a GPU-built snapshot opened with build='host' is
+    refused with a message -- never an index that silently answers nothing."""
+    from annlite_amd import HnswPQGpuIndex, Metric, PQCodec
+
+    rs = np.random.RandomState(8)
+    N, D, M, B, k = 20_000, 64, 16, 32, 10
+    gen = _data(rs, N, D)
+    x, q = gen(N), gen(B)
+    codec = PQCodec(dim=D, n_subvectors=M, n_clusters=256, metric=Metric.EUCLIDEAN, n_init=1)
+    codec.seed = 2
+    codec.fit(x[:8192], iter=6)
+
+    def mk(**kw):
+        return HnswPQGpuIndex(dim=D, metric=Metric.EUCLIDEAN, pq_codec=codec, initial_size=N, ef_search=96, rerank=False, **kw)
+
+    host = mk(build='host')
+    host.add_with_ids(x, np.arange(N))
+    _, want = host.search_batch(q, limit=k)
+    host.dump(tmp_path / 'h.idx')
+    a = mk()
+    assert a.build == 'gpu'
+    a.load(tmp_path / 'h.idx')
+    assert a.build == 'host'
+    assert np.array_equal(a.search_batch(q, limit=k)[1], want)
+    # no graph file at all: rebuilt (from the decoded rows here: no float vectors kept)
+    (tmp_path / 'h.idx.graph').unlink()
+    b = mk()
+    b.load(tmp_path / 'h.idx')
+    assert b.build == 'gpu' and b._gg.n == N
+    got = b.search_batch(q, limit=k)[1]
+    assert np.mean([len(set(got[i]) & set(want[i])) / k for i in range(B)]) >= 0.9
+    b.dump(tmp_path / 'g.idx')
+    assert (tmp_path / 'g.idx.level0.npy').exists() and not (tmp_path / 'g.idx.graph').exists()
+    c = mk(build='host')
+    with pytest.raises(RuntimeError, match='GPU-built'):
+        c.load(tmp_path / 'g.idx')
+    d = mk()
+    d.load(tmp_path / 'g.idx')
+    assert np.array_equal(d.search_batch(q, limit=k)[1], got)
