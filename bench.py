@@ -191,7 +191,7 @@ def main():
                                  '--steps', '20', '--warmup', '5', '--cpu-queries', '16', '--cpu-repeats', '3',
                                  '--recall-queries', '32'] + common, 400)
         if 'c5' in legs:  # config 5: HNSW-over-PQ, 5M x 128, ef_search 128, GPU walk + exact re-rank
-            sub['c5'] = sub_run([os.path.join(ROOT, 'scripts', 'bench_hnsw.py'), '--rows', '5000000', '--steps', '5'], 600)
+            sub['c5'] = sub_run([os.path.join(ROOT, 'scripts', 'bench_hnsw.py'), '--rows', '5000000', '--steps', '20'], 600)
         if 'm32' in legs:  # the default workload at m = 32 (the reference's own table-test shape): byte tables of one entry group
             sub['m32'] = sub_run([me, '--m', '32', '--steps', '20', '--warmup', '5', '--cpu-queries', '16', '--cpu-repeats', '3',
                                   '--recall-queries', '32'] + common, 300)
@@ -581,13 +581,16 @@ def main():
                 gidx.add_with_ids(gen_chunk(c, rows, D, A, dev), torch.arange(c * CH, c * CH + rows, device=dev, dtype=torch.int64))
             torch.cuda.synchronize()
             g_build_s = time.time() - t0  # (vector generation, encode, storage and the graph)
-            for j in range(2):
-                gr = gidx.search_batch(q_sets[j % NB], limit=k)
+            g_streams = [torch.cuda.Stream(device=dev) for _ in range(2)]  # (consecutive batches on two caller streams, as the other legs)
+            for j in range(4):  # (warm-up on the timed streams: the allocator keeps a pool per stream)
+                with torch.cuda.stream(g_streams[j % 2]):
+                    gr = gidx.search_batch(q_sets[j % NB], limit=k)
             torch.cuda.synchronize()
             n_g = max(8, args.steps // 2)
             t0 = time.perf_counter()
             for j in range(n_g):
-                gr = gidx.search_batch(q_sets[j % NB], limit=k)
+                with torch.cuda.stream(g_streams[j % 2]):
+                    gr = gidx.search_batch(q_sets[j % NB], limit=k)
             torch.cuda.synchronize()
             g_el = time.perf_counter() - t0
             gr = gidx.search_batch(queries, limit=k)
@@ -595,16 +598,18 @@ def main():
             graph_rec = {'index': 'HnswPQGpuIndex(build="gpu", ef_search=128, max_connection=16, ef_construction=200, rerank=True)',
                          'value': B * n_g / g_el, 'unit': 'queries/s', 'ms_per_step': g_el / n_g * 1e3,
                          'recall_at_10': float(np.mean([len(set(got[b]) & set(truth[b])) / k for b in range(nq)])),
-                         'build_s': g_build_s, 'rows': N, 'answers': 'north_star recall target (>= 0.90 recall@10)'}
+                         'build_s': g_build_s, 'rows': N, 'streams': 2, 'answers': 'north_star recall target (>= 0.90 recall@10)'}
             # ... and with a longer candidate list (config 5 fixes ef_search = 128 at 5M rows; at 10M rows the 128 best by PQ distance
             # hold fewer of the true neighbours): lists beyond 128 entries take four registers per lane
             gidx.ef_search = 160
-            for j in range(2):
-                gr = gidx.search_batch(q_sets[j % NB], limit=k)
+            for j in range(4):
+                with torch.cuda.stream(g_streams[j % 2]):
+                    gr = gidx.search_batch(q_sets[j % NB], limit=k)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for j in range(n_g):
-                gr = gidx.search_batch(q_sets[j % NB], limit=k)
+                with torch.cuda.stream(g_streams[j % 2]):
+                    gr = gidx.search_batch(q_sets[j % NB], limit=k)
             torch.cuda.synchronize()
             g_el2 = time.perf_counter() - t0
             got = gidx.search_batch(queries, limit=k)[1][:nq].cpu().numpy()
@@ -893,9 +898,9 @@ def main():
             if 'error' in r:
                 rec[name] = r
             elif name == 'c5':
-                rec[name] = {kk: r[kk] for kk in ('config', 'value', 'unit', 'recall_at_10', 'graph_built_on', 'build_s', 'gpu_build_s',
+                rec[name] = {kk: r[kk] for kk in ('config', 'value', 'unit', 'streams', 'ms_per_step', 'recall_at_10', 'graph_built_on', 'build_s', 'gpu_build_s',
                                                  'host_build_s', 'graph_walk_queries_per_s', 'roofline', 'cpu_baseline',
-                                                 'hnsw_gpu_walk_adc', 'hnsw_gpu_walk_exact_rerank_on_host_built_graph',
+                                                 'hnsw_gpu_walk_adc', 'hnsw_gpu_walk_exact_rerank', 'hnsw_gpu_walk_exact_rerank_on_host_built_graph',
                                                  'exhaustive_exact_rerank') if kk in r}
             else:
                 rec[name] = {'config': r['config']['workload'], 'streams': r['config'].get('streams'), 'value': r['value'], 'unit': r['unit'],

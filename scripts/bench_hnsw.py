@@ -27,6 +27,9 @@ p.add_argument('--ef-search', type=int, default=128)
 p.add_argument('--ef-construction', type=int, default=200)
 p.add_argument('--max-connection', type=int, default=16)
 p.add_argument('--steps', type=int, default=5)
+p.add_argument('--streams', type=int, default=2,
+               help='caller streams the timed GPU-walk batches alternate between (2: as the other legs of bench.py -- a walk launch lasts as '
+                    'long as its slowest query, the next batch fills the SIMDs the others have left; 1: one batch at a time)')
 p.add_argument('--build', choices=['both', 'gpu', 'host'], default='both',
                help="where the graph is built: 'gpu' = level 0 in batches on the GPU (round 6), 'host' = libannlite_graph.so; 'both' "
                     "(default): the GPU-built graph is what is measured, the host-built one serves the host walks / the CPU baseline "
@@ -97,14 +100,33 @@ def recall(ids):
     return float(np.mean([len(set(ids[b]) & set(truth[b])) / k for b in range(B)]))
 
 
-def timed(fn):
-    fn()
+gq2 = torch.Generator(device=dev)
+gq2.manual_seed(4321 + 7919)
+q_alt = (torch.randn((B, r_lat), generator=gq2, device=dev) @ A + 0.05 * torch.randn((B, D), generator=gq2, device=dev)).contiguous()
+q_rot = [q, q_alt]  # the timed steps rotate through two query batches (recall is the first batch's)
+side = [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams))]
+
+
+def timed(fn, streams=1):
+    """fn(batch) -> result; `streams` > 1: consecutive batches on alternating caller streams."""
+    for j in range(4):  # (warm-up ON the streams that are timed: torch's allocator keeps a pool per stream, the first allocations of a
+        with torch.cuda.stream(side[j % streams] if streams > 1 else torch.cuda.current_stream()):  # stream are hipMalloc calls)
+            fn(q_rot[j % 2])
     torch.cuda.synchronize()
+    n = max(a.steps, 2)
     t = time.perf_counter()
-    for _ in range(a.steps):
-        out = fn()
+    if streams > 1:
+        for j in range(n):
+            with torch.cuda.stream(side[j % streams]):
+                fn(q_rot[j % 2])
+    else:
+        for j in range(n):
+            fn(q_rot[j % 2])
     torch.cuda.synchronize()
-    return out, B * a.steps / (time.perf_counter() - t)
+    el = time.perf_counter() - t
+    out = fn(q)
+    torch.cuda.synchronize()
+    return out, B * n / el
 
 
 res = {}
@@ -117,16 +139,19 @@ for name, rerank, graph, walk in (('hnsw_gpu_walk_adc', False, True, 'gpu'), ('h
     ix.rerank = rerank
     if walk:
         ix.walk = walk
-    fn = (lambda: ix.search_batch(q, limit=k)) if graph else (lambda: ix.search_exhaustive(q, limit=k))
-    (d, i), qps = timed(fn)
-    res[name] = {'queries_per_s': qps, 'recall_at_10': recall(i)}
+    fn = (lambda qq: ix.search_batch(qq, limit=k)) if graph else (lambda qq: ix.search_exhaustive(qq, limit=k))
+    ns = a.streams if (graph and walk == 'gpu') else 1
+    (d, i), qps = timed(fn, ns)
+    res[name] = {'queries_per_s': qps, 'recall_at_10': recall(i), 'streams': ns}
+    if graph and walk == 'gpu' and ns > 1:  # ... and one batch at a time, for the record
+        res[name]['one_stream_queries_per_s'] = timed(fn, 1)[1]
 if index_gpu is not None and index_host is not None:  # graph quality: the same GPU walk over the host-built graph
     index_host.walk, index_host.rerank = 'gpu', True
-    (d, i), qps = timed(lambda: index_host.search_batch(q, limit=k))
-    res['hnsw_gpu_walk_exact_rerank_on_host_built_graph'] = {'queries_per_s': qps, 'recall_at_10': recall(i)}
+    (d, i), qps = timed(lambda qq: index_host.search_batch(qq, limit=k), a.streams)
+    res['hnsw_gpu_walk_exact_rerank_on_host_built_graph'] = {'queries_per_s': qps, 'recall_at_10': recall(i), 'streams': a.streams}
     index_host.rerank = False
-    (d, i), qps = timed(lambda: index_host.search_batch(q, limit=k))
-    res['hnsw_gpu_walk_adc_on_host_built_graph'] = {'queries_per_s': qps, 'recall_at_10': recall(i)}
+    (d, i), qps = timed(lambda qq: index_host.search_batch(qq, limit=k), a.streams)
+    res['hnsw_gpu_walk_adc_on_host_built_graph'] = {'queries_per_s': qps, 'recall_at_10': recall(i), 'streams': a.streams}
 # the walks alone
 walks = {}
 for walk in ('gpu', 'host'):
@@ -272,6 +297,8 @@ if index_host is not None:
 print(json.dumps({'config': f'HNSW-over-PQ: {N} x {D}-dim, PQ m={M} ks=256, L2, max_connection={a.max_connection}, '
                             f'ef_construction={a.ef_construction}, ef_search={a.ef_search}, batch {B}, k={k}',
                   'metric': 'queries/sec', 'value': res['hnsw_gpu_walk_exact_rerank']['queries_per_s'], 'unit': 'queries/s',
+                  'streams': res['hnsw_gpu_walk_exact_rerank']['streams'], 'query_batches': 2,
+                  'ms_per_step': B / res['hnsw_gpu_walk_exact_rerank']['queries_per_s'] * 1e3,
                   'recall_at_10': res['hnsw_gpu_walk_exact_rerank']['recall_at_10'],
                   'graph_built_on': 'gpu (level 0, batches: graph_build.hip)' if index_gpu is not None else 'host (libannlite_graph.so)',
                   'build_s': build_s, 'build_rows_per_s': N / build_s, 'host_build_s': host_build_s, 'gpu_build_s': gpu_build_s,
