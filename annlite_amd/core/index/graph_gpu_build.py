@@ -33,7 +33,7 @@ class GpuLevel0Graph:
 
     def __init__(self, codebooks_dev: torch.Tensor, max_connection: int = 16, ef_construction: int = 200):
         M, Ks, dsub = codebooks_dev.shape
-        assert M in (8, 16, 32) and Ks <= 256, 'the GPU graph build supports M in {8, 16, 32} and uint8 codes'
+        assert M in (8, 16, 32, 64) and Ks <= 256, 'the GPU graph build supports M in {8, 16, 32, 64} and uint8 codes'
         assert 2 <= max_connection <= 16, 'the GPU graph build holds 2 * max_connection <= 32 links per node'
         self.cb = codebooks_dev.contiguous()
         self.M, self.Ks, self.dsub = M, Ks, dsub

@@ -55,10 +55,10 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
         # (the searches of an insertion are the packed pair walk itself: 5M rows in 3.5 s against 60 s on 16 host cores, same
         # recall); GPU walks only; ids must be dense in insertion order (0, 1, 2, ...: what AnnLite's offsets are,
         # storage/table.py:251-257).  'host' = libannlite_graph.so: the full hierarchy (host walks, the reference's structure).
-        # None: 'gpu' where it applies -- walk='gpu', max_connection <= 16, M in {8, 16, 32}, uint8 codes -- else 'host'.
+        # None: 'gpu' where it applies -- walk='gpu', max_connection <= 16, M in {8, 16, 32, 64}, uint8 codes -- else 'host'.
         assert build in (None, 'host', 'gpu')
         if build is None:
-            build = 'gpu' if (walk == 'gpu' and 2 <= self.max_connection <= 16 and self.M in (8, 16, 32) and self.Ks <= 256) else 'host'
+            build = 'gpu' if (walk == 'gpu' and 2 <= self.max_connection <= 16 and self.M in (8, 16, 32, 64) and self.Ks <= 256) else 'host'
         self.build = build
         self._gg = None         # GpuLevel0Graph
         self._packed = None
@@ -199,7 +199,7 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
         self._packed, self._packed_key = None, None
 
     def _gpu_walk_ok(self) -> bool:
-        return self.walk == 'gpu' and self.M in (8, 16, 32) and self.Ks <= 256
+        return self.walk == 'gpu' and self.M in (8, 16, 32, 64) and self.Ks <= 256
 
     def candidates(self, q_dev: torch.Tensor, ef: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """Graph walk: ``(ids i64 [B, ef], L2 pq distance f32 [B, ef])`` on the device, -1 / +inf padded, ascending.
@@ -224,7 +224,7 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
                                                expand_width=self.expand_width if lpn <= 32 else 1)
             return ops.graph_search(links, seeds, plain, lut, ef, valid_bits=self._valid, n_rows=self._n_rows)
         if self.build == 'gpu':
-            raise RuntimeError("build='gpu' keeps level 0 only: walk='gpu' with M in {8, 16, 32}, Ks <= 256, ef <= 256")
+            raise RuntimeError("build='gpu' keeps level 0 only: walk='gpu' with M in {8, 16, 32, 64}, Ks <= 256, ef <= 256")
         x_np = np.ascontiguousarray(xg.cpu().numpy(), dtype=np.float32)
         B = x_np.shape[0]
         ids = np.empty((B, ef), dtype=np.int64)

@@ -659,7 +659,7 @@ static int graph_search_impl(const uint32_t *links_dev, const uint8_t *packed_de
                     (long long)N, ef);
     ANNLITE_REQUIRE(width == 1 || (width == 2 && packed_dev && links_per_node <= 32),
                     "expansion width %d: 1, or 2 over packed records of at most 32 neighbours (links_per_node = %d)", width, links_per_node);
-    ANNLITE_REQUIRE(Ks >= 1 && Ks <= 256 && (M == 8 || M == 16 || M == 32), "graph search supports M in {8,16,32}, Ks <= 256");
+    ANNLITE_REQUIRE(Ks >= 1 && Ks <= 256 && (M == 8 || M == 16 || M == 32 || M == 64), "graph search supports M in {8,16,32,64}, Ks <= 256");
     ANNLITE_REQUIRE(links_per_node >= 1 && n_seeds >= 1 && N < (1ll << 32) - 1, "bad graph");
     ANNLITE_REQUIRE(!packed_dev || links_per_node <= 64, "packed records hold at most 64 neighbours (links_per_node = %d)", links_per_node);
     if (B == 0) return ANNLITE_OK;
@@ -694,24 +694,28 @@ static int graph_search_impl(const uint32_t *links_dev, const uint8_t *packed_de
     if (packed_dev && width == 2) {
         if (M == 8) return ANNLITE_BEAM2(8);
         if (M == 16) return ANNLITE_BEAM2(16);
-        return ANNLITE_BEAM2(32);
+        if (M == 32) return ANNLITE_BEAM2(32);
+        return ANNLITE_BEAM2(64);  // (round 6: 64 KB of table per wave -- one wave per CU: a 256-query batch fills the chip)
     }
 #undef ANNLITE_BEAM2
     if (packed_dev) {
         if (M == 8) return ANNLITE_BEAM(8, true, true);
         if (M == 16) return ANNLITE_BEAM(16, true, true);
-        return ANNLITE_BEAM(32, true, true);
+        if (M == 32) return ANNLITE_BEAM(32, true, true);
+        return ANNLITE_BEAM(64, true, true);
     }
     // ANNLITE_GRAPH_SEQ_INSERT=1 (plain layout): the one-at-a-time list insertion of rounds 2-4 -- the parity tests walk with
     // both and compare
     if (knobs().graph_seq_insert) {
         if (M == 8) return ANNLITE_BEAM(8, false, false);
         if (M == 16) return ANNLITE_BEAM(16, false, false);
-        return ANNLITE_BEAM(32, false, false);
+        if (M == 32) return ANNLITE_BEAM(32, false, false);
+        return ANNLITE_BEAM(64, false, false);
     }
     if (M == 8) return ANNLITE_BEAM(8, false, true);
     if (M == 16) return ANNLITE_BEAM(16, false, true);
-    return ANNLITE_BEAM(32, false, true);
+    if (M == 32) return ANNLITE_BEAM(32, false, true);
+    return ANNLITE_BEAM(64, false, true);
 #undef ANNLITE_BEAM
 #undef ANNLITE_BEAM_ARGS
 }
@@ -738,16 +742,16 @@ extern "C" int annlite_graph_search(const uint32_t *links_dev, int links_per_nod
 }
 
 extern "C" int annlite_graph_record_bytes(int links_per_node, int64_t M, int64_t *bytes) {
-    ANNLITE_REQUIRE(bytes != nullptr && links_per_node >= 1 && links_per_node <= 64 && (M == 8 || M == 16 || M == 32),
-                    "packed records: links_per_node in [1, 64], M in {8,16,32}");
+    ANNLITE_REQUIRE(bytes != nullptr && links_per_node >= 1 && links_per_node <= 64 && (M == 8 || M == 16 || M == 32 || M == 64),
+                    "packed records: links_per_node in [1, 64], M in {8,16,32,64}");
     *bytes = graph_record_stride(links_per_node, M);
     return ANNLITE_OK;
 }
 
 extern "C" int annlite_graph_pack(const uint32_t *links_dev, int links_per_node, const void *codes_dev, int64_t N, int64_t M,
                                   void *packed_dev, void *stream) {
-    ANNLITE_REQUIRE(N >= 0 && links_per_node >= 1 && links_per_node <= 64 && (M == 8 || M == 16 || M == 32),
-                    "packed records: links_per_node in [1, 64], M in {8,16,32}");
+    ANNLITE_REQUIRE(N >= 0 && links_per_node >= 1 && links_per_node <= 64 && (M == 8 || M == 16 || M == 32 || M == 64),
+                    "packed records: links_per_node in [1, 64], M in {8,16,32,64}");
     if (N == 0) return ANNLITE_OK;
     ANNLITE_REQUIRE(links_dev && codes_dev && packed_dev, "null device pointer");
     const int64_t total = N * links_per_node;

@@ -85,14 +85,14 @@ __device__ __forceinline__ void heuristic_select(const float *__restrict__ sdc, 
 // ---- 2. the new points' own lists ---------------------------------------------------------------------------------------------
 // cand i64 [b][ef]: the walk's list for point i (ascending search distance, -1 = none); the point is node base0 + i.
 // links u32 [.][lpn + 1]: row base0 + i <- (count, ids); pairs i64 [b][m_keep] <- (target << 32) | source, INT64_MAX = none.
-template <int M>
-__global__ __launch_bounds__(256) void graph_select_kernel(const int64_t *__restrict__ cand, int ef, int64_t b, int64_t base0,
+template <int M, int WPB>
+__global__ __launch_bounds__(WPB * 64) void graph_select_kernel(const int64_t *__restrict__ cand, int ef, int64_t b, int64_t base0,
                                                           const uint8_t *__restrict__ codes, const float *__restrict__ sdc, int Ks,
                                                           int m_keep, uint32_t *__restrict__ links, int lpn, int64_t *__restrict__ pairs) {
     constexpr int CW = M / 4;
-    __shared__ uint32_t s_all[4][kPoolMax * (2 + CW)];
+    __shared__ uint32_t s_all[WPB][kPoolMax * (2 + CW)];  // (M = 64: 18 KB per wave -- two waves per workgroup stay under 64 KB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t i = (int64_t)blockIdx.x * WPB + wave;
     if (i >= b) return;
     uint32_t *s_id = s_all[wave], *s_code = s_id + kPoolMax;
     float *s_tb = (float *)(s_code + kPoolMax * CW);
@@ -260,19 +260,19 @@ extern "C" int annlite_graph_build_select(const int64_t *cand_dev, int ef, int64
                                           int64_t *pairs_dev, void *stream) {
     ANNLITE_REQUIRE(b >= 0 && base0 >= 0 && ef >= 1 && ef <= kPoolMax, "bad b=%lld base0=%lld ef=%d (ef <= 256)", (long long)b,
                     (long long)base0, ef);
-    ANNLITE_REQUIRE((M == 8 || M == 16 || M == 32) && Ks >= 1 && Ks <= 256, "graph build supports M in {8,16,32}, Ks <= 256");
+    ANNLITE_REQUIRE((M == 8 || M == 16 || M == 32 || M == 64) && Ks >= 1 && Ks <= 256, "graph build supports M in {8,16,32,64}, Ks <= 256");
     ANNLITE_REQUIRE(max_keep >= 1 && max_keep <= links_per_node && links_per_node <= 64, "bad max_keep=%d links_per_node=%d", max_keep,
                     links_per_node);
     if (b == 0) return ANNLITE_OK;
     ANNLITE_REQUIRE(cand_dev && codes_dev && sdc_dev && links_dev && pairs_dev, "null device pointer");
-    const dim3 grid((unsigned)((b + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define ANNLITE_SEL(MM) \
-    hipLaunchKernelGGL(graph_select_kernel<MM>, grid, block, 0, st, cand_dev, ef, b, base0, (const uint8_t *)codes_dev, sdc_dev, (int)Ks, \
-                       max_keep, links_dev, links_per_node, pairs_dev)
-    if (M == 8) ANNLITE_SEL(8);
-    else if (M == 16) ANNLITE_SEL(16);
-    else ANNLITE_SEL(32);
+#define ANNLITE_SEL(MM, WPB) \
+    hipLaunchKernelGGL((graph_select_kernel<MM, WPB>), dim3((unsigned)((b + WPB - 1) / WPB)), dim3(WPB * 64), 0, st, cand_dev, ef, b, base0, \
+                       (const uint8_t *)codes_dev, sdc_dev, (int)Ks, max_keep, links_dev, links_per_node, pairs_dev)
+    if (M == 8) ANNLITE_SEL(8, 4);
+    else if (M == 16) ANNLITE_SEL(16, 4);
+    else if (M == 32) ANNLITE_SEL(32, 4);
+    else ANNLITE_SEL(64, 2);
 #undef ANNLITE_SEL
     return launch_status("graph_select_kernel");
 }
@@ -281,7 +281,7 @@ extern "C" int annlite_graph_build_reverse(const int64_t *keys_dev, const int64_
                                            int64_t M, int64_t Ks, const float *sdc_dev, uint32_t *links_dev, int links_per_node,
                                            void *stream) {
     ANNLITE_REQUIRE(n_segments >= 0, "bad n_segments");
-    ANNLITE_REQUIRE((M == 8 || M == 16 || M == 32) && Ks >= 1 && Ks <= 256, "graph build supports M in {8,16,32}, Ks <= 256");
+    ANNLITE_REQUIRE((M == 8 || M == 16 || M == 32 || M == 64) && Ks >= 1 && Ks <= 256, "graph build supports M in {8,16,32,64}, Ks <= 256");
     ANNLITE_REQUIRE(links_per_node >= 1 && links_per_node <= 32, "reverse links: links_per_node in [1, 32] (%d)", links_per_node);
     if (n_segments == 0) return ANNLITE_OK;
     ANNLITE_REQUIRE(keys_dev && seg_dev && codes_dev && sdc_dev && links_dev, "null device pointer");
@@ -292,15 +292,16 @@ extern "C" int annlite_graph_build_reverse(const int64_t *keys_dev, const int64_
                        (int)Ks, links_dev, links_per_node)
     if (M == 8) ANNLITE_REV(8);
     else if (M == 16) ANNLITE_REV(16);
-    else ANNLITE_REV(32);
+    else if (M == 32) ANNLITE_REV(32);
+    else ANNLITE_REV(64);
 #undef ANNLITE_REV
     return launch_status("graph_reverse_kernel");
 }
 
 extern "C" int annlite_graph_pack_nodes(const uint32_t *links_dev, int links_per_node, const void *codes_dev, int64_t N, int64_t M,
                                         const int64_t *nodes_dev, int64_t n_nodes, void *packed_dev, void *stream) {
-    ANNLITE_REQUIRE(N >= 0 && n_nodes >= 0 && links_per_node >= 1 && links_per_node <= 64 && (M == 8 || M == 16 || M == 32),
-                    "packed records: links_per_node in [1, 64], M in {8,16,32}");
+    ANNLITE_REQUIRE(N >= 0 && n_nodes >= 0 && links_per_node >= 1 && links_per_node <= 64 && (M == 8 || M == 16 || M == 32 || M == 64),
+                    "packed records: links_per_node in [1, 64], M in {8,16,32,64}");
     if (N == 0 || n_nodes == 0) return ANNLITE_OK;
     ANNLITE_REQUIRE(links_dev && codes_dev && nodes_dev && packed_dev, "null device pointer");
     int64_t stride = 0;

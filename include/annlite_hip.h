@@ -151,7 +151,7 @@ ANNLITE_API int annlite_adc_gather(const float *lut_bmk_dev, int64_t B, int64_t 
  * (space_pq.h:15-37) bit for bit.  The graph comes from libannlite_graph.so (annlite_hnsw_export).
  * links_dev u32 [N][links_per_node + 1] (count, ids) ; seeds_dev u32 [n_seeds] DISTINCT nodes (top of the
  * hierarchy, scanned flat -- REQUIRED distinct, as annlite_hnsw_export produces them: the seed scan inserts without a duplicate
- * test, a node listed twice would enter the beam twice and come back twice) ; codes_dev u8 [N][M] PLAIN ; lut_bmk_dev f32 [B][M][Ks] L2 tables ; ef <= 256 ; M in {8, 16, 32}
+ * test, a node listed twice would enter the beam twice and come back twice) ; codes_dev u8 [N][M] PLAIN ; lut_bmk_dev f32 [B][M][Ks] L2 tables ; ef <= 256 ; M in {8, 16, 32, 64} (64, round 6: 64 KB of table per wave, one wave per CU)
  * out_ids_dev i64 [B][ef] ascending by distance (-1 padded, deleted rows per valid_bits dropped),
  * out_dist_dev f32 [B][ef] (+inf padded). */
 ANNLITE_API int annlite_graph_search(const uint32_t *links_dev, int links_per_node, const uint32_t *seeds_dev,

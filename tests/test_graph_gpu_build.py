@@ -54,7 +54,7 @@ def _select(sdc, codes, base, pool, m_max):
     return keep
 
 
-@pytest.mark.parametrize('M,ef,keep', [(16, 200, 16), (8, 64, 16), (32, 256, 12), (16, 10, 16), (16, 40, 4)])
+@pytest.mark.parametrize('M,ef,keep', [(16, 200, 16), (8, 64, 16), (32, 256, 12), (16, 10, 16), (16, 40, 4), (64, 200, 16)])
 def test_select_kernel_is_algorithm_4(ops, M, ef, keep):
     import torch
 
@@ -360,3 +360,47 @@ def test_snapshots_across_the_two_builds(ops, tmp_path):
     d = mk()
     d.load(tmp_path / 'g.idx')
     assert np.array_equal(d.search_batch(q, limit=k)[1], got)
+
+
+def test_gpu_graph_for_64_sub_spaces(ops, oracle):
+    """M = 64 (config 4's code width: 768-d text embeddings, cosine): 64 KB of table per wave -- one wave per CU --, graph built and walked
+    on the GPU like the narrower codes; against the exhaustive scan of the same index and the oracle's PQLookup."""
+    import torch
+
+    from annlite_amd import HnswPQGpuIndex, Metric, PQCodec, PQFlatGpuIndex
+
+    rs = np.random.RandomState(64)
+    N, D, M, B, k = 30_000, 256, 64, 48, 10
+    gen = _data(rs, N, D, r=24)
+    x, q = gen(N), gen(B)
+    codec = PQCodec(dim=D, n_subvectors=M, n_clusters=256, metric=Metric.COSINE, n_init=1)
+    codec.seed = 6
+    codec.fit(x[:8192], iter=6)
+    flat = PQFlatGpuIndex(dim=D, metric=Metric.COSINE, pq_codec=codec, initial_size=N)
+    flat.add_with_ids(x, np.arange(N))
+    fd, fi = flat.search_batch(q, limit=k)
+    hn = HnswPQGpuIndex(dim=D, metric=Metric.COSINE, pq_codec=codec, initial_size=N, ef_search=128, rerank=False)
+    assert hn.build == 'gpu' and hn._gpu_walk_ok()
+    hn.add_with_ids(x[:10_000], np.arange(10_000))
+    hn.add_with_ids(x[10_000:], np.arange(10_000, N))
+    hd, hi = hn.search_batch(q, limit=k)
+    assert np.mean([len(set(hi[b]) & set(fi[b])) / k for b in range(B)]) >= 0.9
+    for b in range(B):  # the ids both return carry the same (cosine) distance bits
+        pos = {int(i): j for j, i in enumerate(fi[b])}
+        for j, i in enumerate(hi[b]):
+            if int(i) in pos:
+                assert hd[b][j] == fd[b][pos[int(i)]]
+    # pair walk == one at a time up to the last places; exact sums under the walk's L2 tables
+    qd = hn._pre(torch.from_numpy(q).cuda())
+    two = hn.candidates(qd, 128)
+    hn.expand_width = 1
+    one = hn.candidates(qd, 128)
+    i1, i2 = one[0].cpu().numpy(), two[0].cpu().numpy()
+    assert np.mean([len(np.intersect1d(i1[b], i2[b])) / 128 for b in range(B)]) >= 0.97
+    from annlite_amd._capi import LAYOUT_BMK, LUT_L2
+    lut = ops.lut_build(codec.scan_inputs(qd)[1], codec.codebooks_dev, LUT_L2, LAYOUT_BMK).cpu().numpy()
+    codes = hn._gg.codes[:N].cpu().numpy()
+    dd = two[1].cpu().numpy()
+    for b in range(0, B, 11):
+        ok = i2[b] >= 0
+        assert np.array_equal(dd[b][ok], oracle.adc_gather_c(lut[b], codes, i2[b][ok]))

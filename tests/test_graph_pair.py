@@ -89,7 +89,7 @@ def walk_restated(oracle, links, seeds, codes, lut, ef, width, valid=None):
 
 
 @pytest.mark.parametrize('M,L,ef', [(16, 32, 128), (16, 32, 64), (16, 32, 200), (8, 32, 100), (32, 24, 128), (16, 5, 10), (16, 32, 33),
-                                    (16, 17, 70), (16, 32, 160), (8, 32, 192), (16, 32, 129)])
+                                    (16, 17, 70), (16, 32, 160), (8, 32, 192), (16, 32, 129), (64, 32, 128), (64, 20, 50)])
 def test_pair_walk_equals_its_restatement(ops, oracle, M, L, ef):
     import torch
 
