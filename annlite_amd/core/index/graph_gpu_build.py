@@ -29,6 +29,7 @@ from ..._capi import LAYOUT_BMK, LUT_L2
 class GpuLevel0Graph:
     BRUTE = 8192       # below this many nodes: exact candidate lists
     BATCH = 16384      # points per walk batch
+    GROW = 4           # ... and at most 1 / GROW of the graph (while it is small)
     MAX_SEEDS = 128    # seeds the walk scans flat (5M rows: 32 ... 1024 seeds give the same recall, 1024 cost 16 rounds of 64 per query)
 
     def __init__(self, codebooks_dev: torch.Tensor, max_connection: int = 16, ef_construction: int = 200):
@@ -87,7 +88,7 @@ class GpuLevel0Graph:
                 b = min(n_new - pos, self.BRUTE - n)
                 cand = self._exact_candidates(x[pos: pos + b], n, b)
             else:
-                b = min(n_new - pos, self.BATCH, max(1024, n // 4))
+                b = min(n_new - pos, self.BATCH, max(1024, n // self.GROW))
                 lut = ops.lut_build(x[pos: pos + b].contiguous(), self.cb, LUT_L2, LAYOUT_BMK)
                 cand, _ = ops.graph_search_packed(self.packed, self.lpn, self.seeds(), self.codes, lut, self.efc, n_rows=n,
                                                   expand_width=2)

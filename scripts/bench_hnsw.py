@@ -30,6 +30,8 @@ p.add_argument('--steps', type=int, default=5)
 p.add_argument('--streams', type=int, default=2,
                help='caller streams the timed GPU-walk batches alternate between (2: as the other legs of bench.py -- a walk launch lasts as '
                     'long as its slowest query, the next batch fills the SIMDs the others have left; 1: one batch at a time)')
+p.add_argument('--gpu-build-batch', type=int, default=0, help='GpuLevel0Graph.BATCH (0: the class default)')
+p.add_argument('--gpu-build-grow', type=int, default=0, help='GpuLevel0Graph.GROW (0: the class default)')
 p.add_argument('--build', choices=['both', 'gpu', 'host'], default='both',
                help="where the graph is built: 'gpu' = level 0 in batches on the GPU (round 6), 'host' = libannlite_graph.so; 'both' "
                     "(default): the GPU-built graph is what is measured, the host-built one serves the host walks / the CPU baseline "
@@ -57,6 +59,13 @@ codec.seed = 7
 codec.deterministic = True
 codec.fit(gen(0, 250_000)[:20480], iter=20)
 CH = 250_000
+if a.gpu_build_batch or a.gpu_build_grow:
+    from annlite_amd.core.index import graph_gpu_build as _gb
+
+    if a.gpu_build_batch:
+        _gb.GpuLevel0Graph.BATCH = a.gpu_build_batch
+    if a.gpu_build_grow:
+        _gb.GpuLevel0Graph.GROW = a.gpu_build_grow
 
 
 def build_index(where):
