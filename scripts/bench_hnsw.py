@@ -32,6 +32,7 @@ p.add_argument('--streams', type=int, default=2,
                     'long as its slowest query, the next batch fills the SIMDs the others have left; 1: one batch at a time)')
 p.add_argument('--gpu-build-batch', type=int, default=0, help='GpuLevel0Graph.BATCH (0: the class default)')
 p.add_argument('--gpu-build-grow', type=int, default=0, help='GpuLevel0Graph.GROW (0: the class default)')
+p.add_argument('--gpu-seeds', type=int, default=0, help='GpuLevel0Graph.MAX_SEEDS, build and search (0: the class default)')
 p.add_argument('--build', choices=['both', 'gpu', 'host'], default='both',
                help="where the graph is built: 'gpu' = level 0 in batches on the GPU (round 6), 'host' = libannlite_graph.so; 'both' "
                     "(default): the GPU-built graph is what is measured, the host-built one serves the host walks / the CPU baseline "
@@ -59,13 +60,15 @@ codec.seed = 7
 codec.deterministic = True
 codec.fit(gen(0, 250_000)[:20480], iter=20)
 CH = 250_000
-if a.gpu_build_batch or a.gpu_build_grow:
+if a.gpu_build_batch or a.gpu_build_grow or a.gpu_seeds:
     from annlite_amd.core.index import graph_gpu_build as _gb
 
     if a.gpu_build_batch:
         _gb.GpuLevel0Graph.BATCH = a.gpu_build_batch
     if a.gpu_build_grow:
         _gb.GpuLevel0Graph.GROW = a.gpu_build_grow
+    if a.gpu_seeds:
+        _gb.GpuLevel0Graph.MAX_SEEDS = a.gpu_seeds
 
 
 def build_index(where):
