@@ -299,6 +299,8 @@ class HnswPQGpuIndex(PQFlatGpuIndex):
 
     def _plain_table(self, N: int) -> torch.Tensor:
         """Code rows in sub-space order for the gather kernel (cached; rebuilt after inserts)."""
+        if getattr(self, 'build', 'host') == 'gpu' and self._gg is not None and self._gg.n >= N and N > 0:
+            return self._gg.codes[:N]  # (the GPU-built graph keeps the PLAIN rows it links: the same bytes, no third copy)
         key = (N, self._structure)
         if getattr(self, '_plain_cache_key', None) != key:
             self._plain_cache = self._plain_codes(N).contiguous()

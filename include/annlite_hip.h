@@ -196,7 +196,9 @@ ANNLITE_API int annlite_graph_search_packed_ex(const void *packed_dev, int links
  *                                (INT64_MAX = none)
  *   annlite_graph_build_reverse  keys_dev i64 [P] = the pairs SORTED ascending; seg_dev i64 [S + 1] = the boundaries of the S runs
  *                                of equal target: every target appends its sources while its list has room, else shrinks
- *                                (list + sources) to links_per_node (<= 32) entries with the same heuristic
+ *                                (list + sources) to links_per_node (<= 32) entries with the same heuristic; a target takes at most
+ *                                64 - (its list's length) sources of one call (the lowest ids; the rest are dropped: a link the
+ *                                heuristic would most likely have pruned -- only the all-at-once start of a graph sees such hubs)
  *   annlite_graph_pack_nodes     the packed records (annlite_graph_pack) of the nodes in nodes_dev i64 [n_nodes] only */
 ANNLITE_API int annlite_graph_build_sdc(const float *codebooks_dev, int64_t M, int64_t Ks, int64_t dsub, float *sdc_dev, void *stream);
 ANNLITE_API int annlite_graph_build_select(const int64_t *cand_dev, int ef, int64_t b, int64_t base0, const void *codes_dev, int64_t M,
