@@ -213,7 +213,7 @@ def test_seed_rows_are_spread_over_the_table():
 
 def test_graph_index_build_side_is_resolved_without_a_gpu():
     """HnswPQGpuIndex(build=None): the GPU builds the level-0 graph where the GPU walk applies (max_connection <= 16, M in {8, 16, 32},
-    uint8 codes, walk='gpu'); everything else keeps the host library -- decided at construction, no device touched."""
+    uint8 codes, walk='gpu' -- M in {8, 16, 32, 64}); everything else keeps the host library -- decided at construction, no device touched."""
     from annlite_amd import HnswPQGpuIndex, Metric, PQCodec
 
     def mk(m=8, ks=256, dim=64, **kw):
@@ -222,7 +222,8 @@ def test_graph_index_build_side_is_resolved_without_a_gpu():
     assert mk().build == 'gpu' and mk().expand_width == 2
     assert mk(walk='host').build == 'host'
     assert mk(max_connection=32).build == 'host'
-    assert mk(m=64, dim=128).build == 'host'
+    assert mk(m=64, dim=128).build == 'gpu'   # (round 6: 64 sub-spaces walk and build on the GPU too)
+    assert mk(m=4, dim=64).build == 'host'    # (no walk kernel for this width)
     assert mk(ks=512).build == 'host'
     assert mk(build='host').build == 'host' and mk(m=16, build='gpu').build == 'gpu'
     with pytest.raises(AssertionError):
