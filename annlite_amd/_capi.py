@@ -62,6 +62,7 @@ SYMBOLS = (
     'annlite_pq_search_split',
     'annlite_pq_search_seed_union',
     'annlite_adc_scan_candidates',
+    'annlite_pq_search_candidates',
     'annlite_topk_merge',
     'annlite_topk_merge_packed',
     'annlite_topk_rows',
@@ -147,6 +148,7 @@ def lib() -> ctypes.CDLL:
     L.annlite_graph_record_bytes.argtypes = [i32, i64, ctypes.POINTER(ctypes.c_int64)]
     L.annlite_adc_scan_topk.argtypes = [vp, i32, i32, i64, i64, i64, vp, vp, i64, i64, i64, vp, vp, vp, sz, vp]
     L.annlite_adc_scan_candidates.argtypes = L.annlite_adc_scan_topk.argtypes
+    L.annlite_pq_search_candidates.argtypes = [i32, vp, i64, i64, vp, vp, i32, i32, i64, i64, i64, vp, i64, i64, vp, vp, vp, sz, vp]
     L.annlite_adc_scan_topk_packed.argtypes = [vp, i32, i32, i64, i64, i64, vp, vp, i64, i64, i64, vp, vp, sz, vp]
     L.annlite_pq_search_workspace_bytes.argtypes = [i64, i64, i64, i32, i64, i64, ctypes.POINTER(ctypes.c_int64)]
     L.annlite_pq_search_topk.argtypes = [i32, vp, i64, i64, vp, vp, i32, i32, i64, i64, i64, vp, i64, i64, vp, vp, vp, i32,

@@ -443,9 +443,9 @@ class PQFlatGpuIndex(BaseIndex):
                                          n_rows=N, codes_layout=self._layout(), workspace=self._ws,
                                          state=None if filtered else self.scan_state)
         else:
-            lut = ops.lut_build(xq, self.pq_codec.codebooks_dev, kind, LAYOUT_TILED if plan.fast else LAYOUT_BMK, plan.qi)
-            _, cand = ops.adc_scan_candidates(self._codes, lut, B, rk, self.M, self.Ks, valid_bits=valid, n_rows=N,
-                                              codes_layout=self._layout(), workspace=self._ws)
+            # (round 6) tables + candidate generator in one C call; M = 16 / L2: through the plain search's ONE preparation launch
+            _, cand = ops.pq_search_candidates(kind, xq, self.pq_codec.codebooks_dev, self._codes, rk, self.M, self.Ks, valid_bits=valid,
+                                               n_rows=N, codes_layout=self._layout(), workspace=self._ws)
         if k <= 64:  # (round 6) exact distances + top-k + ids + sqrt in one launch, a wave per query; same numbers as below
             return ops.rerank_topk(int(self.metric), q, self._vectors, cand, k, sqrt=self.metric == Metric.EUCLIDEAN)
         exact = ops.exact_gather_dist(int(self.metric), q, self._vectors, cand)  # [B, R]

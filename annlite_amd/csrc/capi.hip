@@ -92,6 +92,7 @@ static Knobs *parse_knobs() {
     k->no_inkernel_merge = getenv("ANNLITE_NO_INKERNEL_MERGE") != nullptr;
     k->no_fused_lut = getenv("ANNLITE_NO_FUSED_LUT") != nullptr;
     k->mfma_seed = getenv("ANNLITE_MFMA_SEED") != nullptr;
+    k->no_cand_seed = getenv("ANNLITE_NO_CAND_SEED") != nullptr;
     k->graph_hash_bits = env_int("ANNLITE_GRAPH_HASH_BITS", -1);
     k->graph_seq_insert = getenv("ANNLITE_GRAPH_SEQ_INSERT") != nullptr;
     return k;

@@ -69,6 +69,7 @@ struct Knobs {
     bool no_fused_lut;          // ANNLITE_NO_FUSED_LUT
     bool mfma_seed;             // ANNLITE_MFMA_SEED (opt-in: the seed bound from MFMA-nominated rows, seed_mfma.hip -- measured slower
                                 // than the seed rows' exact scan as a whole)
+    bool no_cand_seed;          // ANNLITE_NO_CAND_SEED (A/B: the candidate generator with per-slice seeds and its own table builds, as before round 6)
     int graph_hash_bits;        // ANNLITE_GRAPH_HASH_BITS
     bool graph_seq_insert;      // ANNLITE_GRAPH_SEQ_INSERT
 };

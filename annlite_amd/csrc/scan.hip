@@ -723,7 +723,8 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                         const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B, int64_t k,
                         void *workspace_dev, size_t workspace_bytes, hipStream_t st, annlite_scan_plan *plan_out,
                         bool share_across_slices, const LutBuild *build = nullptr, ScanOut *outp = nullptr,
-                        const TileMode *tm = nullptr, GuardOpt *gopt = nullptr, const SplitOpt *split = nullptr) {
+                        const TileMode *tm = nullptr, GuardOpt *gopt = nullptr, const SplitOpt *split = nullptr,
+                        bool cand_seed = false) {
     annlite_scan_plan plan;
     int rc = plan_query_impl(N, M, Ks, code_bytes, B, k, tm ? 1 : 0, &plan);
     if (rc != ANNLITE_OK) return rc;
@@ -950,7 +951,14 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
             const int64_t Bq = tm ? tm->n_queries : B;  // tile mode: tables of the real queries only
             // seed rows of the shared first bound (tile mode seeds inside the scan kernel)
             int64_t S = 0;
-            if (share_across_slices && N >= 4096 && !tm) {
+            // (round 6) the candidate generator of the re-rank stage through the ONE preparation launch: its slices share nothing while
+            // they scan, but they can START from one bound -- the k-th smallest exact sum among the seed rows spread over the whole
+            // table is at or above the k-th key of the TABLE, so no slice can lose a row of the table's top-k to it; what a slice far
+            // from the query loses are rows beyond that bound, of no use to a re-rank.  Saves the per-slice seed launch (8 x 8192 rows
+            // against 32768), the separate table build / quantise launches and the work items' own table builds (prebuilt images).
+            const bool cand_prep = cand_seed && !share_across_slices && c.mode == 5 && build && M == 16 && build->D <= 256 &&
+                                   ((build->D / M) % 4) == 0 && !kn.no_fused_seed && !tm && N >= 4096 && k <= 16;
+            if ((share_across_slices || cand_prep) && N >= 4096 && !tm) {
                 S = 8192;
                 // byte-table kernel: its candidate transient shrinks with a tighter first bound faster than the seed launch
                 // grows (12 us per 8192 rows): 1.25M rows x 1024 queries 0.425 / 0.407 / 0.405 / 0.437 ms per batch at
@@ -1039,7 +1047,7 @@ static int scan_partial(const void *codes_dev, int code_bytes, int codes_layout,
                     if (rc != ANNLITE_OK) return rc;
                 }
             }
-            if (!share_across_slices && c.mode == 5 && !tm && N >= 4096) {
+            if (!share_across_slices && c.mode == 5 && !tm && N >= 4096 && !(cand_prep && one_prep)) {
                 // the byte-table kernel as the candidate generator of the re-rank stage: every slice keeps its own complete
                 // list, so every (query, slice) gets its own first bound -- the k-th of the slice's first rows (the gk2 array,
                 // unused without sharing and reset by the fill, holds them).  Without one the slice's table would start "open"
@@ -1656,6 +1664,47 @@ extern "C" int annlite_adc_scan_candidates(const void *codes_dev, int code_bytes
     if (rc != ANNLITE_OK || B == 0) return rc;
     ANNLITE_REQUIRE(out_dist_dev && out_id_dev, "null output pointer");
     const int64_t total = B * plan.n_slices * k;
+    hipLaunchKernelGGL(export_partial_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const unsigned long long *)workspace_dev, total, row_base, out_dist_dev, out_id_dev);
+    return launch_status("export_partial_kernel");
+}
+
+// The candidate generator with the tables built inside the call (round 6): annlite_lut_build + annlite_adc_scan_candidates in one
+// C call, and -- M = 16, L2 tables, 4-float-aligned sub-vectors, k <= 16 -- through the ONE preparation launch of the plain search
+// (tables, quantisation parameters, list reset, ONE seed bound from rows spread over the table, prebuilt byte tables).
+extern "C" int annlite_pq_search_candidates(int lut_kind, const float *queries_dev, int64_t B, int64_t D, const float *codebooks_dev,
+                                            const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M, int64_t Ks,
+                                            const uint32_t *valid_bits_dev, int64_t k, int64_t row_base, float *out_dist_dev,
+                                            int64_t *out_id_dev, void *workspace_dev, size_t workspace_bytes, void *stream) {
+    ANNLITE_REQUIRE(M >= 1 && D >= M && D % M == 0,
+                    "input dimension must be dividable by number of sub-space (D=%lld, M=%lld)", (long long)D, (long long)M);
+    annlite_scan_plan plan;
+    int rc = plan_query_impl(N, M, Ks, code_bytes, B, k, 0, &plan);
+    if (rc != ANNLITE_OK) return rc;
+    if (B == 0) return ANNLITE_OK;
+    const size_t scan_ws = r256z((size_t)plan.workspace_bytes);
+    const size_t need = scan_ws + r256z((size_t)plan.lut_floats * 4);
+    if (workspace_bytes < need) {
+        set_error("workspace %zu B < required %zu B (annlite_pq_search_workspace_bytes)", workspace_bytes, need);
+        return ANNLITE_ERR_WORKSPACE;
+    }
+    ANNLITE_REQUIRE(queries_dev && codebooks_dev && workspace_dev && out_dist_dev && out_id_dev, "null device pointer");
+    hipStream_t st = (hipStream_t)stream;
+    float *lut = (float *)((char *)workspace_dev + scan_ws);
+    FastCfg c;
+    const bool fuse = N > 0 && plan.fast && fast_cfg(M, Ks, code_bytes, k, &c, false) && c.qf() && M != 64 && Ks <= 256 &&
+                      lut_kind == ANNLITE_LUT_L2 && ((D / M) % 4) == 0 && !knobs().no_fused_lut;
+    const LutBuild lb = {queries_dev, codebooks_dev, D};
+    if (!fuse) {
+        rc = annlite_lut_build(lut_kind, queries_dev, B, D, codebooks_dev, M, Ks, lut, plan.fast ? ANNLITE_LAYOUT_TILED : ANNLITE_LAYOUT_BMK,
+                               plan.qi, stream);
+        if (rc != ANNLITE_OK) return rc;
+    }
+    annlite_scan_plan used;
+    rc = scan_partial(codes_dev, code_bytes, codes_layout, N, M, Ks, valid_bits_dev, lut, B, k, workspace_dev, scan_ws, st, &used, false,
+                      fuse ? &lb : nullptr, nullptr, nullptr, nullptr, nullptr, /*cand_seed=*/fuse && !knobs().no_cand_seed);
+    if (rc != ANNLITE_OK) return rc;
+    const int64_t total = B * used.n_slices * k;
     hipLaunchKernelGGL(export_partial_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        (const unsigned long long *)workspace_dev, total, row_base, out_dist_dev, out_id_dev);
     return launch_status("export_partial_kernel");

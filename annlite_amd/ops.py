@@ -460,6 +460,29 @@ def adc_scan_candidates(codes: torch.Tensor, lut: torch.Tensor, B: int, k: int, 
     return od, oi
 
 
+def pq_search_candidates(lut_kind: int, queries: torch.Tensor, codebooks: torch.Tensor, codes: torch.Tensor, k: int, M: int, Ks: int,
+                         valid_bits: Optional[torch.Tensor] = None, row_base: int = 0, n_rows: Optional[int] = None,
+                         codes_layout: int = CODES_PLAIN, workspace: Optional[ScanWorkspace] = None
+                         ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``annlite_pq_search_candidates``: table build + candidate generator in one C call -- (f32 [B, n_slices*k], i64 [B, n_slices*k]),
+    every slice's k best rows at or below the table-wide first bound (a superset of the table's top-k; -1 / +inf padded)."""
+    N = codes.shape[0] if n_rows is None else n_rows
+    B, D = queries.shape
+    cb = code_bytes_of(codes)
+    plan = scan_plan(N, M, Ks, cb, B, k)
+    need = ctypes.c_int64(0)
+    check(lib().annlite_pq_search_workspace_bytes(N, M, Ks, cb, B, k, ctypes.byref(need)), 'pq_search_workspace_bytes')
+    dev = codes.device
+    ws = (workspace or ScanWorkspace()).get(int(need.value), dev)
+    R = plan.n_slices * k
+    od = torch.empty((B, R), dtype=torch.float32, device=dev)
+    oi = torch.empty((B, R), dtype=torch.int64, device=dev)
+    check(lib().annlite_pq_search_candidates(lut_kind, queries.data_ptr(), B, D, codebooks.data_ptr(), codes.data_ptr(), cb, codes_layout,
+                                             N, M, Ks, _ptr(valid_bits), k, row_base, od.data_ptr(), oi.data_ptr(), ws.data_ptr(),
+                                             ws.numel(), stream_ptr()), 'pq_search_candidates')
+    return od, oi
+
+
 def topk_merge(dist: torch.Tensor, ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """[G,B,k] x2 -> [B,k] x2 (the merge after the RCCL all-gather of per-shard top-k)."""
     G, B, k = dist.shape

@@ -307,6 +307,16 @@ ANNLITE_API int annlite_adc_scan_candidates(const void *codes_dev, int code_byte
                                 int64_t Ks, const uint32_t *valid_bits_dev, const float *lut_dev, int64_t B,
                                 int64_t k, int64_t row_base, float *out_dist_dev, int64_t *out_id_dev,
                                 void *workspace_dev, size_t workspace_bytes, void *stream);
+/* ... with the tables built inside the call (round 6): queries_dev f32 [B][D] + codebooks_dev instead of a prebuilt table; same
+ * output, out[b][0 .. n_slices * k) with n_slices of annlite_scan_plan_query(N, M, Ks, code_bytes, B, k); workspace of
+ * annlite_pq_search_workspace_bytes.  M = 16, L2 tables, k <= 16: ONE preparation launch (tables, list reset, ONE first bound from
+ * rows spread over the whole table, prebuilt byte tables) instead of four; every slice then keeps the k best of ITS rows that are at
+ * or below that bound -- the bound lies at or above the k-th key of the whole table, so the lists still hold the table's top-k
+ * (and a row beyond it is of no use to a re-rank: a slice far from the query returns fewer than k rows, -1 padded). */
+ANNLITE_API int annlite_pq_search_candidates(int lut_kind, const float *queries_dev, int64_t B, int64_t D, const float *codebooks_dev,
+                             const void *codes_dev, int code_bytes, int codes_layout, int64_t N, int64_t M, int64_t Ks,
+                             const uint32_t *valid_bits_dev, int64_t k, int64_t row_base, float *out_dist_dev,
+                             int64_t *out_id_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* Measurement hooks (bench.py): when enabled on the calling thread, annlite_adc_scan_topk /
  * _candidates bracket the scan kernel launch -- the dominant kernel -- with HIP events on the
