@@ -267,6 +267,47 @@ __global__ __launch_bounds__(256) void ivf_candidate_ids_kernel(const uint32_t *
     for (int j = off + lane; j < R; j += 64) row[j] = -1;
 }
 
+// ---- merge of a query's per-cell lists (annlite_ivf_search_topk) -----------------------------------
+// The cell-tile scan (adc_scan_q8_kernel<..., TL>) leaves, per SLOT, the k smallest (exact ADC sum, table row) keys of the
+// slot's cell, ascending.  One wave per query: the P lists of its slots (slot_of) -- 64 keys at a time, re-keyed by the rows'
+// external ids (row_ids: ascending inside a cell, so a slot's k best under (distance, table row) ARE its k best under
+// (distance, id); between cells the id decides) -- are folded into a sorted wave list; its first k entries are the result
+// under the fixed order (distance asc, id asc): what CellContainer.ivf_search's concatenate-and-sort returns for the probed cells
+// (container.py:88-144).
+__global__ __launch_bounds__(256) void ivf_merge_lists_kernel(const unsigned long long *__restrict__ lists, int k,
+                                                             const int32_t *__restrict__ slot_of, int B, int P,
+                                                             const int64_t *__restrict__ row_ids, int64_t id_base,
+                                                             float *__restrict__ out_d, int64_t *__restrict__ out_i, int sqrt_out) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    WaveList L;
+    L.reset();
+    const int total = P * k;
+    for (int i0 = 0; i0 < total; i0 += 64) {
+        const int i = i0 + lane;
+        uint32_t hi = kKeyInfHi, lo = kIdNone;
+        if (i < total) {
+            const int p = i / k, j = i - p * k;
+            const int v = slot_of[(int64_t)b * P + p];
+            const unsigned long long key = lists[(int64_t)v * k + j];
+            if (key != ~0ull) {
+                hi = (uint32_t)(key >> 32);
+                const uint32_t row = (uint32_t)key;
+                lo = row_ids ? (uint32_t)row_ids[row] : row;
+            }
+        }
+        wave_sort64(hi, lo, lane);
+        wavelist_merge_sorted(L, hi, lo, lane);
+    }
+    if (lane < k) {
+        const bool none = (L.hi == kKeyInfHi && L.lo == kIdNone);
+        const float d = none ? __builtin_inff() : ordered_to_f32(L.hi);
+        out_d[(int64_t)b * k + lane] = sqrt_out && !none ? __builtin_sqrtf(d) : d;
+        out_i[(int64_t)b * k + lane] = none ? (int64_t)-1 : id_base + (int64_t)L.lo;
+    }
+}
+
 }  // namespace annlite
 
 using namespace annlite;
@@ -358,4 +399,17 @@ extern "C" int annlite_ivf_candidate_ids(const uint32_t *cand_dev, int64_t cand_
     hipLaunchKernelGGL(ivf_candidate_ids_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, cand_dev,
                        (int)cand_cap, cand_count_dev, slot_of_dev, (int)B, (int)P, row_ids_dev, id_base, out_ids_dev, (int)R);
     return launch_status("ivf_candidate_ids_kernel");
+}
+
+extern "C" int annlite_ivf_merge_lists(const uint64_t *lists_dev, int64_t k, const int32_t *slot_of_dev, int64_t B, int64_t P,
+                                       const int64_t *row_ids_dev, int64_t id_base, float *out_dist_dev, int64_t *out_id_dev,
+                                       int flags, void *stream) {
+    ANNLITE_REQUIRE(B >= 0 && P >= 1 && k >= 1 && k <= 64 && P * k < (1ll << 30), "bad B=%lld P=%lld k=%lld (k<=64)", (long long)B,
+                    (long long)P, (long long)k);
+    if (B == 0) return ANNLITE_OK;
+    ANNLITE_REQUIRE(lists_dev && slot_of_dev && out_dist_dev && out_id_dev, "null device pointer");
+    hipLaunchKernelGGL(ivf_merge_lists_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned long long *)lists_dev, (int)k, slot_of_dev, (int)B, (int)P, row_ids_dev, id_base, out_dist_dev,
+                       out_id_dev, (flags & ANNLITE_FLAG_SQRT) ? 1 : 0);
+    return launch_status("ivf_merge_lists_kernel");
 }

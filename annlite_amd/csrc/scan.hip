@@ -1652,6 +1652,121 @@ extern "C" int annlite_pq_search_tiles(int lut_kind, const float *queries_dev, i
                           valid_bits_dev, k, 0, nullptr, nullptr, nullptr, 0, workspace_dev, workspace_bytes, stream, &tm, V);
 }
 
+// ---- pruned search over cells on the byte-table kernel (round 6) --------------------------------------------------------
+// annlite_ivf_plan (tiles of 32 slots) -> the preparation launch with per-cell seeds and per-query byte tables (launch_seed_build_cells)
+// -> adc_scan_q8_kernel<16, ..., TL> (id 1651: exact sums in the tile, lists per slot, bounds shared by QUERY) -> annlite_ivf_merge_lists.
+// Workspace carve (all 256-byte aligned): lists u64 [V][k] | gkey u64 [bpad] | gseed0 u64 [bpad] | qstep f32 | smax f32 | qlo f64 | qlom f32 [bpad][16] |
+// fp32 TILED tables [bpad][Ks][16] | bq u8 [bpad][Ks][16] | vmap i32 [V] | slot_of i32 [B * P] | tile_rows i64 [T][2] | n_tiles_used
+constexpr int kIvfQt = 32;
+static size_t ivf_topk_carve(int64_t B, int64_t P, int64_t C, int64_t Ks, int64_t k, char *base, char **ptrs /* [13] */) {
+    const int64_t bpad = pad_queries(B, kIvfQt);
+    const int64_t T = annlite_ivf_max_tiles(B, P, C, kIvfQt), V = T * kIvfQt;
+    const int64_t sizes[13] = {V * k * 8, bpad * 8, bpad * 8, bpad * 4, bpad * 4, bpad * 8, bpad * 16 * 4, bpad * Ks * 16 * 4, bpad * Ks * 16,
+                               V * 4, B * P * 4, T * 16, 256};
+    size_t off = 0;
+    for (int i = 0; i < 13; ++i) {
+        if (ptrs) ptrs[i] = base + off;
+        off += r256z((size_t)sizes[i]);
+    }
+    return off;
+}
+
+extern "C" int annlite_ivf_search_topk_workspace_bytes(int64_t B, int64_t P, int64_t C, int64_t M, int64_t Ks, int64_t k, int64_t *bytes) {
+    ANNLITE_REQUIRE(bytes != nullptr, "bytes is NULL");
+    ANNLITE_REQUIRE(B >= 0 && P >= 1 && C >= 1 && P <= C && M == 16 && Ks >= 1 && Ks <= 256 && k >= 1 && k <= 16,
+                    "annlite_ivf_search_topk serves M = 16, Ks <= 256, k <= 16 (B=%lld P=%lld C=%lld M=%lld Ks=%lld k=%lld)", (long long)B,
+                    (long long)P, (long long)C, (long long)M, (long long)Ks, (long long)k);
+    *bytes = (int64_t)ivf_topk_carve(B, P, C, Ks, k, nullptr, nullptr);
+    return ANNLITE_OK;
+}
+
+extern "C" int annlite_ivf_search_topk(const float *queries_dev, int64_t B, int64_t D, const float *codebooks_dev, int64_t M, int64_t Ks,
+                                       const void *codes_dev, int codes_layout, int64_t N, const uint32_t *valid_bits_dev,
+                                       const int32_t *cells_dev, int64_t P, int64_t C, const int64_t *cell_rows_dev,
+                                       const int32_t *cell_order_dev, const int64_t *row_ids_dev, int64_t id_base, int64_t k,
+                                       float *out_dist_dev, int64_t *out_id_dev, int flags, void *workspace_dev, size_t workspace_bytes,
+                                       void *stream) {
+    ANNLITE_REQUIRE(M == 16 && Ks >= 1 && Ks <= 256 && k >= 1 && k <= 16,
+                    "annlite_ivf_search_topk serves M = 16, Ks <= 256, k <= 16 (got M=%lld Ks=%lld k=%lld): ANNLITE_NOT_APPLICABLE shapes take "
+                    "annlite_pq_search_tiles + annlite_ivf_rescore", (long long)M, (long long)Ks, (long long)k);
+    ANNLITE_REQUIRE(D >= M && D % M == 0 && D <= 256 && ((D / M) % 4) == 0,
+                    "the fused table build needs D <= 256 and sub-vectors of a multiple of 4 floats (D=%lld)", (long long)D);
+    ANNLITE_REQUIRE(B >= 0 && P >= 1 && C >= 1 && P <= C && C <= 16384 && N > 0 && N < (1ll << 31),
+                    "bad shape B=%lld P=%lld C=%lld N=%lld", (long long)B, (long long)P, (long long)C, (long long)N);
+    ANNLITE_REQUIRE(codes_layout == ANNLITE_CODES_PLAIN || codes_layout == ANNLITE_CODES_SKEWED, "codes_layout %d", codes_layout);
+    if (B == 0) return ANNLITE_OK;
+    ANNLITE_REQUIRE(queries_dev && codebooks_dev && codes_dev && cells_dev && cell_rows_dev && cell_order_dev && out_dist_dev &&
+                        out_id_dev && workspace_dev,
+                    "null device pointer");
+    char *ptr[13];
+    const size_t need = ivf_topk_carve(B, P, C, Ks, k, (char *)workspace_dev, ptr);
+    if (workspace_bytes < need) {
+        set_error("workspace %zu B < required %zu B (annlite_ivf_search_topk_workspace_bytes)", workspace_bytes, need);
+        return ANNLITE_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t T = annlite_ivf_max_tiles(B, P, C, kIvfQt);
+    unsigned long long *lists = (unsigned long long *)ptr[0], *gkey = (unsigned long long *)ptr[1], *gseed0 = (unsigned long long *)ptr[2];
+    float *qstep = (float *)ptr[3], *smax = (float *)ptr[4], *qlom = (float *)ptr[6], *lut = (float *)ptr[7];
+    double *qlo = (double *)ptr[5];
+    uint8_t *bq = (uint8_t *)ptr[8];
+    int32_t *vmap = (int32_t *)ptr[9], *slot_of = (int32_t *)ptr[10], *n_used = (int32_t *)ptr[12];
+    int64_t *tile_rows = (int64_t *)ptr[11];
+    int rc = annlite_ivf_plan(cells_dev, B, P, C, kIvfQt, cell_rows_dev, cell_order_dev, T, vmap, slot_of, tile_rows, n_used, stream);
+    if (rc != ANNLITE_OK) return rc;
+    const Knobs &kn = knobs();
+    // seed rows: S / 4 per query from its nearest cell (the workgroup's four queries share the launch's blocks)
+    int64_t S = 32768;
+    if (kn.seed_rows_set && kn.seed_rows >= 256) S = kn.seed_rows;
+    const int target = (kn.q8_target >= 16 && kn.q8_target <= 127) ? kn.q8_target : 88;
+    const LutBuild lb = {queries_dev, codebooks_dev, D};
+    const bool sk = codes_layout == ANNLITE_CODES_SKEWED;
+    rc = launch_seed_build_cells(sk, codes_dev, S, N, valid_bits_dev, lb, lut, B, Ks, k, qstep, qlo, smax, qlom, gkey, st, gseed0, bq, target,
+                                 cells_dev, P, cell_rows_dev);
+    if (rc != ANNLITE_OK) return rc;
+    ScanArgs a = {};
+    a.codes = codes_dev;
+    a.valid = valid_bits_dev;
+    a.lut = lut;
+    a.partial = lists;
+    a.N = N;
+    a.Ks = (int)Ks;
+    a.B = (int)B;
+    a.k = (int)k;
+    a.n_tiles = (int)T;
+    a.n_slices = 1;
+    a.n_items = (int)T;
+    a.slice_rows = ((N + 63) / 64) * 64;
+    a.smax = smax;
+    a.qstep = qstep;
+    a.qlo = qlo;
+    a.qlom = qlom;
+    a.gkey = gkey;
+    a.gk2 = nullptr;
+    a.jm1 = 0;
+    a.tile_rows = tile_rows;
+    a.vmap = vmap;
+    a.gseed0 = gseed0;
+    a.btab = bq;
+    a.q8_epoch0 = 1 << 28;  // (no epoch ends in a cell tile)
+    a.q8_epoch_mul = 1;
+    a.q8_ring_limit = 384;
+    a.q8_import_mask = 3;
+    a.q8_target = target;
+    a.q8_rebuild_8ths = 4;
+    a.q8_thw_mask = 1;
+    a.flush_mask = 63;
+    a.dbg_skip = kn.debug_skip;
+    if (kn.q8_tune_ok) a.q8_import_mask = kn.q8_tune[3];
+    const int n_cu = device_cu_count();
+    const int grid = (int)(T < n_cu ? T : n_cu);
+    prof_begin(st);
+    rc = launch_q8_scan(1651, sk, a, grid, st);
+    prof_end(st);
+    if (rc != ANNLITE_OK) return rc;
+    return annlite_ivf_merge_lists((const uint64_t *)lists, k, slot_of, B, P, row_ids_dev, id_base, out_dist_dev, out_id_dev, flags, stream);
+}
+
 extern "C" int annlite_adc_scan_candidates(const void *codes_dev, int code_bytes, int codes_layout, int64_t N,
                                            int64_t M, int64_t Ks, const uint32_t *valid_bits_dev,
                                            const float *lut_dev, int64_t B, int64_t k, int64_t row_base,

@@ -135,6 +135,13 @@ struct SeedBuild {
     // THEIR exact sums (n_cand x 4 rows per workgroup) instead of the exact sums of all S seed rows
     const uint32_t *cand;        // [B][n_cand] table rows, distinct per query
     int32_t n_cand;
+    // CELLS (annlite_ivf_search_topk: a query scans only the rows of its n_probe nearest cells -- a bound from rows OUTSIDE them
+    // would be wrong): query b's seed rows are 64-row blocks spread evenly over its NEAREST cell, rows [cell_rows[2 c], cell_rows[2 c + 1])
+    // of the cell-sorted table, c = cells[b * n_probe]; and the byte tables go out per QUERY (a cell tile's slots hold arbitrary queries)
+    const int32_t *cells;        // [B][n_probe], nearest first
+    const int64_t *cell_rows;    // [C][2] (begin: multiple of 64, end)
+    int32_t n_probe;
+    uint8_t *bq;                 // [ceil4(B)][Ks][M] byte tables quantised for gseed0 (q8_gather_table assembles a tile's image from them)
 };
 // BUILD (round 6): the seed bound from the rows an MFMA launch has nominated (seed_mfma.hip) instead of from S seed rows this
 // kernel scans itself.  Query p of the workgroup's 4 takes ceil(n_cand / 64) wave-iterations: lane = nominee; a row's sums run in
@@ -214,7 +221,7 @@ __device__ __forceinline__ f32x4 seed_nominee_minima(const uint8_t *codes, const
 constexpr int kSeedWkeyOff = 16384, kSeedCtrOff = 20480, kSeedKeepOff = 20544, kSeedLdsExtra = 24576;
 // QPB queries per workgroup: 4 (one fp32 TILED group) where their rows fit the LDS, 2 for M = 64
 // CODE16: uint16 codes (PLAIN tables)
-template <int M, bool SKEWED, int QPB, bool CODE16 = false, bool BUILD = false>
+template <int M, bool SKEWED, int QPB, bool CODE16 = false, bool BUILD = false, bool CELLS = false>
 __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8_t *__restrict__ codes, int64_t S,
                                                                     const uint32_t *__restrict__ valid,
                                                                     const float *__restrict__ lut, int B, int Ks, int k,
@@ -224,6 +231,7 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
                                                                     const SeedBuild sb) {
     static_assert(!(CODE16 && SKEWED), "uint16 code tables are PLAIN");
     static_assert(!BUILD || (QPB == 4 && !CODE16 && M <= 16), "the fused build serves the byte-table plan");
+    static_assert(!CELLS || (BUILD && M == 16), "per-cell seeds: the fused build of the M = 16 byte-table plan");
     if (sb.gate && __hip_atomic_load(sb.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     auto stamp = [&](int i) {
         if constexpr (BUILD) {
@@ -356,6 +364,17 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
             gkey[b] = ~0ull;  // (the fill leaves the bounds to this kernel; the selection below overwrites it)
             if (sb.seedk)
                 for (int j = 0; j < kSeedKeys; ++j) sb.seedk[(int64_t)b * kSeedKeys + j] = ~0ull;
+            if constexpr (CELLS) {  // the query's nearest cell: [begin, end) and its blocks of 64 rows (behind the kept parameters)
+                int32_t *s_cell = (int32_t *)(s_par + 96);  // [4] begin, [4] end, [4] blocks
+                int64_t cb = 0, ce = 0;
+                if (b < B) {
+                    const int32_t c = sb.cells[(int64_t)b * sb.n_probe];
+                    cb = sb.cell_rows[2 * (int64_t)c], ce = sb.cell_rows[2 * (int64_t)c + 1];
+                }
+                s_cell[tid] = (int32_t)cb;
+                s_cell[4 + tid] = (int32_t)ce;
+                s_cell[8 + tid] = (int32_t)((ce - cb + 63) >> 6);
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -420,7 +439,29 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
     const uint32_t cmask = (1u << clog) - 1u;
     int64_t run_step = ((ext >> 6) / ((n_blocks + cmask) >> clog)) << 6;  // rows between the starts of two runs of seed blocks
     if (run_step < ((int64_t)64 << clog)) run_step = (int64_t)64 << clog;
-    auto block_row = [&](uint32_t b) -> int64_t { return (int64_t)(b >> clog) * run_step + (int64_t)((b & cmask) << 6); };
+    // CELLS: seed block b belongs to query b & 3 and is block (b >> 2) * stride of that query's nearest cell (stride: the cell's
+    // blocks over the query's share n_blocks / 4 of the seed blocks, at least 1; past the cell's end: no rows)
+    int32_t c_begin[4] = {0, 0, 0, 0}, c_end[4] = {0, 0, 0, 0}, c_stride[4] = {1, 1, 1, 1};
+    if constexpr (CELLS) {
+        const int32_t *s_cell = (const int32_t *)((const float *)((unsigned char *)cand + kSeedKeepOff) + 96);
+        const int32_t per_q = (int32_t)(n_blocks >> 2) > 0 ? (int32_t)(n_blocks >> 2) : 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            c_begin[i] = __builtin_amdgcn_readfirstlane(s_cell[i]);
+            c_end[i] = __builtin_amdgcn_readfirstlane(s_cell[4 + i]);
+            const int32_t nb = __builtin_amdgcn_readfirstlane(s_cell[8 + i]);
+            c_stride[i] = nb / per_q > 1 ? nb / per_q : 1;
+        }
+    }
+    auto block_row = [&](uint32_t b) -> int64_t {
+        if constexpr (CELLS) {
+            const int i = (int)(b & 3u);
+            const int32_t cb = i == 0 ? c_begin[0] : i == 1 ? c_begin[1] : i == 2 ? c_begin[2] : c_begin[3];
+            const int32_t st = i == 0 ? c_stride[0] : i == 1 ? c_stride[1] : i == 2 ? c_stride[2] : c_stride[3];
+            return (int64_t)cb + (((int64_t)(b >> 2) * st) << 6);
+        } else
+        return (int64_t)(b >> clog) * run_step + (int64_t)((b & cmask) << 6);
+    };
     bool nominated = false;
     if constexpr (BUILD) nominated = sb.cand != nullptr;
     if constexpr (BUILD && PERM) {
@@ -438,6 +479,11 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
         const int64_t r = block_row(b_cur) + lane;
         b_pend = draw_block();
         bool ok = r < ext && ((vn >> (r & 31)) & 1u);
+        if constexpr (CELLS) {  // (rows past the end of the block's cell belong to another cell or are padding)
+            const int i = (int)(b_cur & 3u);
+            const int32_t ce = i == 0 ? c_end[0] : i == 1 ? c_end[1] : i == 2 ? c_end[2] : c_end[3];
+            ok = ok && r < (int64_t)ce;
+        }
         uint32_t c[CW];
 #pragma unroll
         for (int i = 0; i < CW; ++i) c[i] = cn[i];
@@ -474,8 +520,14 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
 #pragma unroll
             for (int i = 0; i < CH; ++i) d += v[i];  // (the lane's skewed order: see the kernel's header)
         });
+        if constexpr (CELLS) {  // the block's rows are seed rows of ONE of the four queries
+            const int i = (int)(b_cur & 3u);
+#pragma unroll
+            for (int q = 0; q < QPB; ++q) bestf[q] = fminf(bestf[q], (ok && q == i) ? d[q] : __builtin_inff());
+        } else {
 #pragma unroll
         for (int q = 0; q < QPB; ++q) bestf[q] = fminf(bestf[q], ok ? d[q] : __builtin_inff());
+        }
         b_cur = b_nxt;
         b_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_pend);
     }
@@ -569,7 +621,7 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
         }
     }
     if constexpr (BUILD) {
-        if (sb.btab) {
+        if (CELLS ? sb.bq != nullptr : sb.btab != nullptr) {
             // ---- the scan kernel's byte tables for these 4 queries, quantised for their seed bound: exactly what the scan
             // workgroups would build (q8_slot_params from the seed key, q8_build_table's conversion) -- built ONCE here, from
             // the fp32 tables still in LDS, instead of by the 8 workgroups of the tile from L2.  Query b = g4 * 4 + i sits in
@@ -611,6 +663,11 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
                         t = __builtin_fminf(t, clip_r[e]);
                         pk = __builtin_amdgcn_cvt_pk_u8_f32(t, e, pk);  // saturates below 0 (q8_build_table's conversion)
                     }
+                    if constexpr (CELLS) {  // per query: bq[b][kk][m]
+                        uint8_t *dst = sb.bq + ((int64_t)(g4 * 4) * Ks + kk) * M + m;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dst[(int64_t)e * Ks * M] = (uint8_t)(pk >> (8 * e));
+                    } else
                     *(uint32_t *)(img + q8_entry16((uint32_t)kk, (uint32_t)m, grp)) = pk;
                 }
             }
@@ -1046,6 +1103,10 @@ int annlite::launch_seed_build(bool skw, const void *codes_dev, int64_t S, int64
     sb.seedk = seedk;
     sb.cand = cand;
     sb.n_cand = cand ? n_cand : 0;
+    sb.cells = nullptr;
+    sb.cell_rows = nullptr;
+    sb.n_probe = 0;
+    sb.bq = nullptr;
     auto fn = skw ? seed_bound_kernel<M, true, 4, false, true> : seed_bound_kernel<M, false, 4, false, true>;
     const size_t lds = (size_t)Ks * M * 16 + (size_t)kSeedLdsExtra;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1053,4 +1114,39 @@ int annlite::launch_seed_build(bool skw, const void *codes_dev, int64_t S, int64
     hipLaunchKernelGGL(fn, dim3(n_g4, 1), dim3(kSeedWaves * 64), lds, st, (const uint8_t *)codes_dev, S, valid_bits_dev,
                        (const float *)nullptr, (int)B, (int)Ks, (int)k, (const float *)nullptr, gk, (int64_t)0, N > S ? N : S, 0, sb);
     return launch_status("seed_bound_kernel (fused table build)");
+}
+
+// The preparation launch of a pruned search over cells (annlite_ivf_search_topk): launch_seed_build's kernel with CELLS -- every
+// query's first bound comes from S / 4 rows of its NEAREST cell, the byte tables go out per query (bq) with their seed keys (gseed0).
+int annlite::launch_seed_build_cells(bool skw, const void *codes_dev, int64_t S, int64_t N, const uint32_t *valid_bits_dev,
+                                     const LutBuild &build, float *lut_out, int64_t B, int64_t Ks, int64_t k, float *qstep, double *qlo,
+                                     float *smax, float *qlom, unsigned long long *gk, hipStream_t st, unsigned long long *gseed0,
+                                     uint8_t *bq, int target, const int32_t *cells, int64_t n_probe, const int64_t *cell_rows) {
+    constexpr int M = 16;
+    SeedBuild sb = {};
+    sb.queries = build.queries;
+    sb.cb = build.codebooks;
+    sb.lut_out = lut_out;
+    sb.qstep = qstep;
+    sb.smax = smax;
+    sb.qlom = qlom;
+    sb.qlo = qlo;
+    sb.fill = nullptr;  // (nothing to reset: the scan writes every list it later reads, gkey is written here)
+    sb.fill_vec16 = 0;
+    sb.D = (int32_t)build.D;
+    sb.qmax = 32767 / M;
+    sb.gseed0 = gseed0;
+    sb.target = target;
+    sb.chunk_log = 0;
+    sb.cells = cells;
+    sb.cell_rows = cell_rows;
+    sb.n_probe = (int32_t)n_probe;
+    sb.bq = bq;
+    auto fn = skw ? seed_bound_kernel<M, true, 4, false, true, true> : seed_bound_kernel<M, false, 4, false, true, true>;
+    const size_t lds = (size_t)Ks * M * 16 + (size_t)kSeedLdsExtra;
+    ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned n_g4 = (unsigned)(((B + 15) / 16) * 4);
+    hipLaunchKernelGGL(fn, dim3(n_g4, 1), dim3(kSeedWaves * 64), lds, st, (const uint8_t *)codes_dev, S, valid_bits_dev,
+                       (const float *)nullptr, (int)B, (int)Ks, (int)k, (const float *)nullptr, gk, (int64_t)0, N > S ? N : S, 0, sb);
+    return launch_status("seed_bound_kernel (cells)");
 }

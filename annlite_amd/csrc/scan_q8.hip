@@ -190,6 +190,50 @@ __device__ __forceinline__ void q8_build_table(const Q8Build &a, int tile, uint3
     }
 }
 
+// Cell tiles (TL; annlite_ivf_search_topk): the 32 slots of a tile hold ARBITRARY queries (ScanArgs::vmap), so the tile's image cannot be
+// prebuilt per tile -- the preparation launch leaves every query's byte table on its own, bq [B][Ks][16] (4 KB per query, quantised
+// for the query's seed key like a prebuilt image), and the workgroup assembles its image from the 32 tables of its slots: entry
+// (code, m, group g) = byte (code, m) of the 16 queries of group g.  Lane = (w, g, u, c2): it loads dword w (sub-spaces 4 w .. 4 w + 3)
+// of code kk = 2 c2 + u + 8 (wave + 16 pass) from the 16 tables of group g (a wave reads 128 contiguous bytes of each of two tables
+// per load), transposes 4 x 4 bytes at a time (v_perm_b32) into the four entries (m = 4 w + t) and stores them with ds_write_b128 in
+// the order t ^ 2 u: the 16 lanes of a store then cover the 16 slots of one 256-byte row of a half twice over two codes -- 16 distinct
+// bank groups (two lanes with the same code differ in (m >> 1, g), the two codes in m >> 1 parity).  Pad slots (query -1) get zeros.
+template <int NW>
+__device__ __forceinline__ void q8_gather_table(const uint8_t *bq, int Ks, uint32_t tab_ad, uint32_t qmap_ad, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t w = (uint32_t)lane & 3u, g = ((uint32_t)lane >> 2) & 1u, u = ((uint32_t)lane >> 3) & 1u, c2 = (uint32_t)lane >> 4;
+    int32_t qb[16];  // byte offset of the slot's table, -1: pad
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int b = ldsv<int32_t>(qmap_ad + 4u * (g * 16u + (uint32_t)j));
+        qb[j] = b < 0 ? -1 : b * (Ks * 16);
+    }
+    for (int kk = (int)(2u * c2 + u) + 8 * wave; kk < Ks; kk += 8 * NW) {
+        uint32_t r[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            r[j] = qb[j] < 0 ? 0u : *(const uint32_t *)(bq + (int64_t)qb[j] + (int64_t)(kk * 16) + (int64_t)(4u * w));
+        u32x4 e[4];  // e[t]: the 16 queries' bytes of sub-space 4 w + t
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const uint32_t a = __builtin_amdgcn_perm(r[4 * v + 1], r[4 * v + 0], 0x05010400u);   // [r0.b0, r1.b0, r0.b1, r1.b1]
+            const uint32_t a2 = __builtin_amdgcn_perm(r[4 * v + 1], r[4 * v + 0], 0x07030602u);  // [r0.b2, r1.b2, r0.b3, r1.b3]
+            const uint32_t c = __builtin_amdgcn_perm(r[4 * v + 3], r[4 * v + 2], 0x05010400u);
+            const uint32_t cc2 = __builtin_amdgcn_perm(r[4 * v + 3], r[4 * v + 2], 0x07030602u);
+            e[0][v] = __builtin_amdgcn_perm(c, a, 0x05040100u);
+            e[1][v] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+            e[2][v] = __builtin_amdgcn_perm(cc2, a2, 0x05040100u);
+            e[3][v] = __builtin_amdgcn_perm(cc2, a2, 0x07060302u);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t tt = (uint32_t)t ^ (2u * u);
+            const u32x4 val = tt == 0u ? e[0] : tt == 1u ? e[1] : tt == 2u ? e[2] : e[3];
+            *(ANNLITE_LDS u32x4 *)(uintptr_t)(tab_ad + q8_entry16((uint32_t)kk, 4u * w + tt, g)) = val;
+        }
+    }
+}
+
 // M = 64: the workgroup's byte table of its 8 queries (two fp32 TILED groups of 4) in the layout of the M = 64 u16 kernel
 // -- two half tables of 32 sub-spaces, [Ks + 1][32 columns][8 B], the second HALF_B = (Ks + 1) * 256 bytes behind the first,
 // row Ks a copy of row 0 (the wrap-coded SKEWED rows address one row down where a lane's column wraps: wrap64_mask) -- with
@@ -256,8 +300,9 @@ constexpr int kPopPerRing = 8;    // entries the consumer takes from one wave's 
 //   list     u64 [32][16] the 16 smallest keys of every slot, ascending; gjl u64 [32] the j-th key last published
 //   ring     u64 [16][kWaveRing]; qkey u64 [4][128], qslot u8 [4][128] insertion queues; chg u8 [32]; stamps u64 [4] (debug)
 //   seen     u32 x 2 (guard statistics); rowq [64 lanes][48 B]: the row queue's parked masks / row ids / code bytes
+//   qmap     i32 [32]  cell tiles (TL): the real query whose tables slot q scans with (ScanArgs::vmap), -1 = padding slot
 struct Q8Lds {
-    uint32_t tab, shq, ring_ctl, gkl, step, inv, tb, ctl, clip, tau, c0, c1, list, gjl, ring, qkey, qslot, chg, stamps, seen, rowq;
+    uint32_t tab, shq, ring_ctl, gkl, step, inv, tb, ctl, clip, tau, c0, c1, list, gjl, ring, qkey, qslot, chg, stamps, seen, rowq, qmap;
     // lk: keys per slot list -- 16 (k <= 16, four insertions at a time), or 64 (16 < k <= 64: one 64-lane list per slot, 16 KB;
     // its ring entries are the row queue's bare 4-byte row ids, which is what makes the 160 KB hold it)
     // re: bytes of a ring entry (q8_ring_entry_bytes: 4 = the row queue's bare row ids, 8 = (S, slot, row))
@@ -283,6 +328,7 @@ struct Q8Lds {
         stamps = chg + 32;
         seen = stamps + 32;  // u32: candidates this workgroup has seen (guard statistics), u32: abort flag of later items
         rowq = seen + 16;    // [64 lanes][48 B]: the consumer's (pass masks, row ids) u32x4 + the two popped rows' 16 code bytes (row queue)
+        qmap = rowq + 3072;  // i32 [32] (cell tiles only, TL: allocated behind the row queue's area): the query of every slot, -1 = padding
     }
     __device__ __forceinline__ uint32_t arrived() const { return ring_ctl; }
     __device__ __forceinline__ uint32_t blk_ctr() const { return ring_ctl + 4; }
@@ -344,11 +390,15 @@ __device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t x) {
 // The global publication of a batch's bounds (the other row slices' workgroups import them) is DEFERRED to the next batch,
 // behind the issue of its table gathers: the device-scope atomics take microseconds and the wave's memory counter is in
 // order -- issued right away they sat in front of the next batch's gathers.
-template <int QT, int LK = 16>
+template <int QT, int LK = 16, bool TL = false>
 __device__ __forceinline__ void q8_publish_global(const FlushCtx &c, const Q8Lds &o, int lane, unsigned long long &pend_o,
                                                   unsigned long long &pend_j) {
     if (lane < QT) {  // (slots beyond QT never change; their cells do not exist)
-        const int b = c.b0 + lane;
+        int b = c.b0 + lane;
+        if constexpr (TL) {  // cell tiles: the bound belongs to the slot's QUERY -- its other cells' tiles import it (gk2 is NULL)
+            b = ldsv<int32_t>(o.qmap + 4u * (uint32_t)lane);
+            if (b < 0) pend_o = ~0ull, b = 0;
+        }
         if (pend_o != ~0ull && c.gkey) __hip_atomic_fetch_min(c.gkey + b, pend_o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (pend_j != ~0ull && c.gk2) {
             unsigned long long *cell = c.gk2 + ((int64_t)b * c.n_slices + c.slice) * kGk2Keys;
@@ -377,7 +427,7 @@ __device__ __forceinline__ void q8_publish_global(const FlushCtx &c, const Q8Lds
     pend_j = ~0ull;
 }
 
-template <int M, bool SKEWED, int QT, int CB, bool ROWS_IN_LDS = false, int LK = 16>
+template <int M, bool SKEWED, int QT, int CB, bool ROWS_IN_LDS = false, int LK = 16, bool TL = false>
 __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, const unsigned long long (&e)[2], bool (&act)[2],
                                            int lane, uint32_t &n_kept, uint32_t &n_offered, unsigned long long &pend_o,
                                            unsigned long long &pend_j) {
@@ -460,7 +510,11 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
                 for (int i = 0; i < 8; ++i) abit_inv[i] = (((sinv >> 2) >> i) & 1) != 0;
                 rotate_row<CW>(cp[u], abit_inv, (uint32_t)(sinv & 3));
             }
-            const int b = c.b0 + (act[u] ? q[u] : 0);
+            int b = c.b0 + (act[u] ? q[u] : 0);
+            if constexpr (TL) {  // cell tiles: the slot's query (a pad slot never passes: its b is not used)
+                b = ldsv<int32_t>(o.qmap + 4u * (uint32_t)(act[u] ? q[u] : 0));
+                b = b < 0 ? 0 : b;
+            }
             const float *lq = c.lut + ((int64_t)(b >> 2) * c.Ks) * (M * 4) + (b & 3);
 #pragma unroll
             for (int m = 0; m < M; ++m) {
@@ -468,7 +522,7 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
                 vals[u][m] = lq[((int64_t)code * M + m) * 4];
             }
         }
-        q8_publish_global<QT, LK>(c, o, lane, pend_o, pend_j);  // (the previous batch's, behind this batch's gathers)
+        q8_publish_global<QT, LK, TL>(c, o, lane, pend_o, pend_j);  // (the previous batch's, behind this batch's gathers)
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -572,24 +626,32 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
 // (Re)build of a workgroup's table: slot parameters (one thread per slot) from the best bound known for the query, then
 // the byte table.  Out of line on purpose: it runs a dozen times per work item, and inlined into the step loop its 40
 // live registers made the compiler spill the loop-invariant LDS base registers of the look-ups into the hot path.
-template <int M, int NW, int NQ, int LK = 16>
+template <int M, int NW, int NQ, int LK = 16, bool TL = false>
 __device__ __attribute__((noinline)) void q8_rebuild(q8_kernarg_ptr ka, int tile, int first, int slice) {
     constexpr int QT = q8_qt<M, NQ>();
+    static_assert(!TL || (M == 16 && NQ == 2 && LK == 16), "cell tiles: the M = 16 kernel with 16-key lists");
     // first bounds of the item's queries: what the seed launch left in the shared array, or -- candidate generator, nothing
     // shared between the slices -- in this slice's row of the per-slice seeds ([n_slices][n_tiles * 32])
     const Q8Build a = {ka->lut, ka->qlom, ka->qstep, ka->smax, ka->qlo,
                        ka->gkey ? ka->gkey : (ka->gseed ? ka->gseed + (int64_t)slice * (ka->n_tiles * QT) : nullptr),
                        ka->Ks, ka->B, ka->k, ka->q8_target, ka->gseed0, ka->btab};
-    const bool prebuilt = first && a.btab != nullptr && M == 16 && NQ == 2;
+    const bool prebuilt = first && a.btab != nullptr && M == 16 && NQ == 2;  // (TL: btab = the per-query byte tables, always there)
     const int tid = threadIdx.x;
     const Q8Lds o(q8_table_bytes<M, NQ>(a.Ks), LK, q8_ring_entry_bytes<M, LK>());
     if (tid < 32) {  // (the control block has 32 slots whatever QT is: the consumer's lanes 0 .. 31 look at all of them)
         const uint32_t t8 = 8u * (uint32_t)tid, t4 = 4u * (uint32_t)tid;
-        const int b = tile * QT + tid;
-        const bool real = tid < QT && b < a.B;
+        int b = tile * QT + tid;
+        bool real = tid < QT && b < a.B;
+        if constexpr (TL) {  // cell tiles: slot -> query (the per-query arrays below are the REAL queries')
+            b = tid < QT ? ka->vmap[tile * QT + tid] : -1;
+            real = b >= 0;
+            b = real ? b : 0;
+            ldsv_st<int32_t>(o.qmap + t4, real ? b : -1);
+        }
         unsigned long long key = ~0ull, key_now = ~0ull;
         if (first) {
             if (a.gkey && real) key = __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (TL) key |= 0xffffffffull;  // (a key of ANOTHER cell's list: the distance alone bounds this cell's rows -- see import_bounds)
             key_now = key;
             // (prebuilt table: quantised for the SEED key -- the shared bound may have moved on since; it only tightens T below)
             if (prebuilt && real) key = a.gseed0[b];
@@ -629,6 +691,7 @@ __device__ __attribute__((noinline)) void q8_rebuild(q8_kernarg_ptr ka, int tile
     }
     __syncthreads();
     if constexpr (Q8Cfg<M>::WIDE) q8_build_table_wide<NW>(a, tile, o.tab, o.inv, o.clip, tid);
+    else if constexpr (TL) q8_gather_table<NW>(a.btab, a.Ks, o.tab, o.qmap, tid);  // (only ever the first table: no epoch ends in a cell tile)
     else if constexpr (M == 16 && NQ == 2) {
         if (prebuilt) q8_copy_table<M, NW, NQ>(a, tile, o.tab, tid);
         else q8_build_table<M, NW, NQ>(a, tile, o.tab, o.inv, o.clip, tid);
@@ -1001,7 +1064,7 @@ __device__ __forceinline__ void q8_early_merge(const ScanArgs &a, const Q8Lds &l
 // End of a work item: the lists ARE the workgroup's result for this (tile, slice) -- the final epoch_sync was the barrier:
 // every candidate is in --; the last of the tile's workgroups to arrive merges the slices.  Out of line, arguments from the
 // kernarg segment (see q8_kernarg).
-template <int M, int NW, int NQ, int LK = 16>
+template <int M, int NW, int NQ, int LK = 16, bool TL = false>
 __device__ __attribute__((noinline)) void q8_finish_item(q8_kernarg_ptr ka, int tile, int slice) {
     constexpr int QT = q8_qt<M, NQ>();
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1011,13 +1074,14 @@ __device__ __attribute__((noinline)) void q8_finish_item(q8_kernarg_ptr ka, int 
     for (int q = wave; q < QT; q += NW) {
         const int b = tile * QT + q;
         // device-scope stores: the merging workgroup may sit on another XCD (own L2)
-        if (b < B && lane <= km1)
+        // (TL: b is the SLOT -- every slot of a used tile leaves its list, a pad slot's is empty; annlite_ivf_merge reads them by slot)
+        if ((TL || b < B) && lane <= km1)
             __hip_atomic_store(partial + ((int64_t)b * n_slices + slice) * k + lane,
                                ldsv<unsigned long long>(lds.list + 8u * (uint32_t)(q * LK + lane)), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
     }
     unsigned int *tile_done = ka->tile_done;
-    if constexpr (LK == 16)  // (64-key lists: the slices are merged by merge_partial_kernel -- the in-kernel merges hold 16 keys per lane row)
+    if constexpr (LK == 16 && !TL)  // (64-key lists: the slices are merged by merge_partial_kernel -- the in-kernel merges hold 16 keys per lane row)
     if (tile_done) {
         // the last of the tile's n_slices workgroups to arrive merges them
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have completed
@@ -1046,8 +1110,13 @@ __device__ __attribute__((noinline)) void q8_finish_item(q8_kernarg_ptr ka, int 
     }
 }
 
-template <int M, int NW, bool SKEWED, int NQ, int CB, bool RQ, int LK = 16>
+// TL (cell tiles, annlite_ivf_search_topk -- DESIGN 8c): a work item = one tile of up to 32 (query, cell) pairs that probe the SAME cell,
+// scanning that cell's rows (ScanArgs::tile_rows); slot q scans with the tables of query vmap[tile * 32 + q] (Q8Lds::qmap), the image is
+// assembled from the queries' own byte tables (q8_gather_table), gkey is indexed by QUERY -- the tiles of a query's other cells import
+// its bound --, no epoch ends (a cell is a few dozen steps), every slot's list goes to `partial` by slot (annlite_ivf_merge).
+template <int M, int NW, bool SKEWED, int NQ, int CB, bool RQ, int LK = 16, bool TL = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const ScanArgs a) {
+    static_assert(!TL || (M == 16 && NQ == 2 && CB == 1 && RQ && LK == 16), "cell tiles: the M = 16 row-queue kernel with 16-key lists");
     static_assert(LK == 16 || (LK == 64 && (RQ || M != 16) && M != 64), "64-key lists: M = 16 with the row queue (4-byte ring entries), M = 8 / 32");
     constexpr uint32_t RE = (uint32_t)q8_ring_entry_bytes<M, LK>();  // bytes of a ring entry
     constexpr bool WIDE = Q8Cfg<M>::WIDE;
@@ -1084,15 +1153,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
         const int item = blockIdx.x + it * gridDim.x;
         if (item >= a.n_items) break;
         int tile, slice;
-        if (!q8_item_map(a, item, tile, slice)) continue;
+        if constexpr (TL) {
+            tile = item, slice = 0;
+            if (a.tile_rows[2 * (int64_t)tile] < 0) continue;  // (tiles past the last used one)
+        } else if (!q8_item_map(a, item, tile, slice)) continue;
         if (a.guard && it > 0) {  // a launch that gave up (below) is redone by the launch behind it: no further items
             __syncthreads();
             if (tid == 0) ldsv_st<uint32_t>(lds.seen + 4, __hip_atomic_load(a.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             __syncthreads();
             if (ldsv<uint32_t>(lds.seen + 4) == 0u) break;
         }
-        const int64_t slice_begin = (int64_t)slice * a.slice_rows;
+        int64_t slice_begin = (int64_t)slice * a.slice_rows;
         int64_t slice_end = slice_begin + a.slice_rows;
+        if constexpr (TL) slice_begin = a.tile_rows[2 * (int64_t)tile], slice_end = a.tile_rows[2 * (int64_t)tile + 1];  // the tile's cell
         if (slice_end > a.N) slice_end = a.N;
         // blocks of 64 rows of this work item: its contiguous range, or (q8_ilv_log > 0) the runs of G = 2^q8_ilv_log blocks number
         // slice, slice + n_slices, ... of the table's ceil(N / 64) blocks
@@ -1118,7 +1191,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
         // quarter of the real slots are below q8_rebuild_8ths / 8 of what their table was built for.
         auto epoch_sync = [&](bool final) {
             __syncthreads();
-            if (final) return;
+            if (final || TL) return;
             if (wave == 0) {
                 const int q = lane & (QT - 1);
                 const bool real = tile * QT + q < a.B && lane < QT;
@@ -1129,7 +1202,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             }
             __syncthreads();
             if (ldsv<uint32_t>(lds.ctl)) {
-                q8_rebuild<M, NW, NQ, LK>(ka, tile, 0, slice);
+                q8_rebuild<M, NW, NQ, LK, TL>(ka, tile, 0, slice);
                 if (a.dbg && tid == 0) atomicAdd(a.dbg + 5, 1ull);
             }
         };
@@ -1142,7 +1215,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             ldsv_st<uint32_t>(lds.arrived(), 0);
             ldsv_st<uint32_t>(lds.blk_ctr(), 0);  // the block counter the scanning waves draw from
         }
-        q8_rebuild<M, NW, NQ, LK>(ka, tile, 1, slice);  // (its barriers cover the initialisation above)
+        q8_rebuild<M, NW, NQ, LK, TL>(ka, tile, 1, slice);  // (its barriers cover the initialisation above)
         stamp(1);
 
         // epochs end after steps q8_epoch0, q8_epoch0 * mul + (mul - 1), ... and after the last step
@@ -1159,10 +1232,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 // lane = (slot, half): all loads in flight together -- one global round trip per group of 8 slices for the
                 // whole tile
                 const int q = lane & 31, part = lane >> 5;
-                const int b = tile * QT + q;
-                const bool real = q < QT && b < a.B;
+                int b = tile * QT + q;
+                bool real = q < QT && b < a.B;
+                if constexpr (TL) {
+                    b = ldsv<int32_t>(lds.qmap + 4u * (uint32_t)q);
+                    real = b >= 0;
+                }
                 unsigned long long bound = ~0ull;
                 if (real) bound = __hip_atomic_load(a.gkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (TL: the key comes from ANOTHER cell's list, and the final order is by external id, which is ascending inside a cell only:
+                // a row of this cell at the same distance must still be accepted -- the bound is the distance alone)
+                if constexpr (TL) bound |= 0xffffffffull;
                 if constexpr (LK == 64) {
                     if (a.gk2 && a.n_slices > 1) {
                         const unsigned long long wb = q8_weighted_bound(a.gk2, b, a.n_slices, a.k, a.q8_pos, real);
@@ -1267,7 +1347,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             uint32_t n_batches = 0;
             int epoch = 0, epoch_step = a.q8_epoch0;  // the current epoch ends after step `epoch_step` (the last: after step n_steps - 1)
             for (;;) {
-                const bool final = epoch_step >= n_steps - 1;
+                const bool final = TL || epoch_step >= n_steps - 1;
                 const uint32_t want = (uint32_t)NS * (uint32_t)(epoch + 1);  // `arrived` is cumulative over the item
                 int idle = 0;
                 import_bounds();
@@ -1371,7 +1451,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                             ldsv_st<u32x2>(park, (u32x2){pmr[0], pmr[1]});
                             rowq_more = __ballot((pmr[0] | pmr[1]) != 0u) != 0;
                         }
-                        q8_consume<M, SKEWED, QT, CB, ROWQ, LK>(fc, lds, e, act, lane, n_kept, n_offered, pend_o, pend_j);
+                        q8_consume<M, SKEWED, QT, CB, ROWQ, LK, TL>(fc, lds, e, act, lane, n_kept, n_offered, pend_o, pend_j);
                         __builtin_amdgcn_s_setprio(0);
                         ++n_batches;
                         if (a.dbg) t_busy += __builtin_readcyclecounter() - t0;
@@ -1396,7 +1476,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                     }
                     __builtin_amdgcn_s_sleep(4);
                 }
-                q8_publish_global<QT, LK>(fc, lds, lane, pend_o, pend_j);
+                q8_publish_global<QT, LK, TL>(fc, lds, lane, pend_o, pend_j);
                 epoch_sync(final);
                 if (final) break;
                 if (ldsv<uint32_t>(lds.ctl)) {
@@ -1737,7 +1817,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             uint32_t n_slow = 0, n_push = 0;
             unsigned long long t_wait = 0;
             for (int epoch_step = a.q8_epoch0;; epoch_step = a.q8_epoch_mul * epoch_step + (a.q8_epoch_mul - 1)) {
-                const bool final = epoch_step >= n_steps - 1;
+                const bool final = TL || epoch_step >= n_steps - 1;
                 const uint32_t end_blk = final ? n_blocks : (uint32_t)NS * (uint32_t)(epoch_step + 1);
                 for (; b_cur < end_blk; ++it_no) {
                     const uint32_t row0 = blk_row(b_cur);  // (< s_end: b_cur < n_blocks)
@@ -1910,7 +1990,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             }
         }
 
-        q8_finish_item<M, NW, NQ, LK>(ka, tile, slice);
+        q8_finish_item<M, NW, NQ, LK, TL>(ka, tile, slice);
         if (a.dbg && tid == 0) {
             // [8] 2^62 - earliest start, [9] latest end, sums over the work items: [10] start, [11] init + first table build,
             // [12] thread 0's step loop, [13] its wait at the last barrier (the consumer's backlog, the slower waves),
@@ -1972,16 +2052,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
 
 using namespace annlite;
 
-template <int M, int NW, bool SKEWED, int NQ, int CB, bool RQ = false, int LK = 16>
+template <int M, int NW, bool SKEWED, int NQ, int CB, bool RQ = false, int LK = 16, bool TL = false>
 static int launch_q8(const ScanArgs &a, int grid, hipStream_t st) {
     constexpr int QT = 32;  // (the control block is laid out for 32 slots whatever the kernel uses)
     // (the row queue's parking area, 3072 B behind everything else, exists only for the kernels that run it: the 128 KB tables of
     // M = 32 / M = 8 with uint16 codes + 16 KB of 64-key lists + the 8 KB ring fit the 160 KB without it)
     const size_t need = (size_t)(M == 64 ? (a.Ks + 1) * 512 : M == 32 ? 131072 : (M == 16 && NQ == 2) ? kQ8Image16 : a.Ks * NQ * M * 16) + 1664 +
                         (size_t)QT * LK * 8 + QT * 8 +
-                        (size_t)kRingSize * q8_ring_entry_bytes<M, LK>() + 4 * 128 * 9 + 32 + 32 + 16 + ((RQ || LK == 16) ? 3072 : 0);
+                        (size_t)kRingSize * q8_ring_entry_bytes<M, LK>() + 4 * 128 * 9 + 32 + 32 + 16 + ((RQ || LK == 16) ? 3072 : 0) + (TL ? 128 : 0);
     ANNLITE_REQUIRE(need <= 160 * 1024, "byte-table kernel: %zu B of LDS", need);
-    auto fn = adc_scan_q8_kernel<M, NW, SKEWED, NQ, CB, RQ, LK>;
+    auto fn = adc_scan_q8_kernel<M, NW, SKEWED, NQ, CB, RQ, LK, TL>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(NW * 64), need, st, a);
     return launch_status("adc_scan_q8_kernel");
@@ -1995,6 +2075,12 @@ int annlite::launch_q8_scan(int id, bool sk, const ScanArgs &a, int grid, hipStr
             // re-rank leg ran at 513 k q/s instead of 554 k
             if (a.gkey) return sk ? launch_q8<16, 16, true, 2, 1, true>(a, grid, st) : launch_q8<16, 16, false, 2, 1, true>(a, grid, st);
             return sk ? launch_q8<16, 16, true, 2, 1>(a, grid, st) : launch_q8<16, 16, false, 2, 1>(a, grid, st);
+        case 1651:  // M = 16, k <= 16, cell tiles (annlite_ivf_search_topk): one work item per tile of (query, cell) pairs
+            if (!a.gkey || !a.tile_rows || !a.vmap || !a.btab || !a.gseed0 || a.tile_done || a.gk2 || a.guard) {
+                set_error("the cell-tile kernel needs vmap / tile_rows / per-query byte tables and shared bounds by query");
+                return ANNLITE_ERR_UNSUPPORTED;
+            }
+            return sk ? launch_q8<16, 16, true, 2, 1, true, 16, true>(a, grid, st) : launch_q8<16, 16, false, 2, 1, true, 16, true>(a, grid, st);
         case 1664:  // M = 16, 16 < k <= 64: 64-key lists (one insertion per wave operation), the slices merged by merge_partial_kernel
             if (!a.gkey || a.tile_done) { set_error("the 64-key-list kernel serves the shared-bound search without an in-kernel merge"); return ANNLITE_ERR_UNSUPPORTED; }
             return sk ? launch_q8<16, 16, true, 2, 1, true, 64>(a, grid, st) : launch_q8<16, 16, false, 2, 1, true, 64>(a, grid, st);

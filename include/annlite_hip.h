@@ -517,6 +517,38 @@ ANNLITE_API int annlite_ivf_candidate_ids(const uint32_t *cand_dev, int64_t cand
                               const int32_t *slot_of_dev, int64_t B, int64_t P, const int64_t *row_ids_dev,
                               int64_t id_base, int64_t *out_ids_dev, int64_t R, void *stream);
 
+/* (round 6) The pruned search over cells on the BYTE-TABLE kernel, one call: annlite_ivf_plan (tiles of 32 slots that probe one
+ * cell each) -> ONE preparation launch (L2 tables of the B real queries, quantisation parameters, every query's first bound from
+ * rows of its NEAREST cell -- a bound from rows outside the probed cells would be wrong --, its byte table) -> the scan in cell
+ * tiles (exact ascending-m fp32 sums, space_pq.h:32-35 / pq_bindings.pyx:44-45, of the rows that pass the byte filter; a 16-key
+ * list per slot; the bounds shared between the tiles of a QUERY's cells) -> annlite_ivf_merge_lists.  Result: for every query the
+ * exact top-k, under the fixed order (distance asc, id asc), of the rows of its P probed cells -- bit-equal to
+ * annlite_pq_search_tiles + annlite_ivf_rescore and to the oracle's ivf_search.
+ *   cells_dev      i32 [B][P]  the probed cells, nearest first (annlite_ivf_select_cells)
+ *   codes_dev      u8 [N][16]  the CELL-SORTED table (cell c = rows [cell_rows[c][0], cell_rows[c][1]), begin a multiple of 64), in
+ *                  codes_layout; valid_bits_dev (may be NULL): bitmap over TABLE rows; row_ids_dev i64 [N] (may be NULL): external id
+ *                  of every table row, ascending inside a cell
+ *   cell_order_dev i32 [C]     cells by descending size (the plan's tile order)
+ *   flags: ANNLITE_FLAG_SQRT.  Serves M = 16, Ks <= 256, k <= 16, squared-L2 tables built from queries and codebooks (D <= 256,
+ *   sub-vectors of a multiple of 4 floats); other shapes: annlite_pq_search_tiles + annlite_ivf_rescore.
+ * replaces: _cell_selection's consumers -- the per-cell search loop and the hstack / argsort merge of CellContainer.ivf_search
+ * (annlite/container.py:88-144) with n_probe < n_cells. */
+ANNLITE_API int annlite_ivf_search_topk_workspace_bytes(int64_t B, int64_t P, int64_t C, int64_t M, int64_t Ks, int64_t k,
+                                            int64_t *bytes);
+ANNLITE_API int annlite_ivf_search_topk(const float *queries_dev, int64_t B, int64_t D, const float *codebooks_dev, int64_t M,
+                            int64_t Ks, const void *codes_dev, int codes_layout, int64_t N, const uint32_t *valid_bits_dev,
+                            const int32_t *cells_dev, int64_t P, int64_t C, const int64_t *cell_rows_dev,
+                            const int32_t *cell_order_dev, const int64_t *row_ids_dev, int64_t id_base, int64_t k,
+                            float *out_dist_dev, int64_t *out_id_dev, int flags, void *workspace_dev, size_t workspace_bytes,
+                            void *stream);
+
+/* Merge of per-slot lists: lists_dev u64 [V][k] (ordered distance << 32 | table row, ascending, ~0 = none: what the cell-tile scan
+ * leaves per slot) -> per query the k smallest of its P slots' keys re-keyed by external id (id_base + row_ids[row]); one wave per
+ * query.  replaces: the concatenate + sort at the end of CellContainer.ivf_search (annlite/container.py:131-144). */
+ANNLITE_API int annlite_ivf_merge_lists(const uint64_t *lists_dev, int64_t k, const int32_t *slot_of_dev, int64_t B, int64_t P,
+                            const int64_t *row_ids_dev, int64_t id_base, float *out_dist_dev, int64_t *out_id_dev, int flags,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif
