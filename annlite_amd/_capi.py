@@ -75,6 +75,8 @@ SYMBOLS = (
     'annlite_ivf_select_cells',
     'annlite_ivf_max_tiles',
     'annlite_ivf_plan',
+    'annlite_ivf_max_tiles_first',
+    'annlite_ivf_plan_first',
     'annlite_pq_search_tiles_workspace_bytes',
     'annlite_pq_search_tiles',
     'annlite_ivf_rescore',
@@ -177,6 +179,8 @@ def lib() -> ctypes.CDLL:
     L.annlite_ivf_select_cells.argtypes = [i32, vp, i64, i64, vp, i64, i64, vp, vp]
     L.annlite_ivf_max_tiles.argtypes = [i64, i64, i64, i64]
     L.annlite_ivf_plan.argtypes = [vp, i64, i64, i64, i64, vp, vp, i64, vp, vp, vp, vp, vp]
+    L.annlite_ivf_max_tiles_first.argtypes = [i64, i64, i64, i64]
+    L.annlite_ivf_plan_first.argtypes = [vp, i64, i64, i64, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp]
     L.annlite_pq_search_tiles_workspace_bytes.argtypes = [i64, i64, i64, i32, i64, i64, ctypes.POINTER(ctypes.c_int64)]
     L.annlite_pq_search_tiles.argtypes = [i32, vp, i64, i64, vp, vp, i32, i32, i64, i64, i64, vp, i64, i64, vp, vp, vp,
                                           i64, vp, vp, sz, vp]
@@ -200,7 +204,7 @@ def lib() -> ctypes.CDLL:
     L.annlite_graph_search_stats_ex.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     for name in SYMBOLS:
         fn = getattr(L, name)  # AttributeError here == the .so does not export a declared symbol
-        if name == 'annlite_ivf_max_tiles':
+        if name in ('annlite_ivf_max_tiles', 'annlite_ivf_max_tiles_first'):
             fn.restype = i64
         elif name not in ('annlite_hip_last_error',):
             fn.restype = i32

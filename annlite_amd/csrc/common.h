@@ -72,6 +72,8 @@ struct Knobs {
     bool no_cand_seed;          // ANNLITE_NO_CAND_SEED (A/B: the candidate generator with per-slice seeds and its own table builds, as before round 6)
     int graph_hash_bits;        // ANNLITE_GRAPH_HASH_BITS
     bool graph_seq_insert;      // ANNLITE_GRAPH_SEQ_INSERT
+    bool ivf_static_tiles;      // ANNLITE_IVF_STATIC_TILES (A/B: the cell tiles dealt round-robin instead of drawn from a counter)
+    int ivf_first;              // ANNLITE_IVF_FIRST (annlite_ivf_search_topk: probes per query whose tiles come first; -1: the default)
 };
 const Knobs &knobs();
 

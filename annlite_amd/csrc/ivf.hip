@@ -98,16 +98,54 @@ __global__ __launch_bounds__(256) void ivf_select_cells_kernel(const float *__re
 //   slot_of[i]   slot of pair i = (query i / P, probe i % P) [n_pairs]
 //   tile_rows[t] (begin, end) of the tile's cell, begin = -1 for tiles past the last used one
 // The slot order inside a cell depends on atomic arrival order; results do not (every slot has its own list).
-__global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *__restrict__ cells, int n_pairs, int P, int C,
+// n_first > 0 (annlite_ivf_search_topk): the pairs of every query's n_first NEAREST cells (probe ranks < n_first) get tiles of their own,
+// and those tiles come FIRST -- the scan shares a query's bound between its tiles, and the k best rows of the nearest cells bound the
+// others' candidates from the start.  Internally 2 C "virtual cells": v = c (first class) or C + c, walked in `order` twice.
+__device__ __forceinline__ void ivf_plan_body(const int32_t *__restrict__ cells, int n_pairs, int P, int C_real,
                                                        int qt, const int64_t *__restrict__ cell_rows,
-                                                       const int32_t *__restrict__ order, int n_tiles_max,
+                                                       const int32_t *__restrict__ order_real, int n_tiles_max,
                                                        int32_t *__restrict__ vmap, int32_t *__restrict__ slot_of,
-                                                       int64_t *__restrict__ tile_rows, int32_t *__restrict__ n_tiles_used) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+                                                       int64_t *__restrict__ tile_rows, int32_t *__restrict__ n_tiles_used,
+                                                       int n_first, unsigned char *smem) {
+    const int C = n_first > 0 ? 2 * C_real : C_real;  // virtual cells
     int *cnt = (int *)smem;        // [C] pairs per cell
     int *tstart = cnt + C;         // [C] first tile of the cell
     int *wsum = tstart + C;        // [16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto vcell = [&](int i) -> int {  // virtual cell of pair i
+        const int c = (unsigned)cells[i] < (unsigned)C_real ? cells[i] : 0;
+        return (n_first > 0 && i % P >= n_first) ? C_real + c : c;
+    };
+    auto order = [&](int j) -> int { return j < C_real ? order_real[j] : C_real + order_real[j - C_real]; };
+    // (round 6) latency, not work, is what this single workgroup costs (it ran 24 us for 16384 pairs: every pair went cell load ->
+    // LDS atomic -> store -> reload, one dependent global round trip per loop iteration).  Up to kReg pairs per thread now stay in
+    // REGISTERS between the two passes (their loads all in flight together), and the cells' order / row ranges are requested before
+    // the first barrier; larger batches keep the loops through memory.
+    constexpr int kReg = 16, kCellReg = 4;
+    const bool in_regs = n_pairs <= 1024 * kReg;
+    const int per = (C + 1023) / 1024;  // cells per thread in the scan of the tile counts; thread t owns positions [t*per, (t+1)*per)
+    const bool cells_in_regs = per <= kCellReg;
+    int vc[kReg], rk[kReg];
+    int c_loc[kCellReg];
+    int64_t rb_loc[kCellReg], re_loc[kCellReg];
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < kReg; ++u) {
+            const int i = u * 1024 + tid;
+            vc[u] = i < n_pairs ? vcell(i) : -1;
+        }
+    }
+    if (cells_in_regs) {
+#pragma unroll
+        for (int u = 0; u < kCellReg; ++u) {
+            const int j = tid * per + u;
+            c_loc[u] = -1, rb_loc[u] = re_loc[u] = 0;
+            if (u < per && j < C) {
+                const int c = order(j), cr = c < C_real ? c : c - C_real;
+                c_loc[u] = c, rb_loc[u] = cell_rows[2 * cr], re_loc[u] = cell_rows[2 * cr + 1];
+            }
+        }
+    }
     for (int i = tid; i < C; i += 1024) cnt[i] = 0;
     for (int i = tid; i < n_tiles_max * qt; i += 1024) vmap[i] = -1;
     for (int i = tid; i < n_tiles_max; i += 1024) {
@@ -115,14 +153,24 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *__restric
         tile_rows[2 * i + 1] = -1;
     }
     __syncthreads();
-    for (int i = tid; i < n_pairs; i += 1024) slot_of[i] = atomicAdd(&cnt[(unsigned)cells[i] < (unsigned)C ? cells[i] : 0], 1);  // rank inside the cell
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < kReg; ++u) rk[u] = vc[u] >= 0 ? atomicAdd(&cnt[vc[u]], 1) : 0;  // rank inside the (virtual) cell
+    } else {
+        for (int i = tid; i < n_pairs; i += 1024) slot_of[i] = atomicAdd(&cnt[vcell(i)], 1);
+    }
     __syncthreads();
-    // exclusive scan of the tile counts in `order`; thread t owns positions [t*per, (t+1)*per)
-    const int per = (C + 1023) / 1024;
+    // exclusive scan of the tile counts in `order`
     int local = 0;
-    for (int u = 0; u < per; ++u) {
-        const int j = tid * per + u;
-        if (j < C) local += (cnt[order[j]] + qt - 1) / qt;
+    if (cells_in_regs) {
+#pragma unroll
+        for (int u = 0; u < kCellReg; ++u)
+            if (c_loc[u] >= 0) local += (cnt[c_loc[u]] + qt - 1) / qt;
+    } else {
+        for (int u = 0; u < per; ++u) {
+            const int j = tid * per + u;
+            if (j < C) local += (cnt[order(j)] + qt - 1) / qt;
+        }
     }
     int incl = local;
 #pragma unroll
@@ -135,28 +183,57 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *__restric
     int base = 0;
     for (int w = 0; w < wave; ++w) base += wsum[w];
     int run = base + incl - local;
-    for (int u = 0; u < per; ++u) {
-        const int j = tid * per + u;
-        if (j < C) {
-            const int c = order[j];
-            const int nt = (cnt[c] + qt - 1) / qt;
-            tstart[c] = run;
-            const int64_t rb = cell_rows[2 * c], re = cell_rows[2 * c + 1];
-            for (int t = 0; t < nt; ++t) {
-                tile_rows[2 * (int64_t)(run + t)] = rb;
-                tile_rows[2 * (int64_t)(run + t) + 1] = re;
+    auto place = [&](int c, int64_t rb, int64_t re) {
+        const int nt = (cnt[c] + qt - 1) / qt;
+        tstart[c] = run;
+        for (int t = 0; t < nt; ++t) {
+            tile_rows[2 * (int64_t)(run + t)] = rb;
+            tile_rows[2 * (int64_t)(run + t) + 1] = re;
+        }
+        run += nt;
+    };
+    if (cells_in_regs) {
+#pragma unroll
+        for (int u = 0; u < kCellReg; ++u)
+            if (c_loc[u] >= 0) place(c_loc[u], rb_loc[u], re_loc[u]);
+    } else {
+        for (int u = 0; u < per; ++u) {
+            const int j = tid * per + u;
+            if (j < C) {
+                const int c = order(j), cr = c < C_real ? c : c - C_real;
+                place(c, cell_rows[2 * cr], cell_rows[2 * cr + 1]);
             }
-            run += nt;
         }
     }
     if (tid == 1023 && n_tiles_used) *n_tiles_used = run;
     __syncthreads();
-    for (int i = tid; i < n_pairs; i += 1024) {
-        const int r = slot_of[i];
-        const int v = (tstart[(unsigned)cells[i] < (unsigned)C ? cells[i] : 0] + r / qt) * qt + r % qt;
-        slot_of[i] = v;
-        vmap[v] = i / P;
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < kReg; ++u) {
+            const int i = u * 1024 + tid;
+            if (vc[u] >= 0) {
+                const int v = (tstart[vc[u]] + rk[u] / qt) * qt + rk[u] % qt;
+                slot_of[i] = v;
+                vmap[v] = i / P;
+            }
+        }
+    } else {
+        for (int i = tid; i < n_pairs; i += 1024) {
+            const int r = slot_of[i];
+            const int v = (tstart[vcell(i)] + r / qt) * qt + r % qt;
+            slot_of[i] = v;
+            vmap[v] = i / P;
+        }
     }
+}
+__global__ __launch_bounds__(1024) void ivf_plan_kernel(const int32_t *__restrict__ cells, int n_pairs, int P, int C_real,
+                                                       int qt, const int64_t *__restrict__ cell_rows,
+                                                       const int32_t *__restrict__ order_real, int n_tiles_max,
+                                                       int32_t *__restrict__ vmap, int32_t *__restrict__ slot_of,
+                                                       int64_t *__restrict__ tile_rows, int32_t *__restrict__ n_tiles_used,
+                                                       int n_first) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ivf_plan_body(cells, n_pairs, P, C_real, qt, cell_rows, order_real, n_tiles_max, vmap, slot_of, tile_rows, n_tiles_used, n_first, smem);
 }
 
 // ---- exact re-score of a query's candidate lists ---------------------------------------------------
@@ -343,24 +420,39 @@ extern "C" int64_t annlite_ivf_max_tiles(int64_t B, int64_t P, int64_t C, int64_
     // every probed cell has at most one partly filled tile
     return pairs / qt + (C < pairs ? C : pairs);
 }
+// ... with the nearest cells' pairs in tiles of their own (annlite_ivf_plan_first): two classes of cells
+extern "C" int64_t annlite_ivf_max_tiles_first(int64_t B, int64_t P, int64_t C, int64_t qt) {
+    if (B <= 0 || P <= 0 || C <= 0 || qt <= 0) return 0;
+    const int64_t pairs = B * P;
+    return pairs / qt + (2 * C < pairs ? 2 * C : pairs);
+}
 
 extern "C" int annlite_ivf_plan(const int32_t *cells_dev, int64_t B, int64_t P, int64_t C, int64_t qt,
                                 const int64_t *cell_rows_dev, const int32_t *cell_order_dev, int64_t n_tiles_max,
                                 int32_t *vmap_dev, int32_t *slot_of_dev, int64_t *tile_rows_dev, int32_t *n_tiles_used_dev,
                                 void *stream) {
-    ANNLITE_REQUIRE(B >= 0 && P >= 1 && C >= 1 && C <= 16384 && qt >= 1, "bad shape B=%lld P=%lld C=%lld qt=%lld",
-                    (long long)B, (long long)P, (long long)C, (long long)qt);
-    ANNLITE_REQUIRE(n_tiles_max >= annlite_ivf_max_tiles(B, P, C, qt), "n_tiles_max=%lld too small (annlite_ivf_max_tiles)",
-                    (long long)n_tiles_max);
+    return annlite_ivf_plan_first(cells_dev, B, P, C, qt, cell_rows_dev, cell_order_dev, n_tiles_max, vmap_dev, slot_of_dev, tile_rows_dev,
+                                  n_tiles_used_dev, 0, stream);
+}
+
+extern "C" int annlite_ivf_plan_first(const int32_t *cells_dev, int64_t B, int64_t P, int64_t C, int64_t qt,
+                                      const int64_t *cell_rows_dev, const int32_t *cell_order_dev, int64_t n_tiles_max,
+                                      int32_t *vmap_dev, int32_t *slot_of_dev, int64_t *tile_rows_dev, int32_t *n_tiles_used_dev,
+                                      int64_t n_first, void *stream) {
+    ANNLITE_REQUIRE(B >= 0 && P >= 1 && C >= 1 && C <= 16384 && qt >= 1 && n_first >= 0, "bad shape B=%lld P=%lld C=%lld qt=%lld n_first=%lld",
+                    (long long)B, (long long)P, (long long)C, (long long)qt, (long long)n_first);
+    if (n_first >= P) n_first = 0;  // (every pair in the first class: one class)
+    ANNLITE_REQUIRE(n_tiles_max >= (n_first > 0 ? annlite_ivf_max_tiles_first(B, P, C, qt) : annlite_ivf_max_tiles(B, P, C, qt)),
+                    "n_tiles_max=%lld too small (annlite_ivf_max_tiles / _first)", (long long)n_tiles_max);
     ANNLITE_REQUIRE(B * P < (1ll << 31) && n_tiles_max * qt < (1ll << 31), "too many (query, cell) pairs");
     if (B == 0) return ANNLITE_OK;
     ANNLITE_REQUIRE(cells_dev && cell_rows_dev && cell_order_dev && vmap_dev && slot_of_dev && tile_rows_dev,
                     "null device pointer");
-    const size_t lds = (size_t)(2 * C + 16) * 4;
+    const size_t lds = (size_t)(2 * (n_first > 0 ? 2 * C : C) + 16) * 4;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)ivf_plan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, cells_dev, (int)(B * P), (int)P, (int)C,
                        (int)qt, cell_rows_dev, cell_order_dev, (int)n_tiles_max, vmap_dev, slot_of_dev, tile_rows_dev,
-                       n_tiles_used_dev);
+                       n_tiles_used_dev, (int)n_first);
     return launch_status("ivf_plan_kernel");
 }
 

@@ -1660,7 +1660,7 @@ extern "C" int annlite_pq_search_tiles(int lut_kind, const float *queries_dev, i
 constexpr int kIvfQt = 32;
 static size_t ivf_topk_carve(int64_t B, int64_t P, int64_t C, int64_t Ks, int64_t k, char *base, char **ptrs /* [13] */) {
     const int64_t bpad = pad_queries(B, kIvfQt);
-    const int64_t T = annlite_ivf_max_tiles(B, P, C, kIvfQt), V = T * kIvfQt;
+    const int64_t T = annlite_ivf_max_tiles_first(B, P, C, kIvfQt), V = T * kIvfQt;
     const int64_t sizes[13] = {V * k * 8, bpad * 8, bpad * 8, bpad * 4, bpad * 4, bpad * 8, bpad * 16 * 4, bpad * Ks * 16 * 4, bpad * Ks * 16,
                                V * 4, B * P * 4, T * 16, 256};
     size_t off = 0;
@@ -1705,24 +1705,33 @@ extern "C" int annlite_ivf_search_topk(const float *queries_dev, int64_t B, int6
         return ANNLITE_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    const int64_t T = annlite_ivf_max_tiles(B, P, C, kIvfQt);
+    const int64_t T = annlite_ivf_max_tiles_first(B, P, C, kIvfQt);
     unsigned long long *lists = (unsigned long long *)ptr[0], *gkey = (unsigned long long *)ptr[1], *gseed0 = (unsigned long long *)ptr[2];
     float *qstep = (float *)ptr[3], *smax = (float *)ptr[4], *qlom = (float *)ptr[6], *lut = (float *)ptr[7];
     double *qlo = (double *)ptr[5];
     uint8_t *bq = (uint8_t *)ptr[8];
     int32_t *vmap = (int32_t *)ptr[9], *slot_of = (int32_t *)ptr[10], *n_used = (int32_t *)ptr[12];
     int64_t *tile_rows = (int64_t *)ptr[11];
-    int rc = annlite_ivf_plan(cells_dev, B, P, C, kIvfQt, cell_rows_dev, cell_order_dev, T, vmap, slot_of, tile_rows, n_used, stream);
-    if (rc != ANNLITE_OK) return rc;
     const Knobs &kn = knobs();
+    // the tiles of every query's nearest cells first (ANNLITE_IVF_FIRST = 0 .. P - 1 probes in the first class; measurements)
+    // (measured, profiles/r06/ivf_first_tiles_ab.txt: slower at 1 / 2 / 4 -- the first class adds a scan of every cell for a few slots each
+    // and the candidates do not shrink in proportion: off by default)
+    int64_t n_first = kn.ivf_first >= 0 ? kn.ivf_first : 0;
+    if (n_first >= P) n_first = 0;
+    // (the plan as an extra workgroup of the preparation launch was measured too: that launch fills every CU with one workgroup each, the
+    // extra one ran behind them -- 93.7 us against 69 + 24)
+    int rc = annlite_ivf_plan_first(cells_dev, B, P, C, kIvfQt, cell_rows_dev, cell_order_dev, T, vmap, slot_of, tile_rows, n_used, n_first, stream);
+    if (rc != ANNLITE_OK) return rc;
     // seed rows: S / 4 per query from its nearest cell (the workgroup's four queries share the launch's blocks)
-    int64_t S = 32768;
+    // (10M rows, 16 of 256 cells, scan kernel / whole call at 16k / 32k / 64k / 128k: 0.307 / 0.263 / 0.212 / 0.193 and 0.378 / 0.347 / 0.323 / 0.349 ms)
+    int64_t S = 65536;
     if (kn.seed_rows_set && kn.seed_rows >= 256) S = kn.seed_rows;
     const int target = (kn.q8_target >= 16 && kn.q8_target <= 127) ? kn.q8_target : 88;
     const LutBuild lb = {queries_dev, codebooks_dev, D};
     const bool sk = codes_layout == ANNLITE_CODES_SKEWED;
+    unsigned int *item_counter = (unsigned int *)(n_used + 16);
     rc = launch_seed_build_cells(sk, codes_dev, S, N, valid_bits_dev, lb, lut, B, Ks, k, qstep, qlo, smax, qlom, gkey, st, gseed0, bq, target,
-                                 cells_dev, P, cell_rows_dev);
+                                 cells_dev, P, cell_rows_dev, item_counter);
     if (rc != ANNLITE_OK) return rc;
     ScanArgs a = {};
     a.codes = codes_dev;
@@ -1746,6 +1755,7 @@ extern "C" int annlite_ivf_search_topk(const float *queries_dev, int64_t B, int6
     a.jm1 = 0;
     a.tile_rows = tile_rows;
     a.vmap = vmap;
+    a.item_counter = kn.ivf_static_tiles ? nullptr : item_counter;  // (NULL: the tiles dealt round-robin -- A/B)
     a.gseed0 = gseed0;
     a.btab = bq;
     a.q8_epoch0 = 1 << 28;  // (no epoch ends in a cell tile)
@@ -1757,6 +1767,12 @@ extern "C" int annlite_ivf_search_topk(const float *queries_dev, int64_t B, int6
     a.q8_thw_mask = 1;
     a.flush_mask = 63;
     a.dbg_skip = kn.debug_skip;
+    if (kn.debug_counters) {  // (ANNLITE_DEBUG_COUNTERS: the scan's event counters / per-item stamps, as scan_partial wires them)
+        if (!g_dbg) ANNLITE_HIP_TRY(hipMalloc((void **)&g_dbg, 128 + 4096 * 64));
+        ANNLITE_HIP_TRY(hipMemsetAsync(g_dbg, 0, 128, st));
+        a.dbg = g_dbg;
+        if (kn.debug_counters == 2) a.dbg_skip |= 8;
+    }
     if (kn.q8_tune_ok) a.q8_import_mask = kn.q8_tune[3];
     const int n_cu = device_cu_count();
     const int grid = (int)(T < n_cu ? T : n_cu);

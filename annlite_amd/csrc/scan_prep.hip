@@ -142,6 +142,7 @@ struct SeedBuild {
     const int64_t *cell_rows;    // [C][2] (begin: multiple of 64, end)
     int32_t n_probe;
     uint8_t *bq;                 // [ceil4(B)][Ks][M] byte tables quantised for gseed0 (q8_gather_table assembles a tile's image from them)
+    unsigned int *item_counter;  // reset to 0 for the scan behind this launch (its workgroups draw their cell tiles from it)
 };
 // BUILD (round 6): the seed bound from the rows an MFMA launch has nominated (seed_mfma.hip) instead of from S seed rows this
 // kernel scans itself.  Query p of the workgroup's 4 takes ceil(n_cand / 64) wave-iterations: lane = nominee; a row's sums run in
@@ -233,6 +234,9 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
     static_assert(!BUILD || (QPB == 4 && !CODE16 && M <= 16), "the fused build serves the byte-table plan");
     static_assert(!CELLS || (BUILD && M == 16), "per-cell seeds: the fused build of the M = 16 byte-table plan");
     if (sb.gate && __hip_atomic_load(sb.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    if constexpr (CELLS) {
+        if (sb.item_counter && blockIdx.x == 0 && threadIdx.x == 0) *sb.item_counter = 0u;
+    }
     auto stamp = [&](int i) {
         if constexpr (BUILD) {
             if (sb.dbg && threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
@@ -520,7 +524,10 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
 #pragma unroll
             for (int i = 0; i < CH; ++i) d += v[i];  // (the lane's skewed order: see the kernel's header)
         });
-        if constexpr (CELLS) {  // the block's rows are seed rows of ONE of the four queries
+        if constexpr (CELLS) {
+            // the block's rows are seed rows of ONE of the four queries.  (Evaluating only that query's sum -- 16 four-byte look-ups, 16
+            // adds, the query's column as the instruction's offset, one copy of the look-ups per query behind a scalar branch -- was
+            // SLOWER: 81.9 against ~69 us per launch at 65536 rows; four lanes of a wave share a sub-space: 4-way bank conflicts)
             const int i = (int)(b_cur & 3u);
 #pragma unroll
             for (int q = 0; q < QPB; ++q) bestf[q] = fminf(bestf[q], (ok && q == i) ? d[q] : __builtin_inff());
@@ -1121,7 +1128,8 @@ int annlite::launch_seed_build(bool skw, const void *codes_dev, int64_t S, int64
 int annlite::launch_seed_build_cells(bool skw, const void *codes_dev, int64_t S, int64_t N, const uint32_t *valid_bits_dev,
                                      const LutBuild &build, float *lut_out, int64_t B, int64_t Ks, int64_t k, float *qstep, double *qlo,
                                      float *smax, float *qlom, unsigned long long *gk, hipStream_t st, unsigned long long *gseed0,
-                                     uint8_t *bq, int target, const int32_t *cells, int64_t n_probe, const int64_t *cell_rows) {
+                                     uint8_t *bq, int target, const int32_t *cells, int64_t n_probe, const int64_t *cell_rows,
+                                     unsigned int *item_counter) {
     constexpr int M = 16;
     SeedBuild sb = {};
     sb.queries = build.queries;
@@ -1142,8 +1150,9 @@ int annlite::launch_seed_build_cells(bool skw, const void *codes_dev, int64_t S,
     sb.cell_rows = cell_rows;
     sb.n_probe = (int32_t)n_probe;
     sb.bq = bq;
-    auto fn = skw ? seed_bound_kernel<M, true, 4, false, true, true> : seed_bound_kernel<M, false, 4, false, true, true>;
+    sb.item_counter = item_counter;
     const size_t lds = (size_t)Ks * M * 16 + (size_t)kSeedLdsExtra;
+    auto fn = skw ? seed_bound_kernel<M, true, 4, false, true, true> : seed_bound_kernel<M, false, 4, false, true, true>;
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned n_g4 = (unsigned)(((B + 15) / 16) * 4);
     hipLaunchKernelGGL(fn, dim3(n_g4, 1), dim3(kSeedWaves * 64), lds, st, (const uint8_t *)codes_dev, S, valid_bits_dev,

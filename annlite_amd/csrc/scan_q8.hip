@@ -1150,12 +1150,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
         }
     }
     for (int it = 0;; ++it) {
-        const int item = blockIdx.x + it * gridDim.x;
+        int item = blockIdx.x + it * gridDim.x;
+        // TL: the tiles come longest first; a workgroup's first one is its own index, the later ones are DRAWN from a device counter (the
+        // consumer wave requests the next number at the start of an item -- behind its first import -- and leaves it in LDS)
+        if constexpr (TL) {
+            if (it > 0 && a.item_counter) item = (int)ldsv<uint32_t>(lds.seen + 8);
+        }
         if (item >= a.n_items) break;
         int tile, slice;
         if constexpr (TL) {
             tile = item, slice = 0;
-            if (a.tile_rows[2 * (int64_t)tile] < 0) continue;  // (tiles past the last used one)
+            if (a.tile_rows[2 * (int64_t)tile] < 0) break;  // (tiles past the last used one: the used ones come first)
         } else if (!q8_item_map(a, item, tile, slice)) continue;
         if (a.guard && it > 0) {  // a launch that gave up (below) is redone by the launch behind it: no further items
             __syncthreads();
@@ -1350,7 +1355,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
                 const bool final = TL || epoch_step >= n_steps - 1;
                 const uint32_t want = (uint32_t)NS * (uint32_t)(epoch + 1);  // `arrived` is cumulative over the item
                 int idle = 0;
+                uint32_t next_item = 0u;
+                if constexpr (TL) {
+                    if (a.item_counter && lane == 0)
+                        next_item = gridDim.x + __hip_atomic_fetch_add(a.item_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 import_bounds();
+                if constexpr (TL) {
+                    if (a.item_counter && lane == 0) ldsv_st<uint32_t>(lds.seen + 8, next_item);
+                }
                 for (;;) {
                     const uint32_t arrived = ldsv<uint32_t>(lds.arrived());  // (read BEFORE the tails: a wave pushes, then arrives)
                     const uint32_t tail_v = has_ring ? ldsv<uint32_t>(lds.tails() + 4u * (uint32_t)my_ring) : 0u;

@@ -475,6 +475,16 @@ ANNLITE_API int annlite_ivf_plan(const int32_t *cells_dev, int64_t B, int64_t P,
                      int32_t *vmap_dev, int32_t *slot_of_dev, int64_t *tile_rows_dev, int32_t *n_tiles_used_dev,
                      void *stream);
 
+/* ... with two classes of tiles: the pairs of every query's n_first nearest cells (probe ranks < n_first) in tiles of their own that
+ * come FIRST, the other pairs behind them (annlite_ivf_search_topk: the scan shares a query's bound between its tiles; the k best
+ * rows of the nearest cells then bound the candidates of the others from the start).  n_tiles_max >= annlite_ivf_max_tiles_first.
+ * n_first = 0 or >= P: annlite_ivf_plan. */
+ANNLITE_API int64_t annlite_ivf_max_tiles_first(int64_t B, int64_t P, int64_t C, int64_t qt);
+ANNLITE_API int annlite_ivf_plan_first(const int32_t *cells_dev, int64_t B, int64_t P, int64_t C, int64_t qt,
+                           const int64_t *cell_rows_dev, const int32_t *cell_order_dev, int64_t n_tiles_max,
+                           int32_t *vmap_dev, int32_t *slot_of_dev, int64_t *tile_rows_dev, int32_t *n_tiles_used_dev,
+                           int64_t n_first, void *stream);
+
 /* The scan of annlite_pq_search_topk where query tile t = slots [t*qt, (t+1)*qt) scans ONLY rows
  * tile_rows[t] (one work item per tile, handed out dynamically) -- with INTEGER sums only: a tile is
  * too short to amortise exact fp32 recomputes.  The kernel keeps, per slot, the k smallest integer

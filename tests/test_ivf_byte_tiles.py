@@ -29,6 +29,7 @@ def _both(idx, q, k, P, indices=None):
     (64, 8, 1, 3, 1, 5000),           # a handful of queries, one probe, k = 1
     (32, 40, 7, 33, 5, 9000),         # 2-float sub-vectors do not take this path (dsub % 4): the fallback answers
     (256, 32, 8, 129, 10, 12000),     # the widest vectors the fused build takes
+    (64, 32, 20, 1000, 10, 40000),    # more than 16384 (query, cell) pairs: the plan's loops through memory
 ], ids=lambda v: str(v))
 def test_byte_tiles_equal_oracle_and_u16_path(oracle, D, C, P, B, k, N):
     from annlite_amd import Metric
