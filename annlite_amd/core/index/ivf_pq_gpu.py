@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from ... import ops
-from ..._capi import CODES_SKEWED, LUT_L2, scan_plan, scan_plan_tiles
+from ..._capi import CODES_SKEWED, LUT_IPDIST, LUT_L2, scan_plan, scan_plan_tiles
 from ...enums import Metric
 from ..codec.pq import PQCodec
 from ..codec.vq import VQCodec
@@ -48,8 +48,9 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
         self._sealed = False
         self._table = self._table_plain = self._row_ids = self._cell_rows = self._cell_order = self._pos_of = None
         self.cand_cap = 256  # emitted candidates per (query, cell) list; an overflowing list falls back to the whole cell
-        self.byte_tiles = True  # M = 16, L2 tables, k <= 16, no float re-rank: annlite_ivf_search_topk (False: the u16 tile scan + re-score)
+        self.byte_tiles = True  # M = 16, k <= 16, no float re-rank: annlite_ivf_search_topk (False: the u16 tile scan + re-score)
         self._tws = ops.ScanWorkspace()
+        self.last_pruned_path = None  # which kernels served the last pruned search (measurement scripts)
 
     @property
     def n_cells(self) -> int:
@@ -182,14 +183,16 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
             k = max(k, min(32, int(rerank_k or 16)))
         cells = self.probe_cells(q, P)
         kind_l, xq_l = self.pq_codec.scan_inputs(q)
-        if (self.byte_tiles and not rerank and kind_l == LUT_L2 and self.M == 16 and k <= 16 and self.dim <= 256
+        if (self.byte_tiles and not rerank and kind_l in (LUT_L2, LUT_IPDIST) and self.M == 16 and k <= 16 and self.dim <= 256
                 and (self.dim // self.M) % 4 == 0 and self._n_table < 2 ** 31):
             # (round 6) the byte-table kernel in cell tiles: exact sums inside the tile, bounds shared by query, one merge
             # launch -- the same results as the u16 tile scan + re-score below
-            return ops.ivf_search_topk(xq_l, self.pq_codec.codebooks_dev, self._table, cells, self.n_cells, self._cell_rows,
+            self.last_pruned_path = 'annlite_ivf_search_topk (byte-table cell tiles)'
+            return ops.ivf_search_topk(kind_l, xq_l, self.pq_codec.codebooks_dev, self._table, cells, self.n_cells, self._cell_rows,
                                        self._cell_order, k, self.M, self.Ks, row_ids=self._row_ids, valid_bits=self._table_bits(indices),
                                        n_rows=self._n_table, codes_layout=CODES_SKEWED, sqrt=self.metric == Metric.EUCLIDEAN,
                                        workspace=self._tws)
+        self.last_pruned_path = 'annlite_pq_search_tiles + annlite_ivf_rescore (u16 tables)'
         qt = scan_plan_tiles(self._n_table, self.M, self.Ks, 1, 16, k).qt
         vmap, slot_of, tile_rows, _ = ops.ivf_plan(cells, self.n_cells, qt, self._cell_rows, self._cell_order)
         kind, xq = self.pq_codec.scan_inputs(q)

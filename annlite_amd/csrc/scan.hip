@@ -1680,7 +1680,7 @@ extern "C" int annlite_ivf_search_topk_workspace_bytes(int64_t B, int64_t P, int
     return ANNLITE_OK;
 }
 
-extern "C" int annlite_ivf_search_topk(const float *queries_dev, int64_t B, int64_t D, const float *codebooks_dev, int64_t M, int64_t Ks,
+extern "C" int annlite_ivf_search_topk(int lut_kind, const float *queries_dev, int64_t B, int64_t D, const float *codebooks_dev, int64_t M, int64_t Ks,
                                        const void *codes_dev, int codes_layout, int64_t N, const uint32_t *valid_bits_dev,
                                        const int32_t *cells_dev, int64_t P, int64_t C, const int64_t *cell_rows_dev,
                                        const int32_t *cell_order_dev, const int64_t *row_ids_dev, int64_t id_base, int64_t k,
@@ -1689,6 +1689,8 @@ extern "C" int annlite_ivf_search_topk(const float *queries_dev, int64_t B, int6
     ANNLITE_REQUIRE(M == 16 && Ks >= 1 && Ks <= 256 && k >= 1 && k <= 16,
                     "annlite_ivf_search_topk serves M = 16, Ks <= 256, k <= 16 (got M=%lld Ks=%lld k=%lld): ANNLITE_NOT_APPLICABLE shapes take "
                     "annlite_pq_search_tiles + annlite_ivf_rescore", (long long)M, (long long)Ks, (long long)k);
+    ANNLITE_REQUIRE(lut_kind == ANNLITE_LUT_L2 || lut_kind == ANNLITE_LUT_IPDIST,
+                    "lut_kind must be ANNLITE_LUT_L2 or ANNLITE_LUT_IPDIST (the tables get_dist_mat builds), got %d", lut_kind);
     ANNLITE_REQUIRE(D >= M && D % M == 0 && D <= 256 && ((D / M) % 4) == 0,
                     "the fused table build needs D <= 256 and sub-vectors of a multiple of 4 floats (D=%lld)", (long long)D);
     ANNLITE_REQUIRE(B >= 0 && P >= 1 && C >= 1 && P <= C && C <= 16384 && N > 0 && N < (1ll << 31),
@@ -1726,12 +1728,13 @@ extern "C" int annlite_ivf_search_topk(const float *queries_dev, int64_t B, int6
     // (10M rows, 16 of 256 cells, scan kernel / whole call at 16k / 32k / 64k / 128k: 0.307 / 0.263 / 0.212 / 0.193 and 0.378 / 0.347 / 0.323 / 0.349 ms)
     int64_t S = 65536;
     if (kn.seed_rows_set && kn.seed_rows >= 256) S = kn.seed_rows;
+    if (S > N) S = N;  // (the launch takes max(N, S) as the table's extent: S must not exceed it)
     const int target = (kn.q8_target >= 16 && kn.q8_target <= 127) ? kn.q8_target : 88;
     const LutBuild lb = {queries_dev, codebooks_dev, D};
     const bool sk = codes_layout == ANNLITE_CODES_SKEWED;
     unsigned int *item_counter = (unsigned int *)(n_used + 16);
     rc = launch_seed_build_cells(sk, codes_dev, S, N, valid_bits_dev, lb, lut, B, Ks, k, qstep, qlo, smax, qlom, gkey, st, gseed0, bq, target,
-                                 cells_dev, P, cell_rows_dev, item_counter);
+                                 cells_dev, P, cell_rows_dev, item_counter, lut_kind == ANNLITE_LUT_IPDIST);
     if (rc != ANNLITE_OK) return rc;
     ScanArgs a = {};
     a.codes = codes_dev;

@@ -143,6 +143,7 @@ struct SeedBuild {
     int32_t n_probe;
     uint8_t *bq;                 // [ceil4(B)][Ks][M] byte tables quantised for gseed0 (q8_gather_table assembles a tile's image from them)
     unsigned int *item_counter;  // reset to 0 for the scan behind this launch (its workgroups draw their cell tiles from it)
+    float ip_inv_ks;             // IP tables (template parameter): float32(1 / Ks), the constant of pq.py:316-322
 };
 // BUILD (round 6): the seed bound from the rows an MFMA launch has nominated (seed_mfma.hip) instead of from S seed rows this
 // kernel scans itself.  Query p of the workgroup's 4 takes ceil(n_cand / 64) wave-iterations: lane = nominee; a row's sums run in
@@ -222,7 +223,9 @@ __device__ __forceinline__ f32x4 seed_nominee_minima(const uint8_t *codes, const
 constexpr int kSeedWkeyOff = 16384, kSeedCtrOff = 20480, kSeedKeepOff = 20544, kSeedLdsExtra = 24576;
 // QPB queries per workgroup: 4 (one fp32 TILED group) where their rows fit the LDS, 2 for M = 64
 // CODE16: uint16 codes (PLAIN tables)
-template <int M, bool SKEWED, int QPB, bool CODE16 = false, bool BUILD = false, bool CELLS = false>
+// IP (with CELLS): the tables are float32(1 / Ks) - <codeword, query> (batch_precompute_adc_table_ip's j-ascending fmaf chain,
+// pq_bindings.pyx:214-274, and the subtraction of pq.py:316-322) instead of the squared-L2 ones
+template <int M, bool SKEWED, int QPB, bool CODE16 = false, bool BUILD = false, bool CELLS = false, bool IP = false>
 __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8_t *__restrict__ codes, int64_t S,
                                                                     const uint32_t *__restrict__ valid,
                                                                     const float *__restrict__ lut, int B, int Ks, int k,
@@ -233,6 +236,7 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
     static_assert(!(CODE16 && SKEWED), "uint16 code tables are PLAIN");
     static_assert(!BUILD || (QPB == 4 && !CODE16 && M <= 16), "the fused build serves the byte-table plan");
     static_assert(!CELLS || (BUILD && M == 16), "per-cell seeds: the fused build of the M = 16 byte-table plan");
+    static_assert(!IP || CELLS, "inner-product tables are built here for the pruned search only");
     if (sb.gate && __hip_atomic_load(sb.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     if constexpr (CELLS) {
         if (sb.item_counter && blockIdx.x == 0 && threadIdx.x == 0) *sb.item_counter = 0u;
@@ -312,10 +316,18 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
                         const f32x4 qj = *(const f32x4 *)(s_q + i * D + m * dsub + j);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float c = cj[e] - qj[e];
-                            acc[i] = __builtin_fmaf(c, c, acc[i]);
+                            if constexpr (IP) {
+                                acc[i] = __builtin_fmaf(cj[e], qj[e], acc[i]);
+                            } else {
+                                const float c = cj[e] - qj[e];
+                                acc[i] = __builtin_fmaf(c, c, acc[i]);
+                            }
                         }
                     }
+                }
+                if constexpr (IP) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = sb.ip_inv_ks - acc[i];
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -1129,7 +1141,7 @@ int annlite::launch_seed_build_cells(bool skw, const void *codes_dev, int64_t S,
                                      const LutBuild &build, float *lut_out, int64_t B, int64_t Ks, int64_t k, float *qstep, double *qlo,
                                      float *smax, float *qlom, unsigned long long *gk, hipStream_t st, unsigned long long *gseed0,
                                      uint8_t *bq, int target, const int32_t *cells, int64_t n_probe, const int64_t *cell_rows,
-                                     unsigned int *item_counter) {
+                                     unsigned int *item_counter, bool ip_tables) {
     constexpr int M = 16;
     SeedBuild sb = {};
     sb.queries = build.queries;
@@ -1151,8 +1163,10 @@ int annlite::launch_seed_build_cells(bool skw, const void *codes_dev, int64_t S,
     sb.n_probe = (int32_t)n_probe;
     sb.bq = bq;
     sb.item_counter = item_counter;
+    sb.ip_inv_ks = (float)(1.0 / (double)Ks);
     const size_t lds = (size_t)Ks * M * 16 + (size_t)kSeedLdsExtra;
-    auto fn = skw ? seed_bound_kernel<M, true, 4, false, true, true> : seed_bound_kernel<M, false, 4, false, true, true>;
+    auto fn = ip_tables ? (skw ? seed_bound_kernel<M, true, 4, false, true, true, true> : seed_bound_kernel<M, false, 4, false, true, true, true>)
+                        : (skw ? seed_bound_kernel<M, true, 4, false, true, true> : seed_bound_kernel<M, false, 4, false, true, true>);
     ANNLITE_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned n_g4 = (unsigned)(((B + 15) / 16) * 4);
     hipLaunchKernelGGL(fn, dim3(n_g4, 1), dim3(kSeedWaves * 64), lds, st, (const uint8_t *)codes_dev, S, valid_bits_dev,

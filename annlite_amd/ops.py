@@ -431,14 +431,14 @@ def ivf_candidate_ids(cand: torch.Tensor, count: torch.Tensor, slot_of: torch.Te
     return out
 
 
-def ivf_search_topk(queries: torch.Tensor, codebooks: torch.Tensor, codes: torch.Tensor, cells: torch.Tensor, n_cells: int,
+def ivf_search_topk(lut_kind: int, queries: torch.Tensor, codebooks: torch.Tensor, codes: torch.Tensor, cells: torch.Tensor, n_cells: int,
                     cell_rows: torch.Tensor, cell_order: torch.Tensor, k: int, M: int, Ks: int,
                     row_ids: Optional[torch.Tensor] = None, valid_bits: Optional[torch.Tensor] = None,
                     n_rows: Optional[int] = None, codes_layout: int = CODES_PLAIN, id_base: int = 0, sqrt: bool = False,
                     workspace: Optional[ScanWorkspace] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """``annlite_ivf_search_topk``: the pruned search over cells on the byte-table kernel in one call -- plan, preparation
     launch (tables, per-cell seed bounds, per-query byte tables), scan in cell tiles with exact sums, merge of the per-cell
-    lists.  ``queries`` f32 [B, D] (squared-L2 tables are built from them and ``codebooks`` [M, Ks, D/M]), ``codes`` the
+    lists.  ``queries`` f32 [B, D] (the tables of ``lut_kind`` -- LUT_L2 or LUT_IPDIST -- are built from them and ``codebooks`` [M, Ks, D/M]), ``codes`` the
     CELL-SORTED table, ``cells`` i32 [B, P] nearest first.  M = 16, Ks <= 256, k <= 16.  Returns ([B,k] f32, [B,k] i64)."""
     N = codes.shape[0] if n_rows is None else n_rows
     B, D = queries.shape
@@ -449,7 +449,7 @@ def ivf_search_topk(queries: torch.Tensor, codebooks: torch.Tensor, codes: torch
     ws = (workspace or ScanWorkspace()).get(int(need.value), dev)
     od = torch.empty((B, k), dtype=torch.float32, device=dev)
     oi = torch.empty((B, k), dtype=torch.int64, device=dev)
-    check(lib().annlite_ivf_search_topk(queries.data_ptr(), B, D, codebooks.data_ptr(), M, Ks, codes.data_ptr(), codes_layout, N,
+    check(lib().annlite_ivf_search_topk(lut_kind, queries.data_ptr(), B, D, codebooks.data_ptr(), M, Ks, codes.data_ptr(), codes_layout, N,
                                         _ptr(valid_bits), cells.data_ptr(), P, n_cells, cell_rows.data_ptr(), cell_order.data_ptr(),
                                         _ptr(row_ids), id_base, k, od.data_ptr(), oi.data_ptr(), 1 if sqrt else 0, ws.data_ptr(),
                                         ws.numel(), stream_ptr()), 'ivf_search_topk')

@@ -645,17 +645,55 @@ def main():
         for _ in range(2):
             iv = ivf.search_batch(queries, limit=k, n_probe=P)
         torch.cuda.synchronize()
-        n_iv = max(3, args.steps // 2)
+        n_iv = max(4, args.steps // 2)
         t0 = time.perf_counter()
         for _ in range(n_iv):
             iv = ivf.search_batch(queries, limit=k, n_probe=P)
         torch.cuda.synchronize()
-        iv_qps = B * n_iv / (time.perf_counter() - t0)
+        iv_qps_1 = B * n_iv / (time.perf_counter() - t0)
+        # consecutive batches on two caller streams, as the other legs (`value`); the one-stream figure stays beside it
+        i_streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        for j in range(4):  # (warm-up on the timed streams: scratch and the allocator's pool are per stream)
+            with torch.cuda.stream(i_streams[j % 2]):
+                ivf.search_batch(queries, limit=k, n_probe=P)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for j in range(2 * n_iv):
+            with torch.cuda.stream(i_streams[j % 2]):
+                ivf.search_batch(queries, limit=k, n_probe=P)
+        torch.cuda.synchronize()
+        iv_qps = B * 2 * n_iv / (time.perf_counter() - t0)
         got_iv = iv[1][:nq].cpu().numpy()
         adc_ids = out[1][:nq].cpu().numpy()
-        ivf_rec = {'n_cells': args.ivf_cells, 'n_probe': P, 'value': iv_qps, 'unit': 'queries/s',
+        ivf_rec = {'n_cells': args.ivf_cells, 'n_probe': P, 'value': iv_qps, 'unit': 'queries/s', 'streams': 2, 'one_stream_value': iv_qps_1,
+                   'path': ivf.last_pruned_path,
                    'recall_at_10': float(np.mean([len(set(got_iv[b]) & set(truth[b])) / k for b in range(nq)])),
                    'agreement_with_exhaustive_adc_top10': float(np.mean([len(set(got_iv[b]) & set(adc_ids[b])) / k for b in range(nq)]))}
+        if ivf.last_pruned_path and ivf.last_pruned_path.startswith('annlite_ivf_search_topk'):
+            # the u16 tile scan + re-score it replaces: same results (compared), its rate beside the new one; and the cell-tile launch's
+            # duration against the look-up roof (the units it processes: B x P / C x N x M look-ups)
+            try:
+                from annlite_amd import _capi as _c
+
+                _c.profile_enable(True)
+                ivf.search_batch(queries, limit=k, n_probe=P)
+                scan_ms = _c.profile_last_scan_ms()
+                _c.profile_enable(False)
+                ivf.byte_tiles = False
+                for _ in range(2):
+                    iv16 = ivf.search_batch(queries, limit=k, n_probe=P)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n_iv):
+                    iv16 = ivf.search_batch(queries, limit=k, n_probe=P)
+                torch.cuda.synchronize()
+                ivf_rec['u16_tiles_one_stream_value'] = B * n_iv / (time.perf_counter() - t0)
+                ivf_rec['equal_to_u16_tiles'] = bool(torch.equal(iv16[0], iv[0]) and torch.equal(iv16[1], iv[1]))
+                ivf.byte_tiles = True
+                lookups = float(B) * P / args.ivf_cells * N * M
+                ivf_rec['scan_kernel'] = {'ms': scan_ms, 'lookups': lookups, 'frac_of_lookup_roof': lookups / (scan_ms * 1e-3) / 1.573e14}
+            except Exception as ex:  # noqa: BLE001
+                ivf_rec['u16_tiles_error'] = repr(ex)[:200]
         if keep_vectors:
             ivf.rerank = True
             for _ in range(2):
@@ -933,7 +971,8 @@ def main():
             if 'ef_search_160' in graph_rec:
                 summ['graph']['ef160'] = [_r(graph_rec['ef_search_160']['value'], 0), _r(graph_rec['ef_search_160']['recall_at_10'], 3)]
         if ivf_rec:
-            summ['ivf'] = {'qps': _r(ivf_rec['value'], 0), 'agree': _r(ivf_rec['agreement_with_exhaustive_adc_top10'], 3)}
+            summ['ivf'] = {'qps': _r(ivf_rec['value'], 0), 'qps_1s': _r(ivf_rec.get('one_stream_value', 0), 0),
+                           'agree': _r(ivf_rec['agreement_with_exhaustive_adc_top10'], 3)}
         if facade:
             summ['facade'] = {'search_qps': _r(facade['search']['value'], 0), 'numpy_qps': _r(facade['search_numpy']['value'], 0)}
         for name in ('c2', 'c4', 'c5', 'm32', 'k50', 'uniform'):

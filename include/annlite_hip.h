@@ -539,13 +539,15 @@ ANNLITE_API int annlite_ivf_candidate_ids(const uint32_t *cand_dev, int64_t cand
  *                  codes_layout; valid_bits_dev (may be NULL): bitmap over TABLE rows; row_ids_dev i64 [N] (may be NULL): external id
  *                  of every table row, ascending inside a cell
  *   cell_order_dev i32 [C]     cells by descending size (the plan's tile order)
- *   flags: ANNLITE_FLAG_SQRT.  Serves M = 16, Ks <= 256, k <= 16, squared-L2 tables built from queries and codebooks (D <= 256,
- *   sub-vectors of a multiple of 4 floats); other shapes: annlite_pq_search_tiles + annlite_ivf_rescore.
+ *   lut_kind: ANNLITE_LUT_L2 (pq_bindings.pyx:149-210) or ANNLITE_LUT_IPDIST (float32(1 / Ks) - <q_sub, codeword>, pq_bindings.pyx:214-274 +
+ *   pq.py:316-322: INNER_PRODUCT, and COSINE on normalised queries) -- the tables are built inside the preparation launch, the reference's
+ *   j-ascending fmaf chains.  flags: ANNLITE_FLAG_SQRT.  Serves M = 16, Ks <= 256, k <= 16, D <= 256, sub-vectors of a multiple of 4
+ *   floats; other shapes: annlite_pq_search_tiles + annlite_ivf_rescore.
  * replaces: _cell_selection's consumers -- the per-cell search loop and the hstack / argsort merge of CellContainer.ivf_search
  * (annlite/container.py:88-144) with n_probe < n_cells. */
 ANNLITE_API int annlite_ivf_search_topk_workspace_bytes(int64_t B, int64_t P, int64_t C, int64_t M, int64_t Ks, int64_t k,
                                             int64_t *bytes);
-ANNLITE_API int annlite_ivf_search_topk(const float *queries_dev, int64_t B, int64_t D, const float *codebooks_dev, int64_t M,
+ANNLITE_API int annlite_ivf_search_topk(int lut_kind, const float *queries_dev, int64_t B, int64_t D, const float *codebooks_dev, int64_t M,
                             int64_t Ks, const void *codes_dev, int codes_layout, int64_t N, const uint32_t *valid_bits_dev,
                             const int32_t *cells_dev, int64_t P, int64_t C, const int64_t *cell_rows_dev,
                             const int32_t *cell_order_dev, const int64_t *row_ids_dev, int64_t id_base, int64_t k,

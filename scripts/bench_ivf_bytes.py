@@ -96,11 +96,11 @@ def main():
         q = idx._pre(queries)
         st = {}
         st['select_ms'], cells = timed(lambda: idx.probe_cells(q, P))
-        st['search_topk_ms'], _ = timed(lambda: ops.ivf_search_topk(q, codec.codebooks_dev, idx._table, cells, C, idx._cell_rows, idx._cell_order,
+        st['search_topk_ms'], _ = timed(lambda: ops.ivf_search_topk(_capi.LUT_L2, q, codec.codebooks_dev, idx._table, cells, C, idx._cell_rows, idx._cell_order,
                                                                    k, M, Ks, row_ids=idx._row_ids, n_rows=idx._n_table,
                                                                    codes_layout=_capi.CODES_SKEWED, sqrt=True, workspace=idx._tws))
         _capi.profile_enable(True)
-        ops.ivf_search_topk(q, codec.codebooks_dev, idx._table, cells, C, idx._cell_rows, idx._cell_order, k, M, Ks, row_ids=idx._row_ids,
+        ops.ivf_search_topk(_capi.LUT_L2, q, codec.codebooks_dev, idx._table, cells, C, idx._cell_rows, idx._cell_order, k, M, Ks, row_ids=idx._row_ids,
                             n_rows=idx._n_table, codes_layout=_capi.CODES_SKEWED, sqrt=True, workspace=idx._tws)
         st['scan_kernel_ms'] = _capi.profile_last_scan_ms()
         _capi.profile_enable(False)

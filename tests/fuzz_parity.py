@@ -115,11 +115,97 @@ def run(seconds, seed, verbose=True):
     return n_cases, n_calls, n_bad, dict(sorted(by_m.items()))
 
 
+def run_cells(seconds, seed, verbose=True):
+    """Random pruned searches over cells through the C ABI (annlite_ivf_search_topk, the byte-table cell tiles) against the oracle's
+    restatement of CellContainer.ivf_search (container.py:88-144) over the probed cells, bit for bit: random cell sizes (empty and
+    one-row cells included), ANY distinct probed cells in any order (the first one seeds the bound), both table layouts, both table
+    kinds, validity bitmaps, Ks below 256, heavy ties.  Returns (cases, calls, mismatches)."""
+    oracle.build()
+    torch.cuda.set_device(0)
+    rs = np.random.RandomState(seed)
+    t_end = time.time() + seconds
+    n_cases = n_calls = n_bad = 0
+    M = 16
+    while time.time() < t_end:
+        dsub = int(rs.choice([4, 8, 16]))
+        Ks = int(rs.choice([256, 256, 100, 37]))
+        N = int(np.exp(rs.uniform(np.log(1), np.log(300_000))))
+        C = int(rs.choice([1, 2, 7, 32, 100, 256]))
+        P = int(rs.randint(1, C + 1)) if C <= 7 else int(rs.choice([1, 2, 5, 16, min(C, 40)]))
+        B = int(np.exp(rs.uniform(np.log(1), np.log(1100))))
+        B = max(1, min(B, int(2e9 / (max(N * P // C, 1) * M + 1)), 1100))
+        k = int(rs.choice([1, 3, 10, 10, 16]))
+        kind = int(rs.choice([1, 1, 3]))
+        D = M * dsub
+        r = 6
+        A = rs.randn(r, D).astype(np.float32)
+        cb = (rs.randn(Ks, r).astype(np.float32) @ A).reshape(Ks, M, dsub).transpose(1, 0, 2).copy()
+        order = rs.choice(['iid', 'few_distinct', 'uniform_codes'])
+        if order == 'uniform_codes':
+            codes = rs.randint(0, Ks, size=(N, M)).astype(np.uint8)
+        elif order == 'few_distinct':
+            base = rs.randint(0, Ks, size=(max(1, min(N, 50)), M)).astype(np.uint8)
+            codes = base[rs.randint(0, base.shape[0], N)]
+        else:
+            x = rs.randn(N, r).astype(np.float32) @ A + 0.05 * rs.randn(N, D).astype(np.float32)
+            codes = oracle.encode_c(x, cb, threads=oracle.max_threads()).astype(np.uint8)
+        q = (rs.randn(B, r).astype(np.float32) @ A).astype(np.float32)
+        # cells of uneven size (some empty): a row's cell by a skewed draw
+        w = rs.rand(C) ** 3 + 1e-3
+        w[rs.rand(C) < 0.1] = 0.0
+        if w.sum() == 0:
+            w[0] = 1.0
+        cell_of = rs.choice(C, size=N, p=w / w.sum()).astype(np.int32)
+        probe = np.stack([rs.permutation(C)[:P] for _ in range(B)]).astype(np.int32)
+        vmode = rs.choice(['none', 'random', 'most'])
+        valid = np.ones(N, dtype=bool)
+        if vmode == 'random':
+            valid &= rs.rand(N) > 0.2
+        elif vmode == 'most':
+            valid &= rs.rand(N) > 0.95
+        omet = {1: oracle.EUCLIDEAN, 3: oracle.INNER_PRODUCT}[kind]
+        rd, ri = oracle.ivf_search(q, cb, codes, cell_of, probe, omet, k, valid=valid, sqrt_euclidean=False)
+        # the cell-sorted table: every cell starts at a multiple of 64 rows, ascending ids inside a cell
+        counts = np.bincount(cell_of, minlength=C)
+        padded = (counts + 63) // 64 * 64
+        begin = np.cumsum(padded) - padded
+        srt = np.argsort(cell_of, kind='stable')
+        rank = np.arange(N) - (np.cumsum(counts) - counts)[cell_of[srt]]
+        pos = begin[cell_of[srt]] + rank
+        Nt = max(64, int(padded.sum()))
+        table = np.zeros((Nt, M), dtype=np.uint8)
+        table[pos] = codes[srt]
+        row_ids = np.full(Nt, -1, dtype=np.int64)
+        row_ids[pos] = srt
+        vt = np.zeros(((Nt + 31) // 32 + 2) * 32, dtype=bool)
+        vt[pos] = valid[srt]
+        bits = None if vmode == 'none' else ops.to_dev(np.packbits(vt.reshape(-1, 32), axis=1, bitorder='little').view(np.int32).reshape(-1))
+        cell_rows = ops.to_dev(np.stack([begin, begin + counts], axis=1).astype(np.int64))
+        cell_order = ops.to_dev(np.argsort(-counts, kind='stable').astype(np.int32))
+        table_d = ops.to_dev(table)
+        n_cases += 1
+        for layout in (0, 1):
+            td = ops.codes_skew(table_d) if layout == 1 else table_d
+            d, i = ops.ivf_search_topk(kind, ops.to_dev(q), ops.to_dev(cb), td, ops.to_dev(probe), C, cell_rows, cell_order, k, M, Ks,
+                                       row_ids=ops.to_dev(row_ids), valid_bits=bits, n_rows=Nt, codes_layout=layout)
+            n_calls += 1
+            if not (np.array_equal(i.cpu().numpy(), ri) and np.array_equal(d.cpu().numpy(), rd, equal_nan=True)):
+                n_bad += 1
+                print('MISMATCH cells', dict(dsub=dsub, Ks=Ks, N=N, C=C, P=P, B=B, k=k, kind=kind, order=str(order), valid=str(vmode), layout=layout),
+                      flush=True)
+    return n_cases, n_calls, n_bad
+
+
 if __name__ == '__main__':
     p = argparse.ArgumentParser()
     p.add_argument('--seconds', type=float, default=200)
     p.add_argument('--seed', type=int, default=1)
+    p.add_argument('--cells', action='store_true', help='the pruned search over cells (annlite_ivf_search_topk) instead of the flat search')
     a = p.parse_args()
+    if a.cells:
+        n_cases, n_calls, n_bad = run_cells(a.seconds, a.seed)
+        print('fuzz_parity (cells): seed %d, %d cases, %d calls compared with the oracle bit for bit, %d mismatches' % (a.seed, n_cases, n_calls, n_bad))
+        sys.exit(1 if n_bad else 0)
     n_cases, n_calls, n_bad, by_m = run(a.seconds, a.seed)
     print('fuzz_parity: seed %d, %d cases (by M: %s), %d calls compared with the oracle bit for bit, %d mismatches' % (a.seed, n_cases, by_m, n_calls, n_bad))
     sys.exit(1 if n_bad else 0)

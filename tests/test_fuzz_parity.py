@@ -18,3 +18,14 @@ def test_random_cases_equal_the_oracle(oracle):
     n_cases, n_calls, n_bad, by_m = fuzz_parity.run(seconds, seed)
     assert n_bad == 0, (n_cases, n_calls, n_bad)
     assert n_cases >= 10 and n_calls >= 2 * n_cases, (n_cases, n_calls, by_m)
+
+
+def test_random_pruned_searches_over_cells_equal_the_oracle(oracle):
+    """annlite_ivf_search_topk (byte-table cell tiles) on random cell sizes / probes / validity / layouts / table kinds"""
+    import fuzz_parity
+
+    seconds = float(os.environ.get('ANNLITE_FUZZ_SECONDS', '12'))
+    seed = int(os.environ.get('ANNLITE_FUZZ_SEED', '3'))
+    n_cases, n_calls, n_bad = fuzz_parity.run_cells(seconds, seed + 100)
+    assert n_bad == 0, (n_cases, n_calls, n_bad)
+    assert n_cases >= 5 and n_calls == 2 * n_cases, (n_cases, n_calls)

@@ -55,8 +55,27 @@ def test_byte_tiles_is_the_path_taken(monkeypatch):
     idx.search_batch(q, limit=20, n_probe=4)  # k > 16: the u16 tile scan
     assert len(calls) == 1
     idx2, *_ = _build(6000, 64, 16, 16, Metric.COSINE, seed=5)
-    idx2.search_batch(q, limit=10, n_probe=4)  # inner-product tables: the u16 tile scan
-    assert len(calls) == 1
+    idx2.search_batch(q, limit=10, n_probe=4)  # cosine: inner-product tables, built in the same launch
+    assert len(calls) == 2
+    idx3, *_ = _build(6000, 64, 8, 16, Metric.EUCLIDEAN, seed=5)
+    idx3.search_batch(q, limit=10, n_probe=4)  # M = 8: the u16 tile scan
+    assert len(calls) == 2
+
+
+@pytest.mark.parametrize('metric_name,D,C,P,B,k', [
+    ('COSINE', 64, 32, 4, 200, 10),
+    ('INNER_PRODUCT', 128, 16, 5, 77, 16),
+    ('COSINE', 128, 64, 16, 1024, 10),
+], ids=lambda v: str(v))
+def test_byte_tiles_inner_product_tables(oracle, metric_name, D, C, P, B, k):
+    """COSINE (the reference's default metric) and INNER_PRODUCT: float32(1 / Ks) - <q_sub, codeword> tables (pq.py:316-322) built inside
+    the preparation launch -- negative entries, the byte tables' minima / ranges as for L2"""
+    from annlite_amd import Metric
+
+    idx, codec, vq, x = _build(30000, D, 16, C, Metric[metric_name], seed=9)
+    _, q = _data(np.random.RandomState(10), 1, D, B)
+    d, i = _both(idx, q, k, P)
+    _check_against_oracle(oracle, idx, codec, q, k, P, d, i)
 
 
 def test_byte_tiles_deletes_filter_and_ties(oracle):
@@ -125,4 +144,4 @@ def test_c_abi_argument_checks():
     rows = torch.tensor([[0, 64]], dtype=torch.int64, device=dev)
     order = torch.zeros((1,), dtype=torch.int32, device=dev)
     with pytest.raises(Exception, match='M = 16'):
-        ops.ivf_search_topk(q, cb, codes, cells, 1, rows, order, 10, 8, 256)
+        ops.ivf_search_topk(1, q, cb, codes, cells, 1, rows, order, 10, 8, 256)
