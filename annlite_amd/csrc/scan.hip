@@ -1726,10 +1726,15 @@ extern "C" int annlite_ivf_search_topk(int lut_kind, const float *queries_dev, i
     if (rc != ANNLITE_OK) return rc;
     // seed rows: S / 4 per query from its nearest cell (the workgroup's four queries share the launch's blocks)
     // (10M rows, 16 of 256 cells, scan kernel / whole call at 16k / 32k / 64k / 128k: 0.307 / 0.263 / 0.212 / 0.193 and 0.378 / 0.347 / 0.323 / 0.349 ms)
-    int64_t S = 65536;
+    // (call 50, same box, with the table target below: 65536 rows 0.3331 / 0.2783 ms per batch on one / two caller streams, 49152 rows + target 72
+    // 0.3260 / 0.2666)
+    int64_t S = 49152;
     if (kn.seed_rows_set && kn.seed_rows >= 256) S = kn.seed_rows;
     if (S > N) S = N;  // (the launch takes max(N, S) as the table's extent: S must not exceed it)
-    const int target = (kn.q8_target >= 16 && kn.q8_target <= 127) ? kn.q8_target : 88;
+    // T of a slot's freshly built byte table: a cell tile never rebuilds and its bound falls by more than a long scan's, so a coarser
+    // step than the exhaustive scan's 88 (fewer entries of the rows near the bound clip at 15 steps): scan kernel at 64 / 72 / 80 / 88:
+    // 0.1927 / 0.1904 / 0.1964 / 0.2011 ms (profiles/r06/ivf_target_seed.txt)
+    const int target = (kn.q8_target >= 16 && kn.q8_target <= 127) ? kn.q8_target : 72;
     const LutBuild lb = {queries_dev, codebooks_dev, D};
     const bool sk = codes_layout == ANNLITE_CODES_SKEWED;
     unsigned int *item_counter = (unsigned int *)(n_used + 16);
