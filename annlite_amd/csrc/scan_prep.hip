@@ -334,6 +334,14 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
                     if (g4 * 4 + i >= B) acc[i] = 0.f;  // pad queries -> 0, like lut_l2_tiled_kernel
                 const f32x4 v = {acc[0], acc[1], acc[2], acc[3]};
                 tab[kk * M + m] = v;
+                if constexpr (CELLS) {
+                    // per QUERY, [b][Ks][M]: the cell tiles' consumer gathers 16 entries of ONE query per exact sum from far memory (the
+                    // batch's tables do not fit an XCD's L2 and a tile's 32 slots hold arbitrary queries) -- a query's 16 KB on its own take
+                    // 128 cache lines where the TILED groups of four spread them over 512
+                    float *gq = sb.lut_out + ((int64_t)(g4 * 4) * Ks + kk) * M + m;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gq[(int64_t)i * Ks * M] = acc[i];
+                } else
                 gout[(int64_t)kk * M + m] = v;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) mn[i] = fminf(mn[i], acc[i]), mx[i] = fmaxf(mx[i], col_max_arg(acc[i]));

@@ -515,11 +515,12 @@ __device__ __forceinline__ void q8_consume(const FlushCtx &c, const Q8Lds &o, co
                 b = ldsv<int32_t>(o.qmap + 4u * (uint32_t)(act[u] ? q[u] : 0));
                 b = b < 0 ? 0 : b;
             }
-            const float *lq = c.lut + ((int64_t)(b >> 2) * c.Ks) * (M * 4) + (b & 3);
+            // (TL: the preparation launch of the pruned search leaves the tables per QUERY, [b][Ks][M] -- see seed_bound_kernel<CELLS>)
+            const float *lq = TL ? c.lut + (int64_t)b * c.Ks * M : c.lut + ((int64_t)(b >> 2) * c.Ks) * (M * 4) + (b & 3);
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 const uint32_t code = C16 ? (cp[u][m / 2] >> (16 * (m % 2))) & 0xffffu : (cp[u][m / 4] >> (8 * (m % 4))) & 0xffu;
-                vals[u][m] = lq[((int64_t)code * M + m) * 4];
+                vals[u][m] = TL ? lq[(int64_t)code * M + m] : lq[((int64_t)code * M + m) * 4];
             }
         }
         q8_publish_global<QT, LK, TL>(c, o, lane, pend_o, pend_j);  // (the previous batch's, behind this batch's gathers)
