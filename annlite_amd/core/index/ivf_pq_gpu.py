@@ -18,9 +18,12 @@ Layout in HBM on top of the flat index's storage (codes by offset, validity, opt
       ``_row_ids``   i64 [Nt] offset of every table row (-1: padding)
       ``_cell_rows`` i64 [C, 2] (begin, end) of every cell, ``_cell_order`` i32 [C] cells by descending size
       ``_table_plain`` the same rows in the PLAIN layout (read by the exact re-score)
-Search = ``annlite_ivf_select_cells`` -> ``annlite_ivf_plan`` (query tiles of one cell each) ->
-``annlite_pq_search_tiles`` (quantised tables of the queries + integer scan: per-slot candidate lists) ->
-``annlite_lut_build`` for the real queries -> ``annlite_ivf_rescore`` (exact sums of the candidates, top-k).
+Search, ``n_subvectors = 16`` and ``limit <= 16`` (round 6) = ``annlite_ivf_select_cells`` -> ``annlite_ivf_search_topk`` (plan of
+cell tiles of 32 (query, cell) pairs; ONE preparation launch: the queries' tables, a first bound from each query's nearest cell, a
+byte table per query; the byte-table kernel over the tiles with exact sums and bounds shared between a query's tiles; merge of the
+per-cell lists).  Other shapes and the float re-rank = ``annlite_ivf_select_cells`` -> ``annlite_ivf_plan`` (query tiles of one cell
+each) -> ``annlite_pq_search_tiles`` (quantised tables of the queries + integer scan: per-slot candidate lists) ->
+``annlite_lut_build`` for the real queries -> ``annlite_ivf_rescore`` (exact sums of the candidates, top-k).  Same results.
 """
 from typing import Optional, Tuple
 

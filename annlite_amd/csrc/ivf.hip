@@ -6,8 +6,9 @@
 // sets n_probe = max(n_probe, n_cells) (index.py:94), i.e. it always visits every cell; the pruned search is the
 // build's extension of the same structure.
 //
-// The scan itself is annlite_pq_search_tiles (scan.hip): the rows of a cell are contiguous in the code table, a
-// query tile = up to QT queries that probe the same cell, one work item per tile.
+// The scan itself is annlite_ivf_search_topk (scan.hip; M = 16, k <= 16: the byte-table kernel in cell tiles, exact sums in the
+// tile, annlite_ivf_merge_lists below) or annlite_pq_search_tiles (the u16 tables, integer sums + annlite_ivf_rescore below): the rows
+// of a cell are contiguous in the code table, a query tile = up to QT queries that probe the same cell, one work item per tile.
 #include "common.h"
 
 namespace annlite {
