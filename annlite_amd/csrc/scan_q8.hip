@@ -1156,6 +1156,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
         // consumer wave requests the next number at the start of an item -- behind its first import -- and leaves it in LDS)
         if constexpr (TL) {
             if (it > 0 && a.item_counter) item = (int)ldsv<uint32_t>(lds.seen + 8);
+            // (the first items of one XCD's workgroups as CONSECUTIVE tiles -- the 2-3 tiles of a cell streaming its rows through one L2 --
+            // measured: no difference, profiles/r06/ivf_xcd_first_ab.txt)
         }
         if (item >= a.n_items) break;
         int tile, slice;

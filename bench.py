@@ -313,6 +313,15 @@ def main():
 
     n_streams = args.streams or (2 if (world > 1 or os.environ.get('ANNLITE_FORCE_GATHER')) else 1)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams >= 2 else [torch.cuda.current_stream(dev)]
+    _leg_streams = []
+
+    def leg_stream_pair():
+        # ONE pair of caller streams for every in-process leg that alternates batches (graph, ivf): HIP maps a process's streams onto a few
+        # hardware queues, and a fresh pair per leg can land both of its streams on one queue (the ivf leg's two-stream figure then
+        # equalled its one-stream figure while scripts/bench_ivf_bytes.py, two streams in a fresh process, measured 1.24x)
+        if not _leg_streams:
+            _leg_streams.extend(streams if len(streams) >= 2 else [torch.cuda.Stream(device=dev) for _ in range(2)])
+        return _leg_streams
     for st in streams:
         st.wait_stream(torch.cuda.current_stream(dev))
     # clocks: a GPU that has idled through index construction and host-side set-up takes milliseconds of work to reach its
@@ -581,7 +590,7 @@ def main():
                 gidx.add_with_ids(gen_chunk(c, rows, D, A, dev), torch.arange(c * CH, c * CH + rows, device=dev, dtype=torch.int64))
             torch.cuda.synchronize()
             g_build_s = time.time() - t0  # (vector generation, encode, storage and the graph)
-            g_streams = [torch.cuda.Stream(device=dev) for _ in range(2)]  # (consecutive batches on two caller streams, as the other legs)
+            g_streams = leg_stream_pair()  # (consecutive batches on two caller streams, as the other legs)
             for j in range(4):  # (warm-up on the timed streams: the allocator keeps a pool per stream)
                 with torch.cuda.stream(g_streams[j % 2]):
                     gr = gidx.search_batch(q_sets[j % NB], limit=k)
@@ -652,7 +661,7 @@ def main():
         torch.cuda.synchronize()
         iv_qps_1 = B * n_iv / (time.perf_counter() - t0)
         # consecutive batches on two caller streams, as the other legs (`value`); the one-stream figure stays beside it
-        i_streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        i_streams = leg_stream_pair()
         for j in range(4):  # (warm-up on the timed streams: scratch and the allocator's pool are per stream)
             with torch.cuda.stream(i_streams[j % 2]):
                 ivf.search_batch(queries, limit=k, n_probe=P)
