@@ -78,11 +78,30 @@ __global__ __launch_bounds__(256) void ivf_select_cells_kernel(const float *__re
                 const float v = row[c];
                 if (v < best || (v == best && c < bi)) best = v, bi = c;
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(best, o);
-                const int oi = __shfl_xor(bi, o);
-                if (ov < best || (ov == best && oi < bi)) best = ov, bi = oi;
+            // wave argmin by DPP (round 6): row_shr 1 / 2 / 4 / 8 inside the 16-lane rows, row_bcast 15 / 31 across them -- lane 63 ends
+            // up with the minimum of all 64 (the order (distance, cell) as a 64-bit key: ordered float bits, then the cell), read back
+            // through an SGPR.  (Six __shfl_xor steps of two values each went through ds_bpermute: ~1 us per round, 16 of the
+            // kernel's 26 us at 16 probes.)
+            {
+                uint32_t khi = f32_to_ordered(best + 0.f);  // (never NaN: the lane's minimum starts at +inf; -0 as +0: the float order's tie)
+                uint32_t klo = (uint32_t)bi;
+                auto step = [&](int ctrl_id) {
+                    uint32_t ohi, olo;
+                    // (old = all-ones: a lane without a source in this step keeps the key that loses every comparison)
+                    switch (ctrl_id) {
+                        case 0: ohi = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)khi, 0x111, 0xf, 0xf, false), olo = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)klo, 0x111, 0xf, 0xf, false); break;
+                        case 1: ohi = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)khi, 0x112, 0xf, 0xf, false), olo = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)klo, 0x112, 0xf, 0xf, false); break;
+                        case 2: ohi = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)khi, 0x114, 0xf, 0xf, false), olo = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)klo, 0x114, 0xf, 0xf, false); break;
+                        case 3: ohi = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)khi, 0x118, 0xf, 0xf, false), olo = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)klo, 0x118, 0xf, 0xf, false); break;
+                        case 4: ohi = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)khi, 0x142, 0xa, 0xf, false), olo = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)klo, 0x142, 0xa, 0xf, false); break;
+                        default: ohi = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)khi, 0x143, 0xc, 0xf, false), olo = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)klo, 0x143, 0xc, 0xf, false); break;
+                    }
+                    if (ohi < khi || (ohi == khi && olo < klo)) khi = ohi, klo = olo;
+                };
+                step(0), step(1), step(2), step(3), step(4), step(5);
+                const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)khi, 63);
+                bi = __builtin_amdgcn_readlane((int)klo, 63);
+                best = ordered_to_f32(whi);
             }
             // (a query with NaN / inf components finds no minimum: fall back to cell p so that the plan never sees an
             // out-of-range cell -- the results of such a query are meaningless either way)
