@@ -35,6 +35,9 @@
 //      insertion queues]
 // Shapes (template <M, NW, SKEWED, NQ, CB = bytes per code>; launch_q8_scan ids):
 //   1650  M = 16, uint8 codes, NQ = 2 entry groups = 32 queries per workgroup -- everything above; the headline kernel;
+//   1651  the same kernel over CELL TILES (template flag TL; annlite_ivf_search_topk): a work item = up to 32 (query, cell) pairs
+//         of ONE cell scanning that cell's rows; slot -> query through a map in LDS, the image gathered from per-query byte tables
+//         (q8_gather_table), bounds shared by query, tiles drawn from a device counter; the step loop is 1650's;
 //   6450  M = 64 ("WIDE"): 8 queries per 8-BYTE entry (ds_read_b64), byte sums of 16 look-ups widened into u16 sums (T up to
 //         960), two half tables [Ks + 1][32][8 B] with wrap-coded SKEWED rows and one v_perm_b32 per address;
 //   850   M = 8, uint16 codes, Ks <= 512, NQ = 2: table [Ks][2][8][16 B], one v_perm_b32 per address, the two entry groups
