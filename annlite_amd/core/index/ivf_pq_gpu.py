@@ -186,6 +186,16 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
             k = max(k, min(32, int(rerank_k or 16)))
         cells = self.probe_cells(q, P)
         kind_l, xq_l = self.pq_codec.scan_inputs(q)
+        if (self.byte_tiles and rerank and kind_l in (LUT_L2, LUT_IPDIST) and self.M == 16 and k <= 16 and k_out <= 16
+                and self.dim <= 256 and (self.dim // self.M) % 4 == 0 and self._n_table < 2 ** 31):
+            # (round 6) float re-rank on the byte-table cell tiles: every probed cell's own list (its best <= k rows by ADC sum at or
+            # below the query's first bound -- private lists: a function of the cell, whatever else runs) -> P x k candidate ids ->
+            # exact distances + top-k in one launch.  The union of a query's lists holds its exact ADC top-k of the probed cells.
+            self.last_pruned_path = 'annlite_ivf_search_candidates (byte-table cell tiles) + annlite_rerank_topk'
+            ids = ops.ivf_search_candidates(kind_l, xq_l, self.pq_codec.codebooks_dev, self._table, cells, self.n_cells, self._cell_rows,
+                                            self._cell_order, k, self.M, self.Ks, row_ids=self._row_ids, valid_bits=self._table_bits(indices),
+                                            n_rows=self._n_table, codes_layout=CODES_SKEWED, workspace=self._tws)
+            return ops.rerank_topk(int(self.metric), q, self._vectors, ids, k_out, sqrt=self.metric == Metric.EUCLIDEAN)
         if (self.byte_tiles and not rerank and kind_l in (LUT_L2, LUT_IPDIST) and self.M == 16 and k <= 16 and self.dim <= 256
                 and (self.dim // self.M) % 4 == 0 and self._n_table < 2 ** 31):
             # (round 6) the byte-table kernel in cell tiles: exact sums inside the tile, bounds shared by query, one merge

@@ -10,6 +10,7 @@
 // tile, annlite_ivf_merge_lists below) or annlite_pq_search_tiles (the u16 tables, integer sums + annlite_ivf_rescore below): the rows
 // of a cell are contiguous in the code table, a query tile = up to QT queries that probe the same cell, one work item per tile.
 #include "common.h"
+#include "scan_common.h"
 
 namespace annlite {
 
@@ -405,6 +406,22 @@ __global__ __launch_bounds__(256) void ivf_merge_lists_kernel(const unsigned lon
     }
 }
 
+// ---- the per-slot lists as candidate ids (annlite_ivf_search_candidates) ---------------------------
+// out[b][p * k + j] = external id of key j of pair (b, p)'s list (the cell tiles' private lists: the cell's best <= k rows at or below the
+// query's first bound, ascending), -1 where the list is shorter: the input of the exact re-rank (annlite_rerank_topk).
+__global__ __launch_bounds__(256) void ivf_lists_to_ids_kernel(const unsigned long long *__restrict__ lists, int k,
+                                                              const int32_t *__restrict__ slot_of, int64_t n_pairs,
+                                                              const int64_t *__restrict__ row_ids, int64_t id_base,
+                                                              int64_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pairs * k) return;
+    const int64_t pair = i / k;
+    const int j = (int)(i - pair * k);
+    const unsigned long long key = lists[(int64_t)slot_of[pair] * k + j];
+    const uint32_t row = (uint32_t)key;
+    out[i] = key == ~0ull ? (int64_t)-1 : id_base + (row_ids ? row_ids[row] : (int64_t)row);
+}
+
 }  // namespace annlite
 
 using namespace annlite;
@@ -524,4 +541,13 @@ extern "C" int annlite_ivf_merge_lists(const uint64_t *lists_dev, int64_t k, con
                        (const unsigned long long *)lists_dev, (int)k, slot_of_dev, (int)B, (int)P, row_ids_dev, id_base, out_dist_dev,
                        out_id_dev, (flags & ANNLITE_FLAG_SQRT) ? 1 : 0);
     return launch_status("ivf_merge_lists_kernel");
+}
+
+int annlite::launch_ivf_lists_to_ids(const unsigned long long *lists, int64_t k, const int32_t *slot_of, int64_t B, int64_t P,
+                                     const int64_t *row_ids, int64_t id_base, int64_t *out_ids, hipStream_t st) {
+    const int64_t total = B * P * k;
+    if (total == 0) return ANNLITE_OK;
+    hipLaunchKernelGGL(ivf_lists_to_ids_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, lists, (int)k, slot_of, B * P, row_ids,
+                       id_base, out_ids);
+    return launch_status("ivf_lists_to_ids_kernel");
 }

@@ -1680,12 +1680,14 @@ extern "C" int annlite_ivf_search_topk_workspace_bytes(int64_t B, int64_t P, int
     return ANNLITE_OK;
 }
 
-extern "C" int annlite_ivf_search_topk(int lut_kind, const float *queries_dev, int64_t B, int64_t D, const float *codebooks_dev, int64_t M, int64_t Ks,
-                                       const void *codes_dev, int codes_layout, int64_t N, const uint32_t *valid_bits_dev,
-                                       const int32_t *cells_dev, int64_t P, int64_t C, const int64_t *cell_rows_dev,
-                                       const int32_t *cell_order_dev, const int64_t *row_ids_dev, int64_t id_base, int64_t k,
-                                       float *out_dist_dev, int64_t *out_id_dev, int flags, void *workspace_dev, size_t workspace_bytes,
-                                       void *stream) {
+// cand_ids_dev != NULL (annlite_ivf_search_candidates): the slots keep PRIVATE lists -- nothing is shared between a query's tiles, every
+// (query, cell) list is the cell's best <= k rows at or below the query's first bound -- and the lists go out as ids, unmerged
+static int ivf_search_impl(int lut_kind, const float *queries_dev, int64_t B, int64_t D, const float *codebooks_dev, int64_t M, int64_t Ks,
+                           const void *codes_dev, int codes_layout, int64_t N, const uint32_t *valid_bits_dev,
+                           const int32_t *cells_dev, int64_t P, int64_t C, const int64_t *cell_rows_dev,
+                           const int32_t *cell_order_dev, const int64_t *row_ids_dev, int64_t id_base, int64_t k,
+                           float *out_dist_dev, int64_t *out_id_dev, int flags, void *workspace_dev, size_t workspace_bytes,
+                           void *stream, int64_t *cand_ids_dev) {
     ANNLITE_REQUIRE(M == 16 && Ks >= 1 && Ks <= 256 && k >= 1 && k <= 16,
                     "annlite_ivf_search_topk serves M = 16, Ks <= 256, k <= 16 (got M=%lld Ks=%lld k=%lld): ANNLITE_NOT_APPLICABLE shapes take "
                     "annlite_pq_search_tiles + annlite_ivf_rescore", (long long)M, (long long)Ks, (long long)k);
@@ -1697,8 +1699,8 @@ extern "C" int annlite_ivf_search_topk(int lut_kind, const float *queries_dev, i
                     "bad shape B=%lld P=%lld C=%lld N=%lld", (long long)B, (long long)P, (long long)C, (long long)N);
     ANNLITE_REQUIRE(codes_layout == ANNLITE_CODES_PLAIN || codes_layout == ANNLITE_CODES_SKEWED, "codes_layout %d", codes_layout);
     if (B == 0) return ANNLITE_OK;
-    ANNLITE_REQUIRE(queries_dev && codebooks_dev && codes_dev && cells_dev && cell_rows_dev && cell_order_dev && out_dist_dev &&
-                        out_id_dev && workspace_dev,
+    ANNLITE_REQUIRE(queries_dev && codebooks_dev && codes_dev && cells_dev && cell_rows_dev && cell_order_dev &&
+                        (cand_ids_dev || (out_dist_dev && out_id_dev)) && workspace_dev,
                     "null device pointer");
     char *ptr[13];
     const size_t need = ivf_topk_carve(B, P, C, Ks, k, (char *)workspace_dev, ptr);
@@ -1738,7 +1740,16 @@ extern "C" int annlite_ivf_search_topk(int lut_kind, const float *queries_dev, i
     const LutBuild lb = {queries_dev, codebooks_dev, D};
     const bool sk = codes_layout == ANNLITE_CODES_SKEWED;
     unsigned int *item_counter = (unsigned int *)(n_used + 16);
-    rc = launch_seed_build_cells(sk, codes_dev, S, N, valid_bits_dev, lb, lut, B, Ks, k, qstep, qlo, smax, qlom, gkey, st, gseed0, bq, target,
+    // candidate generator: the first bound at the (f k)-th smallest seed sum, f = ANNLITE_IVF_CAND_RANK (default 1: the k-th, the plain
+    // search's).  Measured at 10M rows, 16 of 256 cells, k = 16 (profiles/r06/ivf_cand_rank.txt): f = 1 / 2 / 4 -> 2.44 / 1.72 / 1.21 M q/s on
+    // two streams at re-ranked recall@10 0.803 / 0.813 / 0.813 -- the lists are cut at k rows per cell either way, a looser bound only
+    // lengthens the far cells' lists
+    int64_t k_seed = k;
+    if (cand_ids_dev) {
+        const int64_t f = kn.ivf_cand_rank > 0 ? kn.ivf_cand_rank : 1;
+        k_seed = k * f > 64 ? 64 : k * f;
+    }
+    rc = launch_seed_build_cells(sk, codes_dev, S, N, valid_bits_dev, lb, lut, B, Ks, k_seed, qstep, qlo, smax, qlom, gkey, st, gseed0, bq, target,
                                  cells_dev, P, cell_rows_dev, item_counter, lut_kind == ANNLITE_LUT_IPDIST);
     if (rc != ANNLITE_OK) return rc;
     ScanArgs a = {};
@@ -1764,6 +1775,7 @@ extern "C" int annlite_ivf_search_topk(int lut_kind, const float *queries_dev, i
     a.tile_rows = tile_rows;
     a.vmap = vmap;
     a.item_counter = kn.ivf_static_tiles ? nullptr : item_counter;  // (NULL: the tiles dealt round-robin -- A/B)
+    a.tl_private = cand_ids_dev ? 1 : 0;
     a.gseed0 = gseed0;
     a.btab = bq;
     a.q8_epoch0 = 1 << 28;  // (no epoch ends in a cell tile)
@@ -1788,7 +1800,30 @@ extern "C" int annlite_ivf_search_topk(int lut_kind, const float *queries_dev, i
     rc = launch_q8_scan(1651, sk, a, grid, st);
     prof_end(st);
     if (rc != ANNLITE_OK) return rc;
+    if (cand_ids_dev) return launch_ivf_lists_to_ids((const unsigned long long *)lists, k, slot_of, B, P, row_ids_dev, id_base, cand_ids_dev, st);
     return annlite_ivf_merge_lists((const uint64_t *)lists, k, slot_of, B, P, row_ids_dev, id_base, out_dist_dev, out_id_dev, flags, stream);
+}
+
+extern "C" int annlite_ivf_search_topk(int lut_kind, const float *queries_dev, int64_t B, int64_t D, const float *codebooks_dev, int64_t M, int64_t Ks,
+                                       const void *codes_dev, int codes_layout, int64_t N, const uint32_t *valid_bits_dev,
+                                       const int32_t *cells_dev, int64_t P, int64_t C, const int64_t *cell_rows_dev,
+                                       const int32_t *cell_order_dev, const int64_t *row_ids_dev, int64_t id_base, int64_t k,
+                                       float *out_dist_dev, int64_t *out_id_dev, int flags, void *workspace_dev, size_t workspace_bytes,
+                                       void *stream) {
+    return ivf_search_impl(lut_kind, queries_dev, B, D, codebooks_dev, M, Ks, codes_dev, codes_layout, N, valid_bits_dev, cells_dev, P, C,
+                           cell_rows_dev, cell_order_dev, row_ids_dev, id_base, k, out_dist_dev, out_id_dev, flags, workspace_dev, workspace_bytes,
+                           stream, nullptr);
+}
+
+extern "C" int annlite_ivf_search_candidates(int lut_kind, const float *queries_dev, int64_t B, int64_t D, const float *codebooks_dev, int64_t M,
+                                             int64_t Ks, const void *codes_dev, int codes_layout, int64_t N, const uint32_t *valid_bits_dev,
+                                             const int32_t *cells_dev, int64_t P, int64_t C, const int64_t *cell_rows_dev,
+                                             const int32_t *cell_order_dev, const int64_t *row_ids_dev, int64_t id_base, int64_t k,
+                                             int64_t *out_ids_dev, void *workspace_dev, size_t workspace_bytes, void *stream) {
+    ANNLITE_REQUIRE(out_ids_dev != nullptr || B == 0, "out_ids_dev is NULL");
+    return ivf_search_impl(lut_kind, queries_dev, B, D, codebooks_dev, M, Ks, codes_dev, codes_layout, N, valid_bits_dev, cells_dev, P, C,
+                           cell_rows_dev, cell_order_dev, row_ids_dev, id_base, k, nullptr, nullptr, 0, workspace_dev, workspace_bytes, stream,
+                           out_ids_dev);
 }
 
 extern "C" int annlite_adc_scan_candidates(const void *codes_dev, int code_bytes, int codes_layout, int64_t N,

@@ -52,6 +52,8 @@ struct ScanArgs {
     // tile mode (IVF cells, annlite_pq_search_tiles): every query tile scans its OWN row range, one work item per
     // tile (n_slices = 1); the tiles are handed out dynamically, longest first
     const int64_t *tile_rows;    // [n_tiles][2] (begin: multiple of 64, end); begin < 0: unused tile; NULL = slices
+    int32_t tl_private;          // byte-table kernel in cell tiles (TL): 1 = the slots' lists are PRIVATE -- a query's bound is neither published to
+                                 // nor imported from its other tiles (annlite_ivf_search_candidates: every list is a function of its own cell)
     const int32_t *vmap;         // [n_tiles * QT] >= 0: the query whose tables the slot scans with (q16 / smax / qstep
                                  // hold the REAL queries); < 0: padding slot (never passes the filter)
     unsigned int *item_counter;  // starts at 0xffffffff (workspace fill): next item = atomicAdd + 1
@@ -378,6 +380,9 @@ int launch_seed_build(bool skewed, const void *codes_dev, int64_t S, int64_t N, 
                       int n_cand = 0);
 // pruned search over cells (annlite_ivf_search_topk): the same launch with per-query seed rows (the query's nearest cell) and the
 // byte tables per QUERY (bq [ceil16(B)][Ks][16], quantised for gseed0) instead of per tile
+// the cell tiles' per-slot lists as ids, unmerged (ivf.hip): out[b][p * k + j] = id_base + row_ids[row] of key j of pair (b, p)'s list, -1 = none
+int launch_ivf_lists_to_ids(const unsigned long long *lists, int64_t k, const int32_t *slot_of, int64_t B, int64_t P, const int64_t *row_ids,
+                            int64_t id_base, int64_t *out_ids, hipStream_t st);
 // item_counter (optional): reset to 0 for the scan behind the launch
 int launch_seed_build_cells(bool skewed, const void *codes_dev, int64_t S, int64_t N, const uint32_t *valid_bits_dev,
                             const LutBuild &build, float *lut_out, int64_t B, int64_t Ks, int64_t k, float *qstep, double *qlo,

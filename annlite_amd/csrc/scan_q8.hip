@@ -1232,7 +1232,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
         // epochs end after steps q8_epoch0, q8_epoch0 * mul + (mul - 1), ... and after the last step
         if (wave == NS) {
             // ------------------------------------------------------------------------------- consumer wave
-            const FlushCtx fc = {(const uint8_t *)a.codes, a.lut, a.smax, a.qstep, a.qlo, a.gkey, a.gk2, nullptr,
+            const FlushCtx fc = {(const uint8_t *)a.codes, a.lut, a.smax, a.qstep, a.qlo, (TL && a.tl_private) ? nullptr : a.gkey, a.gk2, nullptr,
                                  a.Ks, tile * QT, a.n_slices, slice, km1, a.jm1, a.dbg_skip,
                                  0u, 0u, 0u, 0u, 0u, 0u, a.q8_pos};
             // what the other workgroups of these queries (the other row slices) have proven: the best k-th key any of
@@ -1240,6 +1240,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void adc_scan_q8_kernel(const Scan
             // (below; +1: that row itself must still be accepted)
             auto import_bounds = [&]() {
                 if (!a.gkey) return;
+                if constexpr (TL) {
+                    if (a.tl_private) return;  // (private lists: the slot's first bound, read when the image was built, and its own k-th key)
+                }
                 // lane = (slot, half): all loads in flight together -- one global round trip per group of 8 slices for the
                 // whole tile
                 const int q = lane & 31, part = lane >> 5;

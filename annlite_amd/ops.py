@@ -456,6 +456,29 @@ def ivf_search_topk(lut_kind: int, queries: torch.Tensor, codebooks: torch.Tenso
     return od, oi
 
 
+def ivf_search_candidates(lut_kind: int, queries: torch.Tensor, codebooks: torch.Tensor, codes: torch.Tensor, cells: torch.Tensor,
+                          n_cells: int, cell_rows: torch.Tensor, cell_order: torch.Tensor, k: int, M: int, Ks: int,
+                          row_ids: Optional[torch.Tensor] = None, valid_bits: Optional[torch.Tensor] = None,
+                          n_rows: Optional[int] = None, codes_layout: int = CODES_PLAIN, id_base: int = 0,
+                          workspace: Optional[ScanWorkspace] = None) -> torch.Tensor:
+    """``annlite_ivf_search_candidates``: the pruned search's pipeline as the candidate generator of an exact re-rank -- every
+    (query, probed cell) list on its own (the cell's best <= k rows at or below the query's first bound).  Returns i64 [B, P * k]
+    external ids, -1 = none."""
+    N = codes.shape[0] if n_rows is None else n_rows
+    B, D = queries.shape
+    P = cells.shape[1]
+    need = ctypes.c_int64(0)
+    check(lib().annlite_ivf_search_topk_workspace_bytes(B, P, n_cells, M, Ks, k, ctypes.byref(need)), 'ivf_search_topk_workspace_bytes')
+    dev = codes.device
+    ws = (workspace or ScanWorkspace()).get(int(need.value), dev)
+    out = torch.empty((B, P * k), dtype=torch.int64, device=dev)
+    check(lib().annlite_ivf_search_candidates(lut_kind, queries.data_ptr(), B, D, codebooks.data_ptr(), M, Ks, codes.data_ptr(), codes_layout,
+                                              N, _ptr(valid_bits), cells.data_ptr(), P, n_cells, cell_rows.data_ptr(), cell_order.data_ptr(),
+                                              _ptr(row_ids), id_base, k, out.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()),
+          'ivf_search_candidates')
+    return out
+
+
 def topk_merge_packed(packed: torch.Tensor, sqrt: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """[G,B,k,2] i64 (id, distance bits) -> ([B,k] f32, [B,k] i64), same order rule as ``topk_merge``."""
     G, B, k, _ = packed.shape

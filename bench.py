@@ -715,6 +715,33 @@ def main():
             got_iv = iv[1][:nq].cpu().numpy()
             ivf_rec['rerank'] = {'value': B * n_iv / (time.perf_counter() - t0), 'unit': 'queries/s', 'rerank_k': 32,
                                  'recall_at_10': float(np.mean([len(set(got_iv[b]) & set(truth[b])) / k for b in range(nq)]))}
+            ivf_rec['rerank']['path'] = ivf.last_pruned_path
+            # (round 6) the re-rank on the byte-table cell tiles: every probed cell's own ADC list of 16 (private lists) as the candidates,
+            # exact distances + top-k fused; one stream, then consecutive batches on the two caller streams
+            try:
+                for _ in range(2):
+                    iv = ivf.search_batch(queries, limit=k, n_probe=P, rerank_k=16)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n_iv):
+                    iv = ivf.search_batch(queries, limit=k, n_probe=P, rerank_k=16)
+                torch.cuda.synchronize()
+                q1 = B * n_iv / (time.perf_counter() - t0)
+                for j in range(4):
+                    with torch.cuda.stream(i_streams[j % 2]):
+                        ivf.search_batch(queries, limit=k, n_probe=P, rerank_k=16)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for j in range(2 * n_iv):
+                    with torch.cuda.stream(i_streams[j % 2]):
+                        iv = ivf.search_batch(queries, limit=k, n_probe=P, rerank_k=16)
+                torch.cuda.synchronize()
+                q2 = B * 2 * n_iv / (time.perf_counter() - t0)
+                got_iv = iv[1][:nq].cpu().numpy()
+                ivf_rec['rerank16'] = {'value': q2, 'unit': 'queries/s', 'streams': 2, 'one_stream_value': q1, 'rerank_k': 16, 'path': ivf.last_pruned_path,
+                                       'recall_at_10': float(np.mean([len(set(got_iv[b]) & set(truth[b])) / k for b in range(nq)]))}
+            except Exception as ex:  # noqa: BLE001
+                ivf_rec['rerank16'] = {'error': repr(ex)[:200]}
         del ivf
 
     # ---- the drop-in API itself (north_star: "keeping the AnnLite(...)/index()/search() Python API and DocArray result shape"):
@@ -982,6 +1009,8 @@ def main():
         if ivf_rec:
             summ['ivf'] = {'qps': _r(ivf_rec['value'], 0), 'qps_1s': _r(ivf_rec.get('one_stream_value', 0), 0),
                            'agree': _r(ivf_rec['agreement_with_exhaustive_adc_top10'], 3)}
+            if isinstance(ivf_rec.get('rerank16'), dict) and 'value' in ivf_rec['rerank16']:
+                summ['ivf']['rr16'] = [_r(ivf_rec['rerank16']['value'], 0), _r(ivf_rec['rerank16']['recall_at_10'], 3)]
         if facade:
             summ['facade'] = {'search_qps': _r(facade['search']['value'], 0), 'numpy_qps': _r(facade['search_numpy']['value'], 0)}
         for name in ('c2', 'c4', 'c5', 'm32', 'k50', 'uniform'):

@@ -145,3 +145,74 @@ def test_c_abi_argument_checks():
     order = torch.zeros((1,), dtype=torch.int32, device=dev)
     with pytest.raises(Exception, match='M = 16'):
         ops.ivf_search_topk(1, q, cb, codes, cells, 1, rows, order, 10, 8, 256)
+
+
+def test_candidate_lists_are_private_prefixes_and_hold_the_adc_topk(oracle):
+    """annlite_ivf_search_candidates: every (query, probed cell) list is a PREFIX of that cell's exact ADC ranking (the cell's best rows at
+    or below the query's first bound, at most k), whatever the other tiles do; the union of a query's lists holds its exact ADC top-k of
+    the probed cells"""
+    from annlite_amd import Metric, ops
+    from annlite_amd._capi import CODES_SKEWED, LUT_L2
+
+    N, D, C, P, B, k = 30000, 64, 24, 5, 24, 16
+    idx, codec, vq, x = _build(N, D, 16, C, Metric.EUCLIDEAN, seed=41)
+    _, q = _data(np.random.RandomState(42), 1, D, B)
+    idx._seal()
+    qd = idx._pre(q)
+    cells = idx.probe_cells(qd, P)
+    args = (LUT_L2, qd, codec.codebooks_dev, idx._table, cells, C, idx._cell_rows, idx._cell_order, k, 16, 256)
+    kw = dict(row_ids=idx._row_ids, n_rows=idx._n_table, codes_layout=CODES_SKEWED)
+    ids = ops.ivf_search_candidates(*args, **kw).cpu().numpy().reshape(B, P, k)
+    # (a second call may cut the far cells' lists at another length: the first bound is the k-th smallest of per-(wave, lane) minima over
+    # seed blocks the waves DRAW -- any such bound is valid; the prefix property below holds for both calls)
+    ids2 = ops.ivf_search_candidates(*args, **kw).cpu().numpy().reshape(B, P, k)
+    assert np.array_equal(ids[:, 0], ids2[:, 0])  # the nearest cell's list: complete either way
+    codes = ops.codes_to_numpy(idx._plain_codes(N))
+    cell_of = idx._cell_of[:N].cpu().numpy()
+    probe = cells.cpu().numpy()
+    _, top = oracle.ivf_search(q, codec.codebooks, codes, cell_of, probe, oracle.EUCLIDEAN, 10)
+    n_short = 0
+    for b in range(B):
+        for p in range(P):
+            lst = ids[b, p]
+            n = int((lst >= 0).sum())
+            assert (lst[:n] >= 0).all() and (lst[n:] == -1).all()
+            _, own = oracle.ivf_search(q[b:b + 1], codec.codebooks, codes, cell_of, probe[b:b + 1, p:p + 1], oracle.EUCLIDEAN, k)
+            assert np.array_equal(lst[:n], own[0][:n]), (b, p)
+            n_short += n < min(k, int((cell_of == probe[b, p]).sum()))
+        assert set(top[b].tolist()) <= set(ids[b].reshape(-1).tolist())
+        assert n >= 0
+    assert n_short > 0  # (lists of far cells ARE cut by the first bound: that is the point)
+    # the nearest cell's list is never cut below k rows by the bound (the bound comes from ITS rows)
+    for b in range(B):
+        assert (ids[b, 0] >= 0).sum() == min(k, int((cell_of == probe[b, 0]).sum()))
+
+
+def test_float_rerank_on_the_cell_tiles(oracle):
+    """IvfPQGpuIndex(rerank=True) with limit <= 16: candidates from annlite_ivf_search_candidates, exact distances + top-k fused; the
+    distances are the true ones, the recall is at least the ADC search's, and the u16 pipeline's re-rank is in the same range"""
+    from annlite_amd import Metric
+
+    N, D, C, P, B, k = 40000, 64, 32, 8, 200, 10
+    idx, codec, vq, x = _build(N, D, 16, C, Metric.EUCLIDEAN, seed=51, rerank=True)
+    _, q = _data(np.random.RandomState(52), 1, D, B)
+    d, i = idx.search_batch(q, limit=k, n_probe=P)
+    assert idx.last_pruned_path.startswith('annlite_ivf_search_candidates')
+    assert (i >= 0).all() and (np.diff(d, axis=1) >= -1e-6).all()
+    for b in range(0, B, 17):
+        np.testing.assert_allclose(d[b], np.sqrt(((x[i[b]] - q[b]) ** 2).sum(1)), rtol=1e-4, atol=1e-5)
+        assert len(set(i[b].tolist())) == k
+    truth = np.argsort(((q[:, None, :] - x[None, :, :]) ** 2).sum(2), axis=1)[:, :k] if N * B <= 8_000_000 else None
+    if truth is None:
+        dd = (q ** 2).sum(1)[:, None] + (x ** 2).sum(1)[None, :] - 2.0 * q @ x.T
+        truth = np.argsort(dd, axis=1)[:, :k]
+    rec = lambda ids: float(np.mean([len(set(ids[b]) & set(truth[b])) / k for b in range(B)]))
+    r_new = rec(i)
+    idx.rerank = False
+    _, i_adc = idx.search_batch(q, limit=k, n_probe=P)
+    idx.rerank = True
+    idx.byte_tiles = False
+    _, i_u16 = idx.search_batch(q, limit=k, n_probe=P)
+    assert idx.last_pruned_path.startswith('annlite_pq_search_tiles')
+    idx.byte_tiles = True
+    assert r_new >= rec(i_adc) and r_new >= rec(i_u16) - 0.05, (r_new, rec(i_adc), rec(i_u16))
