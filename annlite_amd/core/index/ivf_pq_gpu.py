@@ -51,7 +51,10 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
         self._sealed = False
         self._table = self._table_plain = self._row_ids = self._cell_rows = self._cell_order = self._pos_of = None
         self.cand_cap = 256  # emitted candidates per (query, cell) list; an overflowing list falls back to the whole cell
-        self.byte_tiles = True  # M = 16, k <= 16, no float re-rank: annlite_ivf_search_topk (False: the u16 tile scan + re-score)
+        self.byte_tiles = True  # M = 16, k <= 16: annlite_ivf_search_topk / _candidates (False: the u16 tile scan + re-score)
+        # float re-rank on the cell tiles: the candidate lists' first bound = the (rank x k)-th smallest seed sum of the nearest cell (1: the
+        # smallest pool that still holds the ADC top-k, fastest; larger: longer lists from the far cells, better recall; include/annlite_hip.h)
+        self.rerank_bound_rank = 2
         self._tws = ops.ScanWorkspace()
         self.last_pruned_path = None  # which kernels served the last pruned search (measurement scripts)
 
@@ -194,7 +197,8 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
             self.last_pruned_path = 'annlite_ivf_search_candidates (byte-table cell tiles) + annlite_rerank_topk'
             ids = ops.ivf_search_candidates(kind_l, xq_l, self.pq_codec.codebooks_dev, self._table, cells, self.n_cells, self._cell_rows,
                                             self._cell_order, k, self.M, self.Ks, row_ids=self._row_ids, valid_bits=self._table_bits(indices),
-                                            n_rows=self._n_table, codes_layout=CODES_SKEWED, workspace=self._tws)
+                                            n_rows=self._n_table, codes_layout=CODES_SKEWED, workspace=self._tws,
+                                            bound_rank=self.rerank_bound_rank)
             return ops.rerank_topk(int(self.metric), q, self._vectors, ids, k_out, sqrt=self.metric == Metric.EUCLIDEAN)
         if (self.byte_tiles and not rerank and kind_l in (LUT_L2, LUT_IPDIST) and self.M == 16 and k <= 16 and self.dim <= 256
                 and (self.dim // self.M) % 4 == 0 and self._n_table < 2 ** 31):

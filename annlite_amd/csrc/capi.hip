@@ -96,7 +96,6 @@ static Knobs *parse_knobs() {
     k->graph_hash_bits = env_int("ANNLITE_GRAPH_HASH_BITS", -1);
     k->graph_seq_insert = getenv("ANNLITE_GRAPH_SEQ_INSERT") != nullptr;
     k->ivf_first = env_int("ANNLITE_IVF_FIRST", -1);
-    k->ivf_cand_rank = env_int("ANNLITE_IVF_CAND_RANK", 0);
     k->ivf_static_tiles = getenv("ANNLITE_IVF_STATIC_TILES") != nullptr;
     return k;
 }

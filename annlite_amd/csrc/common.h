@@ -73,7 +73,6 @@ struct Knobs {
     int graph_hash_bits;        // ANNLITE_GRAPH_HASH_BITS
     bool graph_seq_insert;      // ANNLITE_GRAPH_SEQ_INSERT
     bool ivf_static_tiles;      // ANNLITE_IVF_STATIC_TILES (A/B: the cell tiles dealt round-robin instead of drawn from a counter)
-    int ivf_cand_rank;          // ANNLITE_IVF_CAND_RANK (annlite_ivf_search_candidates: the first bound at the (factor x k)-th seed sum; 0: default 1)
     int ivf_first;              // ANNLITE_IVF_FIRST (annlite_ivf_search_topk: probes per query whose tiles come first; -1: the default)
 };
 const Knobs &knobs();

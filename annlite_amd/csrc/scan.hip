@@ -1687,7 +1687,7 @@ static int ivf_search_impl(int lut_kind, const float *queries_dev, int64_t B, in
                            const int32_t *cells_dev, int64_t P, int64_t C, const int64_t *cell_rows_dev,
                            const int32_t *cell_order_dev, const int64_t *row_ids_dev, int64_t id_base, int64_t k,
                            float *out_dist_dev, int64_t *out_id_dev, int flags, void *workspace_dev, size_t workspace_bytes,
-                           void *stream, int64_t *cand_ids_dev) {
+                           void *stream, int64_t *cand_ids_dev, int64_t bound_rank) {
     ANNLITE_REQUIRE(M == 16 && Ks >= 1 && Ks <= 256 && k >= 1 && k <= 16,
                     "annlite_ivf_search_topk serves M = 16, Ks <= 256, k <= 16 (got M=%lld Ks=%lld k=%lld): ANNLITE_NOT_APPLICABLE shapes take "
                     "annlite_pq_search_tiles + annlite_ivf_rescore", (long long)M, (long long)Ks, (long long)k);
@@ -1740,15 +1740,11 @@ static int ivf_search_impl(int lut_kind, const float *queries_dev, int64_t B, in
     const LutBuild lb = {queries_dev, codebooks_dev, D};
     const bool sk = codes_layout == ANNLITE_CODES_SKEWED;
     unsigned int *item_counter = (unsigned int *)(n_used + 16);
-    // candidate generator: the first bound at the (f k)-th smallest seed sum, f = ANNLITE_IVF_CAND_RANK (default 1: the k-th, the plain
-    // search's).  Measured at 10M rows, 16 of 256 cells, k = 16 (profiles/r06/ivf_cand_rank.txt): f = 1 / 2 / 4 -> 2.44 / 1.72 / 1.21 M q/s on
-    // two streams at re-ranked recall@10 0.803 / 0.813 / 0.813 -- the lists are cut at k rows per cell either way, a looser bound only
-    // lengthens the far cells' lists
+    // candidate generator: the first bound at the (bound_rank x k)-th smallest seed sum (at most the 64th: the seed lists' length).  Measured
+    // at 10M rows, 16 of 256 cells, k = 16 (profiles/r06/ivf_cand_rank.txt): rank 1 / 2 / 4 -> 2.44 / 1.72 / 1.21 M q/s on two streams at
+    // re-ranked recall@10 0.803 / 0.813 / 0.813 -- a looser bound only lengthens the far cells' lists (cut at k rows per cell either way)
     int64_t k_seed = k;
-    if (cand_ids_dev) {
-        const int64_t f = kn.ivf_cand_rank > 0 ? kn.ivf_cand_rank : 1;
-        k_seed = k * f > 64 ? 64 : k * f;
-    }
+    if (cand_ids_dev) k_seed = k * bound_rank > 64 ? 64 : k * bound_rank;
     rc = launch_seed_build_cells(sk, codes_dev, S, N, valid_bits_dev, lb, lut, B, Ks, k_seed, qstep, qlo, smax, qlom, gkey, st, gseed0, bq, target,
                                  cells_dev, P, cell_rows_dev, item_counter, lut_kind == ANNLITE_LUT_IPDIST);
     if (rc != ANNLITE_OK) return rc;
@@ -1812,18 +1808,20 @@ extern "C" int annlite_ivf_search_topk(int lut_kind, const float *queries_dev, i
                                        void *stream) {
     return ivf_search_impl(lut_kind, queries_dev, B, D, codebooks_dev, M, Ks, codes_dev, codes_layout, N, valid_bits_dev, cells_dev, P, C,
                            cell_rows_dev, cell_order_dev, row_ids_dev, id_base, k, out_dist_dev, out_id_dev, flags, workspace_dev, workspace_bytes,
-                           stream, nullptr);
+                           stream, nullptr, 1);
 }
 
 extern "C" int annlite_ivf_search_candidates(int lut_kind, const float *queries_dev, int64_t B, int64_t D, const float *codebooks_dev, int64_t M,
                                              int64_t Ks, const void *codes_dev, int codes_layout, int64_t N, const uint32_t *valid_bits_dev,
                                              const int32_t *cells_dev, int64_t P, int64_t C, const int64_t *cell_rows_dev,
                                              const int32_t *cell_order_dev, const int64_t *row_ids_dev, int64_t id_base, int64_t k,
-                                             int64_t *out_ids_dev, void *workspace_dev, size_t workspace_bytes, void *stream) {
+                                             int64_t bound_rank, int64_t *out_ids_dev, void *workspace_dev, size_t workspace_bytes,
+                                             void *stream) {
     ANNLITE_REQUIRE(out_ids_dev != nullptr || B == 0, "out_ids_dev is NULL");
+    ANNLITE_REQUIRE(bound_rank >= 1 && bound_rank <= 64, "bound_rank %lld (1 .. 64)", (long long)bound_rank);
     return ivf_search_impl(lut_kind, queries_dev, B, D, codebooks_dev, M, Ks, codes_dev, codes_layout, N, valid_bits_dev, cells_dev, P, C,
                            cell_rows_dev, cell_order_dev, row_ids_dev, id_base, k, nullptr, nullptr, 0, workspace_dev, workspace_bytes, stream,
-                           out_ids_dev);
+                           out_ids_dev, bound_rank);
 }
 
 extern "C" int annlite_adc_scan_candidates(const void *codes_dev, int code_bytes, int codes_layout, int64_t N,

@@ -19,6 +19,8 @@ def main():
     p.add_argument('--cells', type=int, default=256)
     p.add_argument('--probe', type=int, default=16)
     p.add_argument('--loop', type=int, default=0)
+    p.add_argument('--rerank', type=int, default=0, help='> 0: the float re-rank on the cell tiles (annlite_ivf_search_candidates + '
+                   'annlite_rerank_topk, rerank_k 16) with this bound_rank instead of the plain pruned search')
     args = p.parse_args()
     from annlite_amd import Metric, PQCodec, _capi
     from annlite_amd.core.codec.vq import VQCodec
@@ -37,7 +39,9 @@ def main():
     vq = VQCodec(C, metric=Metric.EUCLIDEAN, iter=15, n_init=1)
     vq.seed = 11
     vq.fit(train)
-    idx = IvfPQGpuIndex(dim=D, metric=Metric.EUCLIDEAN, pq_codec=codec, vq_codec=vq, initial_size=N, rerank=False)
+    idx = IvfPQGpuIndex(dim=D, metric=Metric.EUCLIDEAN, pq_codec=codec, vq_codec=vq, initial_size=N, rerank=args.rerank > 0)
+    idx.rerank_bound_rank = max(1, args.rerank)
+    kw = dict(rerank_k=16) if args.rerank else {}
     for c in range((N + CH - 1) // CH):
         rows = min(CH, N - c * CH)
         idx.add_with_ids(bench.gen_chunk(c, rows, D, A, dev), torch.arange(c * CH, c * CH + rows, device=dev))
@@ -46,14 +50,16 @@ def main():
     gq.manual_seed(4321)
     queries = (torch.randn((B, 16), generator=gq, device=dev) @ A + 0.05 * torch.randn((B, D), generator=gq, device=dev)).contiguous()
     for _ in range(3):
-        idx.search_batch(queries, limit=k, n_probe=P)
+        idx.search_batch(queries, limit=k, n_probe=P, **kw)
     torch.cuda.synchronize()
+    if args.rerank:
+        print('path:', idx.last_pruned_path, 'bound_rank', idx.rerank_bound_rank, flush=True)
     if args.loop:
         for _ in range(args.loop):
-            idx.search_batch(queries, limit=k, n_probe=P)
+            idx.search_batch(queries, limit=k, n_probe=P, **kw)
         torch.cuda.synchronize()
         return
-    idx.search_batch(queries, limit=k, n_probe=P)
+    idx.search_batch(queries, limit=k, n_probe=P, **kw)
     torch.cuda.synchronize()
     it = _capi.debug_items()
     cnt = _capi.debug_counters()

@@ -1,4 +1,5 @@
 #!/usr/bin/env bash
+# (ANNLITE_IVF_CAND_RANK was this call's switch; it has since become the C entry's bound_rank argument / IvfPQGpuIndex.rerank_bound_rank)
 # Round 6, call 55: candidate generator on the cell tiles -- the first bound's rank (1 / 2 / 4 x k) against pool size, recall and rate.
 set -u
 cd "$(dirname "$0")/.."; OUT=gpurun_out/r06c55; mkdir -p $OUT

