@@ -53,8 +53,15 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
         self.cand_cap = 256  # emitted candidates per (query, cell) list; an overflowing list falls back to the whole cell
         self.byte_tiles = True  # M = 16, k <= 16: annlite_ivf_search_topk / _candidates (False: the u16 tile scan + re-score)
         # float re-rank on the cell tiles: the candidate lists' first bound = the (rank x k)-th smallest seed sum of the nearest cell (1: the
-        # smallest pool that still holds the ADC top-k, fastest; larger: longer lists from the far cells, better recall; include/annlite_hip.h)
-        self.rerank_bound_rank = 2
+        # smallest pool that still holds the ADC top-k; larger: longer lists from the far cells, better recall; include/annlite_hip.h).
+        # 0: no private lists at all -- the pool is exactly the ADC top-`rerank_k` (annlite_ivf_search_topk's ids), the fastest
+        self.rerank_bound_rank = 1
+        # ... and the nearest cells in parts: a list holds 16 keys, so a whole cell hands the re-rank 16 rows at most -- the cap on the
+        # recall of that path, since the nearest cells hold most true neighbours.  (n, S): each of the query's n nearest cells is probed as
+        # S contiguous row ranges ("sub-cells": entries C .. C (1 + S) of the split cell table, _split_tables), each with a list of its own
+        # -- up to 16 S rows from such a cell.  (0, 1): whole cells only.
+        self.rerank_split = (2, 4)
+        self._split_cache = None
         self._tws = ops.ScanWorkspace()
         self.last_pruned_path = None  # which kernels served the last pruned search (measurement scripts)
 
@@ -122,7 +129,26 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
         self._cell_rows = torch.stack([begin, begin + counts], dim=1).contiguous()
         self._cell_order = torch.sort(counts, descending=True, stable=True).indices.to(torch.int32).contiguous()
         self._n_table = Nt
+        self._split_cache = None
         self._sealed = True
+
+    def _split_tables(self, S: int):
+        """(cell_rows [C (1 + S)][2], cell_order) with every cell ALSO listed as S contiguous parts: entry C + c S + s = part s of cell c (begins at
+        multiples of 64 rows like the cells themselves; a cell of fewer than S blocks leaves empty parts).  A query probes a cell either whole
+        or through its parts, never both."""
+        if self._split_cache is None or self._split_cache[0] != S:
+            begin, ln = self._cell_rows[:, 0], self._cell_rows[:, 1] - self._cell_rows[:, 0]
+            chunk = ((ln + S - 1) // S + 63) // 64 * 64
+            s = torch.arange(S, device=begin.device)[None, :]
+            lo = torch.minimum(s * chunk[:, None], ln[:, None])
+            hi = torch.minimum((s + 1) * chunk[:, None], ln[:, None])
+            some = hi > lo  # (an empty part is [begin, begin): a multiple of 64 like every other range's first row)
+            lo, hi = torch.where(some, lo, torch.zeros_like(lo)), torch.where(some, hi, torch.zeros_like(hi))
+            parts = torch.stack([begin[:, None] + lo, begin[:, None] + hi], dim=2).reshape(-1, 2)
+            rows = torch.cat([self._cell_rows, parts]).contiguous()
+            order = torch.sort(rows[:, 1] - rows[:, 0], descending=True, stable=True).indices.to(torch.int32).contiguous()
+            self._split_cache = (S, rows, order)
+        return self._split_cache[1], self._split_cache[2]
 
     def _select_kind_and_centroids(self) -> Tuple[int, torch.Tensor]:
         """cdist(query, vq codebook, metric) of ``_cell_selection`` (index.py:462-464) as a ranking."""
@@ -194,9 +220,27 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
             # (round 6) float re-rank on the byte-table cell tiles: every probed cell's own list (its best <= k rows by ADC sum at or
             # below the query's first bound -- private lists: a function of the cell, whatever else runs) -> P x k candidate ids ->
             # exact distances + top-k in one launch.  The union of a query's lists holds its exact ADC top-k of the probed cells.
+            if self.rerank_bound_rank == 0:
+                # exactly the ADC top-`rerank_k` of the probed cells as the pool: the plain pruned search (bounds SHARED by a query's
+                # tiles, the fastest scan) with k = rerank_k, its ids re-ranked
+                self.last_pruned_path = 'annlite_ivf_search_topk (byte-table cell tiles) + annlite_rerank_topk'
+                _, ids = ops.ivf_search_topk(kind_l, xq_l, self.pq_codec.codebooks_dev, self._table, cells, self.n_cells, self._cell_rows,
+                                             self._cell_order, k, self.M, self.Ks, row_ids=self._row_ids,
+                                             valid_bits=self._table_bits(indices), n_rows=self._n_table, codes_layout=CODES_SKEWED,
+                                             workspace=self._tws)
+                return ops.rerank_topk(int(self.metric), q, self._vectors, ids, k_out, sqrt=self.metric == Metric.EUCLIDEAN)
             self.last_pruned_path = 'annlite_ivf_search_candidates (byte-table cell tiles) + annlite_rerank_topk'
-            ids = ops.ivf_search_candidates(kind_l, xq_l, self.pq_codec.codebooks_dev, self._table, cells, self.n_cells, self._cell_rows,
-                                            self._cell_order, k, self.M, self.Ks, row_ids=self._row_ids, valid_bits=self._table_bits(indices),
+            n_split, S = self.rerank_split
+            n_split = min(int(n_split), P)
+            cell_rows, cell_order, n_entries = self._cell_rows, self._cell_order, self.n_cells
+            if n_split > 0 and S > 1:
+                cell_rows, cell_order = self._split_tables(int(S))
+                n_entries = cell_rows.shape[0]
+                parts = self.n_cells + cells[:, :n_split, None].to(torch.int64) * S + torch.arange(S, device=cells.device)
+                cells = torch.cat([parts.reshape(cells.shape[0], -1).to(torch.int32), cells[:, n_split:]], dim=1).contiguous()
+                self.last_pruned_path += ' (nearest %d cells in %d parts)' % (n_split, S)
+            ids = ops.ivf_search_candidates(kind_l, xq_l, self.pq_codec.codebooks_dev, self._table, cells, n_entries, cell_rows,
+                                            cell_order, k, self.M, self.Ks, row_ids=self._row_ids, valid_bits=self._table_bits(indices),
                                             n_rows=self._n_table, codes_layout=CODES_SKEWED, workspace=self._tws,
                                             bound_rank=self.rerank_bound_rank)
             return ops.rerank_topk(int(self.metric), q, self._vectors, ids, k_out, sqrt=self.metric == Metric.EUCLIDEAN)

@@ -460,7 +460,7 @@ def ivf_search_candidates(lut_kind: int, queries: torch.Tensor, codebooks: torch
                           n_cells: int, cell_rows: torch.Tensor, cell_order: torch.Tensor, k: int, M: int, Ks: int,
                           row_ids: Optional[torch.Tensor] = None, valid_bits: Optional[torch.Tensor] = None,
                           n_rows: Optional[int] = None, codes_layout: int = CODES_PLAIN, id_base: int = 0,
-                          workspace: Optional[ScanWorkspace] = None, bound_rank: int = 2) -> torch.Tensor:
+                          workspace: Optional[ScanWorkspace] = None, bound_rank: int = 1) -> torch.Tensor:
     """``annlite_ivf_search_candidates``: the pruned search's pipeline as the candidate generator of an exact re-rank -- every
     (query, probed cell) list on its own (the cell's best <= k rows at or below the query's first bound, the
     ``min(bound_rank * k, 64)``-th smallest seed sum of its nearest cell).  Returns i64 [B, P * k] external ids, -1 = none."""

@@ -719,27 +719,41 @@ def main():
             # (round 6) the re-rank on the byte-table cell tiles: every probed cell's own ADC list of 16 (private lists) as the candidates,
             # exact distances + top-k fused; one stream, then consecutive batches on the two caller streams
             try:
-                for _ in range(2):
-                    iv = ivf.search_batch(queries, limit=k, n_probe=P, rerank_k=16)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(n_iv):
-                    iv = ivf.search_batch(queries, limit=k, n_probe=P, rerank_k=16)
-                torch.cuda.synchronize()
-                q1 = B * n_iv / (time.perf_counter() - t0)
-                for j in range(4):
-                    with torch.cuda.stream(i_streams[j % 2]):
-                        ivf.search_batch(queries, limit=k, n_probe=P, rerank_k=16)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for j in range(2 * n_iv):
-                    with torch.cuda.stream(i_streams[j % 2]):
+                def _rr16():
+                    for _ in range(2):
                         iv = ivf.search_batch(queries, limit=k, n_probe=P, rerank_k=16)
-                torch.cuda.synchronize()
-                q2 = B * 2 * n_iv / (time.perf_counter() - t0)
-                got_iv = iv[1][:nq].cpu().numpy()
-                ivf_rec['rerank16'] = {'value': q2, 'unit': 'queries/s', 'streams': 2, 'one_stream_value': q1, 'rerank_k': 16, 'path': ivf.last_pruned_path,
-                                       'recall_at_10': float(np.mean([len(set(got_iv[b]) & set(truth[b])) / k for b in range(nq)]))}
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(n_iv):
+                        iv = ivf.search_batch(queries, limit=k, n_probe=P, rerank_k=16)
+                    torch.cuda.synchronize()
+                    q1 = B * n_iv / (time.perf_counter() - t0)
+                    for j in range(4):
+                        with torch.cuda.stream(i_streams[j % 2]):
+                            ivf.search_batch(queries, limit=k, n_probe=P, rerank_k=16)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for j in range(2 * n_iv):
+                        with torch.cuda.stream(i_streams[j % 2]):
+                            iv = ivf.search_batch(queries, limit=k, n_probe=P, rerank_k=16)
+                    torch.cuda.synchronize()
+                    q2 = B * 2 * n_iv / (time.perf_counter() - t0)
+                    got = iv[1][:nq].cpu().numpy()
+                    return {'value': q2, 'unit': 'queries/s', 'streams': 2, 'one_stream_value': q1, 'rerank_k': 16,
+                            'bound_rank': ivf.rerank_bound_rank, 'path': ivf.last_pruned_path,
+                            'recall_at_10': float(np.mean([len(set(got[b]) & set(truth[b])) / k for b in range(nq)]))}
+
+                ivf_rec['rerank16'] = _rr16()  # the index's default: private lists, first bound at the 16-th seed sum, nearest 2 cells in 4 parts
+                ivf_rec['rerank16']['split'] = list(ivf.rerank_split)
+                split0 = ivf.rerank_split
+                ivf.rerank_split = (0, 1)      # whole cells only (16 rows per cell at most)
+                ivf_rec['rerank16_whole_cells'] = _rr16()
+                ivf.rerank_split = split0
+                ivf.rerank_bound_rank = 2      # a looser first bound (the 32nd seed sum): longer lists from the far cells
+                ivf_rec['rerank16_rank2'] = _rr16()
+                ivf.rerank_bound_rank = 0      # the pool = exactly the ADC top-16 (shared bounds: annlite_ivf_search_topk's ids)
+                ivf_rec['rerank16_top16'] = _rr16()
+                ivf.rerank_bound_rank = 1
             except Exception as ex:  # noqa: BLE001
                 ivf_rec['rerank16'] = {'error': repr(ex)[:200]}
         del ivf
@@ -1011,6 +1025,8 @@ def main():
                            'agree': _r(ivf_rec['agreement_with_exhaustive_adc_top10'], 3)}
             if isinstance(ivf_rec.get('rerank16'), dict) and 'value' in ivf_rec['rerank16']:
                 summ['ivf']['rr16'] = [_r(ivf_rec['rerank16']['value'], 0), _r(ivf_rec['rerank16']['recall_at_10'], 3)]
+            if isinstance(ivf_rec.get('rerank16_rank2'), dict) and 'value' in ivf_rec['rerank16_rank2']:
+                summ['ivf']['rr16_r2'] = [_r(ivf_rec['rerank16_rank2']['value'], 0), _r(ivf_rec['rerank16_rank2']['recall_at_10'], 3)]
         if facade:
             summ['facade'] = {'search_qps': _r(facade['search']['value'], 0), 'numpy_qps': _r(facade['search_numpy']['value'], 0)}
         for name in ('c2', 'c4', 'c5', 'm32', 'k50', 'uniform'):

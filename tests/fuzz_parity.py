@@ -207,6 +207,32 @@ def run_cells(seconds, seed, verbose=True, candidates=True):
                     n_bad += 1
                     print('MISMATCH candidates (%s)' % why, dict(dsub=dsub, Ks=Ks, N=N, C=C, P=P, B=B, k=k, kind=kind, order=str(order),
                                                                  valid=str(vmode), layout=layout), flush=True)
+                # ... and with every probed cell in S parts (IvfPQGpuIndex.rerank_split's cell table: entries C + c S + s = contiguous row
+                # ranges of cell c, first rows at multiples of 64): the same promises per PART
+                S = int(rs.choice([2, 3, 4]))
+                if B * P * S * N <= 3e8 and C * (1 + S) <= 16384:
+                    chunk = ((counts + S - 1) // S + 63) // 64 * 64
+                    rank_of_row = np.empty(N, dtype=np.int64)
+                    rank_of_row[srt] = rank
+                    vcell = (C + cell_of.astype(np.int64) * S + rank_of_row // np.maximum(chunk[cell_of], 1)).astype(np.int64)
+                    sidx = np.arange(S)[None, :]
+                    lo = np.minimum(sidx * chunk[:, None], counts[:, None])
+                    hi = np.minimum((sidx + 1) * chunk[:, None], counts[:, None])
+                    some = hi > lo
+                    lo, hi = np.where(some, lo, 0), np.where(some, hi, 0)
+                    parts = np.stack([begin[:, None] + lo, begin[:, None] + hi], axis=2).reshape(-1, 2)
+                    rows_x = np.concatenate([np.stack([begin, begin + counts], axis=1), parts]).astype(np.int64)
+                    order_x = np.argsort(-(rows_x[:, 1] - rows_x[:, 0]), kind='stable').astype(np.int32)
+                    probe_x = (C + probe[:, :, None].astype(np.int64) * S + sidx[None]).reshape(B, -1).astype(np.int32)
+                    ids = ops.ivf_search_candidates(kind, ops.to_dev(q), ops.to_dev(cb), td, ops.to_dev(probe_x), C * (1 + S), ops.to_dev(rows_x),
+                                                    ops.to_dev(order_x), k, M, Ks, row_ids=ops.to_dev(row_ids), valid_bits=bits, n_rows=Nt,
+                                                    codes_layout=layout, bound_rank=int(rs.choice([1, 2, 4]))).cpu().numpy()
+                    n_calls += 1
+                    why = check_candidate_lists(ids.reshape(B, P * S, k), q, cb, codes, vcell, probe_x, omet, k, valid, ri)
+                    if why:
+                        n_bad += 1
+                        print('MISMATCH candidates in %d parts (%s)' % (S, why), dict(dsub=dsub, Ks=Ks, N=N, C=C, P=P, B=B, k=k, kind=kind,
+                                                                                    order=str(order), valid=str(vmode), layout=layout), flush=True)
     return n_cases, n_calls, n_bad
 
 

@@ -4,6 +4,7 @@ pairs, exact sums inside the tile, bounds shared by query, one merge launch.  Pi
 the u16 tile scan + re-score it replaces (`IvfPQGpuIndex.byte_tiles = False`)."""
 import numpy as np
 import pytest
+import torch
 
 from conftest import has_gpu
 from test_ivf import _build, _check_against_oracle, _data
@@ -189,6 +190,56 @@ def test_candidate_lists_are_private_prefixes_and_hold_the_adc_topk(oracle):
         assert (ids[b, 0] >= 0).sum() == min(k, int((cell_of == probe[b, 0]).sum()))
 
 
+def test_candidate_lists_with_the_nearest_cells_in_parts(oracle):
+    """IvfPQGpuIndex.rerank_split: the query's nearest cells probed as S contiguous row ranges each (entries C .. of the split cell table),
+    every range with a private list of its own: every list is the prefix of ITS range's exact ADC ranking, the ranges of a query are
+    disjoint (no row twice), the first range's list is complete, the union still holds the oracle's ADC top-k of the probed cells --
+    and it is a larger pool than whole cells give"""
+    from annlite_amd import Metric, ops
+    from annlite_amd._capi import CODES_SKEWED, LUT_L2
+
+    N, D, C, P, B, k, n_split, S = 30000, 64, 24, 5, 24, 16, 2, 4
+    idx, codec, vq, x = _build(N, D, 16, C, Metric.EUCLIDEAN, seed=43)
+    _, q = _data(np.random.RandomState(44), 1, D, B)
+    idx._seal()
+    qd = idx._pre(q)
+    cells = idx.probe_cells(qd, P)
+    rows_t, order_t = idx._split_tables(S)
+    assert rows_t.shape[0] == C * (1 + S) and torch.equal(rows_t[:C], idx._cell_rows)
+    parts = C + cells[:, :n_split, None].to(torch.int64) * S + torch.arange(S, device=cells.device)
+    cells_x = torch.cat([parts.reshape(B, -1).to(torch.int32), cells[:, n_split:]], dim=1).contiguous()
+    Px = cells_x.shape[1]
+    kw = dict(row_ids=idx._row_ids, n_rows=idx._n_table, codes_layout=CODES_SKEWED, bound_rank=2)
+    ids = ops.ivf_search_candidates(LUT_L2, qd, codec.codebooks_dev, idx._table, cells_x, C * (1 + S), rows_t, order_t, k, 16, 256,
+                                    **kw).cpu().numpy().reshape(B, Px, k)
+    whole = ops.ivf_search_candidates(LUT_L2, qd, codec.codebooks_dev, idx._table, cells, C, idx._cell_rows, idx._cell_order, k, 16, 256,
+                                      **kw).cpu().numpy()
+    assert (ids >= 0).sum() > (whole >= 0).sum()
+    codes = ops.codes_to_numpy(idx._plain_codes(N))
+    cell_of = idx._cell_of[:N].cpu().numpy()
+    probe = cells.cpu().numpy()
+    row_ids = idx._row_ids.cpu().numpy()
+    rows_np, cx = rows_t.cpu().numpy(), cells_x.cpu().numpy()
+    lut = oracle.get_dist_mat_c(q, codec.codebooks, oracle.EUCLIDEAN)
+    _, top = oracle.ivf_search(q, codec.codebooks, codes, cell_of, probe, oracle.EUCLIDEAN, k)
+    for b in range(B):
+        dist = oracle.dist_pqcodes_to_codebooks_c(lut[b], codes)
+        got = ids[b].reshape(-1)
+        got = got[got >= 0]
+        assert len(set(got.tolist())) == got.size and np.isin(cell_of[got], probe[b]).all()
+        assert set(top[b][top[b] >= 0].tolist()) <= set(got.tolist())
+        for p in range(Px):
+            lst = ids[b, p]
+            n = int((lst >= 0).sum())
+            assert (lst[n:] == -1).all()
+            own = row_ids[rows_np[cx[b, p], 0]:rows_np[cx[b, p], 1]]
+            own = own[own >= 0]
+            ranked = own[np.lexsort((own, dist[own]))]
+            assert np.array_equal(lst[:n], ranked[:n]), (b, p)
+            if p == 0:
+                assert n == min(k, own.size)
+
+
 def test_float_rerank_on_the_cell_tiles(oracle):
     """IvfPQGpuIndex(rerank=True) with limit <= 16: candidates from annlite_ivf_search_candidates, exact distances + top-k fused; the
     distances are the true ones, the recall is at least the ADC search's, and the u16 pipeline's re-rank is in the same range"""
@@ -209,12 +260,29 @@ def test_float_rerank_on_the_cell_tiles(oracle):
         truth = np.argsort(dd, axis=1)[:, :k]
     rec = lambda ids: float(np.mean([len(set(ids[b]) & set(truth[b])) / k for b in range(B)]))
     r_new = rec(i)
+    assert idx.rerank_split == (2, 4) and 'nearest 2 cells in 4 parts' in idx.last_pruned_path
+    idx.rerank_split = (0, 1)  # whole cells only: 16 rows per cell at most -- the smaller pool
+    r_whole = rec(idx.search_batch(q, limit=k, n_probe=P)[1])
+    assert 'parts' not in idx.last_pruned_path and r_new >= r_whole - 0.01, (r_new, r_whole)
+    idx.rerank_split = (2, 4)
     by_rank = {}
-    for rank in (1, 4):  # (the default is 2) a looser first bound = longer lists from the far cells: a superset pool, up to the seed draw
+    assert idx.rerank_bound_rank == 1
+    for rank in (2, 4):  # (the default is 1) a looser first bound = longer lists from the far cells: a superset pool, up to the seed draw
         idx.rerank_bound_rank = rank
         by_rank[rank] = rec(idx.search_batch(q, limit=k, n_probe=P)[1])
-    idx.rerank_bound_rank = 2
-    assert by_rank[1] <= r_new + 0.02 and r_new <= by_rank[4] + 0.02, (by_rank, r_new)
+    by_rank[1] = r_new
+    idx.rerank_bound_rank = 0  # the pool = exactly the ADC top-16 (annlite_ivf_search_topk with k = 16): a subset of every rank's pool
+    d0, i0 = idx.search_batch(q, limit=k, n_probe=P)
+    assert idx.last_pruned_path.startswith('annlite_ivf_search_topk') and idx.last_pruned_path.endswith('annlite_rerank_topk')
+    by_rank[0] = rec(i0)
+    idx.rerank, idx.rerank_bound_rank = False, 1
+    _, i16 = idx.search_batch(q, limit=16, n_probe=P)
+    idx.rerank = True
+    for b in range(0, B, 13):  # the exact top-10 of those 16 rows, nothing else
+        e = np.sqrt(((x[i16[b]] - q[b]) ** 2).sum(1))
+        assert set(i0[b].tolist()) <= set(i16[b].tolist())
+        np.testing.assert_allclose(d0[b], np.sort(e)[:k], rtol=1e-4, atol=1e-5)
+    assert by_rank[0] <= by_rank[1] + 0.02 and by_rank[1] <= by_rank[2] + 0.02 and by_rank[2] <= by_rank[4] + 0.02, by_rank
     idx.rerank = False
     _, i_adc = idx.search_batch(q, limit=k, n_probe=P)
     idx.rerank = True
