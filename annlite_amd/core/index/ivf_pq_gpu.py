@@ -42,7 +42,7 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
     R_CAP = 4096  # rows a query re-ranks at most (float re-rank of a pruned search); grows with k * n_probe: see _search_pruned
     rerank_truncated = 0  # queries (so far) whose candidate set exceeded the cap and lost the later cells' lists
     def __init__(self, dim: int, pq_codec: Optional[PQCodec] = None, vq_codec: Optional[VQCodec] = None,
-                 n_probe: Optional[int] = None, **kwargs):
+                 n_probe: Optional[int] = None, rerank_bound_rank: int = 1, rerank_split: Tuple[int, int] = (2, 4), **kwargs):
         super().__init__(dim, pq_codec=pq_codec, **kwargs)
         assert vq_codec is not None, 'IvfPQGpuIndex needs a VQCodec'
         self.vq_codec = vq_codec
@@ -55,12 +55,12 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
         # float re-rank on the cell tiles: the candidate lists' first bound = the (rank x k)-th smallest seed sum of the nearest cell (1: the
         # smallest pool that still holds the ADC top-k; larger: longer lists from the far cells, better recall; include/annlite_hip.h).
         # 0: no private lists at all -- the pool is exactly the ADC top-`rerank_k` (annlite_ivf_search_topk's ids), the fastest
-        self.rerank_bound_rank = 1
+        self.rerank_bound_rank = int(rerank_bound_rank)
         # ... and the nearest cells in parts: a list holds 16 keys, so a whole cell hands the re-rank 16 rows at most -- the cap on the
         # recall of that path, since the nearest cells hold most true neighbours.  (n, S): each of the query's n nearest cells is probed as
         # S contiguous row ranges ("sub-cells": entries C .. C (1 + S) of the split cell table, _split_tables), each with a list of its own
         # -- up to 16 S rows from such a cell.  (0, 1): whole cells only.
-        self.rerank_split = (2, 4)
+        self.rerank_split = (int(rerank_split[0]), int(rerank_split[1]))
         self._split_cache = None
         self._tws = ops.ScanWorkspace()
         self.last_pruned_path = None  # which kernels served the last pruned search (measurement scripts)

@@ -64,7 +64,8 @@ class AnnLite:
         GPU index is PQ-encoded; the reference's un-quantised float-HNSW path is out of scope)
     :param n_clusters: codewords per sub-quantiser (default 256)
     :param rerank: keep the float vectors in HBM and re-score ADC candidates exactly (kwarg, rides
-        the reference's ``**kwargs`` channel to the index, container.py:56)
+        the reference's ``**kwargs`` channel to the index, container.py:56).  With ``n_cells > 1`` and ``ivf_prune=True`` the same channel
+        takes ``rerank_bound_rank`` / ``rerank_split`` (the candidate pool of the pruned search's re-rank: ``IvfPQGpuIndex``)
     """
 
     def __init__(

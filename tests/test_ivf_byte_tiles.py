@@ -292,3 +292,32 @@ def test_float_rerank_on_the_cell_tiles(oracle):
     idx.byte_tiles = True
     # (the u16 pipeline re-ranks every tile's whole candidate list, a larger pool than P lists of 16: rank 4 is within 0.05 of it)
     assert by_rank[1] >= rec(i_adc) and by_rank[4] >= rec(i_u16) - 0.05, (by_rank, r_new, rec(i_adc), rec(i_u16))
+
+
+def test_facade_pruned_search_with_the_float_rerank(tmp_path):
+    """AnnLite(n_cells, n_probe, ivf_prune=True, rerank=True[, rerank_split, rerank_bound_rank]): the keyword channel of the reference's
+    container (container.py:56) reaches IvfPQGpuIndex; a search with limit <= 16 takes the cell tiles' candidate lists + the exact
+    re-rank, and the scores are the TRUE distances of the returned documents"""
+    from annlite_amd import AnnLite
+    from annlite_amd.docarray_compat import Document, DocumentArray
+
+    rs = np.random.RandomState(15)
+    N, D = 8000, 64
+    x, q = _data(rs, N, D, 24)
+    for kw, tag in ((dict(), 'nearest 2 cells in 4 parts'), (dict(rerank_split=(1, 2), rerank_bound_rank=2), 'nearest 1 cells in 2 parts'),
+                    (dict(rerank_split=(0, 1)), None)):
+        ann = AnnLite(D, metric='euclidean', n_subvectors=16, n_cells=8, n_probe=3, ivf_prune=True, rerank=True,
+                      data_path=str(tmp_path / ('a%d' % len(kw))), **kw)
+        ann.train(x[:4096])
+        ann.index(DocumentArray([Document(id=str(i), embedding=x[i]) for i in range(N)]))
+        docs = DocumentArray([Document(id='q%d' % i, embedding=q[i]) for i in range(len(q))])
+        ann.search(docs, limit=10)
+        idx = ann._vec_indexes[0]
+        assert idx.last_pruned_path.startswith('annlite_ivf_search_candidates'), idx.last_pruned_path
+        assert (tag in idx.last_pruned_path) if tag else ('parts' not in idx.last_pruned_path)
+        for b, d in enumerate(docs):
+            ids = [int(m.id) for m in d.matches]
+            assert len(ids) == 10 and len(set(ids)) == 10
+            got = np.array([m.scores['euclidean'].value for m in d.matches], dtype=np.float64)
+            np.testing.assert_allclose(got, np.sqrt(((x[ids] - q[b]) ** 2).sum(1)), rtol=1e-4, atol=1e-5)
+            assert (np.diff(got) >= -1e-6).all()
