@@ -192,7 +192,7 @@ def lib() -> ctypes.CDLL:
     L.annlite_ivf_search_topk.argtypes = [i32, vp, i64, i64, vp, i64, i64, vp, i32, i64, vp, vp, i64, i64, vp, vp, vp, i64, i64, vp, vp,
                                           i32, vp, sz, vp]
     L.annlite_ivf_search_candidates.argtypes = [i32, vp, i64, i64, vp, i64, i64, vp, i32, i64, vp, vp, i64, i64, vp, vp, vp, i64, i64, i64,
-                                                vp, vp, sz, vp]
+                                                vp, vp, vp, sz, vp]
     L.annlite_ivf_merge_lists.argtypes = [vp, i64, vp, i64, i64, vp, i64, vp, vp, i32, vp]
     L.annlite_profile_enable.argtypes = [i32]
     L.annlite_profile_last_scan_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]

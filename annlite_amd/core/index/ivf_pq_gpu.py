@@ -61,6 +61,7 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
         # S contiguous row ranges ("sub-cells": entries C .. C (1 + S) of the split cell table, _split_tables), each with a list of its own
         # -- up to 16 S rows from such a cell.  (0, 1): whole cells only.
         self.rerank_split = (int(rerank_split[0]), int(rerank_split[1]))
+        self.rerank_seed_whole_cell = True
         self._split_cache = None
         self._tws = ops.ScanWorkspace()
         self.last_pruned_path = None  # which kernels served the last pruned search (measurement scripts)
@@ -233,7 +234,10 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
             n_split, S = self.rerank_split
             n_split = min(int(n_split), P)
             cell_rows, cell_order, n_entries = self._cell_rows, self._cell_order, self.n_cells
+            seed_cells = None
             if n_split > 0 and S > 1:
+                if self.rerank_seed_whole_cell:  # the first bound from the WHOLE nearest cell's rows, not from its first part's
+                    seed_cells = cells[:, 0].contiguous()
                 cell_rows, cell_order = self._split_tables(int(S))
                 n_entries = cell_rows.shape[0]
                 parts = self.n_cells + cells[:, :n_split, None].to(torch.int64) * S + torch.arange(S, device=cells.device)
@@ -242,7 +246,7 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
             ids = ops.ivf_search_candidates(kind_l, xq_l, self.pq_codec.codebooks_dev, self._table, cells, n_entries, cell_rows,
                                             cell_order, k, self.M, self.Ks, row_ids=self._row_ids, valid_bits=self._table_bits(indices),
                                             n_rows=self._n_table, codes_layout=CODES_SKEWED, workspace=self._tws,
-                                            bound_rank=self.rerank_bound_rank)
+                                            bound_rank=self.rerank_bound_rank, seed_cells=seed_cells)
             return ops.rerank_topk(int(self.metric), q, self._vectors, ids, k_out, sqrt=self.metric == Metric.EUCLIDEAN)
         if (self.byte_tiles and not rerank and kind_l in (LUT_L2, LUT_IPDIST) and self.M == 16 and k <= 16 and self.dim <= 256
                 and (self.dim // self.M) % 4 == 0 and self._n_table < 2 ** 31):

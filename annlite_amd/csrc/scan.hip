@@ -1687,7 +1687,7 @@ static int ivf_search_impl(int lut_kind, const float *queries_dev, int64_t B, in
                            const int32_t *cells_dev, int64_t P, int64_t C, const int64_t *cell_rows_dev,
                            const int32_t *cell_order_dev, const int64_t *row_ids_dev, int64_t id_base, int64_t k,
                            float *out_dist_dev, int64_t *out_id_dev, int flags, void *workspace_dev, size_t workspace_bytes,
-                           void *stream, int64_t *cand_ids_dev, int64_t bound_rank) {
+                           void *stream, int64_t *cand_ids_dev, int64_t bound_rank, const int32_t *seed_cells_dev) {
     ANNLITE_REQUIRE(M == 16 && Ks >= 1 && Ks <= 256 && k >= 1 && k <= 16,
                     "annlite_ivf_search_topk serves M = 16, Ks <= 256, k <= 16 (got M=%lld Ks=%lld k=%lld): ANNLITE_NOT_APPLICABLE shapes take "
                     "annlite_pq_search_tiles + annlite_ivf_rescore", (long long)M, (long long)Ks, (long long)k);
@@ -1746,7 +1746,7 @@ static int ivf_search_impl(int lut_kind, const float *queries_dev, int64_t B, in
     int64_t k_seed = k;
     if (cand_ids_dev) k_seed = k * bound_rank > 64 ? 64 : k * bound_rank;
     rc = launch_seed_build_cells(sk, codes_dev, S, N, valid_bits_dev, lb, lut, B, Ks, k_seed, qstep, qlo, smax, qlom, gkey, st, gseed0, bq, target,
-                                 cells_dev, P, cell_rows_dev, item_counter, lut_kind == ANNLITE_LUT_IPDIST);
+                                 cells_dev, P, cell_rows_dev, item_counter, lut_kind == ANNLITE_LUT_IPDIST, seed_cells_dev);
     if (rc != ANNLITE_OK) return rc;
     ScanArgs a = {};
     a.codes = codes_dev;
@@ -1808,20 +1808,20 @@ extern "C" int annlite_ivf_search_topk(int lut_kind, const float *queries_dev, i
                                        void *stream) {
     return ivf_search_impl(lut_kind, queries_dev, B, D, codebooks_dev, M, Ks, codes_dev, codes_layout, N, valid_bits_dev, cells_dev, P, C,
                            cell_rows_dev, cell_order_dev, row_ids_dev, id_base, k, out_dist_dev, out_id_dev, flags, workspace_dev, workspace_bytes,
-                           stream, nullptr, 1);
+                           stream, nullptr, 1, nullptr);
 }
 
 extern "C" int annlite_ivf_search_candidates(int lut_kind, const float *queries_dev, int64_t B, int64_t D, const float *codebooks_dev, int64_t M,
                                              int64_t Ks, const void *codes_dev, int codes_layout, int64_t N, const uint32_t *valid_bits_dev,
                                              const int32_t *cells_dev, int64_t P, int64_t C, const int64_t *cell_rows_dev,
                                              const int32_t *cell_order_dev, const int64_t *row_ids_dev, int64_t id_base, int64_t k,
-                                             int64_t bound_rank, int64_t *out_ids_dev, void *workspace_dev, size_t workspace_bytes,
-                                             void *stream) {
+                                             int64_t bound_rank, const int32_t *seed_cells_dev, int64_t *out_ids_dev, void *workspace_dev,
+                                             size_t workspace_bytes, void *stream) {
     ANNLITE_REQUIRE(out_ids_dev != nullptr || B == 0, "out_ids_dev is NULL");
     ANNLITE_REQUIRE(bound_rank >= 1 && bound_rank <= 64, "bound_rank %lld (1 .. 64)", (long long)bound_rank);
     return ivf_search_impl(lut_kind, queries_dev, B, D, codebooks_dev, M, Ks, codes_dev, codes_layout, N, valid_bits_dev, cells_dev, P, C,
                            cell_rows_dev, cell_order_dev, row_ids_dev, id_base, k, nullptr, nullptr, 0, workspace_dev, workspace_bytes, stream,
-                           out_ids_dev, bound_rank);
+                           out_ids_dev, bound_rank, seed_cells_dev);
 }
 
 extern "C" int annlite_adc_scan_candidates(const void *codes_dev, int code_bytes, int codes_layout, int64_t N,

@@ -388,7 +388,7 @@ int launch_seed_build_cells(bool skewed, const void *codes_dev, int64_t S, int64
                             const LutBuild &build, float *lut_out, int64_t B, int64_t Ks, int64_t k, float *qstep, double *qlo,
                             float *smax, float *qlom, unsigned long long *gkey, hipStream_t st, unsigned long long *gseed0,
                             uint8_t *bq, int target, const int32_t *cells, int64_t n_probe, const int64_t *cell_rows,
-                            unsigned int *item_counter = nullptr, bool ip_tables = false);
+                            unsigned int *item_counter = nullptr, bool ip_tables = false, const int32_t *seed_cells = nullptr);
 // seedk (optional): [B][kSeedKeys] the bounds implied by the seed's k smallest rows (annlite_pq_search_split)
 constexpr int kSeedKeys = 16;
 // seed_mfma.hip (round 6): per query the best row -- by a bf16 MFMA approximation of the ADC sum -- of each of kSeedCand disjoint

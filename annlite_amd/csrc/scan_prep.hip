@@ -139,6 +139,8 @@ struct SeedBuild {
     // would be wrong): query b's seed rows are 64-row blocks spread evenly over its NEAREST cell, rows [cell_rows[2 c], cell_rows[2 c + 1])
     // of the cell-sorted table, c = cells[b * n_probe]; and the byte tables go out per QUERY (a cell tile's slots hold arbitrary queries)
     const int32_t *cells;        // [B][n_probe], nearest first
+    const int32_t *seed_cells;   // optional [B]: the entry whose rows seed query b's bound instead of cells[b * n_probe] (a cell probed in PARTS:
+                                 // the whole cell's range -- rows of the probed ranges all the same)
     const int64_t *cell_rows;    // [C][2] (begin: multiple of 64, end)
     int32_t n_probe;
     uint8_t *bq;                 // [ceil4(B)][Ks][M] byte tables quantised for gseed0 (q8_gather_table assembles a tile's image from them)
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(kSeedWaves * 64) void seed_bound_kernel(const uint8
                 int32_t *s_cell = (int32_t *)(s_par + 96);  // [4] begin, [4] end, [4] blocks
                 int64_t cb = 0, ce = 0;
                 if (b < B) {
-                    const int32_t c = sb.cells[(int64_t)b * sb.n_probe];
+                    const int32_t c = sb.seed_cells ? sb.seed_cells[b] : sb.cells[(int64_t)b * sb.n_probe];
                     cb = sb.cell_rows[2 * (int64_t)c], ce = sb.cell_rows[2 * (int64_t)c + 1];
                 }
                 s_cell[tid] = (int32_t)cb;
@@ -1149,7 +1151,7 @@ int annlite::launch_seed_build_cells(bool skw, const void *codes_dev, int64_t S,
                                      const LutBuild &build, float *lut_out, int64_t B, int64_t Ks, int64_t k, float *qstep, double *qlo,
                                      float *smax, float *qlom, unsigned long long *gk, hipStream_t st, unsigned long long *gseed0,
                                      uint8_t *bq, int target, const int32_t *cells, int64_t n_probe, const int64_t *cell_rows,
-                                     unsigned int *item_counter, bool ip_tables) {
+                                     unsigned int *item_counter, bool ip_tables, const int32_t *seed_cells) {
     constexpr int M = 16;
     SeedBuild sb = {};
     sb.queries = build.queries;
@@ -1167,6 +1169,7 @@ int annlite::launch_seed_build_cells(bool skw, const void *codes_dev, int64_t S,
     sb.target = target;
     sb.chunk_log = 0;
     sb.cells = cells;
+    sb.seed_cells = seed_cells;
     sb.cell_rows = cell_rows;
     sb.n_probe = (int32_t)n_probe;
     sb.bq = bq;

@@ -460,10 +460,12 @@ def ivf_search_candidates(lut_kind: int, queries: torch.Tensor, codebooks: torch
                           n_cells: int, cell_rows: torch.Tensor, cell_order: torch.Tensor, k: int, M: int, Ks: int,
                           row_ids: Optional[torch.Tensor] = None, valid_bits: Optional[torch.Tensor] = None,
                           n_rows: Optional[int] = None, codes_layout: int = CODES_PLAIN, id_base: int = 0,
-                          workspace: Optional[ScanWorkspace] = None, bound_rank: int = 1) -> torch.Tensor:
+                          workspace: Optional[ScanWorkspace] = None, bound_rank: int = 1,
+                          seed_cells: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``annlite_ivf_search_candidates``: the pruned search's pipeline as the candidate generator of an exact re-rank -- every
     (query, probed cell) list on its own (the cell's best <= k rows at or below the query's first bound, the
-    ``min(bound_rank * k, 64)``-th smallest seed sum of its nearest cell).  Returns i64 [B, P * k] external ids, -1 = none."""
+    ``min(bound_rank * k, 64)``-th smallest seed sum of its nearest cell -- of entry ``seed_cells[b]`` (i32 [B]) of the cell table when given).
+    Returns i64 [B, P * k] external ids, -1 = none."""
     N = codes.shape[0] if n_rows is None else n_rows
     B, D = queries.shape
     P = cells.shape[1]
@@ -474,7 +476,8 @@ def ivf_search_candidates(lut_kind: int, queries: torch.Tensor, codebooks: torch
     out = torch.empty((B, P * k), dtype=torch.int64, device=dev)
     check(lib().annlite_ivf_search_candidates(lut_kind, queries.data_ptr(), B, D, codebooks.data_ptr(), M, Ks, codes.data_ptr(), codes_layout,
                                               N, _ptr(valid_bits), cells.data_ptr(), P, n_cells, cell_rows.data_ptr(), cell_order.data_ptr(),
-                                              _ptr(row_ids), id_base, k, bound_rank, out.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()),
+                                              _ptr(row_ids), id_base, k, bound_rank, _ptr(seed_cells), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                              stream_ptr()),
           'ivf_search_candidates')
     return out
 

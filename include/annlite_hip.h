@@ -560,15 +560,17 @@ ANNLITE_API int annlite_ivf_search_topk(int lut_kind, const float *queries_dev, 
  * rows of its nearest cell: at or above the k-th key of the probed rows for every bound_rank >= 1, so the union of a query's lists holds
  * its exact ADC top-k; the nearest cell's list is never cut).  bound_rank 1 .. 64 trades pool size for time: a looser bound lengthens
  * the far cells' lists (10M rows, 16 of 256 cells, k = 16: rank 1 / 2 / 4 -> 2.44 / 1.72 / 1.21 M q/s, re-ranked recall@10 0.803 / 0.813 /
- * 0.813).  out_ids_dev i64 [B][P * k]: list (b, p) at [p * k, (p + 1) * k), ascending by (sum, id), -1 where it is shorter -- the input of
+ * 0.813).  seed_cells_dev (may be NULL) i32 [B]: the entry of the cell table whose rows seed query b's bound instead of cells[b][0] --
+ * for a cell table that lists a cell's rows ALSO as parts (IvfPQGpuIndex.rerank_split): the probe names the parts, the seed the whole
+ * cell, whose rows must all be probed by that query; the first list may then be cut like the others.  out_ids_dev i64 [B][P * k]: list (b, p) at [p * k, (p + 1) * k), ascending by (sum, id), -1 where it is shorter -- the input of
  * annlite_rerank_topk.  Workspace and shapes: annlite_ivf_search_topk's.  (Not in the reference: its cells hold exact vectors or PQ
  * codes, never both.) */
 ANNLITE_API int annlite_ivf_search_candidates(int lut_kind, const float *queries_dev, int64_t B, int64_t D, const float *codebooks_dev,
                                   int64_t M, int64_t Ks, const void *codes_dev, int codes_layout, int64_t N,
                                   const uint32_t *valid_bits_dev, const int32_t *cells_dev, int64_t P, int64_t C,
                                   const int64_t *cell_rows_dev, const int32_t *cell_order_dev, const int64_t *row_ids_dev,
-                                  int64_t id_base, int64_t k, int64_t bound_rank, int64_t *out_ids_dev, void *workspace_dev,
-                                  size_t workspace_bytes, void *stream);
+                                  int64_t id_base, int64_t k, int64_t bound_rank, const int32_t *seed_cells_dev,
+                                  int64_t *out_ids_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* Merge of per-slot lists: lists_dev u64 [V][k] (ordered distance << 32 | table row, ascending, ~0 = none: what the cell-tile scan
  * leaves per slot) -> per query the k smallest of its P slots' keys re-keyed by external id (id_base + row_ids[row]); one wave per

@@ -77,11 +77,12 @@ def main():
 
     for cfg in args.configs.split(','):
         rank, sp = cfg.split(':')
-        n, S = sp.split('x')
+        idx.rerank_seed_whole_cell = not sp.endswith('p')  # (suffix p: the first bound from the nearest cell's first PART)
+        n, S = sp.rstrip('p').split('x')
         idx.rerank_bound_rank, idx.rerank_split = int(rank), (int(n), int(S))
         qps, rec = run(rerank_k=16)
         print(json.dumps({'bound_rank': int(rank), 'split': [int(n), int(S)], 'qps_two_streams': round(qps), 'recall_at_10': round(rec, 4),
-                          'path': idx.last_pruned_path}), flush=True)
+                          'seed': 'whole cell' if idx.rerank_seed_whole_cell else 'first part', 'path': idx.last_pruned_path}), flush=True)
     qps, rec = run(rerank_k=32)
     print(json.dumps({'rerank_k': 32, 'qps_two_streams': round(qps), 'recall_at_10': round(rec, 4), 'path': idx.last_pruned_path}), flush=True)
 

@@ -215,6 +215,10 @@ def test_candidate_lists_with_the_nearest_cells_in_parts(oracle):
     whole = ops.ivf_search_candidates(LUT_L2, qd, codec.codebooks_dev, idx._table, cells, C, idx._cell_rows, idx._cell_order, k, 16, 256,
                                       **kw).cpu().numpy()
     assert (ids >= 0).sum() > (whole >= 0).sum()
+    # the first bound from the WHOLE nearest cell (seed_cells) instead of its first part: a tighter bound, the same promises but the last
+    ids_ws = ops.ivf_search_candidates(LUT_L2, qd, codec.codebooks_dev, idx._table, cells_x, C * (1 + S), rows_t, order_t, k, 16, 256,
+                                       seed_cells=cells[:, 0].contiguous(), **kw).cpu().numpy().reshape(B, Px, k)
+    assert (whole >= 0).sum() < (ids_ws >= 0).sum() <= (ids >= 0).sum()
     codes = ops.codes_to_numpy(idx._plain_codes(N))
     cell_of = idx._cell_of[:N].cpu().numpy()
     probe = cells.cpu().numpy()
@@ -224,20 +228,21 @@ def test_candidate_lists_with_the_nearest_cells_in_parts(oracle):
     _, top = oracle.ivf_search(q, codec.codebooks, codes, cell_of, probe, oracle.EUCLIDEAN, k)
     for b in range(B):
         dist = oracle.dist_pqcodes_to_codebooks_c(lut[b], codes)
-        got = ids[b].reshape(-1)
-        got = got[got >= 0]
-        assert len(set(got.tolist())) == got.size and np.isin(cell_of[got], probe[b]).all()
-        assert set(top[b][top[b] >= 0].tolist()) <= set(got.tolist())
-        for p in range(Px):
-            lst = ids[b, p]
-            n = int((lst >= 0).sum())
-            assert (lst[n:] == -1).all()
-            own = row_ids[rows_np[cx[b, p], 0]:rows_np[cx[b, p], 1]]
-            own = own[own >= 0]
-            ranked = own[np.lexsort((own, dist[own]))]
-            assert np.array_equal(lst[:n], ranked[:n]), (b, p)
-            if p == 0:
-                assert n == min(k, own.size)
+        for which, first_complete in ((ids, True), (ids_ws, False)):
+            got = which[b].reshape(-1)
+            got = got[got >= 0]
+            assert len(set(got.tolist())) == got.size and np.isin(cell_of[got], probe[b]).all()
+            assert set(top[b][top[b] >= 0].tolist()) <= set(got.tolist())
+            for p in range(Px):
+                lst = which[b, p]
+                n = int((lst >= 0).sum())
+                assert (lst[n:] == -1).all()
+                own = row_ids[rows_np[cx[b, p], 0]:rows_np[cx[b, p], 1]]
+                own = own[own >= 0]
+                ranked = own[np.lexsort((own, dist[own]))]
+                assert np.array_equal(lst[:n], ranked[:n]), (b, p)
+                if p == 0 and first_complete:
+                    assert n == min(k, own.size)
 
 
 def test_float_rerank_on_the_cell_tiles(oracle):
