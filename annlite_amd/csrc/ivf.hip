@@ -142,7 +142,7 @@ __device__ __forceinline__ void ivf_plan_body(const int32_t *__restrict__ cells,
     // LDS atomic -> store -> reload, one dependent global round trip per loop iteration).  Up to kReg pairs per thread now stay in
     // REGISTERS between the two passes (their loads all in flight together), and the cells' order / row ranges are requested before
     // the first barrier; larger batches keep the loops through memory.
-    constexpr int kReg = 16, kCellReg = 4;
+    constexpr int kReg = 24, kCellReg = 4;  // (24: 1024 queries x 22 entries -- 16 probed cells, the nearest two in four parts -- stay in registers)
     const bool in_regs = n_pairs <= 1024 * kReg;
     const int per = (C + 1023) / 1024;  // cells per thread in the scan of the tile counts; thread t owns positions [t*per, (t+1)*per)
     const bool cells_in_regs = per <= kCellReg;
