@@ -235,7 +235,7 @@ class IvfPQGpuIndex(PQFlatGpuIndex):
             n_split = min(int(n_split), P)
             cell_rows, cell_order, n_entries = self._cell_rows, self._cell_order, self.n_cells
             seed_cells = None
-            if n_split > 0 and S > 1:
+            if n_split > 0 and S > 1 and self.n_cells * (1 + int(S)) <= 16384:  # (the plan's limit on cell-table entries)
                 if self.rerank_seed_whole_cell:  # the first bound from the WHOLE nearest cell's rows, not from its first part's
                     seed_cells = cells[:, 0].contiguous()
                 cell_rows, cell_order = self._split_tables(int(S))
