@@ -562,7 +562,9 @@ ANNLITE_API int annlite_ivf_search_topk(int lut_kind, const float *queries_dev, 
  * the far cells' lists (10M rows, 16 of 256 cells, k = 16: rank 1 / 2 / 4 -> 2.44 / 1.72 / 1.21 M q/s, re-ranked recall@10 0.803 / 0.813 /
  * 0.813).  seed_cells_dev (may be NULL) i32 [B]: the entry of the cell table whose rows seed query b's bound instead of cells[b][0] --
  * for a cell table that lists a cell's rows ALSO as parts (IvfPQGpuIndex.rerank_split): the probe names the parts, the seed the whole
- * cell, whose rows must all be probed by that query; the first list may then be cut like the others.  out_ids_dev i64 [B][P * k]: list (b, p) at [p * k, (p + 1) * k), ascending by (sum, id), -1 where it is shorter -- the input of
+ * cell, whose rows must all be probed by that query; the first list may then be cut like the others.  (Entries of the cell table may
+ * overlap -- a cell and its parts -- as long as the entries ONE query probes are disjoint row ranges: a row then appears in one list.)
+ * out_ids_dev i64 [B][P * k]: list (b, p) at [p * k, (p + 1) * k), ascending by (sum, id), -1 where it is shorter -- the input of
  * annlite_rerank_topk.  Workspace and shapes: annlite_ivf_search_topk's.  (Not in the reference: its cells hold exact vectors or PQ
  * codes, never both.) */
 ANNLITE_API int annlite_ivf_search_candidates(int lut_kind, const float *queries_dev, int64_t B, int64_t D, const float *codebooks_dev,
